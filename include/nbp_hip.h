@@ -1,0 +1,168 @@
+/* nbp_hip.h -- C ABI of libnbp_hip.so: the MI355X (gfx950) hot path of NextBestPath.
+ *
+ * The reference (shiyao-li/NextBestPath) is pure Python and has no native boundary; the
+ * functions below are what a maintainer's ctypes binding replaces the cited torch /
+ * PyTorch3D / trimesh call sites with (INTEGRATION.md shows the stubs).  Citations are
+ * relative to the reference repository root.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative NBP_E_* code on an argument error
+ *    (nothing is launched / written) or a positive hipError_t if a launch failed;
+ *  - every pointer is caller-owned DEVICE memory unless the name ends in _host;
+ *  - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; pass
+ *    torch.cuda.current_stream().cuda_stream); no function synchronises or allocates device
+ *    memory: scratch comes in through (ws, ws_bytes) sized by the matching *_workspace_bytes;
+ *  - activations inside the network are NHWC fp32; the public tensors keep the reference's
+ *    NCHW layout ([B,5,S,S] in, [B,8,S/4,S/4] and [B,1,S,S] out);
+ *  - no exceptions cross the boundary, no global mutable state besides the explicit handle.
+ */
+#ifndef NBP_HIP_H
+#define NBP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBP_E_ARG      (-1)  /* null pointer / bad shape / bad enum                       */
+#define NBP_E_WS       (-2)  /* workspace too small                                       */
+#define NBP_E_SHAPE    (-3)  /* shape not supported by the kernels (e.g. S % 16 != 0)     */
+
+/* ---------------------------------------------------------------- library info */
+/* ABI version of this header; bumped on any signature change. */
+int nbp_abi_version(void);
+/* Writes gcnArchName / CU count of the current device (host strings/ints). */
+int nbp_device_info(char* arch_host, int arch_len, int* cu_count_host);
+
+/* ================================================================ A1: NBP network
+ * Replaces NBP.forward, next_best_path/networks/nbp_model.py:110-160 (and the layer
+ * classes :8-62) for inference (module.eval(): BatchNorm uses running statistics).
+ *
+ * Canonical order of the 48 convolutions (index -> reference parameter prefix):
+ *   0..9   Conv{1..5}.conv.{0,3}
+ *   then for decoder d=1 (levels L=5,4) and d=2 (levels L=5,4,3,2), six per level:
+ *          Up{L}_d.up.1, Att{L}_d.W_g.0, Att{L}_d.W_x.0, Att{L}_d.psi.0,
+ *          Up_conv{L}_d.conv.0, Up_conv{L}_d.conv.3
+ *   i.e. 10..21 decoder 1, 22..45 decoder 2, then 46 Final1, 47 Final2.0
+ */
+#define NBP_N_CONV 48
+
+typedef struct nbp_weights nbp_weights;   /* opaque: host-side table of pointers into `packed` */
+
+/* Bytes of device memory the packed fp32 weights + folded affine terms need. */
+size_t nbp_packed_weights_bytes(void);
+
+/* Re-lays the 48 OIHW fp32 weight tensors into the K-chunked layout the implicit-GEMM
+ * kernels stream ([c_in/32][tap][c_out][32]) inside caller memory `packed`, and copies the
+ * per-output-channel epilogue terms: out = act(acc * scale + shift).
+ *   w[i]      OIHW fp32 weight of conv i (device)
+ *   scale[i]  [c_out] fp32 (device): gamma/sqrt(var+eps) (1 when the conv has no BatchNorm)
+ *   shift[i]  [c_out] fp32 (device): (bias-mean)*scale+beta
+ * For the attention pair (W_g, W_x) the two 1x1 convolutions are fused into one GEMM over
+ * the concatenated K = [g | x]: their `scale` is multiplied into the packed weights and the
+ * caller passes shift[W_g] = shift_g + shift_x (shift[W_x] is ignored).
+ * On success *handle_out is a host object to pass to nbp_forward_f32; free it with
+ * nbp_free_weights (which never touches `packed`). */
+int nbp_pack_weights(const void* const* w_host_array, const void* const* scale_host_array,
+                     const void* const* shift_host_array, void* packed, size_t packed_bytes,
+                     void* stream, nbp_weights** handle_out);
+void nbp_free_weights(nbp_weights* handle);
+
+size_t nbp_forward_workspace_bytes(int B, int S);
+
+/* x [B,5,S,S] -> out1 [B,8,S/4,S/4] (linear), out2 [B,1,S,S] (sigmoid); S % 16 == 0. */
+int nbp_forward_f32(const nbp_weights* handle, const float* x, int B, int S, float* out1,
+                    float* out2, void* ws, size_t ws_bytes, void* stream);
+
+/* Profiling twin of nbp_forward_f32: brackets every launch group with hipEvents on `stream`,
+ * SYNCHRONISES the stream, and fills timings_host[0..*n_entries_host) (one entry per layer, in
+ * launch order; `ms` of a split-K layer includes its reduce kernel).  tile: NBP_TILE id of the
+ * implicit-GEMM kernel used, -1 for the non-GEMM kernels.  Not re-entrant. */
+typedef struct nbp_layer_timing {
+    char name[48];
+    double flops;      /* 2*M*N*K */
+    float ms;
+    int tile, split_k;
+    long long M;
+    int N, K;
+} nbp_layer_timing;
+int nbp_forward_timed_f32(const nbp_weights* handle, const float* x, int B, int S, float* out1,
+                          float* out2, void* ws, size_t ws_bytes, void* stream,
+                          nbp_layer_timing* timings_host, int max_entries, int* n_entries_host);
+
+/* FLOPs (2*MAC over the 48 convolutions) of one forward at batch B, size S. */
+double nbp_forward_flops(int B, int S);
+
+/* ---- single layers (same kernels the forward uses; exported for layer-level parity tests)
+ * Implicit-GEMM convolution on NHWC fp32, k in {1,3}, stride 1, "same" padding:
+ *   input channels [0,C0) come from src0, [C0,C0+C1) from src1 (fused torch.cat, ref :128);
+ *   ups != 0 reads the sources through a x2 nearest upsample (fused nn.Upsample, ref :27):
+ *   sources are then [B,H/2,W/2,C];  C0,C1 multiples of 32 (C1 may be 0), N multiple of 32.
+ *   w_packed: layout produced by nbp_pack_conv_weight.  out [B,H,W,N] = act(acc*scale+shift).
+ *   split_k >= 1 splits the K loop over blockIdx.z (ws must hold split_k*B*H*W*N floats);
+ *   split_k == 0 lets the library choose.  tile: 0 = auto, else a NBP_TILE_* id. */
+int nbp_conv_igemm_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H,
+                       int W, int ksize, const float* w_packed, int N, const float* scale,
+                       const float* shift, int relu, float* out, int split_k, int tile, void* ws,
+                       size_t ws_bytes, void* stream);
+size_t nbp_conv_igemm_workspace_bytes(int B, int H, int W, int N, int split_k);
+
+/* OIHW [N][C][k][k] -> packed [(c_off+c)/32][tap][N][32]; optional per-n scale multiply.
+ * c_total = total input channels of the fused K (c_off + C <= c_total). */
+int nbp_pack_conv_weight(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null,
+                         int c_off, int c_total, float* dst, void* stream);
+
+/* Conv1.conv.0: NCHW [B,5,H,W] -> NHWC [B,H,W,64], 3x3, act(acc*scale+shift), ReLU.
+ * w is the raw OIHW [64,5,3,3] tensor. */
+int nbp_conv_first_f32(const float* x_nchw, int B, int H, int W, const float* w_oihw,
+                       const float* scale, const float* shift, float* out_nhwc, void* stream);
+/* nn.MaxPool2d(2,2) on NHWC (ref :68). */
+int nbp_maxpool2_nhwc_f32(const float* in, int B, int H, int W, int C, float* out, void* stream);
+/* Attention gate tail (ref :59-62): psi = sigmoid((q . w_psi) * s + t) per pixel,
+ * out = x * psi.  q [M,F] (already ReLU'd g1+x1), x/out [M,C]. */
+int nbp_psi_gate_f32(const float* q, int F, const float* w_psi, const float* s_t2, const float* x,
+                     int C, long long M, float* out, void* stream);
+/* Final 1x1 convolutions (ref :85,105-106): NHWC [B,H,W,C] -> NCHW [B,n_out,H,W],
+ * out = act(acc*scale+shift), act = sigmoid if `sigmoid` else identity.  n_out <= 8. */
+int nbp_final_1x1_f32(const float* in, int B, int H, int W, int C, const float* w_oc, int n_out,
+                      const float* scale, const float* shift, int sigmoid, float* out_nchw,
+                      void* stream);
+/* Layout helpers (tests / training path). */
+int nbp_nchw_to_nhwc_f32(const float* in, int B, int C, int H, int W, float* out, void* stream);
+int nbp_nhwc_to_nchw_f32(const float* in, int B, int C, int H, int W, float* out, void* stream);
+
+/* ================================================================ A4-A7: map accumulation
+ * World points -> agent-centred top-down count images.
+ * Index rule (next_best_path/utility/utils.py:198-223, :160-164):
+ *   v0 = -(p.z - c.z), v1 = -(p.x - c.x)                       (utils.py:166-196, R = I)
+ *   i0 = rint((v0 - lo) * (S / (hi - lo))) , i1 likewise        (fp32, half-to-even)
+ *   counted iff 0 <= i0,i1 < S;  out[i0*S + i1] += 1
+ */
+/* utils.py:166-196 transform_points_to_n_pieces (no_rotation=True): [N,3] -> [N,2]. */
+int nbp_transform_points_f32(const float* points, long long N, float cx, float cy, float cz,
+                             float* out_2d, void* stream);
+/* utils.py:198-223 map_points_to_n_imgs: pts2d [n,m,2] -> out [n,S0,S1] fp32 counts.
+ * `out` is zeroed by this call. */
+int nbp_map_points_to_imgs_f32(const float* pts2d, int n, long long m, int S0, int S1, float lo,
+                               float hi, float* out, void* stream);
+/* utils.py:160-164 get_point_position_in_the_img for K points: -> [2,K] int64 (no bounds
+ * check, like the reference). */
+int nbp_point_position_i64(const float* pts2d, long long K, int S0, int S1, float lo, float hi,
+                           long long* out_2xK, void* stream);
+/* One fused pass over the accumulated cloud (nbp_planning.py:114-127 slab split +
+ * :172-183 full / height-band projections): out [6,S,S] fp32, zeroed by this call:
+ *   ch 0..3  height slabs: bin = #{k : bounds[k] < p.y} - 1 (torch.bucketize, right=False)
+ *            counted iff 0 <= bin < 4 (n_bounds is len(y_bins)-1, normally 4, at most 8)
+ *   ch 4     points that fall in no slab (so that ch0+..+ch4 = projection of ALL points)
+ *   ch 5     points with  band_lo < p.y < band_hi   (the reference's +-0.1 height band)
+ */
+int nbp_map_accumulate_f32(const float* points, long long N, float cx, float cy, float cz,
+                           const float* bounds_host, int n_bounds, float band_lo, float band_hi,
+                           int S, float lo, float hi, float* out6, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBP_HIP_H */

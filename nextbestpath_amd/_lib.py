@@ -1,0 +1,106 @@
+"""ctypes loader for libnbp_hip.so (the C ABI declared in include/nbp_hip.h).
+
+The product path has no fallback: ``lib()`` raises if the shared object is missing or does
+not export a declared symbol.  Building is explicit (``python -m nextbestpath_amd.build`` or
+``__graft_entry__.build()``); importing this module never compiles anything.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libnbp_hip.so")
+
+_vp, _i, _ll, _f, _sz, _d = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_double
+
+# name -> (restype, argtypes).  Kept in the order of include/nbp_hip.h.
+SIGNATURES = {
+    "nbp_abi_version": (_i, []),
+    "nbp_device_info": (_i, [C.c_char_p, _i, C.POINTER(_i)]),
+    "nbp_packed_weights_bytes": (_sz, []),
+    "nbp_pack_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, _sz, _vp, C.POINTER(_vp)]),
+    "nbp_free_weights": (None, [_vp]),
+    "nbp_forward_workspace_bytes": (_sz, [_i, _i]),
+    "nbp_forward_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "nbp_forward_flops": (_d, [_i, _i]),
+    "nbp_conv_igemm_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp,
+                                _sz, _vp]),
+    "nbp_conv_igemm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "nbp_pack_conv_weight": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "nbp_conv_first_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "nbp_maxpool2_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "nbp_psi_gate_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _ll, _vp, _vp]),
+    "nbp_final_1x1_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "nbp_nchw_to_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "nbp_nhwc_to_nchw_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "nbp_transform_points_f32": (_i, [_vp, _ll, _f, _f, _f, _vp, _vp]),
+    "nbp_map_points_to_imgs_f32": (_i, [_vp, _i, _ll, _i, _i, _f, _f, _vp, _vp]),
+    "nbp_point_position_i64": (_i, [_vp, _ll, _i, _i, _f, _f, _vp, _vp]),
+    "nbp_map_accumulate_f32": (_i, [_vp, _ll, _f, _f, _f, C.POINTER(_f), _i, _f, _f, _i, _f, _f, _vp, _vp]),
+}
+
+
+
+class LayerTiming(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("flops", _d), ("ms", _f), ("tile", _i), ("split_k", _i), ("M", _ll),
+                ("N", _i), ("K", _i)]
+
+
+SIGNATURES["nbp_forward_timed_f32"] = (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, C.POINTER(LayerTiming), _i,
+                                            C.POINTER(_i)])
+
+_lock = threading.Lock()
+_lib = None
+
+
+class NbpHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Returns the loaded library; raises (never falls back) if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NbpHipError(
+                f"{LIB_PATH} is missing: build it with `python -m nextbestpath_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:  # pragma: no cover
+                raise NbpHipError(f"libnbp_hip.so does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+_ERR = {-1: "NBP_E_ARG (bad argument)", -2: "NBP_E_WS (workspace too small)", -3: "NBP_E_SHAPE (unsupported shape)"}
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = _ERR.get(rc, f"hipError_t {rc}" if rc > 0 else f"error {rc}")
+        raise NbpHipError(f"{what} failed: {msg}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a contiguous torch tensor (0 for None)."""
+    if t is None:
+        return 0
+    if not t.is_contiguous():
+        raise ValueError("tensor passed to the HIP path must be contiguous")
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

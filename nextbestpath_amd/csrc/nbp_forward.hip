@@ -1,0 +1,393 @@
+// nbp_forward.hip -- weight packing + the whole-network forward of NBP on gfx950.
+//
+// Replaces NBP.forward, next_best_path/networks/nbp_model.py:110-160: one C call enqueues
+// every kernel of the Attention U-Net (shared encoder, two decoders) on one stream.
+// Fusions relative to the reference's op list: BatchNorm+bias+ReLU in the conv epilogue,
+// nn.Upsample and torch.cat in the conv's operand gather, the attention gate's two 1x1
+// convolutions as ONE GEMM over K=[g|x] followed by a psi+multiply tail.
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+int nbp_conv_igemm_launch(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
+                          int ksize, const float* wpk, int N, const float* scale, const float* shift, int relu,
+                          float* out, int split_k, int tile, void* ws, size_t ws_bytes, hipStream_t st);
+struct ConvPlan { int tile; int split_k; int chunks_per_split; };
+ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k);
+
+namespace {
+
+enum Kind { K_FIRST, K_CONV3, K_ATT_G, K_ATT_X, K_PSI, K_FINAL };
+struct LayerSpec { Kind kind; int cin, cout, k; };
+
+// canonical order documented in include/nbp_hip.h
+struct Table {
+    LayerSpec L[NBP_N_CONV];
+    size_t w_off[NBP_N_CONV];   // float offsets into the packed buffer
+    size_t s_off[NBP_N_CONV], t_off[NBP_N_CONV];
+    size_t total_floats;
+    Table() {
+        int i = 0;
+        const int enc[5] = {64, 128, 256, 512, 1024};
+        int cin = 5;
+        for (int e = 0; e < 5; ++e) {
+            L[i++] = {e == 0 ? K_FIRST : K_CONV3, cin, enc[e], 3};
+            L[i++] = {K_CONV3, enc[e], enc[e], 3};
+            cin = enc[e];
+        }
+        auto level = [&](int ci, int co) {
+            L[i++] = {K_CONV3, ci, co, 3};         // Up{L}_d.up.1
+            L[i++] = {K_ATT_G, co, co / 2, 1};     // Att W_g
+            L[i++] = {K_ATT_X, co, co / 2, 1};     // Att W_x
+            L[i++] = {K_PSI, co / 2, 1, 1};        // Att psi
+            L[i++] = {K_CONV3, ci, co, 3};         // Up_conv.conv.0 (cat(a, d) -> co)
+            L[i++] = {K_CONV3, co, co, 3};         // Up_conv.conv.3
+        };
+        level(1024, 512); level(512, 256);                                   // decoder 1
+        level(1024, 512); level(512, 256); level(256, 128); level(128, 64);  // decoder 2
+        L[i++] = {K_FINAL, 256, 8, 1};
+        L[i++] = {K_FINAL, 64, 1, 1};
+        size_t off = 0;
+        auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };  // 256 B aligned
+        for (int j = 0; j < NBP_N_CONV; ++j) {
+            const LayerSpec& s = L[j];
+            size_t wn = 0;
+            switch (s.kind) {
+                case K_FIRST: case K_PSI: case K_FINAL: wn = (size_t)s.cout * s.cin * s.k * s.k; break;
+                case K_CONV3: wn = (size_t)s.cout * s.cin * 9; break;
+                case K_ATT_G: wn = (size_t)s.cout * s.cin * 2; break;   // joint [g|x] K
+                case K_ATT_X: wn = 0; break;
+            }
+            w_off[j] = take(wn);
+            s_off[j] = take(s.cout);
+            t_off[j] = take(s.cout);
+        }
+        total_floats = off;
+    }
+};
+const Table& table() { static Table t; return t; }
+
+__global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+int copy_f32(const float* src, float* dst, long long n, hipStream_t st) {
+    copy_f32_kernel<<<nbp_ew_grid(n, 256), 256, 0, st>>>(src, dst, n);
+    return nbp_launch_status();
+}
+
+__global__ void fill_f32_kernel(float* __restrict__ dst, float v, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = v;
+}
+int fill_f32(float* dst, float v, long long n, hipStream_t st) {
+    fill_f32_kernel<<<nbp_ew_grid(n, 256), 256, 0, st>>>(dst, v, n);
+    return nbp_launch_status();
+}
+
+}  // namespace
+
+struct nbp_weights {
+    const float* w[NBP_N_CONV];
+    const float* scale[NBP_N_CONV];
+    const float* shift[NBP_N_CONV];
+};
+
+extern "C" int nbp_abi_version(void) { return NBP_ABI_VERSION; }
+
+extern "C" int nbp_device_info(char* arch_host, int arch_len, int* cu_count_host) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return (int)e;
+    if (arch_host && arch_len > 0) { strncpy(arch_host, p.gcnArchName, arch_len - 1); arch_host[arch_len - 1] = 0; }
+    if (cu_count_host) *cu_count_host = p.multiProcessorCount;
+    return 0;
+}
+
+extern "C" size_t nbp_packed_weights_bytes(void) { return table().total_floats * sizeof(float); }
+
+extern "C" int nbp_pack_weights(const void* const* w_host_array, const void* const* scale_host_array,
+                                const void* const* shift_host_array, void* packed, size_t packed_bytes, void* stream,
+                                nbp_weights** handle_out) {
+    NBP_RETURN_IF(!w_host_array || !scale_host_array || !shift_host_array || !packed || !handle_out, NBP_E_ARG);
+    const Table& T = table();
+    NBP_RETURN_IF(packed_bytes < T.total_floats * sizeof(float), NBP_E_WS);
+    for (int i = 0; i < NBP_N_CONV; ++i) {
+        NBP_RETURN_IF(!w_host_array[i] || !scale_host_array[i], NBP_E_ARG);
+        NBP_RETURN_IF(T.L[i].kind != K_ATT_X && !shift_host_array[i], NBP_E_ARG);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* base = (float*)packed;
+    nbp_weights* h = (nbp_weights*)calloc(1, sizeof(nbp_weights));
+    NBP_RETURN_IF(!h, NBP_E_ARG);
+    int rc = 0;
+    for (int i = 0; i < NBP_N_CONV && !rc; ++i) {
+        const LayerSpec& s = T.L[i];
+        const float* w = (const float*)w_host_array[i];
+        const float* sc = (const float*)scale_host_array[i];
+        const float* sh = (const float*)shift_host_array[i];
+        float* wd = base + T.w_off[i];
+        float* sd = base + T.s_off[i];
+        float* td = base + T.t_off[i];
+        h->w[i] = wd; h->scale[i] = sd; h->shift[i] = td;
+        switch (s.kind) {
+            case K_FIRST: case K_FINAL:
+                rc = copy_f32(w, wd, (long long)s.cout * s.cin * s.k * s.k, st);
+                if (!rc) rc = copy_f32(sc, sd, s.cout, st);
+                if (!rc) rc = copy_f32(sh, td, s.cout, st);
+                break;
+            case K_PSI:   // psi tail reads {scale, shift} as two consecutive floats
+                rc = copy_f32(w, wd, s.cin, st);
+                if (!rc) rc = copy_f32(sc, sd, 1, st);
+                if (!rc) rc = copy_f32(sh, sd + 1, 1, st);
+                if (!rc) rc = copy_f32(sh, td, 1, st);
+                break;
+            case K_CONV3:
+                rc = nbp_pack_conv_weight(w, s.cout, s.cin, 3, nullptr, 0, s.cin, wd, st);
+                if (!rc) rc = copy_f32(sc, sd, s.cout, st);
+                if (!rc) rc = copy_f32(sh, td, s.cout, st);
+                break;
+            case K_ATT_G: {
+                // joint GEMM over K=[g|x]: scale folded into the weights, epilogue scale = 1
+                rc = nbp_pack_conv_weight(w, s.cout, s.cin, 1, sc, 0, 2 * s.cin, wd, st);
+                const float* wx = (const float*)w_host_array[i + 1];
+                const float* scx = (const float*)scale_host_array[i + 1];
+                if (!rc) rc = nbp_pack_conv_weight(wx, s.cout, s.cin, 1, scx, s.cin, 2 * s.cin, wd, st);
+                if (!rc) rc = fill_f32(sd, 1.0f, s.cout, st);
+                if (!rc) rc = copy_f32(sh, td, s.cout, st);
+                break;
+            }
+            case K_ATT_X:
+                h->w[i] = nullptr;
+                break;
+        }
+    }
+    if (rc) { free(h); return rc; }
+    *handle_out = h;
+    return 0;
+}
+
+extern "C" void nbp_free_weights(nbp_weights* handle) { free(handle); }
+
+// ------------------------------------------------------------------ forward
+namespace {
+
+struct Bump {
+    char* base; size_t size, off; bool dry;
+    float* take(size_t floats) {
+        size_t bytes = (floats * sizeof(float) + 255) / 256 * 256;
+        size_t o = off; off += bytes;
+        if (dry) return (float*)(uintptr_t)256;   // non-null dummy
+        return (float*)(base + o);
+    }
+};
+
+struct Timer {
+    hipStream_t st;
+    nbp_layer_timing* out; int cap; int n;
+    hipEvent_t ev[256];
+    int nev;
+    int begin() {
+        nev = 0; n = 0;
+        hipError_t e = hipEventCreate(&ev[0]);
+        if (e != hipSuccess) return (int)e;
+        nev = 1;
+        return (int)hipEventRecord(ev[0], st);
+    }
+    void mark(const char* name, double flops, int tile, int split_k, long long M, int N, int K) {
+        if (n >= cap || nev >= 256) return;
+        if (hipEventCreate(&ev[nev]) != hipSuccess) return;
+        (void)hipEventRecord(ev[nev], st);
+        ++nev;
+        nbp_layer_timing& t = out[n++];
+        memset(&t, 0, sizeof(t));
+        strncpy(t.name, name, sizeof(t.name) - 1);
+        t.flops = flops; t.tile = tile; t.split_k = split_k; t.M = M; t.N = N; t.K = K;
+    }
+    int finish() {
+        hipError_t e = hipStreamSynchronize(st);
+        for (int i = 0; i + 1 < nev && i < n; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            out[i].ms = ms;
+        }
+        for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
+        return (int)e;
+    }
+};
+
+size_t splitk_scratch_floats(long long M, int N, int cin_total, int taps) {
+    ConvPlan p = nbp_plan_conv(M, N, cin_total / 32 * taps, 0, 0);
+    return p.split_k > 1 ? (size_t)p.split_k * M * N : 0;
+}
+
+// Runs (or, with h == nullptr, only sizes) the network.
+int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1, float* out2, Bump& bp,
+                hipStream_t st, Timer* tm = nullptr) {
+    char nm[48];
+    const bool dry = bp.dry;
+    const int enc[5] = {64, 128, 256, 512, 1024};
+    int rc = 0;
+    // split-K scratch: sized for the worst layer, shared by all (stream-ordered)
+    size_t sk = 0;
+    {
+        int s = S;
+        sk = 0;
+        for (int e = 0; e < 5; ++e, s /= 2) {
+            long long M = (long long)B * s * s;
+            if (e > 0) sk = max(sk, splitk_scratch_floats(M, enc[e], enc[e - 1], 9));
+            sk = max(sk, splitk_scratch_floats(M, enc[e], enc[e], 9));
+            if (e < 4) {   // decoder level at this resolution: co = enc[e], ci = enc[e+1]
+                sk = max(sk, splitk_scratch_floats(M, enc[e], enc[e + 1], 9));
+                sk = max(sk, splitk_scratch_floats(M, enc[e] / 2, 2 * enc[e], 1));
+            }
+        }
+    }
+    float* skws = bp.take(sk ? sk : 64);
+    const size_t skbytes = sk * sizeof(float);
+
+    auto conv = [&](const char* name, int li, const float* s0, int C0, const float* s1, int C1, int ups, int Hh,
+                    int ksize, int N, float* out) {
+        if (dry || rc) return;
+        rc = nbp_conv_igemm_launch(s0, C0, s1, C1, ups, B, Hh, Hh, ksize, h->w[li], N, h->scale[li], h->shift[li], 1,
+                                   out, 0, 0, skws, skbytes, st);
+        if (tm && !rc) {
+            const long long M = (long long)B * Hh * Hh;
+            const int K = (C0 + C1) * ksize * ksize;
+            ConvPlan p = nbp_plan_conv(M, N, K / 32, 0, 0);
+            tm->mark(name, 2.0 * M * N * K, p.tile, p.split_k, M, N, K);
+        }
+    };
+    auto stamp = [&](const char* name, double flops, long long M, int N, int K) {
+        if (tm && !dry && !rc) tm->mark(name, flops, -1, 1, M, N, K);
+    };
+
+    // ---- encoder
+    float* skip[5];
+    int li = 0;
+    int s = S;
+    const float* prev = nullptr;
+    for (int e = 0; e < 5; ++e) {
+        const int co = enc[e];
+        const size_t n = (size_t)B * s * s * co;
+        float* a = bp.take(n);
+        float* b = bp.take(n);
+        if (e == 0) {
+            if (!dry && !rc) rc = nbp_conv_first_f32(x, B, s, s, h->w[0], h->scale[0], h->shift[0], a, st);
+            stamp("Conv1.conv.0(first)", 2.0 * B * s * s * 64 * 45, (long long)B * s * s, 64, 45);
+        } else {
+            float* pooled = bp.take((size_t)B * s * s * enc[e - 1]);
+            if (!dry && !rc) rc = nbp_maxpool2_nhwc_f32(prev, B, 2 * s, 2 * s, enc[e - 1], pooled, st);
+            snprintf(nm, sizeof nm, "Maxpool%d", e);
+            stamp(nm, 0, (long long)B * s * s, enc[e - 1], 0);
+            snprintf(nm, sizeof nm, "Conv%d.conv.0", e + 1);
+            conv(nm, li, pooled, enc[e - 1], nullptr, 0, 0, s, 3, co, a);
+        }
+        snprintf(nm, sizeof nm, "Conv%d.conv.3", e + 1);
+        conv(nm, li + 1, a, co, nullptr, 0, 0, s, 3, co, b);
+        li += 2;
+        skip[e] = b; prev = b;
+        if (e < 4) s /= 2;
+    }
+    // ---- decoders.  Level L (5..2) works at resolution S >> (L-1) with co = enc[L-2], ci = enc[L-1].
+    for (int d = 1; d <= 2; ++d) {
+        const float* cur = skip[4];
+        const size_t mark = bp.off;           // decoder scratch is reused by decoder 2
+        const int last_level = (d == 1) ? 4 : 2;
+        for (int Lv = 5; Lv >= last_level; --Lv) {
+            const int co = enc[Lv - 2], ci = enc[Lv - 1];
+            const int sr = S >> (Lv - 2);
+            const long long M = (long long)B * sr * sr;
+            float* dd = bp.take((size_t)M * co);
+            float* q = bp.take((size_t)M * (co / 2));
+            float* ag = bp.take((size_t)M * co);
+            float* u = bp.take((size_t)M * co);
+            float* o = bp.take((size_t)M * co);
+            const float* xs = skip[Lv - 2];
+            snprintf(nm, sizeof nm, "Up%d_%d.up.1", Lv, d);
+            conv(nm, li, cur, ci, nullptr, 0, 1, sr, 3, co, dd);                   // Up: upsample + conv3x3
+            snprintf(nm, sizeof nm, "Att%d_%d.W_g+W_x", Lv, d);
+            conv(nm, li + 1, dd, co, xs, co, 0, sr, 1, co / 2, q);                 // relu(W_g g + W_x x)
+            if (!dry && !rc)
+                rc = nbp_psi_gate_f32(q, co / 2, h->w[li + 3], h->scale[li + 3], xs, co, M, ag, st);
+            snprintf(nm, sizeof nm, "Att%d_%d.psi*x", Lv, d);
+            stamp(nm, 2.0 * M * (co / 2), M, 1, co / 2);
+            snprintf(nm, sizeof nm, "Up_conv%d_%d.conv.0", Lv, d);
+            conv(nm, li + 4, ag, co, dd, co, 0, sr, 3, co, u);                      // conv(cat(a, d))
+            snprintf(nm, sizeof nm, "Up_conv%d_%d.conv.3", Lv, d);
+            conv(nm, li + 5, u, co, nullptr, 0, 0, sr, 3, co, o);
+            li += 6;
+            cur = o;
+        }
+        if (d == 1) {
+            if (!dry && !rc)
+                rc = nbp_final_1x1_f32(cur, B, S / 4, S / 4, 256, h->w[46], 8, h->scale[46], h->shift[46], 0, out1, st);
+            stamp("Final1", 2.0 * B * (S / 4) * (S / 4) * 8 * 256, (long long)B * (S / 4) * (S / 4), 8, 256);
+            bp.off = mark;   // decoder 2 reuses decoder 1's scratch (it needs strictly more, so sizing is safe)
+        } else {
+            if (!dry && !rc)
+                rc = nbp_final_1x1_f32(cur, B, S, S, 64, h->w[47], 1, h->scale[47], h->shift[47], 1, out2, st);
+            stamp("Final2", 2.0 * B * S * S * 64, (long long)B * S * S, 1, 64);
+        }
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" size_t nbp_forward_workspace_bytes(int B, int S) {
+    if (B < 1 || S < 16 || S % 16) return 0;
+    Bump bp{nullptr, 0, 0, true};
+    run_forward(nullptr, nullptr, B, S, nullptr, nullptr, bp, nullptr);
+    return bp.off + 256;
+}
+
+extern "C" int nbp_forward_f32(const nbp_weights* handle, const float* x, int B, int S, float* out1, float* out2,
+                               void* ws, size_t ws_bytes, void* stream) {
+    NBP_RETURN_IF(!handle || !x || !out1 || !out2 || !ws, NBP_E_ARG);
+    NBP_RETURN_IF(B < 1, NBP_E_ARG);
+    NBP_RETURN_IF(S < 16 || S % 16, NBP_E_SHAPE);
+    NBP_RETURN_IF(ws_bytes < nbp_forward_workspace_bytes(B, S), NBP_E_WS);
+    uintptr_t p = ((uintptr_t)ws + 255) / 256 * 256;
+    Bump bp{(char*)p, ws_bytes, 0, false};
+    return run_forward(handle, x, B, S, out1, out2, bp, (hipStream_t)stream);
+}
+
+extern "C" int nbp_forward_timed_f32(const nbp_weights* handle, const float* x, int B, int S, float* out1,
+                                     float* out2, void* ws, size_t ws_bytes, void* stream,
+                                     nbp_layer_timing* timings_host, int max_entries, int* n_entries_host) {
+    NBP_RETURN_IF(!handle || !x || !out1 || !out2 || !ws || !timings_host || !n_entries_host, NBP_E_ARG);
+    NBP_RETURN_IF(B < 1 || max_entries < 1, NBP_E_ARG);
+    NBP_RETURN_IF(S < 16 || S % 16, NBP_E_SHAPE);
+    NBP_RETURN_IF(ws_bytes < nbp_forward_workspace_bytes(B, S), NBP_E_WS);
+    uintptr_t p = ((uintptr_t)ws + 255) / 256 * 256;
+    Bump bp{(char*)p, ws_bytes, 0, false};
+    static Timer tm;   // 256 events; profiling entry point is not re-entrant
+    tm.st = (hipStream_t)stream; tm.out = timings_host; tm.cap = max_entries;
+    int rc = tm.begin();
+    if (rc) return rc;
+    rc = run_forward(handle, x, B, S, out1, out2, bp, (hipStream_t)stream, &tm);
+    int rc2 = tm.finish();
+    *n_entries_host = tm.n;
+    return rc ? rc : rc2;
+}
+
+extern "C" double nbp_forward_flops(int B, int S) {
+    const Table& T = table();
+    // spatial size of each conv's output, canonical order
+    double macs = 0;
+    auto add = [&](int li, int res) { const LayerSpec& s = T.L[li]; macs += (double)res * res * s.cout * s.cin * s.k * s.k; };
+    int li = 0, s = S;
+    for (int e = 0; e < 5; ++e, s /= 2) { add(li++, s); add(li++, s); }
+    for (int d = 1; d <= 2; ++d)
+        for (int Lv = 5; Lv >= (d == 1 ? 4 : 2); --Lv) {
+            int sr = S >> (Lv - 2);
+            for (int k = 0; k < 6; ++k) add(li++, sr);
+        }
+    add(46, S / 4); add(47, S);
+    return 2.0 * macs * B;
+}

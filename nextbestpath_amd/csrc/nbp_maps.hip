@@ -1,0 +1,158 @@
+// nbp_maps.hip -- per-step map accumulation: world points -> agent-centred top-down count
+// images (HBM-bound scatter; 12 B read per point, fp32 atomics resolve in L2).
+//
+// Replaces next_best_path/utility/utils.py:160-223 (get_point_position_in_the_img,
+// transform_points_to_n_pieces, map_points_to_n_imgs) and the slab split / projections of
+// next_best_path/testers/nbp_planning.py:114-127,172-183.  All arithmetic is the
+// reference's fp32 sequence: sub, negate, add 40, multiply by fp32(S/80), rint (half to
+// even), bounds test -- so the integer cell of every point is bit-identical.
+#include "common.h"
+#pragma clang fp contract(off)
+
+namespace {
+
+struct Bounds { float b[8]; int n; };
+
+__device__ __forceinline__ bool cell_of(float v0, float v1, float lo, float sc0, float sc1, int S0, int S1,
+                                        int& i0, int& i1) {
+    const float f0 = rintf((v0 - lo) * sc0);
+    const float f1 = rintf((v1 - lo) * sc1);
+    const bool ok = f0 >= 0.f && f0 < (float)S0 && f1 >= 0.f && f1 < (float)S1;
+    i0 = ok ? (int)f0 : 0;
+    i1 = ok ? (int)f1 : 0;
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void transform_points_kernel(const float* __restrict__ p, long long N, float cx,
+                                                               float cz, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float x = p[3 * i], z = p[3 * i + 2];
+        out[2 * i] = -(z - cz);
+        out[2 * i + 1] = -(x - cx);
+    }
+}
+
+__global__ __launch_bounds__(256) void map_points_kernel(const float* __restrict__ pts, int n, long long m, int S0,
+                                                         int S1, float lo, float sc0, float sc1,
+                                                         float* __restrict__ out) {
+    const long long total = (long long)n * m;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float2 v = reinterpret_cast<const float2*>(pts)[i];
+        int i0, i1;
+        if (cell_of(v.x, v.y, lo, sc0, sc1, S0, S1, i0, i1)) {
+            const long long img = i / m;
+            atomicAdd(out + (img * S0 + i0) * S1 + i1, 1.0f);
+        }
+    }
+}
+
+__global__ void point_position_kernel(const float* __restrict__ pts, long long K, float lo, float sc0, float sc1,
+                                      long long* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < K;
+         i += (long long)gridDim.x * blockDim.x) {
+        out[i] = (long long)rintf((pts[2 * i] - lo) * sc0);
+        out[K + i] = (long long)rintf((pts[2 * i + 1] - lo) * sc1);
+    }
+}
+
+__device__ __forceinline__ void accumulate_point(float x, float y, float z, float cx, float cz, const Bounds& bd,
+                                                 float band_lo, float band_hi, int S, float lo, float sc,
+                                                 float* __restrict__ out) {
+    int i0, i1;
+    if (!cell_of(-(z - cz), -(x - cx), lo, sc, sc, S, S, i0, i1)) return;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cnt += (k < bd.n && bd.b[k] < y) ? 1 : 0;
+    const int bin = cnt - 1;
+    const int ch = (bin >= 0 && bin < 4) ? bin : 4;
+    const int cell = i0 * S + i1;
+    atomicAdd(out + ch * S * S + cell, 1.0f);
+    if (band_lo < y && y < band_hi) atomicAdd(out + 5 * S * S + cell, 1.0f);
+}
+
+// 4 points (48 contiguous bytes = three 16-byte loads) per thread per iteration.  `head`
+// (< 4) leading points bring the pointer to 16-byte alignment; they and the N % 4 tail are
+// handled by the first threads of block 0.
+__global__ __launch_bounds__(256) void map_accumulate_kernel(const float* __restrict__ p, long long N, int head,
+                                                             float cx, float cz, Bounds bd, float band_lo,
+                                                             float band_hi, int S, float lo, float sc,
+                                                             float* __restrict__ out) {
+    const long long groups = (N - head) >> 2;
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(p + 3 * head);
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < groups;
+         g += (long long)gridDim.x * blockDim.x) {
+        const f32x4 a = p4[3 * g], b = p4[3 * g + 1], c = p4[3 * g + 2];
+        accumulate_point(a[0], a[1], a[2], cx, cz, bd, band_lo, band_hi, S, lo, sc, out);
+        accumulate_point(a[3], b[0], b[1], cx, cz, bd, band_lo, band_hi, S, lo, sc, out);
+        accumulate_point(b[2], b[3], c[0], cx, cz, bd, band_lo, band_hi, S, lo, sc, out);
+        accumulate_point(c[1], c[2], c[3], cx, cz, bd, band_lo, band_hi, S, lo, sc, out);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 8) {
+        long long i = -1;
+        if ((int)threadIdx.x < head) i = threadIdx.x;                                  // head points
+        else if (threadIdx.x >= 4) i = head + (groups << 2) + (threadIdx.x - 4);       // tail points
+        if (i >= 0 && i < N && (i < head || i >= head + (groups << 2)))
+            accumulate_point(p[3 * i], p[3 * i + 1], p[3 * i + 2], cx, cz, bd, band_lo, band_hi, S, lo, sc, out);
+    }
+}
+
+inline float grid_scale(int S, float lo, float hi) { return (float)((double)S / ((double)hi - (double)lo)); }
+
+}  // namespace
+
+extern "C" int nbp_transform_points_f32(const float* points, long long N, float cx, float cy, float cz, float* out_2d,
+                                        void* stream) {
+    (void)cy;
+    NBP_RETURN_IF(N < 0, NBP_E_ARG);
+    if (N == 0) return 0;
+    NBP_RETURN_IF(!points || !out_2d, NBP_E_ARG);
+    transform_points_kernel<<<nbp_ew_grid(N, 256), 256, 0, (hipStream_t)stream>>>(points, N, cx, cz, out_2d);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_map_points_to_imgs_f32(const float* pts2d, int n, long long m, int S0, int S1, float lo, float hi,
+                                          float* out, void* stream) {
+    NBP_RETURN_IF(!out || n < 1 || m < 0 || S0 < 1 || S1 < 1 || !(hi > lo), NBP_E_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)n * S0 * S1 * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (m == 0) return 0;
+    NBP_RETURN_IF(!pts2d, NBP_E_ARG);
+    map_points_kernel<<<nbp_ew_grid((long long)n * m, 256), 256, 0, st>>>(pts2d, n, m, S0, S1, lo,
+                                                                          grid_scale(S0, lo, hi),
+                                                                          grid_scale(S1, lo, hi), out);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_point_position_i64(const float* pts2d, long long K, int S0, int S1, float lo, float hi,
+                                      long long* out_2xK, void* stream) {
+    NBP_RETURN_IF(!pts2d || !out_2xK || K < 1 || S0 < 1 || S1 < 1 || !(hi > lo), NBP_E_ARG);
+    point_position_kernel<<<nbp_ew_grid(K, 256), 256, 0, (hipStream_t)stream>>>(pts2d, K, lo, grid_scale(S0, lo, hi),
+                                                                                grid_scale(S1, lo, hi), out_2xK);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_map_accumulate_f32(const float* points, long long N, float cx, float cy, float cz,
+                                      const float* bounds_host, int n_bounds, float band_lo, float band_hi, int S,
+                                      float lo, float hi, float* out6, void* stream) {
+    (void)cy;
+    NBP_RETURN_IF(!out6 || N < 0 || S < 1 || !(hi > lo), NBP_E_ARG);
+    NBP_RETURN_IF(n_bounds < 0 || n_bounds > 8 || (n_bounds > 0 && !bounds_host), NBP_E_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out6, 0, (size_t)6 * S * S * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (N == 0) return 0;
+    NBP_RETURN_IF(!points, NBP_E_ARG);
+    NBP_RETURN_IF(((uintptr_t)points & 3) != 0, NBP_E_ARG);
+    int head = 0;
+    while ((((uintptr_t)points + 12u * head) & 15) != 0) ++head;   // 12k mod 16 cycles 0,12,8,4: head <= 3
+    if (head > N) head = (int)N;
+    Bounds bd;
+    for (int k = 0; k < 8; ++k) bd.b[k] = k < n_bounds ? bounds_host[k] : 0.f;
+    bd.n = n_bounds;
+    map_accumulate_kernel<<<nbp_ew_grid(nbp_cdiv(N, 4), 256), 256, 0, st>>>(points, N, head, cx, cz, bd, band_lo, band_hi, S,
+                                                                            lo, grid_scale(S, lo, hi), out6);
+    return nbp_launch_status();
+}

@@ -1,0 +1,149 @@
+"""NBP value network -- host-side mirror of the reference interface, HIP compute.
+
+Reference: next_best_path/networks/nbp_model.py:64-173 (class ``NBP``: Attention U-Net
+with one shared encoder and two decoders).  This module keeps the reference's *interface*:
+
+* ``NBP(img_ch=5, output_ch1=8, output_ch2=1)``
+* ``forward(x) -> (out1 [B,8,S/4,S/4] linear, out2 [B,1,S,S] sigmoid)``
+* ``loss(pred1, target1, pred2, target2)`` (uncertainty weighted MSE + BCE, ref :162-173)
+* the exact 327 ``state_dict`` keys (``Conv1.conv.0.weight`` ... ``Final2.0.bias``,
+  ``log_vars``) so a reference checkpoint loads with ``strict=True``.
+
+The arithmetic is NOT torch: ``forward`` hands raw device pointers to the hand written
+gfx950 kernels in ``csrc/`` through the C ABI declared in ``include/nbp_hip.h``
+(BN is applied as a per-channel scale/shift in the conv epilogue, upsample / concat /
+attention gate are fused into the operand gather of the implicit-GEMM convolution).
+There is no CPU fallback: a CPU tensor, or a missing ``libnbp_hip.so``, raises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+
+# (name, kind, c_in, c_out) in reference construction order (nbp_model.py:70-108).
+# kind: "block" = conv3x3-BN-ReLU x2 under attribute ``conv`` (ref :8-21)
+#       "up"    = Upsample(x2 nearest)-conv3x3-BN-ReLU under attribute ``up`` (ref :23-34)
+#       "att"   = attention gate W_g / W_x / psi (ref :36-62); c_out is F_int
+_ENCODER = [("Conv1", None, 64), ("Conv2", 64, 128), ("Conv3", 128, 256),
+            ("Conv4", 256, 512), ("Conv5", 512, 1024)]
+_DEC1 = [(5, 1024, 512), (4, 512, 256)]
+_DEC2 = [(5, 1024, 512), (4, 512, 256), (3, 256, 128), (2, 128, 64)]
+
+
+def _c3(ci, co):
+    return nn.Conv2d(ci, co, kernel_size=3, stride=1, padding=1, bias=True)
+
+
+def _c1(ci, co):
+    return nn.Conv2d(ci, co, kernel_size=1, stride=1, padding=0, bias=True)
+
+
+class _Holder(nn.Module):
+    """A module whose only child is an ``nn.Sequential`` registered under ``attr``.
+
+    This reproduces the reference's parameter *names* (``<X>.conv.<i>.*``, ``<X>.up.<i>.*``)
+    without reproducing its module code; the Sequential is a parameter container only --
+    it is never called on the product path.
+    """
+
+    def __init__(self, attr: str, layers):
+        super().__init__()
+        setattr(self, attr, nn.Sequential(*layers))
+
+
+def _double_conv(ci, co):
+    return _Holder("conv", [_c3(ci, co), nn.BatchNorm2d(co), nn.ReLU(inplace=True),
+                            _c3(co, co), nn.BatchNorm2d(co), nn.ReLU(inplace=True)])
+
+
+def _up_conv(ci, co):
+    return _Holder("up", [nn.Upsample(scale_factor=2), _c3(ci, co), nn.BatchNorm2d(co),
+                          nn.ReLU(inplace=True)])
+
+
+class _Gate(nn.Module):
+    def __init__(self, f_g, f_l, f_int):
+        super().__init__()
+        self.W_g = nn.Sequential(_c1(f_g, f_int), nn.BatchNorm2d(f_int))
+        self.W_x = nn.Sequential(_c1(f_l, f_int), nn.BatchNorm2d(f_int))
+        self.psi = nn.Sequential(_c1(f_int, 1), nn.BatchNorm2d(1), nn.Sigmoid())
+        self.relu = nn.ReLU(inplace=True)
+
+
+class NBP(nn.Module):
+    def __init__(self, img_ch: int = 5, output_ch1: int = 8, output_ch2: int = 1):
+        super().__init__()
+        if (img_ch, output_ch1, output_ch2) != (5, 8, 1):
+            raise ValueError("the HIP path is built for the reference's NBP(5, 8, 1)")
+        self.Maxpool = nn.MaxPool2d(kernel_size=2, stride=2)
+        for name, ci, co in _ENCODER:
+            setattr(self, name, _double_conv(img_ch if ci is None else ci, co))
+        # decoder 1 (value map) -- registration order follows the reference so that
+        # default-initialised weights draw the global RNG in the same order.
+        for lvl, ci, co in _DEC1:
+            setattr(self, f"Up{lvl}_1", _up_conv(ci, co))
+            setattr(self, f"Att{lvl}_1", _Gate(co, co, co // 2))
+            setattr(self, f"Up_conv{lvl}_1", _double_conv(ci, co))
+        self.Final1 = _c1(256, output_ch1)
+        for lvl, ci, co in _DEC2:
+            setattr(self, f"Up{lvl}_2", _up_conv(ci, co))
+            setattr(self, f"Att{lvl}_2", _Gate(co, co, co // 2))
+            setattr(self, f"Up_conv{lvl}_2", _double_conv(ci, co))
+        self.Final2 = nn.Sequential(_c1(64, output_ch2), nn.Sigmoid())
+        self.log_vars = nn.Parameter(torch.zeros(2))
+        self._packed = None          # opaque handle into libnbp_hip (eval-mode packed weights)
+        self._packed_key = None
+        self._tensors = None
+
+    # ------------------------------------------------------------------ packing
+    def _state_key(self):
+        # cheap staleness check: storage pointers + in-place version counters of every
+        # parameter / buffer (optimizer steps and load_state_dict bump the versions)
+        if self._tensors is None:
+            self._tensors = list(self.parameters()) + list(self.buffers())
+        return tuple((t.data_ptr(), t._version) for t in self._tensors)
+
+    def invalidate_packed(self):
+        if self._packed is not None:
+            self._packed.free()
+        self._packed = None
+        self._packed_key = None
+        self._tensors = None
+
+    def _apply(self, fn, *a, **k):     # .to() / .cuda() / .float() replace storages
+        self.invalidate_packed()
+        return super()._apply(fn, *a, **k)
+
+    def _ensure_packed(self, device):
+        key = (self._state_key(), str(device))
+        if self._packed is None or key != self._packed_key:
+            from . import packing
+            if self._packed is not None:
+                self._packed.free()
+            self._packed = packing.pack_eval_weights(self, device)
+            self._packed_key = key
+        return self._packed
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor):
+        if not x.is_cuda:
+            raise RuntimeError(
+                "nextbestpath_amd.NBP.forward runs on MI355X only (got a CPU tensor); "
+                "there is no CPU fallback -- the CPU checker lives in oracle/ and is test-only")
+        if x.dim() != 4 or x.shape[1] != 5 or x.shape[2] != x.shape[3] or x.shape[2] % 16:
+            raise ValueError(f"expected [B,5,S,S] with S % 16 == 0, got {tuple(x.shape)}")
+        if self.training:
+            from . import training
+            return training.forward_train(self, x)
+        from . import packing
+        return packing.forward_eval(self, x)
+
+    # ------------------------------------------------------------------ loss (ref :162-173)
+    def loss(self, pred1, target1, pred2, target2):
+        s = self.log_vars
+        l1 = F.mse_loss(pred1, target1) / (2.0 * torch.exp(2 * s[0])) + s[0]
+        l2 = F.binary_cross_entropy(pred2, target2) / torch.exp(2 * s[1]) + s[1]
+        return l1 + l2

@@ -1,0 +1,127 @@
+"""Eval-mode weight packing and the forward call into libnbp_hip.so.
+
+BatchNorm (eval, running statistics) and the conv bias collapse to one per-output-channel
+affine applied in the conv epilogue:  out = act(acc * scale + shift) with
+    scale = gamma / sqrt(var + eps),   shift = (bias - mean) * scale + beta
+computed here in float64 and rounded once to fp32 (reference semantics:
+next_best_path/networks/nbp_model.py:8-62 with nn.BatchNorm2d defaults eps=1e-5).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+# canonical conv order of include/nbp_hip.h -> (conv prefix, bn prefix or None)
+def canonical_layers():
+    out = []
+    for e in range(1, 6):
+        out.append((f"Conv{e}.conv.0", f"Conv{e}.conv.1"))
+        out.append((f"Conv{e}.conv.3", f"Conv{e}.conv.4"))
+    for d, levels in ((1, (5, 4)), (2, (5, 4, 3, 2))):
+        for L in levels:
+            out.append((f"Up{L}_{d}.up.1", f"Up{L}_{d}.up.2"))
+            out.append((f"Att{L}_{d}.W_g.0", f"Att{L}_{d}.W_g.1"))
+            out.append((f"Att{L}_{d}.W_x.0", f"Att{L}_{d}.W_x.1"))
+            out.append((f"Att{L}_{d}.psi.0", f"Att{L}_{d}.psi.1"))
+            out.append((f"Up_conv{L}_{d}.conv.0", f"Up_conv{L}_{d}.conv.1"))
+            out.append((f"Up_conv{L}_{d}.conv.3", f"Up_conv{L}_{d}.conv.4"))
+    out.append(("Final1", None))
+    out.append(("Final2.0", None))
+    assert len(out) == 48
+    return out
+
+
+def fold_affine(sd, conv, bn, eps=1e-5):
+    """(scale, shift) float64 tensors for conv `conv` followed by BatchNorm `bn` (or none)."""
+    bias = sd[conv + ".bias"].double()
+    if bn is None:
+        return torch.ones_like(bias), bias
+    g, b = sd[bn + ".weight"].double(), sd[bn + ".bias"].double()
+    mu, var = sd[bn + ".running_mean"].double(), sd[bn + ".running_var"].double()
+    scale = g / torch.sqrt(var + eps)
+    return scale, (bias - mu) * scale + b
+
+
+class PackedWeights:
+    """Owns the device buffer and the C handle; freed explicitly or on GC."""
+
+    def __init__(self, handle, buf, keep):
+        self.handle, self.buf, self.keep = handle, buf, keep
+
+    def free(self):
+        if self.handle:
+            _lib.lib().nbp_free_weights(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pack_state_dict(sd, device) -> PackedWeights:
+    L = _lib.lib()
+    layers = canonical_layers()
+    ws, ss, ts, keep = [], [], [], []
+    folded = [fold_affine(sd, c, b) for c, b in layers]
+    for i, (conv, bn) in enumerate(layers):
+        w = sd[conv + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()
+        scale, shift = folded[i]
+        if ".W_g." in conv:       # fused attention GEMM: shift_g + shift_x rides on W_g
+            shift = shift + folded[i + 1][1]
+        s = scale.to(torch.float32).to(device).contiguous()
+        t = shift.to(torch.float32).to(device).contiguous()
+        keep += [w, s, t]
+        ws.append(w.data_ptr()); ss.append(s.data_ptr()); ts.append(t.data_ptr())
+    nbytes = L.nbp_packed_weights_bytes()
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    arr = lambda v: (C.c_void_p * 48)(*v)
+    handle = C.c_void_p()
+    with torch.cuda.device(device):
+        rc = L.nbp_pack_weights(arr(ws), arr(ss), arr(ts), buf.data_ptr(), nbytes, _lib.current_stream(),
+                                C.byref(handle))
+        _lib.check(rc, "nbp_pack_weights")
+        torch.cuda.current_stream().synchronize()   # sources in `keep` may now be released
+    return PackedWeights(handle, buf, None)
+
+
+def pack_eval_weights(module, device) -> PackedWeights:
+    return pack_state_dict(module.state_dict(), device)
+
+
+_ws_cache = {}
+
+
+def _workspace(B, S, device):
+    key = (B, S, str(device))
+    ws = _ws_cache.get(key)
+    if ws is None:
+        n = _lib.lib().nbp_forward_workspace_bytes(B, S)
+        if n == 0:
+            raise _lib.NbpHipError(f"unsupported NBP input size B={B} S={S}")
+        ws = torch.empty(n, dtype=torch.uint8, device=device)
+        _ws_cache.clear()          # keep one workspace alive (sizes rarely change)
+        _ws_cache[key] = ws
+    return ws
+
+
+def forward_packed(packed: PackedWeights, x: torch.Tensor):
+    B, _, S, _ = x.shape
+    x = x.contiguous().float()
+    out1 = torch.empty(B, 8, S // 4, S // 4, dtype=torch.float32, device=x.device)
+    out2 = torch.empty(B, 1, S, S, dtype=torch.float32, device=x.device)
+    ws = _workspace(B, S, x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().nbp_forward_f32(packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), _lib.current_stream())
+    _lib.check(rc, "nbp_forward_f32")
+    return out1, out2
+
+
+def forward_eval(module, x: torch.Tensor):
+    packed = module._ensure_packed(x.device)
+    return forward_packed(packed, x)

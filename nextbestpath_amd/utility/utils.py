@@ -1,0 +1,96 @@
+"""Map accumulation -- drop-in for next_best_path/utility/utils.py:160-223.
+
+Same function names, positional arguments and return shapes as the reference; the work is
+done by the HIP kernels of csrc/nbp_maps.hip (no torch arithmetic, no CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+
+def _need_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the HIP path needs a cuda tensor (no CPU fallback)")
+
+
+def _pose_xyz(camera_pose):
+    # the reference reads the pose through .tolist() (one device sync); accept host floats too
+    if isinstance(camera_pose, torch.Tensor):
+        vals = camera_pose.detach().flatten()[:3].tolist()
+    else:
+        vals = list(camera_pose)[:3]
+    return float(vals[0]), float(vals[1]), float(vals[2])
+
+
+def get_point_position_in_the_img(points_2d, grid_size, grid_range):
+    """ref utils.py:160-164 -- [...,2] fp32 -> stack((i0, i1)).squeeze() int64, no bounds check."""
+    _need_cuda(points_2d, "get_point_position_in_the_img")
+    p = points_2d.reshape(-1, 2).contiguous().float()
+    K = p.shape[0]
+    out = torch.empty(2, K, dtype=torch.int64, device=p.device)
+    with torch.cuda.device(p.device):
+        rc = _lib.lib().nbp_point_position_i64(p.data_ptr(), K, int(grid_size[0]), int(grid_size[1]),
+                                               float(grid_range[0]), float(grid_range[1]), out.data_ptr(),
+                                               _lib.current_stream())
+    _lib.check(rc, "nbp_point_position_i64")
+    return out.reshape((2,) + tuple(points_2d.shape[:-1])).squeeze()
+
+
+def transform_points_to_n_pieces(points, camera_pose, device=None, no_rotation=True):
+    """ref utils.py:166-196 -- world [N,3] -> agent-centred [1,N,2] = (-(z-cz), -(x-cx))."""
+    if not no_rotation:
+        raise NotImplementedError("the reference only ever calls this with no_rotation=True")
+    _need_cuda(points, "transform_points_to_n_pieces")
+    cx, cy, cz = _pose_xyz(camera_pose)
+    p = points.contiguous().float()
+    N = p.shape[0]
+    out = torch.empty(1, N, 2, dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        rc = _lib.lib().nbp_transform_points_f32(p.data_ptr(), N, cx, cy, cz, out.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "nbp_transform_points_f32")
+    return out
+
+
+def map_points_to_n_imgs(points_2d_batch, grid_size, grid_range, device=None):
+    """ref utils.py:198-223 -- [n,m,2] -> [n,S0,S1] fp32 point counts."""
+    _need_cuda(points_2d_batch, "map_points_to_n_imgs")
+    p = points_2d_batch.contiguous().float()
+    n, m, _ = p.shape
+    out = torch.empty((n, int(grid_size[0]), int(grid_size[1])), dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        rc = _lib.lib().nbp_map_points_to_imgs_f32(p.data_ptr(), n, m, int(grid_size[0]), int(grid_size[1]),
+                                                   float(grid_range[0]), float(grid_range[1]), out.data_ptr(),
+                                                   _lib.current_stream())
+    _lib.check(rc, "nbp_map_points_to_imgs_f32")
+    return out
+
+
+def accumulate_step_maps(full_pc, camera_pose, y_bins, grid_size=256, grid_range=(-40, 40), band=0.1):
+    """One fused pass replacing nbp_planning.py:114-127 + :172-183.
+
+    Returns [6,S,S]: four height slabs (torch.bucketize(p_y, y_bins[:-1]) - 1 semantics),
+    the points in no slab, and the +-`band` height band around the camera.
+    """
+    _need_cuda(full_pc, "accumulate_step_maps")
+    cx, cy, cz = _pose_xyz(camera_pose)
+    yb = [float(v) for v in (y_bins.tolist() if isinstance(y_bins, torch.Tensor) else y_bins)]
+    bounds = yb[:-1]
+    if len(bounds) > 8:
+        raise ValueError("at most 8 slab boundaries")
+    S = int(grid_size)
+    out = torch.empty(6, S, S, dtype=torch.float32, device=full_pc.device)
+    p = full_pc.contiguous().float()
+    arr = (C.c_float * max(len(bounds), 1))(*bounds)
+    # thresholds exactly as the reference forms them: python double +-0.1, then fp32 compare
+    band_hi = torch.tensor(cy + band, dtype=torch.float32).item()
+    band_lo = torch.tensor(cy - band, dtype=torch.float32).item()
+    with torch.cuda.device(p.device):
+        rc = _lib.lib().nbp_map_accumulate_f32(p.data_ptr(), p.shape[0], cx, cy, cz, arr, len(bounds), band_lo,
+                                               band_hi, S, float(grid_range[0]), float(grid_range[1]),
+                                               out.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "nbp_map_accumulate_f32")
+    return out

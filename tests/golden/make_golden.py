@@ -1,0 +1,192 @@
+"""Generates the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference; the GPU box has neither the
+reference nor this need -- it consumes the committed .npz files).  The reference is pure
+Python with heavy third-party imports that are absent here (pytorch3d, trimesh, torchvision,
+lmdb, ...): those are stubbed with MagicMock modules, which is enough because every function
+captured below is pure torch / pure Python arithmetic.  Nothing from the reference (source,
+bytecode) is written anywhere: the outputs are plain arrays.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+
+ABSENT = ("torchsummary", "trimesh", "lmdb", "msgpack_numpy", "torchvision", "pytorch3d", "plotly", "rtree")
+
+
+class _StubFinder:
+    """Serves a MagicMock-backed module for every import under an absent top-level package."""
+
+    @staticmethod
+    def find_spec(name, path=None, target=None):
+        import importlib.machinery
+        if name.split(".")[0] in ABSENT:
+            return importlib.machinery.ModuleSpec(name, _StubFinder, is_package=True)
+        return None
+
+    @staticmethod
+    def create_module(spec):
+        m = types.ModuleType(spec.name)
+        m.__getattr__ = lambda attr, _n=spec.name: MagicMock(name=f"{_n}.{attr}")   # type: ignore
+        m.__path__ = []
+        return m
+
+    @staticmethod
+    def exec_module(module):
+        pass
+
+
+def import_reference():
+    sys.meta_path.insert(0, _StubFinder)
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.path.insert(0, REF)
+    # entry-point import order (the reverse order hits the reference's import cycle)
+    import next_best_path.testers.nbp_planning as planning   # noqa: F401
+    import next_best_path.networks.nbp_model as model
+    import next_best_path.utility.utils as utils
+    import next_best_path.utility.long_term_utils as ltu
+    import macarons.utility.macarons_utils as mu
+    return model, utils, ltu, mu
+
+
+def gen_network(model):
+    from nextbestpath_amd.utility.synthetic import make_nbp_state_dict, make_count_maps
+    sd = make_nbp_state_dict(9)
+    net = model.NBP()
+    net.load_state_dict(sd, strict=True)          # also proves the 327 keys/shapes match
+    net.eval()
+    torch.set_num_threads(8)
+    # pin the weight generator itself
+    probe = {k: float(sd[k].double().sum()) for k in ["Conv1.conv.0.weight", "Conv5.conv.3.weight",
+                                                      "Att4_2.W_x.1.running_var", "Final1.weight"]}
+    for tag, B, S, seed in [("S32", 1, 32, 11), ("S64B2", 2, 64, 12), ("S128", 1, 128, 13)]:
+        x = make_count_maps(B, S, seed=seed)
+        with torch.no_grad():
+            o1, o2 = net(x)
+        np.savez_compressed(os.path.join(HERE, f"nbp_fwd_{tag}.npz"), x=x.numpy(), out1=o1.numpy(), out2=o2.numpy(),
+                            weight_seed=9, input_seed=seed,
+                            probe_keys=np.array(list(probe)), probe_sums=np.array(list(probe.values())))
+        print(tag, "out1", float(o1.abs().max()), "out2", float(o2.min()), float(o2.max()))
+
+
+def gen_maps(utils):
+    rng = np.random.default_rng(21)
+    dev = torch.device("cpu")
+    S = 256
+    pose = torch.tensor([3.25, 13.3, -7.5, 0.0, 90.0])
+    # random cloud + adversarial points: exact half-integer cells, the +-40 window edge
+    n = 20000
+    pts = rng.uniform(-60, 60, (n, 3)).astype(np.float32)
+    pts[:, 1] = rng.uniform(5, 35, n)
+    special = []
+    scale = np.float32(256 / 80)
+    for cell in [0.5, 1.5, 2.5, 127.5, 128.5, 254.5, 255.5, -0.5, 255.4999, 256.0, 255.0, 0.0]:
+        v = np.float32(cell) / scale - np.float32(40)        # v such that (v+40)*scale ~ cell
+        for dv in (0.0, 1e-6, -1e-6):
+            # v0 = -(z - cz)  =>  z = cz - v0
+            special.append([pose[0].item() - (v + dv), 13.3, pose[2].item() - (v + dv)])
+    pts = np.concatenate([pts, np.array(special, np.float32)], 0)
+    p = torch.from_numpy(pts)
+    t2d = utils.transform_points_to_n_pieces(p, pose, dev)
+    img = utils.map_points_to_n_imgs(t2d, (S, S), (-40, 40), dev)
+    pos256 = utils.get_point_position_in_the_img(t2d.squeeze(0)[:64], (S, S), (-40, 40))
+    pos64 = utils.get_point_position_in_the_img(t2d.squeeze(0)[:64], (64, 64), (-40, 40))
+    pos1 = utils.get_point_position_in_the_img(t2d.squeeze(0)[5:6].squeeze(0), (S, S), (-40, 40))
+    # slab split: the inline code of next_best_path/testers/nbp_planning.py:114-127,446-451
+    out = {}
+    for tag, (min_v, max_v) in {"nominal": (4.2, 36.1), "six_bins": (0.0, 30.0)}.items():
+        n_pieces = 4
+        min_y, max_y = min_v + 0.5, max_v - 0.5
+        bin_width = (max_y - min_y) / n_pieces
+        y_bins = torch.arange(min_y, max_y + bin_width, bin_width)
+        bins = torch.bucketize(p[:, 1], y_bins[:-1]) - 1
+        imgs = []
+        for i in range(n_pieces):
+            g = p[bins == i]
+            if len(g) > 0:
+                imgs.append(utils.map_points_to_n_imgs(utils.transform_points_to_n_pieces(g, pose, dev), (S, S),
+                                                       (-40, 40), dev))
+            else:
+                imgs.append(torch.zeros(1, S, S))
+        out[f"ybins_{tag}"] = y_bins.numpy()
+        out[f"slabs_{tag}"] = torch.cat(imgs, 0).numpy().astype(np.uint16)
+    # height band (nbp_planning.py:178-183)
+    cy = pose[1].item()
+    m = (p[:, 1] < cy + 0.1) & (p[:, 1] > cy - 0.1)
+    band = utils.map_points_to_n_imgs(utils.transform_points_to_n_pieces(p[m], pose, dev), (S, S), (-40, 40), dev)
+    # batched form n=2
+    t2 = torch.stack([t2d[0, :5000], t2d[0, 5000:10000]])
+    img2 = utils.map_points_to_n_imgs(t2, (128, 128), (-40, 40), dev)
+    np.savez_compressed(os.path.join(HERE, "maps.npz"), points=pts, pose=pose.numpy(), t2d=t2d.numpy(),
+                        img=img.numpy().astype(np.uint16), pos256=pos256.numpy(), pos64=pos64.numpy(),
+                        pos1=pos1.numpy(), band=band.numpy().astype(np.uint16),
+                        img2=img2.numpy().astype(np.uint16), **out)
+    print("maps: total count", float(img.sum()), "six-bin len", len(out["ybins_six_bins"]))
+
+
+def gen_planner(ltu, mu):
+    rng = np.random.default_rng(31)
+    # Bresenham truth table (long_term_utils.py:277-298)
+    ends = rng.integers(0, 64, (200, 4))
+    ends[:8] = [[0, 0, 0, 0], [0, 0, 5, 0], [0, 0, 0, 5], [5, 5, 0, 0], [3, 7, 9, 2], [63, 0, 0, 63], [10, 10, 11, 40],
+                [40, 11, 10, 10]]
+    lines, lens = [], []
+    for x0, y0, x1, y1 in ends.tolist():
+        pts = ltu.bresenham_line(x0, y0, x1, y1)
+        lens.append(len(pts))
+        lines.extend(pts)
+    # edge test (long_term_utils.py:300-331) on a random obstacle layout
+    S = 256
+    layout = (torch.from_numpy(rng.random((1, 1, S, S))) < 0.08).float()
+    pose = torch.tensor([1.0, 13.3, -2.0, 0.0, 0.0])
+    p1 = torch.from_numpy(rng.uniform(-45, 45, (300, 3)).astype(np.float32))
+    step = torch.from_numpy(rng.choice([-3.0, 0.0, 3.0], (300, 3)).astype(np.float32))
+    step[:, 1] = 0
+    p2 = p1 + step
+    blocked = [bool(ltu.line_across_image_pixel(p1[i], p2[i], pose, (S, S), (-40, 40), layout, torch.device("cpu")))
+               for i in range(300)]
+    # check_pixel_values (macarons_utils.py:86-100)
+    proj = torch.from_numpy(rng.poisson(0.002, (1, 1, S, S)).astype(np.float32))
+    proj[proj > 1] = 1
+    cells = rng.integers(0, S, (200, 2))
+    cpv = [bool(mu.check_pixel_values(proj, torch.tensor(c))) for c in cells.tolist()]
+    # coverage (long_term_utils.py:437-468)
+    gt = torch.from_numpy(rng.uniform(-20, 20, (1500, 3)).astype(np.float32))
+    pc = torch.from_numpy(rng.uniform(-20, 20, (9000, 3)).astype(np.float32))
+    pc[:, 1] *= 0.3
+    torch.manual_seed(5)
+    cov = ltu.calculate_coverage_percentage(gt, pc)
+    torch.manual_seed(5)
+    perm = torch.randperm(pc.shape[0])[:int(len(gt) * 2)]
+    cov_small = ltu.calculate_coverage_percentage(gt, pc[:1000])      # no subsampling branch
+    cov_empty = ltu.calculate_coverage_percentage(gt, pc[:0])
+    auc = ltu.compute_auc(np.linspace(0, 0.8, 101))
+    np.savez_compressed(os.path.join(HERE, "planner.npz"), ends=ends, line_pts=np.array(lines), line_lens=np.array(lens),
+                        layout=layout.numpy().astype(np.uint8), edge_pose=pose.numpy(), edge_p1=p1.numpy(),
+                        edge_p2=p2.numpy(), edge_blocked=np.array(blocked), proj=proj.numpy().astype(np.uint8),
+                        cpv_cells=cells, cpv=np.array(cpv), cov_gt=gt.numpy(), cov_pc=pc.numpy(),
+                        cov_perm=perm.numpy(), cov=cov, cov_small=cov_small, cov_empty=cov_empty, auc=auc)
+    print("planner: blocked", sum(blocked), "/300  cpv", sum(cpv), "/200  cov", cov, cov_small, cov_empty)
+
+
+if __name__ == "__main__":
+    model, utils, ltu, mu = import_reference()
+    gen_maps(utils)
+    gen_planner(ltu, mu)
+    gen_network(model)

@@ -1,0 +1,43 @@
+"""ctypes call helpers for the GPU parity tests (thin: pointers + sizes only)."""
+import torch
+
+from nextbestpath_amd import _lib
+
+
+def stream():
+    return _lib.current_stream()
+
+
+def pack_conv(w_oihw, scale=None, c_off=0, c_total=None, dst=None):
+    L = _lib.lib()
+    N, C, k, _ = w_oihw.shape
+    c_total = c_total or C
+    if dst is None:
+        dst = torch.zeros(c_total // 32 * k * k * N * 32, dtype=torch.float32, device=w_oihw.device)
+    rc = L.nbp_pack_conv_weight(_lib.ptr(w_oihw), N, C, k, _lib.ptr(scale), c_off, c_total, _lib.ptr(dst), stream())
+    _lib.check(rc, "pack")
+    return dst
+
+
+def conv_igemm(src0, src1, ups, wpk, N, ksize, scale, shift, relu, split_k=0, tile=0):
+    """src*: NHWC cuda tensors [B,Hs,Ws,C]; returns NHWC [B,H,W,N]."""
+    L = _lib.lib()
+    B, Hs, Ws, C0 = src0.shape
+    H, W = (Hs * 2, Ws * 2) if ups else (Hs, Ws)
+    C1 = 0 if src1 is None else src1.shape[3]
+    out = torch.empty(B, H, W, N, dtype=torch.float32, device=src0.device)
+    nws = L.nbp_conv_igemm_workspace_bytes(B, H, W, N, split_k)
+    ws = torch.empty(max(nws, 256), dtype=torch.uint8, device=src0.device)
+    rc = L.nbp_conv_igemm_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, ksize, _lib.ptr(wpk), N,
+                              _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), split_k, tile,
+                              _lib.ptr(ws), ws.numel(), stream())
+    _lib.check(rc, "conv_igemm")
+    return out
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
