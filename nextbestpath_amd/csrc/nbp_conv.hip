@@ -37,6 +37,7 @@ struct IgemmArgs {
     int split_k;
     int chunks_total;
     int chunks_per_split;
+    unsigned bytes0, bytes1;   // byte sizes of src0 / src1 (buffer-descriptor range, < 2 GiB)
 };
 
 template <int WM, int WN, int TM, int TN>
@@ -78,24 +79,33 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
         wsw[i] = r * 32 + ((slot ^ ((r >> 1) & 7)) << 2);
     }
 
+    // Activation gather through buffer descriptors: out-of-image taps (zero padding) and rows
+    // past M get voffset = OOB, which the hardware range check turns into zeros -- the eight
+    // loads of a chunk issue back to back with no exec-mask branches.
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1 ? a.src1 : a.src0), 0, a.bytes1, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
     f32x4 ga[RA], gb[RB];
     auto load_global = [&](int c) {
         const int cc = c / a.taps;
         const int tap = c - cc * a.taps;
         int dy = 0, dx = 0;
         if (a.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
-        const float* src; int Cs, coff;
-        if (cc < a.cc0) { src = a.src0; Cs = a.C0; coff = cc * 32; }
-        else { src = a.src1; Cs = a.C1; coff = (cc - a.cc0) * 32; }
+        const bool first = cc < a.cc0;
+        const int Cs = first ? a.C0 : a.C1;
+        const int coff = (first ? cc : cc - a.cc0) * 32 + slot * 4;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            int yy = py[i] + dy, xx = px[i] + dx;
-            bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-            int sy = yy >> a.ups, sx = xx >> a.ups;
-            long long off = ((long long)(pb[i] + sy * a.Ws + sx)) * Cs + coff + slot * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(src + off);
-            ga[i] = v;
+            const int yy = py[i] + dy, xx = px[i] + dx;
+            const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            const int pix = pb[i] + (yy >> a.ups) * a.Ws + (xx >> a.ups);
+            const unsigned off = ok ? (unsigned)(pix * Cs + coff) * 4u : OOB;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 r = first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0)
+                            : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0);
+            ga[i] = __builtin_bit_cast(f32x4, r);
         }
         const float* wb = a.wpk + ((long long)c * a.N + n0 + lrow) * 32 + slot * 4;
 #pragma unroll
@@ -288,6 +298,11 @@ int nbp_conv_igemm_launch(const float* src0, int C0, const float* src1, int C1, 
     a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W;
     a.taps = ksize * ksize; a.wpk = wpk; a.N = N; a.scale = scale; a.shift = shift; a.relu = relu;
     a.M = (long long)B * H * W;
+    {
+        const long long b0 = (long long)B * a.Hs * a.Ws * C0 * 4, b1 = (long long)B * a.Hs * a.Ws * C1 * 4;
+        NBP_RETURN_IF(b0 >= (1ll << 31) || b1 >= (1ll << 31), NBP_E_SHAPE);   // 32-bit buffer offsets
+        a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0;
+    }
     a.chunks_total = (C0 + C1) / 32 * a.taps;
     ConvPlan p = nbp_plan_conv(a.M, N, a.chunks_total, tile, split_k);
     TileInfo ti = tile_info(p.tile);

@@ -50,9 +50,11 @@ def test_conv_igemm_vs_torch(hip, case):
     if ups:
         xin = F.interpolate(xin, scale_factor=2)
     ref = F.relu(F.conv2d(xin, w, None, padding=k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
-    wpk = pack_conv(w.to(dev).contiguous())
-    out = conv_igemm(nhwc(x0).to(dev), None if x1 is None else nhwc(x1).to(dev), ups, wpk, N, k, scale.to(dev),
-                     shift.to(dev), True, split_k, tile)
+    wd = w.to(dev).contiguous()
+    wpk = pack_conv(wd)
+    x0d, x1d = nhwc(x0).to(dev), None if x1 is None else nhwc(x1).to(dev)
+    scd, shd = scale.to(dev), shift.to(dev)
+    out = conv_igemm(x0d, x1d, ups, wpk, N, k, scd, shd, True, split_k, tile)
     got = nchw(out).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < TOL
@@ -61,6 +63,7 @@ def test_conv_igemm_vs_torch(hip, case):
 def test_small_layers_vs_torch(hip):
     dev = "cuda"
     L = hip
+    d = lambda t: t.to(dev).contiguous()          # keep device copies alive until the sync below
     # Conv1.conv.0: NCHW in, NHWC out
     B, H, W = 2, 20, 12
     x = torch.floor(_rand(B, 5, H, W, seed=1).abs() * 4)
@@ -68,13 +71,15 @@ def test_small_layers_vs_torch(hip):
     sc, sh = _rand(64, seed=3) * 0.2 + 1, _rand(64, seed=4) * 0.1
     ref = F.relu(F.conv2d(x, w, None, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
     out = torch.empty(B, H, W, 64, device=dev)
-    _lib.check(L.nbp_conv_first_f32(_lib.ptr(x.to(dev)), B, H, W, _lib.ptr(w.to(dev)), _lib.ptr(sc.to(dev)),
-                                    _lib.ptr(sh.to(dev)), _lib.ptr(out), stream()), "first")
+    xd, wd, scd, shd = d(x), d(w), d(sc), d(sh)
+    _lib.check(L.nbp_conv_first_f32(_lib.ptr(xd), B, H, W, _lib.ptr(wd), _lib.ptr(scd), _lib.ptr(shd),
+                                    _lib.ptr(out), stream()), "first")
     assert (nchw(out).cpu() - ref).abs().max() < TOL
     # maxpool
     a = _rand(2, 64, 8, 12, seed=5)
+    ad = d(nhwc(a))
     o = torch.empty(2, 4, 6, 64, device=dev)
-    _lib.check(L.nbp_maxpool2_nhwc_f32(_lib.ptr(nhwc(a).to(dev)), 2, 8, 12, 64, _lib.ptr(o), stream()), "pool")
+    _lib.check(L.nbp_maxpool2_nhwc_f32(_lib.ptr(ad), 2, 8, 12, 64, _lib.ptr(o), stream()), "pool")
     assert torch.equal(nchw(o).cpu(), F.max_pool2d(a, 2, 2))
     # psi gate
     M, Fq, C = 37, 32, 64
@@ -82,23 +87,25 @@ def test_small_layers_vs_torch(hip):
     st = torch.tensor([0.9, -0.2])
     ref = xs * torch.sigmoid((q @ wp) * st[0] + st[1]).unsqueeze(1)
     o = torch.empty(M, C, device=dev)
-    _lib.check(L.nbp_psi_gate_f32(_lib.ptr(q.to(dev)), Fq, _lib.ptr(wp.to(dev)), _lib.ptr(st.to(dev)),
-                                  _lib.ptr(xs.to(dev)), C, M, _lib.ptr(o), stream()), "gate")
+    qd, wpd, std, xsd = d(q), d(wp), d(st), d(xs)
+    _lib.check(L.nbp_psi_gate_f32(_lib.ptr(qd), Fq, _lib.ptr(wpd), _lib.ptr(std), _lib.ptr(xsd), C, M, _lib.ptr(o),
+                                  stream()), "gate")
     assert (o.cpu() - ref).abs().max() < 1e-5
     # final 1x1 (8 outputs linear; 1 output sigmoid)
     a = _rand(2, 256, 6, 5, seed=9)
+    ad = d(nhwc(a))
     for n_out, sig in ((8, 0), (1, 1)):
         w = _rand(n_out, 256, 1, 1, seed=10, scale=0.1)
         b = _rand(n_out, seed=11)
         ref = F.conv2d(a, w, b)
         ref = torch.sigmoid(ref) if sig else ref
         o = torch.empty(2, n_out, 6, 5, device=dev)
-        ones = torch.ones(n_out, device=dev)
-        _lib.check(L.nbp_final_1x1_f32(_lib.ptr(nhwc(a).to(dev)), 2, 6, 5, 256, _lib.ptr(w.to(dev).contiguous()), n_out,
-                                       _lib.ptr(ones), _lib.ptr(b.to(dev)), sig, _lib.ptr(o), stream()), "final")
+        ones, wd, bd = torch.ones(n_out, device=dev), d(w), d(b)
+        _lib.check(L.nbp_final_1x1_f32(_lib.ptr(ad), 2, 6, 5, 256, _lib.ptr(wd), n_out, _lib.ptr(ones), _lib.ptr(bd),
+                                       sig, _lib.ptr(o), stream()), "final")
         assert (o.cpu() - ref).abs().max() < 1e-5
     # layout helpers round trip
-    t = _rand(2, 7, 5, 3, seed=12).to(dev)
+    t = d(_rand(2, 7, 5, 3, seed=12))
     o = torch.empty(2, 5, 3, 7, device=dev)
     _lib.check(L.nbp_nchw_to_nhwc_f32(_lib.ptr(t), 2, 7, 5, 3, _lib.ptr(o), stream()), "to_nhwc")
     assert torch.equal(o, t.permute(0, 2, 3, 1).contiguous())
