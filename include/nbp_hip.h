@@ -157,10 +157,81 @@ int nbp_point_position_i64(const float* pts2d, long long K, int S0, int S1, floa
  *            counted iff 0 <= bin < 4 (n_bounds is len(y_bins)-1, normally 4, at most 8)
  *   ch 4     points that fall in no slab (so that ch0+..+ch4 = projection of ALL points)
  *   ch 5     points with  band_lo < p.y < band_hi   (the reference's +-0.1 height band)
- */
-int nbp_map_accumulate_f32(const float* points, long long N, float cx, float cy, float cz,
-                           const float* bounds_host, int n_bounds, float band_lo, float band_hi,
-                           int S, float lo, float hi, float* out6, void* stream);
+ * N_dev_or_null: when non-null the point count is read from device memory (the rollout keeps the
+ * cloud size on the device so the step loop never synchronises) and N is only an upper bound. */
+int nbp_map_accumulate_f32(const float* points, long long N, const long long* N_dev_or_null, float cx,
+                           float cy, float cz, const float* bounds_host, int n_bounds, float band_lo,
+                           float band_hi, int S, float lo, float hi, float* out6, void* stream);
+
+/* ================================================================ A14-A17: simulator
+ * PyTorch3D / trimesh conventions restated (third-party; parity with the libraries unpinned):
+ * cameras are [n][12] fp32 = R row-major (9) then T (3) with X_view = X_world R + T.         */
+
+/* Camera.compute_partial_point_cloud (macarons/utility/macarons_utils.py:2811-2847) for n_frames
+ * depth maps at once, appended to a device-resident cloud:
+ *   valid  = (mask ? mask != 0 : depth > -1) && depth < fov_range            (mu:2825-2828)
+ *   n_keep = int(n_valid * gathering_factor)                                  (mu:2836)
+ *   kept   = the first n_keep entries of a seeded pseudo-random permutation of the valid pixels
+ *            (stands in for torch.randperm, mu:2837; see perm_index in csrc/common.h)
+ *   point  = un-projection of (ndc_x(col), ndc_y(row), depth) through the FoV camera (mu:2788-2809)
+ * counts2[f] = {n_valid, n_keep}; points land at cloud[*cloud_count + sum_{g<f} n_keep_g + j];
+ * *cloud_count is advanced on the device (clamped to capacity). */
+size_t nbp_unproject_workspace_bytes(int n_frames, int H, int W);
+int nbp_unproject_append_f32(const float* depth, const unsigned char* mask_or_null, const float* cams12,
+                             int n_frames, int H, int W, float tan_half_fov, float fov_range,
+                             double gathering_factor, unsigned seed, int* counts2, float* cloud,
+                             long long* cloud_count, long long capacity, void* ws, size_t ws_bytes,
+                             void* stream);
+
+/* Camera.capture_image's depth output (mu:2743-2786): zbuf [n_frames,H,W] = view-space z of the
+ * nearest face through each pixel centre (perspective-correct, faces clipped at z_clip), -1 where
+ * no face.  Faces are binned into 8x8-pixel tiles with at most bin_cap faces per tile;
+ * *overflow_flag (device int, caller zeroes it) is set if a tile overflowed. */
+size_t nbp_raster_workspace_bytes(int n_faces, int n_frames, int H, int W, int bin_cap);
+int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* faces, int n_faces,
+                        const float* cams12, int n_frames, int H, int W, float tan_half_fov,
+                        float z_clip, int bin_cap, float* zbuf, int* overflow_flag, void* ws,
+                        size_t ws_bytes, void* stream);
+
+/* line_segment_mesh_intersection (mu:120-151): hit[e] = 1 iff the ray from segs6[e][0:3] towards
+ * segs6[e][3:6] meets a triangle at distance < |segment|. */
+int nbp_segments_hit_mesh_f32(const float* verts, const int* faces, int n_faces, const float* segs6,
+                              int n_segs, int* hit, void* stream);
+/* check_camera_in_mesh (next_best_path/utility/long_term_utils.py:158-170): counts3[k] = number
+ * of triangles hit from pts3[k] along +Y, +X, +Z (inside iff all three are odd). */
+int nbp_axis_ray_counts_f32(const float* verts, const int* faces, int n_faces, const float* pts3,
+                            int n_pts, int* counts3, void* stream);
+/* Host mirror of the sampling bijection (driver / tests). */
+unsigned nbp_perm_index_host(unsigned j, unsigned n, unsigned seed);
+
+/* ================================================================ A8-A12: planner
+ * Obstacle fusion (next_best_path/testers/nbp_planning.py:166-191): obst = out2 >= threshold;
+ * where the projection of the whole cloud (maps6 ch0..4 summed) is non-empty take (ch5 > 0);
+ * zero where traj > 0.  fullproj = min(sum, 1)  (:172-175). */
+int nbp_fuse_obstacle_f32(const float* out2, const float* maps6, const float* traj, float threshold,
+                          int S, float* obst, float* fullproj, void* stream);
+/* Candidate scoring (nbp_planning.py:203-231 + macarons_utils.py:86-100) for P lattice positions:
+ * valid[i] iff the V-grid cell is inside and the 21x21 window of fullproj around the S-grid cell
+ * contains a pixel == 1; cell2[i] = V-grid cell; score[i] = max_c out1[c,cell] - 10*fullproj[S cell]
+ * in float64 (Python float arithmetic of the reference). */
+int nbp_score_candidates_f32(const float* pos3, int P, float cx, float cz, const float* out1, int V,
+                             const float* fullproj, int S, float lo, float hi,
+                             const unsigned char* skip_or_null, unsigned char* valid, int* cell2,
+                             double* score, void* stream);
+/* line_across_image_pixel (long_term_utils.py:300-331) for E lattice edges in one launch:
+ * blocked iff an endpoint maps outside the S x S image or >= 2 Bresenham pixels equal 1. */
+int nbp_edges_blocked_u8(const float* obst, int S, float lo, float hi, float cx, float cz,
+                         const float* pos3, const int* edges2, int E, unsigned char* blocked,
+                         void* stream);
+/* calculate_coverage_percentage (long_term_utils.py:437-468): *count_out = #{g : min_j |gt_g - s_j|
+ * < threshold} where s = the cloud, or a seeded random subset of sample_k points of it when it
+ * has more (random_sample_pc, :437-447); *m_out = number of points used.  bbox_* = bounds of gt. */
+size_t nbp_coverage_workspace_bytes(const float* bbox_lo_host, const float* bbox_hi_host,
+                                    float threshold, long long sample_k);
+int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3, long long N,
+                           const long long* N_dev_or_null, long long sample_k, unsigned seed,
+                           float threshold, const float* bbox_lo_host, const float* bbox_hi_host,
+                           int* count_out, int* m_out, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

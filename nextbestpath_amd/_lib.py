@@ -38,7 +38,21 @@ SIGNATURES = {
     "nbp_transform_points_f32": (_i, [_vp, _ll, _f, _f, _f, _vp, _vp]),
     "nbp_map_points_to_imgs_f32": (_i, [_vp, _i, _ll, _i, _i, _f, _f, _vp, _vp]),
     "nbp_point_position_i64": (_i, [_vp, _ll, _i, _i, _f, _f, _vp, _vp]),
-    "nbp_map_accumulate_f32": (_i, [_vp, _ll, _f, _f, _f, C.POINTER(_f), _i, _f, _f, _i, _f, _f, _vp, _vp]),
+    "nbp_map_accumulate_f32": (_i, [_vp, _ll, _vp, _f, _f, _f, C.POINTER(_f), _i, _f, _f, _i, _f, _f, _vp, _vp]),
+    "nbp_unproject_workspace_bytes": (_sz, [_i, _i, _i]),
+    "nbp_unproject_append_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _d, C.c_uint, _vp, _vp, _vp, _ll, _vp, _sz,
+                                      _vp]),
+    "nbp_raster_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "nbp_raster_zbuf_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _sz, _vp]),
+    "nbp_segments_hit_mesh_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "nbp_axis_ray_counts_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "nbp_perm_index_host": (C.c_uint, [C.c_uint, C.c_uint, C.c_uint]),
+    "nbp_fuse_obstacle_f32": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "nbp_score_candidates_f32": (_i, [_vp, _i, _f, _f, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "nbp_edges_blocked_u8": (_i, [_vp, _i, _f, _f, _f, _f, _vp, _vp, _i, _vp, _vp]),
+    "nbp_coverage_workspace_bytes": (_sz, [C.POINTER(_f), C.POINTER(_f), _f, _ll]),
+    "nbp_coverage_count_f32": (_i, [_vp, _i, _vp, _ll, _vp, _ll, C.c_uint, _f, C.POINTER(_f), C.POINTER(_f), _vp, _vp,
+                                    _vp, _sz, _vp]),
 }
 
 

@@ -28,3 +28,28 @@ static inline int nbp_ew_grid(long long work_items, int block) {
     if (g > 256 * 8) g = 256 * 8;
     return (int)g;
 }
+
+// ------------------------------------------------------------------ index bijection
+// perm_index(j) for j in [0,n) enumerates [0,n) in a pseudo-random order: a bijection on
+// b-bit integers (multiply by an odd constant, add, xor-shift; 3 rounds) cycle-walked into
+// [0,n).  "The first k of a random permutation" = {perm_index(j) : j < k}: an exact-size
+// random subset without a sort (stands in for torch.randperm(n)[:k] of the reference).
+// oracle/sampling.py restates it bit for bit.
+__host__ __device__ inline unsigned perm_bits(unsigned n) {
+    unsigned b = 2;
+    while (b < 32 && (1ull << b) < (unsigned long long)n) ++b;
+    return b;
+}
+__host__ __device__ inline unsigned perm_index(unsigned j, unsigned n, unsigned b, unsigned seed) {
+    const unsigned mask = b >= 32 ? 0xffffffffu : ((1u << b) - 1u);
+    const unsigned sh = (b + 1) >> 1;
+    unsigned v = j;
+    do {
+#pragma unroll
+        for (unsigned r = 0; r < 3; ++r) {
+            v = (v * 0x9E3779B1u + seed + r * 0x7F4A7C15u) & mask;
+            v ^= v >> sh;
+        }
+    } while (v >= n);
+    return v;
+}

@@ -75,10 +75,13 @@ __device__ __forceinline__ void accumulate_point(float x, float y, float z, floa
 // 4 points (48 contiguous bytes = three 16-byte loads) per thread per iteration.  `head`
 // (< 4) leading points bring the pointer to 16-byte alignment; they and the N % 4 tail are
 // handled by the first threads of block 0.
-__global__ __launch_bounds__(256) void map_accumulate_kernel(const float* __restrict__ p, long long N, int head,
+__global__ __launch_bounds__(256) void map_accumulate_kernel(const float* __restrict__ p, long long N,
+                                                             const long long* __restrict__ n_dev, int head,
                                                              float cx, float cz, Bounds bd, float band_lo,
                                                              float band_hi, int S, float lo, float sc,
                                                              float* __restrict__ out) {
+    if (n_dev) N = *n_dev;                       // cloud size lives on the device (no host sync per step)
+    if (head > N) head = (int)N;
     const long long groups = (N - head) >> 2;
     const f32x4* p4 = reinterpret_cast<const f32x4*>(p + 3 * head);
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < groups;
@@ -134,8 +137,8 @@ extern "C" int nbp_point_position_i64(const float* pts2d, long long K, int S0, i
     return nbp_launch_status();
 }
 
-extern "C" int nbp_map_accumulate_f32(const float* points, long long N, float cx, float cy, float cz,
-                                      const float* bounds_host, int n_bounds, float band_lo, float band_hi, int S,
+extern "C" int nbp_map_accumulate_f32(const float* points, long long N, const long long* N_dev_or_null, float cx,
+                                      float cy, float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi, int S,
                                       float lo, float hi, float* out6, void* stream) {
     (void)cy;
     NBP_RETURN_IF(!out6 || N < 0 || S < 1 || !(hi > lo), NBP_E_ARG);
@@ -148,11 +151,10 @@ extern "C" int nbp_map_accumulate_f32(const float* points, long long N, float cx
     NBP_RETURN_IF(((uintptr_t)points & 3) != 0, NBP_E_ARG);
     int head = 0;
     while ((((uintptr_t)points + 12u * head) & 15) != 0) ++head;   // 12k mod 16 cycles 0,12,8,4: head <= 3
-    if (head > N) head = (int)N;
     Bounds bd;
     for (int k = 0; k < 8; ++k) bd.b[k] = k < n_bounds ? bounds_host[k] : 0.f;
     bd.n = n_bounds;
-    map_accumulate_kernel<<<nbp_ew_grid(nbp_cdiv(N, 4), 256), 256, 0, st>>>(points, N, head, cx, cz, bd, band_lo, band_hi, S,
+    map_accumulate_kernel<<<nbp_ew_grid(nbp_cdiv(N, 4), 256), 256, 0, st>>>(points, N, N_dev_or_null, head, cx, cz, bd, band_lo, band_hi, S,
                                                                             lo, grid_scale(S, lo, hi), out6);
     return nbp_launch_status();
 }

@@ -1,0 +1,222 @@
+// nbp_planner.hip -- planner-side kernels: obstacle-map fusion, batched candidate scoring,
+// all-edges Bresenham passability, coverage metric (hash grid).
+//
+// Replaces the per-item Python loops (one .item() device sync per pixel / per lattice pose) of
+//   * next_best_path/testers/nbp_planning.py:166-194 (obstacle fusion), :203-231 (scoring) with
+//     macarons/utility/macarons_utils.py:86-100 (check_pixel_values);
+//   * next_best_path/utility/long_term_utils.py:277-331 (bresenham_line, line_across_image_pixel);
+//   * next_best_path/utility/long_term_utils.py:437-468 (calculate_coverage_percentage: torch.cdist
+//     G x 2G + row-min) -- here a uniform grid with cell = threshold, 27-cell neighbourhood,
+//     direct-difference distances (no G x M matrix).
+// Integer results (cells, masks, counts) are bit-exact against oracle/planner.py.
+#include "common.h"
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ long long cell_index(float v, float lo, float sc) { return (long long)rintf((v - lo) * sc); }
+inline float grid_scale(int S, float lo, float hi) { return (float)((double)S / ((double)hi - (double)lo)); }
+
+// obst = (out2 >= thr); where the full projection is non empty take the height-band projection > 0;
+// zero along the trajectory.  fullproj = min(sum of the 5 cloud channels, 1).
+__global__ __launch_bounds__(256) void fuse_obstacle_kernel(const float* __restrict__ out2, const float* __restrict__ maps6,
+                                                            const float* __restrict__ traj, float thr, int SS,
+                                                            float* __restrict__ obst, float* __restrict__ fullproj) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < SS; i += gridDim.x * blockDim.x) {
+        const float full = (((maps6[i] + maps6[SS + i]) + maps6[2 * SS + i]) + maps6[3 * SS + i]) + maps6[4 * SS + i];
+        float o = out2[i] >= thr ? 1.f : 0.f;
+        if (full > 0.f) o = maps6[5 * SS + i] > 0.f ? 1.f : 0.f;
+        if (traj[i] > 0.f) o = 0.f;
+        obst[i] = o;
+        fullproj[i] = full > 1.f ? 1.f : full;
+    }
+}
+
+__global__ __launch_bounds__(256) void score_candidates_kernel(const float* __restrict__ pos, int P, float cx, float cz,
+                                                               const float* __restrict__ out1, int V,
+                                                               const float* __restrict__ fullproj, int S, float lo,
+                                                               float scV, float scS, const unsigned char* __restrict__ skip,
+                                                               unsigned char* __restrict__ valid, int* __restrict__ cell,
+                                                               double* __restrict__ score) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    valid[i] = 0; cell[2 * i] = 0; cell[2 * i + 1] = 0; score[i] = 0.0;
+    if (skip && skip[i]) return;
+    const float v0 = -(pos[3 * i + 2] - cz), v1 = -(pos[3 * i] - cx);
+    const long long g0 = cell_index(v0, lo, scV), g1 = cell_index(v1, lo, scV);
+    if (g0 < 0 || g0 >= V || g1 < 0 || g1 >= V) return;
+    float best = out1[g0 * V + g1];
+    for (int c = 1; c < 8; ++c) best = fmaxf(best, out1[(size_t)c * V * V + g0 * V + g1]);
+    const long long s0 = cell_index(v0, lo, scS), s1 = cell_index(v1, lo, scS);
+    // torch indexing semantics: a negative index wraps once (the reference does not bounds check)
+    const long long w0 = s0 < 0 ? s0 + S : s0, w1 = s1 < 0 ? s1 + S : s1;
+    if (w0 < 0 || w0 >= S || w1 < 0 || w1 >= S) return;
+    const float dens = fullproj[w0 * S + w1];
+    // check_pixel_values: any pixel == 1 in rows [max(s0-10,0), min(s0+11,S)) x cols likewise (unwrapped index)
+    const long long r0 = s0 - 10 > 0 ? s0 - 10 : 0, r1 = s0 + 11 < S ? s0 + 11 : S;
+    const long long c0 = s1 - 10 > 0 ? s1 - 10 : 0, c1 = s1 + 11 < S ? s1 + 11 : S;
+    bool any1 = false;
+    for (long long r = r0; r < r1 && !any1; ++r)
+        for (long long c = c0; c < c1; ++c)
+            if (fullproj[r * S + c] == 1.f) { any1 = true; break; }
+    if (!any1) return;
+    valid[i] = 1; cell[2 * i] = (int)g0; cell[2 * i + 1] = (int)g1;
+    score[i] = (double)best - 10.0 * (double)dens;
+}
+
+__global__ __launch_bounds__(256) void edges_blocked_kernel(const float* __restrict__ obst, int S, float lo, float sc,
+                                                            float cx, float cz, const float* __restrict__ pos,
+                                                            const int* __restrict__ edges, int E,
+                                                            unsigned char* __restrict__ blocked) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const float* a = pos + 3 * (size_t)edges[2 * e];
+    const float* b = pos + 3 * (size_t)edges[2 * e + 1];
+    long long x0 = cell_index(-(a[2] - cz), lo, sc), y0 = cell_index(-(a[0] - cx), lo, sc);
+    const long long x1 = cell_index(-(b[2] - cz), lo, sc), y1 = cell_index(-(b[0] - cx), lo, sc);
+    if (x0 < 0 || x0 >= S || y0 < 0 || y0 >= S || x1 < 0 || x1 >= S || y1 < 0 || y1 >= S) { blocked[e] = 1; return; }
+    const long long dx = x1 > x0 ? x1 - x0 : x0 - x1, dy = y1 > y0 ? y1 - y0 : y0 - y1;
+    const long long sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+    long long err = dx - dy;
+    int hits = 0;
+    for (int guard = 0; guard < 4 * S; ++guard) {
+        if (obst[x0 * S + y0] == 1.f) ++hits;
+        if (x0 == x1 && y0 == y1) break;
+        const long long e2 = 2 * err;
+        if (e2 > -dy) { err -= dy; x0 += sx; }
+        if (e2 < dx) { err += dx; y0 += sy; }
+    }
+    blocked[e] = hits >= 2 ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ coverage
+
+struct Grid { float lo[3]; float inv; int n[3]; };
+
+__device__ __forceinline__ int grid_cell(const Grid& g, float x, float y, float z, int* ijk) {
+    int i = (int)floorf((x - g.lo[0]) * g.inv), j = (int)floorf((y - g.lo[1]) * g.inv), k = (int)floorf((z - g.lo[2]) * g.inv);
+    i = min(max(i, 0), g.n[0] - 1); j = min(max(j, 0), g.n[1] - 1); k = min(max(k, 0), g.n[2] - 1);
+    if (ijk) { ijk[0] = i; ijk[1] = j; ijk[2] = k; }
+    return (i * g.n[1] + j) * g.n[2] + k;
+}
+
+// sample (first k of the index bijection when N > k, else everything) + insert into per-cell lists
+__global__ __launch_bounds__(256) void coverage_insert_kernel(const float* __restrict__ pc, const long long* __restrict__ n_dev,
+                                                              long long n_host, long long k, unsigned seed, Grid g,
+                                                              float* __restrict__ sp, int* __restrict__ head,
+                                                              int* __restrict__ next, int* __restrict__ m_out) {
+    const long long N = n_dev ? *n_dev : n_host;
+    const long long M = N > k ? k : N;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *m_out = (int)M;
+    const unsigned bits = perm_bits((unsigned)N);
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (long long)gridDim.x * blockDim.x) {
+        const long long src = N > k ? (long long)perm_index((unsigned)j, (unsigned)N, bits, seed) : j;
+        const float x = pc[3 * src], y = pc[3 * src + 1], z = pc[3 * src + 2];
+        sp[3 * j] = x; sp[3 * j + 1] = y; sp[3 * j + 2] = z;
+        const int c = grid_cell(g, x, y, z, nullptr);
+        next[j] = atomicExch(&head[c], (int)j);
+    }
+}
+
+__global__ __launch_bounds__(256) void coverage_query_kernel(const float* __restrict__ gt, int G, Grid g, float thr,
+                                                             const float* __restrict__ sp, const int* __restrict__ head,
+                                                             const int* __restrict__ next, int* __restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool found = false;
+    if (i < G) {
+        const float x = gt[3 * i], y = gt[3 * i + 1], z = gt[3 * i + 2];
+        int c[3];
+        grid_cell(g, x, y, z, c);
+        for (int a = max(c[0] - 1, 0); a <= min(c[0] + 1, g.n[0] - 1) && !found; ++a)
+            for (int b = max(c[1] - 1, 0); b <= min(c[1] + 1, g.n[1] - 1) && !found; ++b)
+                for (int d = max(c[2] - 1, 0); d <= min(c[2] + 1, g.n[2] - 1) && !found; ++d)
+                    for (int j = head[(a * g.n[1] + b) * g.n[2] + d]; j >= 0; j = next[j]) {
+                        const float ex = x - sp[3 * j], ey = y - sp[3 * j + 1], ez = z - sp[3 * j + 2];
+                        const float d2 = (ex * ex + ey * ey) + ez * ez;
+                        if (sqrtf(d2) < thr) { found = true; break; }
+                    }
+    }
+    const unsigned long long b = __ballot(found);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, __popcll(b));
+}
+
+}  // namespace
+
+extern "C" int nbp_fuse_obstacle_f32(const float* out2, const float* maps6, const float* traj, float threshold, int S,
+                                     float* obst, float* fullproj, void* stream) {
+    NBP_RETURN_IF(!out2 || !maps6 || !traj || !obst || !fullproj || S < 1, NBP_E_ARG);
+    fuse_obstacle_kernel<<<nbp_ew_grid((long long)S * S, 256), 256, 0, (hipStream_t)stream>>>(out2, maps6, traj, threshold,
+                                                                                              S * S, obst, fullproj);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_score_candidates_f32(const float* pos3, int P, float cx, float cz, const float* out1, int V,
+                                        const float* fullproj, int S, float lo, float hi, const unsigned char* skip_or_null,
+                                        unsigned char* valid, int* cell2, double* score, void* stream) {
+    NBP_RETURN_IF(!pos3 || !out1 || !fullproj || !valid || !cell2 || !score || P < 1 || V < 1 || S < 1 || !(hi > lo),
+                  NBP_E_ARG);
+    score_candidates_kernel<<<(unsigned)nbp_cdiv(P, 256), 256, 0, (hipStream_t)stream>>>(
+        pos3, P, cx, cz, out1, V, fullproj, S, lo, grid_scale(V, lo, hi), grid_scale(S, lo, hi), skip_or_null, valid, cell2,
+        score);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_edges_blocked_u8(const float* obst, int S, float lo, float hi, float cx, float cz, const float* pos3,
+                                    const int* edges2, int E, unsigned char* blocked, void* stream) {
+    NBP_RETURN_IF(!obst || !pos3 || !edges2 || !blocked || S < 1 || E < 1 || !(hi > lo), NBP_E_ARG);
+    edges_blocked_kernel<<<(unsigned)nbp_cdiv(E, 256), 256, 0, (hipStream_t)stream>>>(obst, S, lo, grid_scale(S, lo, hi), cx,
+                                                                                      cz, pos3, edges2, E, blocked);
+    return nbp_launch_status();
+}
+
+static int coverage_grid(const float* bbox_lo, const float* bbox_hi, float thr, Grid* g, size_t* ncell) {
+    size_t n = 1;
+    for (int a = 0; a < 3; ++a) {
+        g->lo[a] = bbox_lo[a] - thr;
+        const double ext = (double)bbox_hi[a] + thr - g->lo[a];
+        if (!(ext > 0)) return NBP_E_ARG;
+        g->n[a] = (int)(ext / thr) + 1;
+        n *= (size_t)g->n[a];
+    }
+    g->inv = 1.f / thr;
+    if (n > (size_t)1 << 28) return NBP_E_SHAPE;
+    *ncell = n;
+    return 0;
+}
+
+extern "C" size_t nbp_coverage_workspace_bytes(const float* bbox_lo_host, const float* bbox_hi_host, float threshold,
+                                               long long sample_k) {
+    Grid g; size_t ncell;
+    if (!bbox_lo_host || !bbox_hi_host || !(threshold > 0) || sample_k < 1) return 0;
+    if (coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell)) return 0;
+    return (ncell * 4 + 255) / 256 * 256 + ((size_t)sample_k * 4 + 255) / 256 * 256 +
+           ((size_t)sample_k * 12 + 255) / 256 * 256 + 512;
+}
+
+extern "C" int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3, long long N, const long long* N_dev_or_null,
+                                      long long sample_k, unsigned seed, float threshold, const float* bbox_lo_host,
+                                      const float* bbox_hi_host, int* count_out, int* m_out, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    NBP_RETURN_IF(!gt3 || !pc3 || !count_out || !m_out || !ws || !bbox_lo_host || !bbox_hi_host, NBP_E_ARG);
+    NBP_RETURN_IF(G < 1 || N < 0 || sample_k < 1 || !(threshold > 0) || N > 0xffffffffll, NBP_E_ARG);
+    Grid g; size_t ncell;
+    int rc = coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell);
+    if (rc) return rc;
+    NBP_RETURN_IF(ws_bytes < nbp_coverage_workspace_bytes(bbox_lo_host, bbox_hi_host, threshold, sample_k), NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)(((uintptr_t)ws + 255) / 256 * 256);
+    int* head = (int*)p; p += (ncell * 4 + 255) / 256 * 256;
+    int* next = (int*)p; p += ((size_t)sample_k * 4 + 255) / 256 * 256;
+    float* sp = (float*)p;
+    hipError_t e = hipMemsetAsync(head, 0xff, ncell * 4, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(count_out, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    const long long work = N_dev_or_null ? sample_k : (N < sample_k ? N : sample_k);
+    coverage_insert_kernel<<<nbp_ew_grid(work > 0 ? work : 1, 256), 256, 0, st>>>(pc3, N_dev_or_null, N, sample_k, seed, g, sp,
+                                                                                   head, next, m_out);
+    rc = nbp_launch_status();
+    if (rc) return rc;
+    coverage_query_kernel<<<(unsigned)nbp_cdiv(G, 256), 256, 0, st>>>(gt3, G, g, threshold, sp, head, next, count_out);
+    return nbp_launch_status();
+}

@@ -1,0 +1,380 @@
+// nbp_sim.hip -- simulator kernels: depth un-projection with exact-size random sub-sampling,
+// tile-binned z-buffer rasteriser, segment/mesh and inside-mesh ray tests.
+//
+// Replaces, on the reference's NBP path:
+//   * Camera.compute_partial_point_cloud / project_depth_in_3D
+//     (macarons/utility/macarons_utils.py:2788-2847; NDC tables :2270-2279) -- PyTorch3D
+//     FoVPerspectiveCameras.unproject_points + torch.randperm sub-sampling;
+//   * Camera.capture_image's zbuf (macarons_utils.py:2743-2786, renderer :905-937) --
+//     PyTorch3D MeshRasterizer(image_size=(256,456), faces_per_pixel=1, blur_radius=0);
+//   * line_segment_mesh_intersection (macarons_utils.py:120-151) and check_camera_in_mesh
+//     (next_best_path/utility/long_term_utils.py:158-170) -- trimesh ray queries.
+// PyTorch3D / trimesh are third-party and absent from the reference tree: these kernels follow
+// the libraries' documented conventions (row-vector X_view = X_world R + T, NDC +X left / +Y
+// up, zbuf = view-space z of the nearest face at the pixel centre, -1 background); parity with
+// the libraries themselves is UNPINNED (oracle/__init__.py), parity with oracle/ is exact.
+#include "common.h"
+#pragma clang fp contract(off)
+
+namespace {
+
+// ------------------------------------------------------------------ un-projection
+struct Cam { float R[9]; float T[3]; };
+
+// Pixel (row, col) with view-space depth z -> world point.  fp32 op order is part of the
+// contract with oracle/camera.py (no FMA contraction in this file).
+__device__ __forceinline__ void unproject_pixel(int row, int col, float z, int H, int W, float tanh_fov,
+                                                const float* R, const float* T, float* out) {
+    const int s = H < W ? H : W;
+    const float ndc_x = (float)((double)W / s) - ((float)col / (float)(s - 1)) * 2.f;   // ref mu:2272-2274
+    const float ndc_y = (float)((double)H / s) - ((float)row / (float)(s - 1)) * 2.f;   // ref mu:2275-2277
+    const float xv = (ndc_x * z) * tanh_fov;
+    const float yv = (ndc_y * z) * tanh_fov;
+    const float dx = xv - T[0], dy = yv - T[1], dz = z - T[2];
+    // X_world = (X_view - T) R^T  (row vectors)
+    out[0] = (dx * R[0] + dy * R[1]) + dz * R[2];
+    out[1] = (dx * R[3] + dy * R[4]) + dz * R[5];
+    out[2] = (dx * R[6] + dy * R[7]) + dz * R[8];
+}
+
+// K1: one 1024-thread block per frame compacts the valid pixel indices (pixel order).
+__global__ __launch_bounds__(1024) void unproject_compact_kernel(const float* __restrict__ depth,
+                                                                 const unsigned char* __restrict__ mask, int HW,
+                                                                 float fov_range, double gather, unsigned* __restrict__ list,
+                                                                 int* __restrict__ counts) {
+    __shared__ int wave_tot[16];
+    __shared__ int base_s;
+    const int f = blockIdx.x;
+    const float* d = depth + (size_t)f * HW;
+    const unsigned char* mk = mask ? mask + (size_t)f * HW : nullptr;
+    unsigned* out = list + (size_t)f * HW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < HW; p0 += 1024) {
+        const int p = p0 + threadIdx.x;
+        bool ok = false;
+        if (p < HW) {
+            const float z = d[p];
+            ok = (mk ? mk[p] != 0 : z > -1.f) && z < fov_range;
+        }
+        const unsigned long long b = __ballot(ok);
+        const int within = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(b);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (ok) out[off + within] = (unsigned)p;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wave_tot[w];
+            base_s += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counts[2 * f] = base_s;
+        counts[2 * f + 1] = (int)((double)base_s * gather);   // int(len(world_points) * gathering_factor)
+    }
+}
+
+// K2: gather the sub-sample and append it to the cloud at *cloud_count + sum of earlier frames.
+__global__ __launch_bounds__(256) void unproject_append_kernel(const float* __restrict__ depth, const Cam* __restrict__ cams,
+                                                               int H, int W, float tanh_fov, unsigned seed,
+                                                               const unsigned* __restrict__ list,
+                                                               const int* __restrict__ counts, float* __restrict__ cloud,
+                                                               const long long* __restrict__ cloud_count,
+                                                               long long capacity) {
+    const int f = blockIdx.y;
+    const int HW = H * W;
+    const int nvalid = counts[2 * f], nkeep = counts[2 * f + 1];
+    long long base = *cloud_count;
+    for (int g = 0; g < f; ++g) base += counts[2 * g + 1];
+    const unsigned bits = perm_bits((unsigned)nvalid);
+    const unsigned sd = seed + 0x632BE5ABu * (unsigned)(f + 1);
+    const Cam cam = cams[f];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nkeep; j += gridDim.x * blockDim.x) {
+        if (base + j >= capacity) return;
+        const unsigned pix = list[(size_t)f * HW + perm_index((unsigned)j, (unsigned)nvalid, bits, sd)];
+        const int row = (int)(pix / (unsigned)W), col = (int)(pix - (unsigned)row * W);
+        float o[3];
+        unproject_pixel(row, col, depth[(size_t)f * HW + pix], H, W, tanh_fov, cam.R, cam.T, o);
+        float* dst = cloud + (base + j) * 3;
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+    }
+}
+
+__global__ void cloud_count_update_kernel(const int* __restrict__ counts, int F, long long* __restrict__ cloud_count,
+                                          long long capacity) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        long long n = *cloud_count;
+        for (int f = 0; f < F; ++f) n += counts[2 * f + 1];
+        *cloud_count = n < capacity ? n : capacity;
+    }
+}
+
+// ------------------------------------------------------------------ rasteriser
+constexpr int TILE = 8;            // 8x8 pixel tiles, one wave per tile
+struct FaceRec { float e1[3], e2[3], v0[3], q[3], tnum, pad[3]; };   // 64 bytes
+
+__device__ __forceinline__ void to_view(const float* p, const float* R, const float* T, float* o) {
+    // X_view = X_world R + T (row vector): o_j = sum_k p_k R[k][j] + T_j
+    o[0] = ((p[0] * R[0] + p[1] * R[3]) + p[2] * R[6]) + T[0];
+    o[1] = ((p[0] * R[1] + p[1] * R[4]) + p[2] * R[7]) + T[1];
+    o[2] = ((p[0] * R[2] + p[1] * R[5]) + p[2] * R[8]) + T[2];
+}
+
+// One thread per (face, frame): view transform, near-plane clip for the screen bbox, binning.
+__global__ __launch_bounds__(256) void raster_setup_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                           int n_faces, const Cam* __restrict__ cams, int H, int W,
+                                                           float tanh_fov, float zclip, int tiles_x, int tiles_y,
+                                                           int bin_cap, FaceRec* __restrict__ recs, int* __restrict__ tile_count,
+                                                           int* __restrict__ tile_list, int* __restrict__ overflow) {
+    const int fr = blockIdx.y;
+    const int fi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (fi >= n_faces) return;
+    const Cam cam = cams[fr];
+    float v[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) to_view(verts + 3 * (size_t)faces[3 * (size_t)fi + k], cam.R, cam.T, v[k]);
+    if (v[0][2] <= zclip && v[1][2] <= zclip && v[2][2] <= zclip) return;       // behind the clip plane
+    FaceRec r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { r.e1[c] = v[1][c] - v[0][c]; r.e2[c] = v[2][c] - v[0][c]; r.v0[c] = v[0][c]; }
+    // q = e1 x v0  (= (-v0) x e1),  tnum = e2 . q
+    r.q[0] = r.e1[1] * r.v0[2] - r.e1[2] * r.v0[1];
+    r.q[1] = r.e1[2] * r.v0[0] - r.e1[0] * r.v0[2];
+    r.q[2] = r.e1[0] * r.v0[1] - r.e1[1] * r.v0[0];
+    r.tnum = (r.e2[0] * r.q[0] + r.e2[1] * r.q[1]) + r.e2[2] * r.q[2];
+    r.pad[0] = r.pad[1] = r.pad[2] = 0.f;
+    // screen bbox of the part with z >= zclip (Sutherland-Hodgman against one plane)
+    const int s = H < W ? H : W;
+    float cmin = 1e30f, cmax = -1e30f, rmin = 1e30f, rmax = -1e30f;
+    auto emit = [&](float x, float y, float z) {
+        const float nx = x / (z * tanh_fov), ny = y / (z * tanh_fov);
+        const float col = ((float)W - (float)s * nx - 1.f) * 0.5f;   // ndc_x(col) = W/s - (2 col + 1)/s
+        const float row = ((float)H - (float)s * ny - 1.f) * 0.5f;
+        cmin = fminf(cmin, col); cmax = fmaxf(cmax, col); rmin = fminf(rmin, row); rmax = fmaxf(rmax, row);
+    };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float* a = v[k];
+        const float* b = v[(k + 1) % 3];
+        const bool ain = a[2] >= zclip, bin_ = b[2] >= zclip;
+        if (ain) emit(a[0], a[1], a[2]);
+        if (ain != bin_) {
+            const float t = (zclip - a[2]) / (b[2] - a[2]);
+            emit(a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), zclip);
+        }
+    }
+    if (!(cmax >= cmin)) return;
+    int c0 = (int)floorf(cmin) - 1, c1 = (int)ceilf(cmax) + 1, r0 = (int)floorf(rmin) - 1, r1 = (int)ceilf(rmax) + 1;
+    if (cmin < -1e8f) c0 = 0; if (cmax > 1e8f) c1 = W - 1;
+    if (rmin < -1e8f) r0 = 0; if (rmax > 1e8f) r1 = H - 1;
+    c0 = max(c0, 0); r0 = max(r0, 0); c1 = min(c1, W - 1); r1 = min(r1, H - 1);
+    if (c0 > c1 || r0 > r1) return;
+    recs[(size_t)fr * n_faces + fi] = r;
+    const int ntiles = tiles_x * tiles_y;
+    for (int ty = r0 / TILE; ty <= r1 / TILE; ++ty)
+        for (int tx = c0 / TILE; tx <= c1 / TILE; ++tx) {
+            const int t = fr * ntiles + ty * tiles_x + tx;
+            const int pos = atomicAdd(&tile_count[t], 1);
+            if (pos < bin_cap) tile_list[(size_t)t * bin_cap + pos] = fi;
+            else *overflow = 1;
+        }
+}
+
+// One wave per 8x8 tile: faces staged 64 at a time through LDS, every lane ray-casts its pixel.
+__global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restrict__ recs, int n_faces, int H, int W,
+                                                         float tanh_fov, float zclip, int tiles_x, int tiles_y, int bin_cap,
+                                                         const int* __restrict__ tile_count, const int* __restrict__ tile_list,
+                                                         float* __restrict__ zbuf) {
+    __shared__ __attribute__((aligned(16))) FaceRec sh[64];
+    const int fr = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int lane = threadIdx.x;
+    const int col = tx * TILE + (lane & 7), row = ty * TILE + (lane >> 3);
+    const int s = H < W ? H : W;
+    // pixel-centre ray in view space (PyTorch3D NDC: +X left, +Y up)
+    const float ndc_x = ((float)W - (2.f * col + 1.f)) / (float)s;
+    const float ndc_y = ((float)H - (2.f * row + 1.f)) / (float)s;
+    const float dx = ndc_x * tanh_fov, dy = ndc_y * tanh_fov;   // dz = 1
+    const int t = fr * tiles_x * tiles_y + tile;
+    const int n = min(tile_count[t], bin_cap);
+    const int* lst = tile_list + (size_t)t * bin_cap;
+    const FaceRec* rb = recs + (size_t)fr * n_faces;
+    float zbest = 3.0e38f;
+    const float eps = 1e-6f;
+    for (int base = 0; base < n; base += 64) {
+        const int m = min(64, n - base);
+        __syncthreads();
+        if (lane < m) sh[lane] = rb[lst[base + lane]];
+        __syncthreads();
+        for (int k = 0; k < m; ++k) {
+            const FaceRec& f = sh[k];
+            // p = d x e2 ; det = e1 . p ; u = (-v0 . p)/det ; v = (d . q)/det ; z = tnum/det
+            const float p0 = dy * f.e2[2] - f.e2[1];
+            const float p1 = f.e2[0] - dx * f.e2[2];
+            const float p2 = dx * f.e2[1] - dy * f.e2[0];
+            const float det = (f.e1[0] * p0 + f.e1[1] * p1) + f.e1[2] * p2;
+            if (fabsf(det) < 1e-12f) continue;
+            const float inv = 1.f / det;
+            const float u = -((f.v0[0] * p0 + f.v0[1] * p1) + f.v0[2] * p2) * inv;
+            const float vv = ((dx * f.q[0] + dy * f.q[1]) + f.q[2]) * inv;
+            const float z = f.tnum * inv;
+            if (u >= -eps && vv >= -eps && u + vv <= 1.f + eps && z > zclip && z < zbest) zbest = z;
+        }
+    }
+    if (row < H && col < W) zbuf[((size_t)fr * H + row) * W + col] = zbest < 1.0e38f ? zbest : -1.f;
+}
+
+// ------------------------------------------------------------------ ray / mesh tests (world space)
+// Ray o + t d, |d| = 1: returns t of the hit with triangle (a,b,c) or -1.
+__device__ __forceinline__ float ray_tri(const float* o, const float* d, const float* a, const float* b, const float* c) {
+    const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    const float e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    const float p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+    const float det = (e1[0] * p[0] + e1[1] * p[1]) + e1[2] * p[2];
+    if (fabsf(det) < 1e-12f) return -1.f;
+    const float inv = 1.f / det;
+    const float tv[3] = {o[0] - a[0], o[1] - a[1], o[2] - a[2]};
+    const float u = ((tv[0] * p[0] + tv[1] * p[1]) + tv[2] * p[2]) * inv;
+    if (u < 0.f || u > 1.f) return -1.f;
+    const float q[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+    const float v = ((d[0] * q[0] + d[1] * q[1]) + d[2] * q[2]) * inv;
+    if (v < 0.f || u + v > 1.f) return -1.f;
+    const float t = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv;
+    return t > 0.f ? t : -1.f;
+}
+
+// grid: x over faces, y over segments.  hit[e] = 1 iff some triangle is hit at distance < |segment|.
+__global__ __launch_bounds__(256) void segments_hit_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                           int n_faces, const float* __restrict__ segs, int* __restrict__ hit) {
+    const int e = blockIdx.y;
+    const int fi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (fi >= n_faces) return;
+    const float* sg = segs + 6 * (size_t)e;
+    float d[3] = {sg[3] - sg[0], sg[4] - sg[1], sg[5] - sg[2]};
+    const float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    if (!(len > 0.f)) return;
+    d[0] /= len; d[1] /= len; d[2] /= len;
+    const int* f = faces + 3 * (size_t)fi;
+    const float t = ray_tri(sg, d, verts + 3 * (size_t)f[0], verts + 3 * (size_t)f[1], verts + 3 * (size_t)f[2]);
+    if (t >= 0.f && t < len) atomicOr(&hit[e], 1);
+}
+
+// counts[k][axis] = number of triangles hit by the ray from pts[k] along +Y (0), +X (1), +Z (2).
+__global__ __launch_bounds__(256) void axis_ray_count_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                             int n_faces, const float* __restrict__ pts, int* __restrict__ counts) {
+    const int k = blockIdx.y;
+    const int fi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (fi >= n_faces) return;
+    const int* f = faces + 3 * (size_t)fi;
+    const float* a = verts + 3 * (size_t)f[0];
+    const float* b = verts + 3 * (size_t)f[1];
+    const float* c = verts + 3 * (size_t)f[2];
+    const float dirs[3][3] = {{0, 1, 0}, {1, 0, 0}, {0, 0, 1}};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax)
+        if (ray_tri(pts + 3 * (size_t)k, dirs[ax], a, b, c) >= 0.f) atomicAdd(&counts[3 * k + ax], 1);
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+extern "C" size_t nbp_unproject_workspace_bytes(int n_frames, int H, int W) {
+    if (n_frames < 1 || H < 2 || W < 2) return 0;
+    return (size_t)n_frames * H * W * sizeof(unsigned) + 256;
+}
+
+extern "C" int nbp_unproject_append_f32(const float* depth, const unsigned char* mask_or_null, const float* cams12,
+                                        int n_frames, int H, int W, float tan_half_fov, float fov_range,
+                                        double gathering_factor, unsigned seed, int* counts2, float* cloud,
+                                        long long* cloud_count, long long capacity, void* ws, size_t ws_bytes,
+                                        void* stream) {
+    NBP_RETURN_IF(!depth || !cams12 || !counts2 || !cloud || !cloud_count || !ws, NBP_E_ARG);
+    NBP_RETURN_IF(n_frames < 1 || n_frames > 64 || H < 2 || W < 2 || capacity < 1, NBP_E_ARG);
+    NBP_RETURN_IF(!(gathering_factor >= 0.0 && gathering_factor <= 1.0), NBP_E_ARG);
+    NBP_RETURN_IF(ws_bytes < nbp_unproject_workspace_bytes(n_frames, H, W), NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* list = (unsigned*)(((uintptr_t)ws + 255) / 256 * 256);
+    unproject_compact_kernel<<<n_frames, 1024, 0, st>>>(depth, mask_or_null, H * W, fov_range, gathering_factor, list,
+                                                        counts2);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    const Cam* cams = reinterpret_cast<const Cam*>(cams12);   // [F][12]: R row-major (9) then T (3)
+    const int max_keep = (int)((double)H * W * gathering_factor) + 1;
+    dim3 grid((unsigned)nbp_cdiv(max_keep, 256), (unsigned)n_frames);
+    unproject_append_kernel<<<grid, 256, 0, st>>>(depth, cams, H, W, tan_half_fov, seed, list, counts2, cloud,
+                                                  cloud_count, capacity);
+    rc = nbp_launch_status();
+    if (rc) return rc;
+    cloud_count_update_kernel<<<1, 64, 0, st>>>(counts2, n_frames, cloud_count, capacity);
+    return nbp_launch_status();
+}
+
+extern "C" size_t nbp_raster_workspace_bytes(int n_faces, int n_frames, int H, int W, int bin_cap) {
+    if (n_faces < 1 || n_frames < 1 || H < 1 || W < 1 || bin_cap < 1) return 0;
+    const size_t tiles = (size_t)nbp_cdiv(W, TILE) * nbp_cdiv(H, TILE) * n_frames;
+    size_t b = 256;
+    b += ((size_t)n_frames * n_faces * sizeof(FaceRec) + 255) / 256 * 256;
+    b += (tiles * sizeof(int) + 255) / 256 * 256;
+    b += (tiles * bin_cap * sizeof(int) + 255) / 256 * 256;
+    return b + 256;
+}
+
+extern "C" int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* faces, int n_faces, const float* cams12,
+                                   int n_frames, int H, int W, float tan_half_fov, float z_clip, int bin_cap, float* zbuf,
+                                   int* overflow_flag, void* ws, size_t ws_bytes, void* stream) {
+    NBP_RETURN_IF(!verts || !faces || !cams12 || !zbuf || !overflow_flag || !ws, NBP_E_ARG);
+    NBP_RETURN_IF(n_verts < 3 || n_faces < 1 || n_frames < 1 || H < 1 || W < 1 || bin_cap < 64, NBP_E_ARG);
+    NBP_RETURN_IF(ws_bytes < nbp_raster_workspace_bytes(n_faces, n_frames, H, W, bin_cap), NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_x = (int)nbp_cdiv(W, TILE), tiles_y = (int)nbp_cdiv(H, TILE);
+    const size_t tiles = (size_t)tiles_x * tiles_y * n_frames;
+    char* p = (char*)(((uintptr_t)ws + 255) / 256 * 256);
+    FaceRec* recs = (FaceRec*)p; p += ((size_t)n_frames * n_faces * sizeof(FaceRec) + 255) / 256 * 256;
+    int* tile_count = (int*)p; p += (tiles * sizeof(int) + 255) / 256 * 256;
+    int* tile_list = (int*)p;
+    hipError_t e = hipMemsetAsync(tile_count, 0, tiles * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    dim3 g1((unsigned)nbp_cdiv(n_faces, 256), (unsigned)n_frames);
+    raster_setup_kernel<<<g1, 256, 0, st>>>(verts, faces, n_faces, reinterpret_cast<const Cam*>(cams12), H, W,
+                                            tan_half_fov, z_clip, tiles_x, tiles_y, bin_cap, recs, tile_count, tile_list,
+                                            overflow_flag);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    dim3 g2((unsigned)(tiles_x * tiles_y), (unsigned)n_frames);
+    raster_tile_kernel<<<g2, 64, 0, st>>>(recs, n_faces, H, W, tan_half_fov, z_clip, tiles_x, tiles_y, bin_cap, tile_count,
+                                          tile_list, zbuf);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_segments_hit_mesh_f32(const float* verts, const int* faces, int n_faces, const float* segs6, int n_segs,
+                                         int* hit, void* stream) {
+    NBP_RETURN_IF(!verts || !faces || !segs6 || !hit || n_faces < 1 || n_segs < 1 || n_segs > 65535, NBP_E_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(hit, 0, (size_t)n_segs * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    dim3 g((unsigned)nbp_cdiv(n_faces, 256), (unsigned)n_segs);
+    segments_hit_kernel<<<g, 256, 0, st>>>(verts, faces, n_faces, segs6, hit);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_axis_ray_counts_f32(const float* verts, const int* faces, int n_faces, const float* pts3, int n_pts,
+                                       int* counts3, void* stream) {
+    NBP_RETURN_IF(!verts || !faces || !pts3 || !counts3 || n_faces < 1 || n_pts < 1 || n_pts > 65535, NBP_E_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(counts3, 0, (size_t)n_pts * 3 * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    dim3 g((unsigned)nbp_cdiv(n_faces, 256), (unsigned)n_pts);
+    axis_ray_count_kernel<<<g, 256, 0, st>>>(verts, faces, n_faces, pts3, counts3);
+    return nbp_launch_status();
+}
+
+// Host mirror of the index bijection (the Python driver and the oracle cross-check use it).
+extern "C" unsigned nbp_perm_index_host(unsigned j, unsigned n, unsigned seed) {
+    return n == 0 ? 0 : perm_index(j, n, perm_bits(n), seed);
+}

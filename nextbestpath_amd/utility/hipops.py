@@ -1,0 +1,142 @@
+"""Thin tensor-level wrappers over the simulator / planner entry points of libnbp_hip.so
+(pointers + sizes only; all arithmetic is in the HIP kernels).  Used by the rollout driver,
+the reference-API mirrors and the GPU parity tests."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from .. import _lib
+
+TAN_HALF_FOV = float(torch.tensor(math.tan(math.radians(30.0)), dtype=torch.float32))   # FoV 60 deg (pytorch3d default)
+Z_CLIP = 0.5                                                                            # znear / 2
+
+
+def _st():
+    return _lib.current_stream()
+
+
+_ws = {}
+
+
+def _workspace(tag, nbytes, device):
+    key = (tag, str(device))
+    w = _ws.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws[key] = w
+    return w
+
+
+def cams12(R, T, device):
+    """[n,3,3], [n,3] (host or device) -> device [n,12] fp32."""
+    R = torch.as_tensor(R, dtype=torch.float32).reshape(-1, 9)
+    T = torch.as_tensor(T, dtype=torch.float32).reshape(-1, 3)
+    return torch.cat([R, T], 1).contiguous().to(device)
+
+
+def unproject_append(depth, mask, cams, cloud, cloud_count, gathering_factor=0.05, fov_range=70.0, seed=0,
+                     tan_half_fov=TAN_HALF_FOV):
+    """depth [F,H,W] fp32, mask [F,H,W] uint8|None, cams [F,12]; appends to cloud [cap,3] at the
+    device counter cloud_count (int64[1]).  Returns counts [F,2] int32 (device)."""
+    F_, H, W = depth.shape
+    L = _lib.lib()
+    counts = torch.empty(F_, 2, dtype=torch.int32, device=depth.device)
+    ws = _workspace("unproject", L.nbp_unproject_workspace_bytes(F_, H, W), depth.device)
+    rc = L.nbp_unproject_append_f32(_lib.ptr(depth), _lib.ptr(mask), _lib.ptr(cams), F_, H, W, tan_half_fov,
+                                    float(fov_range), float(gathering_factor), int(seed) & 0xFFFFFFFF,
+                                    _lib.ptr(counts), _lib.ptr(cloud), _lib.ptr(cloud_count), cloud.shape[0],
+                                    _lib.ptr(ws), ws.numel(), _st())
+    _lib.check(rc, "nbp_unproject_append_f32")
+    return counts
+
+
+def raster_zbuf(verts, faces, cams, H, W, bin_cap=2048, tan_half_fov=TAN_HALF_FOV, z_clip=Z_CLIP, out=None,
+                overflow=None):
+    """verts [V,3] fp32, faces [F,3] int32, cams [n,12] -> zbuf [n,H,W] (-1 background)."""
+    L = _lib.lib()
+    n = cams.shape[0]
+    if out is None:
+        out = torch.empty(n, H, W, dtype=torch.float32, device=verts.device)
+    if overflow is None:
+        overflow = torch.zeros(1, dtype=torch.int32, device=verts.device)
+    ws = _workspace("raster", L.nbp_raster_workspace_bytes(faces.shape[0], n, H, W, bin_cap), verts.device)
+    rc = L.nbp_raster_zbuf_f32(_lib.ptr(verts), verts.shape[0], _lib.ptr(faces), faces.shape[0], _lib.ptr(cams), n, H,
+                               W, tan_half_fov, z_clip, bin_cap, _lib.ptr(out), _lib.ptr(overflow), _lib.ptr(ws),
+                               ws.numel(), _st())
+    _lib.check(rc, "nbp_raster_zbuf_f32")
+    return out, overflow
+
+
+def segments_hit_mesh(verts, faces, segs):
+    """segs [E,6] fp32 device -> int32 [E] (1 = the segment hits the mesh)."""
+    hit = torch.empty(segs.shape[0], dtype=torch.int32, device=verts.device)
+    rc = _lib.lib().nbp_segments_hit_mesh_f32(_lib.ptr(verts), _lib.ptr(faces), faces.shape[0], _lib.ptr(segs),
+                                              segs.shape[0], _lib.ptr(hit), _st())
+    _lib.check(rc, "nbp_segments_hit_mesh_f32")
+    return hit
+
+
+def axis_ray_counts(verts, faces, pts):
+    cnt = torch.empty(pts.shape[0], 3, dtype=torch.int32, device=verts.device)
+    rc = _lib.lib().nbp_axis_ray_counts_f32(_lib.ptr(verts), _lib.ptr(faces), faces.shape[0], _lib.ptr(pts),
+                                            pts.shape[0], _lib.ptr(cnt), _st())
+    _lib.check(rc, "nbp_axis_ray_counts_f32")
+    return cnt
+
+
+def fuse_obstacle(out2, maps6, traj, threshold=0.13):
+    S = maps6.shape[-1]
+    obst = torch.empty(S, S, dtype=torch.float32, device=maps6.device)
+    fullproj = torch.empty(S, S, dtype=torch.float32, device=maps6.device)
+    rc = _lib.lib().nbp_fuse_obstacle_f32(_lib.ptr(out2), _lib.ptr(maps6), _lib.ptr(traj), float(threshold), S,
+                                          _lib.ptr(obst), _lib.ptr(fullproj), _st())
+    _lib.check(rc, "nbp_fuse_obstacle_f32")
+    return obst, fullproj
+
+
+def score_candidates(pos, pose_xyz, out1, fullproj, skip=None, grid_range=(-40, 40)):
+    """pos [P,3] device; out1 [8,V,V] device; -> (valid u8 [P], cell int32 [P,2], score f64 [P]) on device."""
+    P, V, S = pos.shape[0], out1.shape[-1], fullproj.shape[-1]
+    dev = pos.device
+    valid = torch.empty(P, dtype=torch.uint8, device=dev)
+    cell = torch.empty(P, 2, dtype=torch.int32, device=dev)
+    score = torch.empty(P, dtype=torch.float64, device=dev)
+    rc = _lib.lib().nbp_score_candidates_f32(_lib.ptr(pos), P, float(pose_xyz[0]), float(pose_xyz[2]), _lib.ptr(out1),
+                                             V, _lib.ptr(fullproj), S, float(grid_range[0]), float(grid_range[1]),
+                                             _lib.ptr(skip), _lib.ptr(valid), _lib.ptr(cell), _lib.ptr(score), _st())
+    _lib.check(rc, "nbp_score_candidates_f32")
+    return valid, cell, score
+
+
+def edges_blocked(obst, pose_xyz, pos, edges, grid_range=(-40, 40)):
+    E = edges.shape[0]
+    out = torch.empty(E, dtype=torch.uint8, device=pos.device)
+    rc = _lib.lib().nbp_edges_blocked_u8(_lib.ptr(obst), obst.shape[-1], float(grid_range[0]), float(grid_range[1]),
+                                         float(pose_xyz[0]), float(pose_xyz[2]), _lib.ptr(pos), _lib.ptr(edges), E,
+                                         _lib.ptr(out), _st())
+    _lib.check(rc, "nbp_edges_blocked_u8")
+    return out
+
+
+def coverage_count(gt, pc, n_dev=None, n=None, weight=2, seed=0, threshold=1.0, bbox=None, out=None):
+    """-> (count int32[1], m int32[1]) device tensors; coverage = count / len(gt)."""
+    L = _lib.lib()
+    G = gt.shape[0]
+    k = int(G * weight)
+    if bbox is None:
+        lo, hi = gt.min(0).values.tolist(), gt.max(0).values.tolist()
+    else:
+        lo, hi = bbox
+    lo_a, hi_a = (C.c_float * 3)(*lo), (C.c_float * 3)(*hi)
+    ws = _workspace("coverage", L.nbp_coverage_workspace_bytes(lo_a, hi_a, float(threshold), k), gt.device)
+    if out is None:
+        out = torch.empty(2, dtype=torch.int32, device=gt.device)
+    N = pc.shape[0] if n is None else int(n)
+    rc = L.nbp_coverage_count_f32(_lib.ptr(gt), G, _lib.ptr(pc), N, _lib.ptr(n_dev), k, int(seed) & 0xFFFFFFFF,
+                                  float(threshold), lo_a, hi_a, out[0:1].data_ptr(), out[1:2].data_ptr(), _lib.ptr(ws),
+                                  ws.numel(), _st())
+    _lib.check(rc, "nbp_coverage_count_f32")
+    return out

@@ -69,7 +69,8 @@ def map_points_to_n_imgs(points_2d_batch, grid_size, grid_range, device=None):
     return out
 
 
-def accumulate_step_maps(full_pc, camera_pose, y_bins, grid_size=256, grid_range=(-40, 40), band=0.1):
+def accumulate_step_maps(full_pc, camera_pose, y_bins, grid_size=256, grid_range=(-40, 40), band=0.1, n_dev=None,
+                         out=None):
     """One fused pass replacing nbp_planning.py:114-127 + :172-183.
 
     Returns [6,S,S]: four height slabs (torch.bucketize(p_y, y_bins[:-1]) - 1 semantics),
@@ -82,14 +83,16 @@ def accumulate_step_maps(full_pc, camera_pose, y_bins, grid_size=256, grid_range
     if len(bounds) > 8:
         raise ValueError("at most 8 slab boundaries")
     S = int(grid_size)
-    out = torch.empty(6, S, S, dtype=torch.float32, device=full_pc.device)
+    if out is None:
+        out = torch.empty(6, S, S, dtype=torch.float32, device=full_pc.device)
     p = full_pc.contiguous().float()
+    n_dev = None if n_dev is None else n_dev.data_ptr()
     arr = (C.c_float * max(len(bounds), 1))(*bounds)
     # thresholds exactly as the reference forms them: python double +-0.1, then fp32 compare
     band_hi = torch.tensor(cy + band, dtype=torch.float32).item()
     band_lo = torch.tensor(cy - band, dtype=torch.float32).item()
     with torch.cuda.device(p.device):
-        rc = _lib.lib().nbp_map_accumulate_f32(p.data_ptr(), p.shape[0], cx, cy, cz, arr, len(bounds), band_lo,
+        rc = _lib.lib().nbp_map_accumulate_f32(p.data_ptr(), p.shape[0], n_dev, cx, cy, cz, arr, len(bounds), band_lo,
                                                band_hi, S, float(grid_range[0]), float(grid_range[1]),
                                                out.data_ptr(), _lib.current_stream())
     _lib.check(rc, "nbp_map_accumulate_f32")

@@ -1,0 +1,107 @@
+"""numpy restatement of the camera arithmetic on the NBP path.  PARITY UNPINNED against the
+libraries: pytorch3d 0.7.4 (environment.yml:204) is a third-party dependency absent from
+/root/reference and from this image; this file restates its documented conventions
+(row vectors, X_view = X_world R + T; NDC +X left, +Y up, short side in [-1,1];
+FoVPerspectiveCameras defaults fov=60 deg, znear=1, aspect 1) at the reference's call sites:
+
+  * get_camera_RT (macarons/utility/macarons_utils.py:940-957) = get_cartesian_coords
+    (macarons/utility/CustomGeometry.py:5-24) + pytorch3d look_at_view_transform(eye, at)
+  * Camera NDC tables (macarons_utils.py:2270-2279) + project_depth_in_3D (:2788-2809) +
+    compute_partial_point_cloud (:2811-2847)
+  * Camera.__init__ pose lattice (:2283-2327) and update_camera interpolation (:2590-2632)
+
+fp32 operation order matches nextbestpath_amd/csrc/nbp_sim.hip exactly (parity with the HIP
+path is bit-exact); known-answer tests (tests/test_oracle_sim.py) validate the geometry."""
+import numpy as np
+
+from . import sampling
+
+f32 = np.float32
+TAN_HALF_FOV = f32(np.tan(np.deg2rad(30.0)))       # FoVPerspectiveCameras default fov = 60 deg
+
+
+def cartesian(r, elev_deg, azim_deg):
+    """CustomGeometry.get_cartesian_coords: x = r cos(e) sin(a), y = r sin(e), z = r cos(e) cos(a)."""
+    e, a = np.deg2rad(elev_deg), np.deg2rad(azim_deg)
+    return np.stack([r * np.cos(e) * np.sin(a), r * np.sin(e), r * np.cos(e) * np.cos(a)], -1)
+
+
+def look_at_RT(eye, at, up=(0.0, 1.0, 0.0)):
+    """pytorch3d look_at_view_transform: z = normalize(at-eye), x = normalize(up x z), y = z x x;
+    R has those axes as COLUMNS (row-vector convention), T = -eye R."""
+    eye, at, up = np.asarray(eye, np.float64), np.asarray(at, np.float64), np.asarray(up, np.float64)
+    z = at - eye
+    z = z / max(np.linalg.norm(z), 1e-5)
+    x = np.cross(up, z)
+    nx = np.linalg.norm(x)
+    if nx < 5e-3:                       # up parallel to view axis: pytorch3d falls back to y x z
+        y0 = np.cross(z, np.array([1.0, 0.0, 0.0]))
+        y0 = y0 / np.linalg.norm(y0)
+        x = np.cross(y0, z)
+        nx = np.linalg.norm(x)
+    x = x / nx
+    y = np.cross(z, x)
+    y = y / max(np.linalg.norm(y), 1e-5)
+    R = np.stack([x, y, z], axis=1)
+    T = -(eye @ R)
+    return R.astype(f32), T.astype(f32)
+
+
+def camera_RT(X_cam, V_cam):
+    """get_camera_RT (mu:940-957): rays = -cartesian(1, -elev, 180 + azim); look at X + rays."""
+    rays = -cartesian(1.0, -float(V_cam[0]), 180.0 + float(V_cam[1]))
+    X = np.asarray(X_cam, np.float64)
+    return look_at_RT(X, X + rays)
+
+
+def ndc_tables(H, W):
+    s = min(H, W)
+    col = np.arange(W, dtype=f32)[None, :].repeat(H, 0)
+    row = np.arange(H, dtype=f32)[:, None].repeat(W, 1)
+    ndc_x = f32(W / s) - (col / f32(s - 1)) * f32(2)
+    ndc_y = f32(H / s) - (row / f32(s - 1)) * f32(2)
+    return ndc_x, ndc_y
+
+
+def unproject(depth, R, T):
+    """All pixels: [H,W] view-space depth -> [H*W,3] world points (fp32, kernel op order)."""
+    H, W = depth.shape
+    ndc_x, ndc_y = ndc_tables(H, W)
+    z = depth.astype(f32)
+    xv = (ndc_x * z) * TAN_HALF_FOV
+    yv = (ndc_y * z) * TAN_HALF_FOV
+    dx, dy, dz = xv - f32(T[0]), yv - f32(T[1]), z - f32(T[2])
+    R = R.astype(f32)
+    out = np.empty((H, W, 3), f32)
+    for j in range(3):
+        out[..., j] = (dx * R[j, 0] + dy * R[j, 1]) + dz * R[j, 2]
+    return out.reshape(-1, 3)
+
+
+def partial_point_cloud(depth, mask, R, T, gathering_factor, fov_range, seed, frame_index=0):
+    """compute_partial_point_cloud with the seeded bijection instead of torch.randperm.
+    Returns (points [n_keep,3], n_valid)."""
+    H, W = depth.shape
+    m = (depth > -1) if mask is None else (mask != 0)
+    valid = m.reshape(-1) & (depth.reshape(-1) < f32(fov_range))
+    lst = np.nonzero(valid)[0]
+    n_valid = len(lst)
+    n_keep = int(n_valid * gathering_factor)
+    sd = (seed + 0x632BE5AB * (frame_index + 1)) & sampling.M32
+    sel = lst[sampling.perm_index(np.arange(n_keep), n_valid, sd)] if n_keep else lst[:0]
+    return unproject(depth, R, T)[sel], n_valid
+
+
+def pose_lattice(x_min, pose_l, pose_w, pose_h, n_elev, n_azim):
+    """Camera.__init__ (mu:2283-2327): poses [L,W,H,E,A,5] (x,y,z,elev,azim), i-major order.
+    NOTE the reference offsets from the *scene* x_min argument (not self.x_min = x_min + 3)."""
+    x_min = np.asarray(x_min, f32)
+    idx = np.stack(np.meshgrid(np.arange(pose_l), np.arange(pose_w), np.arange(pose_h), np.arange(n_elev),
+                               np.arange(n_azim), indexing="ij"), -1).reshape(-1, 5)
+    poses = np.zeros((len(idx), 5), f32)
+    poses[:, 0] = x_min[0] + (idx[:, 0] * 3).astype(f32)
+    poses[:, 1] = x_min[1] + f32(3.3)
+    poses[:, 2] = x_min[2] + (idx[:, 2] * 3).astype(f32)
+    poses[:, 3] = f32(-90.0) + (f32(180.0) * (1 + idx[:, 3]).astype(f32)) / f32(n_elev + 1)
+    poses[:, 4] = (f32(360.0) * idx[:, 4].astype(f32)) / f32(n_azim)
+    return idx, poses

@@ -1,0 +1,50 @@
+"""numpy restatement of the z-buffer rasteriser (brute force: every pixel x every face).
+PARITY UNPINNED against pytorch3d 0.7.4 MeshRasterizer (third-party, absent): restates its
+documented semantics at the reference's call site (macarons/utility/macarons_utils.py:905-937,
+2743-2786: image_size=(256,456), blur_radius=0, faces_per_pixel=1, perspective-correct z,
+z_clip = znear/2 = 0.5): zbuf = view-space z of the nearest face through the pixel centre,
+-1 for background; pixel centres at ndc_x = (W-(2c+1))/s, ndc_y = (H-(2r+1))/s, s = min(H,W).
+Same ray/triangle algebra as nextbestpath_amd/csrc/nbp_sim.hip (fp32)."""
+import numpy as np
+
+f32 = np.float32
+
+
+def to_view(verts, R, T):
+    v = np.asarray(verts, f32)
+    R = np.asarray(R, f32)
+    out = np.empty_like(v)
+    for j in range(3):
+        out[:, j] = ((v[:, 0] * R[0, j] + v[:, 1] * R[1, j]) + v[:, 2] * R[2, j]) + f32(T[j])
+    return out
+
+
+def raster_zbuf(verts, faces, R, T, H, W, tan_half_fov, z_clip=0.5, eps=1e-6):
+    vv = to_view(verts, R, T)
+    s = min(H, W)
+    col = np.arange(W, dtype=f32)[None, :]
+    row = np.arange(H, dtype=f32)[:, None]
+    dx = ((f32(W) - (f32(2) * col + f32(1))) / f32(s) * f32(tan_half_fov)) + np.zeros((H, 1), f32)
+    dy = ((f32(H) - (f32(2) * row + f32(1))) / f32(s) * f32(tan_half_fov)) + np.zeros((1, W), f32)
+    zb = np.full((H, W), 3.0e38, f32)
+    zc = f32(z_clip)
+    for f in np.asarray(faces):
+        v0, v1, v2 = vv[f[0]], vv[f[1]], vv[f[2]]
+        if v0[2] <= zc and v1[2] <= zc and v2[2] <= zc:
+            continue
+        e1, e2 = v1 - v0, v2 - v0
+        q = np.array([e1[1] * v0[2] - e1[2] * v0[1], e1[2] * v0[0] - e1[0] * v0[2], e1[0] * v0[1] - e1[1] * v0[0]], f32)
+        tnum = (e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]
+        p0 = dy * e2[2] - e2[1]
+        p1 = e2[0] - dx * e2[2]
+        p2 = dx * e2[1] - dy * e2[0]
+        det = (e1[0] * p0 + e1[1] * p1) + e1[2] * p2
+        ok = np.abs(det) >= f32(1e-12)
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            inv = f32(1) / det
+            u = -((v0[0] * p0 + v0[1] * p1) + v0[2] * p2) * inv
+            v = ((dx * q[0] + dy * q[1]) + q[2]) * inv
+            z = tnum * inv
+            hit = ok & (u >= -f32(eps)) & (v >= -f32(eps)) & (u + v <= f32(1) + f32(eps)) & (z > zc) & (z < zb)
+        zb = np.where(hit, z, zb)
+    return np.where(zb < 1.0e38, zb, f32(-1)).astype(f32)

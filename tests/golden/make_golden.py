@@ -115,6 +115,8 @@ def gen_maps(utils):
         min_y, max_y = min_v + 0.5, max_v - 0.5
         bin_width = (max_y - min_y) / n_pieces
         y_bins = torch.arange(min_y, max_y + bin_width, bin_width)
+        if tag == "six_bins":       # a 6-entry y_bins (float arange may overshoot): slab 4 must be dropped
+            y_bins = torch.tensor([0.5, 6.0, 11.5, 17.0, 22.5, 28.0])
         bins = torch.bucketize(p[:, 1], y_bins[:-1]) - 1
         imgs = []
         for i in range(n_pieces):
@@ -185,8 +187,88 @@ def gen_planner(ltu, mu):
     print("planner: blocked", sum(blocked), "/300  cpv", sum(cpv), "/200  cov", cov, cov_small, cov_empty)
 
 
+def gen_replan(utils, ltu, mu):
+    """Obstacle fusion + candidate scoring (nbp_planning.py:166-233) and generate_Dijkstra_path
+    (long_term_utils.py:334-418) on a synthetic lattice; the inline tester code is restated with
+    the reference's own functions doing the arithmetic."""
+    import types as _t
+    rng = np.random.default_rng(41)
+    dev = torch.device("cpu")
+    S, V = 256, 64
+    pose = torch.tensor([4.0, 13.3, -5.0, 0.0, 0.0])
+    # lattice 12 x 12 positions, 3-unit pitch, partly outside the +-40 window
+    ii, kk = np.meshgrid(np.arange(12), np.arange(12), indexing="ij")
+    idx = np.stack([ii.ravel(), np.zeros(144, int), kk.ravel()], 1)
+    pos = np.stack([-20.0 + 3.0 * idx[:, 0] + 4.0, np.full(144, 13.3), -50.0 + 3.0 * idx[:, 2] - 5.0], 1).astype(np.float32)
+    out1 = torch.from_numpy(rng.normal(0, 1, (1, 8, V, V)).astype(np.float32))
+    out2 = torch.from_numpy(np.where(rng.random((1, 1, S, S)) < 0.06, 0.13 + 0.8 * rng.random((1, 1, S, S)),
+                                     0.13 * rng.random((1, 1, S, S))).astype(np.float32))
+    out2[0, 0, 100, 100] = 0.13        # threshold is >= (nbp_planning.py:168)
+    full = torch.from_numpy(rng.poisson(0.03, (1, 1, S, S)).astype(np.float32))
+    band = torch.from_numpy((rng.random((1, 1, S, S)) < 0.3).astype(np.float32)) * (full > 0)
+    traj = torch.from_numpy((rng.random((1, 1, S, S)) < 0.01).astype(np.float32))
+    # --- fusion (nbp_planning.py:166-191)
+    obst = (out2 >= 0.13).float()
+    fullproj = full.clone()
+    fullproj[fullproj > 1] = 1
+    filt = band.clone()
+    filt[filt > 0] = 1
+    mask_layout = fullproj > 0
+    obst[mask_layout] = filt[mask_layout]
+    obst[traj > 0] = 0
+    max_gain, _ = torch.max(out1, dim=1, keepdim=True)
+    # --- scoring (nbp_planning.py:203-233)
+    skip = rng.random(144) < 0.05
+    rows = []
+    for i in range(144):
+        if skip[i]:
+            continue
+        p3 = torch.from_numpy(pos[i])
+        p2 = utils.transform_points_to_n_pieces(p3.unsqueeze(0), pose, dev)
+        g = utils.get_point_position_in_the_img(p2.squeeze(0), (V, V), (-40, 40))
+        if 0 <= g[0] < V and 0 <= g[1] < V:
+            val = max_gain[0, 0, g[0], g[1]]
+            sel = utils.get_point_position_in_the_img(p2.squeeze(0), (S, S), (-40, 40))
+            selp = torch.tensor([sel[0], sel[1]])
+            dens = fullproj[0, 0, selp[0], selp[1]]
+            if mu.check_pixel_values(fullproj, selp):
+                rows.append([i, int(g[0]), int(g[1]), val.item() - 10 * dens.item()])
+    order = sorted(range(len(rows)), key=lambda r: rows[r][-1], reverse=True)     # list.sort(reverse=True) is stable
+    # --- Dijkstra (long_term_utils.py:334-418)
+    pose_space = {str([int(a), int(b), int(c)]).replace(", ", ",  "): torch.from_numpy(pos[n])
+                  for n, (a, b, c) in enumerate(idx.tolist())}
+    cam = _t.SimpleNamespace(cam_idx_history=torch.tensor([[5., 0., 6., 2., 3.], [5., 0., 7., 2., 1.]]))
+    start = [5, 0, 7]
+    goals, paths, plens = [], [], []
+    collision = [[[5, 0, 7], [5, 0, 8]], [[5, 0, 8], [5, 0, 7]]]
+    passable = [[[5, 0, 7], [5, 0, 6]], [[5, 0, 6], [5, 0, 7]]]
+    import random as _r
+    for gi in [rows[r][0] for r in order[:12]] + [0, 143]:
+        _r.seed(3)
+        goal = idx[gi].tolist()
+        pth = ltu.generate_Dijkstra_path(pose_space, start, goal, None, pose, cam, (V, V), (-40, 40), out1, dev,
+                                         layout_image=obst, layout_size=(S, S), collision_list=collision,
+                                         training_flag=False, passable_list=passable)
+        goals.append(gi)
+        if pth is None:
+            plens.append(-1)
+        else:
+            plens.append(len(pth))
+            paths.extend(pth.long().tolist())
+    np.savez_compressed(os.path.join(HERE, "replan.npz"), pose=pose.numpy(), idx=idx, pos=pos, out1=out1.numpy(),
+                        out2=out2.numpy()[0, 0], full=full.numpy()[0, 0].astype(np.uint8), band=band.numpy()[0, 0].astype(np.uint8),
+                        traj=traj.numpy()[0, 0].astype(np.uint8), obst=obst.numpy()[0, 0].astype(np.uint8),
+                        fullproj=fullproj.numpy()[0, 0].astype(np.uint8), skip=skip,
+                        cand=np.array([r[:3] for r in rows]), cand_score=np.array([r[3] for r in rows]),
+                        cand_order=np.array(order), start=np.array(start), goals=np.array(goals),
+                        path_lens=np.array(plens), paths=np.array(paths), cam_hist=cam.cam_idx_history.numpy(),
+                        collision=np.array(collision), passable=np.array(passable))
+    print("replan: candidates", len(rows), "paths", plens)
+
+
 if __name__ == "__main__":
     model, utils, ltu, mu = import_reference()
     gen_maps(utils)
     gen_planner(ltu, mu)
+    gen_replan(utils, ltu, mu)
     gen_network(model)

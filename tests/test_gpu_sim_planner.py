@@ -1,0 +1,204 @@
+"""GPU parity: simulator + planner kernels vs oracle/ (bit-exact for integer / index results and
+for fp32 results whose op order is shared) and vs the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nextbestpath_amd.utility import hipops as ho
+from nextbestpath_amd import _lib
+from oracle import camera as ocam
+from oracle import mesh_rays
+from oracle import planner as opl
+from oracle import raster as orast
+from oracle import sampling
+
+pytestmark = pytest.mark.gpu
+D = "cuda"
+
+
+def _maze(seed=0, n=12, size=60.0, h=30.0):
+    from nextbestpath_amd.simulator.mesh import make_maze_mesh
+    return make_maze_mesh(seed=seed, cells=n, size=size, height=h)
+
+
+def test_perm_index_host_matches_oracle(hip):
+    for n, seed in ((1, 0), (7, 3), (1000, 99), (116_736, 12345)):
+        js = np.arange(min(n, 300))
+        want = sampling.perm_index(js, n, seed)
+        got = np.array([hip.nbp_perm_index_host(int(j), n, seed) for j in js])
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("H,W", [(32, 57), (256, 456)])
+def test_unproject_append_vs_oracle(hip, H, W):
+    rng = np.random.default_rng(5)
+    F_ = 5
+    depth = rng.uniform(0.6, 120, (F_, H, W)).astype(np.float32)
+    depth[rng.random((F_, H, W)) < 0.25] = -1
+    depth[4] = -1                                                   # a frame that sees nothing
+    poses = [([1.0, 3.3, -2.0], [0.0, 45.0]), ([4.0, 3.3, -2.0], [30.0, 90.0]), ([4.0, 3.3, 1.0], [-30.0, 200.0]),
+             ([7.0, 3.3, 1.0], [0.0, 315.0]), ([7.0, 3.3, 4.0], [60.0, 0.0])]
+    RT = [ocam.camera_RT(x, v) for x, v in poses]
+    cams = ho.cams12(np.stack([r for r, _ in RT]), np.stack([t for _, t in RT]), D)
+    cap = 100_000
+    cloud = torch.zeros(cap, 3, device=D)
+    cnt = torch.tensor([17], dtype=torch.int64, device=D)           # non-zero base: appended after 17 points
+    counts = ho.unproject_append(torch.from_numpy(depth).to(D), None, cams, cloud, cnt, 0.05, 70.0, seed=11)
+    want, nvs = [], []
+    for f in range(F_):
+        pts, nv = ocam.partial_point_cloud(depth[f], None, RT[f][0], RT[f][1], 0.05, 70.0, seed=11, frame_index=f)
+        want.append(pts); nvs.append(nv)
+    counts = counts.cpu().numpy()
+    assert counts[:, 0].tolist() == nvs and counts[:, 1].tolist() == [len(w) for w in want]
+    total = sum(len(w) for w in want)
+    assert int(cnt.item()) == 17 + total
+    got = cloud[17:17 + total].cpu().numpy()
+    assert np.array_equal(got, np.concatenate(want, 0))             # bit-exact fp32 (shared op order)
+    assert float(cloud[:17].abs().sum()) == 0.0
+    # explicit mask input == derived mask
+    cloud2 = torch.zeros(cap, 3, device=D)
+    cnt2 = torch.zeros(1, dtype=torch.int64, device=D)
+    m = torch.from_numpy((depth > -1).astype(np.uint8)).to(D)
+    ho.unproject_append(torch.from_numpy(depth).to(D), m, cams, cloud2, cnt2, 0.05, 70.0, seed=11)
+    assert torch.equal(cloud2[:total], cloud[17:17 + total])
+    # capacity clamp
+    small = torch.zeros(100, 3, device=D)
+    c3 = torch.tensor([90], dtype=torch.int64, device=D)
+    ho.unproject_append(torch.from_numpy(depth).to(D), None, cams, small, c3, 0.05, 70.0, seed=11)
+    assert int(c3.item()) == 100
+
+
+def test_raster_vs_oracle_maze(hip):
+    verts, faces = _maze(seed=3)
+    H, W = 64, 114
+    poses = [([-12.0, 3.3, -9.0], [0.0, 30.0]), ([6.0, 3.3, 3.0], [20.0, 170.0]), ([15.0, 10.0, -21.0], [-45.0, 260.0])]
+    RT = [ocam.camera_RT(x, v) for x, v in poses]
+    cams = ho.cams12(np.stack([r for r, _ in RT]), np.stack([t for _, t in RT]), D)
+    z, ov = ho.raster_zbuf(torch.from_numpy(verts).to(D), torch.from_numpy(faces).to(D), cams, H, W, bin_cap=4096)
+    assert int(ov.item()) == 0
+    z = z.cpu().numpy()
+    for i, (R, T) in enumerate(RT):
+        want = orast.raster_zbuf(verts, faces, R, T, H, W, ocam.TAN_HALF_FOV)
+        same = np.isclose(z[i], want, rtol=1e-5, atol=1e-5)
+        # identical algebra; only silhouette pixels within eps of an edge may differ through rounding order
+        assert same.mean() > 0.999, (i, same.mean())
+        assert (z[i] > 0).mean() > 0.9
+
+
+def test_raster_closed_form_box_full_res(hip):
+    """256x456 (the reference's image size): closed room, camera at the centre -> closed-form depth, no cracks."""
+    h = 4.0
+    v = np.array([[x, y, zz] for x in (-h, h) for y in (-h, h) for zz in (-h, h)], np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    f = np.array([t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))], np.int32)
+    H, W = 256, 456
+    R, T = ocam.camera_RT([0, 0, 0], [0.0, 0.0])
+    z, ov = ho.raster_zbuf(torch.from_numpy(v).to(D), torch.from_numpy(f).to(D), ho.cams12(R[None], T[None], D), H, W)
+    z = z[0].cpu().numpy()
+    t = float(ocam.TAN_HALF_FOV)
+    col, row = np.meshgrid(np.arange(W), np.arange(H))
+    dx, dy = (W - (2 * col + 1)) / 256 * t, (H - (2 * row + 1)) / 256 * t
+    want = h / np.maximum(np.maximum(np.abs(dx), np.abs(dy)), 1.0)
+    assert (z > 0).all() and np.allclose(z, want, rtol=2e-5)
+    # render -> un-project round trip: every un-projected pixel lies on the box surface
+    depth = torch.from_numpy(z[None]).to(D)
+    cloud = torch.zeros(H * W, 3, device=D)
+    cnt = torch.zeros(1, dtype=torch.int64, device=D)
+    ho.unproject_append(depth, None, ho.cams12(R[None], T[None], D), cloud, cnt, 1.0, 70.0, seed=1)
+    assert int(cnt.item()) == H * W
+    p = cloud.cpu().numpy()
+    # NOTE the reference un-projects with NDC tables (mu:2270-2279) whose pixel pitch differs slightly from
+    # the rasteriser's pixel centres, so points land on the walls only to within that skew
+    assert np.abs(np.abs(p).max(1) - h).max() < 0.05
+
+
+def test_mesh_ray_queries_vs_oracle(hip):
+    verts, faces = _maze(seed=4)
+    rng = np.random.default_rng(6)
+    vd, fd = torch.from_numpy(verts).to(D), torch.from_numpy(faces).to(D)
+    p0 = rng.uniform(-28, 28, (64, 3)).astype(np.float32); p0[:, 1] = rng.uniform(1, 20, 64)
+    p1 = p0 + rng.normal(0, 4, (64, 3)).astype(np.float32)
+    p1[0] = p0[0]                                                       # zero-length segment
+    segs = np.concatenate([p0, p1], 1)
+    got = ho.segments_hit_mesh(vd, fd, torch.from_numpy(segs).to(D)).cpu().numpy().astype(bool)
+    want = np.array([mesh_rays.segment_hits_mesh(a, b, verts, faces) for a, b in zip(p0, p1)])
+    assert np.array_equal(got, want) and 0 < want.sum() < 64
+    cnt = ho.axis_ray_counts(vd, fd, torch.from_numpy(p0).to(D)).cpu().numpy()
+    assert np.array_equal(cnt, np.array([mesh_rays.axis_ray_counts(p, verts, faces) for p in p0]))
+
+
+def test_fusion_scoring_edges_vs_reference_golden(hip, golden_dir):
+    g = np.load(os.path.join(golden_dir, "replan.npz"))
+    S = 256
+    maps6 = torch.zeros(6, S, S, device=D)
+    maps6[0] = torch.from_numpy(g["full"].astype(np.float32))
+    maps6[5] = torch.from_numpy(g["band"].astype(np.float32))
+    out2 = torch.from_numpy(g["out2"]).to(D).contiguous()
+    traj = torch.from_numpy(g["traj"].astype(np.float32)).to(D)
+    obst, fullproj = ho.fuse_obstacle(out2, maps6, traj)
+    assert np.array_equal(obst.cpu().numpy(), g["obst"].astype(np.float32))
+    assert np.array_equal(fullproj.cpu().numpy(), g["fullproj"].astype(np.float32))
+    pos = torch.from_numpy(g["pos"]).to(D)
+    out1 = torch.from_numpy(g["out1"][0]).to(D).contiguous()
+    skip = torch.from_numpy(g["skip"].astype(np.uint8)).to(D)
+    valid, cell, score = ho.score_candidates(pos, g["pose"], out1, fullproj, skip)
+    ids = np.nonzero(valid.cpu().numpy())[0]
+    assert np.array_equal(ids, g["cand"][:, 0])
+    assert np.array_equal(cell.cpu().numpy()[ids], g["cand"][:, 1:3])
+    assert np.array_equal(score.cpu().numpy()[ids], g["cand_score"])        # float64, exact
+    # every lattice edge in one launch == the reference's per-edge Python loop (via the pinned oracle)
+    idx = g["idx"]
+    nodes = {tuple(r): n for n, r in enumerate(idx.tolist())}
+    edges = [(n, nodes[nb]) for n, (i, j, k) in enumerate(idx.tolist())
+             for nb in ((i + 1, j, k), (i - 1, j, k), (i, j, k + 1), (i, j, k - 1)) if nb in nodes]
+    ed = torch.tensor(edges, dtype=torch.int32, device=D)
+    got = ho.edges_blocked(obst, g["pose"], pos, ed).cpu().numpy().astype(bool)
+    layout = g["obst"].astype(np.float32)
+    want = np.array([opl.edge_blocked(g["pos"][a], g["pos"][b], g["pose"], layout) for a, b in edges])
+    assert np.array_equal(got, want) and 0 < want.sum() < len(want)
+
+
+def test_edges_blocked_vs_reference_golden(hip, golden_dir):
+    g = np.load(os.path.join(golden_dir, "planner.npz"))
+    p = np.concatenate([g["edge_p1"], g["edge_p2"]], 0)
+    n = len(g["edge_p1"])
+    ed = torch.tensor([[i, n + i] for i in range(n)], dtype=torch.int32, device=D)
+    obst = torch.from_numpy(g["layout"][0, 0].astype(np.float32)).to(D)
+    got = ho.edges_blocked(obst, g["edge_pose"], torch.from_numpy(p).to(D), ed).cpu().numpy().astype(bool)
+    assert got.tolist() == g["edge_blocked"].tolist()
+
+
+def test_coverage_vs_oracle_and_reference(hip, golden_dir):
+    g = np.load(os.path.join(golden_dir, "planner.npz"))
+    gt, pc = g["cov_gt"], g["cov_pc"]
+    gtd, pcd = torch.from_numpy(gt).to(D), torch.from_numpy(pc).to(D)
+    out = ho.coverage_count(gtd, pcd, seed=21).cpu().numpy()
+    frac, cnt = opl.coverage(gt, pc, seed=21)
+    assert out[1] == 2 * len(gt) and out[0] == cnt                          # same subset, same count
+    # the reference's own subset (its randperm is in the fixture): no resampling when len == 2G
+    sub = torch.from_numpy(pc[g["cov_perm"]]).to(D)
+    o2 = ho.coverage_count(gtd, sub, seed=0).cpu().numpy()
+    assert abs(o2[0] / len(gt) - float(g["cov"])) <= 2.0 / len(gt)
+    # device-side N, small cloud (no subsampling), empty cloud
+    nd = torch.tensor([1000], dtype=torch.int64, device=D)
+    o3 = ho.coverage_count(gtd, pcd, n_dev=nd).cpu().numpy()
+    assert o3[1] == 1000 and o3[0] == opl.coverage(gt, pc[:1000])[1]
+    nd.zero_()
+    o4 = ho.coverage_count(gtd, pcd, n_dev=nd).cpu().numpy()
+    assert o4[0] == 0 and o4[1] == 0
+
+
+def test_coverage_full_size_properties(hip):
+    """G = 50k vs a 3 M cloud (BASELINE sizes): monotone in the cloud, 100 % on itself, deterministic."""
+    rng = np.random.default_rng(8)
+    gt = torch.from_numpy(rng.uniform(-30, 30, (50_000, 3)).astype(np.float32)).to(D)
+    pc = torch.from_numpy(rng.uniform(-30, 30, (3_000_000, 3)).astype(np.float32)).to(D)
+    a = ho.coverage_count(gt, pc, seed=1).cpu().numpy()
+    b = ho.coverage_count(gt, pc, seed=1).cpu().numpy()
+    assert np.array_equal(a, b) and a[1] == 100_000
+    self_cov = ho.coverage_count(gt, gt, seed=1).cpu().numpy()
+    assert self_cov[0] == 50_000
+    half = ho.coverage_count(gt, pc[:50_000], seed=1).cpu().numpy()
+    assert half[0] <= a[0] <= 50_000

@@ -1,0 +1,188 @@
+"""CPU: planner / simulator oracles vs the reference's golden vectors and analytic known answers."""
+import os
+
+import numpy as np
+
+from oracle import camera as ocam
+from oracle import mesh_rays
+from oracle import planner as opl
+from oracle import raster as orast
+from oracle import sampling
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ------------------------------------------------------------------ pinned by the reference
+def test_bresenham_vs_reference(golden_dir):
+    g = _g(golden_dir, "planner.npz")
+    off = 0
+    for (x0, y0, x1, y1), n in zip(g["ends"].tolist(), g["line_lens"].tolist()):
+        want = [tuple(p) for p in g["line_pts"][off:off + n].tolist()]
+        assert opl.bresenham_line(x0, y0, x1, y1) == want
+        off += n
+
+
+def test_edge_blocked_and_window_check_vs_reference(golden_dir):
+    g = _g(golden_dir, "planner.npz")
+    layout = g["layout"][0, 0].astype(np.float32)
+    got = [opl.edge_blocked(a, b, g["edge_pose"], layout) for a, b in zip(g["edge_p1"], g["edge_p2"])]
+    assert got == g["edge_blocked"].tolist()
+    assert 0 < sum(got) < len(got)
+    proj = g["proj"][0, 0].astype(np.float32)
+    assert [opl.check_pixel_values(proj, c) for c in g["cpv_cells"]] == g["cpv"].tolist()
+
+
+def test_coverage_vs_reference(golden_dir):
+    g = _g(golden_dir, "planner.npz")
+    gt, pc = g["cov_gt"], g["cov_pc"]
+    # same subset as the reference drew (its randperm is recorded in the fixture)
+    sub = pc[g["cov_perm"]]
+    frac, cnt = opl.coverage(gt, sub, seed=0)          # len(sub) == 2G -> no resampling
+    assert abs(frac - float(g["cov"])) <= 2.0 / len(gt)     # cdist matmul vs direct difference at d ~ 1.0
+    frac_small, _ = opl.coverage(gt, pc[:1000])
+    assert abs(frac_small - float(g["cov_small"])) <= 2.0 / len(gt)
+    assert opl.coverage(gt, pc[:0])[0] == float(g["cov_empty"]) == 0.0
+    assert abs(opl.compute_auc(np.linspace(0, 0.8, 101)) - float(g["auc"])) < 1e-12
+
+
+def test_fusion_scoring_vs_reference(golden_dir):
+    g = _g(golden_dir, "replan.npz")
+    maps6 = np.zeros((6, 256, 256), np.float32)
+    maps6[0] = g["full"]
+    maps6[5] = g["band"]
+    obst, fullproj = opl.fuse_obstacle(g["out2"], maps6, g["traj"].astype(np.float32))
+    assert np.array_equal(obst, g["obst"].astype(np.float32))
+    assert np.array_equal(fullproj, g["fullproj"].astype(np.float32))
+    valid, cells, scores = opl.score_candidates(g["pos"], g["pose"], g["out1"][0], fullproj, skip=g["skip"])
+    ids = np.nonzero(valid)[0]
+    assert np.array_equal(ids, g["cand"][:, 0])
+    assert np.array_equal(cells[ids], g["cand"][:, 1:3])
+    assert np.array_equal(scores[ids], g["cand_score"])                 # float64, exact
+    order = sorted(range(len(ids)), key=lambda r: scores[ids[r]], reverse=True)
+    assert order == g["cand_order"].tolist()
+
+
+def test_dijkstra_vs_reference(golden_dir):
+    from nextbestpath_amd.utility import planner_host as ph
+    g = _g(golden_dir, "replan.npz")
+    idx = [tuple(r) for r in g["idx"].tolist()]
+    nodes = {t: n for n, t in enumerate(idx)}
+    layout = g["obst"].astype(np.float32)
+    coll = [[list(a), list(b)] for a, b in g["collision"].tolist()]
+    pas = [[list(a), list(b)] for a, b in g["passable"].tolist()]
+
+    def passable(a, b):
+        if [list(a), list(b)] in pas:
+            return True
+        return (not opl.edge_blocked(g["pos"][nodes[a]], g["pos"][nodes[b]], g["pose"], layout)) and \
+            [list(a), list(b)] not in coll
+
+    tree = opl.dijkstra_tree(set(nodes), tuple(g["start"].tolist()), passable)
+    off = 0
+    for gi, n in zip(g["goals"].tolist(), g["path_lens"].tolist()):
+        path = opl.path_from_tree(tree, idx[gi])
+        if n < 0:
+            assert path is None
+            continue
+        want = g["paths"][off:off + n]
+        off += n
+        assert [list(p) for p in path[1:]] == want[:, :3].tolist()
+        # heading choice (long_term_utils.py:395-404) through the product's host helper
+        got = ph.choose_headings(path, g["pos"], nodes, g["pose"], g["out1"][0], g["cam_hist"].astype(np.int64))
+        assert np.array_equal(np.array(got)[1:], want)
+
+
+# ------------------------------------------------------------------ analytic known answers (unpinned libraries)
+def test_sampling_bijection():
+    for n in (1, 2, 3, 5, 64, 1000, 116_736):
+        p = sampling.perm_index(np.arange(n), n, 1234)
+        assert np.array_equal(np.sort(p), np.arange(n))
+    a = sampling.perm_index(np.arange(1000), 116_736, 7)
+    assert len(set(a.tolist())) == 1000 and a.max() < 116_736
+    assert not np.array_equal(a, sampling.perm_index(np.arange(1000), 116_736, 8))
+
+
+def test_look_at_and_unproject_plane():
+    # camera at origin looking down +z (elev 0, azim 0 in the reference's convention)
+    R, T = ocam.camera_RT([0.0, 0.0, 0.0], [0.0, 0.0])
+    view = np.array([[0.0, 0.0, 5.0]]) @ R + T
+    assert abs(abs(view[0, 2]) - 5.0) < 1e-5 and abs(view[0, 0]) < 1e-5
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-6)
+    # constant depth d: every un-projected point lies on the plane z_view = d, and re-projects to its pixel
+    H, W, d = 16, 28, 7.5
+    X = np.array([3.0, 1.0, -2.0])
+    R, T = ocam.camera_RT(X, [10.0, 135.0])
+    pts = ocam.unproject(np.full((H, W), d, np.float32), R, T)
+    v = pts.astype(np.float64) @ R + T
+    assert np.allclose(v[:, 2], d, atol=1e-4)
+    ndc_x, ndc_y = ocam.ndc_tables(H, W)
+    assert np.allclose(v[:, 0] / (v[:, 2] * ocam.TAN_HALF_FOV), ndc_x.reshape(-1), atol=1e-4)
+    assert np.allclose(v[:, 1] / (v[:, 2] * ocam.TAN_HALF_FOV), ndc_y.reshape(-1), atol=1e-4)
+    # the camera centre un-projects nothing: depth 0 -> the camera position itself
+    c = ocam.unproject(np.zeros((2, 2), np.float32), R, T)
+    assert np.allclose(c, X, atol=1e-5)
+
+
+def test_partial_point_cloud_counts():
+    H, W = 32, 57
+    rng = np.random.default_rng(0)
+    depth = rng.uniform(1, 100, (H, W)).astype(np.float32)
+    depth[rng.random((H, W)) < 0.2] = -1
+    R, T = ocam.camera_RT([0, 0, 0], [0, 0])
+    pts, nv = ocam.partial_point_cloud(depth, None, R, T, 0.05, 70.0, seed=3)
+    assert nv == int(((depth > -1) & (depth < 70)).sum())
+    assert len(pts) == int(nv * 0.05)
+    allp = ocam.unproject(depth, R, T)
+    # every kept point is one of the valid pixels, no pixel twice
+    keys = {tuple(p) for p in allp[((depth > -1) & (depth < 70)).reshape(-1)].tolist()}
+    got = [tuple(p) for p in pts.tolist()]
+    assert set(got) <= keys and len(set(got)) == len(got)
+
+
+def _box_room(h=4.0):
+    """Axis-aligned room [-h,h]^3 seen from inside: 12 triangles."""
+    v = np.array([[x, y, z] for x in (-h, h) for y in (-h, h) for z in (-h, h)], np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    f = np.array([t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))], np.int32)
+    return v, f
+
+
+def test_raster_plane_and_box_closed_form():
+    H, W = 24, 40
+    t = ocam.TAN_HALF_FOV
+    R, T = ocam.camera_RT([0, 0, 0], [0.0, 0.0])
+    v, f = _box_room(4.0)
+    z = orast.raster_zbuf(v, f, R, T, H, W, t)
+    assert (z > 0).all()                       # closed room: no background pixel, no cracks on shared edges
+    s = min(H, W)
+    col, row = np.meshgrid(np.arange(W), np.arange(H))
+    dx = (W - (2 * col + 1)) / s * t
+    dy = (H - (2 * row + 1)) / s * t
+    want = 4.0 / np.maximum(np.maximum(np.abs(dx), np.abs(dy)), 1.0)      # first wall hit along the pixel ray
+    assert np.allclose(z, want, rtol=1e-5)
+    # a wall crossing the near plane is clipped, not dropped: camera 0.3 from the x = +4 wall, looking along it
+    R2, T2 = ocam.camera_RT([3.7, 0, 0], [0.0, 0.0])
+    z2 = orast.raster_zbuf(v, f, R2, T2, H, W, t)
+    vis = z2[z2 > 0]
+    assert (vis > 0.5).all() and vis.min() < 1.0           # the wall is visible right up to the clip plane
+    assert (z2 < 0).any() and (z2 < 0).sum() < 0.5 * z2.size   # only the sliver nearer than z_clip is lost
+
+
+def test_mesh_ray_queries_on_cube():
+    v, f = _box_room(1.0)
+    assert mesh_rays.point_in_mesh([0.1, 0.2, -0.3], v, f)
+    assert not mesh_rays.point_in_mesh([1.5, 0.2, -0.3], v, f)
+    assert mesh_rays.axis_ray_counts([-3.0, 0.2, 0.1], v, f) == [0, 2, 0]
+    assert mesh_rays.segment_hits_mesh([0.1, 0.1, 0.1], [2.0, 0.1, 0.1], v, f)
+    assert not mesh_rays.segment_hits_mesh([0.1, 0.1, 0.1], [0.8, 0.1, 0.1], v, f)      # stops before the wall
+    assert not mesh_rays.segment_hits_mesh([0.1, 0.1, 0.1], [0.1, 0.1, 0.1], v, f)      # zero length
+
+
+def test_pose_lattice_order_and_values():
+    idx, poses = ocam.pose_lattice([-10.0, 0.0, -20.0], 3, 1, 4, 5, 8)
+    assert len(idx) == 3 * 1 * 4 * 5 * 8
+    assert idx[1].tolist() == [0, 0, 0, 0, 1] and idx[8].tolist() == [0, 0, 0, 1, 0]      # i-major ... azimuth fastest
+    k = np.nonzero((idx == [2, 0, 3, 2, 4]).all(1))[0][0]
+    assert np.allclose(poses[k], [-10 + 6, 3.3, -20 + 9, 0.0, 180.0])
