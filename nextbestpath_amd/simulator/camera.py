@@ -1,0 +1,210 @@
+"""Camera for the exploration rollout -- host-side mirror of the reference's ``Camera``
+(macarons/utility/macarons_utils.py:2193-2949) restricted to what the NBP drivers use.
+
+Differences that are deliberate:
+  * the pose lattice is index based (the reference keys a dict by ``str(list(np.int64 row))``,
+    which breaks under numpy >= 2);
+  * frames stay on the device (the reference torch.save()s every frame and torch.load()s it
+    back: nbp_planning.py:66,271-282); rendering is the HIP tile rasteriser, un-projection the
+    HIP kernel, both through libnbp_hip.so;
+  * the 4 interpolated frames of one move are rasterised in ONE launch.
+Pose arithmetic follows the reference line by line (fp32): lattice :2283-2327, interpolation
+and azimuth wrap :2590-2632, look-at :940-957 (pytorch3d look_at_view_transform conventions).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ..utility import hipops
+
+f32 = np.float32
+
+
+def _cartesian(elev_deg, azim_deg):
+    e, a = np.deg2rad(elev_deg), np.deg2rad(azim_deg)
+    return np.array([np.cos(e) * np.sin(a), np.sin(e), np.cos(e) * np.cos(a)])
+
+
+def camera_RT(X_cam, V_cam):
+    """get_camera_RT (mu:940-957): look from X_cam along -cartesian(1, -elev, 180 + azim).
+    pytorch3d convention: R columns = camera x / y / z axes (row vectors), T = -X R."""
+    X = np.asarray(X_cam, np.float64).reshape(3)
+    z = -_cartesian(-float(V_cam[0]), 180.0 + float(V_cam[1]))
+    z = z / max(np.linalg.norm(z), 1e-5)
+    up = np.array([0.0, 1.0, 0.0])
+    x = np.cross(up, z)
+    nx = np.linalg.norm(x)
+    if nx < 5e-3:                                  # looking straight up / down
+        y0 = np.cross(z, np.array([1.0, 0.0, 0.0]))
+        x = np.cross(y0 / np.linalg.norm(y0), z)
+        nx = np.linalg.norm(x)
+    x = x / nx
+    y = np.cross(z, x)
+    y = y / max(np.linalg.norm(y), 1e-5)
+    R = np.stack([x, y, z], axis=1)
+    return R.astype(f32), (-(X @ R)).astype(f32)
+
+
+class Camera:
+    def __init__(self, x_min, x_max, pose_l, pose_w, pose_h, pose_n_elev, pose_n_azim, n_interpolation_steps,
+                 zfar, image_height, image_width, device, gathering_factor=0.05, sensor_range=70.0, seed=0):
+        self.x_min_arg = np.asarray(x_min, f32)
+        self.x_min = self.x_min_arg + f32(3)             # mu:2230-2231 (kept for parity of attributes)
+        self.x_max = np.asarray(x_max, f32) - f32(3)
+        self.pose_l, self.pose_w, self.pose_h = int(pose_l), int(pose_w), int(pose_h)
+        self.pose_n_elev, self.pose_n_azim = int(pose_n_elev), int(pose_n_azim)
+        self.n_interpolation_steps = int(n_interpolation_steps)
+        self.zfar = zfar
+        self.image_height, self.image_width = int(image_height), int(image_width)
+        self.device = device
+        self.gathering_factor, self.sensor_range = gathering_factor, sensor_range
+        self.seed = int(seed)
+        self.l_step = self.h_step = 3
+        # ---- lattice (mu:2295-2320); flat order = cartesian product order (i, j, k, e, a)
+        self.dims = (self.pose_l, self.pose_w, self.pose_h, self.pose_n_elev, self.pose_n_azim)
+        # ---- state
+        self.cam_idx = None
+        self.X_cam = None
+        self.V_cam = None
+        self.R_cam = None
+        self.T_cam = None
+        self.cam_idx_history = []                       # list of 5-int tuples
+        self.X_cam_history = np.zeros((0, 3), f32)
+        self.V_cam_history = np.zeros((0, 2), f32)
+        self.visited = set()
+        self.n_frames_captured = 0
+        self.frames = []                                # last frames: (zbuf [H,W] device view, cam12 host row)
+        self._zbuf_ring = None
+        self._cursor = 0
+        self._traj_dev = torch.zeros(512, 3, dtype=torch.float32, device=device)
+        self._overflow = torch.zeros(1, dtype=torch.int32, device=device)
+
+    # ------------------------------------------------------------------ lattice
+    def pose_from_idx(self, idx):
+        """5-D pose (x, y, z, elev, azim) of lattice index (i, j, k, e, a) -- fp32 like mu:2315-2320."""
+        i, j, k, e, a = (int(v) for v in idx)
+        x_min = self.x_min_arg
+        return np.array([x_min[0] + f32(i * self.l_step), x_min[1] + f32(3.3), x_min[2] + f32(k * self.h_step),
+                         f32(-90.0) + (f32(180.0) * f32(1 + e)) / f32(self.pose_n_elev + 1),
+                         (f32(360.0) * f32(a)) / f32(self.pose_n_azim)], f32)
+
+    def get_pose_from_idx(self, idx):
+        idx = tuple(int(v) for v in idx)
+        return self.pose_from_idx(idx), (idx in self.visited)
+
+    def in_lattice(self, ijk):
+        return 0 <= ijk[0] < self.pose_l and 0 <= ijk[1] < self.pose_w and 0 <= ijk[2] < self.pose_h
+
+    def positions(self, elev_index=2):
+        """Position lattice used by the planner (scene.py:465 keeps elevation index 2 only;
+        long_term_utils.py:420-433 collapses to positions): (idx3 [P,3] int, xyz [P,3] fp32), i-major."""
+        idx = [(i, j, k) for i in range(self.pose_l) for j in range(self.pose_w) for k in range(self.pose_h)]
+        xyz = np.stack([self.pose_from_idx((i, j, k, elev_index, 0))[:3] for i, j, k in idx])
+        return np.asarray(idx, np.int64), xyz.astype(f32)
+
+    def get_neighboring_poses(self, pose_idx):
+        """mu:2473-2498: +-1 along x or z (clamped), same elevation, azimuth shifted by -3..3; sorted unique."""
+        i, j, k, e, a = (int(v) for v in pose_idx)
+        out = set()
+        for di, dk in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+            ni = min(max(i + di, 0), self.pose_l - 1)
+            nk = min(max(k + dk, 0), self.pose_h - 1)
+            if (ni, nk) == (i, k):
+                continue
+            for da in range(-3, 4):
+                out.add((ni, j, nk, e, (a + da) % self.pose_n_azim))
+        return sorted(out)
+
+    # ------------------------------------------------------------------ motion
+    def _interp(self, new_idx, step):
+        """Pose at interpolation step `step` of the move cam_idx -> new_idx (mu:2590-2632), fp32."""
+        n = self.n_interpolation_steps
+        old_pose = self.pose_from_idx(self.cam_idx if step < n else new_idx)
+        new_pose = self.pose_from_idx(new_idx)
+        if step == n:
+            off = f32(0.0)
+        elif self.cam_idx[4] == 0 and new_idx[4] == self.pose_n_azim - 1:
+            off = f32(-360.0)
+        elif self.cam_idx[4] == self.pose_n_azim - 1 and new_idx[4] == 0:
+            off = f32(360.0)
+        else:
+            off = f32(0.0)
+        X = old_pose[:3] + (new_pose[:3] - old_pose[:3]) * f32(step) / f32(n)
+        V = old_pose[3:] + (new_pose[3:] - old_pose[3:]) * f32(step) / f32(n)
+        V[1] = V[1] + off * f32(step) / f32(n)
+        return X.astype(f32), V.astype(f32)
+
+    def update_camera(self, new_cam_index, interpolation_step=None):
+        new_idx = tuple(int(v) for v in new_cam_index)
+        n = self.n_interpolation_steps
+        step = n if interpolation_step is None else int(interpolation_step)
+        if step > n:
+            raise ValueError("interpolation_step is too large")
+        if self.cam_idx is None:
+            self.cam_idx = new_idx
+        X, V = self._interp(new_idx, step)
+        if step == n:
+            self.cam_idx = new_idx
+            self.cam_idx_history.append(new_idx)
+            self.visited.add(new_idx)
+        self.X_cam, self.V_cam = X, V
+        self.X_cam_history = np.vstack([self.X_cam_history, X[None]])
+        self.V_cam_history = np.vstack([self.V_cam_history, V[None]])
+        self.R_cam, self.T_cam = camera_RT(X, V)
+
+    def initialize_camera(self, start_cam_idx):
+        self.update_camera(start_cam_idx)
+
+    # ------------------------------------------------------------------ rendering (device resident frames)
+    def _ring(self):
+        if self._zbuf_ring is None:
+            self._zbuf_ring = torch.empty(16, self.image_height, self.image_width, dtype=torch.float32,
+                                          device=self.device)
+        return self._zbuf_ring
+
+    def capture_images(self, mesh, cams_host):
+        """Rasterises len(cams_host) frames in one launch; cams_host [n,12] fp32 (R row-major, T)."""
+        n = len(cams_host)
+        ring = self._ring()
+        if self._cursor + n > 16:                       # explicit cursor: the 8 newest frames stay intact
+            self._cursor = 0
+        slot = self._cursor
+        self._cursor += n
+        out = ring[slot:slot + n]
+        cams = torch.from_numpy(np.ascontiguousarray(cams_host, f32)).to(self.device)
+        hipops.raster_zbuf(mesh.verts, mesh.faces, cams, self.image_height, self.image_width, bin_cap=mesh.bin_cap,
+                           out=out, overflow=self._overflow)
+        for i in range(n):
+            self.frames.append((out[i], cams_host[i].copy()))
+        self.frames = self.frames[-8:]
+        self.n_frames_captured += n
+        return out
+
+    def capture_image(self, mesh):
+        cam = np.concatenate([self.R_cam.reshape(-1), self.T_cam.reshape(-1)]).astype(f32)
+        return self.capture_images(mesh, cam[None])
+
+    def move_and_capture(self, mesh, next_idx):
+        """The 4 interpolated updates + captures of nbp_planning.py:269-274 with ONE raster launch."""
+        cams = []
+        for step in range(1, self.n_interpolation_steps + 1):
+            self.update_camera(next_idx, interpolation_step=step)
+            cams.append(np.concatenate([self.R_cam.reshape(-1), self.T_cam.reshape(-1)]))
+        return self.capture_images(mesh, np.asarray(cams, f32))
+
+    def frames_batch(self, which):
+        """Stacks frames by negative offsets (e.g. [-1] = current, [-5,-4,-3,-2] = supervision batch):
+        (depth [n,H,W] device, cams [n,12] device)."""
+        sel = [self.frames[w] for w in which]
+        z = sel[0][0].unsqueeze(0) if len(sel) == 1 else torch.stack([s[0] for s in sel])
+        cams = torch.from_numpy(np.stack([s[1] for s in sel]).astype(f32)).to(self.device)
+        return z.contiguous(), cams
+
+    def trajectory_points(self):
+        """X_cam_history on the device (for the trajectory channel)."""
+        n = len(self.X_cam_history)
+        if n > self._traj_dev.shape[0]:
+            self._traj_dev = torch.zeros(2 * n, 3, dtype=torch.float32, device=self.device)
+        self._traj_dev[:n] = torch.from_numpy(self.X_cam_history)
+        return self._traj_dev[:n]

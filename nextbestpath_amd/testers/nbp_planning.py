@@ -1,0 +1,250 @@
+"""Exploration rollout -- host-side mirror of next_best_path/testers/nbp_planning.py
+(compute_nbp_trajectory :23-361, test_nbp_planning :364-516): same entry-point names, same
+step order (S1-S14 of SURVEY.md section 3.1), same result-JSON schema; every tensor op of the
+step is a kernel of libnbp_hip.so and nothing touches the disk inside the loop.
+
+Per step: coverage (device counter, no sync) -> un-project the current frame -> fused 6-channel
+map accumulation + trajectory channel -> replan test (mesh segment query) -> NBP forward ->
+[replan: fusion, scoring, all-edges mask, host search] -> move (4 poses, ONE raster launch) ->
+un-project the 4 supervision frames.  The cloud and its size live on the device.
+
+Deliberate deviations (documented in DESIGN.md): the reference draws its 5 % sub-samples and
+random headings from unseeded global generators (note R of the survey) -- here they are seeded;
+obtain_depth's discarded outputs (long_term_utils.py:50-155) are not computed; the reference's
+unbound-`next_idx` crash when no path exists (nbp_planning.py:255-258) becomes "turn in place".
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from ..networks.nbp_model import NBP
+from ..simulator import scene as sim_scene
+from ..simulator.camera import Camera
+from ..utility import hipops
+from ..utility import utils as hu
+from ..utility.long_term_utils import LatticePlanner, compute_auc, line_segment_mesh_intersection
+
+N_POSES = 101            # range(101) at nbp_planning.py:60
+
+
+class RolloutState:
+    """Device-resident rollout buffers (cloud, counters, per-step coverage counts)."""
+
+    def __init__(self, device, capacity=3_400_000, grid=256):
+        self.device = device
+        self.cloud = torch.zeros(capacity, 3, dtype=torch.float32, device=device)
+        self.cloud_count = torch.zeros(1, dtype=torch.int64, device=device)
+        self.coverage_counts = torch.zeros(N_POSES, 2, dtype=torch.int32, device=device)
+        self.maps6 = torch.zeros(6, grid, grid, dtype=torch.float32, device=device)
+        self.net_in = torch.zeros(1, 5, grid, grid, dtype=torch.float32, device=device)
+
+
+def setup_test_camera(params, mesh, start_cam_idx, settings, device, seed=0):
+    """macarons/testers/scene.py:410-488: build the camera, step to the first collision-free
+    neighbour of the start pose, capture, then walk to the start pose capturing 4 frames."""
+    cam = Camera(settings.camera.x_min, settings.camera.x_max, settings.camera.pose_l, settings.camera.pose_w,
+                 settings.camera.pose_h, settings.camera.pose_n_elev, settings.camera.pose_n_azim,
+                 params.n_interpolation_steps, params.zfar, params.image_height, params.image_width, device,
+                 params.gathering_factor, params.sensor_range, seed=seed)
+    start = tuple(int(v) for v in start_cam_idx)
+    neigh = cam.get_neighboring_poses(start)
+    segs = torch.tensor([np.concatenate([cam.pose_from_idx(n)[:3], cam.pose_from_idx(start)[:3]]) for n in neigh],
+                        dtype=torch.float32, device=device)
+    hit = hipops.segments_hit_mesh(mesh.verts, mesh.faces, segs).cpu().numpy()
+    free = [n for n, h in zip(neigh, hit) if not h]
+    first = free[0] if free else neigh[0]          # the reference raises NameError when none is free
+    cam.initialize_camera(first)
+    cam.capture_image(mesh)
+    cam.move_and_capture(mesh, start)
+    return cam
+
+
+def compute_nbp_trajectory(params, nbp, camera, gt_scene_pc, mesh, mesh_for_check, n_pieces, y_bins, device,
+                           test_resolution=0.05, use_perfect_depth_map=True, n_poses=N_POSES, state=None, seed=0,
+                           hooks=None):
+    t1 = time.time()
+    nbp.eval()
+    S, V = 256, 64
+    grid_range = (-40, 40)
+    st = state or RolloutState(device)
+    st.cloud_count.zero_()
+    st.coverage_counts.zero_()
+    planner = LatticePlanner(camera, mesh_for_check, device, V, S, grid_range)
+    rng = random.Random(seed)
+    gt = gt_scene_pc.contiguous()
+    bbox = (gt.min(0).values.tolist(), gt.max(0).values.tolist())
+    path, path_record = [], 0
+    collision_list, passable_list = [], []
+    idx_history = []
+    step_seed = seed * 1_000_003
+
+    for pose_i in range(n_poses):
+        # S2: coverage of the cloud built so far (device counter; read back after the loop)
+        hipops.coverage_count(gt, st.cloud, n_dev=st.cloud_count, n=st.cloud.shape[0], weight=2,
+                              seed=step_seed + 7 * pose_i, threshold=1.0, bbox=bbox, out=st.coverage_counts[pose_i])
+        # S4: un-project the current frame, append to the cloud
+        depth, cams = camera.frames_batch([-1])
+        hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
+                                params.sensor_range, seed=step_seed + 11 * pose_i)
+        pose, _ = camera.get_pose_from_idx(camera.cam_idx)
+        # S6-S7: NBP input = 4 height slabs + trajectory (one fused pass over the cloud)
+        hu.accumulate_step_maps(st.cloud, pose, y_bins, S, grid_range, n_dev=st.cloud_count, out=st.maps6)
+        traj2d = hu.transform_points_to_n_pieces(camera.trajectory_points(), pose)
+        traj_img = hu.map_points_to_n_imgs(traj2d, (S, S), grid_range)
+        st.net_in[0, :4] = st.maps6[:4]
+        st.net_in[0, 4] = traj_img[0]
+        # S8: replan?
+        if pose_i == 0 or path is None or path_record + 1 > len(path):
+            replan = True
+        else:
+            nxt = camera.pose_from_idx(path[path_record])
+            replan = line_segment_mesh_intersection(pose[:3], nxt[:3], mesh_for_check)
+            if replan:
+                cur3, nxt3 = list(camera.cam_idx[:3]), list(path[path_record][:3])
+                collision_list += [[cur3, nxt3], [nxt3, cur3], list(path[-1][:3])]
+        if len(idx_history) >= 2:
+            p1, p2 = list(idx_history[-1][:3]), list(idx_history[-2][:3])
+            passable_list += [[p1, p2], [p2, p1]]
+        # S9: one NBP forward per step (the reference also runs it when it does not replan, :252)
+        with torch.no_grad():
+            out1, out2 = nbp(st.net_in)
+        if replan:
+            path_record = 0
+            path = planner.replan(pose, out1, out2, st.maps6, traj_img, collision_list, passable_list)
+        # S10: next pose
+        if not path or path_record >= len(path):
+            next_idx = list(camera.cam_idx)
+            next_idx[4] = rng.randrange(8)
+            path = []
+        else:
+            next_idx = list(path[path_record])
+            if tuple(next_idx) in {tuple(h) for h in idx_history}:
+                next_idx[4] = rng.randrange(8)
+        idx_history.append(tuple(camera.cam_idx))
+        # S11: move (4 interpolated poses, one raster launch); S14: un-project the supervision frames
+        camera.move_and_capture(mesh, next_idx)
+        depth, cams = camera.frames_batch([-5, -4, -3, -2])
+        hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
+                                params.sensor_range, seed=step_seed + 11 * pose_i + 5)
+        path_record += 1
+        if hooks and "step" in hooks:
+            hooks["step"](pose_i)
+
+    counts = st.coverage_counts[:n_poses].cpu().numpy()
+    G = np.float32(len(gt))
+    coverage_evolution = [float(np.float32(c) / G) for c in counts[:, 0]]
+    n_cloud = int(st.cloud_count.item())
+    t2 = time.time()
+    print("Time: ", t2 - t1)
+    return coverage_evolution, camera.X_cam_history, camera.V_cam_history, st.cloud[:n_cloud], None
+
+
+def load_params(path):
+    """macarons/utility/utils.py:44-83: JSON -> attribute object, `_section` keys flattened away."""
+    with open(path) as fh:
+        raw = json.load(fh)
+
+    def flat(d, out):
+        for k, v in d.items():
+            if isinstance(v, dict) and k.startswith("_"):
+                flat(v, out)
+            else:
+                out[k] = v
+        return out
+
+    class Params:
+        pass
+
+    p = Params()
+    for k, v in flat(raw, {}).items():
+        setattr(p, k, v)
+    return p
+
+
+def list_runs(dataset, params):
+    """Flattened (scene x start pose) list: the unit of scene-parallel sharding."""
+    runs = []
+    for si in range(len(dataset)):
+        sd = dataset[si]
+        st = sim_scene.Settings(sd["settings"], params.scene_scale_factor)
+        for k in range(len(st.camera.start_positions)):
+            runs.append((si, k))
+    return runs
+
+
+def run_one(params, nbp, dataset, run, device, test_resolution=0.05, state=None, n_poses=N_POSES, seed=0):
+    si, k = run
+    sd = dataset[si]
+    settings = sim_scene.Settings(sd["settings"], params.scene_scale_factor)
+    mesh = sim_scene.load_scene(os.path.join(dataset.data_path, sd["scene_name"], sd["obj_name"]),
+                                params.scene_scale_factor, device)
+    y_bins = sim_scene.y_bins_for(mesh.verts_host, 4)
+    gt = sim_scene.sample_gt_surface(mesh.verts_host, mesh.faces_host, params.n_gt_surface_points,
+                                     settings.scene.x_min - np.float32(0.2), settings.scene.x_max + np.float32(0.2),
+                                     test_resolution * params.scene_scale_factor, seed=seed)
+    gt_dev = torch.from_numpy(gt).to(device)
+    camera = setup_test_camera(params, mesh, settings.camera.start_positions[k], settings, device, seed=seed)
+    cov, X, Vh, pc, _ = compute_nbp_trajectory(params, nbp, camera, gt_dev, mesh, mesh, 4, y_bins, device,
+                                               test_resolution, True, n_poses=n_poses, state=state, seed=seed)
+    return {"scene": sd["scene_name"], "start": k, "coverage": cov, "X_cam_history": X.tolist(),
+            "V_cam_history": Vh.tolist(), "n_points": int(pc.shape[0])}
+
+
+def test_nbp_planning(params_file, model_file, results_json_file, numGPU, test_scenes, test_resolution=0.05,
+                      use_perfect_depth_map=False, compute_collision=False, load_json=False, dataset_path=None,
+                      nbp_weights=None, configs_dir=None, results_dir=None, n_poses=N_POSES, seed=8, torch_seed=9):
+    """Same arguments as the reference (nbp_planning.py:364-374).  Under torchrun the flattened
+    (scene, start pose) runs are sharded round-robin over the ranks and the coverage curves are
+    gathered with ONE all_gather over RCCL (backend "nccl" on ROCm; "gloo" on CPU-only hosts)."""
+    from ..parallel_rollout import gather_results, init_distributed, shard
+    here = os.path.dirname(os.path.abspath(__file__))
+    configs_dir = configs_dir or os.path.join(here, "../../configs/macarons")
+    results_dir = results_dir or os.path.join(here, "../../data")
+    params = load_params(os.path.join(configs_dir, params_file))
+    params.test_scenes = test_scenes
+    rank, world, local_rank = init_distributed()
+    device = torch.device("cuda", local_rank if world > 1 else numGPU)
+    torch.cuda.set_device(device)
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(torch_seed)
+    nbp = NBP()
+    if nbp_weights and os.path.exists(nbp_weights):
+        ck = torch.load(nbp_weights, map_location="cpu")
+        nbp.load_state_dict(ck["model_state_dict"])
+    else:
+        from ..utility.synthetic import make_nbp_state_dict
+        print("[nbp] no checkpoint at", nbp_weights, "-> seeded synthetic weights")
+        nbp.load_state_dict(make_nbp_state_dict(torch_seed))
+    nbp.to(device).eval()
+    dataset = sim_scene.SceneDataset(dataset_path, test_scenes)
+    runs = list_runs(dataset, params)
+    mine = shard(runs, rank, world)
+    state = RolloutState(device)
+    results = []
+    with torch.no_grad():
+        for run in mine:
+            res = run_one(params, nbp, dataset, run, device, test_resolution, state, n_poses,
+                          seed=seed + 1000 * run[0] + run[1])
+            res["run_id"] = runs.index(run)
+            results.append(res)
+    gathered = gather_results(results, runs, rank, world, device, n_poses)
+    if rank == 0:
+        out = {}
+        for r in gathered:
+            si, k = runs[r["run_id"]]
+            rec = {"coverage": r["coverage"], "auc": r["auc"]}
+            for key in ("X_cam_history", "V_cam_history"):      # histories of other ranks stay in their part files
+                if key in r:
+                    rec[key] = r[key]
+            out.setdefault(dataset[si]["scene_name"], {})[str(k)] = rec
+        os.makedirs(results_dir, exist_ok=True)
+        with open(os.path.join(results_dir, results_json_file), "w") as fh:
+            json.dump(out, fh)
+        print("Saved data about test losses in", results_json_file)
+        print("All trajectories computed.")
+    return gathered

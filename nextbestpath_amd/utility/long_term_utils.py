@@ -1,0 +1,142 @@
+"""Planner glue -- mirrors of next_best_path/utility/long_term_utils.py for the NBP path, same
+function names and argument meaning; the per-pixel / per-edge Python loops of the reference are
+replaced by one kernel launch each (csrc/nbp_planner.hip, csrc/nbp_sim.hip)."""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+
+from . import hipops, planner_host
+from .utils import _pose_xyz
+
+
+def bresenham_line(x0, y0, x1, y1):
+    """ref :277-298 (pure integer Python; kept for API parity, the kernels inline the same loop)."""
+    pts = []
+    dx, dy = abs(x1 - x0), abs(y1 - y0)
+    sx, sy = (1 if x0 < x1 else -1), (1 if y0 < y1 else -1)
+    err = dx - dy
+    while True:
+        pts.append((x0, y0))
+        if x0 == x1 and y0 == y1:
+            return pts
+        e2 = 2 * err
+        if e2 > -dy:
+            err -= dy
+            x0 += sx
+        if e2 < dx:
+            err += dx
+            y0 += sy
+
+
+def line_across_image_pixel(point_1, point_2, camera_current_pose, grid_size, grid_range, layout_image, device=None):
+    """ref :300-331 -- True iff the edge is blocked (endpoint off-image or >= 2 obstacle pixels)."""
+    pos = torch.stack([point_1[:3], point_2[:3]]).float().contiguous()
+    ed = torch.tensor([[0, 1]], dtype=torch.int32, device=pos.device)
+    obst = layout_image.reshape(grid_size[0], grid_size[1]).float().contiguous()
+    out = hipops.edges_blocked(obst, _pose_xyz(camera_current_pose), pos, ed, grid_range)
+    return bool(out.item())
+
+
+def line_segment_mesh_intersection(start_point, end_point, mesh):
+    """macarons_utils.py:120-151 on a DeviceMesh (brute-force GPU ray/triangle, no rtree)."""
+    a = torch.as_tensor(start_point, dtype=torch.float32).reshape(3)
+    b = torch.as_tensor(end_point, dtype=torch.float32).reshape(3)
+    seg = torch.cat([a, b]).reshape(1, 6).to(mesh.verts.device)
+    return bool(hipops.segments_hit_mesh(mesh.verts, mesh.faces, seg).item())
+
+
+def check_camera_in_mesh(mesh_for_check, camera_position):
+    """ref :158-170: inside iff the +Y, +X, +Z ray hit counts are all odd."""
+    p = torch.as_tensor(camera_position, dtype=torch.float32).reshape(1, 3).to(mesh_for_check.verts.device)
+    c = hipops.axis_ray_counts(mesh_for_check.verts, mesh_for_check.faces, p)[0].tolist()
+    return all(v % 2 == 1 for v in c)
+
+
+def calculate_coverage_percentage(pc1, pc2, threshold=1, weight=2, seed=0):
+    """ref :457-468 (returns a Python float; one device sync, like the reference's .item())."""
+    if len(pc2) == 0:
+        return 0.0
+    out = hipops.coverage_count(pc1.contiguous(), pc2.contiguous(), weight=weight, seed=seed, threshold=threshold)
+    cnt = int(out[0].item())
+    return float(np.float32(cnt) / np.float32(len(pc1)))
+
+
+def compute_auc(y, dx=1 / 40):
+    """ref :488-490."""
+    y = np.asarray(y, np.float64)
+    trap = getattr(np, "trapezoid", None) or np.trapz
+    return float(trap(y, dx=dx) + y[0] * dx / 2.0)
+
+
+class LatticePlanner:
+    """Batched replacement of the replanning block of compute_nbp_trajectory
+    (next_best_path/testers/nbp_planning.py:158-249) + generate_Dijkstra_path (ref :334-418).
+
+    Per replan: 3 kernel launches (obstacle fusion, candidate scoring, all-edges Bresenham) and one
+    device->host copy, then the reference's host logic (stable sort, uniform-cost search with
+    heapq tie-breaking, heading choice, first-edge check against the real mesh)."""
+
+    def __init__(self, camera, mesh, device, value_size=64, layout_size=256, grid_range=(-40, 40)):
+        self.camera, self.mesh, self.device = camera, mesh, device
+        self.V, self.S, self.grid_range = value_size, layout_size, grid_range
+        self.idx3, self.xyz = camera.positions()
+        self.node_index = {tuple(t): n for n, t in enumerate(self.idx3.tolist())}
+        self.pos_dev = torch.from_numpy(self.xyz).to(device)
+        edges = []
+        for n, (i, j, k) in enumerate(self.idx3.tolist()):
+            for nb in ((i + 1, j, k), (i - 1, j, k), (i, j, k + 1), (i, j, k - 1)):
+                if nb in self.node_index:
+                    edges.append((n, self.node_index[nb]))
+        self.edges = edges
+        self.edge_id = {e: q for q, e in enumerate(edges)}
+        self.edges_dev = torch.tensor(edges, dtype=torch.int32, device=device)
+
+    def replan(self, pose, out1, out2, maps6, traj_img, collision_list, passable_list, check_first_edge=True):
+        """Returns the path as a list of [i,j,k,2,h] (first node dropped, like ref :416) or None."""
+        cam = self.camera
+        obst, fullproj = hipops.fuse_obstacle(out2.reshape(self.S, self.S), maps6, traj_img.reshape(self.S, self.S))
+        skip_h = np.array([list(t) in collision_list for t in self.idx3.tolist()], dtype=np.uint8)
+        skip = torch.from_numpy(skip_h).to(self.device) if skip_h.any() else None
+        o1 = out1.reshape(8, self.V, self.V)
+        valid, cell, score = hipops.score_candidates(self.pos_dev, pose, o1, fullproj, skip, self.grid_range)
+        blocked = hipops.edges_blocked(obst, pose, self.pos_dev, self.edges_dev, self.grid_range)
+        # one synchronising copy for everything the host logic needs
+        valid_h, score_h = valid.cpu().numpy().astype(bool), score.cpu().numpy()
+        blocked_h = blocked.cpu().numpy().astype(bool)
+        out1_h = o1.cpu().numpy()
+        cand = [int(i) for i in np.nonzero(valid_h)[0]]
+        cand.sort(key=lambda i: score_h[i], reverse=True)            # stable, descending (ref :233)
+        start = tuple(cam.cam_idx[:3])
+        hist = np.asarray(cam.cam_idx_history, np.int64).reshape(-1, 5)
+
+        def passable(a, b):
+            ab = [list(a), list(b)]
+            if ab in passable_list:
+                return True
+            return (not blocked_h[self.edge_id[(self.node_index[a], self.node_index[b])]]) and ab not in collision_list
+
+        tree, tree_version = None, -1
+        path = None
+        for ci in cand:
+            if tree is None or tree_version != len(collision_list):
+                tree = planner_host.dijkstra_tree(self.node_index, start, passable)
+                tree_version = len(collision_list)
+            nodes = planner_host.path_from_tree(tree, tuple(self.idx3[ci].tolist()))
+            if nodes is None:
+                path = None
+                continue
+            full = planner_host.choose_headings(nodes, self.xyz, self.node_index, pose, out1_h, hist, self.V,
+                                                self.grid_range)
+            path = full[1:]
+            if len(path) > 0:
+                if not check_first_edge:
+                    break
+                nxt = cam.pose_from_idx(path[0])
+                if not line_segment_mesh_intersection(pose[:3], nxt[:3], self.mesh):
+                    break
+                collision_list.append([list(cam.cam_idx[:3]), path[0][:3]])
+                collision_list.append([path[0][:3], list(cam.cam_idx[:3])])
+        return path

@@ -1,0 +1,71 @@
+"""GPU: end-to-end exploration rollout on a procedural maze (short), invariants + determinism."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    from nextbestpath_amd.simulator.mesh import make_maze_scene
+    d = tmp_path_factory.mktemp("synth")
+    for i in range(2):
+        make_maze_scene(str(d / f"maze_{i:02d}"), seed=i, cells=8, size=4.8, height=1.2, tess=0.3)
+    return str(d)
+
+
+def _net(nbp_weights):
+    from nextbestpath_amd.networks.nbp_model import NBP
+    net = NBP()
+    net.load_state_dict(nbp_weights)
+    return net.cuda().eval()
+
+
+def test_short_rollout_invariants_and_determinism(hip, dataset, nbp_weights):
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.testers import nbp_planning as tp
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    ds = sc.SceneDataset(dataset)
+    net = _net(nbp_weights)
+    runs = tp.list_runs(ds, params)
+    assert len(runs) == 2
+    n_poses = 8
+    with torch.no_grad():
+        a = tp.run_one(params, net, ds, runs[0], torch.device("cuda"), n_poses=n_poses, seed=5)
+        b = tp.run_one(params, net, ds, runs[0], torch.device("cuda"), n_poses=n_poses, seed=5)
+    cov = a["coverage"]
+    assert len(cov) == n_poses and cov[0] == 0.0                       # empty cloud at step 0 (ref :457-460)
+    assert all(0.0 <= c <= 1.0 for c in cov) and cov[-1] > 0.0
+    X = np.asarray(a["X_cam_history"])
+    assert X.shape == (1 + 4 + 4 * n_poses, 3)                          # 1 init + 4 first move + 4 per step
+    step = np.linalg.norm(np.diff(X[4::4], axis=0), axis=1)            # lattice moves: 0 (turn) or 3 units
+    assert np.all((np.abs(step) < 1e-4) | (np.abs(step - 3.0) < 1e-4))
+    assert a["n_points"] > 1000
+    assert a["coverage"] == b["coverage"] and a["X_cam_history"] == b["X_cam_history"]     # seeded => bit identical
+
+
+def test_entry_point_json_schema(hip, dataset, tmp_path):
+    cfg = {"numGPU": 0, "dataset_path": dataset, "test_scenes": [], "params_name":
+           "macarons_default_training_config.json", "model_name": "x.pth", "results_json_name": "out_test_entry.json",
+           "test_resolution": 0.05, "use_perfect_depth_map": True, "compute_collision": False, "load_json": False,
+           "random_seed": 8, "torch_seed": 9, "nbp_weights": "./weights/none.pth"}
+    cfg_path = os.path.join(ROOT, "configs/test/_pytest_entry.json")
+    with open(cfg_path, "w") as fh:
+        json.dump(cfg, fh)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "test_nbp_planning.py"), "-c", "_pytest_entry.json",
+                            "--n-poses", "3"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out = json.load(open(os.path.join(ROOT, "data", "out_test_entry.json")))
+        assert sorted(out) == ["maze_00", "maze_01"]
+        rec = out["maze_00"]["0"]
+        assert set(rec) >= {"coverage", "X_cam_history", "V_cam_history"} and len(rec["coverage"]) == 3
+    finally:
+        os.remove(cfg_path)
