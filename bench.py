@@ -1,18 +1,21 @@
 #!/usr/bin/env python
-"""bench.py -- NextBestPath hot path on MI355X.
+"""bench.py -- NextBestPath exploration hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 256] [--batch 1]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the per-step device hot path of one exploration rollout
-(BASELINE.json configs[1]: AiMDoom_simple-like rollout, 256x256 grid, B=1, fp32):
-the fused map accumulation over the rollout's accumulated point cloud + one NBP forward.
-Inputs are synthetic and resident in HBM before the timed region.  Rollouts are independent
-(SURVEY.md 8e), so N ranks run N independent rollouts: weak scaling, no data-path collective.
+One "step" = one exploration step of one rollout (S1-S14 of SURVEY.md section 3.1; BASELINE.json
+configs[1]: AiMDoom_simple-like scene, 256x256 grid, B=1, fp32): coverage of the cloud so far,
+un-projection of 5 depth frames (256x456) into the cloud, fused map accumulation, ONE NBP forward,
+replanning when the path is exhausted / blocked, 4 rasterised frames along the move.  The scene is
+a seeded procedural maze (no AiMDoom data offline), the NBP weights are seeded synthetic; mesh,
+weights and buffers are resident in HBM before the timed region.  Rollouts are independent
+(SURVEY.md 8e): N ranks run N rollouts on N scenes -> weak scaling, no data-path collective.
 
-Prints ONE JSON line (rank 0) with the `roofline` object for the dominant kernel (the fp32
-MFMA implicit-GEMM convolution) and the `cpu_baseline` object (the reference's arithmetic --
-stock PyTorch CPU convolutions on the same weights -- timed on this box's host cores).
+Rank 0 prints ONE JSON line.  `value` = exploration steps/s over all ranks; `nbp_maps_per_s` = NBP
+forwards/s (the second half of BASELINE.json's metric); `roofline` = the dominant kernel (fp32 MFMA
+implicit-GEMM convolution) timed live with HIP events on the launch stream; `roofline_scatter` =
+the HBM-bound map accumulation; `cpu_baseline` = the reference's arithmetic on the host cores.
 """
 from __future__ import annotations
 
@@ -21,6 +24,7 @@ import ctypes as C
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,7 +33,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_HBM_GBS = 8000.0
 TILE_NAMES = {1: "igemm_conv_kernel<2,2,2,2>(128x128)", 2: "igemm_conv_kernel<4,1,2,2>(256x64)",
               3: "igemm_conv_kernel<4,1,2,1>(256x32)", 4: "igemm_conv_kernel<2,2,2,1>(128x64)",
@@ -39,27 +43,35 @@ TILE_NAMES = {1: "igemm_conv_kernel<2,2,2,2>(128x128)", 2: "igemm_conv_kernel<4,
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--batch", type=int, default=1, help="concurrent rollouts batched per forward on each GPU")
-    ap.add_argument("--points", type=int, default=1_500_000, help="accumulated cloud size (mid-rollout)")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--layers", action="store_true", help="print the per-layer timing table to stderr")
+    ap.add_argument("--layers", action="store_true", help="per-layer timing table to stderr")
+    ap.add_argument("--faces", choices=["simple", "hard"], default="simple")
     return ap.parse_args()
 
 
-def timed_layers(net_packed, x, out1, out2, ws):
+def timed_layers(packed, x, out1, out2, ws):
     from nextbestpath_amd import _lib
-    L = _lib.lib()
     arr = (_lib.LayerTiming * 128)()
     n = C.c_int(0)
     B, _, S, _ = x.shape
-    rc = L.nbp_forward_timed_f32(net_packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(),
-                                 ws.data_ptr(), ws.numel(), _lib.current_stream(), arr, 128, C.byref(n))
+    rc = _lib.lib().nbp_forward_timed_f32(packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _lib.current_stream(), arr, 128, C.byref(n))
     _lib.check(rc, "nbp_forward_timed_f32")
     return [dict(name=a.name.decode(), flops=a.flops, ms=a.ms, tile=a.tile, split_k=a.split_k, M=a.M, N=a.N, K=a.K)
             for a in arr[:n.value]]
+
+
+def ev_time(fn, reps=20):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def main():
@@ -79,36 +91,45 @@ def main():
     from nextbestpath_amd import _lib
     from nextbestpath_amd.networks import packing
     from nextbestpath_amd.networks.nbp_model import NBP
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.simulator.mesh import make_maze_scene
+    from nextbestpath_amd.testers import nbp_planning as tp
+    from nextbestpath_amd.utility import hipops
     from nextbestpath_amd.utility import utils as hu
-    from nextbestpath_amd.utility.synthetic import make_count_maps, make_nbp_state_dict, make_point_cloud
+    from nextbestpath_amd.utility.synthetic import make_nbp_state_dict
 
     L = _lib.lib()
-    S, B = args.size, args.batch
+    S = 256
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    tmp = tempfile.mkdtemp(prefix=f"nbp_bench_r{rank}_")
+    if args.faces == "hard":
+        make_maze_scene(os.path.join(tmp, "maze"), seed=100 + rank, cells=12, size=7.2, height=1.2, tess=0.15)
+    else:
+        make_maze_scene(os.path.join(tmp, "maze"), seed=100 + rank, cells=10, size=6.0, height=1.2, tess=0.25)
+    ds = sc.SceneDataset(tmp)
+    settings = sc.Settings(ds[0]["settings"], params.scene_scale_factor)
+    mesh = sc.load_scene(os.path.join(tmp, "maze", ds[0]["obj_name"]), params.scene_scale_factor, dev)
+    y_bins = sc.y_bins_for(mesh.verts_host, 4)
+    gt = torch.from_numpy(sc.sample_gt_surface(mesh.verts_host, mesh.faces_host, params.n_gt_surface_points,
+                                               settings.scene.x_min - np.float32(0.2),
+                                               settings.scene.x_max + np.float32(0.2), 0.5, seed=rank)).to(dev)
     sd = make_nbp_state_dict(9)
     net = NBP()
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()
-    x = make_count_maps(B, S, seed=100 + rank).to(dev)
-    pc = make_point_cloud(args.points, seed=200 + rank, extent=0.21 * S).to(dev)
-    pose = torch.tensor([0.0, 13.3, 0.0, 0.0, 0.0])
-    ybins = torch.arange(0.5, 29.5 + 7.25, 7.25)
-    rng = (-40 * S / 256, 40 * S / 256)
-
-    def step():
-        maps = hu.accumulate_step_maps(pc, pose, ybins, S, rng)
-        with torch.no_grad():
-            o1, o2 = net(x)
-        return maps, o1, o2
+    cam = tp.setup_test_camera(params, mesh, settings.camera.start_positions[0], settings, dev, seed=rank)
+    ro = tp.Rollout(params, net, cam, gt, mesh, mesh, y_bins, dev, seed=8 + rank)
 
     for _ in range(args.warmup):
-        step()
+        ro.step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    replans0 = ro.n_replans
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        ro.step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -119,24 +140,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- per-kernel durations with HIP events on the launch stream (rank 0, N=1 semantics)
-    roofline = None
+    roofline = scatter = None
     stage = {}
-    layer_rows = []
     if rank == 0:
+        # ---- the dominant kernel, per launch, with HIP events on the launch stream
+        x = ro.st.net_in
         packed = net._ensure_packed(dev)
-        o1 = torch.empty(B, 8, S // 4, S // 4, device=dev)
-        o2 = torch.empty(B, 1, S, S, device=dev)
-        ws = packing._workspace(B, S, dev)
-        reps = 5
-        acc = {}
+        o1 = torch.empty(1, 8, S // 4, S // 4, device=dev)
+        o2 = torch.empty(1, 1, S, S, device=dev)
+        ws = packing._workspace(1, S, dev)
+        reps, acc = 5, {}
         for r in range(reps + 1):
             rows = timed_layers(packed, x, o1, o2, ws)
-            if r == 0:
-                continue        # warm
-            for i, row in enumerate(rows):
-                a = acc.setdefault(i, dict(row, ms=0.0))
-                a["ms"] += row["ms"] / reps
+            if r:
+                for i, row in enumerate(rows):
+                    acc.setdefault(i, dict(row, ms=0.0))["ms"] += row["ms"] / reps
         layer_rows = [acc[i] for i in sorted(acc)]
         by_tile = {}
         for row in layer_rows:
@@ -146,52 +164,62 @@ def main():
         dom = max(by_tile, key=lambda k: by_tile[k]["flops"])
         d = by_tile[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        conv_flops = sum(r["flops"] for r in layer_rows if r["tile"] > 0)
-        conv_ms = sum(r["ms"] for r in layer_rows if r["tile"] > 0)
+        cf = sum(r["flops"] for r in layer_rows if r["tile"] > 0)
+        cm = sum(r["ms"] for r in layer_rows if r["tile"] > 0)
         roofline = {"bound": "mfma", "kernel": TILE_NAMES[dom], "achieved": round(achieved, 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": None, "launches_per_forward": d["launches"],
-                    "avg_launch_ms": round(d["ms"] / d["launches"], 5),
-                    "flops_per_launch": d["flops"] / d["launches"],
-                    "all_igemm_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
-                    "all_igemm_frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
-        # scatter kernel: HIP events around the fused map accumulation
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        hu.accumulate_step_maps(pc, pose, ybins, S, rng)
-        e0.record()
-        for _ in range(20):
-            hu.accumulate_step_maps(pc, pose, ybins, S, rng)
-        e1.record(); torch.cuda.synchronize()
-        ms_scatter = e0.elapsed_time(e1) / 20
-        alg_bytes = 12 * args.points + 6 * S * S * 4
-        stage["map_accumulate"] = {"ms": round(ms_scatter, 4), "points": args.points,
-                                   "algorithmic_bytes": alg_bytes,
-                                   "achieved_GBps": round(alg_bytes / (ms_scatter * 1e-3) / 1e9, 1),
-                                   "frac_of_hbm_peak": round(alg_bytes / (ms_scatter * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-        e0.record()
-        for _ in range(20):
-            with torch.no_grad():
-                net(x)
-        e1.record(); torch.cuda.synchronize()
-        ms_fwd = e0.elapsed_time(e1) / 20
-        fl = L.nbp_forward_flops(B, S)
-        stage["nbp_forward"] = {"ms": round(ms_fwd, 4), "maps_per_s": round(B / (ms_fwd * 1e-3), 2),
-                                "tflops": round(fl / (ms_fwd * 1e-3) / 1e12, 3),
-                                "frac_of_f32_mfma_peak": round(fl / (ms_fwd * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                    "avg_launch_ms": round(d["ms"] / d["launches"], 5), "flops_per_launch": d["flops"] / d["launches"],
+                    "note": "avg_launch_ms brackets the igemm launch plus its split-K reduce (event pair per layer)",
+                    "all_igemm_tflops": round(cf / (cm * 1e-3) / 1e12, 3),
+                    "all_igemm_frac": round(cf / (cm * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
         if args.layers:
             for r in layer_rows:
                 tf = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0
                 print(f'{r["name"]:24s} M={r["M"]:7d} N={r["N"]:5d} K={r["K"]:5d} tile={r["tile"]:2d} '
                       f'sk={r["split_k"]:2d} {r["ms"]*1e3:9.1f} us {tf:7.2f} TF', file=sys.stderr)
+        # ---- stage timings on the state the rollout reached
+        n_pts = int(ro.st.cloud_count.item())
+        pose, _ = cam.get_pose_from_idx(cam.cam_idx)
+        ms_fwd = ev_time(lambda: net(x))
+        fl = L.nbp_forward_flops(1, S)
+        stage["nbp_forward"] = {"ms": round(ms_fwd, 4), "maps_per_s": round(1e3 / ms_fwd, 2),
+                                "tflops": round(fl / (ms_fwd * 1e-3) / 1e12, 3),
+                                "frac_of_f32_mfma_peak": round(fl / (ms_fwd * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+        ms_sc = ev_time(lambda: hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=ro.st.cloud_count,
+                                                        out=ro.st.maps6))
+        alg = 12 * n_pts + 6 * S * S * 4
+        scatter = {"bound": "hbm", "kernel": "map_accumulate_kernel", "achieved": round(alg / (ms_sc * 1e-3) / 1e9, 1),
+                   "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(alg / (ms_sc * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                   "traffic": None, "points": n_pts, "algorithmic_bytes": alg, "ms": round(ms_sc, 4)}
+        cams4 = torch.from_numpy(np.stack([f[1] for f in cam.frames[-4:]])).to(dev)
+        zb = torch.empty(4, params.image_height, params.image_width, device=dev)
+        ms_r = ev_time(lambda: hipops.raster_zbuf(mesh.verts, mesh.faces, cams4, params.image_height, params.image_width,
+                                                  bin_cap=mesh.bin_cap, out=zb))
+        stage["raster_4_frames"] = {"ms": round(ms_r, 4), "faces": int(mesh.faces.shape[0]),
+                                    "frames_per_s": round(4e3 / ms_r, 1)}
+        scratch = torch.zeros(200_000, 3, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 
-    # ---- CPU baseline: the reference's arithmetic (stock PyTorch CPU convs) on the host cores
+        def unproj():
+            cnt.zero_()
+            hipops.unproject_append(zb, None, cams4, scratch, cnt, 0.05, 70.0, seed=1)
+        stage["unproject_4_frames"] = {"ms": round(ev_time(unproj), 4)}
+        bbox = (gt.min(0).values.tolist(), gt.max(0).values.tolist())
+        out = torch.zeros(2, dtype=torch.int32, device=dev)
+        stage["coverage"] = {"ms": round(ev_time(lambda: hipops.coverage_count(gt, ro.st.cloud, n_dev=ro.st.cloud_count,
+                                                                                n=ro.st.cloud.shape[0], bbox=bbox,
+                                                                                out=out)), 4),
+                             "gt_points": int(gt.shape[0])}
+        stage["replans_in_timed_region"] = ro.n_replans - replans0
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import maps as omaps
         from oracle import nbp_net
+        from oracle import planner as opl
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        xc = x[:1].cpu()
-        # pick the thread count that is fastest on this host (all logical CPUs oversubscribes badly)
+        xc = ro.st.net_in.cpu()
         best = None
         with torch.no_grad():
             for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
@@ -205,32 +233,40 @@ def main():
             cores = best[0]
             torch.set_num_threads(cores)
             n_it, t0c = 0, time.perf_counter()
-            while time.perf_counter() - t0c < 10.0 and n_it < 50:
+            while time.perf_counter() - t0c < 8.0 and n_it < 50:
                 nbp_net.nbp_forward(sd, xc)
                 n_it += 1
             cpu_fwd = (time.perf_counter() - t0c) / n_it
-        sub = pc[:200_000].cpu().numpy()
+        n_pts = int(ro.st.cloud_count.item())
+        sub = ro.st.cloud[:min(n_pts, 200_000)].cpu().numpy()
         t0c = time.perf_counter()
-        omaps.accumulate_step_maps(sub, pose.numpy(), ybins.numpy(), S, rng)
-        cpu_map = (time.perf_counter() - t0c) * (args.points / 200_000)
-        cpu = {"value": round(1.0 / (cpu_fwd + cpu_map), 3), "unit": "steps/s", "cores": cores, "kind": "port",
-               "sample": f"{n_it} NBP forwards at {S}x{S} B=1 (torch CPU convs, {cores} threads: "
-                         f"{cpu_fwd*1e3:.1f} ms each) + numpy map accumulation of 200k points scaled to "
-                         f"{args.points} ({cpu_map*1e3:.1f} ms)",
+        omaps.accumulate_step_maps(sub, pose, y_bins.numpy(), S, (-40, 40))
+        cpu_map = (time.perf_counter() - t0c) * (n_pts / max(len(sub), 1))
+        gts = gt[:2000].cpu().numpy()
+        t0c = time.perf_counter()
+        opl.coverage(gts, ro.st.cloud[:min(n_pts, 100_000)].cpu().numpy())
+        cpu_cov = (time.perf_counter() - t0c) * (gt.shape[0] / 2000)
+        cpu = {"value": round(1.0 / (cpu_fwd + cpu_map + cpu_cov), 3), "unit": "steps/s", "cores": cores,
+               "kind": "port",
+               "sample": f"{n_it} NBP forwards at 256x256 B=1 with stock PyTorch CPU convs = the reference's own "
+                         f"arithmetic ({cores} threads, {cpu_fwd*1e3:.1f} ms each) + numpy map accumulation of "
+                         f"{len(sub)} points scaled to {n_pts} ({cpu_map*1e3:.1f} ms) + brute-force coverage of 2000 GT "
+                         f"points scaled to {gt.shape[0]} ({cpu_cov*1e3:.0f} ms); rendering/un-projection excluded "
+                         f"(PyTorch3D is not installable here), so this is an upper bound on the CPU step rate",
                "nbp_maps_per_s": round(1.0 / cpu_fwd, 3)}
 
     if rank == 0:
-        steps_total = args.steps * world * B
         out = {
-            "metric": "exploration hot-path steps/s (map accumulation + NBP forward, 256x256)",
-            "value": round(steps_total / dt, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: AiMDoom_simple-like rollout step, 256x256 grid, 1 rollout/GPU, "
-                                   "seeded synthetic NBP weights + synthetic point cloud",
-                       "grid": S, "rollouts_per_gpu": B, "cloud_points": args.points},
-            "nbp_maps_per_s": round(world * stage["nbp_forward"]["maps_per_s"], 2) if stage else None,
-            "stages": stage, "roofline": roofline, "cpu_baseline": cpu,
+            "metric": "exploration steps/s (+ NBP maps/s) at 256x256", "value": round(args.steps * world / dt, 3),
+            "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: AiMDoom_simple-like rollout (seeded procedural maze, "
+                                   f"{int(mesh.faces.shape[0])} faces), 256x256 grid, 1 rollout per GPU, 5 depth frames "
+                                   "of 256x456 per step, seeded synthetic NBP weights",
+                       "grid": S, "rollouts_per_gpu": 1, "image": [params.image_height, params.image_width]},
+            "nbp_maps_per_s": round(world * stage["nbp_forward"]["maps_per_s"], 2),
+            "stages": stage, "roofline": roofline, "roofline_scatter": scatter, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if dist is not None:

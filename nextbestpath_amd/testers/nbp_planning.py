@@ -54,8 +54,8 @@ def setup_test_camera(params, mesh, start_cam_idx, settings, device, seed=0):
                  params.gathering_factor, params.sensor_range, seed=seed)
     start = tuple(int(v) for v in start_cam_idx)
     neigh = cam.get_neighboring_poses(start)
-    segs = torch.tensor([np.concatenate([cam.pose_from_idx(n)[:3], cam.pose_from_idx(start)[:3]]) for n in neigh],
-                        dtype=torch.float32, device=device)
+    segs = torch.from_numpy(np.stack([np.concatenate([cam.pose_from_idx(n)[:3], cam.pose_from_idx(start)[:3]])
+                                      for n in neigh]).astype(np.float32)).to(device)
     hit = hipops.segments_hit_mesh(mesh.verts, mesh.faces, segs).cpu().numpy()
     free = [n for n, h in zip(neigh, hit) if not h]
     first = free[0] if free else neigh[0]          # the reference raises NameError when none is free
@@ -65,84 +65,101 @@ def setup_test_camera(params, mesh, start_cam_idx, settings, device, seed=0):
     return cam
 
 
-def compute_nbp_trajectory(params, nbp, camera, gt_scene_pc, mesh, mesh_for_check, n_pieces, y_bins, device,
-                           test_resolution=0.05, use_perfect_depth_map=True, n_poses=N_POSES, state=None, seed=0,
-                           hooks=None):
-    t1 = time.time()
-    nbp.eval()
-    S, V = 256, 64
-    grid_range = (-40, 40)
-    st = state or RolloutState(device)
-    st.cloud_count.zero_()
-    st.coverage_counts.zero_()
-    planner = LatticePlanner(camera, mesh_for_check, device, V, S, grid_range)
-    rng = random.Random(seed)
-    gt = gt_scene_pc.contiguous()
-    bbox = (gt.min(0).values.tolist(), gt.max(0).values.tolist())
-    path, path_record = [], 0
-    collision_list, passable_list = [], []
-    idx_history = []
-    step_seed = seed * 1_000_003
+class Rollout:
+    """One exploration rollout, steppable (bench.py times K consecutive ``step()`` calls)."""
 
-    for pose_i in range(n_poses):
+    def __init__(self, params, nbp, camera, gt_scene_pc, mesh, mesh_for_check, y_bins, device, state=None, seed=0):
+        self.params, self.nbp, self.camera, self.mesh, self.mesh_for_check = params, nbp, camera, mesh, mesh_for_check
+        self.y_bins, self.device = y_bins, device
+        self.S, self.V, self.grid_range = 256, 64, (-40, 40)
+        self.st = state or RolloutState(device)
+        self.st.cloud_count.zero_()
+        self.st.coverage_counts.zero_()
+        self.planner = LatticePlanner(camera, mesh_for_check, device, self.V, self.S, self.grid_range)
+        self.rng = random.Random(seed)
+        self.gt = gt_scene_pc.contiguous()
+        self.bbox = (self.gt.min(0).values.tolist(), self.gt.max(0).values.tolist())
+        self.path, self.path_record = [], 0
+        self.collision_list, self.passable_list, self.idx_history = [], [], []
+        self.step_seed = seed * 1_000_003
+        self.pose_i = 0
+        self.n_replans = 0
+
+    def step(self):
+        st, camera, params, pose_i = self.st, self.camera, self.params, self.pose_i
+        S, grid_range = self.S, self.grid_range
         # S2: coverage of the cloud built so far (device counter; read back after the loop)
-        hipops.coverage_count(gt, st.cloud, n_dev=st.cloud_count, n=st.cloud.shape[0], weight=2,
-                              seed=step_seed + 7 * pose_i, threshold=1.0, bbox=bbox, out=st.coverage_counts[pose_i])
+        hipops.coverage_count(self.gt, st.cloud, n_dev=st.cloud_count, n=st.cloud.shape[0], weight=2,
+                              seed=self.step_seed + 7 * pose_i, threshold=1.0, bbox=self.bbox,
+                              out=st.coverage_counts[pose_i % N_POSES])
         # S4: un-project the current frame, append to the cloud
         depth, cams = camera.frames_batch([-1])
         hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
-                                params.sensor_range, seed=step_seed + 11 * pose_i)
+                                params.sensor_range, seed=self.step_seed + 11 * pose_i)
         pose, _ = camera.get_pose_from_idx(camera.cam_idx)
         # S6-S7: NBP input = 4 height slabs + trajectory (one fused pass over the cloud)
-        hu.accumulate_step_maps(st.cloud, pose, y_bins, S, grid_range, n_dev=st.cloud_count, out=st.maps6)
+        hu.accumulate_step_maps(st.cloud, pose, self.y_bins, S, grid_range, n_dev=st.cloud_count, out=st.maps6)
         traj2d = hu.transform_points_to_n_pieces(camera.trajectory_points(), pose)
         traj_img = hu.map_points_to_n_imgs(traj2d, (S, S), grid_range)
         st.net_in[0, :4] = st.maps6[:4]
         st.net_in[0, 4] = traj_img[0]
         # S8: replan?
-        if pose_i == 0 or path is None or path_record + 1 > len(path):
+        path = self.path
+        if pose_i == 0 or not path or self.path_record + 1 > len(path):
             replan = True
         else:
-            nxt = camera.pose_from_idx(path[path_record])
-            replan = line_segment_mesh_intersection(pose[:3], nxt[:3], mesh_for_check)
+            nxt = camera.pose_from_idx(path[self.path_record])
+            replan = line_segment_mesh_intersection(pose[:3], nxt[:3], self.mesh_for_check)
             if replan:
-                cur3, nxt3 = list(camera.cam_idx[:3]), list(path[path_record][:3])
-                collision_list += [[cur3, nxt3], [nxt3, cur3], list(path[-1][:3])]
-        if len(idx_history) >= 2:
-            p1, p2 = list(idx_history[-1][:3]), list(idx_history[-2][:3])
-            passable_list += [[p1, p2], [p2, p1]]
+                cur3, nxt3 = list(camera.cam_idx[:3]), list(path[self.path_record][:3])
+                self.collision_list += [[cur3, nxt3], [nxt3, cur3], list(path[-1][:3])]
+        if len(self.idx_history) >= 2:
+            p1, p2 = list(self.idx_history[-1][:3]), list(self.idx_history[-2][:3])
+            self.passable_list += [[p1, p2], [p2, p1]]
         # S9: one NBP forward per step (the reference also runs it when it does not replan, :252)
         with torch.no_grad():
-            out1, out2 = nbp(st.net_in)
+            out1, out2 = self.nbp(st.net_in)
         if replan:
-            path_record = 0
-            path = planner.replan(pose, out1, out2, st.maps6, traj_img, collision_list, passable_list)
+            self.n_replans += 1
+            self.path_record = 0
+            path = self.planner.replan(pose, out1, out2, st.maps6, traj_img, self.collision_list, self.passable_list)
         # S10: next pose
-        if not path or path_record >= len(path):
+        if not path or self.path_record >= len(path):
             next_idx = list(camera.cam_idx)
-            next_idx[4] = rng.randrange(8)
+            next_idx[4] = self.rng.randrange(8)
             path = []
         else:
-            next_idx = list(path[path_record])
-            if tuple(next_idx) in {tuple(h) for h in idx_history}:
-                next_idx[4] = rng.randrange(8)
-        idx_history.append(tuple(camera.cam_idx))
+            next_idx = list(path[self.path_record])
+            if tuple(next_idx) in {tuple(h) for h in self.idx_history}:
+                next_idx[4] = self.rng.randrange(8)
+        self.path = path
+        self.idx_history.append(tuple(camera.cam_idx))
         # S11: move (4 interpolated poses, one raster launch); S14: un-project the supervision frames
-        camera.move_and_capture(mesh, next_idx)
+        camera.move_and_capture(self.mesh, next_idx)
         depth, cams = camera.frames_batch([-5, -4, -3, -2])
         hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
-                                params.sensor_range, seed=step_seed + 11 * pose_i + 5)
-        path_record += 1
-        if hooks and "step" in hooks:
-            hooks["step"](pose_i)
+                                params.sensor_range, seed=self.step_seed + 11 * pose_i + 5)
+        self.path_record += 1
+        self.pose_i += 1
 
-    counts = st.coverage_counts[:n_poses].cpu().numpy()
-    G = np.float32(len(gt))
-    coverage_evolution = [float(np.float32(c) / G) for c in counts[:, 0]]
-    n_cloud = int(st.cloud_count.item())
-    t2 = time.time()
-    print("Time: ", t2 - t1)
-    return coverage_evolution, camera.X_cam_history, camera.V_cam_history, st.cloud[:n_cloud], None
+    def coverage_evolution(self, n):
+        counts = self.st.coverage_counts[:n].cpu().numpy()
+        G = np.float32(len(self.gt))
+        return [float(np.float32(c) / G) for c in counts[:, 0]]
+
+
+def compute_nbp_trajectory(params, nbp, camera, gt_scene_pc, mesh, mesh_for_check, n_pieces, y_bins, device,
+                           test_resolution=0.05, use_perfect_depth_map=True, n_poses=N_POSES, state=None, seed=0):
+    """Same name / leading arguments / return tuple as the reference (nbp_planning.py:23-361)."""
+    t1 = time.time()
+    nbp.eval()
+    ro = Rollout(params, nbp, camera, gt_scene_pc, mesh, mesh_for_check, y_bins, device, state, seed)
+    for _ in range(n_poses):
+        ro.step()
+    coverage_evolution = ro.coverage_evolution(n_poses)
+    n_cloud = int(ro.st.cloud_count.item())
+    print("Time: ", time.time() - t1)
+    return coverage_evolution, camera.X_cam_history, camera.V_cam_history, ro.st.cloud[:n_cloud], None
 
 
 def load_params(path):
