@@ -114,6 +114,9 @@ def main():
                                                settings.scene.x_min - np.float32(0.2),
                                                settings.scene.x_max + np.float32(0.2), 0.5, seed=rank)).to(dev)
     sd = make_nbp_state_dict(9)
+    # random weights give an obstacle head that is > 0.13 everywhere (every lattice edge blocked, the agent
+    # only turns in place); bias it so free space is free and the observed walls do the blocking
+    sd["Final2.0.bias"] = sd["Final2.0.bias"] - 4.0
     net = NBP()
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()

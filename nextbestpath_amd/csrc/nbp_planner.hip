@@ -100,11 +100,14 @@ __device__ __forceinline__ int grid_cell(const Grid& g, float x, float y, float 
     return (i * g.n[1] + j) * g.n[2] + k;
 }
 
-// sample (first k of the index bijection when N > k, else everything) + insert into per-cell lists
-__global__ __launch_bounds__(256) void coverage_insert_kernel(const float* __restrict__ pc, const long long* __restrict__ n_dev,
-                                                              long long n_host, long long k, unsigned seed, Grid g,
-                                                              float* __restrict__ sp, int* __restrict__ head,
-                                                              int* __restrict__ next, int* __restrict__ m_out) {
+// Counting sort of the (sub-sampled) cloud by grid cell, then a 16-lanes-per-GT-point query that
+// streams the 9 contiguous cell runs of the 3x3x3 neighbourhood (k is the fastest cell index).
+// K1: sample (first k of the index bijection when N > k, else everything), cell id, slot in cell.
+__global__ __launch_bounds__(256) void coverage_bin_kernel(const float* __restrict__ pc, const long long* __restrict__ n_dev,
+                                                           long long n_host, long long k, unsigned seed, Grid g,
+                                                           float* __restrict__ sp, int* __restrict__ cell_of,
+                                                           int* __restrict__ slot_of, int* __restrict__ count,
+                                                           int* __restrict__ m_out) {
     const long long N = n_dev ? *n_dev : n_host;
     const long long M = N > k ? k : N;
     if (blockIdx.x == 0 && threadIdx.x == 0) *m_out = (int)M;
@@ -114,30 +117,75 @@ __global__ __launch_bounds__(256) void coverage_insert_kernel(const float* __res
         const float x = pc[3 * src], y = pc[3 * src + 1], z = pc[3 * src + 2];
         sp[3 * j] = x; sp[3 * j + 1] = y; sp[3 * j + 2] = z;
         const int c = grid_cell(g, x, y, z, nullptr);
-        next[j] = atomicExch(&head[c], (int)j);
+        cell_of[j] = c;
+        slot_of[j] = atomicAdd(&count[c], 1);
     }
 }
 
+// K2: exclusive scan of count[0..ncell) -> start[0..ncell] (one 1024-thread block, chunked).
+__global__ __launch_bounds__(1024) void coverage_scan_kernel(const int* __restrict__ count, long long ncell,
+                                                             int* __restrict__ start) {
+    __shared__ int part[1024];
+    const long long per = (ncell + 1023) / 1024;
+    const long long lo = (long long)threadIdx.x * per, hi = lo + per < ncell ? lo + per : ncell;
+    int s = 0;
+    for (long long i = lo; i < hi; ++i) s += count[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (long long i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
+    if (threadIdx.x == 1023) start[ncell] = part[1023];
+}
+
+// K3: scatter the sampled points into cell order.
+__global__ __launch_bounds__(256) void coverage_scatter_kernel(const float* __restrict__ sp, const int* __restrict__ cell_of,
+                                                               const int* __restrict__ slot_of, const int* __restrict__ start,
+                                                               const int* __restrict__ m_ptr, float* __restrict__ sorted) {
+    const int M = *m_ptr;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
+        const int d = start[cell_of[j]] + slot_of[j];
+        sorted[3 * d] = sp[3 * j]; sorted[3 * d + 1] = sp[3 * j + 1]; sorted[3 * d + 2] = sp[3 * j + 2];
+    }
+}
+
+// K4: 16 lanes per GT point.
 __global__ __launch_bounds__(256) void coverage_query_kernel(const float* __restrict__ gt, int G, Grid g, float thr,
-                                                             const float* __restrict__ sp, const int* __restrict__ head,
-                                                             const int* __restrict__ next, int* __restrict__ count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                             const float* __restrict__ sorted, const int* __restrict__ start,
+                                                             int* __restrict__ count) {
+    const int sub = threadIdx.x & 15;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     bool found = false;
     if (i < G) {
         const float x = gt[3 * i], y = gt[3 * i + 1], z = gt[3 * i + 2];
         int c[3];
         grid_cell(g, x, y, z, c);
+        const int d0 = max(c[2] - 1, 0), d1 = min(c[2] + 1, g.n[2] - 1);
         for (int a = max(c[0] - 1, 0); a <= min(c[0] + 1, g.n[0] - 1) && !found; ++a)
-            for (int b = max(c[1] - 1, 0); b <= min(c[1] + 1, g.n[1] - 1) && !found; ++b)
-                for (int d = max(c[2] - 1, 0); d <= min(c[2] + 1, g.n[2] - 1) && !found; ++d)
-                    for (int j = head[(a * g.n[1] + b) * g.n[2] + d]; j >= 0; j = next[j]) {
-                        const float ex = x - sp[3 * j], ey = y - sp[3 * j + 1], ez = z - sp[3 * j + 2];
-                        const float d2 = (ex * ex + ey * ey) + ez * ez;
-                        if (sqrtf(d2) < thr) { found = true; break; }
+            for (int b = max(c[1] - 1, 0); b <= min(c[1] + 1, g.n[1] - 1) && !found; ++b) {
+                const int base = (a * g.n[1] + b) * g.n[2];
+                const int lo = start[base + d0], hi = start[base + d1 + 1];
+                for (int j0 = lo; j0 < hi && !found; j0 += 16) {
+                    const int j = j0 + sub;
+                    bool hit = false;
+                    if (j < hi) {
+                        const float ex = x - sorted[3 * j], ey = y - sorted[3 * j + 1], ez = z - sorted[3 * j + 2];
+                        hit = sqrtf((ex * ex + ey * ey) + ez * ez) < thr;
                     }
+                    // any lane of this 16-lane group
+                    const unsigned long long bal = __ballot(hit);
+                    const int grp = (threadIdx.x & 63) >> 4;
+                    found = ((bal >> (16 * grp)) & 0xffffull) != 0;
+                }
+            }
     }
-    const unsigned long long b = __ballot(found);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, __popcll(b));
+    const unsigned long long fb = __ballot(found && sub == 0);
+    if ((threadIdx.x & 63) == 0 && fb) atomicAdd(count, __popcll(fb));
 }
 
 }  // namespace
@@ -184,13 +232,15 @@ static int coverage_grid(const float* bbox_lo, const float* bbox_hi, float thr, 
     return 0;
 }
 
+static size_t al256(size_t b) { return (b + 255) / 256 * 256; }
+
 extern "C" size_t nbp_coverage_workspace_bytes(const float* bbox_lo_host, const float* bbox_hi_host, float threshold,
                                                long long sample_k) {
     Grid g; size_t ncell;
     if (!bbox_lo_host || !bbox_hi_host || !(threshold > 0) || sample_k < 1) return 0;
     if (coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell)) return 0;
-    return (ncell * 4 + 255) / 256 * 256 + ((size_t)sample_k * 4 + 255) / 256 * 256 +
-           ((size_t)sample_k * 12 + 255) / 256 * 256 + 512;
+    return al256(ncell * 4) + al256((ncell + 1) * 4) + 2 * al256((size_t)sample_k * 4) +
+           2 * al256((size_t)sample_k * 12) + 512;
 }
 
 extern "C" int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3, long long N, const long long* N_dev_or_null,
@@ -205,18 +255,25 @@ extern "C" int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3,
     NBP_RETURN_IF(ws_bytes < nbp_coverage_workspace_bytes(bbox_lo_host, bbox_hi_host, threshold, sample_k), NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;
     char* p = (char*)(((uintptr_t)ws + 255) / 256 * 256);
-    int* head = (int*)p; p += (ncell * 4 + 255) / 256 * 256;
-    int* next = (int*)p; p += ((size_t)sample_k * 4 + 255) / 256 * 256;
-    float* sp = (float*)p;
-    hipError_t e = hipMemsetAsync(head, 0xff, ncell * 4, st);
+    int* count = (int*)p; p += al256(ncell * 4);
+    int* start = (int*)p; p += al256((ncell + 1) * 4);
+    int* cell_of = (int*)p; p += al256((size_t)sample_k * 4);
+    int* slot_of = (int*)p; p += al256((size_t)sample_k * 4);
+    float* sp = (float*)p; p += al256((size_t)sample_k * 12);
+    float* sorted = (float*)p;
+    hipError_t e = hipMemsetAsync(count, 0, ncell * 4, st);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(count_out, 0, sizeof(int), st);
     if (e != hipSuccess) return (int)e;
     const long long work = N_dev_or_null ? sample_k : (N < sample_k ? N : sample_k);
-    coverage_insert_kernel<<<nbp_ew_grid(work > 0 ? work : 1, 256), 256, 0, st>>>(pc3, N_dev_or_null, N, sample_k, seed, g, sp,
-                                                                                   head, next, m_out);
-    rc = nbp_launch_status();
-    if (rc) return rc;
-    coverage_query_kernel<<<(unsigned)nbp_cdiv(G, 256), 256, 0, st>>>(gt3, G, g, threshold, sp, head, next, count_out);
+    const int grid = nbp_ew_grid(work > 0 ? work : 1, 256);
+    coverage_bin_kernel<<<grid, 256, 0, st>>>(pc3, N_dev_or_null, N, sample_k, seed, g, sp, cell_of, slot_of, count, m_out);
+    if ((rc = nbp_launch_status())) return rc;
+    coverage_scan_kernel<<<1, 1024, 0, st>>>(count, (long long)ncell, start);
+    if ((rc = nbp_launch_status())) return rc;
+    coverage_scatter_kernel<<<grid, 256, 0, st>>>(sp, cell_of, slot_of, start, m_out, sorted);
+    if ((rc = nbp_launch_status())) return rc;
+    coverage_query_kernel<<<(unsigned)nbp_cdiv((long long)G * 16, 256), 256, 0, st>>>(gt3, G, g, threshold, sorted, start,
+                                                                                    count_out);
     return nbp_launch_status();
 }
