@@ -96,7 +96,7 @@ def main():
     from nextbestpath_amd.testers import nbp_planning as tp
     from nextbestpath_amd.utility import hipops
     from nextbestpath_amd.utility import utils as hu
-    from nextbestpath_amd.utility.synthetic import make_nbp_state_dict
+    from nextbestpath_amd.utility.synthetic import make_explorer_state_dict
 
     L = _lib.lib()
     S = 256
@@ -113,10 +113,7 @@ def main():
     gt = torch.from_numpy(sc.sample_gt_surface(mesh.verts_host, mesh.faces_host, params.n_gt_surface_points,
                                                settings.scene.x_min - np.float32(0.2),
                                                settings.scene.x_max + np.float32(0.2), 0.5, seed=rank)).to(dev)
-    sd = make_nbp_state_dict(9)
-    # random weights give an obstacle head that is > 0.13 everywhere (every lattice edge blocked, the agent
-    # only turns in place); bias it so free space is free and the observed walls do the blocking
-    sd["Final2.0.bias"] = sd["Final2.0.bias"] - 4.0
+    sd = make_explorer_state_dict(9)     # silent obstacle head: the observed walls do the blocking
     net = NBP()
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()

@@ -41,6 +41,18 @@ def make_nbp_state_dict(seed: int = 9):
     return sd
 
 
+def make_explorer_state_dict(seed: int = 9):
+    """Synthetic weights for ROLLOUTS: same as make_nbp_state_dict but with a silent obstacle head
+    (Final2 weight 0, bias -4 => out2 = 0.018 < 0.13 everywhere).  With plain random weights the
+    obstacle head fires on most pixels, every lattice edge is blocked and the agent only turns in
+    place; with a silent head the observed walls (height-band projection) do the blocking, which is
+    what a trained network converges to in explored space.  Cost of the forward is unchanged."""
+    sd = make_nbp_state_dict(seed)
+    sd["Final2.0.weight"] = torch.zeros_like(sd["Final2.0.weight"])
+    sd["Final2.0.bias"] = torch.full_like(sd["Final2.0.bias"], -4.0)
+    return sd
+
+
 def make_count_maps(B: int, S: int, seed: int = 0, lam: float = 0.3):
     """[B,5,S,S] fp32: Poisson(lam) counts inside a random disc on the 4 slab channels,
     a sparse trajectory on channel 4 (SURVEY.md section 8d, config 3 input recipe)."""

@@ -23,8 +23,9 @@ def dataset(tmp_path_factory):
 
 def _net(nbp_weights):
     from nextbestpath_amd.networks.nbp_model import NBP
+    from nextbestpath_amd.utility.synthetic import make_explorer_state_dict
     net = NBP()
-    net.load_state_dict(nbp_weights)
+    net.load_state_dict(make_explorer_state_dict(9))
     return net.cuda().eval()
 
 
@@ -36,7 +37,7 @@ def test_short_rollout_invariants_and_determinism(hip, dataset, nbp_weights):
     net = _net(nbp_weights)
     runs = tp.list_runs(ds, params)
     assert len(runs) == 2
-    n_poses = 8
+    n_poses = 12
     with torch.no_grad():
         a = tp.run_one(params, net, ds, runs[0], torch.device("cuda"), n_poses=n_poses, seed=5)
         b = tp.run_one(params, net, ds, runs[0], torch.device("cuda"), n_poses=n_poses, seed=5)
@@ -48,6 +49,7 @@ def test_short_rollout_invariants_and_determinism(hip, dataset, nbp_weights):
     step = np.linalg.norm(np.diff(X[4::4], axis=0), axis=1)            # lattice moves: 0 (turn) or 3 units
     assert np.all((np.abs(step) < 1e-4) | (np.abs(step - 3.0) < 1e-4))
     assert a["n_points"] > 1000
+    assert np.abs(step - 3.0).min() < 1e-4                               # the agent actually travels
     assert a["coverage"] == b["coverage"] and a["X_cam_history"] == b["X_cam_history"]     # seeded => bit identical
 
 
