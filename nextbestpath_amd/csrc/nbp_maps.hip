@@ -57,9 +57,29 @@ __global__ void point_position_kernel(const float* __restrict__ pts, long long K
     }
 }
 
+// ---- fused accumulation with per-workgroup LDS pre-aggregation.
+// Walls are vertical, so thousands of points fall into the same top-down cell: sending every
+// point as its own device-scope atomic serialises on the hot addresses.  Each workgroup owns
+// AGG_POINTS consecutive points, counts them in an LDS open-addressing table keyed by
+// (channel, cell) with LDS atomics, then flushes one global atomicAdd(count) per distinct key.
+constexpr int AGG_POINTS = 8192;     // points per workgroup
+constexpr int AGG_SLOTS = 8192;      // table slots (key + count = 64 KiB of LDS)
+constexpr int AGG_EMPTY = -1;
+
+__device__ __forceinline__ void agg_add(int* keys, int* cnts, int key, float* __restrict__ out) {
+    unsigned h = ((unsigned)key * 0x9E3779B1u) >> 19;            // 13-bit slot
+#pragma unroll 1
+    for (int probe = 0; probe < 24; ++probe) {
+        const int old = atomicCAS(&keys[h], AGG_EMPTY, key);
+        if (old == AGG_EMPTY || old == key) { atomicAdd(&cnts[h], 1); return; }
+        h = (h + 1) & (AGG_SLOTS - 1);
+    }
+    atomicAdd(out + key, 1.0f);                                   // table region saturated: go direct
+}
+
 __device__ __forceinline__ void accumulate_point(float x, float y, float z, float cx, float cz, const Bounds& bd,
                                                  float band_lo, float band_hi, int S, float lo, float sc,
-                                                 float* __restrict__ out) {
+                                                 int* keys, int* cnts, float* __restrict__ out) {
     int i0, i1;
     if (!cell_of(-(z - cz), -(x - cx), lo, sc, sc, S, S, i0, i1)) return;
     int cnt = 0;
@@ -68,37 +88,28 @@ __device__ __forceinline__ void accumulate_point(float x, float y, float z, floa
     const int bin = cnt - 1;
     const int ch = (bin >= 0 && bin < 4) ? bin : 4;
     const int cell = i0 * S + i1;
-    atomicAdd(out + ch * S * S + cell, 1.0f);
-    if (band_lo < y && y < band_hi) atomicAdd(out + 5 * S * S + cell, 1.0f);
+    agg_add(keys, cnts, ch * S * S + cell, out);
+    if (band_lo < y && y < band_hi) agg_add(keys, cnts, 5 * S * S + cell, out);
 }
 
-// 4 points (48 contiguous bytes = three 16-byte loads) per thread per iteration.  `head`
-// (< 4) leading points bring the pointer to 16-byte alignment; they and the N % 4 tail are
-// handled by the first threads of block 0.
 __global__ __launch_bounds__(256) void map_accumulate_kernel(const float* __restrict__ p, long long N,
-                                                             const long long* __restrict__ n_dev, int head,
-                                                             float cx, float cz, Bounds bd, float band_lo,
-                                                             float band_hi, int S, float lo, float sc,
-                                                             float* __restrict__ out) {
+                                                             const long long* __restrict__ n_dev, float cx, float cz,
+                                                             Bounds bd, float band_lo, float band_hi, int S, float lo,
+                                                             float sc, float* __restrict__ out) {
+    __shared__ int keys[AGG_SLOTS];
+    __shared__ int cnts[AGG_SLOTS];
     if (n_dev) N = *n_dev;                       // cloud size lives on the device (no host sync per step)
-    if (head > N) head = (int)N;
-    const long long groups = (N - head) >> 2;
-    const f32x4* p4 = reinterpret_cast<const f32x4*>(p + 3 * head);
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < groups;
-         g += (long long)gridDim.x * blockDim.x) {
-        const f32x4 a = p4[3 * g], b = p4[3 * g + 1], c = p4[3 * g + 2];
-        accumulate_point(a[0], a[1], a[2], cx, cz, bd, band_lo, band_hi, S, lo, sc, out);
-        accumulate_point(a[3], b[0], b[1], cx, cz, bd, band_lo, band_hi, S, lo, sc, out);
-        accumulate_point(b[2], b[3], c[0], cx, cz, bd, band_lo, band_hi, S, lo, sc, out);
-        accumulate_point(c[1], c[2], c[3], cx, cz, bd, band_lo, band_hi, S, lo, sc, out);
-    }
-    if (blockIdx.x == 0 && threadIdx.x < 8) {
-        long long i = -1;
-        if ((int)threadIdx.x < head) i = threadIdx.x;                                  // head points
-        else if (threadIdx.x >= 4) i = head + (groups << 2) + (threadIdx.x - 4);       // tail points
-        if (i >= 0 && i < N && (i < head || i >= head + (groups << 2)))
-            accumulate_point(p[3 * i], p[3 * i + 1], p[3 * i + 2], cx, cz, bd, band_lo, band_hi, S, lo, sc, out);
-    }
+    const long long first = (long long)blockIdx.x * AGG_POINTS;
+    if (first >= N) return;
+    const long long last = first + AGG_POINTS < N ? first + AGG_POINTS : N;
+    for (int i = threadIdx.x; i < AGG_SLOTS; i += 256) { keys[i] = AGG_EMPTY; cnts[i] = 0; }
+    __syncthreads();
+    // 12 B per point: three consecutive dword loads per lane (768 contiguous bytes per wave instruction)
+    for (long long i = first + threadIdx.x; i < last; i += 256)
+        accumulate_point(p[3 * i], p[3 * i + 1], p[3 * i + 2], cx, cz, bd, band_lo, band_hi, S, lo, sc, keys, cnts, out);
+    __syncthreads();
+    for (int i = threadIdx.x; i < AGG_SLOTS; i += 256)
+        if (keys[i] != AGG_EMPTY) atomicAdd(out + keys[i], (float)cnts[i]);
 }
 
 inline float grid_scale(int S, float lo, float hi) { return (float)((double)S / ((double)hi - (double)lo)); }
@@ -149,12 +160,11 @@ extern "C" int nbp_map_accumulate_f32(const float* points, long long N, const lo
     if (N == 0) return 0;
     NBP_RETURN_IF(!points, NBP_E_ARG);
     NBP_RETURN_IF(((uintptr_t)points & 3) != 0, NBP_E_ARG);
-    int head = 0;
-    while ((((uintptr_t)points + 12u * head) & 15) != 0) ++head;   // 12k mod 16 cycles 0,12,8,4: head <= 3
+    NBP_RETURN_IF((long long)6 * S * S >= (1ll << 31), NBP_E_SHAPE);
     Bounds bd;
     for (int k = 0; k < 8; ++k) bd.b[k] = k < n_bounds ? bounds_host[k] : 0.f;
     bd.n = n_bounds;
-    map_accumulate_kernel<<<nbp_ew_grid(nbp_cdiv(N, 4), 256), 256, 0, st>>>(points, N, N_dev_or_null, head, cx, cz, bd, band_lo, band_hi, S,
-                                                                            lo, grid_scale(S, lo, hi), out6);
+    map_accumulate_kernel<<<(unsigned)nbp_cdiv(N, AGG_POINTS), 256, 0, st>>>(points, N, N_dev_or_null, cx, cz, bd, band_lo,
+                                                                           band_hi, S, lo, grid_scale(S, lo, hi), out6);
     return nbp_launch_status();
 }

@@ -122,25 +122,42 @@ __global__ __launch_bounds__(256) void coverage_bin_kernel(const float* __restri
     }
 }
 
-// K2: exclusive scan of count[0..ncell) -> start[0..ncell] (one 1024-thread block, chunked).
+// K2: exclusive scan of count[0..ncell) -> start[0..ncell]: one 1024-thread block walks the array in
+// coalesced tiles of 4096 ints (int4 per thread), wave scans by shuffle, 16 wave totals through LDS.
 __global__ __launch_bounds__(1024) void coverage_scan_kernel(const int* __restrict__ count, long long ncell,
                                                              int* __restrict__ start) {
-    __shared__ int part[1024];
-    const long long per = (ncell + 1023) / 1024;
-    const long long lo = (long long)threadIdx.x * per, hi = lo + per < ncell ? lo + per : ncell;
-    int s = 0;
-    for (long long i = lo; i < hi; ++i) s += count[i];
-    part[threadIdx.x] = s;
+    __shared__ int wtot[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    for (long long t0 = 0; t0 < ncell; t0 += 4096) {
+        const long long i = t0 + 4 * (long long)threadIdx.x;
+        int v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = i + e < ncell ? count[i + e] : 0;
+        const int mine = v[0] + v[1] + v[2] + v[3];
+        int inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int n = __shfl_up(inc, o);
+            if (lane >= o) inc += n;
+        }
+        if (lane == 63) wtot[wave] = inc;
         __syncthreads();
-        part[threadIdx.x] += v;
+        int base = carry_s;
+        for (int w = 0; w < wave; ++w) base += wtot[w];
+        int run = base + inc - mine;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (i + e < ncell) start[i + e] = run;
+            run += v[e];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = run;
         __syncthreads();
     }
-    int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-    for (long long i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
-    if (threadIdx.x == 1023) start[ncell] = part[1023];
+    if (threadIdx.x == 0) start[ncell] = carry_s;
 }
 
 // K3: scatter the sampled points into cell order.

@@ -37,45 +37,70 @@ __device__ __forceinline__ void unproject_pixel(int row, int col, float z, int H
     out[2] = (dx * R[6] + dy * R[7]) + dz * R[8];
 }
 
-// K1: one 1024-thread block per frame compacts the valid pixel indices (pixel order).
-__global__ __launch_bounds__(1024) void unproject_compact_kernel(const float* __restrict__ depth,
-                                                                 const unsigned char* __restrict__ mask, int HW,
-                                                                 float fov_range, double gather, unsigned* __restrict__ list,
-                                                                 int* __restrict__ counts) {
-    __shared__ int wave_tot[16];
+// K1a/K1b: ordered compaction of the valid pixel indices (pixel order) with COMPACT_CHUNK pixels
+// per 256-thread block: pass a counts per block, pass b recomputes validity and writes at the
+// block's exclusive prefix (<= 64 block counts per frame are summed directly).
+constexpr int COMPACT_CHUNK = 2048;
+
+__device__ __forceinline__ bool pixel_valid(const float* d, const unsigned char* mk, int p, float fov_range) {
+    const float z = d[p];
+    return (mk ? mk[p] != 0 : z > -1.f) && z < fov_range;
+}
+
+__global__ __launch_bounds__(256) void unproject_count_kernel(const float* __restrict__ depth,
+                                                              const unsigned char* __restrict__ mask, int HW, int nblk,
+                                                              float fov_range, int* __restrict__ blk_count) {
+    __shared__ int tot;
+    const int f = blockIdx.y, b = blockIdx.x;
+    const float* d = depth + (size_t)f * HW;
+    const unsigned char* mk = mask ? mask + (size_t)f * HW : nullptr;
+    if (threadIdx.x == 0) tot = 0;
+    __syncthreads();
+    int c = 0;
+    for (int p = b * COMPACT_CHUNK + threadIdx.x; p < min((b + 1) * COMPACT_CHUNK, HW); p += 256)
+        c += pixel_valid(d, mk, p, fov_range) ? 1 : 0;
+    for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&tot, c);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_count[f * nblk + b] = tot;
+}
+
+__global__ __launch_bounds__(256) void unproject_compact_kernel(const float* __restrict__ depth,
+                                                                const unsigned char* __restrict__ mask, int HW, int nblk,
+                                                                float fov_range, double gather,
+                                                                const int* __restrict__ blk_count, unsigned* __restrict__ list,
+                                                                int* __restrict__ counts) {
+    __shared__ int wave_tot[4];
     __shared__ int base_s;
-    const int f = blockIdx.x;
+    const int f = blockIdx.y, b = blockIdx.x;
     const float* d = depth + (size_t)f * HW;
     const unsigned char* mk = mask ? mask + (size_t)f * HW : nullptr;
     unsigned* out = list + (size_t)f * HW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) base_s = 0;
-    __syncthreads();
-    for (int p0 = 0; p0 < HW; p0 += 1024) {
-        const int p = p0 + threadIdx.x;
-        bool ok = false;
-        if (p < HW) {
-            const float z = d[p];
-            ok = (mk ? mk[p] != 0 : z > -1.f) && z < fov_range;
+    if (threadIdx.x == 0) {
+        int pre = 0, all = 0;
+        for (int k = 0; k < nblk; ++k) { const int v = blk_count[f * nblk + k]; all += v; if (k < b) pre += v; }
+        base_s = pre;
+        if (b == 0) {
+            counts[2 * f] = all;
+            counts[2 * f + 1] = (int)((double)all * gather);   // int(len(world_points) * gathering_factor)
         }
-        const unsigned long long b = __ballot(ok);
-        const int within = __popcll(b & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[wave] = __popcll(b);
+    }
+    __syncthreads();
+    const int pend = min((b + 1) * COMPACT_CHUNK, HW);
+    for (int p0 = b * COMPACT_CHUNK; p0 < pend; p0 += 256) {
+        const int p = p0 + threadIdx.x;
+        const bool ok = p < pend && pixel_valid(d, mk, p, fov_range);
+        const unsigned long long bal = __ballot(ok);
+        const int within = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(bal);
         __syncthreads();
         int off = base_s;
         for (int w = 0; w < wave; ++w) off += wave_tot[w];
         if (ok) out[off + within] = (unsigned)p;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int t = 0;
-            for (int w = 0; w < 16; ++w) t += wave_tot[w];
-            base_s += t;
-        }
+        if (threadIdx.x == 0) base_s += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
         __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        counts[2 * f] = base_s;
-        counts[2 * f + 1] = (int)((double)base_s * gather);   // int(len(world_points) * gathering_factor)
     }
 }
 
@@ -125,64 +150,79 @@ __device__ __forceinline__ void to_view(const float* p, const float* R, const fl
     o[2] = ((p[0] * R[2] + p[1] * R[5]) + p[2] * R[8]) + T[2];
 }
 
-// One thread per (face, frame): view transform, near-plane clip for the screen bbox, binning.
+// One thread per (face, frame): view transform, near-plane clip for the screen bbox (in tiles).
 __global__ __launch_bounds__(256) void raster_setup_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
                                                            int n_faces, const Cam* __restrict__ cams, int H, int W,
-                                                           float tanh_fov, float zclip, int tiles_x, int tiles_y,
-                                                           int bin_cap, FaceRec* __restrict__ recs, int* __restrict__ tile_count,
-                                                           int* __restrict__ tile_list, int* __restrict__ overflow) {
+                                                           float tanh_fov, float zclip, FaceRec* __restrict__ recs,
+                                                           int4* __restrict__ tbox) {
     const int fr = blockIdx.y;
     const int fi = blockIdx.x * blockDim.x + threadIdx.x;
     if (fi >= n_faces) return;
+    int4 box = make_int4(1, 0, 1, 0);                                            // empty (tx0 > tx1)
     const Cam cam = cams[fr];
     float v[3][3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) to_view(verts + 3 * (size_t)faces[3 * (size_t)fi + k], cam.R, cam.T, v[k]);
-    if (v[0][2] <= zclip && v[1][2] <= zclip && v[2][2] <= zclip) return;       // behind the clip plane
-    FaceRec r;
+    if (!(v[0][2] <= zclip && v[1][2] <= zclip && v[2][2] <= zclip)) {          // not entirely behind the clip plane
+        FaceRec r;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { r.e1[c] = v[1][c] - v[0][c]; r.e2[c] = v[2][c] - v[0][c]; r.v0[c] = v[0][c]; }
-    // q = e1 x v0  (= (-v0) x e1),  tnum = e2 . q
-    r.q[0] = r.e1[1] * r.v0[2] - r.e1[2] * r.v0[1];
-    r.q[1] = r.e1[2] * r.v0[0] - r.e1[0] * r.v0[2];
-    r.q[2] = r.e1[0] * r.v0[1] - r.e1[1] * r.v0[0];
-    r.tnum = (r.e2[0] * r.q[0] + r.e2[1] * r.q[1]) + r.e2[2] * r.q[2];
-    r.pad[0] = r.pad[1] = r.pad[2] = 0.f;
-    // screen bbox of the part with z >= zclip (Sutherland-Hodgman against one plane)
-    const int s = H < W ? H : W;
-    float cmin = 1e30f, cmax = -1e30f, rmin = 1e30f, rmax = -1e30f;
-    auto emit = [&](float x, float y, float z) {
-        const float nx = x / (z * tanh_fov), ny = y / (z * tanh_fov);
-        const float col = ((float)W - (float)s * nx - 1.f) * 0.5f;   // ndc_x(col) = W/s - (2 col + 1)/s
-        const float row = ((float)H - (float)s * ny - 1.f) * 0.5f;
-        cmin = fminf(cmin, col); cmax = fmaxf(cmax, col); rmin = fminf(rmin, row); rmax = fmaxf(rmax, row);
-    };
+        for (int c = 0; c < 3; ++c) { r.e1[c] = v[1][c] - v[0][c]; r.e2[c] = v[2][c] - v[0][c]; r.v0[c] = v[0][c]; }
+        // q = e1 x v0  (= (-v0) x e1),  tnum = e2 . q
+        r.q[0] = r.e1[1] * r.v0[2] - r.e1[2] * r.v0[1];
+        r.q[1] = r.e1[2] * r.v0[0] - r.e1[0] * r.v0[2];
+        r.q[2] = r.e1[0] * r.v0[1] - r.e1[1] * r.v0[0];
+        r.tnum = (r.e2[0] * r.q[0] + r.e2[1] * r.q[1]) + r.e2[2] * r.q[2];
+        r.pad[0] = r.pad[1] = r.pad[2] = 0.f;
+        // screen bbox of the part with z >= zclip (Sutherland-Hodgman against one plane)
+        const int s = H < W ? H : W;
+        float cmin = 1e30f, cmax = -1e30f, rmin = 1e30f, rmax = -1e30f;
+        auto emit = [&](float x, float y, float z) {
+            const float nx = x / (z * tanh_fov), ny = y / (z * tanh_fov);
+            const float col = ((float)W - (float)s * nx - 1.f) * 0.5f;   // ndc_x(col) = W/s - (2 col + 1)/s
+            const float row = ((float)H - (float)s * ny - 1.f) * 0.5f;
+            cmin = fminf(cmin, col); cmax = fmaxf(cmax, col); rmin = fminf(rmin, row); rmax = fmaxf(rmax, row);
+        };
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float* a = v[k];
-        const float* b = v[(k + 1) % 3];
-        const bool ain = a[2] >= zclip, bin_ = b[2] >= zclip;
-        if (ain) emit(a[0], a[1], a[2]);
-        if (ain != bin_) {
-            const float t = (zclip - a[2]) / (b[2] - a[2]);
-            emit(a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), zclip);
+        for (int k = 0; k < 3; ++k) {
+            const float* a = v[k];
+            const float* b = v[(k + 1) % 3];
+            const bool ain = a[2] >= zclip, bin_ = b[2] >= zclip;
+            if (ain) emit(a[0], a[1], a[2]);
+            if (ain != bin_) {
+                const float t = (zclip - a[2]) / (b[2] - a[2]);
+                emit(a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), zclip);
+            }
+        }
+        if (cmax >= cmin) {
+            int c0 = (int)floorf(fmaxf(cmin, -1e8f)) - 1, c1 = (int)ceilf(fminf(cmax, 1e8f)) + 1;
+            int r0 = (int)floorf(fmaxf(rmin, -1e8f)) - 1, r1 = (int)ceilf(fminf(rmax, 1e8f)) + 1;
+            c0 = max(c0, 0); r0 = max(r0, 0); c1 = min(c1, W - 1); r1 = min(r1, H - 1);
+            if (c0 <= c1 && r0 <= r1) {
+                recs[(size_t)fr * n_faces + fi] = r;
+                box = make_int4(c0 / TILE, c1 / TILE, r0 / TILE, r1 / TILE);
+            }
         }
     }
-    if (!(cmax >= cmin)) return;
-    int c0 = (int)floorf(cmin) - 1, c1 = (int)ceilf(cmax) + 1, r0 = (int)floorf(rmin) - 1, r1 = (int)ceilf(rmax) + 1;
-    if (cmin < -1e8f) c0 = 0; if (cmax > 1e8f) c1 = W - 1;
-    if (rmin < -1e8f) r0 = 0; if (rmax > 1e8f) r1 = H - 1;
-    c0 = max(c0, 0); r0 = max(r0, 0); c1 = min(c1, W - 1); r1 = min(r1, H - 1);
-    if (c0 > c1 || r0 > r1) return;
-    recs[(size_t)fr * n_faces + fi] = r;
-    const int ntiles = tiles_x * tiles_y;
-    for (int ty = r0 / TILE; ty <= r1 / TILE; ++ty)
-        for (int tx = c0 / TILE; tx <= c1 / TILE; ++tx) {
-            const int t = fr * ntiles + ty * tiles_x + tx;
-            const int pos = atomicAdd(&tile_count[t], 1);
-            if (pos < bin_cap) tile_list[(size_t)t * bin_cap + pos] = fi;
-            else *overflow = 1;
-        }
+    tbox[(size_t)fr * n_faces + fi] = box;
+}
+
+// One thread per (face, tile row, frame): appends the face to the tiles of that row of its bbox
+// (a big face no longer serialises ~2 k atomics in one thread).
+__global__ __launch_bounds__(256) void raster_bin_kernel(const int4* __restrict__ tbox, int n_faces, int tiles_x, int tiles_y,
+                                                         int bin_cap, int* __restrict__ tile_count,
+                                                         int* __restrict__ tile_list, int* __restrict__ overflow) {
+    const int fr = blockIdx.y;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_faces * tiles_y) return;
+    const int fi = (int)(t / tiles_y), ty = (int)(t - (long long)fi * tiles_y);
+    const int4 box = tbox[(size_t)fr * n_faces + fi];
+    if (box.x > box.y || ty < box.z || ty > box.w) return;
+    const int base = fr * tiles_x * tiles_y + ty * tiles_x;
+    for (int tx = box.x; tx <= box.y; ++tx) {
+        const int pos = atomicAdd(&tile_count[base + tx], 1);
+        if (pos < bin_cap) tile_list[(size_t)(base + tx) * bin_cap + pos] = fi;
+        else *overflow = 1;
+    }
 }
 
 // One wave per 8x8 tile: faces staged 64 at a time through LDS, every lane ray-casts its pixel.
@@ -286,7 +326,8 @@ __global__ __launch_bounds__(256) void axis_ray_count_kernel(const float* __rest
 // ================================================================== C ABI
 extern "C" size_t nbp_unproject_workspace_bytes(int n_frames, int H, int W) {
     if (n_frames < 1 || H < 2 || W < 2) return 0;
-    return (size_t)n_frames * H * W * sizeof(unsigned) + 256;
+    const size_t nblk = (size_t)nbp_cdiv((long long)H * W, COMPACT_CHUNK);
+    return (size_t)n_frames * H * W * sizeof(unsigned) + ((size_t)n_frames * nblk * sizeof(int) + 255) / 256 * 256 + 512;
 }
 
 extern "C" int nbp_unproject_append_f32(const float* depth, const unsigned char* mask_or_null, const float* cams12,
@@ -299,10 +340,17 @@ extern "C" int nbp_unproject_append_f32(const float* depth, const unsigned char*
     NBP_RETURN_IF(!(gathering_factor >= 0.0 && gathering_factor <= 1.0), NBP_E_ARG);
     NBP_RETURN_IF(ws_bytes < nbp_unproject_workspace_bytes(n_frames, H, W), NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;
-    unsigned* list = (unsigned*)(((uintptr_t)ws + 255) / 256 * 256);
-    unproject_compact_kernel<<<n_frames, 1024, 0, st>>>(depth, mask_or_null, H * W, fov_range, gathering_factor, list,
-                                                        counts2);
+    const int HW = H * W, nblk = (int)nbp_cdiv(HW, COMPACT_CHUNK);
+    NBP_RETURN_IF(nblk > 4096, NBP_E_SHAPE);
+    int* blk_count = (int*)(((uintptr_t)ws + 255) / 256 * 256);
+    unsigned* list = (unsigned*)((char*)blk_count + ((size_t)n_frames * nblk * sizeof(int) + 255) / 256 * 256);
+    dim3 gc((unsigned)nblk, (unsigned)n_frames);
+    unproject_count_kernel<<<gc, 256, 0, st>>>(depth, mask_or_null, HW, nblk, fov_range, blk_count);
     int rc = nbp_launch_status();
+    if (rc) return rc;
+    unproject_compact_kernel<<<gc, 256, 0, st>>>(depth, mask_or_null, HW, nblk, fov_range, gathering_factor, blk_count,
+                                                 list, counts2);
+    rc = nbp_launch_status();
     if (rc) return rc;
     const Cam* cams = reinterpret_cast<const Cam*>(cams12);   // [F][12]: R row-major (9) then T (3)
     const int max_keep = (int)((double)H * W * gathering_factor) + 1;
@@ -320,6 +368,7 @@ extern "C" size_t nbp_raster_workspace_bytes(int n_faces, int n_frames, int H, i
     const size_t tiles = (size_t)nbp_cdiv(W, TILE) * nbp_cdiv(H, TILE) * n_frames;
     size_t b = 256;
     b += ((size_t)n_frames * n_faces * sizeof(FaceRec) + 255) / 256 * 256;
+    b += ((size_t)n_frames * n_faces * sizeof(int4) + 255) / 256 * 256;
     b += (tiles * sizeof(int) + 255) / 256 * 256;
     b += (tiles * bin_cap * sizeof(int) + 255) / 256 * 256;
     return b + 256;
@@ -336,15 +385,19 @@ extern "C" int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* f
     const size_t tiles = (size_t)tiles_x * tiles_y * n_frames;
     char* p = (char*)(((uintptr_t)ws + 255) / 256 * 256);
     FaceRec* recs = (FaceRec*)p; p += ((size_t)n_frames * n_faces * sizeof(FaceRec) + 255) / 256 * 256;
+    int4* tbox = (int4*)p; p += ((size_t)n_frames * n_faces * sizeof(int4) + 255) / 256 * 256;
     int* tile_count = (int*)p; p += (tiles * sizeof(int) + 255) / 256 * 256;
     int* tile_list = (int*)p;
     hipError_t e = hipMemsetAsync(tile_count, 0, tiles * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
     dim3 g1((unsigned)nbp_cdiv(n_faces, 256), (unsigned)n_frames);
     raster_setup_kernel<<<g1, 256, 0, st>>>(verts, faces, n_faces, reinterpret_cast<const Cam*>(cams12), H, W,
-                                            tan_half_fov, z_clip, tiles_x, tiles_y, bin_cap, recs, tile_count, tile_list,
-                                            overflow_flag);
+                                            tan_half_fov, z_clip, recs, tbox);
     int rc = nbp_launch_status();
+    if (rc) return rc;
+    dim3 gb((unsigned)nbp_cdiv((long long)n_faces * tiles_y, 256), (unsigned)n_frames);
+    raster_bin_kernel<<<gb, 256, 0, st>>>(tbox, n_faces, tiles_x, tiles_y, bin_cap, tile_count, tile_list, overflow_flag);
+    rc = nbp_launch_status();
     if (rc) return rc;
     dim3 g2((unsigned)(tiles_x * tiles_y), (unsigned)n_frames);
     raster_tile_kernel<<<g2, 64, 0, st>>>(recs, n_faces, H, W, tan_half_fov, z_clip, tiles_x, tiles_y, bin_cap, tile_count,

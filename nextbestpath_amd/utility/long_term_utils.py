@@ -92,42 +92,60 @@ class LatticePlanner:
                     edges.append((n, self.node_index[nb]))
         self.edges = edges
         self.edge_id = {e: q for q, e in enumerate(edges)}
+        self.nbrs = [[] for _ in range(len(self.idx3))]          # per node: (neighbour id, edge id) in +x,-x,+z,-z order
+        for q, (a, b) in enumerate(edges):
+            self.nbrs[a].append((b, q))
         self.edges_dev = torch.tensor(edges, dtype=torch.int32, device=device)
+
+    def _edge_ok(self, blocked_h, collision_list, passable_list):
+        """Vectorised edge predicate of generate_Dijkstra_path.get_neighbors (ref :350-360):
+        ok = [a,b] in passable_list or (not blocked and [a,b] not in collision_list)."""
+        ok = ~blocked_h
+        for a, b in (e for e in collision_list if len(e) == 2):
+            q = self.edge_id.get((self.node_index.get(tuple(a), -1), self.node_index.get(tuple(b), -1)))
+            if q is not None:
+                ok[q] = False
+        for a, b in passable_list:
+            q = self.edge_id.get((self.node_index.get(tuple(a), -1), self.node_index.get(tuple(b), -1)))
+            if q is not None:
+                ok[q] = True
+        return ok
 
     def replan(self, pose, out1, out2, maps6, traj_img, collision_list, passable_list, check_first_edge=True):
         """Returns the path as a list of [i,j,k,2,h] (first node dropped, like ref :416) or None."""
         cam = self.camera
         obst, fullproj = hipops.fuse_obstacle(out2.reshape(self.S, self.S), maps6, traj_img.reshape(self.S, self.S))
-        skip_h = np.array([list(t) in collision_list for t in self.idx3.tolist()], dtype=np.uint8)
-        skip = torch.from_numpy(skip_h).to(self.device) if skip_h.any() else None
+        coll_pos = {tuple(e) for e in collision_list if len(e) == 3}
+        skip = None
+        if coll_pos:
+            skip_h = np.fromiter((tuple(t) in coll_pos for t in self.idx3.tolist()), dtype=np.uint8, count=len(self.idx3))
+            skip = torch.from_numpy(skip_h).to(self.device)
         o1 = out1.reshape(8, self.V, self.V)
         valid, cell, score = hipops.score_candidates(self.pos_dev, pose, o1, fullproj, skip, self.grid_range)
         blocked = hipops.edges_blocked(obst, pose, self.pos_dev, self.edges_dev, self.grid_range)
-        # one synchronising copy for everything the host logic needs
+        # one synchronising round of copies for everything the host logic needs
         valid_h, score_h = valid.cpu().numpy().astype(bool), score.cpu().numpy()
         blocked_h = blocked.cpu().numpy().astype(bool)
         out1_h = o1.cpu().numpy()
-        cand = [int(i) for i in np.nonzero(valid_h)[0]]
-        cand.sort(key=lambda i: score_h[i], reverse=True)            # stable, descending (ref :233)
-        start = tuple(cam.cam_idx[:3])
+        cand = np.nonzero(valid_h)[0]
+        cand = cand[np.argsort(-score_h[cand], kind="stable")].tolist()      # stable, descending (ref :233)
+        start_id = self.node_index[tuple(cam.cam_idx[:3])]
         hist = np.asarray(cam.cam_idx_history, np.int64).reshape(-1, 5)
-
-        def passable(a, b):
-            ab = [list(a), list(b)]
-            if ab in passable_list:
-                return True
-            return (not blocked_h[self.edge_id[(self.node_index[a], self.node_index[b])]]) and ab not in collision_list
-
         tree, tree_version = None, -1
         path = None
         for ci in cand:
             if tree is None or tree_version != len(collision_list):
-                tree = planner_host.dijkstra_tree(self.node_index, start, passable)
+                tree = planner_host.level_order_tree(self.nbrs, self._edge_ok(blocked_h, collision_list, passable_list),
+                                                     start_id)
                 tree_version = len(collision_list)
-            nodes = planner_host.path_from_tree(tree, tuple(self.idx3[ci].tolist()))
-            if nodes is None:
+            if ci not in tree:
                 path = None
                 continue
+            ids, cur = [], ci
+            while cur >= 0:
+                ids.append(cur)
+                cur = tree[cur]
+            nodes = [tuple(self.idx3[n].tolist()) for n in ids[::-1]]
             full = planner_host.choose_headings(nodes, self.xyz, self.node_index, pose, out1_h, hist, self.V,
                                                 self.grid_range)
             path = full[1:]

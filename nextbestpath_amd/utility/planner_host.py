@@ -40,6 +40,24 @@ def dijkstra_tree(nodes, start, passable):
     return came_from
 
 
+def level_order_tree(nbrs, ok, start_id):
+    """Same tree as dijkstra_tree, on integer node ids and a precomputed edge mask.
+    Node ids must be assigned in lexicographic (i,j,k) order: then the reference's heap order
+    (cost, tuple) == expanding each BFS level in increasing id, and came_from == first discoverer.
+    nbrs[u] = [(v, edge_id), ...] in the reference's neighbour order (+x, -x, +z, -z)."""
+    parent = {start_id: -1}
+    level = [start_id]
+    while level:
+        nxt = []
+        for u in sorted(level):
+            for v, q in nbrs[u]:
+                if ok[q] and v not in parent:
+                    parent[v] = u
+                    nxt.append(v)
+        level = nxt
+    return parent
+
+
 def path_from_tree(came_from, goal):
     if goal not in came_from:
         return None

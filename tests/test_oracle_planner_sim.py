@@ -80,6 +80,17 @@ def test_dijkstra_vs_reference(golden_dir):
             [list(a), list(b)] not in coll
 
     tree = opl.dijkstra_tree(set(nodes), tuple(g["start"].tolist()), passable)
+    # the product's integer level-order search builds the same tree as the heapq search
+    edges, nbrs = [], [[] for _ in idx]
+    for n, (i, j, k) in enumerate(idx):
+        for nb in ((i + 1, j, k), (i - 1, j, k), (i, j, k + 1), (i, j, k - 1)):
+            if nb in nodes:
+                nbrs[n].append((nodes[nb], len(edges)))
+                edges.append((n, nodes[nb]))
+    ok = [passable(idx[a], idx[b]) for a, b in edges]
+    par = ph.level_order_tree(nbrs, ok, nodes[tuple(g["start"].tolist())])
+    assert {idx[v]: (idx[p] if p >= 0 else None) for v, p in par.items()} == tree
+    assert ph.dijkstra_tree(set(nodes), tuple(g["start"].tolist()), passable) == tree
     off = 0
     for gi, n in zip(g["goals"].tolist(), g["path_lens"].tolist()):
         path = opl.path_from_tree(tree, idx[gi])
