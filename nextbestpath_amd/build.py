@@ -43,7 +43,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    dig = _digest()
+    extra = os.environ.get("NBP_EXTRA_FLAGS", "").split()
+    dig = _digest() + " ".join(extra)
     if not force and os.path.exists(LIB) and os.path.exists(STAMP):
         with open(STAMP) as fh:
             if fh.read().strip() == dig:
@@ -55,7 +56,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, "-c", src, "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -18,6 +18,13 @@
 // 8j+4..8j+7); A and B use the same permutation so the sum over k is complete.
 #include "common.h"
 
+#ifndef NBP_STAGGER
+#define NBP_STAGGER 0
+#endif
+#ifndef NBP_INTERLEAVE
+#define NBP_INTERLEAVE 0
+#endif
+
 struct IgemmArgs {
     const float* src0;
     const float* src1;
@@ -38,10 +45,24 @@ struct IgemmArgs {
     int chunks_total;
     int chunks_per_split;
     unsigned bytes0, bytes1;   // byte sizes of src0 / src1 (buffer-descriptor range, < 2 GiB)
+    float* partial;    // split-K scratch [group][split][M][N]
+    // second problem of a grouped launch (same shapes, other tensors): blockIdx.z >= split_k
+    int groups;
+    const float* g_src0;
+    const float* g_src1;
+    const float* g_wpk;
+    const float* g_scale;
+    const float* g_shift;
+    float* g_out;
 };
 
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
+    int zs = blockIdx.z;
+    if (zs >= a.split_k) {     // second group of a grouped launch (decoder 2 next to decoder 1)
+        zs -= a.split_k;
+        a.src0 = a.g_src0; a.src1 = a.g_src1; a.wpk = a.g_wpk; a.scale = a.g_scale; a.shift = a.g_shift; a.out = a.g_out;
+    }
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int RA = BM / 32, RB = BN / 32;
     constexpr int STAGE = (BM + BN) * 32;  // floats per LDS stage
@@ -52,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const long long m0 = (long long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int c_begin = blockIdx.z * a.chunks_per_split;
+    const int c_begin = zs * a.chunks_per_split;
     const int c_end = min(c_begin + a.chunks_per_split, a.chunks_total);
 
     // ---- per-thread staging coordinates: thread t moves 16 B: row t/8 (+32 i), slot t%8
@@ -148,9 +169,19 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
     }
     __syncthreads();
     int cur = 0;
+#if NBP_STAGGER
+    // the two workgroups that share a CU start in phase and would hit their load/barrier phases together:
+    // delay the second half of the grid by ~half a chunk so one wave's MFMA block covers the other's gap
+    {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lin >= (gridDim.x * gridDim.y * gridDim.z) / 2) __builtin_amdgcn_s_sleep(NBP_STAGGER);
+    }
+#endif
     for (int c = c_begin; c < c_end; ++c) {
         const bool more = (c + 1 < c_end);
+#if !NBP_INTERLEAVE
         if (more) load_global(c + 1);
+#endif
         const float* A = lds + cur * STAGE;
         const float* Bt = A + BM * 32;
 #pragma unroll
@@ -163,6 +194,9 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 bf[j] = *reinterpret_cast<const f32x4*>(Bt + fb_row[j] + ((s ^ fb_sw[j]) << 2));
+#if NBP_INTERLEAVE
+            if (j4 == 0 && more) load_global(c + 1);      // issued under the first MFMA group
+#endif
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -170,15 +204,20 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+#if NBP_INTERLEAVE
+            if (j4 == 2 && more) store_lds(cur ^ 1);      // lands while the last MFMA group runs
+#endif
         }
+#if !NBP_INTERLEAVE
         if (more) store_lds(cur ^ 1);
+#endif
         __syncthreads();
         cur ^= 1;
     }
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
     const bool final_out = (a.split_k == 1);
-    float* outp = a.out + (final_out ? 0 : (long long)blockIdx.z * a.M * a.N);
+    float* outp = final_out ? a.out : a.partial + (long long)blockIdx.z * a.M * a.N;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -202,11 +241,13 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
     }
 }
 
-// out[m][n] = act(sum_s partial[s][m][n] * scale[n] + shift[n]);  N % 4 == 0
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int split_k,
-                                                            long long MN, int N, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, int relu,
-                                                            float* __restrict__ out) {
+// out[m][n] = act(sum_s partial[s][m][n] * scale[n] + shift[n]);  N % 4 == 0; blockIdx.y = group
+struct ReduceGroup { const float* scale; const float* shift; float* out; };
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial_all, int split_k,
+                                                            long long MN, int N, ReduceGroup g0, ReduceGroup g1,
+                                                            int relu) {
+    const ReduceGroup g = blockIdx.y ? g1 : g0;
+    const float* __restrict__ partial = partial_all + (long long)blockIdx.y * split_k * MN;
     const long long n4 = MN >> 2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
@@ -216,14 +257,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             s += p;
         }
         const int n = (int)((i * 4) % N);
-        f32x4 sc = *reinterpret_cast<const f32x4*>(scale + n);
-        f32x4 sh = *reinterpret_cast<const f32x4*>(shift + n);
+        f32x4 sc = *reinterpret_cast<const f32x4*>(g.scale + n);
+        f32x4 sh = *reinterpret_cast<const f32x4*>(g.shift + n);
         f32x4 v = s * sc + sh;
         if (relu) {
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
             v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
         }
-        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+        *reinterpret_cast<f32x4*>(g.out + i * 4) = v;
     }
 }
 
@@ -246,7 +287,7 @@ static TileInfo tile_info(int tile) {
 struct ConvPlan { int tile; int split_k; int chunks_per_split; };
 
 // Shared by the forward, the single-layer entry point and the workspace query.
-ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k) {
+ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k, int groups) {
     ConvPlan p;
     if (tile == NBP_TILE_AUTO) {
         if (N % 128 == 0) tile = (M <= 64 ? NBP_TILE_64x128 : NBP_TILE_128x128);
@@ -259,7 +300,7 @@ ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split
         long long blocks = nbp_cdiv(M, ti.bm) * (N / ti.bn);
         split_k = 1;
         // aim for >= 2 workgroups per CU (512) while each split keeps >= 8 chunks of K
-        while (blocks * split_k < 512 && chunks_total / (split_k * 2) >= 8 && split_k < 64) split_k *= 2;
+        while (blocks * groups * split_k < 512 && chunks_total / (split_k * 2) >= 8 && split_k < 64) split_k *= 2;
     }
     if (split_k > chunks_total) split_k = chunks_total;
     p.chunks_per_split = (int)nbp_cdiv(chunks_total, split_k);
@@ -278,25 +319,33 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((unsigned)nbp_cdiv(a.M, BM), (unsigned)(a.N / BN), (unsigned)a.split_k);
+    dim3 grid((unsigned)nbp_cdiv(a.M, BM), (unsigned)(a.N / BN), (unsigned)(a.split_k * a.groups));
     igemm_conv_kernel<WM, WN, TM, TN><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 
-// Internal entry used by nbp_forward.hip too.
-int nbp_conv_igemm_launch(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
-                          int ksize, const float* wpk, int N, const float* scale, const float* shift, int relu,
-                          float* out, int split_k, int tile, void* ws, size_t ws_bytes, hipStream_t st) {
-    NBP_RETURN_IF(!src0 || !wpk || !scale || !shift || !out, NBP_E_ARG);
+// Internal entry used by nbp_forward.hip too.  groups == 2 runs two same-shaped convolutions
+// (operand set `o` and `o2`) in one launch.
+struct ConvOperands { const float* src0; const float* src1; const float* wpk; const float* scale; const float* shift; float* out; };
+
+int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C0, int C1, int ups, int B, int H, int W,
+                            int ksize, int N, int relu, int split_k, int tile, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int groups = o2 ? 2 : 1;
+    NBP_RETURN_IF(!o.src0 || !o.wpk || !o.scale || !o.shift || !o.out, NBP_E_ARG);
+    NBP_RETURN_IF(o2 && (!o2->src0 || !o2->wpk || !o2->scale || !o2->shift || !o2->out), NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 1 || W < 1, NBP_E_ARG);
     NBP_RETURN_IF(ksize != 1 && ksize != 3, NBP_E_ARG);
     NBP_RETURN_IF(C0 < 32 || C0 % 32 || C1 < 0 || C1 % 32 || N < 32 || N % 32, NBP_E_SHAPE);
-    NBP_RETURN_IF(C1 > 0 && !src1, NBP_E_ARG);
+    NBP_RETURN_IF(C1 > 0 && (!o.src1 || (o2 && !o2->src1)), NBP_E_ARG);
     NBP_RETURN_IF(ups && ((H | W) & 1), NBP_E_SHAPE);
     IgemmArgs a;
-    a.src0 = src0; a.src1 = src1; a.C0 = C0; a.C1 = C1; a.cc0 = C0 / 32; a.ups = ups ? 1 : 0;
+    a.src0 = o.src0; a.src1 = o.src1; a.C0 = C0; a.C1 = C1; a.cc0 = C0 / 32; a.ups = ups ? 1 : 0;
     a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W;
-    a.taps = ksize * ksize; a.wpk = wpk; a.N = N; a.scale = scale; a.shift = shift; a.relu = relu;
+    a.taps = ksize * ksize; a.wpk = o.wpk; a.N = N; a.scale = o.scale; a.shift = o.shift; a.relu = relu;
+    a.out = o.out;
+    a.groups = groups;
+    a.g_src0 = o2 ? o2->src0 : nullptr; a.g_src1 = o2 ? o2->src1 : nullptr; a.g_wpk = o2 ? o2->wpk : nullptr;
+    a.g_scale = o2 ? o2->scale : nullptr; a.g_shift = o2 ? o2->shift : nullptr; a.g_out = o2 ? o2->out : nullptr;
     a.M = (long long)B * H * W;
     {
         const long long b0 = (long long)B * a.Hs * a.Ws * C0 * 4, b1 = (long long)B * a.Hs * a.Ws * C1 * 4;
@@ -304,15 +353,14 @@ int nbp_conv_igemm_launch(const float* src0, int C0, const float* src1, int C1, 
         a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0;
     }
     a.chunks_total = (C0 + C1) / 32 * a.taps;
-    ConvPlan p = nbp_plan_conv(a.M, N, a.chunks_total, tile, split_k);
+    ConvPlan p = nbp_plan_conv(a.M, N, a.chunks_total, tile, split_k, groups);
     TileInfo ti = tile_info(p.tile);
     NBP_RETURN_IF(ti.bm == 0 || N % ti.bn, NBP_E_SHAPE);
     a.split_k = p.split_k; a.chunks_per_split = p.chunks_per_split;
+    a.partial = nullptr;
     if (p.split_k > 1) {
-        NBP_RETURN_IF(!ws || ws_bytes < (size_t)p.split_k * a.M * N * sizeof(float), NBP_E_WS);
-        a.out = (float*)ws;
-    } else {
-        a.out = out;
+        NBP_RETURN_IF(!ws || ws_bytes < (size_t)groups * p.split_k * a.M * N * sizeof(float), NBP_E_WS);
+        a.partial = (float*)ws;
     }
     int rc;
     switch (p.tile) {
@@ -326,11 +374,19 @@ int nbp_conv_igemm_launch(const float* src0, int C0, const float* src1, int C1, 
     if (rc) return rc;
     if (p.split_k > 1) {
         long long MN = a.M * N;
-        splitk_reduce_kernel<<<nbp_ew_grid(MN / 4, 256), 256, 0, st>>>((const float*)ws, p.split_k, MN, N, scale,
-                                                                        shift, relu, out);
+        ReduceGroup g0{o.scale, o.shift, o.out}, g1{a.g_scale, a.g_shift, a.g_out};
+        dim3 grid((unsigned)nbp_ew_grid(MN / 4, 256), (unsigned)groups);
+        splitk_reduce_kernel<<<grid, 256, 0, st>>>((const float*)ws, p.split_k, MN, N, g0, g1, relu);
         rc = nbp_launch_status();
     }
     return rc;
+}
+
+int nbp_conv_igemm_launch(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
+                          int ksize, const float* wpk, int N, const float* scale, const float* shift, int relu,
+                          float* out, int split_k, int tile, void* ws, size_t ws_bytes, hipStream_t st) {
+    ConvOperands o{src0, src1, wpk, scale, shift, out};
+    return nbp_conv_igemm_launch_g(o, nullptr, C0, C1, ups, B, H, W, ksize, N, relu, split_k, tile, ws, ws_bytes, st);
 }
 
 extern "C" int nbp_conv_igemm_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H,

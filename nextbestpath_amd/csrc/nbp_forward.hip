@@ -10,11 +10,11 @@
 #include <stdlib.h>
 #include <string.h>
 
-int nbp_conv_igemm_launch(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
-                          int ksize, const float* wpk, int N, const float* scale, const float* shift, int relu,
-                          float* out, int split_k, int tile, void* ws, size_t ws_bytes, hipStream_t st);
+struct ConvOperands { const float* src0; const float* src1; const float* wpk; const float* scale; const float* shift; float* out; };
+int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C0, int C1, int ups, int B, int H, int W,
+                            int ksize, int N, int relu, int split_k, int tile, void* ws, size_t ws_bytes, hipStream_t st);
 struct ConvPlan { int tile; int split_k; int chunks_per_split; };
-ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k);
+ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k, int groups);
 
 namespace {
 
@@ -220,9 +220,9 @@ struct Timer {
     }
 };
 
-size_t splitk_scratch_floats(long long M, int N, int cin_total, int taps) {
-    ConvPlan p = nbp_plan_conv(M, N, cin_total / 32 * taps, 0, 0);
-    return p.split_k > 1 ? (size_t)p.split_k * M * N : 0;
+size_t splitk_scratch_floats(long long M, int N, int cin_total, int taps, int groups = 1) {
+    ConvPlan p = nbp_plan_conv(M, N, cin_total / 32 * taps, 0, 0, groups);
+    return p.split_k > 1 ? (size_t)groups * p.split_k * M * N : 0;
 }
 
 // Runs (or, with h == nullptr, only sizes) the network.
@@ -242,25 +242,39 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
             if (e > 0) sk = max(sk, splitk_scratch_floats(M, enc[e], enc[e - 1], 9));
             sk = max(sk, splitk_scratch_floats(M, enc[e], enc[e], 9));
             if (e < 4) {   // decoder level at this resolution: co = enc[e], ci = enc[e+1]
-                sk = max(sk, splitk_scratch_floats(M, enc[e], enc[e + 1], 9));
-                sk = max(sk, splitk_scratch_floats(M, enc[e] / 2, 2 * enc[e], 1));
+                for (int g = 1; g <= 2; ++g) {      // levels 5 and 4 run both decoders in one grouped launch
+                    sk = max(sk, splitk_scratch_floats(M, enc[e], enc[e + 1], 9, g));
+                    sk = max(sk, splitk_scratch_floats(M, enc[e], enc[e], 9, g));
+                    sk = max(sk, splitk_scratch_floats(M, enc[e] / 2, 2 * enc[e], 1, g));
+                }
             }
         }
     }
     float* skws = bp.take(sk ? sk : 64);
     const size_t skbytes = sk * sizeof(float);
 
-    auto conv = [&](const char* name, int li, const float* s0, int C0, const float* s1, int C1, int ups, int Hh,
-                    int ksize, int N, float* out) {
+    // one (ng = 1) or two (ng = 2: decoder 1 next to decoder 2) same-shaped convolutions per launch
+    auto conv2 = [&](const char* name, int ng, const int* li, const float* const* s0, int C0, const float* const* s1,
+                     int C1, int ups, int Hh, int ksize, int N, float* const* out) {
         if (dry || rc) return;
-        rc = nbp_conv_igemm_launch(s0, C0, s1, C1, ups, B, Hh, Hh, ksize, h->w[li], N, h->scale[li], h->shift[li], 1,
-                                   out, 0, 0, skws, skbytes, st);
+        ConvOperands o[2];
+        for (int g = 0; g < ng; ++g)
+            o[g] = ConvOperands{s0[g], s1 ? s1[g] : nullptr, h->w[li[g]], h->scale[li[g]], h->shift[li[g]], out[g]};
+        rc = nbp_conv_igemm_launch_g(o[0], ng == 2 ? &o[1] : nullptr, C0, C1, ups, B, Hh, Hh, ksize, N, 1, 0, 0, skws,
+                                     skbytes, st);
         if (tm && !rc) {
             const long long M = (long long)B * Hh * Hh;
             const int K = (C0 + C1) * ksize * ksize;
-            ConvPlan p = nbp_plan_conv(M, N, K / 32, 0, 0);
-            tm->mark(name, 2.0 * M * N * K, p.tile, p.split_k, M, N, K);
+            ConvPlan p = nbp_plan_conv(M, N, K / 32, 0, 0, ng);
+            tm->mark(name, 2.0 * ng * M * N * K, p.tile, p.split_k, M, N, K);
         }
+    };
+    auto conv = [&](const char* name, int li, const float* s0, int C0, const float* s1, int C1, int ups, int Hh,
+                    int ksize, int N, float* out) {
+        const float* s0a[1] = {s0};
+        const float* s1a[1] = {s1};
+        float* oa[1] = {out};
+        conv2(name, 1, &li, s0a, C0, s1 ? s1a : nullptr, C1, ups, Hh, ksize, N, oa);
     };
     auto stamp = [&](const char* name, double flops, long long M, int N, int K) {
         if (tm && !dry && !rc) tm->mark(name, flops, -1, 1, M, N, K);
@@ -293,47 +307,54 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
         skip[e] = b; prev = b;
         if (e < 4) s /= 2;
     }
-    // ---- decoders.  Level L (5..2) works at resolution S >> (L-1) with co = enc[L-2], ci = enc[L-1].
-    for (int d = 1; d <= 2; ++d) {
-        const float* cur = skip[4];
-        const size_t mark = bp.off;           // decoder scratch is reused by decoder 2
-        const int last_level = (d == 1) ? 4 : 2;
-        for (int Lv = 5; Lv >= last_level; --Lv) {
-            const int co = enc[Lv - 2], ci = enc[Lv - 1];
-            const int sr = S >> (Lv - 2);
-            const long long M = (long long)B * sr * sr;
-            float* dd = bp.take((size_t)M * co);
-            float* q = bp.take((size_t)M * (co / 2));
-            float* ag = bp.take((size_t)M * co);
-            float* u = bp.take((size_t)M * co);
-            float* o = bp.take((size_t)M * co);
-            const float* xs = skip[Lv - 2];
-            snprintf(nm, sizeof nm, "Up%d_%d.up.1", Lv, d);
-            conv(nm, li, cur, ci, nullptr, 0, 1, sr, 3, co, dd);                   // Up: upsample + conv3x3
-            snprintf(nm, sizeof nm, "Att%d_%d.W_g+W_x", Lv, d);
-            conv(nm, li + 1, dd, co, xs, co, 0, sr, 1, co / 2, q);                 // relu(W_g g + W_x x)
-            if (!dry && !rc)
-                rc = nbp_psi_gate_f32(q, co / 2, h->w[li + 3], h->scale[li + 3], xs, co, M, ag, st);
-            snprintf(nm, sizeof nm, "Att%d_%d.psi*x", Lv, d);
-            stamp(nm, 2.0 * M * (co / 2), M, 1, co / 2);
-            snprintf(nm, sizeof nm, "Up_conv%d_%d.conv.0", Lv, d);
-            conv(nm, li + 4, ag, co, dd, co, 0, sr, 3, co, u);                      // conv(cat(a, d))
-            snprintf(nm, sizeof nm, "Up_conv%d_%d.conv.3", Lv, d);
-            conv(nm, li + 5, u, co, nullptr, 0, 0, sr, 3, co, o);
-            li += 6;
-            cur = o;
+    // ---- decoders.  Level L (5..2) works at resolution S >> (L-2) with co = enc[L-2], ci = enc[L-1].
+    // Levels 5 and 4 exist in both decoders with identical shapes: each of their layers is ONE grouped
+    // launch (decoder 1 = group 0, decoder 2 = group 1), which doubles the workgroups per launch at
+    // B = 1 and halves the split-K factor.  Decoder 2 then continues alone through levels 3 and 2.
+    const int li_d1 = 10, li_d2 = 22;
+    const float* cur[2] = {skip[4], skip[4]};
+    for (int Lv = 5; Lv >= 2; --Lv) {
+        const int ng = Lv >= 4 ? 2 : 1;
+        const int g0 = Lv >= 4 ? 0 : 1;                 // first decoder index handled (0-based)
+        const int co = enc[Lv - 2], ci = enc[Lv - 1];
+        const int sr = S >> (Lv - 2);
+        const long long M = (long long)B * sr * sr;
+        const float* xs = skip[Lv - 2];
+        float *dd[2], *q[2], *ag[2], *u[2], *o[2];
+        int lis[2];
+        const float *src[2], *xsa[2] = {xs, xs};
+        for (int g = 0; g < ng; ++g) {
+            dd[g] = bp.take((size_t)M * co); q[g] = bp.take((size_t)M * (co / 2)); ag[g] = bp.take((size_t)M * co);
+            u[g] = bp.take((size_t)M * co); o[g] = bp.take((size_t)M * co);
+            const int d = g0 + g;                       // 0 = decoder 1, 1 = decoder 2
+            lis[g] = (d == 0 ? li_d1 : li_d2) + (5 - Lv) * 6;
+            src[g] = cur[d];
         }
-        if (d == 1) {
+        const char* tag = ng == 2 ? "{1,2}" : "2";
+        auto shifted = [&](int k, int* dst) { for (int g = 0; g < ng; ++g) dst[g] = lis[g] + k; };
+        int l[2];
+        snprintf(nm, sizeof nm, "Up%d_%s.up.1", Lv, tag);
+        shifted(0, l); conv2(nm, ng, l, src, ci, nullptr, 0, 1, sr, 3, co, dd);                    // upsample + conv3x3
+        snprintf(nm, sizeof nm, "Att%d_%s.W_g+W_x", Lv, tag);
+        shifted(1, l); conv2(nm, ng, l, (const float* const*)dd, co, xsa, co, 0, sr, 1, co / 2, q);  // relu(W_g g + W_x x)
+        for (int g = 0; g < ng && !dry && !rc; ++g)
+            rc = nbp_psi_gate_f32(q[g], co / 2, h->w[lis[g] + 3], h->scale[lis[g] + 3], xs, co, M, ag[g], st);
+        snprintf(nm, sizeof nm, "Att%d_%s.psi*x", Lv, tag);
+        stamp(nm, 2.0 * ng * M * (co / 2), M, 1, co / 2);
+        snprintf(nm, sizeof nm, "Up_conv%d_%s.conv.0", Lv, tag);
+        shifted(4, l); conv2(nm, ng, l, (const float* const*)ag, co, (const float* const*)dd, co, 0, sr, 3, co, u);
+        snprintf(nm, sizeof nm, "Up_conv%d_%s.conv.3", Lv, tag);
+        shifted(5, l); conv2(nm, ng, l, (const float* const*)u, co, nullptr, 0, 0, sr, 3, co, o);
+        for (int g = 0; g < ng; ++g) cur[g0 + g] = o[g];
+        if (Lv == 4) {
             if (!dry && !rc)
-                rc = nbp_final_1x1_f32(cur, B, S / 4, S / 4, 256, h->w[46], 8, h->scale[46], h->shift[46], 0, out1, st);
+                rc = nbp_final_1x1_f32(cur[0], B, S / 4, S / 4, 256, h->w[46], 8, h->scale[46], h->shift[46], 0, out1, st);
             stamp("Final1", 2.0 * B * (S / 4) * (S / 4) * 8 * 256, (long long)B * (S / 4) * (S / 4), 8, 256);
-            bp.off = mark;   // decoder 2 reuses decoder 1's scratch (it needs strictly more, so sizing is safe)
-        } else {
-            if (!dry && !rc)
-                rc = nbp_final_1x1_f32(cur, B, S, S, 64, h->w[47], 1, h->scale[47], h->shift[47], 1, out2, st);
-            stamp("Final2", 2.0 * B * S * S * 64, (long long)B * S * S, 1, 64);
         }
     }
+    if (!dry && !rc)
+        rc = nbp_final_1x1_f32(cur[1], B, S, S, 64, h->w[47], 1, h->scale[47], h->shift[47], 1, out2, st);
+    stamp("Final2", 2.0 * B * S * S * 64, (long long)B * S * S, 1, 64);
     return rc;
 }
 

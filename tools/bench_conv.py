@@ -1,0 +1,72 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single NBP conv layers through nbp_conv_igemm_f32 (HIP events).
+    python tools/bench_conv.py [--tile T] [--split K] [--batch B]
+Prints time / TFLOP/s per representative layer shape."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nextbestpath_amd import _lib  # noqa: E402
+
+# name, H(=W) of output, C0, C1, N, ksize, ups
+SHAPES = [("Conv1.3", 256, 64, 0, 64, 3, 0), ("Conv2.0", 128, 64, 0, 128, 3, 0), ("Conv2.3", 128, 128, 0, 128, 3, 0),
+          ("Conv3.3", 64, 256, 0, 256, 3, 0), ("Conv4.3", 32, 512, 0, 512, 3, 0), ("Conv5.0", 16, 512, 0, 1024, 3, 0),
+          ("Conv5.3", 16, 1024, 0, 1024, 3, 0), ("Up5", 32, 1024, 0, 512, 3, 1), ("Upc5.0", 32, 512, 512, 512, 3, 0),
+          ("Up4", 64, 512, 0, 256, 3, 1), ("Up3", 128, 256, 0, 128, 3, 1), ("Up2", 256, 128, 0, 64, 3, 1),
+          ("Upc2.0", 256, 64, 64, 64, 3, 0), ("Att5", 32, 512, 512, 256, 1, 0), ("Att2", 256, 64, 64, 32, 1, 0)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--split", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    L = _lib.lib()
+    dev = "cuda"
+    tot_t = tot_f = 0.0
+    for name, H, C0, C1, N, k, ups in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        B = a.batch
+        Hs = H // 2 if ups else H
+        s0 = torch.randn(B, Hs, Hs, C0, device=dev)
+        s1 = torch.randn(B, Hs, Hs, C1, device=dev) if C1 else None
+        wpk = torch.randn((C0 + C1) // 32 * k * k * N * 32, device=dev) * 0.02
+        sc, sh = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+        out = torch.empty(B, H, H, N, device=dev)
+        ws = torch.empty(max(L.nbp_conv_igemm_workspace_bytes(B, H, H, N, a.split), 256), dtype=torch.uint8, device=dev)
+
+        def run():
+            rc = L.nbp_conv_igemm_f32(s0.data_ptr(), C0, _lib.ptr(s1), C1, ups, B, H, H, k, wpk.data_ptr(), N,
+                                      sc.data_ptr(), sh.data_ptr(), 1, out.data_ptr(), a.split, a.tile, ws.data_ptr(),
+                                      ws.numel(), _lib.current_stream())
+            assert rc == 0, rc
+        rc0 = L.nbp_conv_igemm_f32(s0.data_ptr(), C0, _lib.ptr(s1), C1, ups, B, H, H, k, wpk.data_ptr(), N, sc.data_ptr(),
+                                   sh.data_ptr(), 1, out.data_ptr(), a.split, a.tile, ws.data_ptr(), ws.numel(),
+                                   _lib.current_stream())
+        if rc0 != 0:
+            print(f"{name:8s} unsupported with tile {a.tile} (rc {rc0})")
+            continue
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.reps
+        fl = 2.0 * B * H * H * N * (C0 + C1) * k * k
+        tot_t += ms; tot_f += fl
+        print(f"{name:8s} M={B*H*H:6d} N={N:4d} K={(C0+C1)*k*k:5d}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.2f} TF")
+    print(f"TOTAL {tot_t*1e3:.1f} us  {tot_f/tot_t/1e9:.2f} TF")
+
+
+if __name__ == "__main__":
+    main()
