@@ -288,19 +288,28 @@ struct ConvPlan { int tile; int split_k; int chunks_per_split; };
 
 // Shared by the forward, the single-layer entry point and the workspace query.
 ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k, int groups) {
+    // Policy from tools/bench_conv.py --sweep on MI355X (B = 1, 2, 8; SURVEY.md A.1 shapes): the big
+    // 128x128 / 256x64 tiles only pay once they alone give >= 512 workgroups (2 per CU); with fewer
+    // tiles the half-size tiles (64x128, 128x64) reach the same workgroup count with half the split-K,
+    // i.e. half the partial-sum traffic, and win by 5-30 % at B = 1.
     ConvPlan p;
     if (tile == NBP_TILE_AUTO) {
-        if (N % 128 == 0) tile = (M <= 64 ? NBP_TILE_64x128 : NBP_TILE_128x128);
-        else if (N % 64 == 0) tile = (M >= 256 * 256 ? NBP_TILE_256x64 : NBP_TILE_128x64);
-        else tile = NBP_TILE_256x32;
+        if (N % 128 == 0)
+            tile = nbp_cdiv(M, 128) * (N / 128) * groups >= 512 ? NBP_TILE_128x128 : NBP_TILE_64x128;
+        else if (N % 64 == 0)
+            tile = nbp_cdiv(M, 256) * (N / 64) * groups >= 512 ? NBP_TILE_256x64 : NBP_TILE_128x64;
+        else
+            tile = NBP_TILE_256x32;
     }
     p.tile = tile;
     TileInfo ti = tile_info(tile);
     if (split_k <= 0) {
-        long long blocks = nbp_cdiv(M, ti.bm) * (N / ti.bn);
+        const long long blocks = nbp_cdiv(M, ti.bm) * (N / ti.bn) * groups;
         split_k = 1;
-        // aim for >= 2 workgroups per CU (512) while each split keeps >= 8 chunks of K
-        while (blocks * groups * split_k < 512 && chunks_total / (split_k * 2) >= 8 && split_k < 64) split_k *= 2;
+        // aim for >= 2 workgroups per CU (512) while each split keeps >= 4 chunks of K ...
+        while (blocks * split_k < 512 && chunks_total / (split_k * 2) >= 4 && split_k < 64) split_k *= 2;
+        // ... but a 2-way split of a short K (< 12 chunks each) costs more than it buys
+        if (split_k == 2 && chunks_total / 2 < 12) split_k = 1;
     }
     if (split_k > chunks_total) split_k = chunks_total;
     p.chunks_per_split = (int)nbp_cdiv(chunks_total, split_k);

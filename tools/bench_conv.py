@@ -19,6 +19,45 @@ SHAPES = [("Conv1.3", 256, 64, 0, 64, 3, 0), ("Conv2.0", 128, 64, 0, 128, 3, 0),
           ("Upc2.0", 256, 64, 64, 64, 3, 0), ("Att5", 32, 512, 512, 256, 1, 0), ("Att2", 256, 64, 64, 32, 1, 0)]
 
 
+def sweep(a):
+    L = _lib.lib()
+    dev = "cuda"
+    for name, H, C0, C1, N, k, ups in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        B = a.batch
+        Hs = H // 2 if ups else H
+        s0 = torch.randn(B, Hs, Hs, C0, device=dev)
+        s1 = torch.randn(B, Hs, Hs, C1, device=dev) if C1 else None
+        wpk = torch.randn((C0 + C1) // 32 * k * k * N * 32, device=dev) * 0.02
+        sc, sh = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+        out = torch.empty(B, H, H, N, device=dev)
+        ws = torch.empty(max(L.nbp_conv_igemm_workspace_bytes(B, H, H, N, 64), 256), dtype=torch.uint8, device=dev)
+        chunks = (C0 + C1) // 32 * k * k
+        cfgs = [(0, 0)] + [(t, sk) for t in (1, 2, 3, 4, 5) for sk in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32) if sk <= chunks]
+        res = {}
+        for rnd in range(3):
+            for cfg in cfgs:
+                def run():
+                    return L.nbp_conv_igemm_f32(s0.data_ptr(), C0, _lib.ptr(s1), C1, ups, B, H, H, k, wpk.data_ptr(), N,
+                                                sc.data_ptr(), sh.data_ptr(), 1, out.data_ptr(), cfg[1], cfg[0],
+                                                ws.data_ptr(), ws.numel(), _lib.current_stream())
+                if run() != 0:
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                res.setdefault(cfg, []).append(e0.elapsed_time(e1) / 10)
+        fl = 2.0 * B * H * H * N * (C0 + C1) * k * k
+        best = sorted((min(v), c) for c, v in res.items())
+        auto = min(res[(0, 0)])
+        txt = "  ".join(f"t{c[0]}/s{c[1]}:{t*1e3:.1f}" for t, c in best[:5])
+        print(f"{name:8s} M={B*H*H:6d} N={N:4d} K={(C0+C1)*k*k:5d} auto {auto*1e3:7.1f} us ({fl/auto/1e9:6.1f} TF) | best {txt}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tile", type=int, default=0)
@@ -26,7 +65,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--only", default="")
+    ap.add_argument("--sweep", action="store_true", help="try every (tile, split) and report the best per shape")
     a = ap.parse_args()
+    if a.sweep:
+        return sweep(a)
     L = _lib.lib()
     dev = "cuda"
     tot_t = tot_f = 0.0
