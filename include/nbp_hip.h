@@ -201,6 +201,17 @@ int nbp_segments_hit_mesh_f32(const float* verts, const int* faces, int n_faces,
  * of triangles hit from pts3[k] along +Y, +X, +Z (inside iff all three are odd). */
 int nbp_axis_ray_counts_f32(const float* verts, const int* faces, int n_faces, const float* pts3,
                             int n_pts, int* counts3, void* stream);
+/* Depth-map space carving of proxy points (A20): Camera.get_points_in_fov (mu:2849-2884) +
+ * get_signed_distance_to_depth_maps (mu:2900-2949) + Scene.update_proxy_supervision_occ /
+ * update_proxy_out_of_field (mu:3329-3363) fused per point.  For each proxy point inside the frustum
+ * and closer than fov_range: sd = z_view - bilinear(depth) (invalid pixels = 1.1 zfar);
+ * n_inside += 1; n_behind += (sd >= -tol); occ = (n_behind/n_inside >= score_threshold);
+ * out_of_field = 0.  cam12 is a HOST array (one camera).  Not reachable from the NBP drivers. */
+int nbp_carve_update_f32(const float* proxy_pts3, int P, const float* depth,
+                         const unsigned char* mask_or_null, const float* cam12_host, int H, int W,
+                         float tan_half_fov, float zfar, float fov_range, float tol,
+                         float score_threshold, float* n_inside, float* n_behind, float* occ,
+                         float* out_of_field, void* stream);
 /* Host mirror of the sampling bijection (driver / tests). */
 unsigned nbp_perm_index_host(unsigned j, unsigned n, unsigned seed);
 
@@ -232,6 +243,64 @@ int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3, long long 
                            const long long* N_dev_or_null, long long sample_k, unsigned seed,
                            float threshold, const float* bbox_lo_host, const float* bbox_hi_host,
                            int* count_out, int* m_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ================================================================ A2-A3: training step
+ * Kernels behind the autograd functions of nextbestpath_amd/networks/training.py, which replace
+ * autograd + cuDNN under train_experience_data (next_best_path/utility/nbp_utils.py:340-395) for
+ * the layers of next_best_path/networks/nbp_model.py:8-62 in nbp.train() mode.  All [M, C] tensors
+ * are NHWC with M = B*H*W.  Reductions are two-stage => deterministic. */
+size_t nbp_colreduce_workspace_bytes(long long M, int C);
+/* nn.BatchNorm2d training forward (eps, momentum = module values): batch mean / biased variance,
+ * running-stat update (unbiased variance; pass NULL to skip), y = [relu]((x-mean)*invstd*gamma+beta);
+ * mean / invstd are saved for the backward. */
+int nbp_bn_train_forward_f32(const float* x, long long M, int C, const float* gamma, const float* beta,
+                             float eps, float momentum, float* running_mean, float* running_var,
+                             int relu, float* mean, float* invstd, float* y, void* ws, size_t ws_bytes,
+                             void* stream);
+/* Backward of the above (+ fused ReLU mask from y when relu != 0): dx, dgamma, dbeta. */
+int nbp_bn_train_backward_f32(const float* dy, const float* x, const float* y_or_null, long long M, int C,
+                              const float* mean, const float* invstd, const float* gamma, int relu,
+                              float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                              void* stream);
+/* out[c] = sum_m rows[m]*x[m][c] (rows NULL = 1): conv bias gradients, psi weight gradient. */
+int nbp_colsum_f32(const float* x, const float* rows_or_null, long long M, int C, float* out, void* ws,
+                   size_t ws_bytes, void* stream);
+/* op 0: relu(a+b)  1: a*(b>0)  2: sigmoid(a)  3: a*b*(1-b)  4: a+b  5: a+b[0] */
+int nbp_elementwise_f32(int op, const float* a, const float* b, long long n, float* out, void* stream);
+int nbp_rowscale_f32(const float* x, const float* s, long long M, int C, float* out, void* stream);   /* x[m][c]*s[m] */
+int nbp_rowdot_f32(const float* a, const float* b, int b_is_vector, long long M, int C, float* out,
+                   void* stream);                                                                     /* sum_c a*b   */
+int nbp_outer_f32(const float* s, const float* w, long long M, int C, float* out, void* stream);      /* s[m]*w[c]   */
+/* nn.MaxPool2d(2,2) backward (gradient to the first maximum of each window, ATen rule). */
+int nbp_maxpool2_backward_f32(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
+                              void* stream);
+/* nn.Upsample(x2, nearest) backward: 2x2 block sums, dy [B,2Hs,2Ws,C] -> [B,Hs,Ws,C]. */
+int nbp_sum2x2_f32(const float* dy, int B, int Hs, int Ws, int C, float* out, void* stream);
+int nbp_slice_channels_f32(const float* in, long long M, int Cin, int c0, int Cs, float* out, void* stream);
+int nbp_pad_channels_f32(const float* in, long long M, int Cin, int Cout, float* out, void* stream);
+/* Forward packing with zero padding of both channel counts: dst[ci/32][tap][Npad][32]. */
+int nbp_pack_conv_weight_padded(const float* w_oihw, int N, int C, int ksize, int Cpad, int Npad, float* dst,
+                                void* stream);
+/* Data gradient = nbp_conv_igemm_f32 on dY with these weights: flipped taps, co <-> ci transposed,
+ * zero padded to (Cpad, Npad) multiples of 32: dst[co/32][tap][ci][co%32]. */
+int nbp_pack_conv_weight_dgrad(const float* w_oihw, int N, int C, int ksize, int Cpad, int Npad, float* dst,
+                               void* stream);
+/* Weight gradient on the matrix cores: dW [n_real][c_real][k][k] (OIHW) of
+ * out = conv(cat(src0, src1) [x2 upsampled]) given dY [B,H,W,N]; C0, C1, N multiples of 64. */
+size_t nbp_conv_wgrad_workspace_bytes(int B, int H, int W, int C0, int C1, int N, int ksize);
+int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
+                       int ksize, const float* dy, int N, int c_real, int n_real, float* dw, void* ws,
+                       size_t ws_bytes, void* stream);
+/* Sparse value targets (nbp_utils.py:373-379): pred[k] = out1[b,c,x,y], coords [K,4] int64; and the
+ * scatter-add of its gradient into a zeroed d_out1. */
+int nbp_gather_values_f32(const float* out1_nchw, const long long* coords_bcxy, int K, int C, int H, int W,
+                          float* pred, void* stream);
+int nbp_scatter_values_f32(const float* dpred, const long long* coords_bcxy, int K, int C, int H, int W,
+                           float* dout1_nchw_zeroed, void* stream);
+/* mode 0: sum (p-t)^2, mode 1: sum BCE(p,t) (log clamped at -100 like torch) into *sum_out (device
+ * double); dp (optional) = grad_coef * d(mean loss)/dp. */
+int nbp_loss_f32(int mode, const float* p, const float* t, long long n, float grad_coef, double* sum_out,
+                 float* dp_or_null, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

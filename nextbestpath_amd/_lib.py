@@ -46,7 +46,27 @@ SIGNATURES = {
     "nbp_raster_zbuf_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _sz, _vp]),
     "nbp_segments_hit_mesh_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "nbp_axis_ray_counts_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "nbp_carve_update_f32": (_i, [_vp, _i, _vp, _vp, C.POINTER(_f), _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "nbp_perm_index_host": (C.c_uint, [C.c_uint, C.c_uint, C.c_uint]),
+    "nbp_colreduce_workspace_bytes": (_sz, [_ll, _i]),
+    "nbp_bn_train_forward_f32": (_i, [_vp, _ll, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nbp_bn_train_backward_f32": (_i, [_vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nbp_colsum_f32": (_i, [_vp, _vp, _ll, _i, _vp, _vp, _sz, _vp]),
+    "nbp_elementwise_f32": (_i, [_i, _vp, _vp, _ll, _vp, _vp]),
+    "nbp_rowscale_f32": (_i, [_vp, _vp, _ll, _i, _vp, _vp]),
+    "nbp_rowdot_f32": (_i, [_vp, _vp, _i, _ll, _i, _vp, _vp]),
+    "nbp_outer_f32": (_i, [_vp, _vp, _ll, _i, _vp, _vp]),
+    "nbp_maxpool2_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "nbp_sum2x2_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "nbp_slice_channels_f32": (_i, [_vp, _ll, _i, _i, _i, _vp, _vp]),
+    "nbp_pad_channels_f32": (_i, [_vp, _ll, _i, _i, _vp, _vp]),
+    "nbp_pack_conv_weight_padded": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "nbp_pack_conv_weight_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "nbp_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "nbp_conv_wgrad_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "nbp_gather_values_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "nbp_scatter_values_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "nbp_loss_f32": (_i, [_i, _vp, _vp, _ll, _f, _vp, _vp, _vp, _sz, _vp]),
     "nbp_fuse_obstacle_f32": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "nbp_score_candidates_f32": (_i, [_vp, _i, _f, _f, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "nbp_edges_blocked_u8": (_i, [_vp, _i, _f, _f, _f, _f, _vp, _vp, _i, _vp, _vp]),

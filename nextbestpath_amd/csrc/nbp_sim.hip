@@ -321,6 +321,56 @@ __global__ __launch_bounds__(256) void axis_ray_count_kernel(const float* __rest
         if (ray_tri(pts + 3 * (size_t)k, dirs[ax], a, b, c) >= 0.f) atomicAdd(&counts[3 * k + ax], 1);
 }
 
+// ------------------------------------------------------------------ depth-map space carving (A20)
+// One thread per proxy point: frustum + range test, bilinear depth lookup (torch grid_sample
+// semantics: align_corners = False, border padding; invalid pixels read as 1.1 zfar), counters.
+__global__ __launch_bounds__(256) void carve_update_kernel(const float* __restrict__ pts, int P, const float* __restrict__ depth,
+                                                           const unsigned char* __restrict__ mask, Cam cam, int H, int W,
+                                                           float tanh_fov, float zfar, float fov_range, float tol,
+                                                           float score_thr, float* __restrict__ n_inside,
+                                                           float* __restrict__ n_behind, float* __restrict__ occ,
+                                                           float* __restrict__ out_of_field) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    float v[3];
+    to_view(p, cam.R, cam.T, v);
+    // camera centre C = -T R^T
+    const float cx = -((cam.T[0] * cam.R[0] + cam.T[1] * cam.R[1]) + cam.T[2] * cam.R[2]);
+    const float cy = -((cam.T[0] * cam.R[3] + cam.T[1] * cam.R[4]) + cam.T[2] * cam.R[5]);
+    const float cz = -((cam.T[0] * cam.R[6] + cam.T[1] * cam.R[7]) + cam.T[2] * cam.R[8]);
+    const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+    const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const int s = H < W ? H : W;
+    const float nx = v[0] / (v[2] * tanh_fov), ny = v[1] / (v[2] * tanh_fov);
+    // frustum bounds = corners of the reference's NDC tables (mu:2270-2279)
+    const float max_x = (float)((double)W / s), min_x = max_x - ((float)(W - 1) / (float)(s - 1)) * 2.f;
+    const float max_y = (float)((double)H / s), min_y = max_y - ((float)(H - 1) / (float)(s - 1)) * 2.f;
+    const bool in_fov = nx >= min_x && nx <= max_x && ny >= min_y && ny <= max_y && v[2] > 0.f && dist < fov_range;
+    if (!in_fov) return;
+    // grid_sample coordinates (mu:2929-2944): gx = -(s/W) ndc_x, gy = -(s/H) ndc_y
+    const float gx = (-(float)s / (float)W) * nx, gy = (-(float)s / (float)H) * ny;
+    float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const float wx = ix - (float)x0, wy = iy - (float)y0;
+    auto at = [&](int y, int x) {
+        const float d = depth[y * W + x];
+        const bool ok = mask ? mask[y * W + x] != 0 : d > -1.f;
+        return ok ? d : 1.1f * zfar;
+    };
+    const float d00 = at(y0, x0), d01 = at(y0, x1), d10 = at(y1, x0), d11 = at(y1, x1);
+    const float dsamp = (d00 * (1.f - wx) * (1.f - wy) + d01 * wx * (1.f - wy)) + (d10 * (1.f - wx) * wy + d11 * wx * wy);
+    const float sd = v[2] - dsamp;
+    const float ni = n_inside[i] + 1.f;
+    const float nb = n_behind[i] + (sd >= -tol ? 1.f : 0.f);
+    n_inside[i] = ni; n_behind[i] = nb;
+    occ[i] = (nb / ni >= score_thr) ? 1.f : 0.f;
+    out_of_field[i] = 0.f;
+}
+
 }  // namespace
 
 // ================================================================== C ABI
@@ -424,6 +474,21 @@ extern "C" int nbp_axis_ray_counts_f32(const float* verts, const int* faces, int
     if (e != hipSuccess) return (int)e;
     dim3 g((unsigned)nbp_cdiv(n_faces, 256), (unsigned)n_pts);
     axis_ray_count_kernel<<<g, 256, 0, st>>>(verts, faces, n_faces, pts3, counts3);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_carve_update_f32(const float* proxy_pts3, int P, const float* depth, const unsigned char* mask_or_null,
+                                    const float* cam12_host, int H, int W, float tan_half_fov, float zfar, float fov_range,
+                                    float tol, float score_threshold, float* n_inside, float* n_behind, float* occ,
+                                    float* out_of_field, void* stream) {
+    NBP_RETURN_IF(!proxy_pts3 || !depth || !cam12_host || !n_inside || !n_behind || !occ || !out_of_field, NBP_E_ARG);
+    NBP_RETURN_IF(P < 1 || H < 2 || W < 2, NBP_E_ARG);
+    Cam cam;
+    for (int k = 0; k < 9; ++k) cam.R[k] = cam12_host[k];
+    for (int k = 0; k < 3; ++k) cam.T[k] = cam12_host[9 + k];
+    carve_update_kernel<<<(unsigned)nbp_cdiv(P, 256), 256, 0, (hipStream_t)stream>>>(
+        proxy_pts3, P, depth, mask_or_null, cam, H, W, tan_half_fov, zfar, fov_range, tol, score_threshold, n_inside,
+        n_behind, occ, out_of_field);
     return nbp_launch_status();
 }
 

@@ -1,0 +1,677 @@
+// nbp_train.hip -- kernels of the NBP training step (forward in train mode + backward), fp32.
+//
+// Replaces what autograd + cuDNN/MIOpen execute under
+// next_best_path/utility/nbp_utils.py:340-395 (train_experience_data: nbp.train(); forward;
+// gather pred[b,c,x,y]; NBP.loss; backward) for the layers of
+// next_best_path/networks/nbp_model.py:8-62:
+//   * conv weight gradient on the matrix cores (wgrad: reduction over pixels);
+//     the data gradient reuses the forward implicit-GEMM kernel with flipped/transposed weights
+//   * BatchNorm2d in training mode: batch statistics, running-stat update, backward
+//   * MaxPool2d backward, nearest-upsample backward (2x2 sum), attention-gate pieces,
+//     sparse value-map loss gather / scatter, BCE
+// Activations are NHWC [M, C] with M = B*H*W.  Reductions are two-stage (per-workgroup partials,
+// then a finalize kernel) so results are run-to-run deterministic.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ column reductions over [M, C]
+// MODE 0: out0[c] = sum x           out1[c] = sum x*x
+// MODE 1: out0[c] = sum dz          out1[c] = sum dz * xhat,  dz = dy * (y > 0 if relu), xhat = (x-mean)*invstd
+// MODE 2: out0[c] = sum s[m]*x[m][c]                         (row-weighted column sum; s may be null = 1)
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ y, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, const float* __restrict__ rows,
+                                                        long long M, int C, int relu, long long rows_per_block,
+                                                        float* __restrict__ part) {
+    // thread t owns channel c = t % CT (CT = min(C,256) rounded), and rows r = t / CT + k * (256 / CT)
+    const int CT = C < 256 ? C : 256;
+    const int rpb = 256 / CT;                         // rows processed per pass
+    const int c_local = threadIdx.x % CT, rsub = threadIdx.x / CT;
+    __shared__ float sh0[256], sh1[256];
+    for (int c0 = 0; c0 < C; c0 += CT) {
+        const int c = c0 + c_local;
+        float s0 = 0.f, s1 = 0.f;
+        if (rsub < rpb && c < C) {
+            const long long r_begin = (long long)blockIdx.x * rows_per_block;
+            const long long r_end = r_begin + rows_per_block < M ? r_begin + rows_per_block : M;
+            float mu = 0.f, is = 0.f;
+            if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+            for (long long r = r_begin + rsub; r < r_end; r += rpb) {
+                const float v = a[r * C + c];
+                if (MODE == 0) { s0 += v; s1 += v * v; }
+                if (MODE == 1) {
+                    float dz = v;                                   // a = dy
+                    if (relu && !(y[r * C + c] > 0.f)) dz = 0.f;
+                    s0 += dz; s1 += dz * ((b[r * C + c] - mu) * is); // b = x
+                }
+                if (MODE == 2) s0 += (rows ? rows[r] : 1.f) * v;
+            }
+        }
+        sh0[threadIdx.x] = s0; sh1[threadIdx.x] = s1;
+        __syncthreads();
+        if (rsub == 0 && c < C) {
+            for (int k = 1; k < rpb; ++k) { s0 += sh0[k * CT + c_local]; s1 += sh1[k * CT + c_local]; }
+            part[((long long)blockIdx.x * 2 + 0) * C + c] = s0;
+            part[((long long)blockIdx.x * 2 + 1) * C + c] = s1;
+        }
+        __syncthreads();
+    }
+}
+
+// finalize MODE 0: mean, biased var -> invstd; running stats (momentum, unbiased var)
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, long long M, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0;
+    for (int k = 0; k < nblk; ++k) { s0 += part[((long long)k * 2) * C + c]; s1 += part[((long long)k * 2 + 1) * C + c]; }
+    const double mu = s0 / (double)M;
+    double var = s1 / (double)M - mu * mu;
+    if (var < 0) var = 0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mu);
+        run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+    }
+}
+
+// finalize generic: out0[c] (+ out1[c]) = sum over blocks
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out0,
+                                       float* __restrict__ out1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0;
+    for (int k = 0; k < nblk; ++k) { s0 += part[((long long)k * 2) * C + c]; s1 += part[((long long)k * 2 + 1) * C + c]; }
+    if (out0) out0[c] = (float)s0;
+    if (out1) out1[c] = (float)s1;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long long total, int C,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int relu, float* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        float v = (x[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        if (relu) v = fmaxf(v, 0.f);
+        y[i] = v;
+    }
+}
+
+// dx = gamma*invstd/M * (M*dz - dbeta - xhat*dgamma)
+__global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ y, long long total, int C,
+                                                                long long M, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ dgamma,
+                                                                const float* __restrict__ dbeta, int relu,
+                                                                float* __restrict__ dx) {
+    const float invM = 1.f / (float)M;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        float dz = dy[i];
+        if (relu && !(y[i] > 0.f)) dz = 0.f;
+        const float xhat = (x[i] - mean[c]) * invstd[c];
+        dx[i] = gamma[c] * invstd[c] * (dz - invM * (dbeta[c] + xhat * dgamma[c]));
+    }
+}
+
+// ------------------------------------------------------------------ small elementwise pieces
+// op 0: out = relu(a + b)          op 1: out = dy * (y > 0)         op 2: out = sigmoid(a)
+// op 3: out = dy * y * (1 - y)     op 4: out = a + b                op 5: out = a + b[0]
+__global__ __launch_bounds__(256) void ew_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
+                                                 long long n, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v;
+        switch (op) {
+            case 0: v = fmaxf(a[i] + b[i], 0.f); break;
+            case 1: v = b[i] > 0.f ? a[i] : 0.f; break;
+            case 2: v = 1.f / (1.f + expf(-a[i])); break;
+            case 3: v = a[i] * b[i] * (1.f - b[i]); break;
+            case 5: v = a[i] + b[0]; break;
+            default: v = a[i] + b[i]; break;
+        }
+        out[i] = v;
+    }
+}
+
+// out[m][c] = x[m][c] * s[m]
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                       long long total, int C, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        out[i] = x[i] * s[i / C];
+}
+
+// out[m] = sum_c a[m][c] * b[m][c]   (b may be a [C] vector when b_is_vec): 16 lanes per row
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b, int b_is_vec,
+                                                     long long M, int C, float* __restrict__ out) {
+    const int sub = threadIdx.x & 15;
+    const long long rpb = blockDim.x >> 4;
+    for (long long m = (long long)blockIdx.x * rpb + (threadIdx.x >> 4); m < M; m += (long long)gridDim.x * rpb) {
+        float acc = 0.f;
+        for (int c = sub; c < C; c += 16) acc = fmaf(a[m * C + c], b_is_vec ? b[c] : b[m * C + c], acc);
+        acc += __shfl_xor(acc, 8, 16);
+        acc += __shfl_xor(acc, 4, 16);
+        acc += __shfl_xor(acc, 2, 16);
+        acc += __shfl_xor(acc, 1, 16);
+        if (sub == 0) out[m] = acc;
+    }
+}
+
+// out[m][c] = s[m] * w[c]
+__global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ s, const float* __restrict__ w, long long total,
+                                                    int C, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        out[i] = s[i / C] * w[i % C];
+}
+
+// MaxPool2d(2,2) backward: the gradient goes to the FIRST maximum of the window in (dy,dx) scan order (ATen rule).
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B,
+                                                           int H, int W, int C, float* __restrict__ dx) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long long total = (long long)B * Ho * Wo * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long p = i / C;
+        const int xo = (int)(p % Wo);
+        long long q = p / Wo;
+        const int yo = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        const long long base = (((long long)b * H + 2 * yo) * W + 2 * xo) * C + c;
+        const long long off[4] = {0, C, (long long)W * C, (long long)W * C + C};
+        float best = x[base];
+        int arg = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const float v = x[base + off[k]];
+            if (v > best || (v != v && best == best)) { best = v; arg = k; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dx[base + off[k]] = k == arg ? dy[i] : 0.f;
+    }
+}
+
+// nearest x2 upsample backward: out[b][y][x][c] = sum of the 2x2 block of dy
+__global__ __launch_bounds__(256) void sum2x2_kernel(const float* __restrict__ dy, int B, int Hs, int Ws, int C,
+                                                     float* __restrict__ out) {
+    const long long total = (long long)B * Hs * Ws * C;
+    const int W = 2 * Ws;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long p = i / C;
+        const int xs = (int)(p % Ws);
+        long long q = p / Ws;
+        const int ys = (int)(q % Hs);
+        const int b = (int)(q / Hs);
+        const long long base = (((long long)b * 2 * Hs + 2 * ys) * W + 2 * xs) * C + c;
+        out[i] = (dy[base] + dy[base + C]) + (dy[base + (long long)W * C] + dy[base + (long long)W * C + C]);
+    }
+}
+
+// channel slice copy: out[m][0..Cs) = in[m][c0 .. c0+Cs)  (in has Cin channels)
+__global__ __launch_bounds__(256) void slice_channels_kernel(const float* __restrict__ in, long long M, int Cin, int c0, int Cs,
+                                                             float* __restrict__ out) {
+    const long long total = M * Cs;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        out[i] = in[(i / Cs) * Cin + c0 + (i % Cs)];
+}
+
+// out[m][0..Cin) = in[m][:], out[m][Cin..Cout) = 0
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restrict__ in, long long M, int Cin, int Cout,
+                                                           float* __restrict__ out) {
+    const long long total = M * Cout;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cout);
+        out[i] = c < Cin ? in[(i / Cout) * Cin + c] : 0.f;
+    }
+}
+
+// forward packing with zero padding: dst[ci/32][tap][Npad][32] (every entry written)
+__global__ void pack_fwd_padded_kernel(const float* __restrict__ w, int N, int C, int taps, int Cpad, int Npad,
+                                       float* __restrict__ dst) {
+    const long long total = (long long)Npad * Cpad * taps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        long long t = i / taps;
+        const int ci = (int)(t % Cpad), co = (int)(t / Cpad);
+        const float v = (co < N && ci < C) ? w[((long long)co * C + ci) * taps + tap] : 0.f;
+        dst[(((long long)(ci >> 5) * taps + tap) * Npad + co) * 32 + (ci & 31)] = v;
+    }
+}
+
+// ------------------------------------------------------------------ weight gradient on the matrix cores
+// dW[tap][ci][co] = sum_m X[pix(m) + tap][ci] * dY[m][co]:  per tap a GEMM [ci x M] * [M x co] with the
+// reduction over pixels.  v_mfma_f32_32x32x2_f32 with k = 2 consecutive pixels: lanes 0-31 supply
+// pixel p, lanes 32-63 pixel p+1, each lane one channel -> both operands are contiguous 128-B LDS rows.
+struct WgradArgs {
+    const float* src0; const float* src1;
+    int C0, C1, ups, H, W, Hs, Ws, taps;
+    const float* dy; int N;
+    long long M;
+    unsigned bytes0, bytes1;
+    int ci_tiles, co_tiles;
+    int chunks_total, chunks_per_split;    // 32-pixel chunks
+    float* part;                           // [split][tap][Ctot][N]
+};
+
+template <int TI, int TJ>   // wave tile TI*32 (ci) x TJ*32 (co); workgroup = 2x2 waves
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+    constexpr int CI_T = 2 * TI * 32, CO_T = 2 * TJ * 32, PK = 32;
+    __shared__ __attribute__((aligned(16))) float xs[2][PK][CI_T];
+    __shared__ __attribute__((aligned(16))) float ys[2][PK][CO_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int ci0 = (blockIdx.x / a.co_tiles) * CI_T, co0 = (blockIdx.x % a.co_tiles) * CO_T;
+    const int tap = blockIdx.y;
+    int dyy = 0, dxx = 0;
+    if (a.taps == 9) { dyy = tap / 3 - 1; dxx = tap % 3 - 1; }
+    const int Ctot = a.C0 + a.C1;
+    const bool first = ci0 < a.C0;                       // a ci tile never straddles the concat boundary
+    const int Cs = first ? a.C0 : a.C1;
+    const int cbase = first ? ci0 : ci0 - a.C0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(first ? a.src0 : a.src1), 0, first ? a.bytes0 : a.bytes1, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int c_begin = blockIdx.z * a.chunks_per_split;
+    const int c_end = min(c_begin + a.chunks_per_split, a.chunks_total);
+    const int HW = a.H * a.W;
+    // staging: X tile = PK rows x CI_T/4 float4, dY tile = PK rows x CO_T/4 float4
+    constexpr int XV = PK * CI_T / 4 / 256, YV = PK * CO_T / 4 / 256;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    f32x4 gx[XV], gy[YV];
+    auto load = [&](int chunk) {
+        const long long m0 = (long long)chunk * PK;
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            const int e = tid + 256 * k, row = e / (CI_T / 4), col4 = e % (CI_T / 4);
+            const long long m = m0 + row;
+            unsigned off = OOB;
+            if (m < a.M) {
+                const int b = (int)(m / HW), rem = (int)(m - (long long)b * HW);
+                const int y = rem / a.W + dyy, x = rem % a.W + dxx;
+                if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+                    off = (unsigned)(((b * a.Hs + (y >> a.ups)) * a.Ws + (x >> a.ups)) * Cs + cbase + col4 * 4) * 4u;
+            }
+            gx[k] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < YV; ++k) {
+            const int e = tid + 256 * k, row = e / (CO_T / 4), col4 = e % (CO_T / 4);
+            const long long m = m0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < a.M) v = *reinterpret_cast<const f32x4*>(a.dy + m * a.N + co0 + col4 * 4);
+            gy[k] = v;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            const int e = tid + 256 * k;
+            *reinterpret_cast<f32x4*>(&xs[buf][e / (CI_T / 4)][(e % (CI_T / 4)) * 4]) = gx[k];
+        }
+#pragma unroll
+        for (int k = 0; k < YV; ++k) {
+            const int e = tid + 256 * k;
+            *reinterpret_cast<f32x4*>(&ys[buf][e / (CO_T / 4)][(e % (CO_T / 4)) * 4]) = gy[k];
+        }
+    };
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (c_begin < c_end) { load(c_begin); store(0); }
+    __syncthreads();
+    int cur = 0;
+    const int kh = lane >> 5, ln = lane & 31;
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = c + 1 < c_end;
+        if (more) load(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < PK / 2; ++kk) {
+            float af[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = xs[cur][2 * kk + kh][(wi * TI + i) * 32 + ln];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = ys[cur][2 * kk + kh][(wj * TJ + j) * 32 + ln];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* out = a.part + (((long long)blockIdx.z * a.taps + tap) * Ctot) * a.N;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + (wi * TI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int co = co0 + (wj * TJ + j) * 32 + ln;
+                out[(long long)ci * a.N + co] = acc[i][j][r];
+            }
+}
+
+// dW OIHW [N][Creal][taps] = sum_s part[s][tap][ci][co]   (ci < Creal: padded input channels are dropped)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int taps, int Ctot, int N,
+                                                           int Creal, int Nreal, float* __restrict__ dw) {
+    const long long total = (long long)Nreal * Creal * taps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        long long t = i / taps;
+        const int ci = (int)(t % Creal), co = (int)(t / Creal);
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(((long long)k * taps + tap) * Ctot + ci) * N + co];
+        dw[i] = s;
+    }
+}
+
+// flipped + transposed packing for the data gradient: dst[(co)/32][tap][ci][co%32] = w[co][ci][taps-1-tap]
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, int N, int C, int taps, int Cpad, int Npad,
+                                  float* __restrict__ dst) {
+    const long long total = (long long)Npad * Cpad * taps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        long long t = i / taps;
+        const int ci = (int)(t % Cpad), co = (int)(t / Cpad);
+        const float v = (co < N && ci < C) ? w[((long long)co * C + ci) * taps + (taps - 1 - tap)] : 0.f;
+        dst[(((long long)(co >> 5) * taps + tap) * Cpad + ci) * 32 + (co & 31)] = v;
+    }
+}
+
+// ------------------------------------------------------------------ loss pieces (nbp_model.py:162-173, nbp_utils.py:373-381)
+// gather pred[k] = out1[b, c, x, y];  coords [K,4] int64 (b, c, x, y)
+__global__ void gather_values_kernel(const float* __restrict__ out1, const long long* __restrict__ coords, int K, int Cc, int Hh,
+                                     int Ww, float* __restrict__ pred) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const long long* q = coords + 4 * (long long)k;
+    pred[k] = out1[((q[0] * Cc + q[1]) * Hh + q[2]) * Ww + q[3]];
+}
+// scatter-add grad into d_out1 (zeroed by the caller); duplicates accumulate (index_put accumulate=True semantics)
+__global__ void scatter_values_kernel(const float* __restrict__ dpred, const long long* __restrict__ coords, int K, int Cc, int Hh,
+                                      int Ww, float* __restrict__ dout1) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const long long* q = coords + 4 * (long long)k;
+    atomicAdd(&dout1[((q[0] * Cc + q[1]) * Hh + q[2]) * Ww + q[3]], dpred[k]);
+}
+// partial sums of (p-t)^2 (mode 0) or BCE(p,t) with log clamped at -100 (mode 1, torch semantics)
+__global__ __launch_bounds__(256) void loss_partial_kernel(int mode, const float* __restrict__ p, const float* __restrict__ t,
+                                                           long long n, double* __restrict__ part) {
+    __shared__ double sh[256];
+    double s = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (mode == 0) { const float d = p[i] - t[i]; s += (double)(d * d); }
+        else {
+            const float lp = fmaxf(logf(p[i]), -100.f), l1 = fmaxf(logf(1.f - p[i]), -100.f);
+            s += (double)(-(t[i] * lp + (1.f - t[i]) * l1));
+        }
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+// d/dp: mode 0: coef * 2 (p - t) / n ;  mode 1: coef * (p - t) / (max(p (1-p), 1e-12)) / n
+__global__ __launch_bounds__(256) void loss_grad_kernel(int mode, const float* __restrict__ p, const float* __restrict__ t,
+                                                        long long n, float coef, float* __restrict__ dp) {
+    const float inv = coef / (float)n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (mode == 0) dp[i] = 2.f * (p[i] - t[i]) * inv;
+        else dp[i] = (p[i] - t[i]) / fmaxf(p[i] * (1.f - p[i]), 1e-12f) * inv;
+    }
+}
+
+__global__ void sum_doubles_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < n; ++i) s += part[i];
+        *out = s;
+    }
+}
+
+inline int blocks_for_rows(long long M, long long* rows_per_block) {
+    long long nblk = M / 256;
+    if (nblk < 1) nblk = 1;
+    if (nblk > 512) nblk = 512;
+    *rows_per_block = nbp_cdiv(M, nblk);
+    return (int)nbp_cdiv(M, *rows_per_block);
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+extern "C" size_t nbp_colreduce_workspace_bytes(long long M, int C) {
+    long long rpb;
+    const int nblk = blocks_for_rows(M, &rpb);
+    return (size_t)nblk * 2 * C * sizeof(float) + 256;
+}
+
+extern "C" int nbp_bn_train_forward_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
+                                        float momentum, float* running_mean, float* running_var, int relu, float* mean,
+                                        float* invstd, float* y, void* ws, size_t ws_bytes, void* stream) {
+    NBP_RETURN_IF(!x || !gamma || !beta || !mean || !invstd || !y || !ws || M < 1 || C < 1, NBP_E_ARG);
+    NBP_RETURN_IF(ws_bytes < nbp_colreduce_workspace_bytes(M, C), NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    long long rpb;
+    const int nblk = blocks_for_rows(M, &rpb);
+    float* part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
+    colreduce_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, rpb, part);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, 128), 128, 0, st>>>(part, nblk, C, M, eps, momentum, mean, invstd, running_mean,
+                                                                  running_var);
+    if ((rc = nbp_launch_status())) return rc;
+    bn_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(x, M * C, C, mean, invstd, gamma, beta, relu, y);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_bn_train_backward_f32(const float* dy, const float* x, const float* y_or_null, long long M, int C,
+                                         const float* mean, const float* invstd, const float* gamma, int relu, float* dx,
+                                         float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    NBP_RETURN_IF(!dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !ws || M < 1 || C < 1, NBP_E_ARG);
+    NBP_RETURN_IF(relu && !y_or_null, NBP_E_ARG);
+    NBP_RETURN_IF(ws_bytes < nbp_colreduce_workspace_bytes(M, C), NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    long long rpb;
+    const int nblk = blocks_for_rows(M, &rpb);
+    float* part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
+    colreduce_kernel<1><<<nblk, 256, 0, st>>>(dy, x, y_or_null, mean, invstd, nullptr, M, C, relu, rpb, part);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 128), 128, 0, st>>>(part, nblk, C, dbeta, dgamma);
+    if ((rc = nbp_launch_status())) return rc;
+    bn_backward_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(dy, x, y_or_null, M * C, C, M, mean, invstd, gamma,
+                                                                     dgamma, dbeta, relu, dx);
+    return nbp_launch_status();
+}
+
+// out[c] = sum_m rows[m] * x[m][c]  (rows may be null): bias gradients, psi weight gradient
+extern "C" int nbp_colsum_f32(const float* x, const float* rows_or_null, long long M, int C, float* out, void* ws,
+                              size_t ws_bytes, void* stream) {
+    NBP_RETURN_IF(!x || !out || !ws || M < 1 || C < 1, NBP_E_ARG);
+    NBP_RETURN_IF(ws_bytes < nbp_colreduce_workspace_bytes(M, C), NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    long long rpb;
+    const int nblk = blocks_for_rows(M, &rpb);
+    float* part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
+    colreduce_kernel<2><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, rows_or_null, M, C, 0, rpb, part);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 128), 128, 0, st>>>(part, nblk, C, out, nullptr);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_elementwise_f32(int op, const float* a, const float* b, long long n, float* out, void* stream) {
+    NBP_RETURN_IF(!a || !out || n < 1 || op < 0 || op > 5, NBP_E_ARG);
+    NBP_RETURN_IF(op != 2 && !b, NBP_E_ARG);
+    ew_kernel<<<nbp_ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(op, a, b, n, out);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_rowscale_f32(const float* x, const float* s, long long M, int C, float* out, void* stream) {
+    NBP_RETURN_IF(!x || !s || !out || M < 1 || C < 1, NBP_E_ARG);
+    rowscale_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, (hipStream_t)stream>>>(x, s, M * C, C, out);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_rowdot_f32(const float* a, const float* b, int b_is_vector, long long M, int C, float* out, void* stream) {
+    NBP_RETURN_IF(!a || !b || !out || M < 1 || C < 1, NBP_E_ARG);
+    rowdot_kernel<<<nbp_ew_grid(M * 16, 256), 256, 0, (hipStream_t)stream>>>(a, b, b_is_vector, M, C, out);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_outer_f32(const float* s, const float* w, long long M, int C, float* out, void* stream) {
+    NBP_RETURN_IF(!s || !w || !out || M < 1 || C < 1, NBP_E_ARG);
+    outer_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, (hipStream_t)stream>>>(s, w, M * C, C, out);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_maxpool2_backward_f32(const float* x, const float* dy, int B, int H, int W, int C, float* dx, void* stream) {
+    NBP_RETURN_IF(!x || !dy || !dx, NBP_E_ARG);
+    NBP_RETURN_IF(B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1, NBP_E_SHAPE);
+    maxpool2_bwd_kernel<<<nbp_ew_grid((long long)B * (H / 2) * (W / 2) * C, 256), 256, 0, (hipStream_t)stream>>>(x, dy, B, H, W,
+                                                                                                                 C, dx);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_sum2x2_f32(const float* dy, int B, int Hs, int Ws, int C, float* out, void* stream) {
+    NBP_RETURN_IF(!dy || !out || B < 1 || Hs < 1 || Ws < 1 || C < 1, NBP_E_ARG);
+    sum2x2_kernel<<<nbp_ew_grid((long long)B * Hs * Ws * C, 256), 256, 0, (hipStream_t)stream>>>(dy, B, Hs, Ws, C, out);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_slice_channels_f32(const float* in, long long M, int Cin, int c0, int Cs, float* out, void* stream) {
+    NBP_RETURN_IF(!in || !out || M < 1 || Cin < 1 || c0 < 0 || Cs < 1 || c0 + Cs > Cin, NBP_E_ARG);
+    slice_channels_kernel<<<nbp_ew_grid(M * Cs, 256), 256, 0, (hipStream_t)stream>>>(in, M, Cin, c0, Cs, out);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_pad_channels_f32(const float* in, long long M, int Cin, int Cout, float* out, void* stream) {
+    NBP_RETURN_IF(!in || !out || M < 1 || Cin < 1 || Cout < Cin, NBP_E_ARG);
+    pad_channels_kernel<<<nbp_ew_grid(M * Cout, 256), 256, 0, (hipStream_t)stream>>>(in, M, Cin, Cout, out);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_pack_conv_weight_padded(const float* w_oihw, int N, int C, int ksize, int Cpad, int Npad, float* dst,
+                                           void* stream) {
+    NBP_RETURN_IF(!w_oihw || !dst || N < 1 || C < 1 || (ksize != 1 && ksize != 3), NBP_E_ARG);
+    NBP_RETURN_IF(Cpad < C || Cpad % 32 || Npad < N || Npad % 32, NBP_E_SHAPE);
+    const long long total = (long long)Npad * Cpad * ksize * ksize;
+    pack_fwd_padded_kernel<<<nbp_ew_grid(total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, N, C, ksize * ksize, Cpad, Npad,
+                                                                                    dst);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_pack_conv_weight_dgrad(const float* w_oihw, int N, int C, int ksize, int Cpad, int Npad, float* dst,
+                                          void* stream) {
+    NBP_RETURN_IF(!w_oihw || !dst || N < 1 || C < 1 || (ksize != 1 && ksize != 3), NBP_E_ARG);
+    NBP_RETURN_IF(Cpad < C || Cpad % 32 || Npad < N || Npad % 32, NBP_E_SHAPE);
+    const long long total = (long long)Npad * Cpad * ksize * ksize;
+    pack_dgrad_kernel<<<nbp_ew_grid(total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, N, C, ksize * ksize, Cpad, Npad, dst);
+    return nbp_launch_status();
+}
+
+static void wgrad_plan(long long M, int Ctot, int N, int taps, int* ti, int* ci_tiles, int* co_tiles, int* splits,
+                       int* chunks_total, int* cps) {
+    *ti = (Ctot % 128 == 0 && N % 128 == 0) ? 2 : 1;       // 128x128 or 64x64 workgroup tile
+    const int T = *ti * 64;
+    *ci_tiles = Ctot / T; *co_tiles = N / T;
+    *chunks_total = (int)nbp_cdiv(M, 32);
+    const long long base = (long long)*ci_tiles * *co_tiles * taps;
+    long long s = nbp_cdiv(1024, base);
+    if (s > *chunks_total) s = *chunks_total;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    *cps = (int)nbp_cdiv(*chunks_total, s);
+    *splits = (int)nbp_cdiv(*chunks_total, *cps);
+}
+
+extern "C" size_t nbp_conv_wgrad_workspace_bytes(int B, int H, int W, int C0, int C1, int N, int ksize) {
+    int ti, cit, cot, sp, ct, cps;
+    if ((C0 + C1) % 64 || N % 64 || C0 % 64) return 0;
+    wgrad_plan((long long)B * H * W, C0 + C1, N, ksize * ksize, &ti, &cit, &cot, &sp, &ct, &cps);
+    return (size_t)sp * ksize * ksize * (C0 + C1) * N * sizeof(float) + 256;
+}
+
+// dW [n_real][c_real][k][k] (OIHW) of out = conv(cat(src0, src1) [upsampled]) given dY [B,H,W,N].
+// C0, C1, N multiples of 64 (pad small layers); c_real / n_real select the un-padded part written.
+extern "C" int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W, int ksize,
+                                  const float* dy, int N, int c_real, int n_real, float* dw, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    NBP_RETURN_IF(!src0 || !dy || !dw || !ws || B < 1 || H < 1 || W < 1, NBP_E_ARG);
+    NBP_RETURN_IF(ksize != 1 && ksize != 3, NBP_E_ARG);
+    NBP_RETURN_IF(C0 < 64 || C0 % 64 || C1 < 0 || C1 % 64 || N < 64 || N % 64, NBP_E_SHAPE);
+    NBP_RETURN_IF((C1 > 0 && !src1) || c_real < 1 || c_real > C0 + C1 || n_real < 1 || n_real > N, NBP_E_ARG);
+    NBP_RETURN_IF(ups && ((H | W) & 1), NBP_E_SHAPE);
+    WgradArgs a;
+    a.src0 = src0; a.src1 = src1; a.C0 = C0; a.C1 = C1; a.ups = ups ? 1 : 0; a.H = H; a.W = W;
+    a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.taps = ksize * ksize; a.dy = dy; a.N = N;
+    a.M = (long long)B * H * W;
+    const long long b0 = (long long)B * a.Hs * a.Ws * C0 * 4, b1 = (long long)B * a.Hs * a.Ws * C1 * 4;
+    NBP_RETURN_IF(b0 >= (1ll << 31) || b1 >= (1ll << 31), NBP_E_SHAPE);
+    a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0;
+    int ti, sp;
+    wgrad_plan(a.M, C0 + C1, N, a.taps, &ti, &a.ci_tiles, &a.co_tiles, &sp, &a.chunks_total, &a.chunks_per_split);
+    NBP_RETURN_IF(ti == 2 && C0 % 128, NBP_E_SHAPE);
+    NBP_RETURN_IF(ws_bytes < (size_t)sp * a.taps * (C0 + C1) * N * sizeof(float) + 256, NBP_E_WS);
+    a.part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(a.ci_tiles * a.co_tiles), (unsigned)a.taps, (unsigned)sp);
+    if (ti == 2) wgrad_kernel<2, 2><<<grid, 256, 0, st>>>(a);
+    else wgrad_kernel<1, 1><<<grid, 256, 0, st>>>(a);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    const long long total = (long long)n_real * c_real * a.taps;
+    wgrad_reduce_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(a.part, sp, a.taps, C0 + C1, N, c_real, n_real, dw);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_gather_values_f32(const float* out1_nchw, const long long* coords_bcxy, int K, int C, int H, int W, float* pred,
+                                     void* stream) {
+    NBP_RETURN_IF(!out1_nchw || !coords_bcxy || !pred || K < 1, NBP_E_ARG);
+    gather_values_kernel<<<(unsigned)nbp_cdiv(K, 256), 256, 0, (hipStream_t)stream>>>(out1_nchw, coords_bcxy, K, C, H, W, pred);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_scatter_values_f32(const float* dpred, const long long* coords_bcxy, int K, int C, int H, int W,
+                                      float* dout1_nchw_zeroed, void* stream) {
+    NBP_RETURN_IF(!dpred || !coords_bcxy || !dout1_nchw_zeroed || K < 1, NBP_E_ARG);
+    scatter_values_kernel<<<(unsigned)nbp_cdiv(K, 256), 256, 0, (hipStream_t)stream>>>(dpred, coords_bcxy, K, C, H, W,
+                                                                                        dout1_nchw_zeroed);
+    return nbp_launch_status();
+}
+
+// mode 0: MSE, mode 1: BCE.  *sum_out (device double) = sum of per-element losses; dp = coef * d(mean loss)/dp
+extern "C" int nbp_loss_f32(int mode, const float* p, const float* t, long long n, float grad_coef, double* sum_out,
+                            float* dp_or_null, void* ws, size_t ws_bytes, void* stream) {
+    NBP_RETURN_IF(!p || !t || !sum_out || !ws || n < 1 || mode < 0 || mode > 1, NBP_E_ARG);
+    NBP_RETURN_IF(ws_bytes < 512 * sizeof(double) + 256, NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)(((uintptr_t)ws + 255) / 256 * 256);
+    const int nblk = nbp_ew_grid(n, 256) > 512 ? 512 : nbp_ew_grid(n, 256);
+    loss_partial_kernel<<<nblk, 256, 0, st>>>(mode, p, t, n, part);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    sum_doubles_kernel<<<1, 64, 0, st>>>(part, nblk, sum_out);
+    if ((rc = nbp_launch_status())) return rc;
+    if (dp_or_null) {
+        loss_grad_kernel<<<nbp_ew_grid(n, 256), 256, 0, st>>>(mode, p, t, n, grad_coef, dp_or_null);
+        rc = nbp_launch_status();
+    }
+    return rc;
+}

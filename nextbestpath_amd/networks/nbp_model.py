@@ -143,6 +143,9 @@ class NBP(nn.Module):
 
     # ------------------------------------------------------------------ loss (ref :162-173)
     def loss(self, pred1, target1, pred2, target2):
+        if pred1.is_cuda:
+            from . import training
+            return training.loss(self, pred1, target1, pred2, target2)
         s = self.log_vars
         l1 = F.mse_loss(pred1, target1) / (2.0 * torch.exp(2 * s[0])) + s[0]
         l2 = F.binary_cross_entropy(pred2, target2) / torch.exp(2 * s[1]) + s[1]

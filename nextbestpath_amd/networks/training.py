@@ -1,0 +1,423 @@
+"""Training-mode forward / backward of NBP on the HIP kernels (csrc/nbp_train.hip + the implicit-GEMM
+convolution of csrc/nbp_conv.hip).
+
+Reference: next_best_path/utility/nbp_utils.py:340-395 (train_experience_data) drives
+``nbp.train(); out1, out2 = nbp(x); loss = nbp.loss(...); loss.backward()``; the layers are
+next_best_path/networks/nbp_model.py:8-62.  Here every layer is a ``torch.autograd.Function`` whose
+forward and backward are C-ABI kernel launches; torch's autograd engine only threads them together
+(plumbing) and torch.optim.AdamW applies the update, as the survey's build plan allows.
+
+Activations are NHWC ``[B,H,W,C]`` fp32; channel counts are padded to multiples of 64 where the
+matrix-core kernels need it (network input 5->64, F_int 32->64, final 8/1->64) and sliced back, so
+the parameter gradients have the reference's shapes.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+
+
+def _st():
+    return _lib.current_stream()
+
+
+def _up(v, m=64):
+    return (v + m - 1) // m * m
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _chk(rc, what):
+    _lib.check(rc, what)
+
+
+def _colsum(x2d, rows=None):
+    M, C = x2d.shape
+    L = _lib.lib()
+    out = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    ws = _ws(L.nbp_colreduce_workspace_bytes(M, C), x2d.device)
+    _chk(L.nbp_colsum_f32(_lib.ptr(x2d), _lib.ptr(rows), M, C, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _st()), "colsum")
+    return out
+
+
+def _pad_channels(x, cout):
+    B, H, W, C = x.shape
+    if C == cout:
+        return x
+    out = torch.empty(B, H, W, cout, dtype=torch.float32, device=x.device)
+    _chk(_lib.lib().nbp_pad_channels_f32(_lib.ptr(x), B * H * W, C, cout, _lib.ptr(out), _st()), "pad_channels")
+    return out
+
+
+def _slice_channels(x, c0, cs):
+    B, H, W, C = x.shape
+    if c0 == 0 and cs == C:
+        return x
+    out = torch.empty(B, H, W, cs, dtype=torch.float32, device=x.device)
+    _chk(_lib.lib().nbp_slice_channels_f32(_lib.ptr(x), B * H * W, C, c0, cs, _lib.ptr(out), _st()), "slice_channels")
+    return out
+
+
+def _igemm(src0, src1, ups, wpk, N, ksize, scale, shift, relu):
+    L = _lib.lib()
+    B, Hs, Ws, C0 = src0.shape
+    H, W = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
+    C1 = 0 if src1 is None else src1.shape[3]
+    out = torch.empty(B, H, W, N, dtype=torch.float32, device=src0.device)
+    ws = _ws(L.nbp_conv_igemm_workspace_bytes(B, H, W, N, 0), src0.device)
+    _chk(L.nbp_conv_igemm_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, ksize, _lib.ptr(wpk), N,
+                              _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), 0, 0, _lib.ptr(ws), ws.numel(),
+                              _st()), "conv_igemm")
+    return out
+
+
+class ConvFn(torch.autograd.Function):
+    """y = conv_k(cat(x0, x1) [x2 nearest-upsampled]) + bias; weight OIHW [N, c_real, k, k].
+    x0 / x1 channel counts are multiples of 64 (c_real < C0 only for the zero-padded network input)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, ups):
+        L = _lib.lib()
+        N, c_real, k, _ = weight.shape
+        C0 = x0.shape[3]
+        C1 = 0 if x1 is None else x1.shape[3]
+        Ctot, Np = C0 + C1, _up(N)
+        dev = x0.device
+        wpk = torch.empty(Ctot // 32 * k * k * Np * 32, dtype=torch.float32, device=dev)
+        w = weight.detach().contiguous()
+        _chk(L.nbp_pack_conv_weight_padded(_lib.ptr(w), N, c_real, k, Ctot, Np, _lib.ptr(wpk), _st()), "pack_fwd")
+        scale = torch.ones(Np, dtype=torch.float32, device=dev)
+        shift = torch.zeros(Np, dtype=torch.float32, device=dev)
+        shift[:N] = bias.detach()
+        y = _igemm(x0, x1, ups, wpk, Np, k, scale, shift, False)
+        ctx.save_for_backward(x0, x1 if x1 is not None else torch.empty(0, device=dev), w)
+        ctx.meta = (N, c_real, k, C0, C1, Np, bool(ups), x1 is not None)
+        return _slice_channels(y, 0, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x0, x1, w = ctx.saved_tensors
+        N, c_real, k, C0, C1, Np, ups, has1 = ctx.meta
+        x1 = x1 if has1 else None
+        dev = dy.device
+        dy = _pad_channels(dy.contiguous(), Np)
+        B, H, W, _ = dy.shape
+        M = B * H * W
+        db = _colsum(dy.view(M, Np))[:N].clone()
+        dw = torch.empty(N, c_real, k, k, dtype=torch.float32, device=dev)
+        ws = _ws(L.nbp_conv_wgrad_workspace_bytes(B, H, W, C0, C1, Np, k), dev)
+        _chk(L.nbp_conv_wgrad_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, int(ups), B, H, W, k, _lib.ptr(dy), Np, c_real, N,
+                                  _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _st()), "conv_wgrad")
+        dx0 = dx1 = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            Ctot = C0 + C1
+            wt = torch.empty(Np // 32 * k * k * Ctot * 32, dtype=torch.float32, device=dev)
+            _chk(L.nbp_pack_conv_weight_dgrad(_lib.ptr(w), N, c_real, k, Ctot, Np, _lib.ptr(wt), _st()), "pack_dgrad")
+            one = torch.ones(Ctot, dtype=torch.float32, device=dev)
+            zero = torch.zeros(Ctot, dtype=torch.float32, device=dev)
+            dx = _igemm(dy, None, False, wt, Ctot, k, one, zero, False)            # [B,H,W,Ctot] at output resolution
+            if ups:
+                low = torch.empty(B, H // 2, W // 2, Ctot, dtype=torch.float32, device=dev)
+                _chk(L.nbp_sum2x2_f32(_lib.ptr(dx), B, H // 2, W // 2, Ctot, _lib.ptr(low), _st()), "sum2x2")
+                dx = low
+            if has1:
+                dx0, dx1 = _slice_channels(dx, 0, C0), _slice_channels(dx, C0, C1)
+            else:
+                dx0 = dx
+        return dx0, dx1, dw, db, None
+
+
+class BNFn(torch.autograd.Function):
+    """nn.BatchNorm2d in training mode (+ optional fused ReLU); updates the running statistics in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        L = _lib.lib()
+        shp = x.shape
+        C = shp[-1]
+        M = x.numel() // C
+        dev = x.device
+        x = x.contiguous()
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        ws = _ws(L.nbp_colreduce_workspace_bytes(M, C), dev)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        _chk(L.nbp_bn_train_forward_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
+                                        _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
+                                        _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(ws), ws.numel(), _st()), "bn_fwd")
+        ctx.save_for_backward(x, y, mean, invstd, g)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, y, mean, invstd, g = ctx.saved_tensors
+        C = x.shape[-1]
+        M = x.numel() // C
+        dev = x.device
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = _ws(L.nbp_colreduce_workspace_bytes(M, C), dev)
+        _chk(L.nbp_bn_train_backward_f32(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), M, C, _lib.ptr(mean), _lib.ptr(invstd),
+                                         _lib.ptr(g), int(ctx.relu), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(ws),
+                                         ws.numel(), _st()), "bn_bwd")
+        return dx, dg, db, None, None, None, None, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C = x.shape
+        x = x.contiguous()
+        y = torch.empty(B, H // 2, W // 2, C, dtype=torch.float32, device=x.device)
+        _chk(_lib.lib().nbp_maxpool2_nhwc_f32(_lib.ptr(x), B, H, W, C, _lib.ptr(y), _st()), "maxpool")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        _chk(_lib.lib().nbp_maxpool2_backward_f32(_lib.ptr(x), _lib.ptr(dy.contiguous()), B, H, W, C, _lib.ptr(dx), _st()),
+             "maxpool_bwd")
+        return dx
+
+
+def _ew(op, a, b=None):
+    out = torch.empty_like(a)
+    _chk(_lib.lib().nbp_elementwise_f32(op, _lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(out), _st()), "elementwise")
+    return out
+
+
+class AddReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        y = _ew(0, a.contiguous(), b.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        g = _ew(1, dy.contiguous(), y)
+        return g, g
+
+
+class SigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):
+        y = _ew(2, a.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return _ew(3, dy.contiguous(), y)
+
+
+class PsiConvFn(torch.autograd.Function):
+    """1x1 convolution F -> 1 (Attention_block.psi.0): p[m] = q[m,:] . w + b."""
+
+    @staticmethod
+    def forward(ctx, q, weight, bias):
+        L = _lib.lib()
+        B, H, W, Fc = q.shape
+        M = B * H * W
+        q = q.contiguous()
+        w = weight.detach().reshape(-1).contiguous()
+        p = torch.empty(M, dtype=torch.float32, device=q.device)
+        _chk(L.nbp_rowdot_f32(_lib.ptr(q), _lib.ptr(w), 1, M, Fc, _lib.ptr(p), _st()), "rowdot")
+        out = _ew(5, p, bias.detach().contiguous())
+        ctx.save_for_backward(q, w)
+        ctx.wshape = weight.shape
+        return out.view(B, H, W, 1)
+
+    @staticmethod
+    def backward(ctx, dp):
+        L = _lib.lib()
+        q, w = ctx.saved_tensors
+        B, H, W, Fc = q.shape
+        M = B * H * W
+        dp = dp.contiguous().view(M)
+        dq = torch.empty_like(q)
+        _chk(L.nbp_outer_f32(_lib.ptr(dp), _lib.ptr(w), M, Fc, _lib.ptr(dq), _st()), "outer")
+        dw = _colsum(q.view(M, Fc), dp).view(ctx.wshape)
+        db = _colsum(dp.view(M, 1))
+        return dq, dw, db
+
+
+class RowScaleFn(torch.autograd.Function):
+    """out[m, c] = x[m, c] * s[m]  (the attention gate's  x * psi)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        B, H, W, C = x.shape
+        x, s = x.contiguous(), s.contiguous()
+        out = torch.empty_like(x)
+        _chk(_lib.lib().nbp_rowscale_f32(_lib.ptr(x), _lib.ptr(s), B * H * W, C, _lib.ptr(out), _st()), "rowscale")
+        ctx.save_for_backward(x, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, s = ctx.saved_tensors
+        B, H, W, C = x.shape
+        M = B * H * W
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _chk(L.nbp_rowscale_f32(_lib.ptr(dy), _lib.ptr(s), M, C, _lib.ptr(dx), _st()), "rowscale")
+        ds = torch.empty(M, dtype=torch.float32, device=x.device)
+        _chk(L.nbp_rowdot_f32(_lib.ptr(dy), _lib.ptr(x), 0, M, C, _lib.ptr(ds), _st()), "rowdot")
+        return dx, ds.view(s.shape)
+
+
+class ToNCHWFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C = x.shape
+        out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+        _chk(_lib.lib().nbp_nhwc_to_nchw_f32(_lib.ptr(x.contiguous()), B, C, H, W, _lib.ptr(out), _st()), "to_nchw")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = dy.shape
+        out = torch.empty(B, H, W, C, dtype=torch.float32, device=dy.device)
+        _chk(_lib.lib().nbp_nchw_to_nhwc_f32(_lib.ptr(dy.contiguous()), B, C, H, W, _lib.ptr(out), _st()), "to_nhwc")
+        return out
+
+
+class GatherValuesFn(torch.autograd.Function):
+    """pred[k] = out1[b, c, x, y] (nbp_utils.py:379); coords int64 [K,4] = (b, c, x, y)."""
+
+    @staticmethod
+    def forward(ctx, out1, coords):
+        B, C, H, W = out1.shape
+        K = coords.shape[0]
+        coords = coords.contiguous()
+        pred = torch.empty(K, dtype=torch.float32, device=out1.device)
+        _chk(_lib.lib().nbp_gather_values_f32(_lib.ptr(out1.contiguous()), _lib.ptr(coords), K, C, H, W, _lib.ptr(pred), _st()),
+             "gather_values")
+        ctx.save_for_backward(coords)
+        ctx.shape = (B, C, H, W)
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        (coords,) = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        d = torch.zeros(B, C, H, W, dtype=torch.float32, device=dpred.device)
+        _chk(_lib.lib().nbp_scatter_values_f32(_lib.ptr(dpred.contiguous()), _lib.ptr(coords), coords.shape[0], C, H, W,
+                                               _lib.ptr(d), _st()), "scatter_values")
+        return d, None
+
+
+class MeanLossFn(torch.autograd.Function):
+    """mode 0: F.mse_loss(p, t); mode 1: F.binary_cross_entropy(p, t) (mean reduction)."""
+
+    @staticmethod
+    def forward(ctx, p, t, mode):
+        p, t = p.contiguous(), t.contiguous()
+        acc = torch.empty(1, dtype=torch.float64, device=p.device)
+        ws = _ws(512 * 8 + 256, p.device)
+        _chk(_lib.lib().nbp_loss_f32(mode, _lib.ptr(p), _lib.ptr(t), p.numel(), 1.0, _lib.ptr(acc), None, _lib.ptr(ws),
+                                     ws.numel(), _st()), "loss")
+        ctx.save_for_backward(p, t)
+        ctx.mode = mode
+        return (acc / p.numel()).to(torch.float32).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t = ctx.saved_tensors
+        acc = torch.empty(1, dtype=torch.float64, device=p.device)
+        dp = torch.empty_like(p)
+        ws = _ws(512 * 8 + 256, p.device)
+        _chk(_lib.lib().nbp_loss_f32(ctx.mode, _lib.ptr(p), _lib.ptr(t), p.numel(), float(g.item()), _lib.ptr(acc),
+                                     _lib.ptr(dp), _lib.ptr(ws), ws.numel(), _st()), "loss_grad")
+        return dp, None, None
+
+
+# ---------------------------------------------------------------------------------------------- network
+def _bn(mod, x, relu):
+    y = BNFn.apply(x, mod.weight, mod.bias, mod.running_mean, mod.running_var, mod.eps, mod.momentum, relu)
+    with torch.no_grad():
+        mod.num_batches_tracked += 1
+    return y
+
+
+def _block(seq, x0, x1=None):
+    """conv_block (ref :8-21): (conv3x3 -> BN -> ReLU) x 2 on cat(x0, x1)."""
+    y = ConvFn.apply(x0, x1, seq[0].weight, seq[0].bias, False)
+    y = _bn(seq[1], y, True)
+    y = ConvFn.apply(y, None, seq[3].weight, seq[3].bias, False)
+    return _bn(seq[4], y, True)
+
+
+def _up_conv(seq, x):
+    """up_conv (ref :23-34): nearest x2 -> conv3x3 -> BN -> ReLU (the upsample is fused in the conv gather)."""
+    y = ConvFn.apply(x, None, seq[1].weight, seq[1].bias, True)
+    return _bn(seq[2], y, True)
+
+
+def _gate(att, g, x):
+    """Attention_block (ref :36-62)."""
+    g1 = _bn(att.W_g[1], ConvFn.apply(g, None, att.W_g[0].weight, att.W_g[0].bias, False), False)
+    x1 = _bn(att.W_x[1], ConvFn.apply(x, None, att.W_x[0].weight, att.W_x[0].bias, False), False)
+    q = AddReluFn.apply(g1, x1)
+    p = PsiConvFn.apply(q, att.psi[0].weight, att.psi[0].bias)
+    psi = SigmoidFn.apply(_bn(att.psi[1], p, False))
+    return RowScaleFn.apply(x, psi)
+
+
+def forward_train(net, x):
+    """NBP.forward in train mode (ref :110-160) -> (out1 [B,8,S/4,S/4], out2 [B,1,S,S]) with autograd."""
+    L = _lib.lib()
+    B, _, S, _ = x.shape
+    dev = x.device
+    xh = torch.empty(B, S, S, 5, dtype=torch.float32, device=dev)
+    _chk(L.nbp_nchw_to_nhwc_f32(_lib.ptr(x.contiguous().float()), B, 5, S, S, _lib.ptr(xh), _st()), "to_nhwc")
+    x0 = _pad_channels(xh, 64)
+    x1 = _block(net.Conv1.conv, x0)
+    x2 = _block(net.Conv2.conv, MaxPoolFn.apply(x1))
+    x3 = _block(net.Conv3.conv, MaxPoolFn.apply(x2))
+    x4 = _block(net.Conv4.conv, MaxPoolFn.apply(x3))
+    x5 = _block(net.Conv5.conv, MaxPoolFn.apply(x4))
+    skips = {5: x4, 4: x3, 3: x2, 2: x1}
+    outs = {}
+    for d, levels in ((1, (5, 4)), (2, (5, 4, 3, 2))):
+        cur = x5
+        for Lv in levels:
+            dd = _up_conv(getattr(net, f"Up{Lv}_{d}").up, cur)
+            a = _gate(getattr(net, f"Att{Lv}_{d}"), dd, skips[Lv])
+            cur = _block(getattr(net, f"Up_conv{Lv}_{d}").conv, a, dd)
+        outs[d] = cur
+    o1 = ConvFn.apply(outs[1], None, net.Final1.weight, net.Final1.bias, False)          # [B,S/4,S/4,8]
+    out1 = ToNCHWFn.apply(o1)
+    o2 = ConvFn.apply(outs[2], None, net.Final2[0].weight, net.Final2[0].bias, False)    # [B,S,S,1]
+    out2 = SigmoidFn.apply(o2).reshape(B, 1, S, S)                                       # C == 1: NHWC == NCHW
+    return out1, out2
+
+
+def gather_values(out1, batch_indices, coords):
+    """pred_values = predicted_value_map[batch_indices, c, x, y] (nbp_utils.py:379)."""
+    full = torch.cat([batch_indices.view(-1, 1).long(), coords.long()], 1)
+    return GatherValuesFn.apply(out1, full)
+
+
+def loss(net, pred1, target1, pred2, target2):
+    """NBP.loss (ref :162-173) with the MSE / BCE reductions and their gradients on the device kernels."""
+    s = net.log_vars
+    mse = MeanLossFn.apply(pred1, target1, 0)
+    bce = MeanLossFn.apply(pred2, target2, 1)
+    return mse / (2.0 * torch.exp(2 * s[0])) + s[0] + bce / torch.exp(2 * s[1]) + s[1]

@@ -140,3 +140,15 @@ def coverage_count(gt, pc, n_dev=None, n=None, weight=2, seed=0, threshold=1.0, 
                                   ws.numel(), _st())
     _lib.check(rc, "nbp_coverage_count_f32")
     return out
+
+
+def carve_update(proxy_pts, depth, mask, cam12_host, zfar, fov_range, tol, score_threshold, n_inside, n_behind, occ,
+                 out_of_field, tan_half_fov=TAN_HALF_FOV):
+    """A20 (macarons_utils.py:2849-2949, 3329-3363): in-place update of the per-proxy-point carving state."""
+    H, W = depth.shape[-2:]
+    cam = (C.c_float * 12)(*[float(x) for x in cam12_host])
+    rc = _lib.lib().nbp_carve_update_f32(_lib.ptr(proxy_pts), proxy_pts.shape[0], _lib.ptr(depth), _lib.ptr(mask), cam, H, W,
+                                         tan_half_fov, float(zfar), float(fov_range), float(tol), float(score_threshold),
+                                         _lib.ptr(n_inside), _lib.ptr(n_behind), _lib.ptr(occ), _lib.ptr(out_of_field),
+                                         _st())
+    _lib.check(rc, "nbp_carve_update_f32")

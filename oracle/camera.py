@@ -105,3 +105,45 @@ def pose_lattice(x_min, pose_l, pose_w, pose_h, n_elev, n_azim):
     poses[:, 3] = f32(-90.0) + (f32(180.0) * (1 + idx[:, 3]).astype(f32)) / f32(n_elev + 1)
     poses[:, 4] = (f32(360.0) * idx[:, 4].astype(f32)) / f32(n_azim)
     return idx, poses
+
+
+def carve_update(pts, depth, mask, R, T, zfar, fov_range, tol, score_thr, n_inside, n_behind, occ, out_of_field):
+    """Depth-map space carving (A20): Camera.get_points_in_fov (mu:2849-2884) +
+    get_signed_distance_to_depth_maps (mu:2900-2949; F.grid_sample bilinear, border padding,
+    align_corners=False) + Scene.update_proxy_supervision_occ / update_proxy_out_of_field
+    (mu:3329-3363).  Arrays are updated in place; fp32, kernel op order."""
+    H, W = depth.shape
+    s = min(H, W)
+    R, T = np.asarray(R, f32), np.asarray(T, f32)
+    p = np.asarray(pts, f32)
+    v = np.empty_like(p)
+    for j in range(3):
+        v[:, j] = ((p[:, 0] * R[0, j] + p[:, 1] * R[1, j]) + p[:, 2] * R[2, j]) + T[j]
+    C = np.array([-((T[0] * R[j, 0] + T[1] * R[j, 1]) + T[2] * R[j, 2]) for j in range(3)], f32)
+    d = p - C
+    dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=f32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        nx = v[:, 0] / (v[:, 2] * TAN_HALF_FOV)
+        ny = v[:, 1] / (v[:, 2] * TAN_HALF_FOV)
+    max_x = f32(W / s); min_x = max_x - (f32(W - 1) / f32(s - 1)) * f32(2)
+    max_y = f32(H / s); min_y = max_y - (f32(H - 1) / f32(s - 1)) * f32(2)
+    inf = (nx >= min_x) & (nx <= max_x) & (ny >= min_y) & (ny <= max_y) & (v[:, 2] > 0) & (dist < f32(fov_range))
+    gx = (-f32(s) / f32(W)) * nx
+    gy = (-f32(s) / f32(H)) * ny
+    ix = np.clip(((gx + f32(1)) * f32(W) - f32(1)) * f32(0.5), 0, W - 1).astype(f32)
+    iy = np.clip(((gy + f32(1)) * f32(H) - f32(1)) * f32(0.5), 0, H - 1).astype(f32)
+    ix, iy = np.where(inf, ix, 0).astype(f32), np.where(inf, iy, 0).astype(f32)
+    x0, y0 = np.floor(ix).astype(int), np.floor(iy).astype(int)
+    x1, y1 = np.minimum(x0 + 1, W - 1), np.minimum(y0 + 1, H - 1)
+    wx, wy = ix - x0.astype(f32), iy - y0.astype(f32)
+    ok = (depth > -1) if mask is None else (mask != 0)
+    dd = np.where(ok, depth, f32(1.1) * f32(zfar)).astype(f32)
+    one = f32(1)
+    ds = (dd[y0, x0] * (one - wx) * (one - wy) + dd[y0, x1] * wx * (one - wy)) + \
+         (dd[y1, x0] * (one - wx) * wy + dd[y1, x1] * wx * wy)
+    sd = v[:, 2] - ds
+    n_inside[inf] += 1
+    n_behind[inf] += (sd[inf] >= -f32(tol)).astype(f32)
+    occ[inf] = ((n_behind[inf] / n_inside[inf]) >= f32(score_thr)).astype(f32)
+    out_of_field[inf] = 0
+    return inf, sd

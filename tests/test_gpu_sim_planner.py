@@ -202,3 +202,26 @@ def test_coverage_full_size_properties(hip):
     assert self_cov[0] == 50_000
     half = ho.coverage_count(gt, pc[:50_000], seed=1).cpu().numpy()
     assert half[0] <= a[0] <= 50_000
+
+
+def test_carving_vs_oracle(hip):
+    """A20: fused frustum test + bilinear depth lookup + carving counters, two consecutive frames."""
+    H, W, zfar = 64, 114, 750.0
+    rng = np.random.default_rng(9)
+    P = 20000
+    pts = rng.uniform(-40, 40, (P, 3)).astype(np.float32)
+    ptd = torch.from_numpy(pts).to(D)
+    st_o = [np.zeros(P, np.float32), np.zeros(P, np.float32), np.ones(P, np.float32), np.ones(P, np.float32)]
+    st_d = [torch.from_numpy(a.copy()).to(D) for a in st_o]
+    n_in = 0
+    for k, (x, v) in enumerate([([2.0, 3.3, -5.0], [0.0, 30.0]), ([5.0, 3.3, -5.0], [-20.0, 120.0])]):
+        depth = rng.uniform(4, 50, (H, W)).astype(np.float32)
+        depth[rng.random((H, W)) < 0.15] = -1
+        R, T = ocam.camera_RT(x, v)
+        inf, _ = ocam.carve_update(pts, depth, None, R, T, zfar, 70.0, 10.0, 0.95, *st_o)
+        n_in += int(inf.sum())
+        ho.carve_update(ptd, torch.from_numpy(depth).to(D), None, np.concatenate([R.reshape(-1), T]), zfar, 70.0, 10.0, 0.95,
+                        *st_d)
+    assert n_in > 500
+    for a, b in zip(st_o, st_d):
+        assert np.array_equal(a, b.cpu().numpy())

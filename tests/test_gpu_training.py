@@ -1,0 +1,215 @@
+"""GPU parity of the training step (nbp.train(): forward with batch statistics, loss, backward) against
+torch-fp32 CPU autograd on the oracle network (the reference's own arithmetic: same ATen ops)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from nextbestpath_amd import _lib
+from nextbestpath_amd.networks import training as tr
+from nextbestpath_amd.utility.synthetic import make_count_maps
+from oracle import nbp_net
+
+pytestmark = pytest.mark.gpu
+D = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _close(got, want, rtol=2e-4, what=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert err <= rtol * ref + 1e-6, f"{what}: err {err:.3e} vs max {ref:.3e}"
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, C0, C1, N, c_real, k, ups
+    (2, 8, 8, 64, 0, 64, 64, 3, 0),
+    (1, 12, 10, 64, 0, 128, 5, 3, 0),        # zero-padded network input: only 5 real channels
+    (2, 8, 8, 128, 128, 128, 256, 3, 0),     # concat, 128x128 wgrad tile
+    (1, 8, 8, 64, 64, 64, 128, 3, 0),        # concat with 64-wide halves
+    (2, 4, 4, 128, 0, 64, 128, 3, 1),        # fused upsample (input 4x4 -> output 8x8)
+    (2, 6, 6, 256, 0, 8, 256, 1, 0),         # Final1-like: N = 8 padded to 64
+    (1, 8, 8, 64, 0, 32, 64, 1, 0),          # Att2-like 1x1 with N = 32
+])
+def test_conv_function_grads(hip, case):
+    B, H, W, C0, C1, N, c_real, k, ups = case
+    x0 = _rand(B, H, W, C0, seed=1)
+    if c_real < C0 + C1:
+        x0[..., c_real:] = 0
+    x1 = _rand(B, H, W, C1, seed=2) if C1 else None
+    w = _rand(N, c_real, k, k, seed=3, scale=(3.0 / (c_real * k * k)) ** 0.5)
+    b = _rand(N, seed=4, scale=0.1)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    gy = _rand(B, Ho, Wo, N, seed=5)
+    # torch reference (NCHW)
+    xr0 = x0.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    xr1 = x1.permute(0, 3, 1, 2).clone().requires_grad_(True) if C1 else None
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xin = xr0 if xr1 is None else torch.cat((xr0, xr1), 1)
+    xin = xin[:, :c_real]
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2)
+    yr = F.conv2d(xin, wr, br, padding=k // 2)
+    yr.backward(gy.permute(0, 3, 1, 2))
+    # HIP
+    xd0 = x0.to(D).requires_grad_(True)
+    xd1 = x1.to(D).requires_grad_(True) if C1 else None
+    wd, bd = w.to(D).requires_grad_(True), b.to(D).requires_grad_(True)
+    y = tr.ConvFn.apply(xd0, xd1, wd, bd, bool(ups))
+    _close(y.permute(0, 3, 1, 2), yr, what="y")
+    y.backward(gy.to(D))
+    _close(wd.grad, wr.grad, what="dW")
+    _close(bd.grad, br.grad, what="db")
+    if c_real == C0 + C1:
+        _close(xd0.grad.permute(0, 3, 1, 2), xr0.grad, what="dx0")
+        if C1:
+            _close(xd1.grad.permute(0, 3, 1, 2), xr1.grad, what="dx1")
+
+
+@pytest.mark.parametrize("C,relu", [(64, True), (32, False), (1, False), (512, True), (96, True)])
+def test_batchnorm_train_function(hip, C, relu):
+    x = _rand(3, 5, 7, C, seed=1) * 2 + 0.3
+    g, b = _rand(C, seed=2) * 0.3 + 1, _rand(C, seed=3) * 0.2
+    rm, rv = _rand(C, seed=4) * 0.1, _rand(C, seed=5).abs() + 0.5
+    gy = _rand(3, 5, 7, C, seed=6)
+    xr, gr, br_ = x.permute(0, 3, 1, 2).clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rmr, rvr = rm.clone(), rv.clone()
+    yr = F.batch_norm(xr, rmr, rvr, gr, br_, True, 0.1, 1e-5)
+    yr = F.relu(yr) if relu else yr
+    yr.backward(gy.permute(0, 3, 1, 2))
+    xd, gd, bd = x.to(D).requires_grad_(True), g.to(D).requires_grad_(True), b.to(D).requires_grad_(True)
+    rmd, rvd = rm.to(D), rv.to(D)
+    y = tr.BNFn.apply(xd, gd, bd, rmd, rvd, 1e-5, 0.1, relu)
+    _close(y.permute(0, 3, 1, 2), yr, what="y")
+    _close(rmd, rmr, what="running_mean")
+    _close(rvd, rvr, what="running_var")
+    y.backward(gy.to(D))
+    _close(xd.grad.permute(0, 3, 1, 2), xr.grad, rtol=5e-4, what="dx")
+    _close(gd.grad, gr.grad, what="dgamma")
+    _close(bd.grad, br_.grad, what="dbeta")
+
+
+def test_small_functions(hip):
+    # max-pool (with ties -> first maximum), add+relu, psi conv, sigmoid, row scale, layout, gather, losses
+    x = torch.floor(_rand(2, 8, 6, 64, seed=1) * 3)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    gy = _rand(2, 4, 3, 64, seed=2)
+    yr.backward(gy.permute(0, 3, 1, 2))
+    xd = x.to(D).requires_grad_(True)
+    y = tr.MaxPoolFn.apply(xd)
+    y.backward(gy.to(D))
+    assert torch.equal(y.cpu().permute(0, 3, 1, 2), yr.detach())
+    assert torch.equal(xd.grad.cpu().permute(0, 3, 1, 2), xr.grad)
+    # attention tail pieces chained: q = relu(a+b); p = q.w + c; psi = sigmoid(p); out = x * psi
+    a, b2, xs = _rand(2, 4, 4, 32, seed=3), _rand(2, 4, 4, 32, seed=4), _rand(2, 4, 4, 64, seed=5)
+    w, c = _rand(1, 32, 1, 1, seed=6), _rand(1, seed=7)
+    go = _rand(2, 4, 4, 64, seed=8)
+    ar, br_, xr, wr, cr = [t.clone().requires_grad_(True) for t in (a, b2, xs, w, c)]
+    q = F.relu(ar + br_)
+    p = (q * wr.view(1, 1, 1, 32)).sum(-1, keepdim=True) + cr
+    outr = xr * torch.sigmoid(p)
+    outr.backward(go)
+    ad, bd, xd, wd, cd = [t.to(D).requires_grad_(True) for t in (a, b2, xs, w, c)]
+    out = tr.RowScaleFn.apply(xd, tr.SigmoidFn.apply(tr.PsiConvFn.apply(tr.AddReluFn.apply(ad, bd), wd, cd)))
+    out.backward(go.to(D))
+    _close(out, outr, what="gate out")
+    for nm, gd, gr in (("a", ad, ar), ("b", bd, br_), ("x", xd, xr), ("w", wd, wr), ("c", cd, cr)):
+        _close(gd.grad, gr.grad, what="gate d" + nm)
+    # gather with duplicate coordinates + losses
+    o1 = _rand(2, 8, 6, 6, seed=9)
+    coords = torch.tensor([[0, 1, 2, 3], [1, 7, 5, 5], [0, 1, 2, 3], [1, 0, 0, 0]])
+    tgt = _rand(4, seed=10)
+    o1r = o1.clone().requires_grad_(True)
+    pr = o1r[coords[:, 0], coords[:, 1], coords[:, 2], coords[:, 3]]
+    lr = F.mse_loss(pr, tgt)
+    lr.backward()
+    o1d = o1.to(D).requires_grad_(True)
+    pd = tr.GatherValuesFn.apply(o1d, coords.to(D))
+    ld = tr.MeanLossFn.apply(pd, tgt.to(D), 0)
+    ld.backward()
+    _close(ld, lr, what="mse")
+    _close(o1d.grad, o1r.grad, what="scatter grad")
+    p2 = torch.sigmoid(_rand(2, 1, 8, 8, seed=11) * 3)
+    t2 = (_rand(2, 1, 8, 8, seed=12) > 0).float()
+    p2r = p2.clone().requires_grad_(True)
+    l2r = F.binary_cross_entropy(p2r, t2)
+    l2r.backward()
+    p2d = p2.to(D).requires_grad_(True)
+    l2d = tr.MeanLossFn.apply(p2d, t2.to(D), 1)
+    l2d.backward()
+    _close(l2d, l2r, what="bce")
+    _close(p2d.grad, p2r.grad, what="bce grad")
+
+
+def _ref_step(sd, x, coords, gains, gt2):
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+          for k, v in sd.items()}
+    o1, o2 = nbp_net.nbp_forward(sd, x, train=True)
+    pred = o1[coords[:, 0], coords[:, 1], coords[:, 2], coords[:, 3]]
+    loss = nbp_net.nbp_loss(sd["log_vars"], pred, gains, o2, gt2)
+    loss.backward()
+    return o1.detach(), o2.detach(), loss.detach(), sd
+
+
+def test_full_network_training_step_vs_oracle(hip, nbp_weights):
+    """B=2, S=32: train-mode outputs, loss, EVERY parameter gradient and the running statistics."""
+    from nextbestpath_amd.networks.nbp_model import NBP
+    torch.manual_seed(0)
+    x = make_count_maps(2, 32, seed=21)
+    coords = torch.tensor([[0, 3, 1, 2], [0, 0, 7, 7], [1, 5, 4, 4], [1, 5, 4, 4], [1, 2, 0, 6]])
+    gains = torch.tensor([1.5, 0.2, 3.0, 2.0, 0.7])
+    gt2 = (torch.rand(2, 1, 32, 32) < 0.1).float()
+    sd = {k: v.clone() for k, v in nbp_weights.items()}
+    sd["log_vars"] = torch.tensor([0.3, -0.2])
+    r1, r2, rl, rsd = _ref_step(sd, x, coords, gains, gt2)
+    net = NBP()
+    net.load_state_dict(sd)
+    net = net.to(D).train()
+    o1, o2 = net(x.to(D))
+    pred = tr.gather_values(o1, coords[:, 0].to(D), coords[:, 1:].to(D))
+    loss = net.loss(pred, gains.to(D), o2, gt2.to(D))
+    loss.backward()
+    _close(o1, r1, rtol=1e-4, what="out1 (train)")
+    _close(o2, r2, rtol=1e-4, what="out2 (train)")
+    _close(loss, rl, rtol=1e-4, what="loss")
+    bad = []
+    for name, p in net.named_parameters():
+        ref = rsd[name].grad
+        assert p.grad is not None and ref is not None, name
+        err = (p.grad.cpu().double() - ref.double()).abs().max().item()
+        scale = ref.abs().max().item()
+        if err > 1e-3 * scale + 1e-7:
+            bad.append((name, err, scale))
+    assert not bad, bad[:8]
+    # running statistics were updated exactly once with momentum 0.1 (unbiased variance)
+    got = net.state_dict()
+    ro1, _ = nbp_net.nbp_forward(sd, x, train=False)          # oracle eval does not touch the stats
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    for k in list(sd2):
+        if k.endswith("running_mean"):
+            pass
+    # oracle: functional batch_norm with running buffers updated in place
+    sd3 = {k: v.clone() for k, v in sd.items()}
+    def fwd_update(sdict, xx):
+        import oracle.nbp_net as on
+        orig = on._bn
+        def bn(sdd, p, t, train):
+            return F.batch_norm(t, sdd[p + ".running_mean"], sdd[p + ".running_var"], sdd[p + ".weight"], sdd[p + ".bias"],
+                                True, 0.1, 1e-5)
+        on._bn = bn
+        try:
+            with torch.no_grad():
+                on.nbp_forward(sdict, xx, train=True)
+        finally:
+            on._bn = orig
+    fwd_update(sd3, x)
+    for k in ("Conv1.conv.1.running_mean", "Conv3.conv.4.running_var", "Att4_2.psi.1.running_var",
+              "Up_conv2_2.conv.4.running_mean", "Up5_1.up.2.running_var"):
+        _close(got[k], sd3[k], rtol=2e-4, what=k)
+    assert int(got["Conv1.conv.1.num_batches_tracked"]) == 1

@@ -197,3 +197,41 @@ def test_pose_lattice_order_and_values():
     assert idx[1].tolist() == [0, 0, 0, 0, 1] and idx[8].tolist() == [0, 0, 0, 1, 0]      # i-major ... azimuth fastest
     k = np.nonzero((idx == [2, 0, 3, 2, 4]).all(1))[0][0]
     assert np.allclose(poses[k], [-10 + 6, 3.3, -20 + 9, 0.0, 180.0])
+
+
+def test_carving_oracle_bilinear_matches_torch_grid_sample_and_plane_kat():
+    """A20: the oracle's bilinear lookup == torch.nn.functional.grid_sample (the reference's own op,
+    macarons_utils.py:2939-2944); plane known answer: points in front of the depth map are carved."""
+    import torch
+    H, W, zfar = 24, 40, 750.0
+    rng = np.random.default_rng(2)
+    depth = rng.uniform(5, 40, (H, W)).astype(np.float32)
+    depth[rng.random((H, W)) < 0.1] = -1
+    R, T = ocam.camera_RT([1.0, 2.0, -3.0], [15.0, 70.0])
+    X = np.array([1.0, 2.0, -3.0])
+    pts = (X + rng.normal(0, 25, (4000, 3))).astype(np.float32)
+    st = [np.zeros(4000, np.float32), np.zeros(4000, np.float32), np.ones(4000, np.float32), np.ones(4000, np.float32)]
+    inf, sd = ocam.carve_update(pts, depth, None, R, T, zfar, 60.0, 10.0, 0.95, *st)
+    assert 100 < inf.sum() < 3000
+    # reference formulation with torch ops on the in-frustum points
+    v = pts.astype(np.float64) @ R.astype(np.float64) + T.astype(np.float64)
+    t = float(ocam.TAN_HALF_FOV)
+    nx, ny = v[:, 0] / (v[:, 2] * t), v[:, 1] / (v[:, 2] * t)
+    s = min(H, W)
+    grid = torch.tensor(np.stack([-s / W * nx[inf], -s / H * ny[inf]], 1), dtype=torch.float32).view(1, -1, 1, 2)
+    dd = torch.from_numpy(np.where(depth > -1, depth, np.float32(1.1 * zfar)).astype(np.float32)).view(1, 1, H, W)
+    samp = torch.nn.functional.grid_sample(dd, grid, mode="bilinear", padding_mode="border", align_corners=False)
+    want = v[inf, 2] - samp.view(-1).numpy()
+    assert np.allclose(sd[inf], want, rtol=1e-4, atol=2e-3)
+    # state update rules
+    assert np.all(st[0][inf] == 1) and np.all(st[0][~inf] == 0) and np.all(st[3][inf] == 0) and np.all(st[3][~inf] == 1)
+    assert np.array_equal(st[2][inf], (sd[inf] >= -10.0).astype(np.float32))
+    # plane: constant depth 20 -> points at z_view < 20 - tol are carved (occ 0), behind stay occupied
+    plane = np.full((H, W), 20.0, np.float32)
+    zs = np.array([3.0, 15.0, 19.5, 25.0, 45.0], np.float32)
+    view_pts = np.stack([np.zeros(5), np.zeros(5), zs], 1)
+    world = ((view_pts - T) @ R.T).astype(np.float32)
+    st2 = [np.zeros(5, np.float32), np.zeros(5, np.float32), np.ones(5, np.float32), np.ones(5, np.float32)]
+    inf2, sd2 = ocam.carve_update(world, plane, None, R, T, zfar, 60.0, 1.0, 0.95, *st2)
+    assert inf2.all() and np.allclose(sd2, zs - 20.0, atol=1e-3)
+    assert st2[2].tolist() == [0.0, 0.0, 1.0, 1.0, 1.0]
