@@ -192,7 +192,7 @@ def main():
         scatter = {"bound": "hbm", "kernel": "map_accumulate_kernel", "achieved": round(alg / (ms_sc * 1e-3) / 1e9, 1),
                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(alg / (ms_sc * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                    "traffic": None, "points": n_pts, "algorithmic_bytes": alg, "ms": round(ms_sc, 4)}
-        cams4 = torch.from_numpy(np.stack([f[1] for f in cam.frames[-4:]])).to(dev)
+        cams4 = np.stack([f[1] for f in cam.frames[-4:]])
         zb = torch.empty(4, params.image_height, params.image_width, device=dev)
         ms_r = ev_time(lambda: hipops.raster_zbuf(mesh.verts, mesh.faces, cams4, params.image_height, params.image_width,
                                                   bin_cap=mesh.bin_cap, out=zb))

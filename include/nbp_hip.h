@@ -165,7 +165,8 @@ int nbp_map_accumulate_f32(const float* points, long long N, const long long* N_
 
 /* ================================================================ A14-A17: simulator
  * PyTorch3D / trimesh conventions restated (third-party; parity with the libraries unpinned):
- * cameras are [n][12] fp32 = R row-major (9) then T (3) with X_view = X_world R + T.         */
+ * cameras are HOST arrays [n][12] fp32 = R row-major (9) then T (3) with X_view = X_world R + T;
+ * n <= 8: they travel in the kernel arguments, so a step never blocks on a host->device copy. */
 
 /* Camera.compute_partial_point_cloud (macarons/utility/macarons_utils.py:2811-2847) for n_frames
  * depth maps at once, appended to a device-resident cloud:
@@ -177,7 +178,7 @@ int nbp_map_accumulate_f32(const float* points, long long N, const long long* N_
  * counts2[f] = {n_valid, n_keep}; points land at cloud[*cloud_count + sum_{g<f} n_keep_g + j];
  * *cloud_count is advanced on the device (clamped to capacity). */
 size_t nbp_unproject_workspace_bytes(int n_frames, int H, int W);
-int nbp_unproject_append_f32(const float* depth, const unsigned char* mask_or_null, const float* cams12,
+int nbp_unproject_append_f32(const float* depth, const unsigned char* mask_or_null, const float* cams12_host,
                              int n_frames, int H, int W, float tan_half_fov, float fov_range,
                              double gathering_factor, unsigned seed, int* counts2, float* cloud,
                              long long* cloud_count, long long capacity, void* ws, size_t ws_bytes,
@@ -189,7 +190,7 @@ int nbp_unproject_append_f32(const float* depth, const unsigned char* mask_or_nu
  * *overflow_flag (device int, caller zeroes it) is set if a tile overflowed. */
 size_t nbp_raster_workspace_bytes(int n_faces, int n_frames, int H, int W, int bin_cap);
 int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* faces, int n_faces,
-                        const float* cams12, int n_frames, int H, int W, float tan_half_fov,
+                        const float* cams12_host, int n_frames, int H, int W, float tan_half_fov,
                         float z_clip, int bin_cap, float* zbuf, int* overflow_flag, void* ws,
                         size_t ws_bytes, void* stream);
 
@@ -212,6 +213,8 @@ int nbp_carve_update_f32(const float* proxy_pts3, int P, const float* depth,
                          float tan_half_fov, float zfar, float fov_range, float tol,
                          float score_threshold, float* n_inside, float* n_behind, float* occ,
                          float* out_of_field, void* stream);
+/* dst[offset + i] = pts3_host[i] for i < n <= 8 (the camera trajectory buffer, without a blocking copy). */
+int nbp_append_points_f32(float* dst, long long offset, const float* pts3_host, int n, void* stream);
 /* Host mirror of the sampling bijection (driver / tests). */
 unsigned nbp_perm_index_host(unsigned j, unsigned n, unsigned seed);
 

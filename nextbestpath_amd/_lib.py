@@ -40,13 +40,14 @@ SIGNATURES = {
     "nbp_point_position_i64": (_i, [_vp, _ll, _i, _i, _f, _f, _vp, _vp]),
     "nbp_map_accumulate_f32": (_i, [_vp, _ll, _vp, _f, _f, _f, C.POINTER(_f), _i, _f, _f, _i, _f, _f, _vp, _vp]),
     "nbp_unproject_workspace_bytes": (_sz, [_i, _i, _i]),
-    "nbp_unproject_append_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _d, C.c_uint, _vp, _vp, _vp, _ll, _vp, _sz,
+    "nbp_unproject_append_f32": (_i, [_vp, _vp, C.POINTER(_f), _i, _i, _i, _f, _f, _d, C.c_uint, _vp, _vp, _vp, _ll, _vp, _sz,
                                       _vp]),
     "nbp_raster_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "nbp_raster_zbuf_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _sz, _vp]),
+    "nbp_raster_zbuf_f32": (_i, [_vp, _i, _vp, _i, C.POINTER(_f), _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _sz, _vp]),
     "nbp_segments_hit_mesh_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "nbp_axis_ray_counts_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "nbp_carve_update_f32": (_i, [_vp, _i, _vp, _vp, C.POINTER(_f), _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "nbp_append_points_f32": (_i, [_vp, _ll, C.POINTER(_f), _i, _vp]),
     "nbp_perm_index_host": (C.c_uint, [C.c_uint, C.c_uint, C.c_uint]),
     "nbp_colreduce_workspace_bytes": (_sz, [_ll, _i]),
     "nbp_bn_train_forward_f32": (_i, [_vp, _ll, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

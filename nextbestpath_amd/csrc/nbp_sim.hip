@@ -20,6 +20,8 @@ namespace {
 
 // ------------------------------------------------------------------ un-projection
 struct Cam { float R[9]; float T[3]; };
+constexpr int MAX_CAMS = 8;
+struct CamSet { Cam c[MAX_CAMS]; };   // cameras travel in the kernel arguments (no H2D copy, no sync)
 
 // Pixel (row, col) with view-space depth z -> world point.  fp32 op order is part of the
 // contract with oracle/camera.py (no FMA contraction in this file).
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void unproject_compact_kernel(const float* __r
 }
 
 // K2: gather the sub-sample and append it to the cloud at *cloud_count + sum of earlier frames.
-__global__ __launch_bounds__(256) void unproject_append_kernel(const float* __restrict__ depth, const Cam* __restrict__ cams,
+__global__ __launch_bounds__(256) void unproject_append_kernel(const float* __restrict__ depth, CamSet cams,
                                                                int H, int W, float tanh_fov, unsigned seed,
                                                                const unsigned* __restrict__ list,
                                                                const int* __restrict__ counts, float* __restrict__ cloud,
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __re
     for (int g = 0; g < f; ++g) base += counts[2 * g + 1];
     const unsigned bits = perm_bits((unsigned)nvalid);
     const unsigned sd = seed + 0x632BE5ABu * (unsigned)(f + 1);
-    const Cam cam = cams[f];
+    const Cam cam = cams.c[f];
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nkeep; j += gridDim.x * blockDim.x) {
         if (base + j >= capacity) return;
         const unsigned pix = list[(size_t)f * HW + perm_index((unsigned)j, (unsigned)nvalid, bits, sd)];
@@ -152,14 +154,14 @@ __device__ __forceinline__ void to_view(const float* p, const float* R, const fl
 
 // One thread per (face, frame): view transform, near-plane clip for the screen bbox (in tiles).
 __global__ __launch_bounds__(256) void raster_setup_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
-                                                           int n_faces, const Cam* __restrict__ cams, int H, int W,
+                                                           int n_faces, CamSet cams, int H, int W,
                                                            float tanh_fov, float zclip, FaceRec* __restrict__ recs,
                                                            int4* __restrict__ tbox) {
     const int fr = blockIdx.y;
     const int fi = blockIdx.x * blockDim.x + threadIdx.x;
     if (fi >= n_faces) return;
     int4 box = make_int4(1, 0, 1, 0);                                            // empty (tx0 > tx1)
-    const Cam cam = cams[fr];
+    const Cam cam = cams.c[fr];
     float v[3][3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) to_view(verts + 3 * (size_t)faces[3 * (size_t)fi + k], cam.R, cam.T, v[k]);
@@ -380,13 +382,23 @@ extern "C" size_t nbp_unproject_workspace_bytes(int n_frames, int H, int W) {
     return (size_t)n_frames * H * W * sizeof(unsigned) + ((size_t)n_frames * nblk * sizeof(int) + 255) / 256 * 256 + 512;
 }
 
-extern "C" int nbp_unproject_append_f32(const float* depth, const unsigned char* mask_or_null, const float* cams12,
+static CamSet camset_from_host(const float* cams12_host, int n) {
+    CamSet cs;
+    for (int f = 0; f < MAX_CAMS; ++f)
+        for (int k = 0; k < 12; ++k) {
+            const float v = f < n ? cams12_host[12 * f + k] : 0.f;
+            if (k < 9) cs.c[f].R[k] = v; else cs.c[f].T[k - 9] = v;
+        }
+    return cs;
+}
+
+extern "C" int nbp_unproject_append_f32(const float* depth, const unsigned char* mask_or_null, const float* cams12_host,
                                         int n_frames, int H, int W, float tan_half_fov, float fov_range,
                                         double gathering_factor, unsigned seed, int* counts2, float* cloud,
                                         long long* cloud_count, long long capacity, void* ws, size_t ws_bytes,
                                         void* stream) {
-    NBP_RETURN_IF(!depth || !cams12 || !counts2 || !cloud || !cloud_count || !ws, NBP_E_ARG);
-    NBP_RETURN_IF(n_frames < 1 || n_frames > 64 || H < 2 || W < 2 || capacity < 1, NBP_E_ARG);
+    NBP_RETURN_IF(!depth || !cams12_host || !counts2 || !cloud || !cloud_count || !ws, NBP_E_ARG);
+    NBP_RETURN_IF(n_frames < 1 || n_frames > MAX_CAMS || H < 2 || W < 2 || capacity < 1, NBP_E_ARG);
     NBP_RETURN_IF(!(gathering_factor >= 0.0 && gathering_factor <= 1.0), NBP_E_ARG);
     NBP_RETURN_IF(ws_bytes < nbp_unproject_workspace_bytes(n_frames, H, W), NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;
@@ -402,7 +414,7 @@ extern "C" int nbp_unproject_append_f32(const float* depth, const unsigned char*
                                                  list, counts2);
     rc = nbp_launch_status();
     if (rc) return rc;
-    const Cam* cams = reinterpret_cast<const Cam*>(cams12);   // [F][12]: R row-major (9) then T (3)
+    const CamSet cams = camset_from_host(cams12_host, n_frames);   // [F][12]: R row-major (9) then T (3)
     const int max_keep = (int)((double)H * W * gathering_factor) + 1;
     dim3 grid((unsigned)nbp_cdiv(max_keep, 256), (unsigned)n_frames);
     unproject_append_kernel<<<grid, 256, 0, st>>>(depth, cams, H, W, tan_half_fov, seed, list, counts2, cloud,
@@ -424,11 +436,11 @@ extern "C" size_t nbp_raster_workspace_bytes(int n_faces, int n_frames, int H, i
     return b + 256;
 }
 
-extern "C" int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* faces, int n_faces, const float* cams12,
+extern "C" int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* faces, int n_faces, const float* cams12_host,
                                    int n_frames, int H, int W, float tan_half_fov, float z_clip, int bin_cap, float* zbuf,
                                    int* overflow_flag, void* ws, size_t ws_bytes, void* stream) {
-    NBP_RETURN_IF(!verts || !faces || !cams12 || !zbuf || !overflow_flag || !ws, NBP_E_ARG);
-    NBP_RETURN_IF(n_verts < 3 || n_faces < 1 || n_frames < 1 || H < 1 || W < 1 || bin_cap < 64, NBP_E_ARG);
+    NBP_RETURN_IF(!verts || !faces || !cams12_host || !zbuf || !overflow_flag || !ws, NBP_E_ARG);
+    NBP_RETURN_IF(n_verts < 3 || n_faces < 1 || n_frames < 1 || n_frames > MAX_CAMS || H < 1 || W < 1 || bin_cap < 64, NBP_E_ARG);
     NBP_RETURN_IF(ws_bytes < nbp_raster_workspace_bytes(n_faces, n_frames, H, W, bin_cap), NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;
     const int tiles_x = (int)nbp_cdiv(W, TILE), tiles_y = (int)nbp_cdiv(H, TILE);
@@ -441,7 +453,7 @@ extern "C" int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* f
     hipError_t e = hipMemsetAsync(tile_count, 0, tiles * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
     dim3 g1((unsigned)nbp_cdiv(n_faces, 256), (unsigned)n_frames);
-    raster_setup_kernel<<<g1, 256, 0, st>>>(verts, faces, n_faces, reinterpret_cast<const Cam*>(cams12), H, W,
+    raster_setup_kernel<<<g1, 256, 0, st>>>(verts, faces, n_faces, camset_from_host(cams12_host, n_frames), H, W,
                                             tan_half_fov, z_clip, recs, tbox);
     int rc = nbp_launch_status();
     if (rc) return rc;
@@ -489,6 +501,20 @@ extern "C" int nbp_carve_update_f32(const float* proxy_pts3, int P, const float*
     carve_update_kernel<<<(unsigned)nbp_cdiv(P, 256), 256, 0, (hipStream_t)stream>>>(
         proxy_pts3, P, depth, mask_or_null, cam, H, W, tan_half_fov, zfar, fov_range, tol, score_threshold, n_inside,
         n_behind, occ, out_of_field);
+    return nbp_launch_status();
+}
+
+// dst[offset + i] = pts[i], i < n <= 8: the points ride in the kernel arguments (camera trajectory).
+namespace { struct Pts8 { float p[24]; };
+__global__ void append_points_kernel(float* __restrict__ dst, long long offset, Pts8 pts, int n) {
+    const int i = threadIdx.x;
+    if (i < 3 * n) dst[3 * offset + i] = pts.p[i];
+} }
+extern "C" int nbp_append_points_f32(float* dst, long long offset, const float* pts3_host, int n, void* stream) {
+    NBP_RETURN_IF(!dst || !pts3_host || offset < 0 || n < 1 || n > 8, NBP_E_ARG);
+    Pts8 p;
+    for (int i = 0; i < 24; ++i) p.p[i] = i < 3 * n ? pts3_host[i] : 0.f;
+    append_points_kernel<<<1, 64, 0, (hipStream_t)stream>>>(dst, offset, p, n);
     return nbp_launch_status();
 }
 

@@ -78,6 +78,7 @@ class Camera:
         self._zbuf_ring = None
         self._cursor = 0
         self._traj_dev = torch.zeros(512, 3, dtype=torch.float32, device=device)
+        self._traj_n = 0
         self._overflow = torch.zeros(1, dtype=torch.int32, device=device)
 
     # ------------------------------------------------------------------ lattice
@@ -172,8 +173,7 @@ class Camera:
         slot = self._cursor
         self._cursor += n
         out = ring[slot:slot + n]
-        cams = torch.from_numpy(np.ascontiguousarray(cams_host, f32)).to(self.device)
-        hipops.raster_zbuf(mesh.verts, mesh.faces, cams, self.image_height, self.image_width, bin_cap=mesh.bin_cap,
+        hipops.raster_zbuf(mesh.verts, mesh.faces, cams_host, self.image_height, self.image_width, bin_cap=mesh.bin_cap,
                            out=out, overflow=self._overflow)
         for i in range(n):
             self.frames.append((out[i], cams_host[i].copy()))
@@ -195,16 +195,21 @@ class Camera:
 
     def frames_batch(self, which):
         """Stacks frames by negative offsets (e.g. [-1] = current, [-5,-4,-3,-2] = supervision batch):
-        (depth [n,H,W] device, cams [n,12] device)."""
+        (depth [n,H,W] device, cams [n,12] HOST -- cameras travel as kernel arguments)."""
         sel = [self.frames[w] for w in which]
         z = sel[0][0].unsqueeze(0) if len(sel) == 1 else torch.stack([s[0] for s in sel])
-        cams = torch.from_numpy(np.stack([s[1] for s in sel]).astype(f32)).to(self.device)
-        return z.contiguous(), cams
+        return z.contiguous(), np.stack([s[1] for s in sel]).astype(f32)
 
     def trajectory_points(self):
-        """X_cam_history on the device (for the trajectory channel)."""
+        """X_cam_history on the device (for the trajectory channel); new poses are appended by a kernel whose
+        arguments carry the points, so there is no blocking host->device copy in the step loop."""
         n = len(self.X_cam_history)
         if n > self._traj_dev.shape[0]:
-            self._traj_dev = torch.zeros(2 * n, 3, dtype=torch.float32, device=self.device)
-        self._traj_dev[:n] = torch.from_numpy(self.X_cam_history)
+            grown = torch.zeros(2 * n, 3, dtype=torch.float32, device=self.device)
+            grown[:self._traj_n] = self._traj_dev[:self._traj_n]
+            self._traj_dev = grown
+        while self._traj_n < n:
+            k = min(8, n - self._traj_n)
+            hipops.append_points(self._traj_dev, self._traj_n, self.X_cam_history[self._traj_n:self._traj_n + k])
+            self._traj_n += k
         return self._traj_dev[:n]

@@ -30,22 +30,30 @@ def _workspace(tag, nbytes, device):
     return w
 
 
-def cams12(R, T, device):
-    """[n,3,3], [n,3] (host or device) -> device [n,12] fp32."""
-    R = torch.as_tensor(R, dtype=torch.float32).reshape(-1, 9)
-    T = torch.as_tensor(T, dtype=torch.float32).reshape(-1, 3)
-    return torch.cat([R, T], 1).contiguous().to(device)
+def cams12(R, T, device=None):
+    """[n,3,3], [n,3] -> HOST numpy [n,12] fp32 (R row-major then T); cameras travel as kernel arguments."""
+    import numpy as np
+    R = np.asarray(R, np.float32).reshape(-1, 9)
+    T = np.asarray(T, np.float32).reshape(-1, 3)
+    return np.ascontiguousarray(np.concatenate([R, T], 1))
+
+
+def _cam_arg(cams):
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(cams, np.float32).reshape(-1, 12))
+    return a, a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0]
 
 
 def unproject_append(depth, mask, cams, cloud, cloud_count, gathering_factor=0.05, fov_range=70.0, seed=0,
                      tan_half_fov=TAN_HALF_FOV):
-    """depth [F,H,W] fp32, mask [F,H,W] uint8|None, cams [F,12]; appends to cloud [cap,3] at the
+    """depth [F,H,W] fp32, mask [F,H,W] uint8|None, cams host [F,12]; appends to cloud [cap,3] at the
     device counter cloud_count (int64[1]).  Returns counts [F,2] int32 (device)."""
     F_, H, W = depth.shape
     L = _lib.lib()
+    keep, cam_ptr, _ = _cam_arg(cams)
     counts = torch.empty(F_, 2, dtype=torch.int32, device=depth.device)
     ws = _workspace("unproject", L.nbp_unproject_workspace_bytes(F_, H, W), depth.device)
-    rc = L.nbp_unproject_append_f32(_lib.ptr(depth), _lib.ptr(mask), _lib.ptr(cams), F_, H, W, tan_half_fov,
+    rc = L.nbp_unproject_append_f32(_lib.ptr(depth), _lib.ptr(mask), cam_ptr, F_, H, W, tan_half_fov,
                                     float(fov_range), float(gathering_factor), int(seed) & 0xFFFFFFFF,
                                     _lib.ptr(counts), _lib.ptr(cloud), _lib.ptr(cloud_count), cloud.shape[0],
                                     _lib.ptr(ws), ws.numel(), _st())
@@ -55,15 +63,15 @@ def unproject_append(depth, mask, cams, cloud, cloud_count, gathering_factor=0.0
 
 def raster_zbuf(verts, faces, cams, H, W, bin_cap=2048, tan_half_fov=TAN_HALF_FOV, z_clip=Z_CLIP, out=None,
                 overflow=None):
-    """verts [V,3] fp32, faces [F,3] int32, cams [n,12] -> zbuf [n,H,W] (-1 background)."""
+    """verts [V,3] fp32, faces [F,3] int32, cams host [n,12] -> zbuf [n,H,W] (-1 background)."""
     L = _lib.lib()
-    n = cams.shape[0]
+    keep, cam_ptr, n = _cam_arg(cams)
     if out is None:
         out = torch.empty(n, H, W, dtype=torch.float32, device=verts.device)
     if overflow is None:
         overflow = torch.zeros(1, dtype=torch.int32, device=verts.device)
     ws = _workspace("raster", L.nbp_raster_workspace_bytes(faces.shape[0], n, H, W, bin_cap), verts.device)
-    rc = L.nbp_raster_zbuf_f32(_lib.ptr(verts), verts.shape[0], _lib.ptr(faces), faces.shape[0], _lib.ptr(cams), n, H,
+    rc = L.nbp_raster_zbuf_f32(_lib.ptr(verts), verts.shape[0], _lib.ptr(faces), faces.shape[0], cam_ptr, n, H,
                                W, tan_half_fov, z_clip, bin_cap, _lib.ptr(out), _lib.ptr(overflow), _lib.ptr(ws),
                                ws.numel(), _st())
     _lib.check(rc, "nbp_raster_zbuf_f32")
@@ -152,3 +160,11 @@ def carve_update(proxy_pts, depth, mask, cam12_host, zfar, fov_range, tol, score
                                          _lib.ptr(n_inside), _lib.ptr(n_behind), _lib.ptr(occ), _lib.ptr(out_of_field),
                                          _st())
     _lib.check(rc, "nbp_carve_update_f32")
+
+
+def append_points(dst, offset, pts_host):
+    """dst[offset:offset+n] = pts (n <= 8 host points, passed in the kernel arguments)."""
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(pts_host, np.float32).reshape(-1, 3))
+    rc = _lib.lib().nbp_append_points_f32(_lib.ptr(dst), int(offset), a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0], _st())
+    _lib.check(rc, "nbp_append_points_f32")

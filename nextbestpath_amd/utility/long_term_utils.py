@@ -97,6 +97,11 @@ class LatticePlanner:
             self.nbrs[a].append((b, q))
         self.edges_dev = torch.tensor(edges, dtype=torch.int32, device=device)
 
+    def _staging(self, *tensors):
+        if getattr(self, "_stg", None) is None:
+            self._stg = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+        return self._stg
+
     def _edge_ok(self, blocked_h, collision_list, passable_list):
         """Vectorised edge predicate of generate_Dijkstra_path.get_neighbors (ref :350-360):
         ok = [a,b] in passable_list or (not blocked and [a,b] not in collision_list)."""
@@ -123,10 +128,14 @@ class LatticePlanner:
         o1 = out1.reshape(8, self.V, self.V)
         valid, cell, score = hipops.score_candidates(self.pos_dev, pose, o1, fullproj, skip, self.grid_range)
         blocked = hipops.edges_blocked(obst, pose, self.pos_dev, self.edges_dev, self.grid_range)
-        # one synchronising round of copies for everything the host logic needs
-        valid_h, score_h = valid.cpu().numpy().astype(bool), score.cpu().numpy()
-        blocked_h = blocked.cpu().numpy().astype(bool)
-        out1_h = o1.cpu().numpy()
+        # one synchronising round of copies (pinned staging, one stream sync) for the host logic
+        stg = self._staging(valid, score, blocked, o1)
+        for dst, src in zip(stg, (valid, score, blocked, o1)):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        valid_h, score_h = stg[0].numpy().astype(bool), stg[1].numpy().copy()
+        blocked_h = stg[2].numpy().astype(bool)
+        out1_h = stg[3].numpy().copy()
         cand = np.nonzero(valid_h)[0]
         cand = cand[np.argsort(-score_h[cand], kind="stable")].tolist()      # stable, descending (ref :233)
         start_id = self.node_index[tuple(cam.cam_idx[:3])]
