@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="per-layer timing table to stderr")
     ap.add_argument("--faces", choices=["simple", "hard"], default="simple")
+    ap.add_argument("--rollouts-per-gpu", type=int, default=4,
+                    help="independent rollouts stepped in lock-step per GPU (their NBP forwards are one batched launch)")
     return ap.parse_args()
 
 
@@ -102,53 +104,74 @@ def main():
     S = 256
     params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
     tmp = tempfile.mkdtemp(prefix=f"nbp_bench_r{rank}_")
-    if args.faces == "hard":
-        make_maze_scene(os.path.join(tmp, "maze"), seed=100 + rank, cells=12, size=7.2, height=1.2, tess=0.15)
-    else:
-        make_maze_scene(os.path.join(tmp, "maze"), seed=100 + rank, cells=10, size=6.0, height=1.2, tess=0.25)
-    ds = sc.SceneDataset(tmp)
-    settings = sc.Settings(ds[0]["settings"], params.scene_scale_factor)
-    mesh = sc.load_scene(os.path.join(tmp, "maze", ds[0]["obj_name"]), params.scene_scale_factor, dev)
-    y_bins = sc.y_bins_for(mesh.verts_host, 4)
-    gt = torch.from_numpy(sc.sample_gt_surface(mesh.verts_host, mesh.faces_host, params.n_gt_surface_points,
-                                               settings.scene.x_min - np.float32(0.2),
-                                               settings.scene.x_max + np.float32(0.2), 0.5, seed=rank)).to(dev)
+    R = max(1, args.rollouts_per_gpu)
     sd = make_explorer_state_dict(9)     # silent obstacle head: the observed walls do the blocking
     net = NBP()
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()
-    cam = tp.setup_test_camera(params, mesh, settings.camera.start_positions[0], settings, dev, seed=rank)
-    ro = tp.Rollout(params, net, cam, gt, mesh, mesh, y_bins, dev, seed=8 + rank)
+
+    def make_rollout(k):
+        name = f"maze{k}"
+        if args.faces == "hard":
+            make_maze_scene(os.path.join(tmp, name), seed=100 + 16 * rank + k, cells=12, size=7.2, height=1.2, tess=0.15)
+        else:
+            make_maze_scene(os.path.join(tmp, name), seed=100 + 16 * rank + k, cells=10, size=6.0, height=1.2, tess=0.25)
+        ds = sc.SceneDataset(tmp, [name])
+        settings = sc.Settings(ds[0]["settings"], params.scene_scale_factor)
+        mesh = sc.load_scene(os.path.join(tmp, name, ds[0]["obj_name"]), params.scene_scale_factor, dev)
+        y_bins = sc.y_bins_for(mesh.verts_host, 4)
+        gt = torch.from_numpy(sc.sample_gt_surface(mesh.verts_host, mesh.faces_host, params.n_gt_surface_points,
+                                                   settings.scene.x_min - np.float32(0.2),
+                                                   settings.scene.x_max + np.float32(0.2), 0.5, seed=rank)).to(dev)
+        cam = tp.setup_test_camera(params, mesh, settings.camera.start_positions[0], settings, dev, seed=rank)
+        return tp.Rollout(params, net, cam, gt, mesh, mesh, y_bins, dev, seed=8 + 16 * rank + k)
+
+    # ---- single-rollout rate (B = 1 forward, latency-style) on a short separate run, reported beside `value`
+    single = None
+    if rank == 0:
+        r1 = make_rollout(15)
+        for _ in range(5):
+            r1.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            r1.step()
+        torch.cuda.synchronize()
+        single = 20 / (time.perf_counter() - t0)
+        del r1
+    rollouts = [make_rollout(k) for k in range(R)]
+    multi = tp.MultiRollout(rollouts, net, dev)
+    ro, cam, mesh, y_bins, gt = rollouts[0], rollouts[0].camera, rollouts[0].mesh, rollouts[0].y_bins, rollouts[0].gt
 
     for _ in range(args.warmup):
-        ro.step()
+        multi.step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    replans0 = ro.n_replans
+    replans0 = sum(r.n_replans for r in rollouts)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ro.step()
+        multi.step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
 
     roofline = scatter = None
     stage = {}
     if rank == 0:
         # ---- the dominant kernel, per launch, with HIP events on the launch stream
-        x = ro.st.net_in
+        x = multi.net_in
         packed = net._ensure_packed(dev)
-        o1 = torch.empty(1, 8, S // 4, S // 4, device=dev)
-        o2 = torch.empty(1, 1, S, S, device=dev)
-        ws = packing._workspace(1, S, dev)
+        o1 = torch.empty(R, 8, S // 4, S // 4, device=dev)
+        o2 = torch.empty(R, 1, S, S, device=dev)
+        ws = packing._workspace(R, S, dev)
         reps, acc = 5, {}
         for r in range(reps + 1):
             rows = timed_layers(packed, x, o1, o2, ws)
@@ -182,8 +205,12 @@ def main():
         n_pts = int(ro.st.cloud_count.item())
         pose, _ = cam.get_pose_from_idx(cam.cam_idx)
         ms_fwd = ev_time(lambda: net(x))
-        fl = L.nbp_forward_flops(1, S)
-        stage["nbp_forward"] = {"ms": round(ms_fwd, 4), "maps_per_s": round(1e3 / ms_fwd, 2),
+        fl = L.nbp_forward_flops(R, S)
+        x1 = x[:1].contiguous()
+        ms_fwd1 = ev_time(lambda: net(x1))
+        stage["nbp_forward_b1"] = {"ms": round(ms_fwd1, 4), "maps_per_s": round(1e3 / ms_fwd1, 2),
+                                   "tflops": round(L.nbp_forward_flops(1, S) / (ms_fwd1 * 1e-3) / 1e12, 3)}
+        stage["nbp_forward"] = {"ms": round(ms_fwd, 4), "batch": R, "maps_per_s": round(R * 1e3 / ms_fwd, 2),
                                 "tflops": round(fl / (ms_fwd * 1e-3) / 1e12, 3),
                                 "frac_of_f32_mfma_peak": round(fl / (ms_fwd * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
         ms_sc = ev_time(lambda: hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=ro.st.cloud_count,
@@ -211,7 +238,8 @@ def main():
                                                                                 n=ro.st.cloud.shape[0], bbox=bbox,
                                                                                 out=out)), 4),
                              "gt_points": int(gt.shape[0])}
-        stage["replans_in_timed_region"] = ro.n_replans - replans0
+        stage["replans_in_timed_region"] = sum(r.n_replans for r in rollouts) - replans0
+        stage["single_rollout_steps_per_s"] = round(single, 2)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -219,7 +247,7 @@ def main():
         from oracle import nbp_net
         from oracle import planner as opl
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        xc = ro.st.net_in.cpu()
+        xc = multi.net_in[:1].cpu()
         best = None
         with torch.no_grad():
             for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
@@ -257,14 +285,16 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "exploration steps/s (+ NBP maps/s) at 256x256", "value": round(args.steps * world / dt, 3),
+            "metric": "exploration steps/s (+ NBP maps/s) at 256x256", "value": round(args.steps * world * R / dt, 3),
             "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "note": f"ms_per_step is one lock-step step of {R} concurrent rollouts per GPU ({R} exploration steps)",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: AiMDoom_simple-like rollout (seeded procedural maze, "
-                                   f"{int(mesh.faces.shape[0])} faces), 256x256 grid, 1 rollout per GPU, 5 depth frames "
-                                   "of 256x456 per step, seeded synthetic NBP weights",
-                       "grid": S, "rollouts_per_gpu": 1, "image": [params.image_height, params.image_width]},
+                                   f"{int(mesh.faces.shape[0])} faces), 256x256 grid, {R} concurrent rollouts per GPU on "
+                                   f"{R} scenes (NBP forwards batched), 5 depth frames of 256x456 per step per "
+                                   "rollout, seeded synthetic NBP weights",
+                       "grid": S, "rollouts_per_gpu": R, "image": [params.image_height, params.image_width]},
             "nbp_maps_per_s": round(world * stage["nbp_forward"]["maps_per_s"], 2),
             "stages": stage, "roofline": roofline, "roofline_scatter": scatter, "cpu_baseline": cpu,
         }

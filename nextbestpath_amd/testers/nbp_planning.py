@@ -28,7 +28,7 @@ from ..simulator import scene as sim_scene
 from ..simulator.camera import Camera
 from ..utility import hipops
 from ..utility import utils as hu
-from ..utility.long_term_utils import LatticePlanner, compute_auc, line_segment_mesh_intersection
+from ..utility.long_term_utils import LatticePlanner, compute_auc
 
 N_POSES = 101            # range(101) at nbp_planning.py:60
 
@@ -85,45 +85,51 @@ class Rollout:
         self.pose_i = 0
         self.n_replans = 0
 
-    def step(self):
+    # The step is split in enqueue-only halves so that MultiRollout can batch the NBP forward of several
+    # rollouts and share one stream synchronisation per step; step() is the single-rollout composition.
+    def pre(self, net_in=None):
+        """S2-S8: coverage, un-projection of the current frame, maps, replan decision.  No host sync."""
         st, camera, params, pose_i = self.st, self.camera, self.params, self.pose_i
         S, grid_range = self.S, self.grid_range
-        # S2: coverage of the cloud built so far (device counter; read back after the loop)
+        net_in = st.net_in if net_in is None else net_in
         hipops.coverage_count(self.gt, st.cloud, n_dev=st.cloud_count, n=st.cloud.shape[0], weight=2,
                               seed=self.step_seed + 7 * pose_i, threshold=1.0, bbox=self.bbox,
                               out=st.coverage_counts[pose_i % N_POSES])
-        # S4: un-project the current frame, append to the cloud
         depth, cams = camera.frames_batch([-1])
         hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
                                 params.sensor_range, seed=self.step_seed + 11 * pose_i)
-        pose, _ = camera.get_pose_from_idx(camera.cam_idx)
-        # S6-S7: NBP input = 4 height slabs + trajectory (one fused pass over the cloud)
-        hu.accumulate_step_maps(st.cloud, pose, self.y_bins, S, grid_range, n_dev=st.cloud_count, out=st.maps6)
-        traj2d = hu.transform_points_to_n_pieces(camera.trajectory_points(), pose)
-        traj_img = hu.map_points_to_n_imgs(traj2d, (S, S), grid_range)
-        st.net_in[0, :4] = st.maps6[:4]
-        st.net_in[0, 4] = traj_img[0]
-        # S8: replan?
+        self.pose, _ = camera.get_pose_from_idx(camera.cam_idx)
+        hu.accumulate_step_maps(st.cloud, self.pose, self.y_bins, S, grid_range, n_dev=st.cloud_count, out=st.maps6)
+        traj2d = hu.transform_points_to_n_pieces(camera.trajectory_points(), self.pose)
+        self.traj_img = hu.map_points_to_n_imgs(traj2d, (S, S), grid_range)
+        net_in[0, :4] = st.maps6[:4]
+        net_in[0, 4] = self.traj_img[0]
         path = self.path
         if pose_i == 0 or not path or self.path_record + 1 > len(path):
-            replan = True
+            self.need_replan = True
         else:
-            nxt = camera.pose_from_idx(path[self.path_record])
-            replan = line_segment_mesh_intersection(pose[:3], nxt[:3], self.mesh_for_check)
-            if replan:
-                cur3, nxt3 = list(camera.cam_idx[:3]), list(path[self.path_record][:3])
+            nxt = path[self.path_record]
+            self.need_replan = self.planner.edge_hits_mesh(camera.cam_idx[:3], nxt[:3])
+            if self.need_replan:
+                cur3, nxt3 = list(camera.cam_idx[:3]), list(nxt[:3])
                 self.collision_list += [[cur3, nxt3], [nxt3, cur3], list(path[-1][:3])]
         if len(self.idx_history) >= 2:
             p1, p2 = list(self.idx_history[-1][:3]), list(self.idx_history[-2][:3])
             self.passable_list += [[p1, p2], [p2, p1]]
-        # S9: one NBP forward per step (the reference also runs it when it does not replan, :252)
-        with torch.no_grad():
-            out1, out2 = self.nbp(st.net_in)
-        if replan:
+
+    def plan_enqueue(self, out1, out2):
+        if self.need_replan:
             self.n_replans += 1
             self.path_record = 0
-            path = self.planner.replan(pose, out1, out2, st.maps6, traj_img, self.collision_list, self.passable_list)
-        # S10: next pose
+            self.planner.replan_enqueue(self.pose, out1, out2, self.st.maps6, self.traj_img, self.collision_list)
+
+    def plan_finish(self):
+        if self.need_replan:
+            self.path = self.planner.replan_finish(self.collision_list, self.passable_list)
+
+    def post(self):
+        """S10-S14: next pose, move (4 poses, one raster launch), un-project the supervision frames."""
+        st, camera, params, pose_i, path = self.st, self.camera, self.params, self.pose_i, self.path
         if not path or self.path_record >= len(path):
             next_idx = list(camera.cam_idx)
             next_idx[4] = self.rng.randrange(8)
@@ -134,7 +140,6 @@ class Rollout:
                 next_idx[4] = self.rng.randrange(8)
         self.path = path
         self.idx_history.append(tuple(camera.cam_idx))
-        # S11: move (4 interpolated poses, one raster launch); S14: un-project the supervision frames
         camera.move_and_capture(self.mesh, next_idx)
         depth, cams = camera.frames_batch([-5, -4, -3, -2])
         hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
@@ -142,10 +147,45 @@ class Rollout:
         self.path_record += 1
         self.pose_i += 1
 
+    def step(self):
+        self.pre()
+        with torch.no_grad():          # S9: one NBP forward per step (the reference also runs it without replanning, :252)
+            out1, out2 = self.nbp(self.st.net_in)
+        self.plan_enqueue(out1, out2)
+        if self.need_replan:
+            torch.cuda.current_stream().synchronize()
+        self.plan_finish()
+        self.post()
+
     def coverage_evolution(self, n):
         counts = self.st.coverage_counts[:n].cpu().numpy()
         G = np.float32(len(self.gt))
         return [float(np.float32(c) / G) for c in counts[:, 0]]
+
+
+class MultiRollout:
+    """R independent rollouts (different scenes / start poses) stepped in lock-step on one GPU: their NBP
+    forwards are ONE batched launch sequence (B = R in the GEMM M dimension) and all replanning rollouts
+    share ONE stream synchronisation per step ("B_rollout concurrent rollouts per rank")."""
+
+    def __init__(self, rollouts, nbp, device, grid=256):
+        self.rollouts, self.nbp = rollouts, nbp
+        self.net_in = torch.zeros(len(rollouts), 5, grid, grid, dtype=torch.float32, device=device)
+
+    def step(self):
+        for i, r in enumerate(self.rollouts):
+            r.pre(self.net_in[i:i + 1])
+        with torch.no_grad():
+            out1, out2 = self.nbp(self.net_in)
+        need = [(i, r) for i, r in enumerate(self.rollouts) if r.need_replan]
+        for i, r in need:
+            r.plan_enqueue(out1[i], out2[i])
+        if need:
+            torch.cuda.current_stream().synchronize()
+        for _, r in need:
+            r.plan_finish()
+        for r in self.rollouts:
+            r.post()
 
 
 def compute_nbp_trajectory(params, nbp, camera, gt_scene_pc, mesh, mesh_for_check, n_pieces, y_bins, device,

@@ -96,6 +96,8 @@ class LatticePlanner:
         for q, (a, b) in enumerate(edges):
             self.nbrs[a].append((b, q))
         self.edges_dev = torch.tensor(edges, dtype=torch.int32, device=device)
+        segs = np.concatenate([self.xyz[[a for a, _ in edges]], self.xyz[[b for _, b in edges]]], 1).astype(np.float32)
+        self.mesh_hit = hipops.segments_hit_mesh(mesh.verts, mesh.faces, torch.from_numpy(segs).to(device)).cpu().numpy()
 
     def _staging(self, *tensors):
         if getattr(self, "_stg", None) is None:
@@ -116,23 +118,29 @@ class LatticePlanner:
                 ok[q] = True
         return ok
 
-    def replan(self, pose, out1, out2, maps6, traj_img, collision_list, passable_list, check_first_edge=True):
-        """Returns the path as a list of [i,j,k,2,h] (first node dropped, like ref :416) or None."""
-        cam = self.camera
+    # ---- replanning in two halves so that several rollouts can share ONE stream synchronisation
+    def replan_enqueue(self, pose, out1, out2, maps6, traj_img, collision_list):
+        """Launches obstacle fusion, candidate scoring and the all-edges mask, then starts the pinned
+        device->host copies.  Nothing here blocks the host."""
         obst, fullproj = hipops.fuse_obstacle(out2.reshape(self.S, self.S), maps6, traj_img.reshape(self.S, self.S))
         coll_pos = {tuple(e) for e in collision_list if len(e) == 3}
         skip = None
         if coll_pos:
             skip_h = np.fromiter((tuple(t) in coll_pos for t in self.idx3.tolist()), dtype=np.uint8, count=len(self.idx3))
-            skip = torch.from_numpy(skip_h).to(self.device)
+            self._skip_pin = torch.from_numpy(skip_h).pin_memory()
+            skip = self._skip_pin.to(self.device, non_blocking=True)
         o1 = out1.reshape(8, self.V, self.V)
         valid, cell, score = hipops.score_candidates(self.pos_dev, pose, o1, fullproj, skip, self.grid_range)
         blocked = hipops.edges_blocked(obst, pose, self.pos_dev, self.edges_dev, self.grid_range)
-        # one synchronising round of copies (pinned staging, one stream sync) for the host logic
         stg = self._staging(valid, score, blocked, o1)
         for dst, src in zip(stg, (valid, score, blocked, o1)):
             dst.copy_(src, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        self._pending = (pose, stg)
+
+    def replan_finish(self, collision_list, passable_list, check_first_edge=True):
+        """Host half (after a stream synchronisation): stable sort, search, heading choice, first-edge test."""
+        cam = self.camera
+        pose, stg = self._pending
         valid_h, score_h = stg[0].numpy().astype(bool), stg[1].numpy().copy()
         blocked_h = stg[2].numpy().astype(bool)
         out1_h = stg[3].numpy().copy()
@@ -159,11 +167,23 @@ class LatticePlanner:
                                                 self.grid_range)
             path = full[1:]
             if len(path) > 0:
-                if not check_first_edge:
-                    break
-                nxt = cam.pose_from_idx(path[0])
-                if not line_segment_mesh_intersection(pose[:3], nxt[:3], self.mesh):
+                if not check_first_edge or not self.edge_hits_mesh(cam.cam_idx[:3], path[0][:3]):
                     break
                 collision_list.append([list(cam.cam_idx[:3]), path[0][:3]])
                 collision_list.append([path[0][:3], list(cam.cam_idx[:3])])
         return path
+
+    def edge_hits_mesh(self, a, b):
+        """line_segment_mesh_intersection (macarons_utils.py:120-151) between two ADJACENT lattice positions:
+        the mesh is static, so the predicate is tabulated once per scene for every lattice edge (one launch)
+        instead of one GPU query + sync per step (nbp_planning.py:142,245)."""
+        a, b = tuple(int(v) for v in a), tuple(int(v) for v in b)
+        if a == b:
+            return False                                   # zero-length segment (turn in place)
+        return bool(self.mesh_hit[self.edge_id[(self.node_index[a], self.node_index[b])]])
+
+    def replan(self, pose, out1, out2, maps6, traj_img, collision_list, passable_list, check_first_edge=True):
+        """Returns the path as a list of [i,j,k,2,h] (first node dropped, like ref :416) or None."""
+        self.replan_enqueue(pose, out1, out2, maps6, traj_img, collision_list)
+        torch.cuda.current_stream().synchronize()
+        return self.replan_finish(collision_list, passable_list, check_first_edge)

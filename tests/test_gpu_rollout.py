@@ -71,3 +71,37 @@ def test_entry_point_json_schema(hip, dataset, tmp_path):
         assert set(rec) >= {"coverage", "X_cam_history", "V_cam_history"} and len(rec["coverage"]) == 3
     finally:
         os.remove(cfg_path)
+
+
+def test_multi_rollout_matches_single(hip, dataset, nbp_weights):
+    """Lock-step batched rollouts (B = 2 forward, shared sync) walk the same trajectories as separate runs."""
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.testers import nbp_planning as tp
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    ds = sc.SceneDataset(dataset)
+    net = _net(nbp_weights)
+    dev = torch.device("cuda")
+
+    def build(si, seed):
+        sd = ds[si]
+        settings = sc.Settings(sd["settings"], params.scene_scale_factor)
+        mesh = sc.load_scene(os.path.join(ds.data_path, sd["scene_name"], sd["obj_name"]), params.scene_scale_factor, dev)
+        gt = torch.from_numpy(sc.sample_gt_surface(mesh.verts_host, mesh.faces_host, 20000, settings.scene.x_min - 0.2,
+                                                   settings.scene.x_max + 0.2, 0.5, seed=1)).to(dev)
+        cam = tp.setup_test_camera(params, mesh, settings.camera.start_positions[0], settings, dev, seed=seed)
+        return tp.Rollout(params, net, cam, gt, mesh, mesh, sc.y_bins_for(mesh.verts_host, 4), dev, seed=seed)
+
+    n = 10
+    singles = [build(0, 3), build(1, 4)]
+    for r in singles:
+        for _ in range(n):
+            r.step()
+    multi_r = [build(0, 3), build(1, 4)]
+    m = tp.MultiRollout(multi_r, net, dev)
+    for _ in range(n):
+        m.step()
+    for a, b in zip(singles, multi_r):
+        assert a.camera.cam_idx_history == b.camera.cam_idx_history          # same goals, same paths, same headings
+        assert np.array_equal(a.camera.X_cam_history, b.camera.X_cam_history)
+        ca, cb = a.coverage_evolution(n), b.coverage_evolution(n)
+        assert ca == cb
