@@ -145,6 +145,7 @@ def main():
 
     for _ in range(args.warmup):
         multi.step()
+    multi.flush()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -153,6 +154,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         multi.step()
+    multi.flush()                      # every rollout has completed exactly `steps` exploration steps
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -167,7 +169,7 @@ def main():
     stage = {}
     if rank == 0:
         # ---- the dominant kernel, per launch, with HIP events on the launch stream
-        x = multi.net_in
+        x = torch.cat(multi.net_in)
         packed = net._ensure_packed(dev)
         o1 = torch.empty(R, 8, S // 4, S // 4, device=dev)
         o2 = torch.empty(R, 1, S, S, device=dev)
@@ -247,7 +249,7 @@ def main():
         from oracle import nbp_net
         from oracle import planner as opl
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        xc = multi.net_in[:1].cpu()
+        xc = multi.net_in[0][:1].cpu()
         best = None
         with torch.no_grad():
             for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):

@@ -164,28 +164,58 @@ class Rollout:
 
 
 class MultiRollout:
-    """R independent rollouts (different scenes / start poses) stepped in lock-step on one GPU: their NBP
-    forwards are ONE batched launch sequence (B = R in the GEMM M dimension) and all replanning rollouts
-    share ONE stream synchronisation per step ("B_rollout concurrent rollouts per rank")."""
+    """R independent rollouts (different scenes / start poses) on one GPU ("B_rollout
+    concurrent rollouts per rank").  They are split in two groups that are software-pipelined: while the GPU
+    runs one group's batched NBP forward (B = R/2 in the GEMM M dimension) the host finishes the other
+    group's replanning (event wait + search) and enqueues its move / raster / un-projection, so neither
+    side idles.  Each rollout's results are identical to running it alone (tests/test_gpu_rollout.py)."""
 
     def __init__(self, rollouts, nbp, device, grid=256):
-        self.rollouts, self.nbp = rollouts, nbp
-        self.net_in = torch.zeros(len(rollouts), 5, grid, grid, dtype=torch.float32, device=device)
+        self.rollouts, self.nbp = list(rollouts), nbp
+        R = len(self.rollouts)
+        half = (R + 1) // 2
+        self.groups = [g for g in (self.rollouts[:half], self.rollouts[half:]) if g]
+        self.net_in = [torch.zeros(len(g), 5, grid, grid, dtype=torch.float32, device=device) for g in self.groups]
+        self.events = [torch.cuda.Event() for _ in self.groups]
+        self.inflight = [False] * len(self.groups)
+
+    def _launch(self, gi):
+        grp, net_in = self.groups[gi], self.net_in[gi]
+        for i, r in enumerate(grp):
+            r.pre(net_in[i:i + 1])
+        with torch.no_grad():
+            out1, out2 = self.nbp(net_in)
+        for i, r in enumerate(grp):
+            r.plan_enqueue(out1[i], out2[i])
+        self.events[gi].record()
+        self.inflight[gi] = True
+
+    def _complete(self, gi):
+        grp = self.groups[gi]
+        if any(r.need_replan for r in grp):
+            self.events[gi].synchronize()          # the GPU keeps running whatever was queued after the event
+        for r in grp:
+            r.plan_finish()
+        for r in grp:
+            r.post()
+        self.inflight[gi] = False
 
     def step(self):
-        for i, r in enumerate(self.rollouts):
-            r.pre(self.net_in[i:i + 1])
-        with torch.no_grad():
-            out1, out2 = self.nbp(self.net_in)
-        need = [(i, r) for i, r in enumerate(self.rollouts) if r.need_replan]
-        for i, r in need:
-            r.plan_enqueue(out1[i], out2[i])
-        if need:
-            torch.cuda.current_stream().synchronize()
-        for _, r in need:
-            r.plan_finish()
-        for r in self.rollouts:
-            r.post()
+        """One exploration step of every rollout (the last group's completion is deferred to the next call)."""
+        for gi in range(len(self.groups)):
+            if self.inflight[gi]:
+                self._complete(gi)
+            self._launch(gi)
+            other = 1 - gi
+            if len(self.groups) == 2 and self.inflight[other] and other != gi:
+                self._complete(other)
+        if len(self.groups) == 1:
+            self._complete(0)
+
+    def flush(self):
+        for gi in range(len(self.groups)):
+            if self.inflight[gi]:
+                self._complete(gi)
 
 
 def compute_nbp_trajectory(params, nbp, camera, gt_scene_pc, mesh, mesh_for_check, n_pieces, y_bins, device,

@@ -100,6 +100,7 @@ def test_multi_rollout_matches_single(hip, dataset, nbp_weights):
     m = tp.MultiRollout(multi_r, net, dev)
     for _ in range(n):
         m.step()
+    m.flush()
     for a, b in zip(singles, multi_r):
         assert a.camera.cam_idx_history == b.camera.cam_idx_history          # same goals, same paths, same headings
         assert np.array_equal(a.camera.X_cam_history, b.camera.X_cam_history)
