@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="per-layer timing table to stderr")
     ap.add_argument("--faces", choices=["simple", "hard"], default="simple")
-    ap.add_argument("--rollouts-per-gpu", type=int, default=4,
+    ap.add_argument("--rollouts-per-gpu", type=int, default=8,
                     help="independent rollouts stepped in lock-step per GPU (their NBP forwards are one batched launch)")
     return ap.parse_args()
 
