@@ -68,11 +68,13 @@ def setup_test_camera(params, mesh, start_cam_idx, settings, device, seed=0):
 class Rollout:
     """One exploration rollout, steppable (bench.py times K consecutive ``step()`` calls)."""
 
-    def __init__(self, params, nbp, camera, gt_scene_pc, mesh, mesh_for_check, y_bins, device, state=None, seed=0):
+    def __init__(self, params, nbp, camera, gt_scene_pc, mesh, mesh_for_check, y_bins, device, state=None, seed=0,
+                 grid=256):
         self.params, self.nbp, self.camera, self.mesh, self.mesh_for_check = params, nbp, camera, mesh, mesh_for_check
         self.y_bins, self.device = y_bins, device
-        self.S, self.V, self.grid_range = 256, 64, (-40, 40)
-        self.st = state or RolloutState(device)
+        # the reference hard-codes 256 / 64 / +-40 (nbp_planning.py:43-45); other grids keep 0.3125 units per pixel
+        self.S, self.V, self.grid_range = grid, grid // 4, (-40 * grid // 256, 40 * grid // 256)
+        self.st = state or RolloutState(device, grid=grid)
         self.st.cloud_count.zero_()
         self.st.coverage_counts.zero_()
         self.planner = LatticePlanner(camera, mesh_for_check, device, self.V, self.S, self.grid_range)
@@ -170,8 +172,9 @@ class MultiRollout:
     group's replanning (event wait + search) and enqueues its move / raster / un-projection, so neither
     side idles.  Each rollout's results are identical to running it alone (tests/test_gpu_rollout.py)."""
 
-    def __init__(self, rollouts, nbp, device, grid=256):
+    def __init__(self, rollouts, nbp, device, grid=None):
         self.rollouts, self.nbp = list(rollouts), nbp
+        grid = grid or self.rollouts[0].S
         R = len(self.rollouts)
         half = (R + 1) // 2
         self.groups = [g for g in (self.rollouts[:half], self.rollouts[half:]) if g]
@@ -265,7 +268,8 @@ def list_runs(dataset, params):
     return runs
 
 
-def run_one(params, nbp, dataset, run, device, test_resolution=0.05, state=None, n_poses=N_POSES, seed=0):
+def build_rollout(params, nbp, dataset, run, device, test_resolution=0.05, state=None, seed=0, grid=256):
+    """Scene + GT surface + camera + Rollout for one (scene, start pose) run (nbp_planning.py:414-492)."""
     si, k = run
     sd = dataset[si]
     settings = sim_scene.Settings(sd["settings"], params.scene_scale_factor)
@@ -277,15 +281,46 @@ def run_one(params, nbp, dataset, run, device, test_resolution=0.05, state=None,
                                      test_resolution * params.scene_scale_factor, seed=seed)
     gt_dev = torch.from_numpy(gt).to(device)
     camera = setup_test_camera(params, mesh, settings.camera.start_positions[k], settings, device, seed=seed)
-    cov, X, Vh, pc, _ = compute_nbp_trajectory(params, nbp, camera, gt_dev, mesh, mesh, 4, y_bins, device,
-                                               test_resolution, True, n_poses=n_poses, state=state, seed=seed)
-    return {"scene": sd["scene_name"], "start": k, "coverage": cov, "X_cam_history": X.tolist(),
-            "V_cam_history": Vh.tolist(), "n_points": int(pc.shape[0])}
+    ro = Rollout(params, nbp, camera, gt_dev, mesh, mesh, y_bins, device, state, seed, grid)
+    ro.scene_name, ro.start = sd["scene_name"], k
+    return ro
+
+
+def _result(ro, n_poses):
+    return {"scene": ro.scene_name, "start": ro.start, "coverage": ro.coverage_evolution(n_poses),
+            "X_cam_history": ro.camera.X_cam_history.tolist(), "V_cam_history": ro.camera.V_cam_history.tolist(),
+            "n_points": int(ro.st.cloud_count.item())}
+
+
+def run_one(params, nbp, dataset, run, device, test_resolution=0.05, state=None, n_poses=N_POSES, seed=0):
+    ro = build_rollout(params, nbp, dataset, run, device, test_resolution, state, seed)
+    nbp.eval()
+    for _ in range(n_poses):
+        ro.step()
+    return _result(ro, n_poses)
+
+
+def run_many(params, nbp, dataset, runs, device, seeds, test_resolution=0.05, n_poses=N_POSES, rollouts_per_gpu=8):
+    """Runs `runs` in lock-step groups of `rollouts_per_gpu` (MultiRollout); same results as run_one each."""
+    out = []
+    nbp.eval()
+    for g0 in range(0, len(runs), rollouts_per_gpu):
+        chunk = list(zip(runs[g0:g0 + rollouts_per_gpu], seeds[g0:g0 + rollouts_per_gpu]))
+        ros = [build_rollout(params, nbp, dataset, run, device, test_resolution, None, seed) for run, seed in chunk]
+        multi = MultiRollout(ros, nbp, device)
+        for _ in range(n_poses):
+            multi.step()
+        multi.flush()
+        out += [_result(ro, n_poses) for ro in ros]
+        del ros, multi
+        torch.cuda.empty_cache()
+    return out
 
 
 def test_nbp_planning(params_file, model_file, results_json_file, numGPU, test_scenes, test_resolution=0.05,
                       use_perfect_depth_map=False, compute_collision=False, load_json=False, dataset_path=None,
-                      nbp_weights=None, configs_dir=None, results_dir=None, n_poses=N_POSES, seed=8, torch_seed=9):
+                      nbp_weights=None, configs_dir=None, results_dir=None, n_poses=N_POSES, seed=8, torch_seed=9,
+                      rollouts_per_gpu=8):
     """Same arguments as the reference (nbp_planning.py:364-374).  Under torchrun the flattened
     (scene, start pose) runs are sharded round-robin over the ranks and the coverage curves are
     gathered with ONE all_gather over RCCL (backend "nccl" on ROCm; "gloo" on CPU-only hosts)."""
@@ -304,21 +339,18 @@ def test_nbp_planning(params_file, model_file, results_json_file, numGPU, test_s
         ck = torch.load(nbp_weights, map_location="cpu")
         nbp.load_state_dict(ck["model_state_dict"])
     else:
-        from ..utility.synthetic import make_nbp_state_dict
+        from ..utility.synthetic import make_explorer_state_dict
         print("[nbp] no checkpoint at", nbp_weights, "-> seeded synthetic weights")
-        nbp.load_state_dict(make_nbp_state_dict(torch_seed))
+        nbp.load_state_dict(make_explorer_state_dict(torch_seed))
     nbp.to(device).eval()
     dataset = sim_scene.SceneDataset(dataset_path, test_scenes)
     runs = list_runs(dataset, params)
     mine = shard(runs, rank, world)
-    state = RolloutState(device)
-    results = []
     with torch.no_grad():
-        for run in mine:
-            res = run_one(params, nbp, dataset, run, device, test_resolution, state, n_poses,
-                          seed=seed + 1000 * run[0] + run[1])
-            res["run_id"] = runs.index(run)
-            results.append(res)
+        results = run_many(params, nbp, dataset, mine, device, [seed + 1000 * r[0] + r[1] for r in mine],
+                           test_resolution, n_poses, rollouts_per_gpu)
+    for run, res in zip(mine, results):
+        res["run_id"] = runs.index(run)
     gathered = gather_results(results, runs, rank, world, device, n_poses)
     if rank == 0:
         out = {}

@@ -106,3 +106,20 @@ def test_multi_rollout_matches_single(hip, dataset, nbp_weights):
         assert np.array_equal(a.camera.X_cam_history, b.camera.X_cam_history)
         ca, cb = a.coverage_evolution(n), b.coverage_evolution(n)
         assert ca == cb
+
+
+def test_rollout_on_512_grid(hip, dataset, nbp_weights):
+    """BASELINE configs[4] geometry: 512x512 grid, +-80 window (same 0.3125 units / pixel), value map 128x128."""
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.testers import nbp_planning as tp
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    ds = sc.SceneDataset(dataset)
+    net = _net(nbp_weights)
+    ro = tp.build_rollout(params, net, ds, (0, 0), torch.device("cuda"), seed=2, grid=512)
+    for _ in range(4):
+        ro.step()
+    assert ro.st.maps6.shape == (6, 512, 512) and ro.S == 512 and ro.V == 128 and ro.grid_range == (-80, 80)
+    cov = ro.coverage_evolution(4)
+    assert cov[0] == 0.0 and cov[-1] > 0.0
+    # the 256-grid map is the centre crop of the 512-grid map's geometry: same points, same pitch
+    assert float(ro.st.maps6[:5].sum()) > 0
