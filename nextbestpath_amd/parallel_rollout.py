@@ -24,12 +24,23 @@ def init_distributed():
         if not dist.is_initialized():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if torch.cuda.is_available():
+            backend = os.environ.get("NBP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            if backend == "nccl":
                 torch.cuda.set_device(local_rank)
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            else:
+            else:       # gloo: CPU-only hosts, or several ranks sharing one GPU (NBP_DIST_BACKEND=gloo) in tests
                 dist.init_process_group("gloo")
+    if torch.cuda.is_available():
+        local_rank = local_rank % torch.cuda.device_count()
     return rank, world, local_rank
+
+
+def collective_device(device):
+    """Tensors of the gather live on the GPU for RCCL and on the host for gloo."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return device
 
 
 def shard(runs, rank, world):
@@ -57,7 +68,7 @@ def gather_results(results, runs, rank, world, device, n_poses):
     """All ranks call this; every rank gets the list of {run_id, coverage, final, auc, scene, start}
     in run order (only the coverage metrics travel; pose histories stay in the per-rank results)."""
     rows = runs_per_rank(len(runs), world)
-    local = torch.from_numpy(pack_results(results, runs, n_poses, rows)).to(device)
+    local = torch.from_numpy(pack_results(results, runs, n_poses, rows)).to(collective_device(device) if world > 1 else device)
     if world > 1:
         import torch.distributed as dist
         buf = [torch.empty_like(local) for _ in range(world)]

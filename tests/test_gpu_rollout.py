@@ -123,3 +123,35 @@ def test_rollout_on_512_grid(hip, dataset, nbp_weights):
     assert cov[0] == 0.0 and cov[-1] > 0.0
     # the 256-grid map is the centre crop of the 512-grid map's geometry: same points, same pitch
     assert float(ro.st.maps6[:5].sum()) > 0
+
+
+def test_scene_parallel_entry_point_two_ranks(hip, dataset):
+    """torchrun with 2 ranks (sharing this box's single GPU, gloo for the one all_gather): each rank runs its
+    shard of the (scene, start) runs; rank 0 writes the merged coverage JSON == the single-process result."""
+    cfg = {"numGPU": 0, "dataset_path": dataset, "test_scenes": [], "params_name":
+           "macarons_default_training_config.json", "model_name": "x.pth", "results_json_name": "out_test_2rank.json",
+           "test_resolution": 0.05, "use_perfect_depth_map": True, "compute_collision": False, "load_json": False,
+           "random_seed": 8, "torch_seed": 9, "nbp_weights": "./weights/none.pth"}
+    cfg_path = os.path.join(ROOT, "configs/test/_pytest_2rank.json")
+    with open(cfg_path, "w") as fh:
+        json.dump(cfg, fh)
+    env = dict(os.environ, NBP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29611",
+                            os.path.join(ROOT, "test_nbp_planning.py"), "-c", "_pytest_2rank.json", "--n-poses", "4"],
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        two = json.load(open(os.path.join(ROOT, "data", "out_test_2rank.json")))
+        cfg["results_json_name"] = "out_test_1rank.json"
+        with open(cfg_path, "w") as fh:
+            json.dump(cfg, fh)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "test_nbp_planning.py"), "-c", "_pytest_2rank.json",
+                            "--n-poses", "4"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        one = json.load(open(os.path.join(ROOT, "data", "out_test_1rank.json")))
+        assert sorted(two) == sorted(one) == ["maze_00", "maze_01"]
+        for scene in one:
+            assert np.allclose(two[scene]["0"]["coverage"], one[scene]["0"]["coverage"], atol=1e-7)
+    finally:
+        os.remove(cfg_path)
