@@ -1,0 +1,18 @@
+#!/bin/bash
+# rocprofv3 passes for profiles/rNN: kernel stats of the default bench, then separate PMC passes
+# (FETCH_SIZE / WRITE_SIZE / SQ counters cannot share a pass; see MI355X_MICROARCH.md).
+# usage (on the GPU box): bash tools/profile.sh gpurun_out/prof_rNN
+set -u
+OUT=${1:-gpurun_out/prof}
+REPO=$(pwd)
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/stats" -o trace -- $BENCH > "$REPO/$OUT/bench_under_rocprof.json" 2> "$REPO/$OUT/stats.err"
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
+  name=$(echo $pass | cut -d' ' -f1)
+  rocprofv3 --pmc $pass --output-format csv -d "$REPO/$OUT/pmc_$name" -o pmc -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline > "$REPO/$OUT/pmc_$name.json" 2> "$REPO/$OUT/pmc_$name.err"
+done
+cd "$REPO"
+python tools/summarize_prof.py "$OUT" > "$OUT/summary.log" 2>&1
