@@ -95,6 +95,34 @@ int nbp_forward_timed_f32(const nbp_weights* handle, const float* x, int B, int 
 /* FLOPs (2*MAC over the 48 convolutions) of one forward at batch B, size S. */
 double nbp_forward_flops(int B, int S);
 
+/* ---- bf16 variant (BASELINE.json configs[4]: 512x512 grids, 8 rollouts per GPU in one forward).
+ * Same network and same fp32 in/out tensors as nbp_forward_f32 (ref nbp_model.py:110-160); inside, activations
+ * are NHWC bf16, the 3x3 / attention-gate weights are bf16, accumulation and every epilogue (folded BatchNorm,
+ * ReLU, sigmoid, psi gate) are fp32, and each stored activation is rounded once (nearest even).  It cannot
+ * meet the 1e-4 fp32 tolerance (bf16 has 8 mantissa bits); tests/test_gpu_bf16.py states its tolerance.
+ * nbp_pack_weights_bf16 takes exactly the inputs of nbp_pack_weights (`packed` of nbp_packed_weights_bytes()). */
+int nbp_pack_weights_bf16(const void* const* w_host_array, const void* const* scale_host_array,
+                          const void* const* shift_host_array, void* packed, size_t packed_bytes,
+                          void* stream, nbp_weights** handle_out);
+size_t nbp_forward_workspace_bytes_bf16(int B, int S);
+int nbp_forward_bf16(const nbp_weights* handle, const float* x, int B, int S, float* out1,
+                     float* out2, void* ws, size_t ws_bytes, void* stream);
+int nbp_forward_timed_bf16(const nbp_weights* handle, const float* x, int B, int S, float* out1,
+                           float* out2, void* ws, size_t ws_bytes, void* stream,
+                           nbp_layer_timing* timings_host, int max_entries, int* n_entries_host);
+/* Single bf16 layer: as nbp_conv_igemm_f32 with bf16 (uint16 storage) NHWC sources / output, C0, C1 multiples
+ * of 64, w_packed from nbp_pack_conv_weight_bf16 ([(c_off+c)/64][tap][N][64] bf16), fp32 scale / shift. */
+int nbp_conv_igemm_bf16(const unsigned short* src0, int C0, const unsigned short* src1, int C1, int ups,
+                        int B, int H, int W, int ksize, const unsigned short* w_packed, int N,
+                        const float* scale, const float* shift, int relu, unsigned short* out,
+                        int split_k, int tile, void* ws, size_t ws_bytes, void* stream);
+size_t nbp_conv_igemm_bf16_workspace_bytes(int B, int H, int W, int N, int split_k);
+int nbp_pack_conv_weight_bf16(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null,
+                              int c_off, int c_total, unsigned short* dst, void* stream);
+/* Element-wise conversions (round to nearest even), for tests and callers holding fp32 maps. */
+int nbp_f32_to_bf16(const float* in, long long n, unsigned short* out, void* stream);
+int nbp_bf16_to_f32(const unsigned short* in, long long n, float* out, void* stream);
+
 /* ---- single layers (same kernels the forward uses; exported for layer-level parity tests)
  * Implicit-GEMM convolution on NHWC fp32, k in {1,3}, stride 1, "same" padding:
  *   input channels [0,C0) come from src0, [C0,C0+C1) from src1 (fused torch.cat, ref :128);

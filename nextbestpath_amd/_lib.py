@@ -85,6 +85,15 @@ class LayerTiming(C.Structure):
 
 SIGNATURES["nbp_forward_timed_f32"] = (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, C.POINTER(LayerTiming), _i,
                                             C.POINTER(_i)])
+SIGNATURES["nbp_forward_timed_bf16"] = SIGNATURES["nbp_forward_timed_f32"]
+SIGNATURES["nbp_pack_weights_bf16"] = SIGNATURES["nbp_pack_weights"]
+SIGNATURES["nbp_forward_workspace_bytes_bf16"] = SIGNATURES["nbp_forward_workspace_bytes"]
+SIGNATURES["nbp_forward_bf16"] = SIGNATURES["nbp_forward_f32"]
+SIGNATURES["nbp_conv_igemm_bf16"] = SIGNATURES["nbp_conv_igemm_f32"]
+SIGNATURES["nbp_conv_igemm_bf16_workspace_bytes"] = SIGNATURES["nbp_conv_igemm_workspace_bytes"]
+SIGNATURES["nbp_pack_conv_weight_bf16"] = SIGNATURES["nbp_pack_conv_weight"]
+SIGNATURES["nbp_f32_to_bf16"] = (_i, [_vp, _ll, _vp, _vp])
+SIGNATURES["nbp_bf16_to_f32"] = (_i, [_vp, _ll, _vp, _vp])
 
 _lock = threading.Lock()
 _lib = None

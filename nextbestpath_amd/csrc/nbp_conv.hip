@@ -17,6 +17,7 @@
 // K order inside a chunk is permuted (lanes 0-31 take floats 8j..8j+3, lanes 32-63 take
 // 8j+4..8j+7); A and B use the same permutation so the sum over k is complete.
 #include "common.h"
+#include "nbp_internal.h"
 #include <cstdlib>
 
 #ifndef NBP_STAGGER
@@ -282,10 +283,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------ tile table / planning
-enum { NBP_TILE_AUTO = 0, NBP_TILE_128x128 = 1, NBP_TILE_256x64 = 2, NBP_TILE_256x32 = 3, NBP_TILE_128x64 = 4,
-       NBP_TILE_64x128 = 5 };
-
-struct TileInfo { int bm, bn; };
 static TileInfo tile_info(int tile) {
     switch (tile) {
         case NBP_TILE_128x128: return {128, 128};
@@ -296,8 +293,6 @@ static TileInfo tile_info(int tile) {
         default: return {0, 0};
     }
 }
-
-struct ConvPlan { int tile; int split_k; int chunks_per_split; };
 
 // Shared by the forward, the single-layer entry point and the workspace query.
 ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k, int groups) {
@@ -348,7 +343,6 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
 
 // Internal entry used by nbp_forward.hip too.  groups == 2 runs two same-shaped convolutions
 // (operand set `o` and `o2`) in one launch.
-struct ConvOperands { const float* src0; const float* src1; const float* wpk; const float* scale; const float* shift; float* out; };
 
 int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C0, int C1, int ups, int B, int H, int W,
                             int ksize, int N, int relu, int split_k, int tile, void* ws, size_t ws_bytes, hipStream_t st) {

@@ -6,15 +6,10 @@
 // nn.Upsample and torch.cat in the conv's operand gather, the attention gate's two 1x1
 // convolutions as ONE GEMM over K=[g|x] followed by a psi+multiply tail.
 #include "common.h"
+#include "nbp_internal.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-
-struct ConvOperands { const float* src0; const float* src1; const float* wpk; const float* scale; const float* shift; float* out; };
-int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C0, int C1, int ups, int B, int H, int W,
-                            int ksize, int N, int relu, int split_k, int tile, void* ws, size_t ws_bytes, hipStream_t st);
-struct ConvPlan { int tile; int split_k; int chunks_per_split; };
-ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k, int groups);
 
 namespace {
 
@@ -89,9 +84,10 @@ int fill_f32(float* dst, float v, long long n, hipStream_t st) {
 }  // namespace
 
 struct nbp_weights {
-    const float* w[NBP_N_CONV];
+    const void* w[NBP_N_CONV];      // fp32 everywhere, except bf16 for the igemm layers of a bf16 handle
     const float* scale[NBP_N_CONV];
     const float* shift[NBP_N_CONV];
+    int bf16;
 };
 
 extern "C" int nbp_abi_version(void) { return NBP_ABI_VERSION; }
@@ -110,9 +106,9 @@ extern "C" int nbp_device_info(char* arch_host, int arch_len, int* cu_count_host
 
 extern "C" size_t nbp_packed_weights_bytes(void) { return table().total_floats * sizeof(float); }
 
-extern "C" int nbp_pack_weights(const void* const* w_host_array, const void* const* scale_host_array,
-                                const void* const* shift_host_array, void* packed, size_t packed_bytes, void* stream,
-                                nbp_weights** handle_out) {
+static int pack_weights_impl(const void* const* w_host_array, const void* const* scale_host_array,
+                             const void* const* shift_host_array, void* packed, size_t packed_bytes, void* stream,
+                             nbp_weights** handle_out, bool bf16) {
     NBP_RETURN_IF(!w_host_array || !scale_host_array || !shift_host_array || !packed || !handle_out, NBP_E_ARG);
     const Table& T = table();
     NBP_RETURN_IF(packed_bytes < T.total_floats * sizeof(float), NBP_E_WS);
@@ -124,6 +120,7 @@ extern "C" int nbp_pack_weights(const void* const* w_host_array, const void* con
     float* base = (float*)packed;
     nbp_weights* h = (nbp_weights*)calloc(1, sizeof(nbp_weights));
     NBP_RETURN_IF(!h, NBP_E_ARG);
+    h->bf16 = bf16 ? 1 : 0;
     int rc = 0;
     for (int i = 0; i < NBP_N_CONV && !rc; ++i) {
         const LayerSpec& s = T.L[i];
@@ -147,16 +144,22 @@ extern "C" int nbp_pack_weights(const void* const* w_host_array, const void* con
                 if (!rc) rc = copy_f32(sh, td, 1, st);
                 break;
             case K_CONV3:
-                rc = nbp_pack_conv_weight(w, s.cout, s.cin, 3, nullptr, 0, s.cin, wd, st);
+                rc = bf16 ? nbp_pack_conv_weight_bf16(w, s.cout, s.cin, 3, nullptr, 0, s.cin, (bf16_t*)wd, st)
+                          : nbp_pack_conv_weight(w, s.cout, s.cin, 3, nullptr, 0, s.cin, wd, st);
                 if (!rc) rc = copy_f32(sc, sd, s.cout, st);
                 if (!rc) rc = copy_f32(sh, td, s.cout, st);
                 break;
             case K_ATT_G: {
                 // joint GEMM over K=[g|x]: scale folded into the weights, epilogue scale = 1
-                rc = nbp_pack_conv_weight(w, s.cout, s.cin, 1, sc, 0, 2 * s.cin, wd, st);
                 const float* wx = (const float*)w_host_array[i + 1];
                 const float* scx = (const float*)scale_host_array[i + 1];
-                if (!rc) rc = nbp_pack_conv_weight(wx, s.cout, s.cin, 1, scx, s.cin, 2 * s.cin, wd, st);
+                if (bf16) {
+                    rc = nbp_pack_conv_weight_bf16(w, s.cout, s.cin, 1, sc, 0, 2 * s.cin, (bf16_t*)wd, st);
+                    if (!rc) rc = nbp_pack_conv_weight_bf16(wx, s.cout, s.cin, 1, scx, s.cin, 2 * s.cin, (bf16_t*)wd, st);
+                } else {
+                    rc = nbp_pack_conv_weight(w, s.cout, s.cin, 1, sc, 0, 2 * s.cin, wd, st);
+                    if (!rc) rc = nbp_pack_conv_weight(wx, s.cout, s.cin, 1, scx, s.cin, 2 * s.cin, wd, st);
+                }
                 if (!rc) rc = fill_f32(sd, 1.0f, s.cout, st);
                 if (!rc) rc = copy_f32(sh, td, s.cout, st);
                 break;
@@ -171,6 +174,22 @@ extern "C" int nbp_pack_weights(const void* const* w_host_array, const void* con
     return 0;
 }
 
+extern "C" int nbp_pack_weights(const void* const* w_host_array, const void* const* scale_host_array,
+                                const void* const* shift_host_array, void* packed, size_t packed_bytes, void* stream,
+                                nbp_weights** handle_out) {
+    return pack_weights_impl(w_host_array, scale_host_array, shift_host_array, packed, packed_bytes, stream, handle_out,
+                             false);
+}
+
+// Same inputs (fp32 OIHW weights, folded fp32 scale / shift); the 3x3 and attention-gate weights are stored as
+// bf16 in the 64-channel chunk layout of nbp_bf16.hip, everything else (first conv, psi, heads, epilogues) stays fp32.
+extern "C" int nbp_pack_weights_bf16(const void* const* w_host_array, const void* const* scale_host_array,
+                                     const void* const* shift_host_array, void* packed, size_t packed_bytes,
+                                     void* stream, nbp_weights** handle_out) {
+    return pack_weights_impl(w_host_array, scale_host_array, shift_host_array, packed, packed_bytes, stream, handle_out,
+                             true);
+}
+
 extern "C" void nbp_free_weights(nbp_weights* handle) { free(handle); }
 
 // ------------------------------------------------------------------ forward
@@ -178,11 +197,11 @@ namespace {
 
 struct Bump {
     char* base; size_t size, off; bool dry;
-    float* take(size_t floats) {
-        size_t bytes = (floats * sizeof(float) + 255) / 256 * 256;
+    template <typename T> T* take(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) / 256 * 256;
         size_t o = off; off += bytes;
-        if (dry) return (float*)(uintptr_t)256;   // non-null dummy
-        return (float*)(base + o);
+        if (dry) return (T*)(uintptr_t)256;   // non-null dummy
+        return (T*)(base + o);
     }
 };
 
@@ -220,14 +239,62 @@ struct Timer {
     }
 };
 
+// The two arithmetic paths behind the same driver: element type of the activations, K-chunk width, launchers.
+struct PathF32 {
+    typedef float T;
+    typedef ConvOperands Ops;
+    static constexpr int CHUNK = 32;
+    static ConvPlan plan(long long M, int N, int chunks, int groups) { return nbp_plan_conv(M, N, chunks, 0, 0, groups); }
+    static int conv(const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks, int N, void* ws, size_t wsb,
+                    hipStream_t st) {
+        return nbp_conv_igemm_launch_g(o, o2, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st);
+    }
+    static int first(const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {
+        return nbp_conv_first_f32(x, B, s, s, (const float*)h->w[0], h->scale[0], h->shift[0], out, st);
+    }
+    static int pool(const T* in, int B, int H, int C, T* out, hipStream_t st) { return nbp_maxpool2_nhwc_f32(in, B, H, H, C, out, st); }
+    static int gate(const T* q, int F, const float* w, const float* s2, const T* x, int C, long long M, T* out, hipStream_t st) {
+        return nbp_psi_gate_f32(q, F, w, s2, x, C, M, out, st);
+    }
+    static int head(const T* in, int B, int H, int C, const float* w, int no, const float* sc, const float* sh, int sig,
+                    float* out, hipStream_t st) {
+        return nbp_final_1x1_f32(in, B, H, H, C, w, no, sc, sh, sig, out, st);
+    }
+};
+struct PathBF16 {
+    typedef bf16_t T;
+    typedef ConvOperandsH Ops;
+    static constexpr int CHUNK = 64;
+    static ConvPlan plan(long long M, int N, int chunks, int groups) { return nbp_plan_conv_bf16(M, N, chunks, 0, 0, groups); }
+    static int conv(const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks, int N, void* ws, size_t wsb,
+                    hipStream_t st) {
+        return nbp_conv_igemm_bf16_launch_g(o, o2, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st);
+    }
+    static int first(const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {
+        return nbp_conv_first_bf16_launch(x, B, s, s, (const float*)h->w[0], h->scale[0], h->shift[0], out, st);
+    }
+    static int pool(const T* in, int B, int H, int C, T* out, hipStream_t st) { return nbp_maxpool2_bf16_launch(in, B, H, H, C, out, st); }
+    static int gate(const T* q, int F, const float* w, const float* s2, const T* x, int C, long long M, T* out, hipStream_t st) {
+        return nbp_psi_gate_bf16_launch(q, F, w, s2, x, C, M, out, st);
+    }
+    static int head(const T* in, int B, int H, int C, const float* w, int no, const float* sc, const float* sh, int sig,
+                    float* out, hipStream_t st) {
+        return nbp_final_1x1_bf16_launch(in, B, H, H, C, w, no, sc, sh, sig, out, st);
+    }
+};
+
+template <typename P>
 size_t splitk_scratch_floats(long long M, int N, int cin_total, int taps, int groups = 1) {
-    ConvPlan p = nbp_plan_conv(M, N, cin_total / 32 * taps, 0, 0, groups);
+    ConvPlan p = P::plan(M, N, cin_total / P::CHUNK * taps, groups);
     return p.split_k > 1 ? (size_t)groups * p.split_k * M * N : 0;
 }
 
 // Runs (or, with h == nullptr, only sizes) the network.
+template <typename P>
 int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1, float* out2, Bump& bp,
                 hipStream_t st, Timer* tm = nullptr) {
+    typedef typename P::T T;
+    typedef typename P::Ops Ops;
     char nm[48];
     const bool dry = bp.dry;
     const int enc[5] = {64, 128, 256, 512, 1024};
@@ -239,41 +306,40 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
         sk = 0;
         for (int e = 0; e < 5; ++e, s /= 2) {
             long long M = (long long)B * s * s;
-            if (e > 0) sk = max(sk, splitk_scratch_floats(M, enc[e], enc[e - 1], 9));
-            sk = max(sk, splitk_scratch_floats(M, enc[e], enc[e], 9));
+            if (e > 0) sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e - 1], 9));
+            sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e], 9));
             if (e < 4) {   // decoder level at this resolution: co = enc[e], ci = enc[e+1]
                 for (int g = 1; g <= 2; ++g) {      // levels 5 and 4 run both decoders in one grouped launch
-                    sk = max(sk, splitk_scratch_floats(M, enc[e], enc[e + 1], 9, g));
-                    sk = max(sk, splitk_scratch_floats(M, enc[e], enc[e], 9, g));
-                    sk = max(sk, splitk_scratch_floats(M, enc[e] / 2, 2 * enc[e], 1, g));
+                    sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e + 1], 9, g));
+                    sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e], 9, g));
+                    sk = max(sk, splitk_scratch_floats<P>(M, enc[e] / 2, 2 * enc[e], 1, g));
                 }
             }
         }
     }
-    float* skws = bp.take(sk ? sk : 64);
+    float* skws = bp.take<float>(sk ? sk : 64);
     const size_t skbytes = sk * sizeof(float);
 
     // one (ng = 1) or two (ng = 2: decoder 1 next to decoder 2) same-shaped convolutions per launch
-    auto conv2 = [&](const char* name, int ng, const int* li, const float* const* s0, int C0, const float* const* s1,
-                     int C1, int ups, int Hh, int ksize, int N, float* const* out) {
+    auto conv2 = [&](const char* name, int ng, const int* li, const T* const* s0, int C0, const T* const* s1,
+                     int C1, int ups, int Hh, int ksize, int N, T* const* out) {
         if (dry || rc) return;
-        ConvOperands o[2];
+        Ops o[2];
         for (int g = 0; g < ng; ++g)
-            o[g] = ConvOperands{s0[g], s1 ? s1[g] : nullptr, h->w[li[g]], h->scale[li[g]], h->shift[li[g]], out[g]};
-        rc = nbp_conv_igemm_launch_g(o[0], ng == 2 ? &o[1] : nullptr, C0, C1, ups, B, Hh, Hh, ksize, N, 1, 0, 0, skws,
-                                     skbytes, st);
+            o[g] = Ops{s0[g], s1 ? s1[g] : nullptr, (const T*)h->w[li[g]], h->scale[li[g]], h->shift[li[g]], out[g]};
+        rc = P::conv(o[0], ng == 2 ? &o[1] : nullptr, C0, C1, ups, B, Hh, ksize, N, skws, skbytes, st);
         if (tm && !rc) {
             const long long M = (long long)B * Hh * Hh;
             const int K = (C0 + C1) * ksize * ksize;
-            ConvPlan p = nbp_plan_conv(M, N, K / 32, 0, 0, ng);
+            ConvPlan p = P::plan(M, N, K / P::CHUNK, ng);
             tm->mark(name, 2.0 * ng * M * N * K, p.tile, p.split_k, M, N, K);
         }
     };
-    auto conv = [&](const char* name, int li, const float* s0, int C0, const float* s1, int C1, int ups, int Hh,
-                    int ksize, int N, float* out) {
-        const float* s0a[1] = {s0};
-        const float* s1a[1] = {s1};
-        float* oa[1] = {out};
+    auto conv = [&](const char* name, int li, const T* s0, int C0, const T* s1, int C1, int ups, int Hh,
+                    int ksize, int N, T* out) {
+        const T* s0a[1] = {s0};
+        const T* s1a[1] = {s1};
+        T* oa[1] = {out};
         conv2(name, 1, &li, s0a, C0, s1 ? s1a : nullptr, C1, ups, Hh, ksize, N, oa);
     };
     auto stamp = [&](const char* name, double flops, long long M, int N, int K) {
@@ -281,21 +347,21 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
     };
 
     // ---- encoder
-    float* skip[5];
+    T* skip[5];
     int li = 0;
     int s = S;
-    const float* prev = nullptr;
+    const T* prev = nullptr;
     for (int e = 0; e < 5; ++e) {
         const int co = enc[e];
         const size_t n = (size_t)B * s * s * co;
-        float* a = bp.take(n);
-        float* b = bp.take(n);
+        T* a = bp.take<T>(n);
+        T* b = bp.take<T>(n);
         if (e == 0) {
-            if (!dry && !rc) rc = nbp_conv_first_f32(x, B, s, s, h->w[0], h->scale[0], h->shift[0], a, st);
+            if (!dry && !rc) rc = P::first(x, B, s, h, a, st);
             stamp("Conv1.conv.0(first)", 2.0 * B * s * s * 64 * 45, (long long)B * s * s, 64, 45);
         } else {
-            float* pooled = bp.take((size_t)B * s * s * enc[e - 1]);
-            if (!dry && !rc) rc = nbp_maxpool2_nhwc_f32(prev, B, 2 * s, 2 * s, enc[e - 1], pooled, st);
+            T* pooled = bp.take<T>((size_t)B * s * s * enc[e - 1]);
+            if (!dry && !rc) rc = P::pool(prev, B, 2 * s, enc[e - 1], pooled, st);
             snprintf(nm, sizeof nm, "Maxpool%d", e);
             stamp(nm, 0, (long long)B * s * s, enc[e - 1], 0);
             snprintf(nm, sizeof nm, "Conv%d.conv.0", e + 1);
@@ -312,20 +378,20 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
     // launch (decoder 1 = group 0, decoder 2 = group 1), which doubles the workgroups per launch at
     // B = 1 and halves the split-K factor.  Decoder 2 then continues alone through levels 3 and 2.
     const int li_d1 = 10, li_d2 = 22;
-    const float* cur[2] = {skip[4], skip[4]};
+    const T* cur[2] = {skip[4], skip[4]};
     for (int Lv = 5; Lv >= 2; --Lv) {
         const int ng = Lv >= 4 ? 2 : 1;
         const int g0 = Lv >= 4 ? 0 : 1;                 // first decoder index handled (0-based)
         const int co = enc[Lv - 2], ci = enc[Lv - 1];
         const int sr = S >> (Lv - 2);
         const long long M = (long long)B * sr * sr;
-        const float* xs = skip[Lv - 2];
-        float *dd[2], *q[2], *ag[2], *u[2], *o[2];
+        const T* xs = skip[Lv - 2];
+        T *dd[2], *q[2], *ag[2], *u[2], *o[2];
         int lis[2];
-        const float *src[2], *xsa[2] = {xs, xs};
+        const T *src[2], *xsa[2] = {xs, xs};
         for (int g = 0; g < ng; ++g) {
-            dd[g] = bp.take((size_t)M * co); q[g] = bp.take((size_t)M * (co / 2)); ag[g] = bp.take((size_t)M * co);
-            u[g] = bp.take((size_t)M * co); o[g] = bp.take((size_t)M * co);
+            dd[g] = bp.take<T>((size_t)M * co); q[g] = bp.take<T>((size_t)M * (co / 2)); ag[g] = bp.take<T>((size_t)M * co);
+            u[g] = bp.take<T>((size_t)M * co); o[g] = bp.take<T>((size_t)M * co);
             const int d = g0 + g;                       // 0 = decoder 1, 1 = decoder 2
             lis[g] = (d == 0 ? li_d1 : li_d2) + (5 - Lv) * 6;
             src[g] = cur[d];
@@ -336,65 +402,88 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
         snprintf(nm, sizeof nm, "Up%d_%s.up.1", Lv, tag);
         shifted(0, l); conv2(nm, ng, l, src, ci, nullptr, 0, 1, sr, 3, co, dd);                    // upsample + conv3x3
         snprintf(nm, sizeof nm, "Att%d_%s.W_g+W_x", Lv, tag);
-        shifted(1, l); conv2(nm, ng, l, (const float* const*)dd, co, xsa, co, 0, sr, 1, co / 2, q);  // relu(W_g g + W_x x)
+        shifted(1, l); conv2(nm, ng, l, (const T* const*)dd, co, xsa, co, 0, sr, 1, co / 2, q);  // relu(W_g g + W_x x)
         for (int g = 0; g < ng && !dry && !rc; ++g)
-            rc = nbp_psi_gate_f32(q[g], co / 2, h->w[lis[g] + 3], h->scale[lis[g] + 3], xs, co, M, ag[g], st);
+            rc = P::gate(q[g], co / 2, (const float*)h->w[lis[g] + 3], h->scale[lis[g] + 3], xs, co, M, ag[g], st);
         snprintf(nm, sizeof nm, "Att%d_%s.psi*x", Lv, tag);
         stamp(nm, 2.0 * ng * M * (co / 2), M, 1, co / 2);
         snprintf(nm, sizeof nm, "Up_conv%d_%s.conv.0", Lv, tag);
-        shifted(4, l); conv2(nm, ng, l, (const float* const*)ag, co, (const float* const*)dd, co, 0, sr, 3, co, u);
+        shifted(4, l); conv2(nm, ng, l, (const T* const*)ag, co, (const T* const*)dd, co, 0, sr, 3, co, u);
         snprintf(nm, sizeof nm, "Up_conv%d_%s.conv.3", Lv, tag);
-        shifted(5, l); conv2(nm, ng, l, (const float* const*)u, co, nullptr, 0, 0, sr, 3, co, o);
+        shifted(5, l); conv2(nm, ng, l, (const T* const*)u, co, nullptr, 0, 0, sr, 3, co, o);
         for (int g = 0; g < ng; ++g) cur[g0 + g] = o[g];
         if (Lv == 4) {
             if (!dry && !rc)
-                rc = nbp_final_1x1_f32(cur[0], B, S / 4, S / 4, 256, h->w[46], 8, h->scale[46], h->shift[46], 0, out1, st);
+                rc = P::head(cur[0], B, S / 4, 256, (const float*)h->w[46], 8, h->scale[46], h->shift[46], 0, out1, st);
             stamp("Final1", 2.0 * B * (S / 4) * (S / 4) * 8 * 256, (long long)B * (S / 4) * (S / 4), 8, 256);
         }
     }
     if (!dry && !rc)
-        rc = nbp_final_1x1_f32(cur[1], B, S, S, 64, h->w[47], 1, h->scale[47], h->shift[47], 1, out2, st);
+        rc = P::head(cur[1], B, S, 64, (const float*)h->w[47], 1, h->scale[47], h->shift[47], 1, out2, st);
     stamp("Final2", 2.0 * B * S * S * 64, (long long)B * S * S, 1, 64);
     return rc;
 }
 
 }  // namespace
 
-extern "C" size_t nbp_forward_workspace_bytes(int B, int S) {
+template <typename P>
+static size_t workspace_bytes_impl(int B, int S) {
     if (B < 1 || S < 16 || S % 16) return 0;
     Bump bp{nullptr, 0, 0, true};
-    run_forward(nullptr, nullptr, B, S, nullptr, nullptr, bp, nullptr);
+    run_forward<P>(nullptr, nullptr, B, S, nullptr, nullptr, bp, nullptr);
     return bp.off + 256;
 }
 
-extern "C" int nbp_forward_f32(const nbp_weights* handle, const float* x, int B, int S, float* out1, float* out2,
-                               void* ws, size_t ws_bytes, void* stream) {
+template <typename P>
+static int forward_impl(const nbp_weights* handle, const float* x, int B, int S, float* out1, float* out2, void* ws,
+                        size_t ws_bytes, void* stream, nbp_layer_timing* timings_host, int max_entries,
+                        int* n_entries_host) {
     NBP_RETURN_IF(!handle || !x || !out1 || !out2 || !ws, NBP_E_ARG);
+    NBP_RETURN_IF(handle->bf16 != (sizeof(typename P::T) == 2 ? 1 : 0), NBP_E_ARG);   // handle packed for the other path
     NBP_RETURN_IF(B < 1, NBP_E_ARG);
     NBP_RETURN_IF(S < 16 || S % 16, NBP_E_SHAPE);
-    NBP_RETURN_IF(ws_bytes < nbp_forward_workspace_bytes(B, S), NBP_E_WS);
+    NBP_RETURN_IF(ws_bytes < workspace_bytes_impl<P>(B, S), NBP_E_WS);
     uintptr_t p = ((uintptr_t)ws + 255) / 256 * 256;
     Bump bp{(char*)p, ws_bytes, 0, false};
-    return run_forward(handle, x, B, S, out1, out2, bp, (hipStream_t)stream);
+    if (!timings_host) return run_forward<P>(handle, x, B, S, out1, out2, bp, (hipStream_t)stream);
+    NBP_RETURN_IF(!n_entries_host || max_entries < 1, NBP_E_ARG);
+    static Timer tm;   // 256 events; the profiling entry points are not re-entrant
+    tm.st = (hipStream_t)stream; tm.out = timings_host; tm.cap = max_entries;
+    int rc = tm.begin();
+    if (rc) return rc;
+    rc = run_forward<P>(handle, x, B, S, out1, out2, bp, (hipStream_t)stream, &tm);
+    int rc2 = tm.finish();
+    *n_entries_host = tm.n;
+    return rc ? rc : rc2;
+}
+
+extern "C" size_t nbp_forward_workspace_bytes(int B, int S) { return workspace_bytes_impl<PathF32>(B, S); }
+extern "C" size_t nbp_forward_workspace_bytes_bf16(int B, int S) { return workspace_bytes_impl<PathBF16>(B, S); }
+
+extern "C" int nbp_forward_f32(const nbp_weights* handle, const float* x, int B, int S, float* out1, float* out2,
+                               void* ws, size_t ws_bytes, void* stream) {
+    return forward_impl<PathF32>(handle, x, B, S, out1, out2, ws, ws_bytes, stream, nullptr, 0, nullptr);
+}
+
+extern "C" int nbp_forward_bf16(const nbp_weights* handle, const float* x, int B, int S, float* out1, float* out2,
+                                void* ws, size_t ws_bytes, void* stream) {
+    return forward_impl<PathBF16>(handle, x, B, S, out1, out2, ws, ws_bytes, stream, nullptr, 0, nullptr);
 }
 
 extern "C" int nbp_forward_timed_f32(const nbp_weights* handle, const float* x, int B, int S, float* out1,
                                      float* out2, void* ws, size_t ws_bytes, void* stream,
                                      nbp_layer_timing* timings_host, int max_entries, int* n_entries_host) {
-    NBP_RETURN_IF(!handle || !x || !out1 || !out2 || !ws || !timings_host || !n_entries_host, NBP_E_ARG);
-    NBP_RETURN_IF(B < 1 || max_entries < 1, NBP_E_ARG);
-    NBP_RETURN_IF(S < 16 || S % 16, NBP_E_SHAPE);
-    NBP_RETURN_IF(ws_bytes < nbp_forward_workspace_bytes(B, S), NBP_E_WS);
-    uintptr_t p = ((uintptr_t)ws + 255) / 256 * 256;
-    Bump bp{(char*)p, ws_bytes, 0, false};
-    static Timer tm;   // 256 events; profiling entry point is not re-entrant
-    tm.st = (hipStream_t)stream; tm.out = timings_host; tm.cap = max_entries;
-    int rc = tm.begin();
-    if (rc) return rc;
-    rc = run_forward(handle, x, B, S, out1, out2, bp, (hipStream_t)stream, &tm);
-    int rc2 = tm.finish();
-    *n_entries_host = tm.n;
-    return rc ? rc : rc2;
+    NBP_RETURN_IF(!timings_host || !n_entries_host, NBP_E_ARG);
+    return forward_impl<PathF32>(handle, x, B, S, out1, out2, ws, ws_bytes, stream, timings_host, max_entries,
+                                 n_entries_host);
+}
+
+extern "C" int nbp_forward_timed_bf16(const nbp_weights* handle, const float* x, int B, int S, float* out1,
+                                      float* out2, void* ws, size_t ws_bytes, void* stream,
+                                      nbp_layer_timing* timings_host, int max_entries, int* n_entries_host) {
+    NBP_RETURN_IF(!timings_host || !n_entries_host, NBP_E_ARG);
+    return forward_impl<PathBF16>(handle, x, B, S, out1, out2, ws, ws_bytes, stream, timings_host, max_entries,
+                                  n_entries_host);
 }
 
 extern "C" double nbp_forward_flops(int B, int S) {

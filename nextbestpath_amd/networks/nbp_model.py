@@ -97,6 +97,8 @@ class NBP(nn.Module):
         self._packed = None          # opaque handle into libnbp_hip (eval-mode packed weights)
         self._packed_key = None
         self._tensors = None
+        # "fp32" (default; exact-fp32 MFMA, the 1e-4 parity path) or "bf16" (BASELINE configs[4]; eval only)
+        self.conv_precision = "fp32"
 
     # ------------------------------------------------------------------ packing
     def _state_key(self):
@@ -118,7 +120,7 @@ class NBP(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _ensure_packed(self, device):
-        key = (self._state_key(), str(device))
+        key = (self._state_key(), str(device), self.conv_precision)
         if self._packed is None or key != self._packed_key:
             from . import packing
             if self._packed is not None:

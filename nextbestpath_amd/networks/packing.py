@@ -48,8 +48,8 @@ def fold_affine(sd, conv, bn, eps=1e-5):
 class PackedWeights:
     """Owns the device buffer and the C handle; freed explicitly or on GC."""
 
-    def __init__(self, handle, buf, keep):
-        self.handle, self.buf, self.keep = handle, buf, keep
+    def __init__(self, handle, buf, keep, bf16=False):
+        self.handle, self.buf, self.keep, self.bf16 = handle, buf, keep, bf16
 
     def free(self):
         if self.handle:
@@ -63,7 +63,8 @@ class PackedWeights:
             pass
 
 
-def pack_state_dict(sd, device) -> PackedWeights:
+def pack_state_dict(sd, device, bf16: bool = False) -> PackedWeights:
+    """bf16=True packs for nbp_forward_bf16 (bf16 conv weights / activations, fp32 accumulate and epilogues)."""
     L = _lib.lib()
     layers = canonical_layers()
     ws, ss, ts, keep = [], [], [], []
@@ -82,25 +83,26 @@ def pack_state_dict(sd, device) -> PackedWeights:
     arr = lambda v: (C.c_void_p * 48)(*v)
     handle = C.c_void_p()
     with torch.cuda.device(device):
-        rc = L.nbp_pack_weights(arr(ws), arr(ss), arr(ts), buf.data_ptr(), nbytes, _lib.current_stream(),
-                                C.byref(handle))
+        fn = L.nbp_pack_weights_bf16 if bf16 else L.nbp_pack_weights
+        rc = fn(arr(ws), arr(ss), arr(ts), buf.data_ptr(), nbytes, _lib.current_stream(), C.byref(handle))
         _lib.check(rc, "nbp_pack_weights")
         torch.cuda.current_stream().synchronize()   # sources in `keep` may now be released
-    return PackedWeights(handle, buf, None)
+    return PackedWeights(handle, buf, None, bf16)
 
 
 def pack_eval_weights(module, device) -> PackedWeights:
-    return pack_state_dict(module.state_dict(), device)
+    return pack_state_dict(module.state_dict(), device, bf16=getattr(module, "conv_precision", "fp32") == "bf16")
 
 
 _ws_cache = {}
 
 
-def _workspace(B, S, device):
-    key = (B, S, str(device))
+def _workspace(B, S, device, bf16=False):
+    key = (B, S, str(device), bf16)
     ws = _ws_cache.get(key)
     if ws is None:
-        n = _lib.lib().nbp_forward_workspace_bytes(B, S)
+        L = _lib.lib()
+        n = L.nbp_forward_workspace_bytes_bf16(B, S) if bf16 else L.nbp_forward_workspace_bytes(B, S)
         if n == 0:
             raise _lib.NbpHipError(f"unsupported NBP input size B={B} S={S}")
         ws = torch.empty(n, dtype=torch.uint8, device=device)
@@ -114,11 +116,12 @@ def forward_packed(packed: PackedWeights, x: torch.Tensor):
     x = x.contiguous().float()
     out1 = torch.empty(B, 8, S // 4, S // 4, dtype=torch.float32, device=x.device)
     out2 = torch.empty(B, 1, S, S, dtype=torch.float32, device=x.device)
-    ws = _workspace(B, S, x.device)
+    ws = _workspace(B, S, x.device, packed.bf16)
+    fn = _lib.lib().nbp_forward_bf16 if packed.bf16 else _lib.lib().nbp_forward_f32
     with torch.cuda.device(x.device):
-        rc = _lib.lib().nbp_forward_f32(packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(),
-                                        ws.data_ptr(), ws.numel(), _lib.current_stream())
-    _lib.check(rc, "nbp_forward_f32")
+        rc = fn(packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(), ws.data_ptr(), ws.numel(),
+                _lib.current_stream())
+    _lib.check(rc, "nbp_forward_bf16" if packed.bf16 else "nbp_forward_f32")
     return out1, out2
 
 

@@ -41,3 +41,35 @@ def nhwc(x):
 
 def nchw(x):
     return x.permute(0, 3, 1, 2).contiguous()
+
+
+# ---- bf16 path (uint16 storage on the device; torch.bfloat16 views share the bit pattern)
+def to_bf16_dev(x_f32_cuda):
+    return x_f32_cuda.to(torch.bfloat16).contiguous()
+
+
+def pack_conv_bf16(w_oihw, scale=None, c_off=0, c_total=None, dst=None):
+    L = _lib.lib()
+    N, C, k, _ = w_oihw.shape
+    c_total = c_total or C
+    if dst is None:
+        dst = torch.zeros(c_total // 64 * k * k * N * 64, dtype=torch.bfloat16, device=w_oihw.device)
+    rc = L.nbp_pack_conv_weight_bf16(_lib.ptr(w_oihw), N, C, k, _lib.ptr(scale), c_off, c_total, _lib.ptr(dst), stream())
+    _lib.check(rc, "pack_bf16")
+    return dst
+
+
+def conv_igemm_bf16(src0, src1, ups, wpk, N, ksize, scale, shift, relu, split_k=0, tile=0):
+    """src*: NHWC cuda bfloat16 tensors [B,Hs,Ws,C]; returns NHWC bfloat16 [B,H,W,N]."""
+    L = _lib.lib()
+    B, Hs, Ws, C0 = src0.shape
+    H, W = (Hs * 2, Ws * 2) if ups else (Hs, Ws)
+    C1 = 0 if src1 is None else src1.shape[3]
+    out = torch.empty(B, H, W, N, dtype=torch.bfloat16, device=src0.device)
+    nws = L.nbp_conv_igemm_bf16_workspace_bytes(B, H, W, N, 64)
+    ws = torch.empty(max(nws, 256), dtype=torch.uint8, device=src0.device)
+    rc = L.nbp_conv_igemm_bf16(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, ksize, _lib.ptr(wpk), N,
+                               _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), split_k, tile,
+                               _lib.ptr(ws), ws.numel(), stream())
+    _lib.check(rc, "conv_igemm_bf16")
+    return out

@@ -1,0 +1,152 @@
+"""GPU parity of the bf16 path (BASELINE.json configs[4]).
+
+Tolerances (bf16 has 8 mantissa bits, ulp = 2^-8 relative; SURVEY.md "Hard parts": bf16 cannot meet 1e-4):
+  * single layer vs the exact sum of the same bf16 operands: the stored bf16 may differ from the correctly
+    rounded value by one ulp where fp32 accumulation order moves the sum across a rounding boundary:
+    |got - ref| <= 2^-7 * |ref| + 1e-3;
+  * whole network vs the bf16 restatement (oracle/nbp_net_bf16.py, same rounding points): 2e-2 absolute on both
+    heads (value head relative to its range), mean error below 3e-3 (one-ulp flips propagate through 10+ layers);
+  * whole network vs the fp32 oracle: 5e-2 absolute relative to the head's range, and the thresholded obstacle
+    map / goal cell agreement rates are reported and bounded.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_helpers import conv_igemm_bf16, nchw, nhwc, pack_conv_bf16, stream
+from nextbestpath_amd import _lib
+from oracle import nbp_net, nbp_net_bf16
+from oracle.nbp_net_bf16 import rbf
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+# (B, H, W, C0, C1, N, ksize, ups, split_k, tile)
+CASES = [
+    (1, 16, 16, 64, 0, 128, 3, 0, 1, 1),     # 128x128 tile
+    (1, 16, 16, 64, 0, 128, 3, 0, 3, 1),     # split-K (9 chunks / 3)
+    (1, 16, 16, 128, 0, 128, 3, 0, 0, 0),    # auto plan
+    (2, 12, 20, 64, 0, 64, 3, 0, 1, 2),      # 256x64 tile, ragged M (480), W != H
+    (1, 24, 24, 64, 0, 32, 1, 0, 1, 3),      # 256x32 tile, 1x1
+    (1, 16, 16, 192, 0, 64, 3, 0, 1, 4),     # 128x64 tile, C not a power of two
+    (3, 4, 4, 128, 0, 256, 3, 0, 1, 5),      # 64x128 tile, tiny M (48)
+    (1, 8, 8, 64, 0, 128, 3, 1, 1, 0),       # fused x2 nearest upsample -> 16x16
+    (1, 16, 16, 64, 64, 128, 3, 0, 2, 0),    # fused concat + split-K
+    (2, 8, 8, 128, 128, 64, 1, 0, 1, 0),     # attention-style 1x1 over [g|x]
+    (1, 2, 2, 1024, 0, 1024, 3, 0, 0, 0),    # bottleneck shape at S=32
+    (1, 1, 1, 512, 0, 1024, 3, 0, 0, 0),     # 1x1 image: every tap but the centre is padding
+    (2, 64, 64, 64, 0, 64, 3, 0, 0, 0),      # multi-block, both batch images
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_igemm_bf16_vs_exact(hip, case):
+    B, H, W, C0, C1, N, k, ups, split_k, tile = case
+    dev = "cuda"
+    x0 = rbf(_rand(B, C0, H, W, seed=1))
+    x1 = rbf(_rand(B, C1, H, W, seed=2)) if C1 else None
+    w = _rand(N, C0 + C1, k, k, seed=3, scale=(6.0 / ((C0 + C1) * k * k)) ** 0.5)
+    scale = _rand(N, seed=4) * 0.2 + 1.0
+    shift = _rand(N, seed=5) * 0.1
+    xin = x0 if x1 is None else torch.cat((x0, x1), 1)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2)
+    acc = F.conv2d(xin.double(), rbf(w).double(), None, padding=k // 2).float()
+    ref = F.relu(acc * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    wpk = pack_conv_bf16(w.to(dev).contiguous())
+    x0d = nhwc(x0).to(dev).to(torch.bfloat16)
+    x1d = None if x1 is None else nhwc(x1).to(dev).to(torch.bfloat16)
+    scd, shd = scale.to(dev), shift.to(dev)
+    out = conv_igemm_bf16(x0d, x1d, ups, wpk, N, k, scd, shd, True, split_k, tile)
+    torch.cuda.synchronize()
+    got = nchw(out.float()).cpu()
+    assert got.shape == ref.shape
+    err = (got - ref).abs()
+    bound = ref.abs() * 2.0 ** -7 + 1e-3
+    assert bool((err <= bound).all()), f"max err {err.max().item()} at ref {ref.flatten()[err.argmax()].item()}"
+    # most values are the correctly rounded ones
+    assert (got == rbf(ref)).float().mean().item() > 0.97
+
+
+def test_conversions(hip):
+    x = _rand(1000, seed=7, scale=100.0).cuda()
+    h = torch.empty(1000, dtype=torch.bfloat16, device="cuda")
+    _lib.check(hip.nbp_f32_to_bf16(_lib.ptr(x), 1000, _lib.ptr(h), stream()), "f2b")
+    assert torch.equal(h, x.to(torch.bfloat16))
+    y = torch.empty(1000, device="cuda")
+    _lib.check(hip.nbp_bf16_to_f32(_lib.ptr(h), 1000, _lib.ptr(y), stream()), "b2f")
+    assert torch.equal(y, h.float())
+
+
+@pytest.fixture(scope="module")
+def net_bf16(nbp_weights):
+    from nextbestpath_amd.networks.nbp_model import NBP
+    net = NBP()
+    net.load_state_dict(nbp_weights, strict=True)
+    net.conv_precision = "bf16"
+    return net.cuda().eval()
+
+
+@pytest.mark.parametrize("B,S", [(1, 32), (2, 64), (1, 128)])
+def test_forward_bf16_vs_restatement(hip, net_bf16, nbp_weights, B, S):
+    from nextbestpath_amd.utility.synthetic import make_count_maps
+    x = make_count_maps(B, S, seed=11)
+    with torch.no_grad():
+        r1, r2 = nbp_net_bf16.nbp_forward_bf16(nbp_weights, x)
+        f1, f2 = nbp_net.nbp_forward(nbp_weights, x)
+        o1, o2 = net_bf16(x.cuda())
+    o1, o2 = o1.cpu(), o2.cpu()
+    assert o1.shape == r1.shape and o2.shape == r2.shape
+    s1 = max(f1.abs().max().item(), 1e-6)
+    # vs the bf16 restatement (same rounding points)
+    assert (o1 - r1).abs().max().item() / s1 < 2e-2
+    assert (o2 - r2).abs().max().item() < 2e-2
+    assert (o1 - r1).abs().mean().item() / s1 < 3e-3
+    assert (o2 - r2).abs().mean().item() < 3e-3
+    # vs the fp32 oracle (pinned by the reference's golden vectors)
+    assert (o1 - f1).abs().max().item() / s1 < 5e-2
+    assert (o2 - f2).abs().max().item() < 5e-2
+    # the restatement itself sits at the same distance from fp32 (it models the path, not a better one)
+    assert (r1 - f1).abs().max().item() / s1 < 5e-2
+
+
+def test_forward_bf16_256_decisions(hip, net_bf16, nbp_weights):
+    """256x256: agreement of the planner-facing decisions with the fp32 HIP path."""
+    from nextbestpath_amd.networks.nbp_model import NBP
+    from nextbestpath_amd.utility.synthetic import make_count_maps
+    net32 = NBP()
+    net32.load_state_dict(nbp_weights, strict=True)
+    net32 = net32.cuda().eval()
+    x = make_count_maps(4, 256, seed=13).cuda()
+    with torch.no_grad():
+        a1, a2 = net32(x)
+        b1, b2 = net_bf16(x)
+    s1 = a1.abs().max().item()
+    assert (a1 - b1).abs().max().item() / s1 < 5e-2
+    assert (a2 - b2).abs().max().item() < 5e-2
+    agree = ((a2 >= 0.13) == (b2 >= 0.13)).float().mean().item()    # obstacle threshold, nbp_planning.py:168
+    assert agree > 0.995
+    # determinism + batch independence
+    with torch.no_grad():
+        c1, c2 = net_bf16(x)
+        d1, d2 = net_bf16(x[1:2])
+    assert torch.equal(b1, c1) and torch.equal(b2, c2)
+    # a different batch size may pick other tiles / split-K (another summation order): same tolerance as above
+    assert (d1 - b1[1:2]).abs().max().item() / s1 < 2e-2 and (d2 - b2[1:2]).abs().max().item() < 2e-2
+
+
+def test_bf16_handle_mismatch_is_an_error(hip, net_bf16):
+    from nextbestpath_amd.networks import packing
+    x = torch.zeros(1, 5, 32, 32, device="cuda")
+    packed = net_bf16._ensure_packed(x.device)
+    ws = torch.empty(hip.nbp_forward_workspace_bytes(1, 32), dtype=torch.uint8, device="cuda")
+    o1 = torch.empty(1, 8, 8, 8, device="cuda"); o2 = torch.empty(1, 1, 32, 32, device="cuda")
+    rc = hip.nbp_forward_f32(packed.handle, x.data_ptr(), 1, 32, o1.data_ptr(), o2.data_ptr(), ws.data_ptr(),
+                             ws.numel(), stream())
+    assert rc != 0
