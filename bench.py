@@ -245,6 +245,19 @@ def main():
                                                                                 n=ro.st.cloud.shape[0], bbox=bbox,
                                                                                 out=out)), 4),
                              "gt_points": int(gt.shape[0])}
+        # BASELINE configs[4] forward (reported beside the headline, not part of `value`): 8 maps of 512x512
+        # through the bf16 network; fraction of the dense bf16 MFMA peak (2.5 PFLOP/s)
+        sd16 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        pk16 = packing.pack_state_dict(sd16, dev, bf16=True)
+        x5 = torch.zeros(8, 5, 512, 512, device=dev)
+        x5[:, :, 128:384, 128:384] = x[:1].expand(8, -1, -1, -1) if S == 256 else 0.0
+        ms16 = ev_time(lambda: packing.forward_packed(pk16, x5), reps=10)
+        fl16 = L.nbp_forward_flops(8, 512)
+        stage["config5_forward_bf16_512_b8"] = {"ms": round(ms16, 4), "maps_per_s": round(8e3 / ms16, 2),
+                                                "tflops": round(fl16 / (ms16 * 1e-3) / 1e12, 2),
+                                                "frac_of_bf16_mfma_peak": round(fl16 / (ms16 * 1e-3) / 1e12 / 2500.0, 4)}
+        pk16.free()
+        del x5, pk16
         stage["replans_in_timed_region"] = sum(r.n_replans for r in rollouts) - replans0
         stage["single_rollout_steps_per_s"] = round(single, 2)
 

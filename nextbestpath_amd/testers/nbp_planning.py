@@ -300,13 +300,15 @@ def run_one(params, nbp, dataset, run, device, test_resolution=0.05, state=None,
     return _result(ro, n_poses)
 
 
-def run_many(params, nbp, dataset, runs, device, seeds, test_resolution=0.05, n_poses=N_POSES, rollouts_per_gpu=8):
+def run_many(params, nbp, dataset, runs, device, seeds, test_resolution=0.05, n_poses=N_POSES, rollouts_per_gpu=8,
+             grid=256):
     """Runs `runs` in lock-step groups of `rollouts_per_gpu` (MultiRollout); same results as run_one each."""
     out = []
     nbp.eval()
     for g0 in range(0, len(runs), rollouts_per_gpu):
         chunk = list(zip(runs[g0:g0 + rollouts_per_gpu], seeds[g0:g0 + rollouts_per_gpu]))
-        ros = [build_rollout(params, nbp, dataset, run, device, test_resolution, None, seed) for run, seed in chunk]
+        ros = [build_rollout(params, nbp, dataset, run, device, test_resolution, None, seed, grid)
+               for run, seed in chunk]
         multi = MultiRollout(ros, nbp, device)
         for _ in range(n_poses):
             multi.step()
@@ -320,8 +322,9 @@ def run_many(params, nbp, dataset, runs, device, seeds, test_resolution=0.05, n_
 def test_nbp_planning(params_file, model_file, results_json_file, numGPU, test_scenes, test_resolution=0.05,
                       use_perfect_depth_map=False, compute_collision=False, load_json=False, dataset_path=None,
                       nbp_weights=None, configs_dir=None, results_dir=None, n_poses=N_POSES, seed=8, torch_seed=9,
-                      rollouts_per_gpu=8):
-    """Same arguments as the reference (nbp_planning.py:364-374).  Under torchrun the flattened
+                      rollouts_per_gpu=8, grid_size=256, nbp_precision="fp32"):
+    """Same arguments as the reference (nbp_planning.py:364-374); `grid_size` / `nbp_precision` select
+    BASELINE.json configs[4] (512 grid at the same 0.3125 units per pixel, bf16 convolutions).  Under torchrun the flattened
     (scene, start pose) runs are sharded round-robin over the ranks and the coverage curves are
     gathered with ONE all_gather over RCCL (backend "nccl" on ROCm; "gloo" on CPU-only hosts)."""
     from ..parallel_rollout import gather_results, init_distributed, shard
@@ -343,12 +346,14 @@ def test_nbp_planning(params_file, model_file, results_json_file, numGPU, test_s
         print("[nbp] no checkpoint at", nbp_weights, "-> seeded synthetic weights")
         nbp.load_state_dict(make_explorer_state_dict(torch_seed))
     nbp.to(device).eval()
+    assert nbp_precision in ("fp32", "bf16"), nbp_precision
+    nbp.conv_precision = nbp_precision
     dataset = sim_scene.SceneDataset(dataset_path, test_scenes)
     runs = list_runs(dataset, params)
     mine = shard(runs, rank, world)
     with torch.no_grad():
         results = run_many(params, nbp, dataset, mine, device, [seed + 1000 * r[0] + r[1] for r in mine],
-                           test_resolution, n_poses, rollouts_per_gpu)
+                           test_resolution, n_poses, rollouts_per_gpu, grid_size)
     for run, res in zip(mine, results):
         res["run_id"] = runs.index(run)
     gathered = gather_results(results, runs, rank, world, device, n_poses)

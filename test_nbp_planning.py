@@ -31,4 +31,5 @@ if __name__ == "__main__":
                           configs_dir=os.path.join(dir_path, "configs/macarons"),
                           results_dir=os.path.join(dir_path, "data"), n_poses=args.n_poses,
                           seed=getattr(p, "random_seed", 8), torch_seed=getattr(p, "torch_seed", 9),
-                          rollouts_per_gpu=args.rollouts_per_gpu)
+                          rollouts_per_gpu=args.rollouts_per_gpu, grid_size=getattr(p, "grid_size", 256),
+                          nbp_precision=getattr(p, "nbp_precision", "fp32"))

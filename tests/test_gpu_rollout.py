@@ -125,6 +125,34 @@ def test_rollout_on_512_grid(hip, dataset, nbp_weights):
     assert float(ro.st.maps6[:5].sum()) > 0
 
 
+def test_config5_bf16_multi_rollout_512(hip, dataset, nbp_weights):
+    """BASELINE configs[4] in miniature: 8 concurrent rollouts on a 512 grid, forwards batched through the bf16
+    network.  bf16 cannot promise the fp32 path's decisions, so the check is behavioural: every rollout explores
+    (coverage grows, no NaN) and the first steps -- where the agent only follows its initial path -- coincide."""
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.testers import nbp_planning as tp
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    ds = sc.SceneDataset(dataset)
+    dev = torch.device("cuda")
+    net16 = _net(nbp_weights)
+    net16.conv_precision = "bf16"
+    net32 = _net(nbp_weights)
+    n = 6
+    out = {}
+    for tag, net in (("bf16", net16), ("fp32", net32)):
+        ros = [tp.build_rollout(params, net, ds, (i % 2, 0), dev, seed=10 + i, grid=512) for i in range(8)]
+        m = tp.MultiRollout(ros, net, dev)
+        for _ in range(n):
+            m.step()
+        m.flush()
+        out[tag] = ros
+    for a, b in zip(out["bf16"], out["fp32"]):
+        ca, cb = a.coverage_evolution(n), b.coverage_evolution(n)
+        assert all(np.isfinite(ca)) and ca[-1] > 0.0 and max(ca) >= ca[1] - 1e-9, (ca, cb)
+        assert a.camera.cam_idx_history[:2] == b.camera.cam_idx_history[:2], (a.camera.cam_idx_history, b.camera.cam_idx_history)
+        assert abs(ca[1] - cb[1]) < 1e-6, (ca, cb)      # same first frames -> same first coverage value
+
+
 def test_scene_parallel_entry_point_two_ranks(hip, dataset):
     """torchrun with 2 ranks (sharing this box's single GPU, gloo for the one all_gather): each rank runs its
     shard of the (scene, start) runs; rank 0 writes the merged coverage JSON == the single-process result."""
