@@ -65,6 +65,25 @@ def timed_layers(packed, x, out1, out2, ws):
             for a in arr[:n.value]]
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM-side bytes per launch of `kernel_prefix` from the committed rocprofv3 PMC passes over the same workload
+    (tools/profile.sh -> profiles/r01/forward_f32_pmc_summary.csv): 2*FETCH_SIZE + WRITE_SIZE (KB -> bytes; the
+    factor 2 is the gfx950 correction for 16-B-per-lane loads, MI355X_MICROARCH.md).  None if no profile."""
+    import csv
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "forward_f32_pmc_summary.csv")
+    if not os.path.exists(path):
+        return None
+    want = kernel_prefix.replace(" ", "")
+    vals = {}
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            if row["kernel"].replace(" ", "").startswith(want):
+                vals[row["counter"]] = float(row["mean_per_dispatch"])
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def ev_time(fn, reps=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fn()
@@ -196,9 +215,19 @@ def main():
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         cf = sum(r["flops"] for r in layer_rows if r["tile"] > 0)
         cm = sum(r["ms"] for r in layer_rows if r["tile"] > 0)
+        # algorithmic bytes of those launches: sources + packed weights + output, each once
+        def layer_bytes(r):
+            taps = 1 if ".W_g" in r["name"] else 9
+            src = r["M"] * (r["K"] // taps) / (4 if ".up.1" in r["name"] else 1)     # fused x2 upsample reads H/2 x W/2
+            return 4.0 * (src + r["K"] * r["N"] + r["M"] * r["N"]) * (2 if "{1,2}" in r["name"] else 1)
+        alg_bytes = sum(layer_bytes(r) for r in layer_rows if r["tile"] == dom)
+        traffic = pmc_traffic(TILE_NAMES[dom].split("(")[0]) if (R, S) == (8, 256) else None
         roofline = {"bound": "mfma", "kernel": TILE_NAMES[dom], "achieved": round(achieved, 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": None, "launches_per_forward": d["launches"],
+                    "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
+                    "profiles/r01/forward_f32_pmc_summary.csv, same B=8 S=256 forward)",
+                    "algorithmic_bytes_per_launch": round(alg_bytes / d["launches"]),
+                    "launches_per_forward": d["launches"],
                     "avg_launch_ms": round(d["ms"] / d["launches"], 5), "flops_per_launch": d["flops"] / d["launches"],
                     "note": "avg_launch_ms brackets the igemm launch plus its split-K reduce (event pair per layer)",
                     "all_igemm_tflops": round(cf / (cm * 1e-3) / 1e12, 3),
