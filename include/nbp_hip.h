@@ -230,6 +230,14 @@ int nbp_segments_hit_mesh_f32(const float* verts, const int* faces, int n_faces,
  * of triangles hit from pts3[k] along +Y, +X, +Z (inside iff all three are odd). */
 int nbp_axis_ray_counts_f32(const float* verts, const int* faces, int n_faces, const float* pts3,
                             int n_pts, int* counts3, void* stream);
+/* GT obstacle label of a training record: get_binary_obstacle_array (next_best_path/utility/utils.py:226-262,
+ * trimesh mesh_plane + matplotlib + PIL in the reference).  out [S,S] fp32 in {0,1}: 1 where the pixel centre is
+ * within half_width_px of the intersection of the mesh with the plane y = y0; the window is [lo,hi] around
+ * (cx, cz), column ~ -(x - cx), row ~ -(z - cz) (the reference's axes after its left-right flip).
+ * The reference's line width is 1.5 pt at 100 dpi = 2.08 px: half_width_px = 1.04.  Parity unpinned
+ * (third-party rasterisation); oracle/slice_raster.py restates THIS definition bit for bit. */
+int nbp_slice_obstacle_f32(const float* verts, const int* faces, int n_faces, float y0, float cx, float cz,
+                           int S, float lo, float hi, float half_width_px, float* out, void* stream);
 /* Depth-map space carving of proxy points (A20): Camera.get_points_in_fov (mu:2849-2884) +
  * get_signed_distance_to_depth_maps (mu:2900-2949) + Scene.update_proxy_supervision_occ /
  * update_proxy_out_of_field (mu:3329-3363) fused per point.  For each proxy point inside the frustum

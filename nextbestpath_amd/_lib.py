@@ -94,6 +94,7 @@ SIGNATURES["nbp_conv_igemm_bf16_workspace_bytes"] = SIGNATURES["nbp_conv_igemm_w
 SIGNATURES["nbp_pack_conv_weight_bf16"] = SIGNATURES["nbp_pack_conv_weight"]
 SIGNATURES["nbp_f32_to_bf16"] = (_i, [_vp, _ll, _vp, _vp])
 SIGNATURES["nbp_bf16_to_f32"] = (_i, [_vp, _ll, _vp, _vp])
+SIGNATURES["nbp_slice_obstacle_f32"] = (_i, [_vp, _vp, _i, _f, _f, _f, _i, _f, _f, _f, _vp, _vp])
 
 _lock = threading.Lock()
 _lib = None

@@ -522,3 +522,67 @@ extern "C" int nbp_append_points_f32(float* dst, long long offset, const float* 
 extern "C" unsigned nbp_perm_index_host(unsigned j, unsigned n, unsigned seed) {
     return n == 0 ? 0 : perm_index(j, n, perm_bits(n), seed);
 }
+
+// ------------------------------------------------------------------ GT obstacle label (training data path)
+// get_binary_obstacle_array (next_best_path/utility/utils.py:226-262) draws the mesh / plane(y = camera height)
+// intersection with matplotlib, saves a PNG, resizes and thresholds it.  Here: one wave per face; the face's
+// intersection segment with the plane is drawn into the S x S label as the set of pixels whose centre lies within
+// half_width pixels of it.  Image axes as in the reference after its left-right flip: column grows with
+// -(x - cx), row with -(z - cz), the window is [lo, hi] around the camera (pixel AREAS, i.e. centres at +0.5).
+namespace {
+__global__ __launch_bounds__(256) void slice_obstacle_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                             int F, float y0, float cx, float cz, int S, float hi,
+                                                             float scale, float half_width, float* __restrict__ out) {
+    const int f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (f >= F) return;
+    float px[3], py[3], pz[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int v = faces[3 * f + k];
+        px[k] = verts[3 * v]; py[k] = verts[3 * v + 1] - y0; pz[k] = verts[3 * v + 2];
+    }
+    float su[2], sv[2];
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int q = (k + 1) % 3;
+        if ((py[k] < 0.f) != (py[q] < 0.f)) {
+            const float t = py[k] / (py[k] - py[q]);
+            const float x = px[k] + t * (px[q] - px[k]);
+            const float z = pz[k] + t * (pz[q] - pz[k]);
+            if (n < 2) { su[n] = ((cx - x) + hi) * scale; sv[n] = ((cz - z) + hi) * scale; }
+            ++n;
+        }
+    }
+    if (n != 2) return;
+    const float wu = su[1] - su[0], wv = sv[1] - sv[0];
+    const float L2 = wu * wu + wv * wv;
+    const float pad = half_width + 1.0f;
+    const int c0 = max(0, (int)floorf(fminf(su[0], su[1]) - pad)), c1 = min(S - 1, (int)ceilf(fmaxf(su[0], su[1]) + pad));
+    const int r0 = max(0, (int)floorf(fminf(sv[0], sv[1]) - pad)), r1 = min(S - 1, (int)ceilf(fmaxf(sv[0], sv[1]) + pad));
+    if (c1 < c0 || r1 < r0) return;
+    const int wbox = c1 - c0 + 1, total = wbox * (r1 - r0 + 1);
+    const float h2 = half_width * half_width;
+    for (int i = lane; i < total; i += 64) {
+        const int r = r0 + i / wbox, c = c0 + i % wbox;
+        const float qu = ((float)c + 0.5f) - su[0], qv = ((float)r + 0.5f) - sv[0];
+        float t = 0.f;
+        if (L2 > 0.f) t = fminf(fmaxf((qu * wu + qv * wv) / L2, 0.f), 1.f);
+        const float du = qu - t * wu, dv = qv - t * wv;
+        if (du * du + dv * dv <= h2) out[r * S + c] = 1.0f;
+    }
+}
+}  // namespace
+
+extern "C" int nbp_slice_obstacle_f32(const float* verts, const int* faces, int n_faces, float y0, float cx, float cz,
+                                      int S, float lo, float hi, float half_width_px, float* out, void* stream) {
+    NBP_RETURN_IF(!verts || !faces || !out || n_faces < 1 || S < 1 || !(hi > lo) || !(half_width_px > 0.f), NBP_E_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)S * S * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    const float scale = (float)((double)S / ((double)hi - (double)lo));
+    slice_obstacle_kernel<<<(unsigned)nbp_cdiv((long long)n_faces * 64, 256), 256, 0, st>>>(verts, faces, n_faces, y0, cx, cz,
+                                                                                          S, hi, scale, half_width_px, out);
+    return nbp_launch_status();
+}

@@ -67,18 +67,23 @@ class _Builder:
         return np.asarray(self.v, np.float32), np.asarray(self.f, np.int32)
 
 
-def make_maze_mesh(seed=0, cells=10, size=60.0, height=12.0, wall=0.6, tess=2.5, extra_openings=0.25):
+def make_maze_mesh(seed=0, cells=10, size=60.0, height=12.0, wall=0.6, tess=2.5, extra_openings=0.25, hull="slab"):
     """Single-floor maze: floor, ceiling, outer walls and interior walls as closed boxes of
     thickness `wall`, footprint [-size/2, size/2]^2, y in [0, height]; every surface is
     tessellated at pitch `tess` (so the face count scales like AiMDoom's 5-50 k faces).
     Connectivity: random spanning tree over the cell grid + `extra_openings` of the remaining
-    walls removed."""
+    walls removed.  hull="shell" makes floor, ceiling and outer walls ONE closed surface around the free
+    space (as in a game level), so that check_camera_in_mesh's "odd hit count along +X, +Y, +Z" means
+    "inside the level" (training scenes); hull="slab" gives them thickness (the evaluation scenes)."""
     rng = np.random.default_rng(seed)
     half, pitch = size / 2.0, size / cells
     b = _Builder()
-    b.box((-half - wall, -wall, -half - wall), (half + wall, 0.0, half + wall), tess * 2)           # floor slab
-    b.box((-half - wall, height, -half - wall), (half + wall, height + wall, half + wall), tess * 2)   # ceiling slab
-    for s in (-1, 1):                                                                             # outer walls
+    if hull == "shell":
+        b.box((-half, 0.0, -half), (half, height, half), tess)
+    else:
+        b.box((-half - wall, -wall, -half - wall), (half + wall, 0.0, half + wall), tess * 2)           # floor slab
+        b.box((-half - wall, height, -half - wall), (half + wall, height + wall, half + wall), tess * 2)   # ceiling slab
+    for s in (-1, 1) if hull != "shell" else ():                                                  # outer walls
         x0 = s * half if s > 0 else -half - wall
         b.box((x0, 0.0, -half - wall), (x0 + wall, height, half + wall), tess)
         b.box((-half, 0.0, x0), (half, height, x0 + wall), tess)
@@ -111,12 +116,12 @@ def make_maze_mesh(seed=0, cells=10, size=60.0, height=12.0, wall=0.6, tess=2.5,
     return b.arrays()
 
 
-def make_maze_scene(scene_dir, seed=0, cells=10, size=6.0, height=1.2, tess=0.25, n_starts=1, scale=10.0):
+def make_maze_scene(scene_dir, seed=0, cells=10, size=6.0, height=1.2, tess=0.25, n_starts=1, scale=10.0, hull="slab"):
     """Writes <scene_dir>/<name>.obj + settings.json in UNSCALED units (the drivers multiply by
     scene_scale_factor = 10 on load, like the reference: nbp_planning.py:442,455) with the
     reference's settings schema (macarons/utility/macarons_utils.py:2152-2190)."""
     os.makedirs(scene_dir, exist_ok=True)
-    v, f = make_maze_mesh(seed, cells, size, height, wall=0.06, tess=tess)
+    v, f = make_maze_mesh(seed, cells, size, height, wall=0.06, tess=tess, hull=hull)
     name = os.path.basename(os.path.normpath(scene_dir))
     save_obj(os.path.join(scene_dir, name + ".obj"), v, f)
     half = size / 2.0

@@ -5,9 +5,10 @@ schema ('current_model_input', 'current_gt_2d_layout', 'target_value_map_pixel',
 'actual_coverage_gain', 'pose_i'), same micro-batch / 8-step gradient accumulation / AdamW /
 ReduceLROnPlateau logic.  Forward and backward run on the HIP kernels (networks/training.py).
 
-Not built yet: the LMDB / msgpack replay store and the DAgger-style
-trajectory collection that fills it; experiences are kept in an in-memory list and, offline, are
-synthesised by ``make_synthetic_experiences`` (lmdb is not installable here)."""
+The replay store and the trajectory collection that fills it live in utility/nbp_utils.py (SURVEY.md 8f
+rank 2); ``make_synthetic_experiences`` synthesises records of the same schema for the config-3 benchmark.
+Under torchrun every rank collects its own scenes into its own store, trains on its own
+samples and the gradients are averaged with bucketed RCCL all-reduces before each optimizer step."""
 from __future__ import annotations
 
 import json
@@ -55,14 +56,63 @@ def _collate(batch_data, device):
     return xs, gt, torch.cat(coords).to(device), gains, bidx
 
 
+BUCKET_BYTES = 64 << 20      # xGMI rings are per-link bound (~153 GB/s): 4 buckets cover the 200 MB of gradients
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+
+
+def allreduce_gradients(nbp):
+    """Averages the accumulated gradients over the ranks: parameters are packed into flat buckets of at most
+    BUCKET_BYTES in registration order, one all-reduce (RCCL on ROCm) per bucket."""
+    dist = _dist()
+    if dist is None:
+        return
+    world = dist.get_world_size()
+    params = [p for p in nbp.parameters() if p.grad is not None]
+    i = 0
+    while i < len(params):
+        bucket, size = [], 0
+        while i < len(params) and (not bucket or size + params[i].grad.numel() * 4 <= BUCKET_BYTES):
+            bucket.append(params[i]); size += params[i].grad.numel() * 4; i += 1
+        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        if dist.get_backend() == "gloo" and flat.is_cuda:      # CPU rendezvous in tests; RCCL reduces in place on the GPU
+            host = flat.cpu()
+            dist.all_reduce(host)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat)
+        flat /= world
+        off = 0
+        for p in bucket:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad)); off += n
+
+
+def _common_count(n, device):
+    """Every rank must take the same number of optimizer steps: min over ranks of the local batch count."""
+    dist = _dist()
+    if dist is None:
+        return n
+    t = torch.tensor([n], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
 def train_experience_data(training_set_db, params, optimizer, nbp, device, current_epoch):
     """ref nbp_utils.py:340-395 (GradScaler without autocast is the identity scale for fp32; omitted)."""
     random.shuffle(training_set_db)
+    if current_epoch == 1:                   # ref :350: early poses are skipped during the first training epoch
+        training_set_db = [d for d in training_set_db if d["pose_i"] > 10] or training_set_db
     training_loss, accumulated, updates = [], 0.0, 0
     accumulation_steps = 8
     bs = params.nbp_batch_size
-    for i in range(0, len(training_set_db), bs):
-        batch = [d for d in training_set_db[i:i + bs] if (d["pose_i"] > 10 and current_epoch == 1) or current_epoch > 1]
+    n_batches = _common_count((len(training_set_db) + bs - 1) // bs, device)
+    for bi in range(n_batches):
+        i = bi * bs
+        batch = training_set_db[i:i + bs]
         if not batch:
             continue
         xs, gt, coords, gains, bidx = _collate(batch, device)
@@ -72,7 +122,8 @@ def train_experience_data(training_set_db, params, optimizer, nbp, device, curre
         loss.backward()
         accumulated += loss.item()
         updates += 1
-        if updates % accumulation_steps == 0 or (i + bs) >= len(training_set_db):
+        if updates % accumulation_steps == 0 or bi + 1 == n_batches:
+            allreduce_gradients(nbp)
             optimizer.step()
             optimizer.zero_grad()
             training_loss.append(accumulated / accumulation_steps)
@@ -109,21 +160,29 @@ def train_nbp(training_set_db, params, optimizer, nbp, device, current_epoch, va
 
 
 def run_training_nbp(params):
-    """ref train_nbp_model.py:40-157, single GPU (the reference's ddp / jz branches are `pass`)."""
-    device = torch.device("cuda", getattr(params, "numGPU", 0))
+    """ref train_nbp_model.py:40-157.  With a dataset at params.data_path: epoch 0 collects trajectories and
+    moves the validation records out of the store, every later epoch collects again and trains on
+    read_combined_data; without one (offline benchmark mode) the records are synthesised."""
+    from ..parallel_rollout import init_distributed
+    from ..simulator import scene as sim_scene
+    from ..utility import nbp_utils as nu
+    rank, world, local_rank = init_distributed()
+    device = torch.device("cuda", local_rank if world > 1 else getattr(params, "numGPU", 0))
     torch.cuda.set_device(device)
-    random.seed(params.random_seed); np.random.seed(params.random_seed); torch.manual_seed(params.torch_seed)
+    random.seed(params.random_seed + rank); np.random.seed(params.random_seed + rank); torch.manual_seed(params.torch_seed)
     nbp = NBP().to(device)
     nbp, optimizer, best_loss, _ = initialize_nbp(params, nbp, params.torch_seed)
     S = getattr(params, "grid_size", 256)
-    validation = make_synthetic_experiences(getattr(params, "n_validation", 16), S, seed=1)
-    history = {}
     os.makedirs(params.output_dir, exist_ok=True)
-    for epoch in range(1, params.epochs + 1):
-        db = make_synthetic_experiences(params.samples_per_epoch, S, seed=100 + epoch)
-        tl, vl = train_nbp(db, params, optimizer, nbp, device, epoch, validation, num_epochs=params.inner_epochs)
+    data_path = getattr(params, "data_path", None)
+    collect = bool(getattr(params, "collect", True)) and data_path and os.path.isdir(data_path)
+    history = {}
+
+    def save(epoch, vl, tl):
+        nonlocal best_loss
+        if rank != 0:
+            return
         history[epoch] = {"training_loss": tl, "validation_loss": vl}
-        print(f"epoch {epoch}: training {tl:.4f} validation {vl:.4f}")
         ck = {"epoch": epoch, "model_state_dict": nbp.state_dict(), "optimizer_state_dict": optimizer.state_dict()}
         if vl < best_loss:
             best_loss = vl
@@ -132,4 +191,36 @@ def run_training_nbp(params):
             torch.save(ck, os.path.join(params.output_dir, f"{params.nbp_model_name}_epoch{epoch}.pth"))
         with open(os.path.join(params.output_dir, "loss.json"), "w") as fh:
             json.dump(history, fh)
+
+    if not collect:
+        validation = make_synthetic_experiences(getattr(params, "n_validation_synthetic", 16), S, seed=1)
+        for epoch in range(1, params.epochs + 1):
+            db = make_synthetic_experiences(params.samples_per_epoch, S, seed=100 + epoch + 1000 * rank)
+            tl, vl = train_nbp(db, params, optimizer, nbp, device, epoch, validation, num_epochs=params.inner_epochs)
+            print(f"epoch {epoch}: training {tl:.4f} validation {vl:.4f}")
+            save(epoch, vl, tl)
+        return history
+
+    dataset = sim_scene.SceneDataset(data_path, getattr(params, "train_scenes", []))
+    db_dir = getattr(params, "db_path", os.path.join(params.output_dir, "db"))
+    env = nu.open_experience_db(os.path.join(db_dir, f"{params.nbp_model_name}.rank{rank}"))
+    validation = None
+    for epoch in range(0, params.epochs + 1):
+        cov = []
+        with torch.no_grad():
+            n = nu.trajectory_collection(params, epoch, dataset, env, (S, S), (S // 4, S // 4), (-40 * S // 256, 40 * S // 256),
+                                         nbp, cov, None, device, rank=rank, world=world,
+                                         n_poses=getattr(params, "n_collect_poses", 100),
+                                         n_gt_points=getattr(params, "n_gt_surface_points", 50000))
+        print(f"[rank {rank}] epoch {epoch}: collected {n} records ({env.entries()} in the store)")
+        if epoch == 0:
+            validation = nu.store_validation_data(env, getattr(params, "n_validation", 1200))
+            continue
+        db = nu.read_combined_data(env)
+        if not db or not validation:
+            continue
+        tl, vl = train_nbp(db, params, optimizer, nbp, device, epoch, validation, num_epochs=params.inner_epochs)
+        print(f"epoch {epoch}: training {tl:.4f} validation {vl:.4f}")
+        save(epoch, vl, tl)
+    env.close()
     return history

@@ -95,6 +95,17 @@ def axis_ray_counts(verts, faces, pts):
     return cnt
 
 
+def slice_obstacle(verts, faces, y0, cx, cz, S=256, grid_range=(-40, 40), half_width_px=1.04, out=None):
+    """GT obstacle label [S,S] fp32 {0,1} around (cx, cz) at height y0 (ref utils.py:226-262)."""
+    if out is None:
+        out = torch.empty(S, S, dtype=torch.float32, device=verts.device)
+    rc = _lib.lib().nbp_slice_obstacle_f32(_lib.ptr(verts), _lib.ptr(faces), faces.shape[0], float(y0), float(cx), float(cz),
+                                           S, float(grid_range[0]), float(grid_range[1]), float(half_width_px),
+                                           _lib.ptr(out), _st())
+    _lib.check(rc, "nbp_slice_obstacle_f32")
+    return out
+
+
 def fuse_obstacle(out2, maps6, traj, threshold=0.13):
     S = maps6.shape[-1]
     obst = torch.empty(S, S, dtype=torch.float32, device=maps6.device)

@@ -1,0 +1,97 @@
+"""GPU: GT obstacle label kernel vs its restatement (bit-exact), trajectory collection into the replay store,
+and the collection-driven train_nbp entry point on a tiny procedural dataset."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.slice_raster import slice_obstacle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    from nextbestpath_amd.simulator.mesh import make_maze_scene
+    d = tmp_path_factory.mktemp("synth_train")
+    for i in range(2):
+        make_maze_scene(str(d / f"maze_{i:02d}"), seed=10 + i, cells=6, size=4.8, height=1.2, tess=0.4, hull="shell")
+    return str(d)
+
+
+def _mesh(dataset):
+    from nextbestpath_amd.simulator import scene as sc
+    ds = sc.SceneDataset(dataset)
+    sd = ds[0]
+    return sc.load_scene(os.path.join(ds.data_path, sd["scene_name"], sd["obj_name"]), 10.0, torch.device("cuda"))
+
+
+@pytest.mark.parametrize("pose", [(0.0, 3.3, 0.0), (7.3, 5.0, -11.9), (-30.0, 1.0, 25.0), (100.0, 3.0, 0.0)])
+def test_slice_obstacle_matches_restatement(hip, dataset, pose):
+    from nextbestpath_amd.utility import hipops
+    mesh = _mesh(dataset)
+    got = hipops.slice_obstacle(mesh.verts, mesh.faces, pose[1], pose[0], pose[2]).cpu().numpy()
+    ref = slice_obstacle(mesh.verts_host, mesh.faces_host, pose[1], pose[0], pose[2])
+    assert np.array_equal(got, ref)
+    if pose[0] < 50:
+        assert got.sum() > 50            # the maze walls are in view
+    else:
+        assert got.sum() == 0            # camera far outside: empty window
+    got512 = hipops.slice_obstacle(mesh.verts, mesh.faces, pose[1], pose[0], pose[2], 512, (-80, 80)).cpu().numpy()
+    assert np.array_equal(got512, slice_obstacle(mesh.verts_host, mesh.faces_host, pose[1], pose[0], pose[2], 512, -80, 80))
+
+
+def test_trajectory_collection_fills_store(hip, dataset, tmp_path):
+    from nextbestpath_amd.networks.nbp_model import NBP
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.testers import nbp_planning as tp
+    from nextbestpath_amd.utility import nbp_utils as nu
+    from nextbestpath_amd.utility.synthetic import make_explorer_state_dict
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    net = NBP()
+    net.load_state_dict(make_explorer_state_dict(9))
+    net = net.cuda().eval()
+    env = nu.LogEnv(str(tmp_path / "db"))
+    cov = []
+    n = nu.trajectory_collection(params, 0, sc.SceneDataset(dataset), env, (256, 256), (64, 64), (-40, 40), net, cov, None,
+                                 torch.device("cuda"), n_poses=60, n_gt_points=8000)
+    assert n > 0 and env.entries() == n
+    recs = [nu.unpack_record(v) for _, v in env.items()]
+    for r in recs:
+        assert r["current_model_input"].shape == (1, 5, 256, 256) and r["current_model_input"].dtype == np.float32
+        assert r["current_gt_2d_layout"].shape == (1, 1, 256, 256)
+        assert set(np.unique(r["current_gt_2d_layout"])) <= {0.0, 1.0} and r["current_gt_2d_layout"].sum() > 0
+        px, g = r["target_value_map_pixel"], r["actual_coverage_gain"]
+        assert px.dtype == np.int64 and px.ndim == 2 and px.shape[1] == 3 and len(px) == len(g) >= 1
+        assert (px[:, 0] >= 0).all() and (px[:, 0] < 8).all() and (px[:, 1:] >= 0).all() and (px[:, 1:] < 64).all()
+        assert (g >= 0).all() and np.isfinite(g).all()
+        assert r["current_model_input"][0, 4].sum() > 0         # trajectory channel holds the camera history
+        assert r["current_model_input"][0, :4].sum() > 0        # slab maps hold the accumulated cloud
+    # thin wall traces, not filled regions
+    assert all(r["current_gt_2d_layout"].mean() < 0.2 for r in recs)
+    # a later pose of the same path reached with more coverage gives a positive gain somewhere
+    assert max(float(r["actual_coverage_gain"].max()) for r in recs) > 0
+
+
+def test_train_nbp_entry_point_with_collection(hip, dataset, tmp_path):
+    cfg = json.load(open(os.path.join(ROOT, "configs/nbp/nbp_default_training_config.json")))
+    cfg["_data"]["data_path"] = dataset
+    cfg["_scene_management"]["n_gt_surface_points"] = 8000
+    cfg["_nbp"].update({"nbp_model_name": "nbp_t", "nbp_batch_size": 4, "epochs": 1, "inner_epochs": 1, "n_validation": 4,
+                        "n_collect_poses": 60, "output_dir": str(tmp_path / "w"), "collect": True})
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from nextbestpath_amd.testers.nbp_planning import load_params\n"
+            "from nextbestpath_amd.trainers.train_nbp_model import run_training_nbp\n"
+            "h = run_training_nbp(load_params(%r)); print('HIST', h)\n") % (ROOT, str(path))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    hist = json.load(open(tmp_path / "w" / "loss.json"))
+    assert "1" in hist and np.isfinite(hist["1"]["training_loss"]) and np.isfinite(hist["1"]["validation_loss"])
+    assert os.path.exists(tmp_path / "w" / "nbp_t_best_val.pth")

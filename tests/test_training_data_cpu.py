@@ -1,0 +1,117 @@
+"""CPU: replay store (record encoding, container semantics, the reference's sampling rules), the GT-label
+restatement on analytic geometry, and the 2-rank gradient averaging of the multi-GPU trainer (gloo)."""
+import os
+import random
+import subprocess
+import sys
+
+import msgpack
+import numpy as np
+import pytest
+import torch
+
+from nextbestpath_amd.utility import nbp_utils as nu
+from oracle.slice_raster import slice_obstacle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rec(i, S=16):
+    rng = np.random.default_rng(i)
+    k = int(rng.integers(1, 5))
+    return {"current_model_input": torch.from_numpy(rng.random((1, 5, S, S)).astype(np.float32)),
+            "current_gt_2d_layout": torch.from_numpy((rng.random((1, 1, S, S)) < 0.2).astype(np.float32)),
+            "target_value_map_pixel": np.stack([rng.integers(0, 8, k), rng.integers(0, S // 4, k), rng.integers(0, S // 4, k)], 1),
+            "actual_coverage_gain": rng.random(k).astype(np.float32), "pose_i": i}
+
+
+def test_record_encoding_is_msgpack_numpy_layout():
+    r = _rec(3)
+    raw = nu.pack_record(r)
+    plain = msgpack.unpackb(raw, raw=True)          # no hook: the nested maps msgpack-numpy would produce
+    x = plain[b"current_model_input"]
+    assert x[b"nd"] is True and x[b"type"] == b"<f4" and x[b"shape"] == [1, 5, 16, 16] and x[b"kind"] == b""
+    assert len(x[b"data"]) == 5 * 16 * 16 * 4
+    assert plain[b"target_value_map_pixel"][b"type"] == b"<i8"
+    back = nu.unpack_record(raw)
+    assert back["pose_i"] == 3
+    assert np.array_equal(back["current_model_input"], r["current_model_input"].numpy())
+    assert np.array_equal(back["target_value_map_pixel"], r["target_value_map_pixel"])
+    assert back["actual_coverage_gain"].dtype == np.float32
+
+
+def test_log_env_order_delete_and_persistence(tmp_path):
+    env = nu.LogEnv(str(tmp_path / "db"))
+    for i in range(20):
+        nu.store_experience(env, _rec(i))
+    assert env.entries() == 20
+    keys = env.keys()
+    assert keys == sorted(keys) and len(set(keys)) == 20 and all(len(k) >= 12 and k.isdigit() for k in keys)
+    poses = [nu.unpack_record(v)["pose_i"] for _, v in env.items()]
+    assert poses == list(range(20))                               # cursor order == insertion order (timestamp keys)
+    val = nu.store_validation_data(env, num=5)                    # every ceil(20/5) = 4th record is moved out
+    assert [v["pose_i"] for v in val] == [0, 4, 8, 12, 16] and env.entries() == 15
+    env2 = nu.LogEnv(str(tmp_path / "db"))                        # reopen: tombstones respected
+    assert env2.entries() == 15 and [nu.unpack_record(v)["pose_i"] for _, v in env2.items()][:3] == [1, 2, 3]
+
+
+def test_read_combined_data_rule(tmp_path):
+    env = nu.LogEnv(str(tmp_path / "db"))
+    for i in range(30):
+        nu.store_experience(env, _rec(i, 8))
+    random.seed(0)
+    out = nu.read_combined_data(env, sample_m=10, sample_size=6)
+    poses = [r["pose_i"] for r in out]
+    assert poses[-10:] == list(range(20, 30))                     # newest sample_m records, in order
+    older = poses[:-10]
+    assert len(older) == 6 and all(p < 20 for p in older) and older == sorted(older)
+    assert [r["pose_i"] for r in nu.read_combined_data(env, sample_m=None)] == list(range(30))
+    random.seed(1)
+    assert len(nu.read_random_data_readonly(env, 7)) == 7
+
+
+def test_slice_label_analytic_wall_and_orientation():
+    # wall in the plane z = 10, x in [-5, 5], y in [0, 3]
+    v = np.array([[-5, 0, 10], [5, 0, 10], [5, 3, 10], [-5, 3, 10]], np.float32)
+    f = np.array([[0, 1, 2], [0, 2, 3]])
+    o = slice_obstacle(v, f, 1.5, 0.0, 0.0)
+    r, c = np.nonzero(o)
+    # row = (cz + 40 - z) * 3.2 = 96 -> pixel centres 95.5 / 96.5; columns (40 -+ 5) * 3.2 = 112 .. 144 (+- 1.04 px)
+    assert set(r) == {95, 96} and c.min() == 111 and c.max() == 144
+    assert slice_obstacle(v, f, 3.5, 0.0, 0.0).sum() == 0         # plane above the wall
+    # moving the camera by +x shifts the label towards larger columns (column ~ -(x - cx))
+    o2 = slice_obstacle(v, f, 1.5, 10.0, 0.0)
+    assert np.nonzero(o2)[1].min() == 111 + 32
+    # a wall along z at x = -20: a vertical line at column (40 + 20) * 3.2 = 192
+    v3 = np.array([[-20, 0, -5], [-20, 0, 5], [-20, 3, 5], [-20, 3, -5]], np.float32)
+    o3 = slice_obstacle(v3, f, 1.0, 0.0, 0.0)
+    assert set(np.nonzero(o3)[1]) == {191, 192}
+
+
+_DDP = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from nextbestpath_amd.trainers import train_nbp_model as T
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(300, 200), torch.nn.Linear(200, 3))
+T.BUCKET_BYTES = 100_000          # force several buckets (first layer alone exceeds one)
+for i, p in enumerate(net.parameters()):
+    p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+T.allreduce_gradients(net)
+ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(net.parameters()))
+n = T._common_count(5 + rank, torch.device("cpu"))
+print("OK" if ok and n == 5 else "BAD", flush=True)
+"""
+
+
+def test_gradient_allreduce_two_ranks_gloo(tmp_path):
+    script = tmp_path / "ddp.py"
+    script.write_text(_DDP)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script), ROOT],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("OK") == 2, out.stdout + out.stderr[-1000:]
