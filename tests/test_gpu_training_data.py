@@ -95,3 +95,43 @@ def test_train_nbp_entry_point_with_collection(hip, dataset, tmp_path):
     hist = json.load(open(tmp_path / "w" / "loss.json"))
     assert "1" in hist and np.isfinite(hist["1"]["training_loss"]) and np.isfinite(hist["1"]["validation_loss"])
     assert os.path.exists(tmp_path / "w" / "nbp_t_best_val.pth")
+
+
+_DDP_TRAIN = r"""
+import json, os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from nextbestpath_amd.testers.nbp_planning import load_params
+from nextbestpath_amd.trainers import train_nbp_model as T
+p = load_params(sys.argv[2])
+orig = T.train_nbp
+state = {}
+def spy(db, params, optimizer, nbp, *a, **k):
+    state["nbp"] = nbp
+    return orig(db, params, optimizer, nbp, *a, **k)
+T.train_nbp = spy
+T.run_training_nbp(p)
+import torch.distributed as dist
+chk = torch.cat([q.detach().double().flatten() for q in state["nbp"].parameters()]).cpu()
+print("CHK", dist.get_rank(), f"{chk.sum().item():.10e}", f"{chk.abs().sum().item():.10e}", flush=True)
+"""
+
+
+def test_two_rank_training_keeps_replicas_identical(hip, tmp_path):
+    """torchrun x2 (gloo rendezvous, both ranks on the one GPU): different data per rank, averaged gradients,
+    identical parameters afterwards."""
+    cfg = json.load(open(os.path.join(ROOT, "configs/nbp/nbp_default_training_config.json")))
+    cfg["_nbp"].update({"nbp_model_name": "nbp_ddp", "nbp_batch_size": 2, "grid_size": 64, "epochs": 1, "inner_epochs": 1,
+                        "samples_per_epoch": 4, "n_validation_synthetic": 2, "output_dir": str(tmp_path / "w"),
+                        "collect": False})
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    script = tmp_path / "ddp_train.py"
+    script.write_text(_DDP_TRAIN)
+    env = dict(os.environ, NBP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29641", str(script), ROOT, str(path)],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    lines = [l.split()[2:] for l in out.stdout.splitlines() if l.startswith("CHK")]
+    assert len(lines) == 2 and lines[0] == lines[1], out.stdout
+    assert os.path.exists(tmp_path / "w" / "loss.json")
