@@ -206,6 +206,163 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmArgsH a) {
     }
 }
 
+// ------------------------------------------------------------------ 3x3 convolution from an LDS-resident halo tile
+// The implicit-GEMM kernel above re-reads every input pixel nine times (once per tap) through the CU's vector
+// memory path, which at 128x128 tiles is as busy as the matrix pipe (64 B/clk/CU).  Here a workgroup owns an
+// 8 x 32 pixel tile of ONE image and BN output channels; per 64-channel chunk it DMAs the 10 x 34 pixel halo tile
+// into LDS once and runs all nine taps from it (A fragments are the halo rows shifted by the tap), streaming only
+// the weights of the next tap (double buffered) behind the current tap's MFMAs.  Vector-memory traffic per chunk
+// drops from 9*(256+BN)*128 B to (344 + 9*BN)*128 B.  Two workgroups share a CU (<= 76 KB of LDS each), so one
+// covers the other's halo reload.  Same K order as the implicit GEMM (chunk, tap, k): results are bit-identical.
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a) {
+    if (blockIdx.z) {
+        a.src0 = a.g_src0; a.src1 = a.g_src1; a.wpk = a.g_wpk; a.scale = a.g_scale; a.shift = a.g_shift; a.out = a.g_out;
+    }
+    constexpr int BN = TN * 32;
+    constexpr int HW_ = 34;                    // halo tile width (32 + 2)
+    constexpr int HALO_ROWS = 344;             // 10 * 34 = 340 halo pixels, padded to 43 DMA instructions of 8 rows
+    constexpr int HALO_BYTES = HALO_ROWS * 128;
+    constexpr int WB = BN * 128;               // one weight stage: BN rows of 64 bf16
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const halo = lds;
+    char* const wbuf = lds + HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = a.W >> 5, tiles_y = a.H >> 3;
+    int tile = blockIdx.x;
+    const int tx = tile % tiles_x; tile /= tiles_x;
+    const int ty = tile % tiles_y;
+    const int b = tile / tiles_y;
+    const int y0 = ty * 8, x0 = tx * 32;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- halo DMA coordinates: instruction q = 4 i + wave covers halo pixels 8 q .. 8 q + 7 (row-major 10 x 34)
+    int hpix[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int q = 4 * i + wave;
+        const int hr = 8 * q + (lane >> 3);
+        const int hy = hr / HW_, hx = hr - hy * HW_;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool ok = q < 43 && hr < 340 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        hpix[i] = ok ? (b * a.Hs + (yy >> a.ups)) * a.Ws + (xx >> a.ups) : -1;
+    }
+    const int hslot = lane & 7;                 // physical 16-B slot; logical = hslot ^ swz(halo row)
+    const int lrow = tid >> 3;
+    const int wslot = (tid & 7) ^ ((lrow >> 1) & 7);
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.src0), 0, a.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.src1 ? a.src1 : a.src0), 0, a.bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wpk), 0, a.bytesw, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    auto issue_halo = [&](int cc) {
+        const bool first = cc < a.cc0;
+        const int Cs = first ? a.C0 : a.C1;
+        const int cbase = (first ? cc : cc - a.cc0) * 64;
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            const int q = 4 * i + wave;
+            if (q < 43) {
+                const int sw = (4 * q + (lane >> 4)) & 7;                  // ((8 q + lane/8) >> 1) & 7
+                const unsigned off = hpix[i] >= 0 ? (unsigned)(hpix[i] * Cs + cbase + ((hslot ^ sw) << 3)) * 2u : OOB;
+                if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(halo + q * 1024), 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(halo + q * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    auto issue_w = [&](int t) {      // t = chunk * 9 + tap: the packed weights are [chunk][tap][N][64]
+        char* dst = wbuf + (t & 1) * WB + wave * 1024;
+        const unsigned woff = (unsigned)(((long long)t * a.N + n0 + lrow) * 64 + wslot * 8) * 2u;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + j * 4096), 16, woff + j * 4096, 0, 0, 0);
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int fb_row[TN], fb_sw[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = j * 32 + (lane & 31);
+        fb_row[j] = r * 128; fb_sw[j] = (r >> 1) & 7;
+    }
+    const int khalf = lane >> 5;
+    const int hbase = (2 * wave) * HW_ + (lane & 31);     // halo row of this lane's pixel for tap (-1,-1), M tile 0
+
+    const int chunks = a.chunks_total / 9;
+    const int t_total = chunks * 9;
+    issue_halo(0);
+    issue_w(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int cc = 0; cc < chunks; ++cc) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int t = cc * 9 + tap;
+            if (t + 1 < t_total) issue_w(t + 1);
+            const char* Bt = wbuf + (t & 1) * WB;
+            const int hr0 = hbase + (tap / 3) * HW_ + (tap % 3);
+            const int hr1 = hr0 + HW_;
+            const int ar0 = hr0 * 128, as0 = (hr0 >> 1) & 7, ar1 = hr1 * 128, as1 = (hr1 >> 1) & 7;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const int s = 2 * j4 + khalf;
+                const bf16x8 x0f = *reinterpret_cast<const bf16x8*>(halo + ar0 + ((s ^ as0) << 4));
+                const bf16x8 x1f = *reinterpret_cast<const bf16x8*>(halo + ar1 + ((s ^ as1) << 4));
+                bf16x8 wf[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    wf[j] = *reinterpret_cast<const bf16x8*>(Bt + fb_row[j] + ((s ^ fb_sw[j]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], x0f, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], x1f, acc[1][j], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (cc + 1 < chunks) {          // every wave is past its last read of this chunk's halo tile
+            issue_halo(cc + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane = pixel (lane & 31) of image row y0 + 2 wave + i, four consecutive channels per quad
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long long m = ((long long)b * a.H + y0 + 2 * wave + i) * a.W + x0 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int n = n0 + j * 32 + 8 * rq + 4 * khalf;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(acc[i][j][4 * rq + e], sc[e], sh[e]);
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    o[e] = f2bf(v);
+                }
+                *reinterpret_cast<u16x4*>(a.out + m * a.N + n) = o;
+            }
+        }
+    }
+}
+
 struct ReduceGroupH { const float* scale; const float* shift; bf16_t* out; };
 __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ partial_all, int split_k,
                                                                  long long MN, int N, ReduceGroupH g0, ReduceGroupH g1,
@@ -234,6 +391,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
 // ------------------------------------------------------------------ planning / launch
 static TileInfo tile_info_h(int tile) {
     switch (tile) {
+        case NBP_TILE_HALO_128: return {256, 128};
+        case NBP_TILE_HALO_64: return {256, 64};
         case NBP_TILE_128x128: return {128, 128};
         case NBP_TILE_256x64: return {256, 64};
         case NBP_TILE_256x32: return {256, 32};
@@ -243,8 +402,24 @@ static TileInfo tile_info_h(int tile) {
     }
 }
 
-ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int split_k, int groups) {
+static bool halo_ok(int H, int W, int N, int ksize, int bn) {
+    return ksize == 3 && H >= 8 && W >= 32 && (H & 7) == 0 && (W & 31) == 0 && N % bn == 0;
+}
+
+ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int split_k, int groups, int H, int W,
+                            int ksize) {
     ConvPlan p;
+    if (tile == NBP_TILE_AUTO && ksize == 3) {
+        // the halo kernel has no split-K: it needs >= 2 workgroups per CU from tiles alone
+        static const int allow = [] { const char* e = getenv("NBP_BF16_HALO"); return e ? atoi(e) : 1; }();
+        const int bn = N % 128 == 0 ? 128 : 64;
+        if (allow && halo_ok(H, W, N, ksize, bn) && (M / 256) * (N / bn) * groups >= 512)
+            tile = bn == 128 ? NBP_TILE_HALO_128 : NBP_TILE_HALO_64;
+    }
+    if (tile == NBP_TILE_HALO_128 || tile == NBP_TILE_HALO_64) {
+        p.tile = tile; p.split_k = 1; p.chunks_per_split = chunks_total;
+        return p;
+    }
     if (tile == NBP_TILE_AUTO) {
         if (N % 128 == 0)
             tile = nbp_cdiv(M, 128) * (N / 128) * groups >= 512 ? NBP_TILE_128x128 : NBP_TILE_64x128;
@@ -265,6 +440,21 @@ ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int 
     p.chunks_per_split = (int)nbp_cdiv(chunks_total, split_k);
     p.split_k = (int)nbp_cdiv(chunks_total, p.chunks_per_split);
     return p;
+}
+
+template <int TN>
+static int launch_halo(const IgemmArgsH& a, hipStream_t st) {
+    constexpr size_t smem = 344 * 128 + 2 * (size_t)TN * 32 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.M / 256), (unsigned)(a.N / (TN * 32)), (unsigned)a.groups);
+    conv3x3_halo_bf16_kernel<TN><<<grid, 256, smem, st>>>(a);
+    return nbp_launch_status();
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -310,9 +500,11 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
         a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0; a.bytesw = (unsigned)bw;
     }
     a.chunks_total = (C0 + C1) / 64 * a.taps;
-    ConvPlan p = nbp_plan_conv_bf16(a.M, N, a.chunks_total, tile, split_k, groups);
+    ConvPlan p = nbp_plan_conv_bf16(a.M, N, a.chunks_total, tile, split_k, groups, H, W, ksize);
     TileInfo ti = tile_info_h(p.tile);
     NBP_RETURN_IF(ti.bm == 0 || N % ti.bn, NBP_E_SHAPE);
+    if (p.tile == NBP_TILE_HALO_128 || p.tile == NBP_TILE_HALO_64)
+        NBP_RETURN_IF(!halo_ok(H, W, N, ksize, ti.bn), NBP_E_SHAPE);
     a.split_k = p.split_k; a.chunks_per_split = p.chunks_per_split;
     a.partial = nullptr;
     if (p.split_k > 1) {
@@ -326,6 +518,8 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
         case NBP_TILE_256x32: rc = launch_igemm_h<4, 1, 2, 1>(a, st); break;
         case NBP_TILE_128x64: rc = launch_igemm_h<2, 2, 2, 1>(a, st); break;
         case NBP_TILE_64x128: rc = launch_igemm_h<1, 4, 2, 1>(a, st); break;
+        case NBP_TILE_HALO_128: rc = launch_halo<4>(a, st); break;
+        case NBP_TILE_HALO_64: rc = launch_halo<2>(a, st); break;
         default: return NBP_E_ARG;
     }
     if (rc) return rc;

@@ -244,7 +244,9 @@ struct PathF32 {
     typedef float T;
     typedef ConvOperands Ops;
     static constexpr int CHUNK = 32;
-    static ConvPlan plan(long long M, int N, int chunks, int groups) { return nbp_plan_conv(M, N, chunks, 0, 0, groups); }
+    static ConvPlan plan(long long M, int N, int chunks, int groups, int = 0, int = 0) {
+        return nbp_plan_conv(M, N, chunks, 0, 0, groups);
+    }
     static int conv(const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks, int N, void* ws, size_t wsb,
                     hipStream_t st) {
         return nbp_conv_igemm_launch_g(o, o2, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st);
@@ -265,7 +267,9 @@ struct PathBF16 {
     typedef bf16_t T;
     typedef ConvOperandsH Ops;
     static constexpr int CHUNK = 64;
-    static ConvPlan plan(long long M, int N, int chunks, int groups) { return nbp_plan_conv_bf16(M, N, chunks, 0, 0, groups); }
+    static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0) {
+        return nbp_plan_conv_bf16(M, N, chunks, 0, 0, groups, H, H, ksize);
+    }
     static int conv(const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks, int N, void* ws, size_t wsb,
                     hipStream_t st) {
         return nbp_conv_igemm_bf16_launch_g(o, o2, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st);
@@ -331,7 +335,7 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
         if (tm && !rc) {
             const long long M = (long long)B * Hh * Hh;
             const int K = (C0 + C1) * ksize * ksize;
-            ConvPlan p = P::plan(M, N, K / P::CHUNK, ng);
+            ConvPlan p = P::plan(M, N, K / P::CHUNK, ng, Hh, ksize);
             tm->mark(name, 2.0 * ng * M * N * K, p.tile, p.split_k, M, N, K);
         }
     };

@@ -42,6 +42,11 @@ CASES = [
     (1, 2, 2, 1024, 0, 1024, 3, 0, 0, 0),    # bottleneck shape at S=32
     (1, 1, 1, 512, 0, 1024, 3, 0, 0, 0),     # 1x1 image: every tap but the centre is padding
     (2, 64, 64, 64, 0, 64, 3, 0, 0, 0),      # multi-block, both batch images
+    (1, 16, 32, 64, 0, 128, 3, 0, 1, 6),     # halo-tile kernel, BN = 128: 2 tiles, image borders on every side
+    (2, 8, 64, 128, 0, 64, 3, 0, 1, 7),      # halo-tile kernel, BN = 64, two chunks, two images
+    (1, 8, 16, 64, 0, 128, 3, 1, 1, 6),      # halo + fused x2 upsample (16 x 32 output)
+    (1, 16, 32, 64, 64, 256, 3, 0, 1, 6),    # halo + fused concat, two n blocks
+    (3, 24, 96, 64, 0, 64, 3, 0, 1, 7),      # halo, 3 x 3 tiles per image: interior tile has no padding at all
 ]
 
 
@@ -72,6 +77,30 @@ def test_conv_igemm_bf16_vs_exact(hip, case):
     assert bool((err <= bound).all()), f"max err {err.max().item()} at ref {ref.flatten()[err.argmax()].item()}"
     # most values are the correctly rounded ones
     assert (got == rbf(ref)).float().mean().item() > 0.97
+
+
+@pytest.mark.parametrize("tile", [6, 7])
+def test_halo_kernel_is_bit_identical_to_implicit_gemm(hip, tile):
+    """Same K order (chunk, tap, k) in both kernels: identical fp32 sums, identical bf16 outputs."""
+    dev = "cuda"
+    B, H, W, C, N = 2, 16, 64, 128, 128
+    x = nhwc(rbf(_rand(B, C, H, W, seed=21))).to(dev).to(torch.bfloat16)
+    w = _rand(N, C, 3, 3, seed=22, scale=0.05).to(dev)
+    wpk = pack_conv_bf16(w)
+    sc = (_rand(N, seed=23) * 0.2 + 1.0).to(dev); sh = (_rand(N, seed=24) * 0.1).to(dev)
+    a = conv_igemm_bf16(x, None, 0, wpk, N, 3, sc, sh, True, 1, tile)
+    b = conv_igemm_bf16(x, None, 0, wpk, N, 3, sc, sh, True, 1, 1 if tile == 6 else 4)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
+def test_halo_kernel_shape_errors(hip):
+    dev = "cuda"
+    x = torch.zeros(1, 12, 32, 64, device=dev, dtype=torch.bfloat16)     # H % 8 != 0
+    wpk = torch.zeros(9 * 64 * 64, device=dev, dtype=torch.bfloat16)
+    one = torch.ones(64, device=dev)
+    with pytest.raises(_lib.NbpHipError):
+        conv_igemm_bf16(x, None, 0, wpk, 64, 3, one, one, True, 1, 7)
 
 
 def test_conversions(hip):
