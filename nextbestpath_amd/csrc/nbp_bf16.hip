@@ -410,10 +410,12 @@ ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int 
                             int ksize) {
     ConvPlan p;
     if (tile == NBP_TILE_AUTO && ksize == 3) {
-        // the halo kernel has no split-K: it needs >= 2 workgroups per CU from tiles alone
+        // the halo kernel has no split-K; below ~128 workgroups the split-K implicit GEMM fills the chip better
+        // (threshold from tools/bench_forward.py sweeps at B = 1..8, S = 256 / 512)
         static const int allow = [] { const char* e = getenv("NBP_BF16_HALO"); return e ? atoi(e) : 1; }();
         const int bn = N % 128 == 0 ? 128 : 64;
-        if (allow && halo_ok(H, W, N, ksize, bn) && (M / 256) * (N / bn) * groups >= 512)
+        static const int min_blocks = [] { const char* e = getenv("NBP_BF16_HALO_MIN"); return e ? atoi(e) : 128; }();
+        if (allow && halo_ok(H, W, N, ksize, bn) && (M / 256) * (N / bn) * groups >= min_blocks)
             tile = bn == 128 ? NBP_TILE_HALO_128 : NBP_TILE_HALO_64;
     }
     if (tile == NBP_TILE_HALO_128 || tile == NBP_TILE_HALO_64) {
