@@ -71,7 +71,6 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
     constexpr int STAGE = (BM + BN) * 32;  // floats per LDS stage
     static_assert(WM * WN == 4, "256-thread workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in linear-id order.  A 3x3 tile
