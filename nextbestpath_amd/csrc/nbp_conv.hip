@@ -47,6 +47,7 @@ struct IgemmArgs {
     int chunks_total;
     int chunks_per_split;
     unsigned bytes0, bytes1;   // byte sizes of src0 / src1 (buffer-descriptor range, < 2 GiB)
+    unsigned bytesw;           // byte size of the packed weights (halo kernel streams them through a descriptor)
     float* partial;    // split-K scratch [group][split][M][N]
     // second problem of a grouped launch (same shapes, other tensors): blockIdx.z >= split_k
     int groups;
@@ -254,6 +255,159 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ 3x3 convolution from an LDS-resident halo tile
+// Same idea as conv3x3_halo_bf16_kernel (nbp_bf16.hip), for the exact-fp32 path: a workgroup owns an 8 x 32 pixel
+// tile of one image and BN output channels; per 32-channel chunk the 10 x 34 pixel halo tile is DMA'd into LDS once
+// (buffer_load ... lds, out-of-image pixels = out-of-range offsets = zeros) and all nine taps run from it, with the
+// next tap's weights streaming into a double buffer behind the current tap's 128 MFMAs per wave.  Compared with the
+// implicit GEMM the main loop has no gather arithmetic, no staging registers and no ds_write pass, and a barrier
+// every 8192 MFMA cycles instead of every 4096.  K order: (chunk, tap, channel) as in the implicit GEMM.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
+    if (blockIdx.z) {
+        a.src0 = a.g_src0; a.src1 = a.g_src1; a.wpk = a.g_wpk; a.scale = a.g_scale; a.shift = a.g_shift; a.out = a.g_out;
+    }
+    constexpr int BN = TN * 32;
+    constexpr int HW_ = 34;
+    constexpr int HALO_BYTES = 344 * 128;     // 10 * 34 = 340 halo pixels of 32 floats, padded to 43 DMA instructions
+    constexpr int WB = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    char* const halo = ldsb;
+    char* const wbuf = ldsb + HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = a.W >> 5, tiles_y = a.H >> 3;
+    int tile = blockIdx.x;
+    const int tx = tile % tiles_x; tile /= tiles_x;
+    const int ty = tile % tiles_y;
+    const int b = tile / tiles_y;
+    const int y0 = ty * 8, x0 = tx * 32;
+    const int n0 = blockIdx.y * BN;
+
+    int hpix[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int q = 4 * i + wave;
+        const int hr = 8 * q + (lane >> 3);
+        const int hy = hr / HW_, hx = hr - hy * HW_;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool ok = q < 43 && hr < 340 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        hpix[i] = ok ? (b * a.Hs + (yy >> a.ups)) * a.Ws + (xx >> a.ups) : -1;
+    }
+    const int hslot = lane & 7;
+    const int lrow = tid >> 3;
+    const int wslot = (tid & 7) ^ ((lrow >> 1) & 7);
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1 ? a.src1 : a.src0), 0, a.bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, a.bytesw, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    auto issue_halo = [&](int cc) {
+        const bool first = cc < a.cc0;
+        const int Cs = first ? a.C0 : a.C1;
+        const int cbase = (first ? cc : cc - a.cc0) * 32;
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            const int q = 4 * i + wave;
+            if (q < 43) {
+                const int sw = (4 * q + (lane >> 4)) & 7;
+                const unsigned off = hpix[i] >= 0 ? (unsigned)(hpix[i] * Cs + cbase + ((hslot ^ sw) << 2)) * 4u : OOB;
+                if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(halo + q * 1024), 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(halo + q * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    auto issue_w = [&](int t) {      // t = chunk * 9 + tap; packed weights are [chunk][tap][N][32]
+        char* dst = wbuf + (t & 1) * WB + wave * 1024;
+        const unsigned woff = (unsigned)(((long long)t * a.N + n0 + lrow) * 32 + wslot * 4) * 4u;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + j * 4096), 16, woff + j * 4096, 0, 0, 0);
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int fb_row[TN], fb_sw[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = j * 32 + (lane & 31);
+        fb_row[j] = r * 128; fb_sw[j] = (r >> 1) & 7;
+    }
+    const int khalf = lane >> 5;
+    const int hbase = (2 * wave) * HW_ + (lane & 31);
+
+    const int chunks = a.chunks_total / 9;
+    const int t_total = chunks * 9;
+    issue_halo(0);
+    issue_w(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int cc = 0; cc < chunks; ++cc) {
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int t = cc * 9 + tap;
+            if (t + 1 < t_total) issue_w(t + 1);
+            const char* Bt = wbuf + (t & 1) * WB;
+            const int hr0 = hbase + (tap / 3) * HW_ + (tap % 3);
+            const int hr1 = hr0 + HW_;
+            const int ar0 = hr0 * 128, as0 = (hr0 >> 1) & 7, ar1 = hr1 * 128, as1 = (hr1 >> 1) & 7;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const int s = 2 * j4 + khalf;
+                const f32x4 x0f = *reinterpret_cast<const f32x4*>(halo + ar0 + ((s ^ as0) << 4));
+                const f32x4 x1f = *reinterpret_cast<const f32x4*>(halo + ar1 + ((s ^ as1) << 4));
+                f32x4 wf[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    wf[j] = *reinterpret_cast<const f32x4*>(Bt + fb_row[j] + ((s ^ fb_sw[j]) << 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0f[e], wf[j][e], acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1f[e], wf[j][e], acc[1][j], 0, 0, 0);
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (cc + 1 < chunks) {
+            issue_halo(cc + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (A = pixels, B = weights): col n = lane & 31, pixel x = (r&3) + 8 (r>>2) + 4 (lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32 + (lane & 31);
+        const float sc = a.scale[n], sh = a.shift[n];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long mrow = ((long long)b * a.H + y0 + 2 * wave + i) * a.W + x0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int px = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                float v = acc[i][j][r] * sc + sh;
+                if (a.relu) v = fmaxf(v, 0.f);
+                a.out[(mrow + px) * a.N + n] = v;
+            }
+        }
+    }
+}
+
 // out[m][n] = act(sum_s partial[s][m][n] * scale[n] + shift[n]);  N % 4 == 0; blockIdx.y = group
 struct ReduceGroup { const float* scale; const float* shift; float* out; };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial_all, int split_k,
@@ -284,6 +438,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // ------------------------------------------------------------------ tile table / planning
 static TileInfo tile_info(int tile) {
     switch (tile) {
+        case NBP_TILE_HALO_128: return {256, 128};
+        case NBP_TILE_HALO_64: return {256, 64};
         case NBP_TILE_128x128: return {128, 128};
         case NBP_TILE_256x64: return {256, 64};
         case NBP_TILE_256x32: return {256, 32};
@@ -294,7 +450,24 @@ static TileInfo tile_info(int tile) {
 }
 
 // Shared by the forward, the single-layer entry point and the workspace query.
-ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k, int groups) {
+static bool halo_ok_f32(int H, int W, int N, int ksize, int bn) {
+    return ksize == 3 && H >= 8 && W >= 32 && (H & 7) == 0 && (W & 31) == 0 && N % bn == 0;
+}
+
+ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k, int groups, int H, int W, int ksize) {
+    if (tile == NBP_TILE_AUTO && ksize == 3 && split_k <= 0) {
+        // halo-tile kernel (no split-K) once tiles alone fill the chip; NBP_F32_HALO=0 disables, NBP_F32_HALO_MIN tunes
+        static const int allow = [] { const char* e = getenv("NBP_F32_HALO"); return e ? atoi(e) : 1; }();
+        static const int min_blocks = [] { const char* e = getenv("NBP_F32_HALO_MIN"); return e ? atoi(e) : 256; }();
+        const int bn = N % 128 == 0 ? 128 : 64;
+        if (allow && halo_ok_f32(H, W, N, ksize, bn) && (M / 256) * (N / bn) * groups >= min_blocks)
+            tile = bn == 128 ? NBP_TILE_HALO_128 : NBP_TILE_HALO_64;
+    }
+    if (tile == NBP_TILE_HALO_128 || tile == NBP_TILE_HALO_64) {
+        ConvPlan h;
+        h.tile = tile; h.split_k = 1; h.chunks_per_split = chunks_total;
+        return h;
+    }
     // Policy from tools/bench_conv.py --sweep on MI355X (B = 1, 2, 8; SURVEY.md A.1 shapes): the big
     // 128x128 / 256x64 tiles only pay once they alone give >= 512 workgroups (2 per CU); with fewer
     // tiles the half-size tiles (64x128, 128x64) reach the same workgroup count with half the split-K,
@@ -322,6 +495,21 @@ ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split
     p.chunks_per_split = (int)nbp_cdiv(chunks_total, split_k);
     p.split_k = (int)nbp_cdiv(chunks_total, p.chunks_per_split);
     return p;
+}
+
+template <int TN>
+static int launch_halo_f32(const IgemmArgs& a, hipStream_t st) {
+    constexpr size_t smem = 344 * 128 + 2 * (size_t)TN * 32 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f32_kernel<TN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.M / 256), (unsigned)(a.N / (TN * 32)), (unsigned)a.groups);
+    conv3x3_halo_f32_kernel<TN><<<grid, 256, smem, st>>>(a);
+    return nbp_launch_status();
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -366,11 +554,15 @@ int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C
         const long long b0 = (long long)B * a.Hs * a.Ws * C0 * 4, b1 = (long long)B * a.Hs * a.Ws * C1 * 4;
         NBP_RETURN_IF(b0 >= (1ll << 31) || b1 >= (1ll << 31), NBP_E_SHAPE);   // 32-bit buffer offsets
         a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0;
+        const long long bw = (long long)(C0 + C1) * a.taps * N * 4;
+        a.bytesw = bw < (1ll << 31) ? (unsigned)bw : 0u;
     }
     a.chunks_total = (C0 + C1) / 32 * a.taps;
-    ConvPlan p = nbp_plan_conv(a.M, N, a.chunks_total, tile, split_k, groups);
+    ConvPlan p = nbp_plan_conv(a.M, N, a.chunks_total, tile, split_k, groups, H, W, ksize);
     TileInfo ti = tile_info(p.tile);
     NBP_RETURN_IF(ti.bm == 0 || N % ti.bn, NBP_E_SHAPE);
+    if (p.tile == NBP_TILE_HALO_128 || p.tile == NBP_TILE_HALO_64)
+        NBP_RETURN_IF(!halo_ok_f32(H, W, N, ksize, ti.bn) || a.bytesw == 0, NBP_E_SHAPE);
     a.split_k = p.split_k; a.chunks_per_split = p.chunks_per_split;
     {   // XCD-contiguous tile runs cut the L2-miss traffic of the 3x3 halo rows; measured on MI355X they are
         // neutral-to-better (+2 %) once the grid is several waves deep and cost up to 10 % on single-wave grids,
@@ -391,6 +583,8 @@ int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C
         case NBP_TILE_256x32: rc = launch_igemm<4, 1, 2, 1>(a, st); break;
         case NBP_TILE_128x64: rc = launch_igemm<2, 2, 2, 1>(a, st); break;
         case NBP_TILE_64x128: rc = launch_igemm<1, 4, 2, 1>(a, st); break;
+        case NBP_TILE_HALO_128: rc = launch_halo_f32<4>(a, st); break;
+        case NBP_TILE_HALO_64: rc = launch_halo_f32<2>(a, st); break;
         default: return NBP_E_ARG;
     }
     if (rc) return rc;

@@ -244,8 +244,8 @@ struct PathF32 {
     typedef float T;
     typedef ConvOperands Ops;
     static constexpr int CHUNK = 32;
-    static ConvPlan plan(long long M, int N, int chunks, int groups, int = 0, int = 0) {
-        return nbp_plan_conv(M, N, chunks, 0, 0, groups);
+    static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0) {
+        return nbp_plan_conv(M, N, chunks, 0, 0, groups, H, H, ksize);
     }
     static int conv(const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks, int N, void* ws, size_t wsb,
                     hipStream_t st) {

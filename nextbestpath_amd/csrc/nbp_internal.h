@@ -6,13 +6,14 @@ typedef unsigned short bf16_t;   // bf16 storage
 
 enum { NBP_TILE_AUTO = 0, NBP_TILE_128x128 = 1, NBP_TILE_256x64 = 2, NBP_TILE_256x32 = 3, NBP_TILE_128x64 = 4,
        NBP_TILE_64x128 = 5,
-       NBP_TILE_HALO_128 = 6, NBP_TILE_HALO_64 = 7 };   // bf16 only: 8x32-pixel halo-tile kernel, BN = 128 / 64
+       NBP_TILE_HALO_128 = 6, NBP_TILE_HALO_64 = 7 };   // 8x32-pixel halo-tile kernels (3x3 only), BN = 128 / 64
 struct TileInfo { int bm, bn; };
 struct ConvPlan { int tile; int split_k; int chunks_per_split; };
 
 // fp32 path (nbp_conv.hip)
 struct ConvOperands { const float* src0; const float* src1; const float* wpk; const float* scale; const float* shift; float* out; };
-ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k, int groups);
+ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k, int groups, int H = 0, int W = 0,
+                       int ksize = 0);
 int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C0, int C1, int ups, int B, int H, int W,
                             int ksize, int N, int relu, int split_k, int tile, void* ws, size_t ws_bytes, hipStream_t st);
 

@@ -34,6 +34,11 @@ CONV_CASES = [
     (2, 8, 8, 128, 128, 64, 1, 0, 1, 0),     # attention-style 1x1 over [g|x]
     (1, 2, 2, 1024, 0, 1024, 3, 0, 0, 0),    # bottleneck shape at S=32 (M=4, K=9216)
     (1, 1, 1, 512, 0, 1024, 3, 0, 0, 0),     # S=16 bottleneck: 1x1 image, all taps but centre OOB
+    (1, 16, 32, 64, 0, 128, 3, 0, 0, 6),     # halo-tile kernel, BN = 128: image borders on every side
+    (2, 8, 64, 96, 0, 64, 3, 0, 0, 7),       # halo-tile kernel, BN = 64, three chunks, two images
+    (1, 8, 16, 64, 0, 128, 3, 1, 0, 6),      # halo + fused x2 upsample (16 x 32 output)
+    (1, 16, 32, 32, 64, 256, 3, 0, 0, 6),    # halo + fused concat, two n blocks
+    (3, 24, 96, 32, 0, 64, 3, 0, 0, 7),      # halo, 3 x 3 tiles per image: an interior tile without padding
 ]
 
 
