@@ -37,7 +37,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfm
 PEAK_HBM_GBS = 8000.0
 TILE_NAMES = {1: "igemm_conv_kernel<2,2,2,2>(128x128)", 2: "igemm_conv_kernel<4,1,2,2>(256x64)",
               3: "igemm_conv_kernel<4,1,2,1>(256x32)", 4: "igemm_conv_kernel<2,2,2,1>(128x64)",
-              5: "igemm_conv_kernel<1,4,2,1>(64x128)"}
+              5: "igemm_conv_kernel<1,4,2,1>(64x128)", 6: "conv3x3_halo_f32_kernel<4>(8x32 px x 128 ch)",
+              7: "conv3x3_halo_f32_kernel<2>(8x32 px x 64 ch)"}
 
 
 def parse():
@@ -229,7 +230,7 @@ def main():
                     "algorithmic_bytes_per_launch": round(alg_bytes / d["launches"]),
                     "launches_per_forward": d["launches"],
                     "avg_launch_ms": round(d["ms"] / d["launches"], 5), "flops_per_launch": d["flops"] / d["launches"],
-                    "note": "avg_launch_ms brackets the igemm launch plus its split-K reduce (event pair per layer)",
+                    "note": "avg_launch_ms: HIP event pair per layer on the launch stream (a split-K layer includes its reduce)",
                     "all_igemm_tflops": round(cf / (cm * 1e-3) / 1e12, 3),
                     "all_igemm_frac": round(cf / (cm * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
         if args.layers:

@@ -216,7 +216,9 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmArgsH a) {
 // covers the other's halo reload.  Same K order as the implicit GEMM (chunk, tap, k): results are bit-identical.
 template <int TN>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a) {
-    if (blockIdx.z) {
+    int zs = blockIdx.z;        // split-K slice (of 64-channel chunks), then the group
+    if (zs >= a.split_k) {
+        zs -= a.split_k;
         a.src0 = a.g_src0; a.src1 = a.g_src1; a.wpk = a.g_wpk; a.scale = a.g_scale; a.shift = a.g_shift; a.out = a.g_out;
     }
     constexpr int BN = TN * 32;
@@ -299,13 +301,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
     const int khalf = lane >> 5;
     const int hbase = (2 * wave) * HW_ + (lane & 31);     // halo row of this lane's pixel for tap (-1,-1), M tile 0
 
-    const int chunks = a.chunks_total / 9;
+    const int cc_begin = zs * (a.chunks_per_split / 9);
+    const int chunks = min(cc_begin + a.chunks_per_split / 9, a.chunks_total / 9);
     const int t_total = chunks * 9;
-    issue_halo(0);
-    issue_w(0);
+    if (cc_begin < chunks) {
+        issue_halo(cc_begin);
+        issue_w(cc_begin * 9);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int cc = 0; cc < chunks; ++cc) {
+    for (int cc = cc_begin; cc < chunks; ++cc) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int t = cc * 9 + tap;
@@ -340,6 +345,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
     }
 
     // ---- epilogue: lane = pixel (lane & 31) of image row y0 + 2 wave + i, four consecutive channels per quad
+    const bool final_out = (a.split_k == 1);
+    float* part = final_out ? nullptr : a.partial + (long long)blockIdx.z * a.M * a.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const long long m = ((long long)b * a.H + y0 + 2 * wave + i) * a.W + x0 + (lane & 31);
@@ -348,6 +355,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 const int n = n0 + j * 32 + 8 * rq + 4 * khalf;
+                if (!final_out) {
+                    const f32x4 v = {acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]};
+                    *reinterpret_cast<f32x4*>(part + m * a.N + n) = v;
+                    continue;
+                }
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
                 u16x4 o;
@@ -409,17 +421,27 @@ static bool halo_ok(int H, int W, int N, int ksize, int bn) {
 ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int split_k, int groups, int H, int W,
                             int ksize) {
     ConvPlan p;
-    if (tile == NBP_TILE_AUTO && ksize == 3) {
-        // the halo kernel has no split-K; below ~128 workgroups the split-K implicit GEMM fills the chip better
+    if (tile == NBP_TILE_AUTO && ksize == 3 && split_k <= 0) {
+        // halo-tile kernel once tiles (x split-K over whole chunks) give >= ~128 workgroups
         // (threshold from tools/bench_forward.py sweeps at B = 1..8, S = 256 / 512)
         static const int allow = [] { const char* e = getenv("NBP_BF16_HALO"); return e ? atoi(e) : 1; }();
         const int bn = N % 128 == 0 ? 128 : 64;
         static const int min_blocks = [] { const char* e = getenv("NBP_BF16_HALO_MIN"); return e ? atoi(e) : 128; }();
-        if (allow && halo_ok(H, W, N, ksize, bn) && (M / 256) * (N / bn) * groups >= min_blocks)
+        const long long blocks = (M / 256) * (N / bn) * groups;
+        const int cc = chunks_total / 9;
+        int sk = 1;
+        while (blocks * sk < min_blocks && cc / (sk * 2) >= 4 && sk < 16) sk *= 2;
+        if (allow && halo_ok(H, W, N, ksize, bn) && blocks * sk >= min_blocks) {
             tile = bn == 128 ? NBP_TILE_HALO_128 : NBP_TILE_HALO_64;
+            split_k = sk;
+        }
     }
     if (tile == NBP_TILE_HALO_128 || tile == NBP_TILE_HALO_64) {
-        p.tile = tile; p.split_k = 1; p.chunks_per_split = chunks_total;
+        const int cc = chunks_total / 9;
+        int sk = split_k <= 0 ? 1 : split_k;
+        if (sk > cc) sk = cc;
+        const int per = (int)nbp_cdiv(cc, sk);
+        p.tile = tile; p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per * 9;
         return p;
     }
     if (tile == NBP_TILE_AUTO) {
@@ -454,7 +476,7 @@ static int launch_halo(const IgemmArgsH& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((unsigned)(a.M / 256), (unsigned)(a.N / (TN * 32)), (unsigned)a.groups);
+    dim3 grid((unsigned)(a.M / 256), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups));
     conv3x3_halo_bf16_kernel<TN><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }

@@ -266,7 +266,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int TN>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
-    if (blockIdx.z) {
+    int zs = blockIdx.z;        // split-K slice (of 32-channel chunks), then the group
+    if (zs >= a.split_k) {
+        zs -= a.split_k;
         a.src0 = a.g_src0; a.src1 = a.g_src1; a.wpk = a.g_wpk; a.scale = a.g_scale; a.shift = a.g_shift; a.out = a.g_out;
     }
     constexpr int BN = TN * 32;
@@ -347,13 +349,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
     const int khalf = lane >> 5;
     const int hbase = (2 * wave) * HW_ + (lane & 31);
 
-    const int chunks = a.chunks_total / 9;
+    // chunks_per_split / chunks_total count (chunk, tap) pairs as in the implicit GEMM; a slice is whole chunks
+    const int cc_begin = zs * (a.chunks_per_split / 9);
+    const int chunks = min(cc_begin + a.chunks_per_split / 9, a.chunks_total / 9);
     const int t_total = chunks * 9;
-    issue_halo(0);
-    issue_w(0);
+    if (cc_begin < chunks) {
+        issue_halo(cc_begin);
+        issue_w(cc_begin * 9);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int cc = 0; cc < chunks; ++cc) {
+    for (int cc = cc_begin; cc < chunks; ++cc) {
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int t = cc * 9 + tap;
@@ -390,19 +396,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
     }
 
     // ---- epilogue (A = pixels, B = weights): col n = lane & 31, pixel x = (r&3) + 8 (r>>2) + 4 (lane>>5)
+    const bool final_out = (a.split_k == 1);
+    float* outp = final_out ? a.out : a.partial + (long long)blockIdx.z * a.M * a.N;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 32 + (lane & 31);
-        const float sc = a.scale[n], sh = a.shift[n];
+        float sc = 1.f, sh = 0.f;
+        if (final_out) { sc = a.scale[n]; sh = a.shift[n]; }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const long long mrow = ((long long)b * a.H + y0 + 2 * wave + i) * a.W + x0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int px = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                float v = acc[i][j][r] * sc + sh;
-                if (a.relu) v = fmaxf(v, 0.f);
-                a.out[(mrow + px) * a.N + n] = v;
+                float v = acc[i][j][r];
+                if (final_out) {
+                    v = v * sc + sh;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                }
+                outp[(mrow + px) * a.N + n] = v;
             }
         }
     }
@@ -460,12 +472,24 @@ ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split
         static const int allow = [] { const char* e = getenv("NBP_F32_HALO"); return e ? atoi(e) : 1; }();
         static const int min_blocks = [] { const char* e = getenv("NBP_F32_HALO_MIN"); return e ? atoi(e) : 256; }();
         const int bn = N % 128 == 0 ? 128 : 64;
-        if (allow && halo_ok_f32(H, W, N, ksize, bn) && (M / 256) * (N / bn) * groups >= min_blocks)
+        // split-K over whole 32-channel chunks may fill the chip when the tiles alone do not (each slice keeps
+        // >= 2 chunks = 18 (chunk, tap) steps)
+        const long long blocks = (M / 256) * (N / bn) * groups;
+        const int cc = chunks_total / 9;
+        int sk = 1;
+        while (blocks * sk < min_blocks && cc / (sk * 2) >= 2 && sk < 16) sk *= 2;
+        if (allow && halo_ok_f32(H, W, N, ksize, bn) && blocks * sk >= min_blocks) {
             tile = bn == 128 ? NBP_TILE_HALO_128 : NBP_TILE_HALO_64;
+            split_k = sk;
+        }
     }
     if (tile == NBP_TILE_HALO_128 || tile == NBP_TILE_HALO_64) {
         ConvPlan h;
-        h.tile = tile; h.split_k = 1; h.chunks_per_split = chunks_total;
+        const int cc = chunks_total / 9;
+        int sk = split_k <= 0 ? 1 : split_k;
+        if (sk > cc) sk = cc;
+        const int per = (int)nbp_cdiv(cc, sk);
+        h.tile = tile; h.split_k = (int)nbp_cdiv(cc, per); h.chunks_per_split = per * 9;
         return h;
     }
     // Policy from tools/bench_conv.py --sweep on MI355X (B = 1, 2, 8; SURVEY.md A.1 shapes): the big
@@ -507,7 +531,7 @@ static int launch_halo_f32(const IgemmArgs& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((unsigned)(a.M / 256), (unsigned)(a.N / (TN * 32)), (unsigned)a.groups);
+    dim3 grid((unsigned)(a.M / 256), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups));
     conv3x3_halo_f32_kernel<TN><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }

@@ -288,8 +288,8 @@ struct PathBF16 {
 };
 
 template <typename P>
-size_t splitk_scratch_floats(long long M, int N, int cin_total, int taps, int groups = 1) {
-    ConvPlan p = P::plan(M, N, cin_total / P::CHUNK * taps, groups);
+size_t splitk_scratch_floats(long long M, int N, int cin_total, int taps, int groups, int H) {
+    ConvPlan p = P::plan(M, N, cin_total / P::CHUNK * taps, groups, H, taps == 9 ? 3 : 1);
     return p.split_k > 1 ? (size_t)groups * p.split_k * M * N : 0;
 }
 
@@ -310,13 +310,14 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
         sk = 0;
         for (int e = 0; e < 5; ++e, s /= 2) {
             long long M = (long long)B * s * s;
-            if (e > 0) sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e - 1], 9));
-            sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e], 9));
+            if (e > 0) sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e - 1], 9, 1, s));
+            sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e], 9, 1, s));
             if (e < 4) {   // decoder level at this resolution: co = enc[e], ci = enc[e+1]
                 for (int g = 1; g <= 2; ++g) {      // levels 5 and 4 run both decoders in one grouped launch
-                    sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e + 1], 9, g));
-                    sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e], 9, g));
-                    sk = max(sk, splitk_scratch_floats<P>(M, enc[e] / 2, 2 * enc[e], 1, g));
+                    sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e + 1], 9, g, s));
+                    sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e], 9, g, s));
+                    sk = max(sk, splitk_scratch_floats<P>(M, enc[e], 2 * enc[e], 9, g, s));
+                    sk = max(sk, splitk_scratch_floats<P>(M, enc[e] / 2, 2 * enc[e], 1, g, s));
                 }
             }
         }

@@ -47,6 +47,8 @@ CASES = [
     (1, 8, 16, 64, 0, 128, 3, 1, 1, 6),      # halo + fused x2 upsample (16 x 32 output)
     (1, 16, 32, 64, 64, 256, 3, 0, 1, 6),    # halo + fused concat, two n blocks
     (3, 24, 96, 64, 0, 64, 3, 0, 1, 7),      # halo, 3 x 3 tiles per image: interior tile has no padding at all
+    (1, 8, 32, 512, 0, 128, 3, 0, 4, 6),     # halo + split-K over whole chunks (8 chunks / 4)
+    (1, 16, 32, 192, 128, 64, 3, 0, 2, 7),   # halo + ragged split (5 chunks / 2) across the concat seam
 ]
 
 

@@ -39,6 +39,8 @@ CONV_CASES = [
     (1, 8, 16, 64, 0, 128, 3, 1, 0, 6),      # halo + fused x2 upsample (16 x 32 output)
     (1, 16, 32, 32, 64, 256, 3, 0, 0, 6),    # halo + fused concat, two n blocks
     (3, 24, 96, 32, 0, 64, 3, 0, 0, 7),      # halo, 3 x 3 tiles per image: an interior tile without padding
+    (1, 8, 32, 256, 0, 128, 3, 0, 4, 6),     # halo + split-K over whole chunks (8 chunks / 4)
+    (1, 16, 32, 96, 64, 64, 3, 0, 2, 7),     # halo + split-K with a ragged split (5 chunks / 2) across the concat seam
 ]
 
 
