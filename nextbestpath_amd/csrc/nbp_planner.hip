@@ -122,42 +122,76 @@ __global__ __launch_bounds__(256) void coverage_bin_kernel(const float* __restri
     }
 }
 
-// K2: exclusive scan of count[0..ncell) -> start[0..ncell]: one 1024-thread block walks the array in
-// coalesced tiles of 4096 ints (int4 per thread), wave scans by shuffle, 16 wave totals through LDS.
-__global__ __launch_bounds__(1024) void coverage_scan_kernel(const int* __restrict__ count, long long ncell,
-                                                             int* __restrict__ start) {
-    __shared__ int wtot[16];
-    __shared__ int carry_s;
+// K2: exclusive scan of count[0..ncell) -> start[0..ncell] in three launches that use the whole chip (a single
+// block walking the array tile by tile pays one global-memory round trip per tile: 34 us for 140 k cells):
+// (a) per-block sums of 4096-int tiles, (b) one block scans the <= 4096 tile sums, (c) per-tile scan + offset.
+constexpr int SCAN_TILE = 4096;
+__device__ __forceinline__ int block_exclusive_scan_256(int mine, int* wtot /*[4]*/, int* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(inc, o);
+        if (lane >= o) inc += n;
+    }
+    if (lane == 63) wtot[wave] = inc;
     __syncthreads();
-    for (long long t0 = 0; t0 < ncell; t0 += 4096) {
-        const long long i = t0 + 4 * (long long)threadIdx.x;
-        int v[4];
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    if (total) *total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    return base + inc - mine;
+}
+
+__global__ __launch_bounds__(256) void coverage_tilesum_kernel(const int* __restrict__ count, long long ncell,
+                                                               int* __restrict__ tsum) {
+    __shared__ int wtot[4];
+    const long long i0 = (long long)blockIdx.x * SCAN_TILE + 16 * (long long)threadIdx.x;
+    int mine = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = i + e < ncell ? count[i + e] : 0;
-        const int mine = v[0] + v[1] + v[2] + v[3];
-        int inc = mine;
+    for (int e = 0; e < 16; ++e) mine += i0 + e < ncell ? count[i0 + e] : 0;
+    int total;
+    (void)block_exclusive_scan_256(mine, wtot, &total);
+    if (threadIdx.x == 0) tsum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void coverage_tilescan_kernel(int* __restrict__ tsum, int ntiles, int* __restrict__ start,
+                                                                long long ncell) {
+    __shared__ int wtot[4];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < ntiles; t0 += 256 * 16) {           // one pass for up to 4096 tiles (16 M cells)
+        int v[16], mine = 0;
+        const int i0 = t0 + 16 * threadIdx.x;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int n = __shfl_up(inc, o);
-            if (lane >= o) inc += n;
-        }
-        if (lane == 63) wtot[wave] = inc;
-        __syncthreads();
-        int base = carry_s;
-        for (int w = 0; w < wave; ++w) base += wtot[w];
-        int run = base + inc - mine;
+        for (int e = 0; e < 16; ++e) { v[e] = i0 + e < ntiles ? tsum[i0 + e] : 0; mine += v[e]; }
+        int total;
+        int run = carry + block_exclusive_scan_256(mine, wtot, &total);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (i + e < ncell) start[i + e] = run;
+        for (int e = 0; e < 16; ++e) {
+            if (i0 + e < ntiles) tsum[i0 + e] = run;
             run += v[e];
         }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = run;
+        if (threadIdx.x == 0) carry += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) start[ncell] = carry_s;
+    if (threadIdx.x == 0) start[ncell] = carry;
+}
+
+__global__ __launch_bounds__(256) void coverage_scan_kernel(const int* __restrict__ count, long long ncell,
+                                                            const int* __restrict__ toff, int* __restrict__ start) {
+    __shared__ int wtot[4];
+    const long long i0 = (long long)blockIdx.x * SCAN_TILE + 16 * (long long)threadIdx.x;
+    int v[16], mine = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { v[e] = i0 + e < ncell ? count[i0 + e] : 0; mine += v[e]; }
+    int run = toff[blockIdx.x] + block_exclusive_scan_256(mine, wtot, nullptr);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if (i0 + e < ncell) start[i0 + e] = run;
+        run += v[e];
+    }
 }
 
 // K3: scatter the sampled points into cell order.
@@ -171,37 +205,47 @@ __global__ __launch_bounds__(256) void coverage_scatter_kernel(const float* __re
     }
 }
 
-// K4: 16 lanes per GT point.
+// K4: 16 lanes per GT point.  The nine (x, y) cell columns around the point (each a contiguous run of up to three
+// z cells in the sorted array) are looked up by nine lanes at once; the runs are then walked 16 points at a time,
+// centre column first (a covered point usually finds its neighbour there and the group leaves after one round).
 __global__ __launch_bounds__(256) void coverage_query_kernel(const float* __restrict__ gt, int G, Grid g, float thr,
                                                              const float* __restrict__ sorted, const int* __restrict__ start,
                                                              int* __restrict__ count) {
     const int sub = threadIdx.x & 15;
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int grp_shift = threadIdx.x & 48;            // first lane of this 16-lane group inside the wave
     bool found = false;
+    float x = 0.f, y = 0.f, z = 0.f;
+    int lo = 0, hi = 0;
     if (i < G) {
-        const float x = gt[3 * i], y = gt[3 * i + 1], z = gt[3 * i + 2];
+        x = gt[3 * i]; y = gt[3 * i + 1]; z = gt[3 * i + 2];
         int c[3];
         grid_cell(g, x, y, z, c);
-        const int d0 = max(c[2] - 1, 0), d1 = min(c[2] + 1, g.n[2] - 1);
-        for (int a = max(c[0] - 1, 0); a <= min(c[0] + 1, g.n[0] - 1) && !found; ++a)
-            for (int b = max(c[1] - 1, 0); b <= min(c[1] + 1, g.n[1] - 1) && !found; ++b) {
+        if (sub < 9) {
+            // column order: centre, then the 4 edge neighbours, then the 4 corners
+            const int ox[9] = {0, -1, 1, 0, 0, -1, -1, 1, 1}, oy[9] = {0, 0, 0, -1, 1, -1, 1, -1, 1};
+            const int a = c[0] + ox[sub], b = c[1] + oy[sub];
+            if (a >= 0 && a < g.n[0] && b >= 0 && b < g.n[1]) {
+                const int d0 = max(c[2] - 1, 0), d1 = min(c[2] + 1, g.n[2] - 1);
                 const int base = (a * g.n[1] + b) * g.n[2];
-                const int lo = start[base + d0], hi = start[base + d1 + 1];
-                for (int j0 = lo; j0 < hi && !found; j0 += 16) {
-                    const int j = j0 + sub;
-                    bool hit = false;
-                    if (j < hi) {
-                        const float ex = x - sorted[3 * j], ey = y - sorted[3 * j + 1], ez = z - sorted[3 * j + 2];
-                        hit = sqrtf((ex * ex + ey * ey) + ez * ez) < thr;
-                    }
-                    // any lane of this 16-lane group
-                    const unsigned long long bal = __ballot(hit);
-                    const int grp = (threadIdx.x & 63) >> 4;
-                    found = ((bal >> (16 * grp)) & 0xffffull) != 0;
-                }
+                lo = start[base + d0]; hi = start[base + d1 + 1];
             }
+        }
     }
-    const unsigned long long fb = __ballot(found && sub == 0);
+    for (int col = 0; col < 9; ++col) {
+        const int clo = __shfl(lo, grp_shift + col), chi = __shfl(hi, grp_shift + col);
+        for (int j0 = clo; j0 < chi && !found; j0 += 16) {
+            const int j = j0 + sub;
+            bool hit = false;
+            if (j < chi) {
+                const float ex = x - sorted[3 * j], ey = y - sorted[3 * j + 1], ez = z - sorted[3 * j + 2];
+                hit = sqrtf((ex * ex + ey * ey) + ez * ez) < thr;
+            }
+            const unsigned long long bal = __ballot(hit);
+            found = ((bal >> grp_shift) & 0xffffull) != 0;
+        }
+    }
+    const unsigned long long fb = __ballot(found && sub == 0 && i < G);
     if ((threadIdx.x & 63) == 0 && fb) atomicAdd(count, __popcll(fb));
 }
 
@@ -257,7 +301,7 @@ extern "C" size_t nbp_coverage_workspace_bytes(const float* bbox_lo_host, const 
     if (!bbox_lo_host || !bbox_hi_host || !(threshold > 0) || sample_k < 1) return 0;
     if (coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell)) return 0;
     return al256(ncell * 4) + al256((ncell + 1) * 4) + 2 * al256((size_t)sample_k * 4) +
-           2 * al256((size_t)sample_k * 12) + 512;
+           2 * al256((size_t)sample_k * 12) + al256((ncell / SCAN_TILE + 1) * 4) + 512;
 }
 
 extern "C" int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3, long long N, const long long* N_dev_or_null,
@@ -277,7 +321,9 @@ extern "C" int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3,
     int* cell_of = (int*)p; p += al256((size_t)sample_k * 4);
     int* slot_of = (int*)p; p += al256((size_t)sample_k * 4);
     float* sp = (float*)p; p += al256((size_t)sample_k * 12);
-    float* sorted = (float*)p;
+    float* sorted = (float*)p; p += al256((size_t)sample_k * 12);
+    int* tsum = (int*)p;
+    const int ntiles = (int)(ncell / SCAN_TILE + 1);
     hipError_t e = hipMemsetAsync(count, 0, ncell * 4, st);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(count_out, 0, sizeof(int), st);
@@ -286,7 +332,9 @@ extern "C" int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3,
     const int grid = nbp_ew_grid(work > 0 ? work : 1, 256);
     coverage_bin_kernel<<<grid, 256, 0, st>>>(pc3, N_dev_or_null, N, sample_k, seed, g, sp, cell_of, slot_of, count, m_out);
     if ((rc = nbp_launch_status())) return rc;
-    coverage_scan_kernel<<<1, 1024, 0, st>>>(count, (long long)ncell, start);
+    coverage_tilesum_kernel<<<ntiles, 256, 0, st>>>(count, (long long)ncell, tsum);
+    coverage_tilescan_kernel<<<1, 256, 0, st>>>(tsum, ntiles, start, (long long)ncell);
+    coverage_scan_kernel<<<ntiles, 256, 0, st>>>(count, (long long)ncell, tsum, start);
     if ((rc = nbp_launch_status())) return rc;
     coverage_scatter_kernel<<<grid, 256, 0, st>>>(sp, cell_of, slot_of, start, m_out, sorted);
     if ((rc = nbp_launch_status())) return rc;
