@@ -32,34 +32,40 @@ __global__ __launch_bounds__(256) void fuse_obstacle_kernel(const float* __restr
     }
 }
 
+// One wave per candidate: the 21 x 21 window test (check_pixel_values) is a ballot over 64 pixels at a time
+// instead of up to 441 dependent loads in one lane.
 __global__ __launch_bounds__(256) void score_candidates_kernel(const float* __restrict__ pos, int P, float cx, float cz,
                                                                const float* __restrict__ out1, int V,
                                                                const float* __restrict__ fullproj, int S, float lo,
                                                                float scV, float scS, const unsigned char* __restrict__ skip,
                                                                unsigned char* __restrict__ valid, int* __restrict__ cell,
                                                                double* __restrict__ score) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (i >= P) return;
-    valid[i] = 0; cell[2 * i] = 0; cell[2 * i + 1] = 0; score[i] = 0.0;
+    if (lane == 0) { valid[i] = 0; cell[2 * i] = 0; cell[2 * i + 1] = 0; score[i] = 0.0; }
     if (skip && skip[i]) return;
     const float v0 = -(pos[3 * i + 2] - cz), v1 = -(pos[3 * i] - cx);
     const long long g0 = cell_index(v0, lo, scV), g1 = cell_index(v1, lo, scV);
     if (g0 < 0 || g0 >= V || g1 < 0 || g1 >= V) return;
-    float best = out1[g0 * V + g1];
-    for (int c = 1; c < 8; ++c) best = fmaxf(best, out1[(size_t)c * V * V + g0 * V + g1]);
     const long long s0 = cell_index(v0, lo, scS), s1 = cell_index(v1, lo, scS);
     // torch indexing semantics: a negative index wraps once (the reference does not bounds check)
     const long long w0 = s0 < 0 ? s0 + S : s0, w1 = s1 < 0 ? s1 + S : s1;
     if (w0 < 0 || w0 >= S || w1 < 0 || w1 >= S) return;
-    const float dens = fullproj[w0 * S + w1];
     // check_pixel_values: any pixel == 1 in rows [max(s0-10,0), min(s0+11,S)) x cols likewise (unwrapped index)
     const long long r0 = s0 - 10 > 0 ? s0 - 10 : 0, r1 = s0 + 11 < S ? s0 + 11 : S;
     const long long c0 = s1 - 10 > 0 ? s1 - 10 : 0, c1 = s1 + 11 < S ? s1 + 11 : S;
+    const int wc = (int)(c1 - c0), total = (r1 > r0 && wc > 0) ? (int)(r1 - r0) * wc : 0;
     bool any1 = false;
-    for (long long r = r0; r < r1 && !any1; ++r)
-        for (long long c = c0; c < c1; ++c)
-            if (fullproj[r * S + c] == 1.f) { any1 = true; break; }
-    if (!any1) return;
+    for (int k0 = 0; k0 < total && !any1; k0 += 64) {
+        const int k = k0 + lane;
+        const bool one = k < total && fullproj[(r0 + k / wc) * S + c0 + k % wc] == 1.f;
+        any1 = __ballot(one) != 0ull;
+    }
+    if (!any1 || lane != 0) return;
+    float best = out1[g0 * V + g1];
+    for (int c = 1; c < 8; ++c) best = fmaxf(best, out1[(size_t)c * V * V + g0 * V + g1]);
+    const float dens = fullproj[w0 * S + w1];
     valid[i] = 1; cell[2 * i] = (int)g0; cell[2 * i + 1] = (int)g1;
     score[i] = (double)best - 10.0 * (double)dens;
 }
@@ -264,7 +270,7 @@ extern "C" int nbp_score_candidates_f32(const float* pos3, int P, float cx, floa
                                         unsigned char* valid, int* cell2, double* score, void* stream) {
     NBP_RETURN_IF(!pos3 || !out1 || !fullproj || !valid || !cell2 || !score || P < 1 || V < 1 || S < 1 || !(hi > lo),
                   NBP_E_ARG);
-    score_candidates_kernel<<<(unsigned)nbp_cdiv(P, 256), 256, 0, (hipStream_t)stream>>>(
+    score_candidates_kernel<<<(unsigned)nbp_cdiv((long long)P * 64, 256), 256, 0, (hipStream_t)stream>>>(
         pos3, P, cx, cz, out1, V, fullproj, S, lo, grid_scale(V, lo, hi), grid_scale(S, lo, hi), skip_or_null, valid, cell2,
         score);
     return nbp_launch_status();
