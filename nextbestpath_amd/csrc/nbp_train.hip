@@ -12,6 +12,7 @@
 // Activations are NHWC [M, C] with M = B*H*W.  Reductions are two-stage (per-workgroup partials,
 // then a finalize kernel) so results are run-to-run deterministic.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -365,6 +366,119 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
             }
 }
 
+// ------------------------------------------------------------------ 3x3 weight gradient from an LDS-resident halo tile
+// wgrad_kernel above runs one filter tap per workgroup: every tap re-reads X and dY and redoes the gather index
+// arithmetic (two integer divisions per row per chunk).  Here a workgroup owns a 64 (ci) x 64 (co) block of dW for
+// ALL nine taps (one 32x32 block per wave and tap: 9 accumulator tiles) and walks 2 x 32 pixel tiles of the images:
+// per tile the 4 x 34 pixel halo of X (64 channels) and the 64 pixels of dY (64 channels) are DMA'd into LDS
+// (buffer_load ... lds; out-of-image = out-of-range offset = zeros) and each pixel pair feeds nine MFMAs from one
+// dY operand and nine shifted X operands.  Two workgroups share a CU; one computes while the other's tile loads.
+struct WgradHaloArgs {
+    const float* src0; const float* src1;
+    int C0, C1, ups, H, W, Hs, Ws;
+    const float* dy; int N;
+    unsigned bytes0, bytes1, bytesy;
+    int co_tiles;          // N / 64
+    int n_tiles, splits;   // pixel tiles in total, workgroups sharing them (blockIdx.y)
+    float* part;           // [split][tap][Ctot][N]
+};
+typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
+
+__global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(WgradHaloArgs a) {
+    constexpr int HW_ = 34, XROWS = 136, XBYTES = 144 * 256;     // 4 x 34 halo pixels x 64 floats (36 DMA slots of 4 rows)
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    char* const xs = wlds;
+    char* const ys = wlds + XBYTES;                               // 64 pixels x 64 floats
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1, kh = lane >> 5, ln = lane & 31;
+    const int ci0 = (blockIdx.x / a.co_tiles) * 64, co0 = (blockIdx.x % a.co_tiles) * 64;
+    const int Ctot = a.C0 + a.C1;
+    const bool first = ci0 < a.C0;
+    const int Cs = first ? a.C0 : a.C1;
+    const int cbase = first ? ci0 : ci0 - a.C0;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(first ? a.src0 : a.src1), 0, first ? a.bytes0 : a.bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.bytesy, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int tiles_x = a.W >> 5, tiles_y = a.H >> 1;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // DMA lane roles: a 1024-B instruction fills 4 rows of 256 B; lane -> (row lane/16, 16-B slot lane%16)
+    const int drow = lane >> 4, dslot = lane & 15;
+    for (int tile = blockIdx.y; tile < a.n_tiles; tile += a.splits) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int b = t / tiles_y;
+        const int y0 = ty * 2, x0 = tx * 32;
+        __syncthreads();                       // every wave is done with the previous tile
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {          // X halo: slots q = 4 i + wave < 34 (136 rows)
+            const int q = 4 * i + wave;
+            if (q < 34) {
+                const int hr = 4 * q + drow;
+                const int hy = hr / HW_, hx = hr - hy * HW_;
+                const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+                const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+                const unsigned off = ok ? (unsigned)(((b * a.Hs + (yy >> a.ups)) * a.Ws + (xx >> a.ups)) * Cs + cbase + dslot * 4) * 4u
+                                        : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (wg_lds_ptr_t)(xs + q * 1024), 16, off, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {          // dY: 64 pixels = 16 slots
+            const int q = 4 * i + wave;
+            const int p = 4 * q + drow;        // pixel of the tile: row p / 32, column p % 32
+            const long long m = ((long long)b * a.H + y0 + (p >> 5)) * a.W + x0 + (p & 31);
+            const unsigned off = (unsigned)((m * a.N + co0 + dslot * 4) * 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (wg_lds_ptr_t)(ys + q * 1024), 16, off, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* xw = reinterpret_cast<const float*>(xs) + wi * 32 + ln;
+        const float* yw = reinterpret_cast<const float*>(ys) + wj * 32 + ln;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll 4
+            for (int pp = 0; pp < 16; ++pp) {
+                const int px = 2 * pp + kh;
+                const float bv = yw[(r * 32 + px) * 64];
+                const float* xr = xw + ((r * HW_) + px) * 64;          // halo pixel (r + dy', px + dx') for tap (0,0)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float av = xr[((tap / 3) * HW_ + (tap % 3)) * 64];
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        float* out = a.part + (((long long)blockIdx.y * 9 + tap) * Ctot) * a.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            out[(long long)ci * a.N + co0 + wj * 32 + ln] = acc[tap][r];
+        }
+    }
+}
+
+static bool wgrad_halo_ok(int H, int W, int ksize) { return ksize == 3 && H >= 2 && W >= 32 && !(H & 1) && !(W & 31); }
+static void wgrad_halo_plan(int B, int H, int W, int Ctot, int N, int* n_tiles, int* splits) {
+    *n_tiles = B * (H / 2) * (W / 32);
+    const long long pairs = (long long)(Ctot / 64) * (N / 64);
+    long long s = nbp_cdiv(1024, pairs);                 // >= 1024 workgroups (2 per CU, 2 rounds)
+    if (s > *n_tiles) s = *n_tiles;
+    if (s > 1024) s = 1024;
+    if (s < 1) s = 1;
+    *splits = (int)s;
+}
+
 // dW OIHW [N][Creal][taps] = sum_s part[s][tap][ci][co]   (ci < Creal: padded input channels are dropped)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int taps, int Ctot, int N,
                                                            int Creal, int Nreal, float* __restrict__ dw) {
@@ -605,6 +719,11 @@ extern "C" size_t nbp_conv_wgrad_workspace_bytes(int B, int H, int W, int C0, in
     int ti, cit, cot, sp, ct, cps;
     if ((C0 + C1) % 64 || N % 64 || C0 % 64) return 0;
     wgrad_plan((long long)B * H * W, C0 + C1, N, ksize * ksize, &ti, &cit, &cot, &sp, &ct, &cps);
+    if (wgrad_halo_ok(H, W, ksize)) {
+        int nt, hs;
+        wgrad_halo_plan(B, H, W, C0 + C1, N, &nt, &hs);
+        if (hs > sp) sp = hs;
+    }
     return (size_t)sp * ksize * ksize * (C0 + C1) * N * sizeof(float) + 256;
 }
 
@@ -625,12 +744,37 @@ extern "C" int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, 
     const long long b0 = (long long)B * a.Hs * a.Ws * C0 * 4, b1 = (long long)B * a.Hs * a.Ws * C1 * 4;
     NBP_RETURN_IF(b0 >= (1ll << 31) || b1 >= (1ll << 31), NBP_E_SHAPE);
     a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0;
+    hipStream_t st = (hipStream_t)stream;
+    static const int use_halo = [] { const char* e = getenv("NBP_WGRAD_HALO"); return e ? atoi(e) : 1; }();
+    if (use_halo && wgrad_halo_ok(H, W, ksize) && (long long)B * H * W * N * 4 < (1ll << 31)) {
+        WgradHaloArgs h;
+        h.src0 = src0; h.src1 = src1; h.C0 = C0; h.C1 = C1; h.ups = a.ups; h.H = H; h.W = W; h.Hs = a.Hs; h.Ws = a.Ws;
+        h.dy = dy; h.N = N; h.bytes0 = a.bytes0; h.bytes1 = a.bytes1; h.bytesy = (unsigned)((long long)B * H * W * N * 4);
+        h.co_tiles = N / 64;
+        wgrad_halo_plan(B, H, W, C0 + C1, N, &h.n_tiles, &h.splits);
+        NBP_RETURN_IF(ws_bytes < (size_t)h.splits * 9 * (C0 + C1) * N * sizeof(float) + 256, NBP_E_WS);
+        h.part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
+        constexpr int smem = 144 * 256 + 64 * 256;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        dim3 grid((unsigned)(((C0 + C1) / 64) * (N / 64)), (unsigned)h.splits);
+        wgrad_halo_kernel<<<grid, 256, smem, st>>>(h);
+        int rc = nbp_launch_status();
+        if (rc) return rc;
+        const long long total = (long long)n_real * c_real * 9;
+        wgrad_reduce_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(h.part, h.splits, 9, C0 + C1, N, c_real, n_real, dw);
+        return nbp_launch_status();
+    }
     int ti, sp;
     wgrad_plan(a.M, C0 + C1, N, a.taps, &ti, &a.ci_tiles, &a.co_tiles, &sp, &a.chunks_total, &a.chunks_per_split);
     NBP_RETURN_IF(ti == 2 && C0 % 128, NBP_E_SHAPE);
     NBP_RETURN_IF(ws_bytes < (size_t)sp * a.taps * (C0 + C1) * N * sizeof(float) + 256, NBP_E_WS);
     a.part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
-    hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(a.ci_tiles * a.co_tiles), (unsigned)a.taps, (unsigned)sp);
     if (ti == 2) wgrad_kernel<2, 2><<<grid, 256, 0, st>>>(a);
     else wgrad_kernel<1, 1><<<grid, 256, 0, st>>>(a);
