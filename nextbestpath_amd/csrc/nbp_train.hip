@@ -61,14 +61,30 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     }
 }
 
-// finalize MODE 0: mean, biased var -> invstd; running stats (momentum, unbiased var)
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, long long M, float eps, float momentum,
-                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
-                                   float* __restrict__ run_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// Column sums of the per-block partials part[k][2][C]: a 256-thread block owns 32 channels; thread (c, ks) adds the
+// rows k = ks, ks + 8, ... in double (fixed order), the 8 slices meet in LDS in a fixed order: deterministic, and
+// nblk / 8 dependent loads per thread instead of nblk.
+__device__ __forceinline__ void colsum_pair(const float* __restrict__ part, int nblk, int C, int c, int ks, double (*sh)[2][32],
+                                            double* s0_out, double* s1_out) {
     double s0 = 0, s1 = 0;
-    for (int k = 0; k < nblk; ++k) { s0 += part[((long long)k * 2) * C + c]; s1 += part[((long long)k * 2 + 1) * C + c]; }
+    if (c < C)
+        for (int k = ks; k < nblk; k += 8) { s0 += part[((long long)k * 2) * C + c]; s1 += part[((long long)k * 2 + 1) * C + c]; }
+    sh[ks][0][threadIdx.x & 31] = s0; sh[ks][1][threadIdx.x & 31] = s1;
+    __syncthreads();
+    s0 = 0; s1 = 0;
+    for (int q = 0; q < 8; ++q) { s0 += sh[q][0][threadIdx.x & 31]; s1 += sh[q][1][threadIdx.x & 31]; }
+    *s0_out = s0; *s1_out = s1;
+}
+
+// finalize MODE 0: mean, biased var -> invstd; running stats (momentum, unbiased var)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, long long M, float eps,
+                                                          float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var) {
+    __shared__ double sh[8][2][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), ks = threadIdx.x >> 5;
+    double s0, s1;
+    colsum_pair(part, nblk, C, c, ks, sh, &s0, &s1);
+    if (c >= C || ks != 0) return;
     const double mu = s0 / (double)M;
     double var = s1 / (double)M - mu * mu;
     if (var < 0) var = 0;
@@ -82,12 +98,13 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int
 }
 
 // finalize generic: out0[c] (+ out1[c]) = sum over blocks
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out0,
-                                       float* __restrict__ out1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0, s1 = 0;
-    for (int k = 0; k < nblk; ++k) { s0 += part[((long long)k * 2) * C + c]; s1 += part[((long long)k * 2 + 1) * C + c]; }
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C,
+                                                              float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ double sh[8][2][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), ks = threadIdx.x >> 5;
+    double s0, s1;
+    colsum_pair(part, nblk, C, c, ks, sh, &s0, &s1);
+    if (c >= C || ks != 0) return;
     if (out0) out0[c] = (float)s0;
     if (out1) out1[c] = (float)s1;
 }
@@ -587,7 +604,7 @@ extern "C" int nbp_bn_train_forward_f32(const float* x, long long M, int C, cons
     colreduce_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, rpb, part);
     int rc = nbp_launch_status();
     if (rc) return rc;
-    bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, 128), 128, 0, st>>>(part, nblk, C, M, eps, momentum, mean, invstd, running_mean,
+    bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, M, eps, momentum, mean, invstd, running_mean,
                                                                   running_var);
     if ((rc = nbp_launch_status())) return rc;
     bn_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(x, M * C, C, mean, invstd, gamma, beta, relu, y);
@@ -607,7 +624,7 @@ extern "C" int nbp_bn_train_backward_f32(const float* dy, const float* x, const 
     colreduce_kernel<1><<<nblk, 256, 0, st>>>(dy, x, y_or_null, mean, invstd, nullptr, M, C, relu, rpb, part);
     int rc = nbp_launch_status();
     if (rc) return rc;
-    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 128), 128, 0, st>>>(part, nblk, C, dbeta, dgamma);
+    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, dbeta, dgamma);
     if ((rc = nbp_launch_status())) return rc;
     bn_backward_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(dy, x, y_or_null, M * C, C, M, mean, invstd, gamma,
                                                                      dgamma, dbeta, relu, dx);
@@ -626,7 +643,7 @@ extern "C" int nbp_colsum_f32(const float* x, const float* rows_or_null, long lo
     colreduce_kernel<2><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, rows_or_null, M, C, 0, rpb, part);
     int rc = nbp_launch_status();
     if (rc) return rc;
-    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 128), 128, 0, st>>>(part, nblk, C, out, nullptr);
+    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, out, nullptr);
     return nbp_launch_status();
 }
 
