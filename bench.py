@@ -350,6 +350,7 @@ def main():
         }
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()                  # keep every rank alive until rank 0 has printed
         dist.destroy_process_group()
 
 

@@ -42,13 +42,32 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
          "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-I", CSRC]
 
 
+def _up_to_date(dig: str) -> bool:
+    if os.path.exists(LIB) and os.path.exists(STAMP):
+        with open(STAMP) as fh:
+            return fh.read().strip() == dig
+    return False
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     extra = os.environ.get("NBP_EXTRA_FLAGS", "").split()
     dig = _digest() + " ".join(extra)
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
-        with open(STAMP) as fh:
-            if fh.read().strip() == dig:
-                return LIB
+    if not force and _up_to_date(dig):
+        return LIB
+    # one builder at a time: the ranks of a torchrun job import the package concurrently
+    import fcntl
+    lock = open(os.path.join(HERE, ".build.lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and _up_to_date(dig):
+            return LIB
+        return _build_locked(dig, extra, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(dig, extra, verbose) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
