@@ -116,6 +116,10 @@ def lib() -> C.CDLL:
             raise NbpHipError(
                 f"{LIB_PATH} is missing: build it with `python -m nextbestpath_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch ships its own libamdhip64; it has to be in the process first so that this library binds to the
+        # SAME HIP runtime (device pointers and streams cross the boundary).  Loaded the other way round the
+        # process ends up with two runtimes and the second one reports hipErrorNoDevice.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             try:

@@ -14,6 +14,10 @@ static inline int nbp_launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// hipGetLastError() is sticky per thread: a benign failure inside the caller's own runtime use (e.g. PyTorch probing a
+// pointer) would otherwise be reported by the first launch-status check of this library.  Every entry point clears it.
+#define NBP_ENTER() (void)hipGetLastError()
+
 #define NBP_RETURN_IF(cond, code) \
     do {                          \
         if (cond) return (code);  \

@@ -566,6 +566,7 @@ extern "C" int nbp_conv_igemm_bf16(const bf16_t* src0, int C0, const bf16_t* src
                                    int ksize, const bf16_t* w_packed, int N, const float* scale, const float* shift,
                                    int relu, bf16_t* out, int split_k, int tile, void* ws, size_t ws_bytes,
                                    void* stream) {
+    NBP_ENTER();
     ConvOperandsH o{src0, src1, w_packed, scale, shift, out};
     return nbp_conv_igemm_bf16_launch_g(o, nullptr, C0, C1, ups, B, H, W, ksize, N, relu, split_k, tile, ws, ws_bytes,
                                         (hipStream_t)stream);
@@ -591,6 +592,7 @@ __global__ void pack_conv_weight_bf16_kernel(const float* __restrict__ w, int N,
 
 extern "C" int nbp_pack_conv_weight_bf16(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null,
                                          int c_off, int c_total, bf16_t* dst, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!w_oihw || !dst, NBP_E_ARG);
     NBP_RETURN_IF(ksize != 1 && ksize != 3, NBP_E_ARG);
     NBP_RETURN_IF(N < 1 || C < 1 || c_off < 0 || c_off + C > c_total || c_total % 64, NBP_E_SHAPE);
@@ -610,11 +612,13 @@ __global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ in, long long n, f
         out[i] = bf2f(in[i]);
 }
 extern "C" int nbp_f32_to_bf16(const float* in, long long n, bf16_t* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!in || !out || n < 1, NBP_E_ARG);
     f32_to_bf16_kernel<<<nbp_ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(in, n, out);
     return nbp_launch_status();
 }
 extern "C" int nbp_bf16_to_f32(const bf16_t* in, long long n, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!in || !out || n < 1, NBP_E_ARG);
     bf16_to_f32_kernel<<<nbp_ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(in, n, out);
     return nbp_launch_status();

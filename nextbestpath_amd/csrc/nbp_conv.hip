@@ -633,6 +633,7 @@ extern "C" int nbp_conv_igemm_f32(const float* src0, int C0, const float* src1, 
                                   int W, int ksize, const float* w_packed, int N, const float* scale,
                                   const float* shift, int relu, float* out, int split_k, int tile, void* ws,
                                   size_t ws_bytes, void* stream) {
+    NBP_ENTER();
     return nbp_conv_igemm_launch(src0, C0, src1, C1, ups, B, H, W, ksize, w_packed, N, scale, shift, relu, out,
                                  split_k, tile, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -662,6 +663,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int N, int 
 
 extern "C" int nbp_pack_conv_weight(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null,
                                     int c_off, int c_total, float* dst, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!w_oihw || !dst, NBP_E_ARG);
     NBP_RETURN_IF(ksize != 1 && ksize != 3, NBP_E_ARG);
     NBP_RETURN_IF(N < 1 || C < 1 || c_off < 0 || c_off + C > c_total || c_total % 32, NBP_E_SHAPE);
@@ -729,6 +731,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 
 extern "C" int nbp_conv_first_f32(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale,
                                   const float* shift, float* out_nhwc, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!x_nchw || !w_oihw || !scale || !shift || !out_nhwc, NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 1 || W < 1, NBP_E_ARG);
     long long M = (long long)B * H * W;
@@ -763,6 +766,7 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__
 }
 
 extern "C" int nbp_maxpool2_nhwc_f32(const float* in, int B, int H, int W, int C, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!in || !out, NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 4 || (C & 3), NBP_E_SHAPE);
     long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
@@ -802,6 +806,7 @@ __global__ __launch_bounds__(256) void psi_gate_kernel(const float* __restrict__
 
 extern "C" int nbp_psi_gate_f32(const float* q, int F, const float* w_psi, const float* s_t2, const float* x, int C,
                                 long long M, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!q || !w_psi || !s_t2 || !x || !out, NBP_E_ARG);
     NBP_RETURN_IF(F < 4 || (F & 3) || C < 4 || (C & 3) || M < 1, NBP_E_SHAPE);
     psi_gate_kernel<<<nbp_ew_grid(M * 16, 256), 256, 0, (hipStream_t)stream>>>(q, F / 4, w_psi, s_t2, x, C / 4, M,
@@ -854,6 +859,7 @@ __global__ __launch_bounds__(256) void final_1x1_kernel(const float* __restrict_
 
 extern "C" int nbp_final_1x1_f32(const float* in, int B, int H, int W, int C, const float* w_oc, int n_out,
                                  const float* scale, const float* shift, int sigmoid, float* out_nchw, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!in || !w_oc || !scale || !shift || !out_nchw, NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 1 || W < 1 || C < 4 || (C & 3), NBP_E_SHAPE);
     long long M = (long long)B * H * W;
@@ -888,12 +894,14 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int B, int C, 
     }
 }
 extern "C" int nbp_nchw_to_nhwc_f32(const float* in, int B, int C, int H, int W, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!in || !out || B < 1 || C < 1 || H < 1 || W < 1, NBP_E_ARG);
     long long total = (long long)B * C * H * W;
     nchw_to_nhwc_kernel<<<nbp_ew_grid(total, 256), 256, 0, (hipStream_t)stream>>>(in, B, C, (long long)H * W, out);
     return nbp_launch_status();
 }
 extern "C" int nbp_nhwc_to_nchw_f32(const float* in, int B, int C, int H, int W, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!in || !out || B < 1 || C < 1 || H < 1 || W < 1, NBP_E_ARG);
     long long total = (long long)B * C * H * W;
     nhwc_to_nchw_kernel<<<nbp_ew_grid(total, 256), 256, 0, (hipStream_t)stream>>>(in, B, C, (long long)H * W, out);

@@ -90,9 +90,11 @@ struct nbp_weights {
     int bf16;
 };
 
-extern "C" int nbp_abi_version(void) { return NBP_ABI_VERSION; }
+extern "C" int nbp_abi_version(void) {
+    NBP_ENTER(); return NBP_ABI_VERSION; }
 
 extern "C" int nbp_device_info(char* arch_host, int arch_len, int* cu_count_host) {
+    NBP_ENTER();
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
@@ -177,6 +179,7 @@ static int pack_weights_impl(const void* const* w_host_array, const void* const*
 extern "C" int nbp_pack_weights(const void* const* w_host_array, const void* const* scale_host_array,
                                 const void* const* shift_host_array, void* packed, size_t packed_bytes, void* stream,
                                 nbp_weights** handle_out) {
+    NBP_ENTER();
     return pack_weights_impl(w_host_array, scale_host_array, shift_host_array, packed, packed_bytes, stream, handle_out,
                              false);
 }
@@ -186,6 +189,7 @@ extern "C" int nbp_pack_weights(const void* const* w_host_array, const void* con
 extern "C" int nbp_pack_weights_bf16(const void* const* w_host_array, const void* const* scale_host_array,
                                      const void* const* shift_host_array, void* packed, size_t packed_bytes,
                                      void* stream, nbp_weights** handle_out) {
+    NBP_ENTER();
     return pack_weights_impl(w_host_array, scale_host_array, shift_host_array, packed, packed_bytes, stream, handle_out,
                              true);
 }
@@ -467,17 +471,20 @@ extern "C" size_t nbp_forward_workspace_bytes_bf16(int B, int S) { return worksp
 
 extern "C" int nbp_forward_f32(const nbp_weights* handle, const float* x, int B, int S, float* out1, float* out2,
                                void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
     return forward_impl<PathF32>(handle, x, B, S, out1, out2, ws, ws_bytes, stream, nullptr, 0, nullptr);
 }
 
 extern "C" int nbp_forward_bf16(const nbp_weights* handle, const float* x, int B, int S, float* out1, float* out2,
                                 void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
     return forward_impl<PathBF16>(handle, x, B, S, out1, out2, ws, ws_bytes, stream, nullptr, 0, nullptr);
 }
 
 extern "C" int nbp_forward_timed_f32(const nbp_weights* handle, const float* x, int B, int S, float* out1,
                                      float* out2, void* ws, size_t ws_bytes, void* stream,
                                      nbp_layer_timing* timings_host, int max_entries, int* n_entries_host) {
+    NBP_ENTER();
     NBP_RETURN_IF(!timings_host || !n_entries_host, NBP_E_ARG);
     return forward_impl<PathF32>(handle, x, B, S, out1, out2, ws, ws_bytes, stream, timings_host, max_entries,
                                  n_entries_host);
@@ -486,6 +493,7 @@ extern "C" int nbp_forward_timed_f32(const nbp_weights* handle, const float* x, 
 extern "C" int nbp_forward_timed_bf16(const nbp_weights* handle, const float* x, int B, int S, float* out1,
                                       float* out2, void* ws, size_t ws_bytes, void* stream,
                                       nbp_layer_timing* timings_host, int max_entries, int* n_entries_host) {
+    NBP_ENTER();
     NBP_RETURN_IF(!timings_host || !n_entries_host, NBP_E_ARG);
     return forward_impl<PathBF16>(handle, x, B, S, out1, out2, ws, ws_bytes, stream, timings_host, max_entries,
                                   n_entries_host);

@@ -122,6 +122,7 @@ inline float grid_scale(int S, float lo, float hi) { return (float)((double)S / 
 
 extern "C" int nbp_transform_points_f32(const float* points, long long N, float cx, float cy, float cz, float* out_2d,
                                         void* stream) {
+    NBP_ENTER();
     (void)cy;
     NBP_RETURN_IF(N < 0, NBP_E_ARG);
     if (N == 0) return 0;
@@ -132,6 +133,7 @@ extern "C" int nbp_transform_points_f32(const float* points, long long N, float 
 
 extern "C" int nbp_map_points_to_imgs_f32(const float* pts2d, int n, long long m, int S0, int S1, float lo, float hi,
                                           float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!out || n < 1 || m < 0 || S0 < 1 || S1 < 1 || !(hi > lo), NBP_E_ARG);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(out, 0, (size_t)n * S0 * S1 * sizeof(float), st);
@@ -146,6 +148,7 @@ extern "C" int nbp_map_points_to_imgs_f32(const float* pts2d, int n, long long m
 
 extern "C" int nbp_point_position_i64(const float* pts2d, long long K, int S0, int S1, float lo, float hi,
                                       long long* out_2xK, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!pts2d || !out_2xK || K < 1 || S0 < 1 || S1 < 1 || !(hi > lo), NBP_E_ARG);
     point_position_kernel<<<nbp_ew_grid(K, 256), 256, 0, (hipStream_t)stream>>>(pts2d, K, lo, grid_scale(S0, lo, hi),
                                                                                 grid_scale(S1, lo, hi), out_2xK);
@@ -155,6 +158,7 @@ extern "C" int nbp_point_position_i64(const float* pts2d, long long K, int S0, i
 extern "C" int nbp_map_accumulate_f32(const float* points, long long N, const long long* N_dev_or_null, float cx,
                                       float cy, float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi, int S,
                                       float lo, float hi, float* out6, void* stream) {
+    NBP_ENTER();
     (void)cy;
     NBP_RETURN_IF(!out6 || N < 0 || S < 1 || !(hi > lo), NBP_E_ARG);
     NBP_RETURN_IF(n_bounds < 0 || n_bounds > 8 || (n_bounds > 0 && !bounds_host), NBP_E_ARG);

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void coverage_query_kernel(const float* __rest
 
 extern "C" int nbp_fuse_obstacle_f32(const float* out2, const float* maps6, const float* traj, float threshold, int S,
                                      float* obst, float* fullproj, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!out2 || !maps6 || !traj || !obst || !fullproj || S < 1, NBP_E_ARG);
     fuse_obstacle_kernel<<<nbp_ew_grid((long long)S * S, 256), 256, 0, (hipStream_t)stream>>>(out2, maps6, traj, threshold,
                                                                                               S * S, obst, fullproj);
@@ -268,6 +269,7 @@ extern "C" int nbp_fuse_obstacle_f32(const float* out2, const float* maps6, cons
 extern "C" int nbp_score_candidates_f32(const float* pos3, int P, float cx, float cz, const float* out1, int V,
                                         const float* fullproj, int S, float lo, float hi, const unsigned char* skip_or_null,
                                         unsigned char* valid, int* cell2, double* score, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!pos3 || !out1 || !fullproj || !valid || !cell2 || !score || P < 1 || V < 1 || S < 1 || !(hi > lo),
                   NBP_E_ARG);
     score_candidates_kernel<<<(unsigned)nbp_cdiv((long long)P * 64, 256), 256, 0, (hipStream_t)stream>>>(
@@ -278,6 +280,7 @@ extern "C" int nbp_score_candidates_f32(const float* pos3, int P, float cx, floa
 
 extern "C" int nbp_edges_blocked_u8(const float* obst, int S, float lo, float hi, float cx, float cz, const float* pos3,
                                     const int* edges2, int E, unsigned char* blocked, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!obst || !pos3 || !edges2 || !blocked || S < 1 || E < 1 || !(hi > lo), NBP_E_ARG);
     edges_blocked_kernel<<<(unsigned)nbp_cdiv(E, 256), 256, 0, (hipStream_t)stream>>>(obst, S, lo, grid_scale(S, lo, hi), cx,
                                                                                       cz, pos3, edges2, E, blocked);
@@ -314,6 +317,7 @@ extern "C" int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3,
                                       long long sample_k, unsigned seed, float threshold, const float* bbox_lo_host,
                                       const float* bbox_hi_host, int* count_out, int* m_out, void* ws, size_t ws_bytes,
                                       void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!gt3 || !pc3 || !count_out || !m_out || !ws || !bbox_lo_host || !bbox_hi_host, NBP_E_ARG);
     NBP_RETURN_IF(G < 1 || N < 0 || sample_k < 1 || !(threshold > 0) || N > 0xffffffffll, NBP_E_ARG);
     Grid g; size_t ncell;

@@ -397,6 +397,7 @@ extern "C" int nbp_unproject_append_f32(const float* depth, const unsigned char*
                                         double gathering_factor, unsigned seed, int* counts2, float* cloud,
                                         long long* cloud_count, long long capacity, void* ws, size_t ws_bytes,
                                         void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!depth || !cams12_host || !counts2 || !cloud || !cloud_count || !ws, NBP_E_ARG);
     NBP_RETURN_IF(n_frames < 1 || n_frames > MAX_CAMS || H < 2 || W < 2 || capacity < 1, NBP_E_ARG);
     NBP_RETURN_IF(!(gathering_factor >= 0.0 && gathering_factor <= 1.0), NBP_E_ARG);
@@ -439,6 +440,7 @@ extern "C" size_t nbp_raster_workspace_bytes(int n_faces, int n_frames, int H, i
 extern "C" int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* faces, int n_faces, const float* cams12_host,
                                    int n_frames, int H, int W, float tan_half_fov, float z_clip, int bin_cap, float* zbuf,
                                    int* overflow_flag, void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!verts || !faces || !cams12_host || !zbuf || !overflow_flag || !ws, NBP_E_ARG);
     NBP_RETURN_IF(n_verts < 3 || n_faces < 1 || n_frames < 1 || n_frames > MAX_CAMS || H < 1 || W < 1 || bin_cap < 64, NBP_E_ARG);
     NBP_RETURN_IF(ws_bytes < nbp_raster_workspace_bytes(n_faces, n_frames, H, W, bin_cap), NBP_E_WS);
@@ -469,6 +471,7 @@ extern "C" int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* f
 
 extern "C" int nbp_segments_hit_mesh_f32(const float* verts, const int* faces, int n_faces, const float* segs6, int n_segs,
                                          int* hit, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!verts || !faces || !segs6 || !hit || n_faces < 1 || n_segs < 1 || n_segs > 65535, NBP_E_ARG);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(hit, 0, (size_t)n_segs * sizeof(int), st);
@@ -480,6 +483,7 @@ extern "C" int nbp_segments_hit_mesh_f32(const float* verts, const int* faces, i
 
 extern "C" int nbp_axis_ray_counts_f32(const float* verts, const int* faces, int n_faces, const float* pts3, int n_pts,
                                        int* counts3, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!verts || !faces || !pts3 || !counts3 || n_faces < 1 || n_pts < 1 || n_pts > 65535, NBP_E_ARG);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(counts3, 0, (size_t)n_pts * 3 * sizeof(int), st);
@@ -493,6 +497,7 @@ extern "C" int nbp_carve_update_f32(const float* proxy_pts3, int P, const float*
                                     const float* cam12_host, int H, int W, float tan_half_fov, float zfar, float fov_range,
                                     float tol, float score_threshold, float* n_inside, float* n_behind, float* occ,
                                     float* out_of_field, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!proxy_pts3 || !depth || !cam12_host || !n_inside || !n_behind || !occ || !out_of_field, NBP_E_ARG);
     NBP_RETURN_IF(P < 1 || H < 2 || W < 2, NBP_E_ARG);
     Cam cam;
@@ -511,6 +516,7 @@ __global__ void append_points_kernel(float* __restrict__ dst, long long offset, 
     if (i < 3 * n) dst[3 * offset + i] = pts.p[i];
 } }
 extern "C" int nbp_append_points_f32(float* dst, long long offset, const float* pts3_host, int n, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!dst || !pts3_host || offset < 0 || n < 1 || n > 8, NBP_E_ARG);
     Pts8 p;
     for (int i = 0; i < 24; ++i) p.p[i] = i < 3 * n ? pts3_host[i] : 0.f;
@@ -577,6 +583,7 @@ __global__ __launch_bounds__(256) void slice_obstacle_kernel(const float* __rest
 
 extern "C" int nbp_slice_obstacle_f32(const float* verts, const int* faces, int n_faces, float y0, float cx, float cz,
                                       int S, float lo, float hi, float half_width_px, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!verts || !faces || !out || n_faces < 1 || S < 1 || !(hi > lo) || !(half_width_px > 0.f), NBP_E_ARG);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(out, 0, (size_t)S * S * sizeof(float), st);

@@ -595,6 +595,7 @@ extern "C" size_t nbp_colreduce_workspace_bytes(long long M, int C) {
 extern "C" int nbp_bn_train_forward_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
                                         float momentum, float* running_mean, float* running_var, int relu, float* mean,
                                         float* invstd, float* y, void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!x || !gamma || !beta || !mean || !invstd || !y || !ws || M < 1 || C < 1, NBP_E_ARG);
     NBP_RETURN_IF(ws_bytes < nbp_colreduce_workspace_bytes(M, C), NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;
@@ -614,6 +615,7 @@ extern "C" int nbp_bn_train_forward_f32(const float* x, long long M, int C, cons
 extern "C" int nbp_bn_train_backward_f32(const float* dy, const float* x, const float* y_or_null, long long M, int C,
                                          const float* mean, const float* invstd, const float* gamma, int relu, float* dx,
                                          float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !ws || M < 1 || C < 1, NBP_E_ARG);
     NBP_RETURN_IF(relu && !y_or_null, NBP_E_ARG);
     NBP_RETURN_IF(ws_bytes < nbp_colreduce_workspace_bytes(M, C), NBP_E_WS);
@@ -634,6 +636,7 @@ extern "C" int nbp_bn_train_backward_f32(const float* dy, const float* x, const 
 // out[c] = sum_m rows[m] * x[m][c]  (rows may be null): bias gradients, psi weight gradient
 extern "C" int nbp_colsum_f32(const float* x, const float* rows_or_null, long long M, int C, float* out, void* ws,
                               size_t ws_bytes, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!x || !out || !ws || M < 1 || C < 1, NBP_E_ARG);
     NBP_RETURN_IF(ws_bytes < nbp_colreduce_workspace_bytes(M, C), NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;
@@ -648,6 +651,7 @@ extern "C" int nbp_colsum_f32(const float* x, const float* rows_or_null, long lo
 }
 
 extern "C" int nbp_elementwise_f32(int op, const float* a, const float* b, long long n, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!a || !out || n < 1 || op < 0 || op > 5, NBP_E_ARG);
     NBP_RETURN_IF(op != 2 && !b, NBP_E_ARG);
     ew_kernel<<<nbp_ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(op, a, b, n, out);
@@ -655,24 +659,28 @@ extern "C" int nbp_elementwise_f32(int op, const float* a, const float* b, long 
 }
 
 extern "C" int nbp_rowscale_f32(const float* x, const float* s, long long M, int C, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!x || !s || !out || M < 1 || C < 1, NBP_E_ARG);
     rowscale_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, (hipStream_t)stream>>>(x, s, M * C, C, out);
     return nbp_launch_status();
 }
 
 extern "C" int nbp_rowdot_f32(const float* a, const float* b, int b_is_vector, long long M, int C, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!a || !b || !out || M < 1 || C < 1, NBP_E_ARG);
     rowdot_kernel<<<nbp_ew_grid(M * 16, 256), 256, 0, (hipStream_t)stream>>>(a, b, b_is_vector, M, C, out);
     return nbp_launch_status();
 }
 
 extern "C" int nbp_outer_f32(const float* s, const float* w, long long M, int C, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!s || !w || !out || M < 1 || C < 1, NBP_E_ARG);
     outer_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, (hipStream_t)stream>>>(s, w, M * C, C, out);
     return nbp_launch_status();
 }
 
 extern "C" int nbp_maxpool2_backward_f32(const float* x, const float* dy, int B, int H, int W, int C, float* dx, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!x || !dy || !dx, NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1, NBP_E_SHAPE);
     maxpool2_bwd_kernel<<<nbp_ew_grid((long long)B * (H / 2) * (W / 2) * C, 256), 256, 0, (hipStream_t)stream>>>(x, dy, B, H, W,
@@ -681,18 +689,21 @@ extern "C" int nbp_maxpool2_backward_f32(const float* x, const float* dy, int B,
 }
 
 extern "C" int nbp_sum2x2_f32(const float* dy, int B, int Hs, int Ws, int C, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!dy || !out || B < 1 || Hs < 1 || Ws < 1 || C < 1, NBP_E_ARG);
     sum2x2_kernel<<<nbp_ew_grid((long long)B * Hs * Ws * C, 256), 256, 0, (hipStream_t)stream>>>(dy, B, Hs, Ws, C, out);
     return nbp_launch_status();
 }
 
 extern "C" int nbp_slice_channels_f32(const float* in, long long M, int Cin, int c0, int Cs, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!in || !out || M < 1 || Cin < 1 || c0 < 0 || Cs < 1 || c0 + Cs > Cin, NBP_E_ARG);
     slice_channels_kernel<<<nbp_ew_grid(M * Cs, 256), 256, 0, (hipStream_t)stream>>>(in, M, Cin, c0, Cs, out);
     return nbp_launch_status();
 }
 
 extern "C" int nbp_pad_channels_f32(const float* in, long long M, int Cin, int Cout, float* out, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!in || !out || M < 1 || Cin < 1 || Cout < Cin, NBP_E_ARG);
     pad_channels_kernel<<<nbp_ew_grid(M * Cout, 256), 256, 0, (hipStream_t)stream>>>(in, M, Cin, Cout, out);
     return nbp_launch_status();
@@ -700,6 +711,7 @@ extern "C" int nbp_pad_channels_f32(const float* in, long long M, int Cin, int C
 
 extern "C" int nbp_pack_conv_weight_padded(const float* w_oihw, int N, int C, int ksize, int Cpad, int Npad, float* dst,
                                            void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!w_oihw || !dst || N < 1 || C < 1 || (ksize != 1 && ksize != 3), NBP_E_ARG);
     NBP_RETURN_IF(Cpad < C || Cpad % 32 || Npad < N || Npad % 32, NBP_E_SHAPE);
     const long long total = (long long)Npad * Cpad * ksize * ksize;
@@ -710,6 +722,7 @@ extern "C" int nbp_pack_conv_weight_padded(const float* w_oihw, int N, int C, in
 
 extern "C" int nbp_pack_conv_weight_dgrad(const float* w_oihw, int N, int C, int ksize, int Cpad, int Npad, float* dst,
                                           void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!w_oihw || !dst || N < 1 || C < 1 || (ksize != 1 && ksize != 3), NBP_E_ARG);
     NBP_RETURN_IF(Cpad < C || Cpad % 32 || Npad < N || Npad % 32, NBP_E_SHAPE);
     const long long total = (long long)Npad * Cpad * ksize * ksize;
@@ -749,6 +762,7 @@ extern "C" size_t nbp_conv_wgrad_workspace_bytes(int B, int H, int W, int C0, in
 extern "C" int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W, int ksize,
                                   const float* dy, int N, int c_real, int n_real, float* dw, void* ws, size_t ws_bytes,
                                   void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!src0 || !dy || !dw || !ws || B < 1 || H < 1 || W < 1, NBP_E_ARG);
     NBP_RETURN_IF(ksize != 1 && ksize != 3, NBP_E_ARG);
     NBP_RETURN_IF(C0 < 64 || C0 % 64 || C1 < 0 || C1 % 64 || N < 64 || N % 64, NBP_E_SHAPE);
@@ -804,6 +818,7 @@ extern "C" int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, 
 
 extern "C" int nbp_gather_values_f32(const float* out1_nchw, const long long* coords_bcxy, int K, int C, int H, int W, float* pred,
                                      void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!out1_nchw || !coords_bcxy || !pred || K < 1, NBP_E_ARG);
     gather_values_kernel<<<(unsigned)nbp_cdiv(K, 256), 256, 0, (hipStream_t)stream>>>(out1_nchw, coords_bcxy, K, C, H, W, pred);
     return nbp_launch_status();
@@ -811,6 +826,7 @@ extern "C" int nbp_gather_values_f32(const float* out1_nchw, const long long* co
 
 extern "C" int nbp_scatter_values_f32(const float* dpred, const long long* coords_bcxy, int K, int C, int H, int W,
                                       float* dout1_nchw_zeroed, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!dpred || !coords_bcxy || !dout1_nchw_zeroed || K < 1, NBP_E_ARG);
     scatter_values_kernel<<<(unsigned)nbp_cdiv(K, 256), 256, 0, (hipStream_t)stream>>>(dpred, coords_bcxy, K, C, H, W,
                                                                                         dout1_nchw_zeroed);
@@ -820,6 +836,7 @@ extern "C" int nbp_scatter_values_f32(const float* dpred, const long long* coord
 // mode 0: MSE, mode 1: BCE.  *sum_out (device double) = sum of per-element losses; dp = coef * d(mean loss)/dp
 extern "C" int nbp_loss_f32(int mode, const float* p, const float* t, long long n, float grad_coef, double* sum_out,
                             float* dp_or_null, void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
     NBP_RETURN_IF(!p || !t || !sum_out || !ws || n < 1 || mode < 0 || mode > 1, NBP_E_ARG);
     NBP_RETURN_IF(ws_bytes < 512 * sizeof(double) + 256, NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;

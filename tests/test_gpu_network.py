@@ -188,3 +188,16 @@ def test_argument_errors(hip):
     assert L.nbp_forward_f32(None, None, 1, 256, None, None, None, 0, None) == -1
     z = torch.zeros(16, device="cuda")
     assert L.nbp_maxpool2_nhwc_f32(_lib.ptr(z), 1, 3, 3, 4, _lib.ptr(z), None) == -3
+
+
+def test_build_then_smoke_in_one_process(hip):
+    """Loading libnbp_hip.so before PyTorch has initialised HIP must still bind to PyTorch's runtime
+    (regression: two libamdhip64 instances in one process -> hipErrorNoDevice on the first call)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from nextbestpath_amd import _lib\n_lib.lib()\n"
+            "import __graft_entry__ as g\ng.build(); g.smoke(); print('OK')\n") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-800:] + out.stderr[-1500:]
