@@ -85,6 +85,46 @@ def gen_network(model):
         print(tag, "out1", float(o1.abs().max()), "out2", float(o2.min()), float(o2.max()))
 
 
+def gen_training(model):
+    """Train-mode forward (batch-statistics BatchNorm), NBP.loss, parameter gradients and the running statistics
+    after one forward of the REFERENCE module: pins oracle/nbp_net.py's train path and nbp_loss."""
+    from nextbestpath_amd.utility.synthetic import make_nbp_state_dict, make_count_maps
+    torch.set_num_threads(8)
+    sd = make_nbp_state_dict(9)
+    net = model.NBP()
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    B, S = 2, 32
+    x = make_count_maps(B, S, seed=31)
+    g = torch.Generator().manual_seed(32)
+    K = 7
+    coords = torch.stack([torch.randint(0, B, (K,), generator=g), torch.randint(0, 8, (K,), generator=g),
+                          torch.randint(0, S // 4, (K,), generator=g), torch.randint(0, S // 4, (K,), generator=g)], 1)
+    gains = torch.rand(K, generator=g) * 5
+    gt = (torch.rand(B, 1, S, S, generator=g) < 0.1).float()
+    o1, o2 = net(x)
+    pred = o1[coords[:, 0], coords[:, 1], coords[:, 2], coords[:, 3]]          # nbp_utils.py:373-381
+    loss = net.loss(pred, gains, o2, gt)
+    loss.backward()
+    keys = ["Conv1.conv.0.weight", "Conv1.conv.1.weight", "Conv3.conv.3.weight", "Conv5.conv.4.bias", "Up5_1.up.1.weight",
+            "Att4_2.W_g.0.weight", "Att3_2.psi.0.weight", "Att2_2.psi.1.bias", "Up_conv2_2.conv.3.bias", "Final1.weight",
+            "Final2.0.bias", "log_vars"]
+    named = dict(net.named_parameters())
+    grads = {}
+    for k in keys:       # small fixtures: at most 4096 strided entries per gradient + its sum and |sum|
+        gflat = named[k].grad.detach().double().flatten()
+        stride = max(1, (gflat.numel() + 4095) // 4096)
+        kk = k.replace(".", "__")
+        grads[kk] = gflat[::stride].float().numpy()
+        grads[kk + "__stats"] = np.array([stride, float(gflat.sum()), float(gflat.abs().sum())])
+    bufs = dict(net.named_buffers())
+    np.savez_compressed(os.path.join(HERE, "nbp_train_S32B2.npz"), x=x.numpy(), coords=coords.numpy(), gains=gains.numpy(),
+                        gt=gt.numpy(), out1=o1.detach().numpy(), out2=o2.detach().numpy(), loss=float(loss),
+                        grad_keys=np.array(keys), run_mean_Conv1=bufs["Conv1.conv.1.running_mean"].numpy(),
+                        run_var_Up5_2=bufs["Up5_2.up.2.running_var"].numpy(), **grads)
+    print("train: loss", float(loss), "|grad Conv1|", float(named[keys[0]].grad.abs().max()))
+
+
 def gen_maps(utils):
     rng = np.random.default_rng(21)
     dev = torch.device("cpu")
@@ -272,3 +312,4 @@ if __name__ == "__main__":
     gen_planner(ltu, mu)
     gen_replan(utils, ltu, mu)
     gen_network(model)
+    gen_training(model)

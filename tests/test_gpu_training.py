@@ -1,5 +1,7 @@
 """GPU parity of the training step (nbp.train(): forward with batch statistics, loss, backward) against
 torch-fp32 CPU autograd on the oracle network (the reference's own arithmetic: same ATen ops)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -302,3 +304,28 @@ def test_wgrad_halo_kernel_vs_fp64(hip, shape):
         xin = torch.nn.functional.interpolate(xin, scale_factor=2)
     ref = torch.nn.grad.conv2d_weight(xin, (N, C0 + C1, 3, 3), dy.permute(0, 3, 1, 2).double().cpu(), padding=1)
     assert (dw.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6
+
+
+def test_training_step_vs_reference_golden(hip, nbp_weights, golden_dir):
+    """HIP train-mode forward + loss against the REFERENCE module's own outputs (tests/golden/nbp_train_S32B2.npz);
+    gradients (ill conditioned at this size, see above) in relative L2 over the strided samples."""
+    g = np.load(os.path.join(golden_dir, "nbp_train_S32B2.npz"))
+    sd = {k: v.clone() for k, v in nbp_weights.items()}
+    coords = torch.from_numpy(g["coords"])
+    net, o1, o2, loss = _hip_step(sd, torch.from_numpy(g["x"]), coords, torch.from_numpy(g["gains"]), torch.from_numpy(g["gt"]))
+    s1 = float(np.abs(g["out1"]).max())
+    assert np.abs(o1.detach().cpu().numpy() - g["out1"]).max() < 1e-4 * max(1.0, s1)
+    assert np.abs(o2.detach().cpu().numpy() - g["out2"]).max() < 1e-4
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    named = dict(net.named_parameters())
+    for k in g["grad_keys"]:
+        k = str(k)
+        kk = k.replace(".", "__")
+        stride = int(g[kk + "__stats"][0])
+        got = named[k].grad.detach().cpu().double().flatten()[::stride].numpy()
+        ref = g[kk].astype(np.float64)
+        if np.abs(ref).max() < 1e-5:       # a conv bias in front of train-mode BatchNorm: the true gradient is 0,
+            assert np.abs(got).max() < 1e-4, (k, np.abs(got).max())   # what is stored is rounding noise
+            continue
+        rel = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-12)
+        assert rel < 0.15, (k, rel)

@@ -77,3 +77,29 @@ def test_maps_edge_cases():
     p = np.array([[40.0, 0.5, 0.0], [-40.0, 0.5, 0.0]], np.float32)
     out = omaps.accumulate_step_maps(p, pose, [0, 1, 2, 3, 4], S=16)
     assert out[:5].sum() == 1
+
+
+def test_training_oracle_vs_reference(nbp_weights, golden_dir):
+    """Train-mode forward, NBP.loss and parameter gradients of the REFERENCE module (tests/golden/make_golden.py::
+    gen_training) reproduced by the oracle's functional restatement + autograd."""
+    g = _load(golden_dir, "nbp_train_S32B2.npz")
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+          for k, v in nbp_weights.items()}
+    x, coords = torch.from_numpy(g["x"]), torch.from_numpy(g["coords"])
+    o1, o2 = nbp_net.nbp_forward(sd, x, train=True)
+    assert np.abs(o1.detach().numpy() - g["out1"]).max() < 5e-5 * max(1.0, float(np.abs(g["out1"]).max()))
+    assert np.abs(o2.detach().numpy() - g["out2"]).max() < 5e-6
+    pred = o1[coords[:, 0], coords[:, 1], coords[:, 2], coords[:, 3]]
+    loss = nbp_net.nbp_loss(sd["log_vars"], pred, torch.from_numpy(g["gains"]), o2, torch.from_numpy(g["gt"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    for k in g["grad_keys"]:
+        k = str(k)
+        kk = k.replace(".", "__")
+        stride, gsum, gabs = g[kk + "__stats"]
+        got = sd[k].grad.double().flatten()
+        # same ops, same weights; the thread-count summation order and one ReLU / BatchNorm conditioning effect apart
+        assert abs(float(got.abs().sum()) - gabs) < 2e-3 * gabs + 1e-9, k
+        ref = g[kk]
+        err = np.abs(got[::int(stride)].numpy() - ref).max()
+        assert err < 2e-3 * max(np.abs(ref).max(), 1e-6), (k, err)
