@@ -98,7 +98,8 @@ _ws_cache = {}
 
 
 def _workspace(B, S, device, bf16=False):
-    key = (B, S, str(device), bf16)
+    # one workspace per (shape, stream): forwards enqueued on different streams may run concurrently
+    key = (B, S, str(device), bf16, torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None:
         L = _lib.lib()
@@ -106,7 +107,9 @@ def _workspace(B, S, device, bf16=False):
         if n == 0:
             raise _lib.NbpHipError(f"unsupported NBP input size B={B} S={S}")
         ws = torch.empty(n, dtype=torch.uint8, device=device)
-        _ws_cache.clear()          # keep one workspace alive (sizes rarely change)
+        if len(_ws_cache) >= 8:    # keep a few workspaces alive (sizes rarely change); an evicted one may still be
+            torch.cuda.synchronize(device)      # in use by a forward in flight on another stream
+            _ws_cache.pop(next(iter(_ws_cache)))
         _ws_cache[key] = ws
     return ws
 

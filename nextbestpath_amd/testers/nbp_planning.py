@@ -170,55 +170,75 @@ class MultiRollout:
     concurrent rollouts per rank").  They are split in two groups that are software-pipelined: while the GPU
     runs one group's batched NBP forward (B = R/2 in the GEMM M dimension) the host finishes the other
     group's replanning (event wait + search) and enqueues its move / raster / un-projection, so neither
-    side idles.  Each rollout's results are identical to running it alone (tests/test_gpu_rollout.py)."""
+    side idles.  Each group has its own HIP stream: the small latency-bound kernels of one group's step (coverage,
+    un-projection, map accumulation, raster, planner) run underneath the other group's convolutions instead of
+    in front of them.  Each rollout's results are identical to running it alone (tests/test_gpu_rollout.py)."""
 
-    def __init__(self, rollouts, nbp, device, grid=None):
+    def __init__(self, rollouts, nbp, device, grid=None, streams=True, n_groups=None):
         self.rollouts, self.nbp = list(rollouts), nbp
         grid = grid or self.rollouts[0].S
         R = len(self.rollouts)
-        half = (R + 1) // 2
-        self.groups = [g for g in (self.rollouts[:half], self.rollouts[half:]) if g]
+        n_groups = n_groups or int(os.environ.get("NBP_ROLLOUT_GROUPS", "2"))
+        n_groups = max(1, min(n_groups, R))
+        per = (R + n_groups - 1) // n_groups
+        self.groups = [self.rollouts[i:i + per] for i in range(0, R, per)]
         self.net_in = [torch.zeros(len(g), 5, grid, grid, dtype=torch.float32, device=device) for g in self.groups]
         self.events = [torch.cuda.Event() for _ in self.groups]
         self.inflight = [False] * len(self.groups)
+        # everything a rollout owns is only ever touched on its group's stream
+        main = torch.cuda.current_stream(device)
+        if streams and len(self.groups) >= 2:
+            self.streams = [torch.cuda.Stream(device) for _ in self.groups]
+            for st in self.streams:
+                st.wait_stream(main)          # the rollouts were built on the caller's stream
+        else:
+            self.streams = [main for _ in self.groups]
 
     def _launch(self, gi):
         grp, net_in = self.groups[gi], self.net_in[gi]
-        for i, r in enumerate(grp):
-            r.pre(net_in[i:i + 1])
-        with torch.no_grad():
-            out1, out2 = self.nbp(net_in)
-        for i, r in enumerate(grp):
-            r.plan_enqueue(out1[i], out2[i])
-        self.events[gi].record()
+        with torch.cuda.stream(self.streams[gi]):
+            for i, r in enumerate(grp):
+                r.pre(net_in[i:i + 1])
+            with torch.no_grad():
+                out1, out2 = self.nbp(net_in)
+            for i, r in enumerate(grp):
+                r.plan_enqueue(out1[i], out2[i])
+            self.events[gi].record()
         self.inflight[gi] = True
 
     def _complete(self, gi):
         grp = self.groups[gi]
         if any(r.need_replan for r in grp):
             self.events[gi].synchronize()          # the GPU keeps running whatever was queued after the event
-        for r in grp:
-            r.plan_finish()
-        for r in grp:
-            r.post()
+        with torch.cuda.stream(self.streams[gi]):
+            for r in grp:
+                r.plan_finish()
+            for r in grp:
+                r.post()
         self.inflight[gi] = False
 
     def step(self):
-        """One exploration step of every rollout (the last group's completion is deferred to the next call)."""
-        for gi in range(len(self.groups)):
+        """One exploration step of every rollout (completions are deferred: a group is finished right after the
+        next group has been launched, so the GPU always has another group's forward queued)."""
+        G = len(self.groups)
+        for gi in range(G):
             if self.inflight[gi]:
                 self._complete(gi)
             self._launch(gi)
-            other = 1 - gi
-            if len(self.groups) == 2 and self.inflight[other] and other != gi:
-                self._complete(other)
-        if len(self.groups) == 1:
+            prev = (gi - 1) % G
+            if G >= 2 and self.inflight[prev] and prev != gi:
+                self._complete(prev)
+        if G == 1:
             self._complete(0)
 
     def flush(self):
         for gi in range(len(self.groups)):
             if self.inflight[gi]:
                 self._complete(gi)
+        main = torch.cuda.current_stream()
+        for st in self.streams:
+            if st is not main:
+                main.wait_stream(st)           # later work on the caller's stream sees every rollout's results
 
 
 def compute_nbp_trajectory(params, nbp, camera, gt_scene_pc, mesh, mesh_for_check, n_pieces, y_bins, device,

@@ -22,7 +22,8 @@ _ws = {}
 
 
 def _workspace(tag, nbytes, device):
-    key = (tag, str(device))
+    # scratch is per (kind, device, STREAM): rollouts stepped on different streams run their kernels concurrently
+    key = (tag, str(device), _st())
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

@@ -108,6 +108,35 @@ def test_multi_rollout_matches_single(hip, dataset, nbp_weights):
         assert ca == cb
 
 
+def test_four_streams_match_single_rollouts(hip, dataset, nbp_weights):
+    """Four groups = four HIP streams stepping concurrently (scratch buffers are per stream): every rollout still walks
+    exactly the trajectory it walks alone."""
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.testers import nbp_planning as tp
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    ds = sc.SceneDataset(dataset)
+    net = _net(nbp_weights)
+    dev = torch.device("cuda")
+    n = 8
+    singles = [tp.build_rollout(params, net, ds, (i % 2, 0), dev, seed=40 + i) for i in range(4)]
+    for r in singles:
+        for _ in range(n):
+            r.step()
+    multi_r = [tp.build_rollout(params, net, ds, (i % 2, 0), dev, seed=40 + i) for i in range(4)]
+    m = tp.MultiRollout(multi_r, net, dev, n_groups=4)
+    assert len(m.groups) == 4 and len({s.cuda_stream for s in m.streams}) == 4
+    for _ in range(n):
+        m.step()
+    m.flush()
+    torch.cuda.synchronize()
+    for a, b in zip(singles, multi_r):
+        assert a.camera.cam_idx_history == b.camera.cam_idx_history
+        assert a.coverage_evolution(n) == b.coverage_evolution(n)
+        assert int(a.st.cloud_count.item()) == int(b.st.cloud_count.item())
+        k = int(a.st.cloud_count.item())
+        assert torch.equal(a.st.cloud[:k], b.st.cloud[:k])
+
+
 def test_rollout_on_512_grid(hip, dataset, nbp_weights):
     """BASELINE configs[4] geometry: 512x512 grid, +-80 window (same 0.3125 units / pixel), value map 128x128."""
     from nextbestpath_amd.simulator import scene as sc
