@@ -20,12 +20,6 @@
 #include "nbp_internal.h"
 #include <cstdlib>
 
-#ifndef NBP_STAGGER
-#define NBP_STAGGER 0
-#endif
-#ifndef NBP_INTERLEAVE
-#define NBP_INTERLEAVE 0
-#endif
 
 struct IgemmArgs {
     const float* src0;
@@ -183,19 +177,9 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
     }
     __syncthreads();
     int cur = 0;
-#if NBP_STAGGER
-    // the two workgroups that share a CU start in phase and would hit their load/barrier phases together:
-    // delay the second half of the grid by ~half a chunk so one wave's MFMA block covers the other's gap
-    {
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (lin >= (gridDim.x * gridDim.y * gridDim.z) / 2) __builtin_amdgcn_s_sleep(NBP_STAGGER);
-    }
-#endif
     for (int c = c_begin; c < c_end; ++c) {
         const bool more = (c + 1 < c_end);
-#if !NBP_INTERLEAVE
         if (more) load_global(c + 1);
-#endif
         const float* A = lds + cur * STAGE;
         const float* Bt = A + BM * 32;
 #pragma unroll
@@ -208,9 +192,6 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 bf[j] = *reinterpret_cast<const f32x4*>(Bt + fb_row[j] + ((s ^ fb_sw[j]) << 2));
-#if NBP_INTERLEAVE
-            if (j4 == 0 && more) load_global(c + 1);      // issued under the first MFMA group
-#endif
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -218,13 +199,8 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
-#if NBP_INTERLEAVE
-            if (j4 == 2 && more) store_lds(cur ^ 1);      // lands while the last MFMA group runs
-#endif
         }
-#if !NBP_INTERLEAVE
         if (more) store_lds(cur ^ 1);
-#endif
         __syncthreads();
         cur ^= 1;
     }
