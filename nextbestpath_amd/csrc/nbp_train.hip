@@ -489,7 +489,9 @@ static bool wgrad_halo_ok(int H, int W, int ksize) { return ksize == 3 && H >= 2
 static void wgrad_halo_plan(int B, int H, int W, int Ctot, int N, int* n_tiles, int* splits) {
     *n_tiles = B * (H / 2) * (W / 32);
     const long long pairs = (long long)(Ctot / 64) * (N / 64);
-    long long s = nbp_cdiv(1024, pairs);                 // >= 1024 workgroups (2 per CU, 2 rounds)
+    // one round of two workgroups per CU; more pixel splits only add partial slices for wgrad_reduce to read back
+    static const int target = [] { const char* e = getenv("NBP_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+    long long s = nbp_cdiv(target, pairs);
     if (s > *n_tiles) s = *n_tiles;
     if (s > 1024) s = 1024;
     if (s < 1) s = 1;
