@@ -11,6 +11,7 @@
 //     consecutive output channels of one pixel: 8-B bf16 stores (16-B fp32 stores for split-K partial sums).
 #include "common.h"
 #include "nbp_internal.h"
+#include "nbp_first_conv.h"
 #include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -677,11 +678,25 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float* __res
     *reinterpret_cast<u16x8*>(op + 8) = o1;
 }
 
+__global__ __launch_bounds__(256) void conv_first_mfma_bf16_kernel(const float* __restrict__ x, int B, int H, int W,
+                                                                   const float* __restrict__ w, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, bf16_t* __restrict__ out) {
+    conv_first_mfma_body<bf16_t>(x, B, H, W, w, scale, shift, out, [](bf16_t* p, const f32x4& v) {
+        u16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<u16x4*>(p) = o;
+    });
+}
+
 int nbp_conv_first_bf16_launch(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale,
                                const float* shift, bf16_t* out_nhwc, hipStream_t st) {
     NBP_RETURN_IF(!x_nchw || !w_oihw || !scale || !shift || !out_nhwc, NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 1 || W < 1, NBP_E_ARG);
     long long M = (long long)B * H * W;
+    static const int use_mfma = [] { const char* e = getenv("NBP_FIRST_MFMA"); return e ? atoi(e) : 1; }();
+    if (use_mfma && (H & 7) == 0 && (W & 31) == 0) {
+        conv_first_mfma_bf16_kernel<<<(unsigned)(M / 256 < 2048 ? M / 256 : 2048), 256, 0, st>>>(x_nchw, B, H, W, w_oihw, scale, shift, out_nhwc);
+        return nbp_launch_status();
+    }
     conv_first_bf16_kernel<<<(unsigned)nbp_cdiv(M, 64), 256, 0, st>>>(x_nchw, B, H, W, w_oihw, scale, shift, out_nhwc);
     return nbp_launch_status();
 }

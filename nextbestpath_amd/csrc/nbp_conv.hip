@@ -18,6 +18,7 @@
 // 8j+4..8j+7); A and B use the same permutation so the sum over k is complete.
 #include "common.h"
 #include "nbp_internal.h"
+#include "nbp_first_conv.h"
 #include <cstdlib>
 
 
@@ -705,12 +706,25 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
     }
 }
 
+__global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __restrict__ x, int B, int H, int W,
+                                                              const float* __restrict__ w, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, float* __restrict__ out) {
+    conv_first_mfma_body<float>(x, B, H, W, w, scale, shift, out,
+                                [](float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; });
+}
+
 extern "C" int nbp_conv_first_f32(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale,
                                   const float* shift, float* out_nhwc, void* stream) {
     NBP_ENTER();
     NBP_RETURN_IF(!x_nchw || !w_oihw || !scale || !shift || !out_nhwc, NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 1 || W < 1, NBP_E_ARG);
     long long M = (long long)B * H * W;
+    static const int use_mfma = [] { const char* e = getenv("NBP_FIRST_MFMA"); return e ? atoi(e) : 1; }();
+    if (use_mfma && (H & 7) == 0 && (W & 31) == 0) {     // 8 x 32 pixel tiles; other sizes take the VALU kernel below
+        conv_first_mfma_kernel<<<(unsigned)(M / 256 < 2048 ? M / 256 : 2048), 256, 0, (hipStream_t)stream>>>(x_nchw, B, H, W, w_oihw, scale, shift,
+                                                                                   out_nhwc);
+        return nbp_launch_status();
+    }
     conv_first_kernel<<<(unsigned)nbp_cdiv(M, 64), 256, 0, (hipStream_t)stream>>>(x_nchw, B, H, W, w_oihw, scale,
                                                                                    shift, out_nhwc);
     return nbp_launch_status();
