@@ -215,7 +215,9 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmArgsH a) {
 // the weights of the next tap (double buffered) behind the current tap's MFMAs.  Vector-memory traffic per chunk
 // drops from 9*(256+BN)*128 B to (344 + 9*BN)*128 B.  Two workgroups share a CU (<= 76 KB of LDS each), so one
 // covers the other's halo reload.  Same K order as the implicit GEMM (chunk, tap, k): results are bit-identical.
-template <int TN>
+// TPS = filter taps per weight stage (= per barrier): the 64-channel variant pairs taps so that a wave still has 32 MFMAs
+// between barriers (its 16 per tap finish in 512 cycles, too close to the barrier + first-fragment latency).
+template <int TN, int TPS>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a) {
     int zs = blockIdx.z;        // split-K slice (of 64-channel chunks), then the group
     if (zs >= a.split_k) {
@@ -226,7 +228,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
     constexpr int HW_ = 34;                    // halo tile width (32 + 2)
     constexpr int HALO_ROWS = 344;             // 10 * 34 = 340 halo pixels, padded to 43 DMA instructions of 8 rows
     constexpr int HALO_BYTES = HALO_ROWS * 128;
-    constexpr int WB = BN * 128;               // one weight stage: BN rows of 64 bf16
+    constexpr int WB = TPS * BN * 128;         // one weight stage: TPS taps x BN rows of 64 bf16
+    constexpr int NST = (9 + TPS - 1) / TPS;   // stages per 64-channel chunk
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const halo = lds;
     char* const wbuf = lds + HALO_BYTES;
@@ -277,12 +280,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
             }
         }
     };
-    auto issue_w = [&](int t) {      // t = chunk * 9 + tap: the packed weights are [chunk][tap][N][64]
-        char* dst = wbuf + (t & 1) * WB + wave * 1024;
-        const unsigned woff = (unsigned)(((long long)t * a.N + n0 + lrow) * 64 + wslot * 8) * 2u;
+    auto issue_w = [&](int u) {      // u = chunk * NST + stage; the packed weights are [chunk][tap][N][64]
+        const int cu = u / NST, su = u - cu * NST;
+        char* dst = wbuf + (u & 1) * WB + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + j * 4096), 16, woff + j * 4096, 0, 0, 0);
+        for (int tt = 0; tt < TPS; ++tt) {
+            const int tap = su * TPS + tt;
+            if (tap < 9) {
+                const unsigned woff = (unsigned)(((long long)(cu * 9 + tap) * a.N + n0 + lrow) * 64 + wslot * 8) * 2u;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + tt * (BN * 128) + j * 4096), 16,
+                                                             woff + j * 4096, 0, 0, 0);
+            }
+        }
     };
 
     f32x16 acc[2][TN];
@@ -304,35 +315,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
 
     const int cc_begin = zs * (a.chunks_per_split / 9);
     const int chunks = min(cc_begin + a.chunks_per_split / 9, a.chunks_total / 9);
-    const int t_total = chunks * 9;
+    const int u_total = chunks * NST;
     if (cc_begin < chunks) {
         issue_halo(cc_begin);
-        issue_w(cc_begin * 9);
+        issue_w(cc_begin * NST);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int cc = cc_begin; cc < chunks; ++cc) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int t = cc * 9 + tap;
-            if (t + 1 < t_total) issue_w(t + 1);
-            const char* Bt = wbuf + (t & 1) * WB;
-            const int hr0 = hbase + (tap / 3) * HW_ + (tap % 3);
-            const int hr1 = hr0 + HW_;
-            const int ar0 = hr0 * 128, as0 = (hr0 >> 1) & 7, ar1 = hr1 * 128, as1 = (hr1 >> 1) & 7;
+        for (int st = 0; st < NST; ++st) {
+            const int u = cc * NST + st;
+            if (u + 1 < u_total) issue_w(u + 1);
 #pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4) {
-                const int s = 2 * j4 + khalf;
-                const bf16x8 x0f = *reinterpret_cast<const bf16x8*>(halo + ar0 + ((s ^ as0) << 4));
-                const bf16x8 x1f = *reinterpret_cast<const bf16x8*>(halo + ar1 + ((s ^ as1) << 4));
-                bf16x8 wf[TN];
+            for (int tt = 0; tt < TPS; ++tt) {
+                const int tap = st * TPS + tt;
+                if (tap < 9) {
+                    const char* Bt = wbuf + (u & 1) * WB + tt * (BN * 128);
+                    const int hr0 = hbase + (tap / 3) * HW_ + (tap % 3);
+                    const int hr1 = hr0 + HW_;
+                    const int ar0 = hr0 * 128, as0 = (hr0 >> 1) & 7, ar1 = hr1 * 128, as1 = (hr1 >> 1) & 7;
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    wf[j] = *reinterpret_cast<const bf16x8*>(Bt + fb_row[j] + ((s ^ fb_sw[j]) << 4));
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const int s = 2 * j4 + khalf;
+                        const bf16x8 x0f = *reinterpret_cast<const bf16x8*>(halo + ar0 + ((s ^ as0) << 4));
+                        const bf16x8 x1f = *reinterpret_cast<const bf16x8*>(halo + ar1 + ((s ^ as1) << 4));
+                        bf16x8 wf[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], x0f, acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], x1f, acc[1][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j)
+                            wf[j] = *reinterpret_cast<const bf16x8*>(Bt + fb_row[j] + ((s ^ fb_sw[j]) << 4));
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], x0f, acc[0][j], 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], x1f, acc[1][j], 0, 0, 0);
+                        }
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -467,18 +484,18 @@ ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int 
     return p;
 }
 
-template <int TN>
+template <int TN, int TPS>
 static int launch_halo(const IgemmArgsH& a, hipStream_t st) {
-    constexpr size_t smem = 344 * 128 + 2 * (size_t)TN * 32 * 128;
+    constexpr size_t smem = 344 * 128 + 2 * (size_t)TPS * TN * 32 * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TN, TPS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((unsigned)(a.M / 256), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups));
-    conv3x3_halo_bf16_kernel<TN><<<grid, 256, smem, st>>>(a);
+    conv3x3_halo_bf16_kernel<TN, TPS><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 
@@ -543,8 +560,12 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
         case NBP_TILE_256x32: rc = launch_igemm_h<4, 1, 2, 1>(a, st); break;
         case NBP_TILE_128x64: rc = launch_igemm_h<2, 2, 2, 1>(a, st); break;
         case NBP_TILE_64x128: rc = launch_igemm_h<1, 4, 2, 1>(a, st); break;
-        case NBP_TILE_HALO_128: rc = launch_halo<4>(a, st); break;
-        case NBP_TILE_HALO_64: rc = launch_halo<2>(a, st); break;
+        case NBP_TILE_HALO_128: rc = launch_halo<4, 1>(a, st); break;
+        case NBP_TILE_HALO_64: {
+            static const int tps = [] { const char* e = getenv("NBP_BF16_TPS"); return e ? atoi(e) : 2; }();
+            rc = tps == 2 ? launch_halo<2, 2>(a, st) : launch_halo<2, 1>(a, st);
+            break;
+        }
         default: return NBP_E_ARG;
     }
     if (rc) return rc;
