@@ -51,6 +51,7 @@ struct IgemmArgsH {
     const float* g_scale;
     const float* g_shift;
     bf16_t* g_out;
+    int xcd_remap;     // halo kernel: XCD-contiguous (pixel tile, channel block) runs
 };
 
 template <int WM, int WN, int TM, int TN>
@@ -236,12 +237,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = a.W >> 5, tiles_y = a.H >> 3;
-    int tile = blockIdx.x;
+    unsigned tile = blockIdx.x, nt = blockIdx.y;
+    if (a.xcd_remap) {      // XCD-contiguous runs of (pixel tile, channel block), channel block fastest (see nbp_conv.hip)
+        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, T = gridDim.x * gridDim.y;
+        const unsigned xcd = L & 7u, idx = L >> 3, q = T >> 3, r = T & 7u;
+        const unsigned v = xcd * q + min(xcd, r) + idx;
+        nt = v % gridDim.y;
+        tile = v / gridDim.y;
+    }
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y;
     const int b = tile / tiles_y;
     const int y0 = ty * 8, x0 = tx * 32;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = nt * BN;
 
     // ---- halo DMA coordinates: instruction q = 4 i + wave covers halo pixels 8 q .. 8 q + 7 (row-major 10 x 34)
     int hpix[11];
@@ -548,6 +556,10 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
     if (p.tile == NBP_TILE_HALO_128 || p.tile == NBP_TILE_HALO_64)
         NBP_RETURN_IF(!halo_ok(H, W, N, ksize, ti.bn), NBP_E_SHAPE);
     a.split_k = p.split_k; a.chunks_per_split = p.chunks_per_split;
+    {
+        static const int forced = [] { const char* e = getenv("NBP_XCD_REMAP"); return e ? atoi(e) : -1; }();
+        a.xcd_remap = forced >= 0 ? forced : ((a.M / 256) * (N / ti.bn) >= 512 ? 1 : 0);
+    }
     a.partial = nullptr;
     if (p.split_k > 1) {
         NBP_RETURN_IF(!ws || ws_bytes < (size_t)groups * p.split_k * a.M * N * sizeof(float), NBP_E_WS);

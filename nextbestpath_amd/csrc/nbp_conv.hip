@@ -258,12 +258,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = a.W >> 5, tiles_y = a.H >> 3;
-    int tile = blockIdx.x;
+    // XCD-aware order: the workgroups one XCD receives (every 8th linear id) take a contiguous run of (pixel tile,
+    // channel block) pairs, channel block fastest: the channel blocks of a tile share its halo in that XCD's L2 and
+    // neighbouring tiles share their border rows / columns
+    unsigned tile = blockIdx.x, nt = blockIdx.y;
+    if (a.xcd_remap) {
+        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, T = gridDim.x * gridDim.y;
+        const unsigned xcd = L & 7u, idx = L >> 3, q = T >> 3, r = T & 7u;
+        const unsigned v = xcd * q + min(xcd, r) + idx;
+        nt = v % gridDim.y;
+        tile = v / gridDim.y;
+    }
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y;
     const int b = tile / tiles_y;
     const int y0 = ty * 8, x0 = tx * 32;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = nt * BN;
 
     int hpix[11];
 #pragma unroll
@@ -570,7 +580,8 @@ int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C
         // so only multi-wave grids get them.  NBP_XCD_REMAP=0/1 forces the choice (A/B measurements).
         static const int forced = [] { const char* e = getenv("NBP_XCD_REMAP"); return e ? atoi(e) : -1; }();
         const long long tiles = nbp_cdiv(a.M, ti.bm) * (N / ti.bn);
-        a.xcd_remap = forced >= 0 ? forced : (tiles >= 2048 ? 1 : 0);
+        const bool halo = p.tile == NBP_TILE_HALO_128 || p.tile == NBP_TILE_HALO_64;
+        a.xcd_remap = forced >= 0 ? forced : ((halo ? tiles >= 512 : tiles >= 2048) ? 1 : 0);
     }
     a.partial = nullptr;
     if (p.split_k > 1) {
