@@ -78,8 +78,8 @@ int nbp_forward_f32(const nbp_weights* handle, const float* x, int B, int S, flo
 
 /* Profiling twin of nbp_forward_f32: brackets every launch group with hipEvents on `stream`,
  * SYNCHRONISES the stream, and fills timings_host[0..*n_entries_host) (one entry per layer, in
- * launch order; `ms` of a split-K layer includes its reduce kernel).  tile: NBP_TILE id of the
- * implicit-GEMM kernel used, -1 for the non-GEMM kernels.  Not re-entrant. */
+ * launch order; `ms` of a split-K layer includes its reduce kernel).  tile: id of the convolution
+ * kernel used (see nbp_conv_igemm_f32), -1 for the other kernels.  Not re-entrant. */
 typedef struct nbp_layer_timing {
     char name[48];
     double flops;      /* 2*M*N*K */
@@ -130,7 +130,9 @@ int nbp_bf16_to_f32(const unsigned short* in, long long n, float* out, void* str
  *   sources are then [B,H/2,W/2,C];  C0,C1 multiples of 32 (C1 may be 0), N multiple of 32.
  *   w_packed: layout produced by nbp_pack_conv_weight.  out [B,H,W,N] = act(acc*scale+shift).
  *   split_k >= 1 splits the K loop over blockIdx.z (ws must hold split_k*B*H*W*N floats);
- *   split_k == 0 lets the library choose.  tile: 0 = auto, else a NBP_TILE_* id. */
+ *   split_k == 0 lets the library choose.  tile: 0 = auto; 1..5 = implicit-GEMM workgroup tiles (pixels x
+ *   channels) 128x128, 256x64, 256x32, 128x64, 64x128; 6 / 7 = the halo-tile kernel (3x3 only, H % 8 == 0,
+ *   W % 32 == 0) with 128 / 64 output channels per workgroup, whose split-K slices are whole channel chunks. */
 int nbp_conv_igemm_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H,
                        int W, int ksize, const float* w_packed, int N, const float* scale,
                        const float* shift, int relu, float* out, int split_k, int tile, void* ws,
