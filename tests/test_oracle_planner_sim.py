@@ -235,3 +235,38 @@ def test_carving_oracle_bilinear_matches_torch_grid_sample_and_plane_kat():
     inf2, sd2 = ocam.carve_update(world, plane, None, R, T, zfar, 60.0, 1.0, 0.95, *st2)
     assert inf2.all() and np.allclose(sd2, zs - 20.0, atol=1e-3)
     assert st2[2].tolist() == [0.0, 0.0, 1.0, 1.0, 1.0]
+
+
+def test_level_order_search_equals_heap_search_on_random_lattices():
+    """Host logic of the product (integer level-order search on a precomputed edge mask) against the heapq restatement
+    of generate_Dijkstra_path (long_term_utils.py:366-383) on 40 random lattices with random DIRECTED blocked edges:
+    same came_from tree, hence the same paths and the reference's tie-breaking."""
+    from nextbestpath_amd.utility import planner_host as ph
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        L, Hh = int(rng.integers(3, 9)), int(rng.integers(3, 9))
+        idx = [(i, 0, k) for i in range(L) for k in range(Hh) if rng.random() > 0.1]      # lexicographic ids, holes
+        if not idx:
+            continue
+        nodes = {t: n for n, t in enumerate(idx)}
+        edges, nbrs = [], [[] for _ in idx]
+        for n, (i, j, k) in enumerate(idx):
+            for nb in ((i + 1, j, k), (i - 1, j, k), (i, j, k + 1), (i, j, k - 1)):
+                if nb in nodes:
+                    nbrs[n].append((nodes[nb], len(edges)))
+                    edges.append((n, nodes[nb]))
+        ok = rng.random(len(edges)) > 0.3
+        okset = {(idx[a], idx[b]) for (a, b), o in zip(edges, ok) if o}
+        start = idx[int(rng.integers(len(idx)))]
+        tree = opl.dijkstra_tree(set(nodes), start, lambda a, b: (tuple(a), tuple(b)) in okset)
+        par = ph.level_order_tree(nbrs, ok, nodes[start])
+        assert {idx[v]: (idx[p] if p >= 0 else None) for v, p in par.items()} == tree, trial
+        for goal in idx:
+            want = opl.path_from_tree(tree, goal)
+            if goal not in tree:
+                assert want is None and nodes[goal] not in par
+                continue
+            got, cur = [], nodes[goal]
+            while cur >= 0:
+                got.append(idx[cur]); cur = par[cur]
+            assert got[::-1] == [tuple(p) for p in want]
