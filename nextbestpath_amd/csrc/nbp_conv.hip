@@ -241,7 +241,9 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {
 // every 8192 MFMA cycles instead of every 4096.  K order: (chunk, tap, channel) as in the implicit GEMM.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int TN>
+// TM = image rows per wave: 2 -> 8 x 32 pixel tiles; 1 -> 4 x 32 pixel tiles (twice the workgroups for small images / B = 1,
+// at half the MFMAs per barrier).
+template <int TN, int TM>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
     int zs = blockIdx.z;        // split-K slice (of 32-channel chunks), then the group
     if (zs >= a.split_k) {
@@ -250,14 +252,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
     }
     constexpr int BN = TN * 32;
     constexpr int HW_ = 34;
-    constexpr int HALO_BYTES = 344 * 128;     // 10 * 34 = 340 halo pixels of 32 floats, padded to 43 DMA instructions
+    constexpr int TROWS = 4 * TM;                              // image rows per tile
+    constexpr int HPIX = (TROWS + 2) * HW_;                    // halo pixels of 32 floats: 340 (TM = 2) / 204 (TM = 1)
+    constexpr int SLOTS = (HPIX + 7) / 8;                      // DMA instructions of 8 halo pixels: 43 / 26
+    constexpr int NI = (SLOTS + 3) / 4;                        // per wave
+    constexpr int HALO_BYTES = SLOTS * 1024;
     constexpr int WB = BN * 128;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* const halo = ldsb;
     char* const wbuf = ldsb + HALO_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_x = a.W >> 5, tiles_y = a.H >> 3;
+    const int tiles_x = a.W >> 5, tiles_y = a.H / TROWS;
     // XCD-aware order: the workgroups one XCD receives (every 8th linear id) take a contiguous run of (pixel tile,
     // channel block) pairs, channel block fastest: the channel blocks of a tile share its halo in that XCD's L2 and
     // neighbouring tiles share their border rows / columns
@@ -272,17 +278,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y;
     const int b = tile / tiles_y;
-    const int y0 = ty * 8, x0 = tx * 32;
+    const int y0 = ty * TROWS, x0 = tx * 32;
     const int n0 = nt * BN;
 
-    int hpix[11];
+    int hpix[NI];
 #pragma unroll
-    for (int i = 0; i < 11; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int q = 4 * i + wave;
         const int hr = 8 * q + (lane >> 3);
         const int hy = hr / HW_, hx = hr - hy * HW_;
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-        const bool ok = q < 43 && hr < 340 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        const bool ok = q < SLOTS && hr < HPIX && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
         hpix[i] = ok ? (b * a.Hs + (yy >> a.ups)) * a.Ws + (xx >> a.ups) : -1;
     }
     const int hslot = lane & 7;
@@ -301,9 +307,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
         const int Cs = first ? a.C0 : a.C1;
         const int cbase = (first ? cc : cc - a.cc0) * 32;
 #pragma unroll
-        for (int i = 0; i < 11; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int q = 4 * i + wave;
-            if (q < 43) {
+            if (q < SLOTS) {
                 const int sw = (4 * q + (lane >> 4)) & 7;
                 const unsigned off = hpix[i] >= 0 ? (unsigned)(hpix[i] * Cs + cbase + ((hslot ^ sw) << 2)) * 4u : OOB;
                 if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(halo + q * 1024), 16, off, 0, 0, 0);
@@ -319,9 +325,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + j * 4096), 16, woff + j * 4096, 0, 0, 0);
     };
 
-    f32x16 acc[2][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
         fb_row[j] = r * 128; fb_sw[j] = (r >> 1) & 7;
     }
     const int khalf = lane >> 5;
-    const int hbase = (2 * wave) * HW_ + (lane & 31);
+    const int hbase = (TM * wave) * HW_ + (lane & 31);
 
     // chunks_per_split / chunks_total count (chunk, tap) pairs as in the implicit GEMM; a slice is whole chunks
     const int cc_begin = zs * (a.chunks_per_split / 9);
@@ -352,25 +358,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
             const int t = cc * 9 + tap;
             if (t + 1 < t_total) issue_w(t + 1);
             const char* Bt = wbuf + (t & 1) * WB;
-            const int hr0 = hbase + (tap / 3) * HW_ + (tap % 3);
-            const int hr1 = hr0 + HW_;
-            const int ar0 = hr0 * 128, as0 = (hr0 >> 1) & 7, ar1 = hr1 * 128, as1 = (hr1 >> 1) & 7;
+            int ar[TM], as[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int hr = hbase + (tap / 3 + i) * HW_ + (tap % 3);
+                ar[i] = hr * 128; as[i] = (hr >> 1) & 7;
+            }
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4) {
                 const int s = 2 * j4 + khalf;
-                const f32x4 x0f = *reinterpret_cast<const f32x4*>(halo + ar0 + ((s ^ as0) << 4));
-                const f32x4 x1f = *reinterpret_cast<const f32x4*>(halo + ar1 + ((s ^ as1) << 4));
-                f32x4 wf[TN];
+                f32x4 xf[TM], wf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const f32x4*>(halo + ar[i] + ((s ^ as[i]) << 4));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     wf[j] = *reinterpret_cast<const f32x4*>(Bt + fb_row[j] + ((s ^ fb_sw[j]) << 4));
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0f[e], wf[j][e], acc[0][j], 0, 0, 0);
-                        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1f[e], wf[j][e], acc[1][j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[i][e], wf[j][e], acc[i][j], 0, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -391,8 +400,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(IgemmArgs a) {
         float sc = 1.f, sh = 0.f;
         if (final_out) { sc = a.scale[n]; sh = a.shift[n]; }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const long long mrow = ((long long)b * a.H + y0 + 2 * wave + i) * a.W + x0;
+        for (int i = 0; i < TM; ++i) {
+            const long long mrow = ((long long)b * a.H + y0 + TM * wave + i) * a.W + x0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int px = (r & 3) + 8 * (r >> 2) + 4 * khalf;
@@ -439,6 +448,8 @@ static TileInfo tile_info(int tile) {
     switch (tile) {
         case NBP_TILE_HALO_128: return {256, 128};
         case NBP_TILE_HALO_64: return {256, 64};
+        case NBP_TILE_HALO4_128: return {128, 128};
+        case NBP_TILE_HALO4_64: return {128, 64};
         case NBP_TILE_128x128: return {128, 128};
         case NBP_TILE_256x64: return {256, 64};
         case NBP_TILE_256x32: return {256, 32};
@@ -449,8 +460,11 @@ static TileInfo tile_info(int tile) {
 }
 
 // Shared by the forward, the single-layer entry point and the workspace query.
-static bool halo_ok_f32(int H, int W, int N, int ksize, int bn) {
-    return ksize == 3 && H >= 8 && W >= 32 && (H & 7) == 0 && (W & 31) == 0 && N % bn == 0;
+static bool halo_ok_f32(int H, int W, int N, int ksize, int bn, int rows = 8) {
+    return ksize == 3 && H >= rows && W >= 32 && H % rows == 0 && (W & 31) == 0 && N % bn == 0;
+}
+static bool is_halo_tile(int t) {
+    return t == NBP_TILE_HALO_128 || t == NBP_TILE_HALO_64 || t == NBP_TILE_HALO4_128 || t == NBP_TILE_HALO4_64;
 }
 
 ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k, int groups, int H, int W, int ksize) {
@@ -461,16 +475,27 @@ ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split
         const int bn = N % 128 == 0 ? 128 : 64;
         // split-K over whole 32-channel chunks may fill the chip when the tiles alone do not (each slice keeps
         // >= 2 chunks = 18 (chunk, tap) steps)
-        const long long blocks = (M / 256) * (N / bn) * groups;
         const int cc = chunks_total / 9;
-        int sk = 1;
-        while (blocks * sk < min_blocks && cc / (sk * 2) >= 2 && sk < 16) sk *= 2;
-        if (allow && halo_ok_f32(H, W, N, ksize, bn) && blocks * sk >= min_blocks) {
-            tile = bn == 128 ? NBP_TILE_HALO_128 : NBP_TILE_HALO_64;
-            split_k = sk;
+        // 8-row tiles; 4-row tiles (twice the workgroups, half the MFMAs per barrier: tile ids 8 / 9) were measured
+        // neutral at B = 1..8 when preferred over a split-K > 2, so the automatic choice uses them only on request
+        static const int allow4 = [] { const char* e = getenv("NBP_F32_HALO4"); return e ? atoi(e) : 0; }();
+        int sk_of[2] = {0, 0};      // split-K that fills the chip with 8-row / 4-row tiles (0 = not possible)
+        for (int v = 0; v < 2 && allow; ++v) {
+            const int rows = v == 0 ? 8 : 4;
+            if ((v == 1 && !allow4) || !halo_ok_f32(H, W, N, ksize, bn, rows)) continue;
+            const long long blocks = (M / (rows * 32)) * (N / bn) * groups;
+            int sk = 1;
+            while (blocks * sk < min_blocks && cc / (sk * 2) >= 2 && sk < 16) sk *= 2;
+            if (blocks * sk >= min_blocks) sk_of[v] = sk;
+        }
+        const int pick = (sk_of[0] && (sk_of[0] <= 2 || !sk_of[1])) ? 0 : (sk_of[1] ? 1 : -1);
+        if (pick >= 0) {
+            tile = pick == 0 ? (bn == 128 ? NBP_TILE_HALO_128 : NBP_TILE_HALO_64)
+                             : (bn == 128 ? NBP_TILE_HALO4_128 : NBP_TILE_HALO4_64);
+            split_k = sk_of[pick];
         }
     }
-    if (tile == NBP_TILE_HALO_128 || tile == NBP_TILE_HALO_64) {
+    if (is_halo_tile(tile)) {
         ConvPlan h;
         const int cc = chunks_total / 9;
         int sk = split_k <= 0 ? 1 : split_k;
@@ -508,18 +533,18 @@ ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split
     return p;
 }
 
-template <int TN>
+template <int TN, int TM>
 static int launch_halo_f32(const IgemmArgs& a, hipStream_t st) {
-    constexpr size_t smem = 344 * 128 + 2 * (size_t)TN * 32 * 128;
+    constexpr size_t smem = (size_t)(((4 * TM + 2) * 34 + 7) / 8) * 1024 + 2 * (size_t)TN * 32 * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f32_kernel<TN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f32_kernel<TN, TM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((unsigned)(a.M / 256), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups));
-    conv3x3_halo_f32_kernel<TN><<<grid, 256, smem, st>>>(a);
+    dim3 grid((unsigned)(a.M / (128 * TM)), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups));
+    conv3x3_halo_f32_kernel<TN, TM><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 
@@ -572,15 +597,15 @@ int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C
     ConvPlan p = nbp_plan_conv(a.M, N, a.chunks_total, tile, split_k, groups, H, W, ksize);
     TileInfo ti = tile_info(p.tile);
     NBP_RETURN_IF(ti.bm == 0 || N % ti.bn, NBP_E_SHAPE);
-    if (p.tile == NBP_TILE_HALO_128 || p.tile == NBP_TILE_HALO_64)
-        NBP_RETURN_IF(!halo_ok_f32(H, W, N, ksize, ti.bn) || a.bytesw == 0, NBP_E_SHAPE);
+    if (is_halo_tile(p.tile))
+        NBP_RETURN_IF(!halo_ok_f32(H, W, N, ksize, ti.bn, ti.bm / 32) || a.bytesw == 0, NBP_E_SHAPE);
     a.split_k = p.split_k; a.chunks_per_split = p.chunks_per_split;
     {   // XCD-contiguous tile runs cut the L2-miss traffic of the 3x3 halo rows; measured on MI355X they are
         // neutral-to-better (+2 %) once the grid is several waves deep and cost up to 10 % on single-wave grids,
         // so only multi-wave grids get them.  NBP_XCD_REMAP=0/1 forces the choice (A/B measurements).
         static const int forced = [] { const char* e = getenv("NBP_XCD_REMAP"); return e ? atoi(e) : -1; }();
         const long long tiles = nbp_cdiv(a.M, ti.bm) * (N / ti.bn);
-        const bool halo = p.tile == NBP_TILE_HALO_128 || p.tile == NBP_TILE_HALO_64;
+        const bool halo = is_halo_tile(p.tile);
         a.xcd_remap = forced >= 0 ? forced : ((halo ? tiles >= 512 : tiles >= 2048) ? 1 : 0);
     }
     a.partial = nullptr;
@@ -595,8 +620,10 @@ int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C
         case NBP_TILE_256x32: rc = launch_igemm<4, 1, 2, 1>(a, st); break;
         case NBP_TILE_128x64: rc = launch_igemm<2, 2, 2, 1>(a, st); break;
         case NBP_TILE_64x128: rc = launch_igemm<1, 4, 2, 1>(a, st); break;
-        case NBP_TILE_HALO_128: rc = launch_halo_f32<4>(a, st); break;
-        case NBP_TILE_HALO_64: rc = launch_halo_f32<2>(a, st); break;
+        case NBP_TILE_HALO_128: rc = launch_halo_f32<4, 2>(a, st); break;
+        case NBP_TILE_HALO_64: rc = launch_halo_f32<2, 2>(a, st); break;
+        case NBP_TILE_HALO4_128: rc = launch_halo_f32<4, 1>(a, st); break;
+        case NBP_TILE_HALO4_64: rc = launch_halo_f32<2, 1>(a, st); break;
         default: return NBP_E_ARG;
     }
     if (rc) return rc;

@@ -6,7 +6,8 @@ typedef unsigned short bf16_t;   // bf16 storage
 
 enum { NBP_TILE_AUTO = 0, NBP_TILE_128x128 = 1, NBP_TILE_256x64 = 2, NBP_TILE_256x32 = 3, NBP_TILE_128x64 = 4,
        NBP_TILE_64x128 = 5,
-       NBP_TILE_HALO_128 = 6, NBP_TILE_HALO_64 = 7 };   // 8x32-pixel halo-tile kernels (3x3 only), BN = 128 / 64
+       NBP_TILE_HALO_128 = 6, NBP_TILE_HALO_64 = 7,
+       NBP_TILE_HALO4_128 = 8, NBP_TILE_HALO4_64 = 9 };   // fp32 only: 4x32-pixel tiles   // 8x32-pixel halo-tile kernels (3x3 only), BN = 128 / 64
 struct TileInfo { int bm, bn; };
 struct ConvPlan { int tile; int split_k; int chunks_per_split; };
 

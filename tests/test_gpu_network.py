@@ -41,6 +41,9 @@ CONV_CASES = [
     (3, 24, 96, 32, 0, 64, 3, 0, 0, 7),      # halo, 3 x 3 tiles per image: an interior tile without padding
     (1, 8, 32, 256, 0, 128, 3, 0, 4, 6),     # halo + split-K over whole chunks (8 chunks / 4)
     (1, 16, 32, 96, 64, 64, 3, 0, 2, 7),     # halo + split-K with a ragged split (5 chunks / 2) across the concat seam
+    (1, 12, 32, 64, 0, 128, 3, 0, 0, 8),     # 4-row halo tiles (H % 4 == 0 only), BN = 128
+    (2, 4, 64, 96, 32, 64, 3, 0, 2, 9),      # 4-row halo tiles, BN = 64, concat + split-K, image = one tile row
+    (1, 4, 16, 64, 0, 128, 3, 1, 0, 8),      # 4-row halo + fused upsample (8 x 32 output)
 ]
 
 
