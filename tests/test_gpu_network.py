@@ -165,6 +165,21 @@ def test_forward_256_vs_oracle(hip, net, nbp_weights):
     assert torch.equal(o1.cpu().amax(1).flatten().argmax(), r1.amax(1).flatten().argmax())
 
 
+def test_forward_512_vs_oracle(hip, net, nbp_weights):
+    """BASELINE configs[4] grid in fp32: 512x512 against the torch-fp32 CPU oracle (every level is >= 32 pixels wide,
+    so every 3x3 layer takes the halo-tile kernel)."""
+    from nextbestpath_amd.utility.synthetic import make_count_maps
+    x = make_count_maps(1, 512, seed=17)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    with torch.no_grad():
+        r1, r2 = nbp_net.nbp_forward(nbp_weights, x)
+        o1, o2 = net(x.cuda())
+    assert tuple(o1.shape) == (1, 8, 128, 128) and tuple(o2.shape) == (1, 1, 512, 512)
+    assert (o1.cpu() - r1).abs().max() < TOL
+    assert (o2.cpu() - r2).abs().max() < TOL
+    assert torch.equal(o1.cpu().amax(1).flatten().argmax(), r1.amax(1).flatten().argmax())
+
+
 def test_forward_batch_consistency_and_determinism(hip, net):
     from nextbestpath_amd.utility.synthetic import make_count_maps
     x = make_count_maps(3, 64, seed=5).cuda()
