@@ -34,7 +34,7 @@ def sweep(a):
         out = torch.empty(B, H, H, N, device=dev)
         ws = torch.empty(max(L.nbp_conv_igemm_workspace_bytes(B, H, H, N, 64), 256), dtype=torch.uint8, device=dev)
         chunks = (C0 + C1) // 32 * k * k
-        cfgs = [(0, 0)] + [(t, sk) for t in (1, 2, 3, 4, 5) for sk in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32) if sk <= chunks]
+        cfgs = [(0, 0)] + [(t, sk) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9) for sk in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32) if sk <= chunks]
         res = {}
         for rnd in range(3):
             for cfg in cfgs:
@@ -78,7 +78,7 @@ def bf16(a):
         chunks = (C0 + C1) // 64 * k * k
         cfgs = [(a.tile, a.split)]
         if a.sweep:
-            cfgs = [(0, 0)] + [(t, sk) for t in (1, 2, 3, 4, 5) for sk in (1, 2, 3, 4, 6, 8, 16) if sk <= chunks]
+            cfgs = [(0, 0)] + [(t, sk) for t in (1, 2, 3, 4, 5, 6, 7) for sk in (1, 2, 3, 4, 6, 8, 16) if sk <= chunks]
         res = {}
         for rnd in range(3 if a.sweep else 1):
             for cfg in cfgs:
