@@ -466,8 +466,9 @@ ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int 
         const int cc = chunks_total / 9;
         int sk = split_k <= 0 ? 1 : split_k;
         if (sk > cc) sk = cc;
-        const int per = (int)nbp_cdiv(cc, sk);
-        p.tile = tile; p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per * 9;
+        if (sk < 1) sk = 1;              // 1x1 convolution asked for a halo tile: rejected by the caller's shape check
+        const int per = cc > 0 ? (int)nbp_cdiv(cc, sk) : 1;
+        p.tile = tile; p.split_k = cc > 0 ? (int)nbp_cdiv(cc, per) : 1; p.chunks_per_split = per * 9;
         return p;
     }
     if (tile == NBP_TILE_AUTO) {

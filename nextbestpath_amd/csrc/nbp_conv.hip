@@ -500,8 +500,9 @@ ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split
         const int cc = chunks_total / 9;
         int sk = split_k <= 0 ? 1 : split_k;
         if (sk > cc) sk = cc;
-        const int per = (int)nbp_cdiv(cc, sk);
-        h.tile = tile; h.split_k = (int)nbp_cdiv(cc, per); h.chunks_per_split = per * 9;
+        if (sk < 1) sk = 1;              // 1x1 convolution asked for a halo tile: rejected by the caller's shape check
+        const int per = cc > 0 ? (int)nbp_cdiv(cc, sk) : 1;
+        h.tile = tile; h.split_k = cc > 0 ? (int)nbp_cdiv(cc, per) : 1; h.chunks_per_split = per * 9;
         return h;
     }
     // Policy from tools/bench_conv.py --sweep on MI355X (B = 1, 2, 8; SURVEY.md A.1 shapes): the big

@@ -201,6 +201,23 @@ def test_repack_after_weight_update(hip, nbp_weights):
     assert (b1 - a1 - 1.0).abs().max() < 1e-5
 
 
+def test_halo_tile_on_1x1_is_a_shape_error(hip):
+    """An explicit halo tile id on a 1x1 convolution (or an image that is not a multiple of the tile) is refused with
+    NBP_E_SHAPE -- regression: the plan used to divide by zero."""
+    dev = "cuda"
+    x = torch.zeros(1, 8, 32, 64, device=dev)
+    one = torch.ones(64, device=dev)
+    wpk = torch.zeros(64 * 64, device=dev)
+    for tile in (6, 7, 8, 9):
+        with pytest.raises(_lib.NbpHipError):
+            conv_igemm(x, None, False, wpk, 64, 1, one, one, True, 0, tile)
+    x2 = torch.zeros(1, 6, 32, 64, device=dev)        # H = 6: neither 8- nor 4-row tiles fit
+    wpk3 = torch.zeros(9 * 64 * 64, device=dev)
+    for tile in (7, 9):
+        with pytest.raises(_lib.NbpHipError):
+            conv_igemm(x2, None, False, wpk3, 64, 3, one, one, True, 0, tile)
+
+
 def test_argument_errors(hip):
     L = hip
     assert L.nbp_forward_f32(None, None, 1, 256, None, None, None, 0, None) == -1
