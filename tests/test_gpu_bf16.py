@@ -181,3 +181,45 @@ def test_bf16_handle_mismatch_is_an_error(hip, net_bf16):
     rc = hip.nbp_forward_f32(packed.handle, x.data_ptr(), 1, 32, o1.data_ptr(), o2.data_ptr(), ws.data_ptr(),
                              ws.numel(), stream())
     assert rc != 0
+
+
+def test_bf16_conv_entry_point_fuzz(hip):
+    """80 seeded random (shape, tile, split) requests: refused with an error or correct within one bf16 ulp."""
+    rng = np.random.default_rng(321)
+    dev = "cuda"
+    ok = refused = 0
+    for trial in range(80):
+        B = int(rng.integers(1, 3))
+        H = int(rng.choice([1, 2, 4, 8, 16]))
+        W = int(rng.choice([1, 4, 16, 32, 64]))
+        C0 = int(rng.choice([64, 128]))
+        C1 = int(rng.choice([0, 0, 64]))
+        N = int(rng.choice([32, 64, 128]))
+        k = int(rng.choice([1, 3]))
+        ups = int(rng.integers(0, 2)) if (H % 2 == 0 and W % 2 == 0) else 0
+        tile = int(rng.integers(0, 9))
+        split = int(rng.choice([0, 0, 1, 2, 3]))
+        Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+        x0 = rbf(_rand(B, C0, Hs, Ws, seed=trial))
+        x1 = rbf(_rand(B, C1, Hs, Ws, seed=trial + 1000)) if C1 else None
+        w = _rand(N, C0 + C1, k, k, seed=trial + 2000, scale=0.05)
+        sc = (_rand(N, seed=trial + 3000) * 0.2 + 1.0)
+        sh = _rand(N, seed=trial + 4000) * 0.1
+        wpk = pack_conv_bf16(w.to(dev).contiguous())
+        try:
+            out = conv_igemm_bf16(nhwc(x0).to(dev).to(torch.bfloat16),
+                                  None if x1 is None else nhwc(x1).to(dev).to(torch.bfloat16), ups, wpk, N, k, sc.to(dev),
+                                  sh.to(dev), True, split, tile)
+        except _lib.NbpHipError:
+            refused += 1
+            continue
+        torch.cuda.synchronize()
+        xin = x0 if x1 is None else torch.cat((x0, x1), 1)
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2)
+        acc = F.conv2d(xin.double(), rbf(w).double(), None, padding=k // 2).float()
+        ref = F.relu(acc * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        err = (nchw(out.float()).cpu() - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -7 + 1e-3).all()), (trial, B, H, W, C0, C1, N, k, ups, tile, split)
+        ok += 1
+    assert ok >= 25 and refused >= 5, (ok, refused)

@@ -236,3 +236,42 @@ def test_build_then_smoke_in_one_process(hip):
             "import __graft_entry__ as g\ng.build(); g.smoke(); print('OK')\n") % root
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-800:] + out.stderr[-1500:]
+
+
+def test_conv_entry_point_fuzz(hip):
+    """120 seeded random (shape, tile, split) requests, valid and invalid: the library either refuses (NbpHipError) or
+    returns the right convolution -- it never crashes the process and never returns garbage."""
+    rng = np.random.default_rng(123)
+    dev = "cuda"
+    ok = refused = 0
+    for trial in range(120):
+        B = int(rng.integers(1, 3))
+        H = int(rng.choice([1, 2, 4, 6, 8, 12, 16]))
+        W = int(rng.choice([1, 4, 8, 16, 32, 64]))
+        C0 = int(rng.choice([32, 64, 96]))
+        C1 = int(rng.choice([0, 0, 32, 64]))
+        N = int(rng.choice([32, 64, 128]))
+        k = int(rng.choice([1, 3]))
+        ups = int(rng.integers(0, 2)) if (H % 2 == 0 and W % 2 == 0) else 0
+        tile = int(rng.integers(0, 10))
+        split = int(rng.choice([0, 0, 1, 2, 3, 5]))
+        Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+        x0 = _rand(B, C0, Hs, Ws, seed=trial)
+        x1 = _rand(B, C1, Hs, Ws, seed=trial + 1000) if C1 else None
+        w = _rand(N, C0 + C1, k, k, seed=trial + 2000, scale=0.05)
+        sc = (_rand(N, seed=trial + 3000) * 0.2 + 1.0)
+        sh = _rand(N, seed=trial + 4000) * 0.1
+        wpk = pack_conv(w.to(dev).contiguous())
+        try:
+            out = conv_igemm(nhwc(x0).to(dev), None if x1 is None else nhwc(x1).to(dev), ups, wpk, N, k, sc.to(dev),
+                             sh.to(dev), True, split, tile)
+        except _lib.NbpHipError:
+            refused += 1
+            continue
+        xin = x0 if x1 is None else torch.cat((x0, x1), 1)
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2)
+        ref = F.relu(F.conv2d(xin, w, None, padding=k // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        assert (nchw(out).cpu() - ref).abs().max().item() < TOL, (trial, B, H, W, C0, C1, N, k, ups, tile, split)
+        ok += 1
+    assert ok >= 40 and refused >= 10, (ok, refused)
