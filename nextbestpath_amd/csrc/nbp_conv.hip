@@ -520,6 +520,10 @@ ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split
     }
     p.tile = tile;
     TileInfo ti = tile_info(tile);
+    if (ti.bm == 0) {                 // unknown tile id: the caller's shape check refuses it
+        p.split_k = 1; p.chunks_per_split = chunks_total;
+        return p;
+    }
     if (split_k <= 0) {
         const long long blocks = nbp_cdiv(M, ti.bm) * (N / ti.bn) * groups;
         split_k = 1;

@@ -197,7 +197,7 @@ def test_bf16_conv_entry_point_fuzz(hip):
         N = int(rng.choice([32, 64, 128]))
         k = int(rng.choice([1, 3]))
         ups = int(rng.integers(0, 2)) if (H % 2 == 0 and W % 2 == 0) else 0
-        tile = int(rng.integers(0, 9))
+        tile = int(rng.integers(0, 10))          # 8, 9 do not exist in the bf16 path
         split = int(rng.choice([0, 0, 1, 2, 3]))
         Hs, Ws = (H // 2, W // 2) if ups else (H, W)
         x0 = rbf(_rand(B, C0, Hs, Ws, seed=trial))

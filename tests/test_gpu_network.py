@@ -253,7 +253,7 @@ def test_conv_entry_point_fuzz(hip):
         N = int(rng.choice([32, 64, 128]))
         k = int(rng.choice([1, 3]))
         ups = int(rng.integers(0, 2)) if (H % 2 == 0 and W % 2 == 0) else 0
-        tile = int(rng.integers(0, 10))
+        tile = int(rng.integers(0, 12))          # 10, 11 do not exist
         split = int(rng.choice([0, 0, 1, 2, 3, 5]))
         Hs, Ws = (H // 2, W // 2) if ups else (H, W)
         x0 = _rand(B, C0, Hs, Ws, seed=trial)
@@ -274,4 +274,4 @@ def test_conv_entry_point_fuzz(hip):
         ref = F.relu(F.conv2d(xin, w, None, padding=k // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
         assert (nchw(out).cpu() - ref).abs().max().item() < TOL, (trial, B, H, W, C0, C1, N, k, ups, tile, split)
         ok += 1
-    assert ok >= 40 and refused >= 10, (ok, refused)
+    assert ok >= 30 and refused >= 10, (ok, refused)
