@@ -225,3 +225,58 @@ def test_carving_vs_oracle(hip):
     assert n_in > 500
     for a, b in zip(st_o, st_d):
         assert np.array_equal(a, b.cpu().numpy())
+
+
+def test_edge_arguments_never_crash(hip):
+    """Degenerate / hostile arguments to the simulator, map and planner entry points: an error code or a sane result,
+    never a crash (each call is followed by a device synchronisation so that a faulting kernel would surface here)."""
+    import numpy as np
+    from nextbestpath_amd import _lib
+    from nextbestpath_amd.utility import hipops
+    from nextbestpath_amd.utility import utils as hu
+    dev = "cuda"
+    sync = torch.cuda.synchronize
+    # one degenerate triangle lying in the slicing plane, one zero-area triangle
+    verts = torch.tensor([[0, 1, 0], [1, 1, 0], [0, 1, 1], [2, 2, 2], [2, 2, 2], [2, 2, 2]], dtype=torch.float32, device=dev)
+    faces = torch.tensor([[0, 1, 2], [3, 4, 5]], dtype=torch.int32, device=dev)
+    lab = hipops.slice_obstacle(verts, faces, 1.0, 0.0, 0.0); sync()
+    assert float(lab.sum()) == 0.0                      # vertices ON the plane count as the positive side: no crossing
+    cams = np.concatenate([np.eye(3, dtype=np.float32).reshape(1, 9), np.zeros((1, 3), np.float32)], 1)
+    with pytest.raises(_lib.NbpHipError):                # bins hold at least one 64-face batch
+        hipops.raster_zbuf(verts, faces, cams, 16, 24, bin_cap=1)
+    z, ovf = hipops.raster_zbuf(verts, faces, cams, 16, 24, bin_cap=64); sync()
+    assert z.shape == (1, 16, 24) and torch.isfinite(z).all() and int(ovf) == 0
+    seg = torch.tensor([[0, 0, 0, 0, 0, 0], [0, 0, 0, 5, 5, 5]], dtype=torch.float32, device=dev)   # zero-length segment
+    hit = hipops.segments_hit_mesh(verts, faces, seg); sync()
+    assert hit.shape == (2,)
+    cnt = hipops.axis_ray_counts(verts, faces, seg[:, :3].contiguous()); sync()
+    assert cnt.shape == (2, 3)
+    # coverage against an EMPTY cloud and a cloud far outside the GT bounding box
+    gt = torch.rand(100, 3, device=dev)
+    cloud = torch.zeros(64, 3, device=dev)
+    n0 = torch.zeros(1, dtype=torch.int64, device=dev)
+    out = hipops.coverage_count(gt, cloud, n_dev=n0, n=64); sync()
+    assert int(out[0]) == 0
+    far = torch.full((64, 3), 1e6, device=dev)
+    out = hipops.coverage_count(gt, far, n_dev=torch.tensor([64], device=dev), n=64); sync()
+    assert int(out[0]) == 0
+    # maps: S = 1, points at +-inf / NaN are dropped, not scattered out of bounds
+    bad = torch.tensor([[float("nan"), 0, 0], [float("inf"), 1, 2], [-float("inf"), 1, 2], [0.1, 1.0, 0.1]], device=dev)
+    m = hu.accumulate_step_maps(bad, torch.zeros(5), torch.tensor([0.0, 0.5, 1.5, 2.5, 3.5]), 8, (-1, 1)); sync()
+    assert torch.isfinite(m).all() and float(m[:5].sum()) == 1.0
+    one = hu.map_points_to_n_imgs(torch.zeros(1, 3, 2, device=dev), (1, 1), (-1, 1)); sync()
+    assert one.shape == (1, 1, 1)
+    # forward: unsupported size and undersized workspace are refused
+    L = _lib.lib()
+    x = torch.zeros(1, 5, 24, 24, device=dev)
+    o1 = torch.zeros(1, 8, 6, 6, device=dev); o2 = torch.zeros(1, 1, 24, 24, device=dev)
+    ws = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    assert L.nbp_forward_workspace_bytes(1, 24) == 0
+    from nextbestpath_amd.networks import packing
+    from nextbestpath_amd.utility.synthetic import make_nbp_state_dict
+    pk = packing.pack_state_dict(make_nbp_state_dict(9), torch.device(dev))
+    assert L.nbp_forward_f32(pk.handle, x.data_ptr(), 1, 24, o1.data_ptr(), o2.data_ptr(), ws.data_ptr(), ws.numel(), None) == -3
+    x = torch.zeros(1, 5, 32, 32, device=dev)
+    assert L.nbp_forward_f32(pk.handle, x.data_ptr(), 1, 32, o1.data_ptr(), o2.data_ptr(), ws.data_ptr(), ws.numel(), None) == -2
+    assert L.nbp_forward_f32(pk.handle, x.data_ptr(), 0, 32, o1.data_ptr(), o2.data_ptr(), ws.data_ptr(), ws.numel(), None) == -1
+    sync()
