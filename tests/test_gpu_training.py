@@ -329,3 +329,46 @@ def test_training_step_vs_reference_golden(hip, nbp_weights, golden_dir):
             continue
         rel = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-12)
         assert rel < 0.15, (k, rel)
+
+
+def test_wgrad_entry_point_fuzz(hip):
+    """40 seeded random shapes through nbp_conv_wgrad_f32 (halo-tile kernel where the image allows, tap-per-workgroup
+    kernel otherwise, 1x1 and 3x3, concat, upsample, channel padding): refused or right."""
+    from nextbestpath_amd import _lib
+    rng = np.random.default_rng(77)
+    ok = refused = 0
+    for trial in range(40):
+        B = int(rng.integers(1, 3))
+        H = int(rng.choice([2, 4, 6, 8]))
+        W = int(rng.choice([2, 8, 32, 64]))
+        C0 = int(rng.choice([64, 128]))
+        C1 = int(rng.choice([0, 0, 64]))
+        N = int(rng.choice([64, 128]))
+        k = int(rng.choice([1, 3]))
+        ups = int(rng.integers(0, 2))
+        c_real = int(rng.choice([C0 + C1, 5])) if C1 == 0 else C0 + C1
+        n_real = int(rng.choice([N, 8]))
+        torch.manual_seed(trial)
+        Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+        x0 = torch.randn(B, Hs, Ws, C0, device="cuda")
+        x1 = torch.randn(B, Hs, Ws, C1, device="cuda") if C1 else None
+        dy = torch.randn(B, H, W, N, device="cuda")
+        dw = torch.zeros(n_real, c_real, k, k, device="cuda")
+        nws = hip.nbp_conv_wgrad_workspace_bytes(B, H, W, C0, C1, N, k)
+        ws = torch.empty(max(nws, 256), dtype=torch.uint8, device="cuda")
+        rc = hip.nbp_conv_wgrad_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, ups, B, H, W, k, _lib.ptr(dy), N, c_real, n_real,
+                                    _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _lib.current_stream())
+        torch.cuda.synchronize()
+        if rc != 0:
+            refused += 1
+            continue
+        xin = x0 if x1 is None else torch.cat((x0, x1), 3)
+        xin = xin.permute(0, 3, 1, 2).double().cpu()
+        if ups:
+            xin = torch.nn.functional.interpolate(xin, scale_factor=2)
+        ref = torch.nn.grad.conv2d_weight(xin, (N, C0 + C1, k, k), dy.permute(0, 3, 1, 2).double().cpu(), padding=k // 2)
+        ref = ref[:n_real, :c_real]
+        err = (dw.cpu().double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
+        assert err < 5e-6, (trial, B, H, W, C0, C1, N, k, ups, c_real, n_real, err)
+        ok += 1
+    assert ok >= 20, (ok, refused)
