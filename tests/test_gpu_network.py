@@ -180,6 +180,19 @@ def test_forward_512_vs_oracle(hip, net, nbp_weights):
     assert torch.equal(o1.cpu().amax(1).flatten().argmax(), r1.amax(1).flatten().argmax())
 
 
+@pytest.mark.parametrize("B,S", [(1, 16), (3, 48), (2, 96), (1, 160), (5, 32)])
+def test_forward_odd_sizes_vs_oracle(hip, net, nbp_weights, B, S):
+    """Sizes whose pyramid mixes the halo-tile kernel (levels that are multiples of 8 x 32) with the implicit GEMM
+    (48, 24, 12 ... wide levels), odd batch sizes, and the smallest legal map (16 -> a 1 x 1 bottleneck)."""
+    from nextbestpath_amd.utility.synthetic import make_count_maps
+    x = make_count_maps(B, S, seed=100 + S + B)
+    with torch.no_grad():
+        r1, r2 = nbp_net.nbp_forward(nbp_weights, x)
+        o1, o2 = net(x.cuda())
+    assert (o1.cpu() - r1).abs().max() < TOL
+    assert (o2.cpu() - r2).abs().max() < TOL
+
+
 def test_forward_batch_consistency_and_determinism(hip, net):
     from nextbestpath_amd.utility.synthetic import make_count_maps
     x = make_count_maps(3, 64, seed=5).cuda()
