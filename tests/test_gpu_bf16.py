@@ -124,7 +124,7 @@ def net_bf16(nbp_weights):
     return net.cuda().eval()
 
 
-@pytest.mark.parametrize("B,S", [(1, 32), (2, 64), (1, 128)])
+@pytest.mark.parametrize("B,S", [(1, 32), (2, 64), (1, 128), (3, 48), (2, 96), (1, 16)])
 def test_forward_bf16_vs_restatement(hip, net_bf16, nbp_weights, B, S):
     from nextbestpath_amd.utility.synthetic import make_count_maps
     x = make_count_maps(B, S, seed=11)
