@@ -212,3 +212,24 @@ def test_scene_parallel_entry_point_two_ranks(hip, dataset):
             assert np.allclose(two[scene]["0"]["coverage"], one[scene]["0"]["coverage"], atol=1e-7)
     finally:
         os.remove(cfg_path)
+
+
+@pytest.mark.parametrize("cells,size", [(1, 1.2), (2, 1.5), (3, 1.8)])
+def test_rollout_on_tiny_scenes(hip, nbp_weights, tmp_path, cells, size):
+    """Degenerate scenes: a single room with a 3 x 3 / 4 x 4 / 5 x 5 pose lattice.  The agent quickly runs out of valid
+    goals (every position visited / no candidate passes the density test) and must keep stepping without an exception
+    (the reference would hit its unbound `next_idx`, nbp_planning.py:255-258)."""
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.simulator.mesh import make_maze_scene
+    from nextbestpath_amd.testers import nbp_planning as tp
+    make_maze_scene(str(tmp_path / "tiny"), seed=cells, cells=cells, size=size, height=1.2, tess=0.3)
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    ds = sc.SceneDataset(str(tmp_path))
+    net = _net(nbp_weights)
+    ro = tp.build_rollout(params, net, ds, (0, 0), torch.device("cuda"), seed=3)
+    for _ in range(25):
+        ro.step()
+    torch.cuda.synchronize()
+    cov = ro.coverage_evolution(25)
+    assert all(np.isfinite(cov)) and cov[-1] > 0.2          # a single room is mostly seen within a few steps
+    assert len(ro.camera.cam_idx_history) >= 25
