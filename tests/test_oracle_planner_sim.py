@@ -270,3 +270,20 @@ def test_level_order_search_equals_heap_search_on_random_lattices():
             while cur >= 0:
                 got.append(idx[cur]); cur = par[cur]
             assert got[::-1] == [tuple(p) for p in want]
+
+
+def test_obj_loader_formats(tmp_path):
+    """Host logic: OBJ records as real scenes carry them (v/vt/vn triples, quads and n-gons, negative indices,
+    comments, mtllib / usemtl / vt / vn lines)."""
+    from nextbestpath_amd.simulator.mesh import load_obj, save_obj
+    lines = ["# comment", "mtllib x.mtl", "v 0 0 0", "v 1 0 0", "v 1 1 0", "v 0 1 0", "v 0.5 0.5 1", "vt 0 0", "vn 0 0 1",
+             "usemtl wall", "f 1/1/1 2/1/1 3/1/1 4/1/1", "f -1 -5 -4", "f 1//1 2//1 5//1 3//1 4//1"]
+    p = tmp_path / "m.obj"
+    p.write_text(chr(10).join(lines) + chr(10))
+    v, f = load_obj(str(p))
+    assert v.shape == (5, 3) and v.dtype == np.float32 and f.dtype == np.int32
+    assert f.tolist() == [[0, 1, 2], [0, 2, 3], [4, 0, 1], [0, 1, 4], [0, 4, 2], [0, 2, 3]]
+    q = tmp_path / "r.obj"
+    save_obj(str(q), v, f)
+    v2, f2 = load_obj(str(q))
+    assert np.array_equal(v, v2) and np.array_equal(f, f2)
