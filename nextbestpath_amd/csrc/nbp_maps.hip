@@ -107,10 +107,22 @@ __global__ __launch_bounds__(THREADS) void map_accumulate_kernel(const float* __
     const long long last = first + AGG_POINTS < N ? first + AGG_POINTS : N;
     for (int i = threadIdx.x; i < AGG_SLOTS; i += THREADS) { keys[i] = AGG_EMPTY; cnts[i] = 0; }
     __syncthreads();
-    // 12 B per point: three consecutive dword loads per lane (768 contiguous bytes per wave instruction)
-    for (long long i = first + threadIdx.x; i < last; i += THREADS)
-        accumulate_point<SLOT_BITS>(p[3 * i], p[3 * i + 1], p[3 * i + 2], cx, cz, bd, band_lo, band_hi, S, lo, sc, keys,
-                                    cnts, out);
+    // 12 B per point: three consecutive dword loads per lane (768 contiguous bytes per wave instruction).  All of a
+    // thread's points are fetched BEFORE the first table insert: the probe loop's LDS atomics would otherwise fence
+    // every iteration's loads behind the previous iteration (one HBM round trip per point instead of one per thread).
+    constexpr int PER = AGG_POINTS / THREADS;
+    float px[PER], py[PER], pz[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const long long i = first + threadIdx.x + (long long)k * THREADS;
+        const bool in = i < last;
+        px[k] = in ? p[3 * i] : __builtin_nanf("");        // NaN fails cell_of: the slot is skipped
+        py[k] = in ? p[3 * i + 1] : 0.f;
+        pz[k] = in ? p[3 * i + 2] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        accumulate_point<SLOT_BITS>(px[k], py[k], pz[k], cx, cz, bd, band_lo, band_hi, S, lo, sc, keys, cnts, out);
     __syncthreads();
     for (int i = threadIdx.x; i < AGG_SLOTS; i += THREADS)
         if (keys[i] != AGG_EMPTY) atomicAdd(out + keys[i], (float)cnts[i]);
