@@ -61,6 +61,58 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     }
 }
 
+// Same reduction for C % 4 == 0 with 16-B loads: thread t owns four channels (float4 column t % CT) and the rows
+// rsub + k * rpb of its block, four rows in flight per iteration.  The scalar kernel above keeps C = 1 (psi BatchNorm).
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ y, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ rows,
+                                                         long long M, int C4, int relu, long long rows_per_block,
+                                                         float* __restrict__ part) {
+    const int CT = C4 < 256 ? C4 : 256;
+    const int rpb = 256 / CT;
+    const int c_local = threadIdx.x % CT, rsub = threadIdx.x / CT;
+    __shared__ f32x4 sh0[256], sh1[256];
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+    const long long r_begin = (long long)blockIdx.x * rows_per_block;
+    const long long r_end = r_begin + rows_per_block < M ? r_begin + rows_per_block : M;
+    for (int c0 = 0; c0 < C4; c0 += CT) {
+        const int c = c0 + c_local;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        if (rsub < rpb && c < C4) {
+            f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == 1) { mu = reinterpret_cast<const f32x4*>(mean)[c]; is = reinterpret_cast<const f32x4*>(invstd)[c]; }
+            auto step = [&](long long r) {
+                const f32x4 v = a4[r * C4 + c];
+                if (MODE == 0) { s0 += v; s1 += v * v; }
+                if (MODE == 1) {
+                    f32x4 dz = v;
+                    if (relu) {
+                        const f32x4 yy = y4[r * C4 + c];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
+                    }
+                    s0 += dz; s1 += dz * ((b4[r * C4 + c] - mu) * is);
+                }
+                if (MODE == 2) s0 += v * (rows ? rows[r] : 1.f);
+            };
+            long long r = r_begin + rsub;
+            for (; r + 3 * rpb < r_end; r += 4 * rpb) { step(r); step(r + rpb); step(r + 2 * rpb); step(r + 3 * rpb); }
+            for (; r < r_end; r += rpb) step(r);
+        }
+        sh0[threadIdx.x] = s0; sh1[threadIdx.x] = s1;
+        __syncthreads();
+        if (rsub == 0 && c < C4) {
+            for (int k = 1; k < rpb; ++k) { s0 += sh0[k * CT + c_local]; s1 += sh1[k * CT + c_local]; }
+            reinterpret_cast<f32x4*>(part + ((long long)blockIdx.x * 2 + 0) * C4 * 4)[c] = s0;
+            reinterpret_cast<f32x4*>(part + ((long long)blockIdx.x * 2 + 1) * C4 * 4)[c] = s1;
+        }
+        __syncthreads();
+    }
+}
+
 // Column sums of the per-block partials part[k][2][C]: a 256-thread block owns 32 channels; thread (c, ks) adds the
 // rows k = ks, ks + 8, ... in double (fixed order), the 8 slices meet in LDS in a fixed order: deterministic, and
 // nblk / 8 dependent loads per thread instead of nblk.
@@ -137,6 +189,54 @@ __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __r
         if (relu && !(y[i] > 0.f)) dz = 0.f;
         const float xhat = (x[i] - mean[c]) * invstd[c];
         dx[i] = gamma[c] * invstd[c] * (dz - invM * (dbeta[c] + xhat * dgamma[c]));
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict__ x, long long total4, int C4,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int relu, float* __restrict__ y) {
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c], is = reinterpret_cast<const f32x4*>(invstd)[c];
+        const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c], bt = reinterpret_cast<const f32x4*>(beta)[c];
+        f32x4 v = (x4[i] - mu) * is * g + bt;
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        y4[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_backward_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ y, long long total4, int C4,
+                                                                 long long M, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ dgamma,
+                                                                 const float* __restrict__ dbeta, int relu,
+                                                                 float* __restrict__ dx) {
+    const float invM = 1.f / (float)M;
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+    f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c], is = reinterpret_cast<const f32x4*>(invstd)[c];
+        const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c];
+        const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[c], db = reinterpret_cast<const f32x4*>(dbeta)[c];
+        f32x4 dz = dy4[i];
+        if (relu) {
+            const f32x4 yy = y4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
+        }
+        const f32x4 xhat = (x4[i] - mu) * is;
+        dx4[i] = g * is * (dz - invM * (db + xhat * dg));
     }
 }
 
@@ -580,7 +680,7 @@ __global__ void sum_doubles_kernel(const double* __restrict__ part, int n, doubl
 inline int blocks_for_rows(long long M, long long* rows_per_block) {
     long long nblk = M / 256;
     if (nblk < 1) nblk = 1;
-    if (nblk > 512) nblk = 512;
+    if (nblk > 2048) nblk = 2048;       // 8 workgroups per CU: the reductions are HBM streams
     *rows_per_block = nbp_cdiv(M, nblk);
     return (int)nbp_cdiv(M, *rows_per_block);
 }
@@ -604,13 +704,15 @@ extern "C" int nbp_bn_train_forward_f32(const float* x, long long M, int C, cons
     long long rpb;
     const int nblk = blocks_for_rows(M, &rpb);
     float* part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
-    colreduce_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, rpb, part);
+    if (C % 4 == 0) colreduce4_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C / 4, 0, rpb, part);
+    else colreduce_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, rpb, part);
     int rc = nbp_launch_status();
     if (rc) return rc;
     bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, M, eps, momentum, mean, invstd, running_mean,
                                                                   running_var);
     if ((rc = nbp_launch_status())) return rc;
-    bn_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(x, M * C, C, mean, invstd, gamma, beta, relu, y);
+    if (C % 4 == 0) bn_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(x, M * C / 4, C / 4, mean, invstd, gamma, beta, relu, y);
+    else bn_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(x, M * C, C, mean, invstd, gamma, beta, relu, y);
     return nbp_launch_status();
 }
 
@@ -625,13 +727,18 @@ extern "C" int nbp_bn_train_backward_f32(const float* dy, const float* x, const 
     long long rpb;
     const int nblk = blocks_for_rows(M, &rpb);
     float* part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
-    colreduce_kernel<1><<<nblk, 256, 0, st>>>(dy, x, y_or_null, mean, invstd, nullptr, M, C, relu, rpb, part);
+    if (C % 4 == 0) colreduce4_kernel<1><<<nblk, 256, 0, st>>>(dy, x, y_or_null, mean, invstd, nullptr, M, C / 4, relu, rpb, part);
+    else colreduce_kernel<1><<<nblk, 256, 0, st>>>(dy, x, y_or_null, mean, invstd, nullptr, M, C, relu, rpb, part);
     int rc = nbp_launch_status();
     if (rc) return rc;
     colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, dbeta, dgamma);
     if ((rc = nbp_launch_status())) return rc;
-    bn_backward_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(dy, x, y_or_null, M * C, C, M, mean, invstd, gamma,
-                                                                     dgamma, dbeta, relu, dx);
+    if (C % 4 == 0)
+        bn_backward_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(dy, x, y_or_null, M * C / 4, C / 4, M, mean, invstd,
+                                                                              gamma, dgamma, dbeta, relu, dx);
+    else
+        bn_backward_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(dy, x, y_or_null, M * C, C, M, mean, invstd, gamma,
+                                                                         dgamma, dbeta, relu, dx);
     return nbp_launch_status();
 }
 
@@ -645,7 +752,8 @@ extern "C" int nbp_colsum_f32(const float* x, const float* rows_or_null, long lo
     long long rpb;
     const int nblk = blocks_for_rows(M, &rpb);
     float* part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
-    colreduce_kernel<2><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, rows_or_null, M, C, 0, rpb, part);
+    if (C % 4 == 0) colreduce4_kernel<2><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, rows_or_null, M, C / 4, 0, rpb, part);
+    else colreduce_kernel<2><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, rows_or_null, M, C, 0, rpb, part);
     int rc = nbp_launch_status();
     if (rc) return rc;
     colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, out, nullptr);
