@@ -680,7 +680,7 @@ __global__ void sum_doubles_kernel(const double* __restrict__ part, int n, doubl
 inline int blocks_for_rows(long long M, long long* rows_per_block) {
     long long nblk = M / 256;
     if (nblk < 1) nblk = 1;
-    if (nblk > 2048) nblk = 2048;       // 8 workgroups per CU: the reductions are HBM streams
+    if (nblk > 1024) nblk = 1024;       // 4 workgroups per CU: the reductions are HBM streams
     *rows_per_block = nbp_cdiv(M, nblk);
     return (int)nbp_cdiv(M, *rows_per_block);
 }
