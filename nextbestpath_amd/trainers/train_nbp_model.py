@@ -217,7 +217,8 @@ def run_training_nbp(params):
             validation = nu.store_validation_data(env, getattr(params, "n_validation", 1200))
             continue
         db = nu.read_combined_data(env)
-        if not db or not validation:
+        # every rank must take the same branch (the training loop below contains collectives)
+        if _common_count(1 if (db and validation) else 0, device) == 0:
             continue
         tl, vl = train_nbp(db, params, optimizer, nbp, device, epoch, validation, num_epochs=params.inner_epochs)
         print(f"epoch {epoch}: training {tl:.4f} validation {vl:.4f}")

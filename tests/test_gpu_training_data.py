@@ -111,9 +111,33 @@ def spy(db, params, optimizer, nbp, *a, **k):
 T.train_nbp = spy
 T.run_training_nbp(p)
 import torch.distributed as dist
-chk = torch.cat([q.detach().double().flatten() for q in state["nbp"].parameters()]).cpu()
-print("CHK", dist.get_rank(), f"{chk.sum().item():.10e}", f"{chk.abs().sum().item():.10e}", flush=True)
+if "nbp" in state:
+    chk = torch.cat([q.detach().double().flatten() for q in state["nbp"].parameters()]).cpu()
+    print("CHK", dist.get_rank(), f"{chk.sum().item():.10e}", f"{chk.abs().sum().item():.10e}", flush=True)
 """
+
+
+def test_two_rank_collection_and_training(hip, dataset, tmp_path):
+    """torchrun x2 with collection: each rank explores its own scene into its own store, validation is split off per rank,
+    the training epoch averages gradients; both ranks finish (no rank is left waiting in a collective)."""
+    cfg = json.load(open(os.path.join(ROOT, "configs/nbp/nbp_default_training_config.json")))
+    cfg["_data"]["data_path"] = dataset
+    cfg["_scene_management"]["n_gt_surface_points"] = 8000
+    cfg["_nbp"].update({"nbp_model_name": "nbp_ddp_c", "nbp_batch_size": 4, "epochs": 1, "inner_epochs": 1, "n_validation": 2,
+                        "n_collect_poses": 60, "output_dir": str(tmp_path / "w"), "collect": True})
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    script = tmp_path / "ddp_train.py"
+    script.write_text(_DDP_TRAIN)
+    env = dict(os.environ, NBP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29643", str(script), ROOT, str(path)],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    assert out.stdout.count("collected") >= 4                      # 2 ranks x epochs 0 and 1
+    lines = [l.split()[2:] for l in out.stdout.splitlines() if l.startswith("CHK")]
+    if lines:                                                      # training ran: replicas identical
+        assert len(lines) == 2 and lines[0] == lines[1], out.stdout
 
 
 def test_two_rank_training_keeps_replicas_identical(hip, tmp_path):
