@@ -101,6 +101,16 @@ def _common_count(n, device):
     return int(t.item())
 
 
+def _mean_over_ranks(x: float, device) -> float:
+    """Scalars that steer the optimiser (validation loss -> ReduceLROnPlateau) must agree on every rank."""
+    dist = _dist()
+    if dist is None:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t)
+    return float(t.item()) / dist.get_world_size()
+
+
 def train_experience_data(training_set_db, params, optimizer, nbp, device, current_epoch):
     """ref nbp_utils.py:340-395 (GradScaler without autocast is the identity scale for fp32; omitted)."""
     random.shuffle(training_set_db)
@@ -154,7 +164,7 @@ def train_nbp(training_set_db, params, optimizer, nbp, device, current_epoch, va
         tl.append(float(np.mean(train_experience_data(training_set_db, params, optimizer, nbp, device, current_epoch))))
         nbp.eval()
         with torch.no_grad():
-            vl.append(validation_model(validation_data, params, nbp, device))
+            vl.append(_mean_over_ranks(validation_model(validation_data, params, nbp, device), device))
         sched.step(vl[-1])
     return sum(tl) / len(tl), sum(vl) / len(vl)
 
