@@ -280,3 +280,32 @@ def test_edge_arguments_never_crash(hip):
     assert L.nbp_forward_f32(pk.handle, x.data_ptr(), 1, 32, o1.data_ptr(), o2.data_ptr(), ws.data_ptr(), ws.numel(), None) == -2
     assert L.nbp_forward_f32(pk.handle, x.data_ptr(), 0, 32, o1.data_ptr(), o2.data_ptr(), ws.data_ptr(), ws.numel(), None) == -1
     sync()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_raster_random_triangle_soup_vs_oracle(hip, seed):
+    """Random triangle soups around random cameras: faces crossing the clip plane, behind the camera, degenerate
+    (zero area), needle-thin and screen-filling ones.  Same criterion as the maze test (silhouette pixels may differ
+    through rounding order)."""
+    rng = np.random.default_rng(seed)
+    n = 300
+    c = rng.uniform(-6, 6, (n, 1, 3))
+    size = rng.choice([0.05, 0.5, 3.0, 30.0], (n, 1, 1), p=[0.2, 0.4, 0.3, 0.1])
+    tri = (c + rng.normal(0, 1, (n, 3, 3)) * size).astype(np.float32)
+    tri[:5, 2] = tri[:5, 1]                                   # degenerate faces
+    tri[5:10, :, 1] = tri[5:10, :1, 1]                        # faces in a plane through ... (flat in y)
+    verts = tri.reshape(-1, 3)
+    faces = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    H, W = 48, 80
+    poses = [(rng.uniform(-3, 3, 3).tolist(), [float(rng.uniform(-60, 60)), float(rng.uniform(0, 360))]) for _ in range(4)]
+    RT = [ocam.camera_RT(x, v) for x, v in poses]
+    cams = ho.cams12(np.stack([r for r, _ in RT]), np.stack([t for _, t in RT]), D)
+    z, ov = ho.raster_zbuf(torch.from_numpy(verts).to(D), torch.from_numpy(faces).to(D), cams, H, W, bin_cap=4096)
+    assert int(ov.item()) == 0
+    z = z.cpu().numpy()
+    assert np.isfinite(z).all()
+    for i, (R, T) in enumerate(RT):
+        want = orast.raster_zbuf(verts, faces, R, T, H, W, ocam.TAN_HALF_FOV)
+        same = np.isclose(z[i], want, rtol=1e-5, atol=1e-5)
+        assert same.mean() > 0.995, (seed, i, same.mean())
+        assert ((z[i] > 0) == (want > 0)).mean() > 0.995
