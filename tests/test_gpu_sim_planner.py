@@ -309,3 +309,26 @@ def test_raster_random_triangle_soup_vs_oracle(hip, seed):
         same = np.isclose(z[i], want, rtol=1e-5, atol=1e-5)
         assert same.mean() > 0.995, (seed, i, same.mean())
         assert ((z[i] > 0) == (want > 0)).mean() > 0.995
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15])
+def test_coverage_random_clouds_vs_oracle(hip, seed):
+    """Clustered / sparse / lattice-aligned clouds (distances exactly equal to the threshold, points on cell borders and
+    outside the GT bounding box): the grid query counts exactly what the brute-force restatement counts."""
+    rng = np.random.default_rng(seed)
+    G = int(rng.integers(200, 3000))
+    kind = seed % 3
+    if kind == 0:        # integer lattice: many distances are exactly 1.0 (not covered: d < 1 is strict)
+        gt = rng.integers(-8, 8, (G, 3)).astype(np.float32)
+        pc = rng.integers(-9, 9, (int(rng.integers(50, 2 * G)), 3)).astype(np.float32)
+    elif kind == 1:      # clusters
+        centres = rng.uniform(-20, 20, (12, 3))
+        gt = (centres[rng.integers(0, 12, G)] + rng.normal(0, 1.5, (G, 3))).astype(np.float32)
+        pc = (centres[rng.integers(0, 6, 2 * G - 7)] + rng.normal(0, 1.0, (2 * G - 7, 3))).astype(np.float32)
+    else:                # sparse cloud partly outside the GT box
+        gt = rng.uniform(-5, 5, (G, 3)).astype(np.float32)
+        pc = rng.uniform(-15, 15, (int(rng.integers(10, G)), 3)).astype(np.float32)
+    assert len(pc) <= 2 * G                                           # no subsampling: exact comparison
+    out = ho.coverage_count(torch.from_numpy(gt).to(D), torch.from_numpy(pc).to(D), seed=seed).cpu().numpy()
+    _, cnt = opl.coverage(gt, pc, seed=seed)
+    assert out[1] == len(pc) and out[0] == cnt, (out, cnt)
