@@ -332,3 +332,31 @@ def test_coverage_random_clouds_vs_oracle(hip, seed):
     out = ho.coverage_count(torch.from_numpy(gt).to(D), torch.from_numpy(pc).to(D), seed=seed).cpu().numpy()
     _, cnt = opl.coverage(gt, pc, seed=seed)
     assert out[1] == len(pc) and out[0] == cnt, (out, cnt)
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_planner_kernels_random_vs_oracle(hip, seed):
+    """Random maps, random lattice positions partly outside the window, random skip flags: candidate scoring (one wave
+    per candidate, 21 x 21 window by ballot) and the all-edges Bresenham mask against the pinned restatements."""
+    rng = np.random.default_rng(seed)
+    S, V = 256, 64
+    full = (rng.random((S, S)) < rng.choice([0.002, 0.02, 0.3])).astype(np.float32) * rng.integers(1, 4, (S, S))
+    fullproj = np.minimum(full, 1).astype(np.float32)
+    obst = (rng.random((S, S)) < 0.05).astype(np.float32)
+    out1 = rng.normal(0, 1, (8, V, V)).astype(np.float32)
+    pose = np.array([rng.uniform(-5, 5), 3.3, rng.uniform(-5, 5), 0, 0], np.float32)
+    P = 400
+    pos = np.stack([rng.uniform(-48, 48, P), np.full(P, 3.3), rng.uniform(-48, 48, P)], 1).astype(np.float32)
+    skip = (rng.random(P) < 0.1)
+    valid, cell, score = ho.score_candidates(torch.from_numpy(pos).to(D), pose, torch.from_numpy(out1).to(D),
+                                             torch.from_numpy(fullproj).to(D), torch.from_numpy(skip.astype(np.uint8)).to(D))
+    v_o, c_o, s_o = opl.score_candidates(pos, pose, out1, fullproj, skip)
+    v_g = valid.cpu().numpy().astype(bool)
+    assert np.array_equal(v_g, v_o) and 0 < v_o.sum() < P
+    assert np.array_equal(cell.cpu().numpy()[v_o], c_o[v_o]) and np.array_equal(score.cpu().numpy()[v_o], s_o[v_o])
+    E = 600
+    ed = rng.integers(0, P, (E, 2)).astype(np.int32)
+    got = ho.edges_blocked(torch.from_numpy(obst).to(D), pose, torch.from_numpy(pos).to(D),
+                           torch.from_numpy(ed).to(D)).cpu().numpy().astype(bool)
+    want = np.array([opl.edge_blocked(pos[a], pos[b], pose, obst) for a, b in ed])
+    assert np.array_equal(got, want) and 0 < want.sum() < E
