@@ -73,12 +73,16 @@ def test_conv_function_grads(hip, case):
             _close(xd1.grad.permute(0, 3, 1, 2), xr1.grad, what="dx1")
 
 
-@pytest.mark.parametrize("C,relu", [(64, True), (32, False), (1, False), (512, True), (96, True)])
-def test_batchnorm_train_function(hip, C, relu):
-    x = _rand(3, 5, 7, C, seed=1) * 2 + 0.3
+@pytest.mark.parametrize("C,relu,hw", [(64, True, (5, 7)), (32, False, (5, 7)), (1, False, (5, 7)), (512, True, (5, 7)),
+                                        (96, True, (5, 7)), (1028, True, (3, 3)), (6, False, (9, 5)), (64, True, (96, 64)),
+                                        (128, False, (40, 52))])
+def test_batchnorm_train_function(hip, C, relu, hw):
+    """C % 4 == 0 takes the 16-B kernels (C4 > 256 loops over column blocks, many rows use several workgroups),
+    other widths (C = 1: the psi BatchNorm) the scalar ones."""
+    x = _rand(3, hw[0], hw[1], C, seed=1) * 2 + 0.3
     g, b = _rand(C, seed=2) * 0.3 + 1, _rand(C, seed=3) * 0.2
     rm, rv = _rand(C, seed=4) * 0.1, _rand(C, seed=5).abs() + 0.5
-    gy = _rand(3, 5, 7, C, seed=6)
+    gy = _rand(3, hw[0], hw[1], C, seed=6)
     xr, gr, br_ = x.permute(0, 3, 1, 2).clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
     rmr, rvr = rm.clone(), rv.clone()
     yr = F.batch_norm(xr, rmr, rvr, gr, br_, True, 0.1, 1e-5)
