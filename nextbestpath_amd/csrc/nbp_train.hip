@@ -266,6 +266,103 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__
         out[i] = x[i] * s[i / C];
 }
 
+// 16-B versions of the streaming kernels above / below (sizes and channel counts that are multiples of 4)
+__global__ __launch_bounds__(256) void ew4_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
+                                                  long long n4, float* __restrict__ out) {
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    const float b0 = op == 5 ? b[0] : 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 x = a4[i];
+        f32x4 y = {0.f, 0.f, 0.f, 0.f}, v;
+        if (op != 2 && op != 5) y = b4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            switch (op) {
+                case 0: v[e] = fmaxf(x[e] + y[e], 0.f); break;
+                case 1: v[e] = y[e] > 0.f ? x[e] : 0.f; break;
+                case 2: v[e] = 1.f / (1.f + expf(-x[e])); break;
+                case 3: v[e] = x[e] * y[e] * (1.f - y[e]); break;
+                case 5: v[e] = x[e] + b0; break;
+                default: v[e] = x[e] + y[e]; break;
+            }
+        }
+        o4[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void rowscale4_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                        long long total4, int C4, float* __restrict__ out) {
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x)
+        o4[i] = x4[i] * s[i / C4];
+}
+
+__global__ __launch_bounds__(256) void slice_channels4_kernel(const float* __restrict__ in, long long M, int Cin4, int c04, int Cs4,
+                                                              float* __restrict__ out) {
+    const f32x4* i4 = reinterpret_cast<const f32x4*>(in);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    const long long total = M * Cs4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        o4[i] = i4[(i / Cs4) * Cin4 + c04 + (i % Cs4)];
+}
+
+__global__ __launch_bounds__(256) void sum2x2_4_kernel(const float* __restrict__ dy, int B, int Hs, int Ws, int C4,
+                                                       float* __restrict__ out) {
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    const long long total = (long long)B * Hs * Ws * C4;
+    const int W = 2 * Ws;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long p = i / C4;
+        const int xs = (int)(p % Ws);
+        long long q = p / Ws;
+        const int ys = (int)(q % Hs);
+        const int b = (int)(q / Hs);
+        const long long base = (((long long)b * 2 * Hs + 2 * ys) * W + 2 * xs) * C4 + c;
+        o4[i] = (d4[base] + d4[base + C4]) + (d4[base + (long long)W * C4] + d4[base + (long long)W * C4 + C4]);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B,
+                                                            int H, int W, int C4, float* __restrict__ dx) {
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
+    f32x4* o4 = reinterpret_cast<f32x4*>(dx);
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long long total = (long long)B * Ho * Wo * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long p = i / C4;
+        const int xo = (int)(p % Wo);
+        long long q = p / Wo;
+        const int yo = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        const long long base = (((long long)b * H + 2 * yo) * W + 2 * xo) * C4 + c;
+        const long long off[4] = {0, C4, (long long)W * C4, (long long)W * C4 + C4};
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = x4[base + off[k]];
+        const f32x4 g = d4[i];
+        f32x4 o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float best = v[0][e];
+            int arg = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (v[k][e] > best || (v[k][e] != v[k][e] && best == best)) { best = v[k][e]; arg = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][e] = k == arg ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o4[base + off[k]] = o[k];
+    }
+}
+
 // out[m] = sum_c a[m][c] * b[m][c]   (b may be a [C] vector when b_is_vec): 16 lanes per row
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b, int b_is_vec,
                                                      long long M, int C, float* __restrict__ out) {
@@ -764,14 +861,19 @@ extern "C" int nbp_elementwise_f32(int op, const float* a, const float* b, long 
     NBP_ENTER();
     NBP_RETURN_IF(!a || !out || n < 1 || op < 0 || op > 5, NBP_E_ARG);
     NBP_RETURN_IF(op != 2 && !b, NBP_E_ARG);
-    ew_kernel<<<nbp_ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(op, a, b, n, out);
+    const bool al16 = (((uintptr_t)a | (uintptr_t)out | (uintptr_t)(op == 2 || op == 5 ? a : b)) & 15) == 0;
+    if (n % 4 == 0 && al16) ew4_kernel<<<nbp_ew_grid(n / 4, 256), 256, 0, (hipStream_t)stream>>>(op, a, b, n / 4, out);
+    else ew_kernel<<<nbp_ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(op, a, b, n, out);
     return nbp_launch_status();
 }
 
 extern "C" int nbp_rowscale_f32(const float* x, const float* s, long long M, int C, float* out, void* stream) {
     NBP_ENTER();
     NBP_RETURN_IF(!x || !s || !out || M < 1 || C < 1, NBP_E_ARG);
-    rowscale_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, (hipStream_t)stream>>>(x, s, M * C, C, out);
+    if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0)
+        rowscale4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, (hipStream_t)stream>>>(x, s, M * C / 4, C / 4, out);
+    else
+        rowscale_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, (hipStream_t)stream>>>(x, s, M * C, C, out);
     return nbp_launch_status();
 }
 
@@ -793,7 +895,11 @@ extern "C" int nbp_maxpool2_backward_f32(const float* x, const float* dy, int B,
     NBP_ENTER();
     NBP_RETURN_IF(!x || !dy || !dx, NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1, NBP_E_SHAPE);
-    maxpool2_bwd_kernel<<<nbp_ew_grid((long long)B * (H / 2) * (W / 2) * C, 256), 256, 0, (hipStream_t)stream>>>(x, dy, B, H, W,
+    if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
+        maxpool2_bwd4_kernel<<<nbp_ew_grid((long long)B * (H / 2) * (W / 2) * C / 4, 256), 256, 0, (hipStream_t)stream>>>(
+            x, dy, B, H, W, C / 4, dx);
+    else
+        maxpool2_bwd_kernel<<<nbp_ew_grid((long long)B * (H / 2) * (W / 2) * C, 256), 256, 0, (hipStream_t)stream>>>(x, dy, B, H, W,
                                                                                                                  C, dx);
     return nbp_launch_status();
 }
@@ -801,14 +907,20 @@ extern "C" int nbp_maxpool2_backward_f32(const float* x, const float* dy, int B,
 extern "C" int nbp_sum2x2_f32(const float* dy, int B, int Hs, int Ws, int C, float* out, void* stream) {
     NBP_ENTER();
     NBP_RETURN_IF(!dy || !out || B < 1 || Hs < 1 || Ws < 1 || C < 1, NBP_E_ARG);
-    sum2x2_kernel<<<nbp_ew_grid((long long)B * Hs * Ws * C, 256), 256, 0, (hipStream_t)stream>>>(dy, B, Hs, Ws, C, out);
+    if (C % 4 == 0 && (((uintptr_t)dy | (uintptr_t)out) & 15) == 0)
+        sum2x2_4_kernel<<<nbp_ew_grid((long long)B * Hs * Ws * C / 4, 256), 256, 0, (hipStream_t)stream>>>(dy, B, Hs, Ws, C / 4, out);
+    else
+        sum2x2_kernel<<<nbp_ew_grid((long long)B * Hs * Ws * C, 256), 256, 0, (hipStream_t)stream>>>(dy, B, Hs, Ws, C, out);
     return nbp_launch_status();
 }
 
 extern "C" int nbp_slice_channels_f32(const float* in, long long M, int Cin, int c0, int Cs, float* out, void* stream) {
     NBP_ENTER();
     NBP_RETURN_IF(!in || !out || M < 1 || Cin < 1 || c0 < 0 || Cs < 1 || c0 + Cs > Cin, NBP_E_ARG);
-    slice_channels_kernel<<<nbp_ew_grid(M * Cs, 256), 256, 0, (hipStream_t)stream>>>(in, M, Cin, c0, Cs, out);
+    if (Cin % 4 == 0 && c0 % 4 == 0 && Cs % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0)
+        slice_channels4_kernel<<<nbp_ew_grid(M * Cs / 4, 256), 256, 0, (hipStream_t)stream>>>(in, M, Cin / 4, c0 / 4, Cs / 4, out);
+    else
+        slice_channels_kernel<<<nbp_ew_grid(M * Cs, 256), 256, 0, (hipStream_t)stream>>>(in, M, Cin, c0, Cs, out);
     return nbp_launch_status();
 }
 
