@@ -216,8 +216,10 @@ int nbp_unproject_append_f32(const float* depth, const unsigned char* mask_or_nu
 
 /* Camera.capture_image's depth output (mu:2743-2786): zbuf [n_frames,H,W] = view-space z of the
  * nearest face through each pixel centre (perspective-correct, faces clipped at z_clip), -1 where
- * no face.  Faces are binned into 8x8-pixel tiles with at most bin_cap faces per tile;
- * *overflow_flag (device int, caller zeroes it) is set if a tile overflowed. */
+ * no face.  Faces are binned into 8x8-pixel tiles with bin_cap list entries per tile.  No face is ever
+ * dropped (the reference renders with max_faces_per_bin = 500000, macarons/testers/scene.py:440-446): a tile
+ * whose bin overflows walks all faces of the frame instead (same result, slower) and
+ * *overflow_flag (device int, caller zeroes it) counts such tiles so that the caller can raise bin_cap. */
 size_t nbp_raster_workspace_bytes(int n_faces, int n_frames, int H, int W, int bin_cap);
 int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* faces, int n_faces,
                         const float* cams12_host, int n_frames, int H, int W, float tan_half_fov,

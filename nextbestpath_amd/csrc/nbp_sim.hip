@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void raster_bin_kernel(const int4* __restrict_
     for (int tx = box.x; tx <= box.y; ++tx) {
         const int pos = atomicAdd(&tile_count[base + tx], 1);
         if (pos < bin_cap) tile_list[(size_t)(base + tx) * bin_cap + pos] = fi;
-        else *overflow = 1;
+        else if (pos == bin_cap) atomicAdd(overflow, 1);      // number of spilled tiles (they fall back to a full face walk)
     }
 }
 
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void raster_bin_kernel(const int4* __restrict_
 __global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restrict__ recs, int n_faces, int H, int W,
                                                          float tanh_fov, float zclip, int tiles_x, int tiles_y, int bin_cap,
                                                          const int* __restrict__ tile_count, const int* __restrict__ tile_list,
-                                                         float* __restrict__ zbuf) {
+                                                         const int4* __restrict__ tbox, float* __restrict__ zbuf) {
     __shared__ __attribute__((aligned(16))) FaceRec sh[64];
     const int fr = blockIdx.y;
     const int tile = blockIdx.x;
@@ -244,15 +244,32 @@ __global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restri
     const float ndc_y = ((float)H - (2.f * row + 1.f)) / (float)s;
     const float dx = ndc_x * tanh_fov, dy = ndc_y * tanh_fov;   // dz = 1
     const int t = fr * tiles_x * tiles_y + tile;
-    const int n = min(tile_count[t], bin_cap);
+    const int n_binned = tile_count[t];
+    // A bin that overflowed its capacity is NOT truncated (the reference's rasteriser never drops faces:
+    // max_faces_per_bin = 500000, macarons/testers/scene.py:440-446): the tile walks every face of the frame and
+    // keeps those whose tile box covers it -- same face set as an unbounded bin, only slower.
+    const bool spill = n_binned > bin_cap;
+    const int n = spill ? n_faces : n_binned;
     const int* lst = tile_list + (size_t)t * bin_cap;
     const FaceRec* rb = recs + (size_t)fr * n_faces;
+    const int4* tb = tbox + (size_t)fr * n_faces;
     float zbest = 3.0e38f;
     const float eps = 1e-6f;
     for (int base = 0; base < n; base += 64) {
-        const int m = min(64, n - base);
+        int m = min(64, n - base);
         __syncthreads();
-        if (lane < m) sh[lane] = rb[lst[base + lane]];
+        if (!spill) {
+            if (lane < m) sh[lane] = rb[lst[base + lane]];
+        } else {
+            bool in = false;
+            if (lane < m) {
+                const int4 bx = tb[base + lane];
+                in = bx.x <= bx.y && tx >= bx.x && tx <= bx.y && ty >= bx.z && ty <= bx.w;
+            }
+            const unsigned long long bal = __ballot(in);
+            if (in) sh[__popcll(bal & ((1ull << lane) - 1ull))] = rb[base + lane];
+            m = __popcll(bal);
+        }
         __syncthreads();
         for (int k = 0; k < m; ++k) {
             const FaceRec& f = sh[k];
@@ -465,7 +482,7 @@ extern "C" int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* f
     if (rc) return rc;
     dim3 g2((unsigned)(tiles_x * tiles_y), (unsigned)n_frames);
     raster_tile_kernel<<<g2, 64, 0, st>>>(recs, n_faces, H, W, tan_half_fov, z_clip, tiles_x, tiles_y, bin_cap, tile_count,
-                                          tile_list, zbuf);
+                                          tile_list, tbox, zbuf);
     return nbp_launch_status();
 }
 

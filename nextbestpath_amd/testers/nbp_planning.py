@@ -77,8 +77,8 @@ class Rollout:
         self.st = state or RolloutState(device, grid=grid)
         self.st.cloud_count.zero_()
         self.st.coverage_counts.zero_()
-        self.planner = LatticePlanner(camera, mesh_for_check, device, self.V, self.S, self.grid_range)
         self.rng = random.Random(seed)
+        self.planner = LatticePlanner(camera, mesh_for_check, device, self.V, self.S, self.grid_range, rng=self.rng)
         self.gt = gt_scene_pc.contiguous()
         self.bbox = (self.gt.min(0).values.tolist(), self.gt.max(0).values.tolist())
         self.path, self.path_record = [], 0

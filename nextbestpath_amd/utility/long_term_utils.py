@@ -79,8 +79,9 @@ class LatticePlanner:
     device->host copy, then the reference's host logic (stable sort, uniform-cost search with
     heapq tie-breaking, heading choice, first-edge check against the real mesh)."""
 
-    def __init__(self, camera, mesh, device, value_size=64, layout_size=256, grid_range=(-40, 40)):
+    def __init__(self, camera, mesh, device, value_size=64, layout_size=256, grid_range=(-40, 40), rng=None):
         self.camera, self.mesh, self.device = camera, mesh, device
+        self.rng = rng or random.Random(0)
         self.V, self.S, self.grid_range = value_size, layout_size, grid_range
         self.idx3, self.xyz = camera.positions()
         self.node_index = {tuple(t): n for n, t in enumerate(self.idx3.tolist())}
@@ -146,6 +147,7 @@ class LatticePlanner:
         out1_h = stg[3].numpy().copy()
         cand = np.nonzero(valid_h)[0]
         cand = cand[np.argsort(-score_h[cand], kind="stable")].tolist()      # stable, descending (ref :233)
+        self.last_candidates, self.last_goal = cand, None                    # introspection for the parity tests
         start_id = self.node_index[tuple(cam.cam_idx[:3])]
         hist = np.asarray(cam.cam_idx_history, np.int64).reshape(-1, 5)
         tree, tree_version = None, -1
@@ -164,10 +166,11 @@ class LatticePlanner:
                 cur = tree[cur]
             nodes = [tuple(self.idx3[n].tolist()) for n in ids[::-1]]
             full = planner_host.choose_headings(nodes, self.xyz, self.node_index, pose, out1_h, hist, self.V,
-                                                self.grid_range)
+                                                self.grid_range, rng=self.rng)
             path = full[1:]
             if len(path) > 0:
                 if not check_first_edge or not self.edge_hits_mesh(cam.cam_idx[:3], path[0][:3]):
+                    self.last_goal = ci
                     break
                 collision_list.append([list(cam.cam_idx[:3]), path[0][:3]])
                 collision_list.append([path[0][:3], list(cam.cam_idx[:3])])

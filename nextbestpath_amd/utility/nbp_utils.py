@@ -254,10 +254,10 @@ class CollectionRollout:
         self.y_bins, self.S, self.V, self.grid_range = y_bins, grid, value_size, grid_range
         self.st = RolloutState(device, grid=grid)
         self.st.cloud_count.zero_(); self.st.coverage_counts.zero_()
-        self.planner = LatticePlanner(camera, mesh, device, value_size, grid, grid_range)
+        self.rng = random.Random(seed)
+        self.planner = LatticePlanner(camera, mesh, device, value_size, grid, grid_range, rng=self.rng)
         self.gt = gt_scene_pc.contiguous()
         self.bbox = (self.gt.min(0).values.tolist(), self.gt.max(0).values.tolist())
-        self.rng = random.Random(seed)
         self.gen = torch.Generator().manual_seed(seed)
         self.seed = seed * 1_000_003
         # check_camera_in_mesh for every lattice position, once per scene (static mesh)
@@ -351,7 +351,8 @@ class CollectionRollout:
                 ids.append(cur)
                 cur = tree[cur]
             nodes = [tuple(pl.idx3[m].tolist()) for m in ids[::-1]]
-            full = planner_host.choose_headings(nodes, pl.xyz, pl.node_index, pose, out1_h, hist, self.V, self.grid_range)
+            full = planner_host.choose_headings(nodes, pl.xyz, pl.node_index, pose, out1_h, hist, self.V, self.grid_range,
+                                                rng=self.rng)
             return full[1:]
         return None
 

@@ -68,10 +68,12 @@ def path_from_tree(came_from, goal):
     return path[::-1]
 
 
-def choose_headings(path, positions, node_index, pose, out1, cam_idx_history, V=64, grid_range=(-40, 40)):
+def choose_headings(path, positions, node_index, pose, out1, cam_idx_history, V=64, grid_range=(-40, 40), rng=None):
     """long_term_utils.py:390-413: for every node of the path pick the best-valued heading that the
-    camera has not used at that node yet (elevation index fixed to 2); random heading off-map.
+    camera has not used at that node yet (elevation index fixed to 2); random heading off-map, drawn from
+    `rng` (the rollout's own random.Random, so that concurrent rollouts do not share a stream).
     out1: host array [8,V,V]; cam_idx_history: host int array [n,5].  Returns [[i,j,k,2,h], ...]."""
+    rng = rng or random
     hist = {tuple(int(v) for v in row) for row in np.asarray(cam_idx_history).tolist()}
     out = []
     for step in path:
@@ -84,8 +86,8 @@ def choose_headings(path, positions, node_index, pose, out1, cam_idx_history, V=
                 if (step[0], step[1], step[2], 2, h) not in hist:
                     break
         else:
-            while True:
-                h = random.randint(0, 7)
+            for _ in range(64):            # the reference loops forever when all 8 headings were used at this node
+                h = rng.randint(0, 7)
                 if (step[0], step[1], step[2], 2, h) not in hist:
                     break
         out.append([int(step[0]), int(step[1]), int(step[2]), 2, h])

@@ -1,0 +1,114 @@
+/* oracle_sim.c -- TEST INFRASTRUCTURE (see oracle/__init__.py): plain-C restatements of the simulator pieces
+ * whose numpy restatement is too slow for rollout-length checks and for bench.py's cpu_baseline leg.
+ *
+ *   oracle_raster_zbuf   == oracle/raster.py::raster_zbuf (PyTorch3D MeshRasterizer as called at
+ *                           macarons/utility/macarons_utils.py:905-937, 2743-2786; PARITY UNPINNED against the
+ *                           library, validated bit-for-bit against raster.py on small cases)
+ *   oracle_unproject     == oracle/camera.py::unproject (Camera.project_depth_in_3D, mu:2788-2809)
+ *   oracle_coverage_count== oracle/planner.py::coverage's inner loop (calculate_coverage_percentage,
+ *                           next_best_path/utility/long_term_utils.py:437-468: G x M distances, row minimum, threshold)
+ *
+ * fp32 throughout with the operation order of the numpy files (compile with -ffp-contract=off, no -ffast-math).
+ * The raster only visits the pixels of a conservative screen box of each face (full image when the face crosses the
+ * clip plane); the per-pixel ray / triangle algebra is raster.py's. */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static void to_view(const float* p, const float* R, const float* T, float* o) {
+    for (int j = 0; j < 3; ++j) o[j] = ((p[0] * R[0 + j] + p[1] * R[3 + j]) + p[2] * R[6 + j]) + T[j];
+}
+
+void oracle_raster_zbuf(const float* verts, int n_verts, const int* faces, int n_faces, const float* R, const float* T,
+                        int H, int W, float tan_half_fov, float z_clip, float eps, float* zbuf) {
+    (void)n_verts;
+    const int s = H < W ? H : W;
+    float* dxs = (float*)malloc(sizeof(float) * (size_t)W);
+    float* dys = (float*)malloc(sizeof(float) * (size_t)H);
+    for (int c = 0; c < W; ++c) dxs[c] = ((float)W - (2.f * (float)c + 1.f)) / (float)s * tan_half_fov;
+    for (int r = 0; r < H; ++r) dys[r] = ((float)H - (2.f * (float)r + 1.f)) / (float)s * tan_half_fov;
+    for (size_t i = 0; i < (size_t)H * W; ++i) zbuf[i] = 3.0e38f;
+    for (int fi = 0; fi < n_faces; ++fi) {
+        float v[3][3];
+        for (int k = 0; k < 3; ++k) to_view(verts + 3 * (size_t)faces[3 * (size_t)fi + k], R, T, v[k]);
+        if (v[0][2] <= z_clip && v[1][2] <= z_clip && v[2][2] <= z_clip) continue;
+        int c0 = 0, c1 = W - 1, r0 = 0, r1 = H - 1;
+        if (v[0][2] > z_clip && v[1][2] > z_clip && v[2][2] > z_clip) {
+            float cmin = 1e30f, cmax = -1e30f, rmin = 1e30f, rmax = -1e30f;
+            for (int k = 0; k < 3; ++k) {
+                const float nx = v[k][0] / (v[k][2] * tan_half_fov), ny = v[k][1] / (v[k][2] * tan_half_fov);
+                const float col = ((float)W - (float)s * nx - 1.f) * 0.5f, row = ((float)H - (float)s * ny - 1.f) * 0.5f;
+                cmin = fminf(cmin, col); cmax = fmaxf(cmax, col); rmin = fminf(rmin, row); rmax = fmaxf(rmax, row);
+            }
+            cmin = fmaxf(cmin, -1e6f); rmin = fmaxf(rmin, -1e6f); cmax = fminf(cmax, 1e6f); rmax = fminf(rmax, 1e6f);
+            c0 = (int)floorf(cmin) - 2; c1 = (int)ceilf(cmax) + 2; r0 = (int)floorf(rmin) - 2; r1 = (int)ceilf(rmax) + 2;
+            if (c0 < 0) c0 = 0;
+            if (r0 < 0) r0 = 0;
+            if (c1 > W - 1) c1 = W - 1;
+            if (r1 > H - 1) r1 = H - 1;
+            if (c0 > c1 || r0 > r1) continue;
+        }
+        float e1[3], e2[3], q[3];
+        for (int c = 0; c < 3; ++c) { e1[c] = v[1][c] - v[0][c]; e2[c] = v[2][c] - v[0][c]; }
+        const float* v0 = v[0];
+        q[0] = e1[1] * v0[2] - e1[2] * v0[1];
+        q[1] = e1[2] * v0[0] - e1[0] * v0[2];
+        q[2] = e1[0] * v0[1] - e1[1] * v0[0];
+        const float tnum = (e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2];
+        for (int r = r0; r <= r1; ++r) {
+            const float dy = dys[r];
+            float* zrow = zbuf + (size_t)r * W;
+            for (int c = c0; c <= c1; ++c) {
+                const float dx = dxs[c];
+                const float p0 = dy * e2[2] - e2[1];
+                const float p1 = e2[0] - dx * e2[2];
+                const float p2 = dx * e2[1] - dy * e2[0];
+                const float det = (e1[0] * p0 + e1[1] * p1) + e1[2] * p2;
+                if (!(fabsf(det) >= 1e-12f)) continue;
+                const float inv = 1.f / det;
+                const float u = -((v0[0] * p0 + v0[1] * p1) + v0[2] * p2) * inv;
+                const float vv = ((dx * q[0] + dy * q[1]) + q[2]) * inv;
+                const float z = tnum * inv;
+                if (u >= -eps && vv >= -eps && u + vv <= 1.f + eps && z > z_clip && z < zrow[c]) zrow[c] = z;
+            }
+        }
+    }
+    for (size_t i = 0; i < (size_t)H * W; ++i)
+        if (!(zbuf[i] < 1.0e38f)) zbuf[i] = -1.f;
+    free(dxs); free(dys);
+}
+
+/* All pixels of one depth frame -> world points [H*W,3] (oracle/camera.py::unproject). */
+void oracle_unproject(const float* depth, int H, int W, float tan_half_fov, const float* R, const float* T, float* out) {
+    const int s = H < W ? H : W;
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            const float ndc_x = (float)((double)W / s) - ((float)c / (float)(s - 1)) * 2.f;
+            const float ndc_y = (float)((double)H / s) - ((float)r / (float)(s - 1)) * 2.f;
+            const float z = depth[(size_t)r * W + c];
+            const float xv = (ndc_x * z) * tan_half_fov, yv = (ndc_y * z) * tan_half_fov;
+            const float dx = xv - T[0], dy = yv - T[1], dz = z - T[2];
+            float* o = out + 3 * ((size_t)r * W + c);
+            for (int j = 0; j < 3; ++j) o[j] = (dx * R[3 * j] + dy * R[3 * j + 1]) + dz * R[3 * j + 2];
+        }
+}
+
+/* Number of gt points whose nearest pc point is closer than threshold (brute force G x M, like torch.cdist + min). */
+long long oracle_coverage_count(const float* gt, long long G, const float* pc, long long M, float threshold) {
+    long long cnt = 0;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : cnt) schedule(static)
+#endif
+    for (long long i = 0; i < G; ++i) {
+        const float gx = gt[3 * i], gy = gt[3 * i + 1], gz = gt[3 * i + 2];
+        float best = 3.0e38f;
+        for (long long j = 0; j < M; ++j) {
+            const float ex = gx - pc[3 * j], ey = gy - pc[3 * j + 1], ez = gz - pc[3 * j + 2];
+            const float d2 = (ex * ex + ey * ey) + ez * ez;
+            if (d2 < best) best = d2;
+        }
+        if (M > 0 && sqrtf(best) < threshold) ++cnt;
+    }
+    return cnt;
+}
