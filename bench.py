@@ -146,9 +146,7 @@ def main():
         settings = sc.Settings(ds[0]["settings"], params.scene_scale_factor)
         mesh = sc.load_scene(os.path.join(tmp, name, ds[0]["obj_name"]), params.scene_scale_factor, dev)
         y_bins = sc.y_bins_for(mesh.verts_host, 4)
-        gt = torch.from_numpy(sc.sample_gt_surface(mesh.verts_host, mesh.faces_host, params.n_gt_surface_points,
-                                                   settings.scene.x_min - np.float32(0.2),
-                                                   settings.scene.x_max + np.float32(0.2), 0.5, seed=rank)).to(dev)
+        _, gt = sc.setup_gt_scene(params, settings, mesh, dev, 0.05, seed=rank)
         cam = tp.setup_test_camera(params, mesh, settings.camera.start_positions[0], settings, dev, seed=rank)
         return tp.Rollout(params, net, cam, gt, mesh, mesh, y_bins, dev, seed=8 + 16 * rank + k)
 

@@ -253,6 +253,32 @@ int nbp_carve_update_f32(const float* proxy_pts3, int P, const float* depth,
                          float tan_half_fov, float zfar, float fov_range, float tol,
                          float score_threshold, float* n_inside, float* n_behind, float* occ,
                          float* out_of_field, void* stream);
+/* ---- Scene / Cell point store (MACARONS scene objects, macarons/utility/macarons_utils.py:2952-3234), device resident.
+ * store_pts [n_cells][capacity][3] fp32 + store_count [n_cells] int32, n_cells = grid3[0]*grid3[1]*grid3[2] in the
+ * cartesian product order (i_l, i_w, i_h) of Scene.__init__ (:3063-3066); box6_host = x_min[3], x_max[3] of the scene.
+ *
+ * nbp_scene_fill_cells_f32 = Scene.fill_cells (:3177-3187) + Cell.fill (:3000-3028): points inside the scene box
+ * (inclusive) go to the cell given by floor_divide (macarons/utility/utils.py:113-117) if they lie STRICTLY inside that
+ * cell's box; a cell that receives more than n_point_min candidates drops those within `resolution` (fp64 distance,
+ * d <= resolution) of a point it already stores -- new points are not compared with each other -- and appends the rest;
+ * above `capacity` an exact-size seeded random subset of [stored | new] survives (torch.randperm(len)[:capacity], :3021).
+ * n_dev_or_null (device int64) optionally bounds n on the device (cloud counters). */
+size_t nbp_scene_fill_workspace_bytes(const float* box6_host, const int* grid3_host, int capacity,
+                                      long long n_pts_max, double resolution);
+int nbp_scene_fill_cells_f32(const float* pts3, long long n, const long long* n_dev_or_null,
+                             const float* box6_host, const int* grid3_host, int capacity, double resolution,
+                             int n_point_min, unsigned seed, float* store_pts, int* store_count, void* ws,
+                             size_t ws_bytes, void* stream);
+/* Scene.return_entire_pt_cloud (:3217-3234): the cells' points back to back, *n_out (device) = their number. */
+int nbp_scene_gather_f32(const float* store_pts, const int* store_count, int n_cells, int capacity, float* out3,
+                         long long out_capacity, long long* n_out, void* stream);
+/* Scene.scene_coverage (:3512-3539): covered_and_total2[0] = number of stored GT points whose nearest recovered point
+ * OF THE SAME CELL is closer than epsilon (fp64, strict), [1] = number of stored GT points; coverage = [0] / [1]. */
+size_t nbp_scene_coverage_workspace_bytes(const float* box6_host, const int* grid3_host, int capacity_rec,
+                                          double epsilon);
+int nbp_scene_coverage_f32(const float* gt_pts, const int* gt_count, int capacity_gt, const float* rec_pts,
+                           const int* rec_count, int capacity_rec, const float* box6_host, const int* grid3_host,
+                           double epsilon, int* covered_and_total2, void* ws, size_t ws_bytes, void* stream);
 /* dst[offset + i] = pts3_host[i] for i < n <= 8 (the camera trajectory buffer, without a blocking copy). */
 int nbp_append_points_f32(float* dst, long long offset, const float* pts3_host, int n, void* stream);
 /* Host mirror of the sampling bijection (driver / tests). */

@@ -94,6 +94,12 @@ SIGNATURES["nbp_conv_igemm_bf16_workspace_bytes"] = SIGNATURES["nbp_conv_igemm_w
 SIGNATURES["nbp_pack_conv_weight_bf16"] = SIGNATURES["nbp_pack_conv_weight"]
 SIGNATURES["nbp_f32_to_bf16"] = (_i, [_vp, _ll, _vp, _vp])
 SIGNATURES["nbp_bf16_to_f32"] = (_i, [_vp, _ll, _vp, _vp])
+_fpp, _ipp = C.POINTER(_f), C.POINTER(_i)
+SIGNATURES["nbp_scene_fill_workspace_bytes"] = (_sz, [_fpp, _ipp, _i, _ll, _d])
+SIGNATURES["nbp_scene_fill_cells_f32"] = (_i, [_vp, _ll, _vp, _fpp, _ipp, _i, _d, _i, C.c_uint, _vp, _vp, _vp, _sz, _vp])
+SIGNATURES["nbp_scene_gather_f32"] = (_i, [_vp, _vp, _i, _i, _vp, _ll, _vp, _vp])
+SIGNATURES["nbp_scene_coverage_workspace_bytes"] = (_sz, [_fpp, _ipp, _i, _d])
+SIGNATURES["nbp_scene_coverage_f32"] = (_i, [_vp, _vp, _i, _vp, _vp, _i, _fpp, _ipp, _d, _vp, _vp, _sz, _vp])
 SIGNATURES["nbp_slice_obstacle_f32"] = (_i, [_vp, _vp, _i, _f, _f, _f, _i, _f, _f, _f, _vp, _vp])
 
 _lock = threading.Lock()

@@ -11,6 +11,7 @@
 // Integer results (cells, masks, counts) are bit-exact against oracle/planner.py.
 #include "common.h"
 #pragma clang fp contract(off)
+#include "nbp_grid.h"
 
 namespace {
 
@@ -97,15 +98,6 @@ __global__ __launch_bounds__(256) void edges_blocked_kernel(const float* __restr
 
 // ------------------------------------------------------------------ coverage
 
-struct Grid { float lo[3]; float inv; int n[3]; };
-
-__device__ __forceinline__ int grid_cell(const Grid& g, float x, float y, float z, int* ijk) {
-    int i = (int)floorf((x - g.lo[0]) * g.inv), j = (int)floorf((y - g.lo[1]) * g.inv), k = (int)floorf((z - g.lo[2]) * g.inv);
-    i = min(max(i, 0), g.n[0] - 1); j = min(max(j, 0), g.n[1] - 1); k = min(max(k, 0), g.n[2] - 1);
-    if (ijk) { ijk[0] = i; ijk[1] = j; ijk[2] = k; }
-    return (i * g.n[1] + j) * g.n[2] + k;
-}
-
 // Counting sort of the (sub-sampled) cloud by grid cell, then a 16-lanes-per-GT-point query that
 // streams the 9 contiguous cell runs of the 3x3x3 neighbourhood (k is the fastest cell index).
 // K1: sample (first k of the index bijection when N > k, else everything), cell id, slot in cell.
@@ -125,78 +117,6 @@ __global__ __launch_bounds__(256) void coverage_bin_kernel(const float* __restri
         const int c = grid_cell(g, x, y, z, nullptr);
         cell_of[j] = c;
         slot_of[j] = atomicAdd(&count[c], 1);
-    }
-}
-
-// K2: exclusive scan of count[0..ncell) -> start[0..ncell] in three launches that use the whole chip (a single
-// block walking the array tile by tile pays one global-memory round trip per tile: 34 us for 140 k cells):
-// (a) per-block sums of 4096-int tiles, (b) one block scans the <= 4096 tile sums, (c) per-tile scan + offset.
-constexpr int SCAN_TILE = 4096;
-__device__ __forceinline__ int block_exclusive_scan_256(int mine, int* wtot /*[4]*/, int* total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int n = __shfl_up(inc, o);
-        if (lane >= o) inc += n;
-    }
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wtot[w];
-    if (total) *total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-    return base + inc - mine;
-}
-
-__global__ __launch_bounds__(256) void coverage_tilesum_kernel(const int* __restrict__ count, long long ncell,
-                                                               int* __restrict__ tsum) {
-    __shared__ int wtot[4];
-    const long long i0 = (long long)blockIdx.x * SCAN_TILE + 16 * (long long)threadIdx.x;
-    int mine = 0;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) mine += i0 + e < ncell ? count[i0 + e] : 0;
-    int total;
-    (void)block_exclusive_scan_256(mine, wtot, &total);
-    if (threadIdx.x == 0) tsum[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(256) void coverage_tilescan_kernel(int* __restrict__ tsum, int ntiles, int* __restrict__ start,
-                                                                long long ncell) {
-    __shared__ int wtot[4];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int t0 = 0; t0 < ntiles; t0 += 256 * 16) {           // one pass for up to 4096 tiles (16 M cells)
-        int v[16], mine = 0;
-        const int i0 = t0 + 16 * threadIdx.x;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { v[e] = i0 + e < ntiles ? tsum[i0 + e] : 0; mine += v[e]; }
-        int total;
-        int run = carry + block_exclusive_scan_256(mine, wtot, &total);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (i0 + e < ntiles) tsum[i0 + e] = run;
-            run += v[e];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) carry += total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) start[ncell] = carry;
-}
-
-__global__ __launch_bounds__(256) void coverage_scan_kernel(const int* __restrict__ count, long long ncell,
-                                                            const int* __restrict__ toff, int* __restrict__ start) {
-    __shared__ int wtot[4];
-    const long long i0 = (long long)blockIdx.x * SCAN_TILE + 16 * (long long)threadIdx.x;
-    int v[16], mine = 0;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { v[e] = i0 + e < ncell ? count[i0 + e] : 0; mine += v[e]; }
-    int run = toff[blockIdx.x] + block_exclusive_scan_256(mine, wtot, nullptr);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        if (i0 + e < ncell) start[i0 + e] = run;
-        run += v[e];
     }
 }
 
@@ -296,7 +216,8 @@ static int coverage_grid(const float* bbox_lo, const float* bbox_hi, float thr, 
         g->n[a] = (int)(ext / thr) + 1;
         n *= (size_t)g->n[a];
     }
-    g->inv = 1.f / thr;
+    g->inv = (float)(1.0 / ((double)thr * 1.001));   // cells a little wider than thr: fp32 rounding of (x - lo) * inv can
+                                                     // never put two points within thr more than one cell apart
     if (n > (size_t)1 << 28) return NBP_E_SHAPE;
     *ncell = n;
     return 0;
@@ -333,7 +254,6 @@ extern "C" int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3,
     float* sp = (float*)p; p += al256((size_t)sample_k * 12);
     float* sorted = (float*)p; p += al256((size_t)sample_k * 12);
     int* tsum = (int*)p;
-    const int ntiles = (int)(ncell / SCAN_TILE + 1);
     hipError_t e = hipMemsetAsync(count, 0, ncell * 4, st);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(count_out, 0, sizeof(int), st);
@@ -342,10 +262,7 @@ extern "C" int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3,
     const int grid = nbp_ew_grid(work > 0 ? work : 1, 256);
     coverage_bin_kernel<<<grid, 256, 0, st>>>(pc3, N_dev_or_null, N, sample_k, seed, g, sp, cell_of, slot_of, count, m_out);
     if ((rc = nbp_launch_status())) return rc;
-    coverage_tilesum_kernel<<<ntiles, 256, 0, st>>>(count, (long long)ncell, tsum);
-    coverage_tilescan_kernel<<<1, 256, 0, st>>>(tsum, ntiles, start, (long long)ncell);
-    coverage_scan_kernel<<<ntiles, 256, 0, st>>>(count, (long long)ncell, tsum, start);
-    if ((rc = nbp_launch_status())) return rc;
+    if ((rc = grid_exclusive_scan(count, (long long)ncell, tsum, start, st))) return rc;
     coverage_scatter_kernel<<<grid, 256, 0, st>>>(sp, cell_of, slot_of, start, m_out, sorted);
     if ((rc = nbp_launch_status())) return rc;
     coverage_query_kernel<<<(unsigned)nbp_cdiv((long long)G * 16, 256), 256, 0, st>>>(gt3, G, g, threshold, sorted, start,

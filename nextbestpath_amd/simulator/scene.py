@@ -2,8 +2,8 @@
 cloud.  Mirrors (for the NBP path only) macarons/utility/CustomDataset.py:313-361 (SceneDataset),
 macarons/utility/macarons_utils.py:2152-2190 (Settings), :554-572 (load_scene), :612-637 +
 macarons/utility/utils.py:1301-1455 (area-weighted GT surface sampling) and the resolution
-thinning of Scene.fill_cells (:2952-3036).  Setup-time code: runs once per start pose on the
-host (numpy); the per-step work is all in libnbp_hip.so."""
+Scene / Cell point store (:2952-3234, :3512-3539).  The surface sampler is setup-time host numpy (once per
+start pose, as in the reference); the store and everything per step is in libnbp_hip.so."""
 from __future__ import annotations
 
 import json
@@ -83,34 +83,159 @@ def load_scene(mesh_path, scene_scale_factor, device):
 
 
 def face_areas(verts, faces):
-    a, b, c = verts[faces[:, 0]].astype(np.float64), verts[faces[:, 1]].astype(np.float64), verts[faces[:, 2]].astype(
-        np.float64)
-    return 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    """compute_mesh_face_area (macarons/utility/utils.py:1301-1330): Heron's formula in the reference's factored
+    form, fp32."""
+    fc = np.asarray(verts, f32)[np.asarray(faces)]
+
+    def norm(d):
+        return np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=f32)
+
+    a, b, c = norm(fc[:, 0] - fc[:, 1]), norm(fc[:, 1] - fc[:, 2]), norm(fc[:, 2] - fc[:, 0])
+    p = (a + b + c) / f32(2)
+    if np.any(p <= 0):
+        return np.sqrt(np.maximum(p * (p - a) * (p - b) * (p - c), f32(0)), dtype=f32)
+    res = ((p - a) / p) * ((p - b) / p) * ((p - c) / p)
+    return (np.sqrt(np.maximum(res, f32(0)), dtype=f32) * (p * p)).astype(f32)
 
 
-def sample_gt_surface(verts, faces, n_points, x_min, x_max, resolution, seed=0):
-    """GT surface cloud: area-weighted triangle choice + uniform barycentric point (utils.py:1332-1439),
-    restricted to faces whose vertices lie inside the scene box (mu:625-626), then thinned so that no
-    two kept points share a voxel of size `resolution` (stands in for Cell.fill's cdist thinning,
-    mu:3000-3028; same target density, deterministic)."""
-    rng = np.random.default_rng(seed)
-    inside = np.all((verts >= x_min) & (verts <= x_max), axis=1)
-    fsel = faces[inside[faces].all(1)]
+def sample_gt_surface(verts, faces, n_points, x_min, x_max, seed=0, uniforms=None):
+    """get_scene_gt_surface (mu:612-637) + sample_points_on_mesh_surface (macarons/utility/utils.py:1332-1455):
+    faces with all three vertices inside the scene box (inclusive), a face per draw with probability ~ its area
+    (first index whose cumulative probability reaches the uniform), a uniform point on it
+    (o + alpha a + beta b, (alpha, beta) reflected into the triangle).  No thinning: that is the scene store's
+    business (Cell.fill does none on an empty cell, mu:3016).  The reference draws from torch's global generator;
+    here the three uniform vectors come from `seed` (or are passed in: tests replay the reference's stream)."""
+    verts = np.asarray(verts, f32)
+    inside = np.all((verts >= np.asarray(x_min, f32)) & (verts <= np.asarray(x_max, f32)), axis=1)
+    fsel = np.asarray(faces)[inside[np.asarray(faces)].all(1)]
     if len(fsel) == 0:
         return np.zeros((0, 3), f32)
+    if uniforms is None:
+        rng = np.random.default_rng(seed)
+        uniforms = tuple(rng.random(n_points, dtype=f32) for _ in range(3))
+    u_face, al, be = (np.asarray(u, f32).copy() for u in uniforms)
     area = face_areas(verts, fsel)
-    pick = rng.choice(len(fsel), size=n_points, p=area / area.sum())
-    tri = verts[fsel[pick]].astype(np.float64)
+    cum = np.cumsum(area / area.sum(dtype=f32), dtype=f32)
+    pick = np.searchsorted(cum, u_face, side="left")
+    pick = np.where(pick >= len(cum), 0, pick)               # every gap negative -> the reference's argmin returns 0
+    tri = verts[fsel[pick]]
     o, a, b = tri[:, 2], tri[:, 0] - tri[:, 2], tri[:, 1] - tri[:, 2]
-    al, be = rng.random(n_points), rng.random(n_points)
-    flip = al + be > 1.0
-    al[flip], be[flip] = 1.0 - al[flip], 1.0 - be[flip]
-    pts = (o + al[:, None] * a + be[:, None] * b).astype(f32)
-    if resolution and resolution > 0:
-        vox = np.floor((pts - x_min) / f32(resolution)).astype(np.int64)
-        _, first = np.unique(vox, axis=0, return_index=True)
-        pts = pts[np.sort(first)]
-    return pts
+    flip = al + be > f32(1)
+    al[flip], be[flip] = f32(1) - al[flip], f32(1) - be[flip]
+    return (o + al[:, None] * a + be[:, None] * b).astype(f32)
+
+
+class Scene:
+    """Device-resident point store with the semantics of the reference's Scene / Cell (mu:2952-3234, 3512-3539):
+    a grid of cells over [x_min, x_max], each holding up to `capacity` points; fill_cells thins incoming points at the
+    cell resolution against what the cell already holds (never on its first fill) and caps by a random subset;
+    scene_coverage compares two stores cell by cell.  The cells are ONE [n_cells, capacity, 3] tensor + counts; every
+    operation is a kernel sequence of libnbp_hip.so (csrc/nbp_scene.hip) without a host sync.  Also carries the proxy
+    point state of the depth-map carving (mu:3239-3249, 3329-3363).  Point features (colours) are not stored."""
+
+    def __init__(self, x_min, x_max, grid_l, grid_w, grid_h, cell_capacity, cell_resolution, n_proxy_points, device,
+                 score_threshold=1.0, seed=0):
+        self.x_min, self.x_max = np.asarray(x_min, f32).copy(), np.asarray(x_max, f32).copy()
+        self.grid_l, self.grid_w, self.grid_h = int(grid_l), int(grid_w), int(grid_h)
+        self.device, self.seed, self.n_fills = device, int(seed), 0
+        d = self.x_max - self.x_min
+        self.l, self.w, self.h = d[0] / f32(self.grid_l), d[1] / f32(self.grid_w), d[2] / f32(self.grid_h)
+        # Cell.__init__ (mu:2962-2990): the missing one of (capacity, resolution) follows from the cell's largest face
+        l, w, h = self.l, self.w, self.h
+        area = max(float(l * np.sqrt(w * w + h * h, dtype=f32)), float(w * np.sqrt(h * h + l * l, dtype=f32)),
+                   float(h * np.sqrt(l * l + w * w, dtype=f32)))
+        if cell_resolution is None:
+            if cell_capacity is None:
+                raise NameError("Please choose a capacity or a resolution.")
+            cell_resolution = 2 * np.sqrt(area / cell_capacity / np.pi)
+        elif cell_capacity is None:
+            cell_capacity = int(area // (np.pi * (cell_resolution / 2.0) ** 2))
+        self.cell_capacity, self.cell_resolution = int(cell_capacity), float(cell_resolution)
+        self.n_cells = self.grid_l * self.grid_w * self.grid_h
+        self.cell_pts = torch.zeros(self.n_cells, self.cell_capacity, 3, dtype=torch.float32, device=device)
+        self.cell_count = torch.zeros(self.n_cells, dtype=torch.int32, device=device)
+        self.n_proxy_points, self.score_threshold = int(n_proxy_points), float(score_threshold)
+        self.proxy_points = None
+        n_per_cell = self.n_proxy_points / self.n_cells
+        vol = float(self.l * self.w * self.h) / max(n_per_cell, 1e-30)
+        self.distance_between_proxy_points = 2 * np.power(3 * vol / (4 * np.pi), 1.0 / 3.0)
+
+    # ---- geometry handed to the kernels
+    def box6(self):
+        return np.concatenate([self.x_min, self.x_max]).astype(f32)
+
+    def grid3(self):
+        return np.array([self.grid_l, self.grid_w, self.grid_h], np.int32)
+
+    def cell_keys(self):
+        return [(i, j, k) for i in range(self.grid_l) for j in range(self.grid_w) for k in range(self.grid_h)]
+
+    # ---- Scene.fill_cells / empty_cells / return_entire_pt_cloud
+    def fill_cells(self, pts, features=None, n_point_min=0, n_dev=None):
+        from ..utility import hipops
+        if features is not None:
+            raise NotImplementedError("point features (colours) are not carried by the device store")
+        if pts.shape[0] == 0:
+            return
+        self.n_fills += 1
+        hipops.scene_fill_cells(self, pts.contiguous(), n_point_min, seed=self.seed + 7919 * self.n_fills, n_dev=n_dev)
+
+    def empty_cells(self):
+        self.cell_count.zero_()
+
+    def return_entire_pt_cloud(self, return_features=False):
+        from ..utility import hipops
+        return hipops.scene_gather(self)
+
+    def cell_points(self, key):
+        """Host-side view of one cell (tests / inspection; one device sync)."""
+        i, j, k = key
+        c = (i * self.grid_w + j) * self.grid_h + k
+        return self.cell_pts[c, :int(self.cell_count[c].item())]
+
+    def scene_coverage(self, recovered_scene, surface_epsilon=None):
+        """mu:3512-3539 -> (coverage, n_gt_pts); coverage is 0.0 when nothing matches (one device sync, like
+        the reference's .item())."""
+        from ..utility import hipops
+        eps = 2.0 * self.cell_resolution if surface_epsilon is None else float(surface_epsilon)
+        covered, n_gt = hipops.scene_coverage(self, recovered_scene, eps).tolist()
+        return (covered / n_gt if n_gt else 0.0), n_gt
+
+    # ---- proxy points of the depth-map carving
+    def sample_in_box(self, n_sample, generator=None):
+        u = torch.rand(n_sample, 3, generator=generator).to(self.device)
+        return torch.from_numpy(self.x_min).to(self.device) + torch.from_numpy(self.x_max - self.x_min).to(self.device) * u
+
+    def initialize_proxy_points(self, n_proxy_points=None, default_proba_value=0.5):
+        n = self.n_proxy_points if n_proxy_points is None else int(n_proxy_points)
+        dev = self.device
+        self.proxy_points = self.sample_in_box(n, torch.Generator().manual_seed(self.seed)).contiguous()
+        self.proxy_proba = torch.full((n, 1), default_proba_value, device=dev)
+        self.proxy_supervision_occ = torch.ones(n, 1, device=dev)
+        self.out_of_field = torch.ones(n, 1, device=dev)
+        self.proxy_n_inside_fov = torch.zeros(n, 1, device=dev)
+        self.proxy_n_behind_depth = torch.zeros(n, 1, device=dev)
+
+    def carve(self, depth, cam12_host, zfar, fov_range, tol):
+        """One depth frame: Camera.get_points_in_fov + get_signed_distance_to_depth_maps (mu:2849-2949) +
+        update_proxy_supervision_occ + update_proxy_out_of_field (mu:3329-3363), one fused launch."""
+        from ..utility import hipops
+        hipops.carve_update(self.proxy_points, depth, None, cam12_host, zfar, fov_range, tol, self.score_threshold,
+                            self.proxy_n_inside_fov, self.proxy_n_behind_depth, self.proxy_supervision_occ,
+                            self.out_of_field)
+
+
+def setup_gt_scene(params, settings, mesh, device, test_resolution=0.05, seed=0, n_points=None):
+    """setup_test_scene's gt_scene (macarons/testers/scene.py:139-177): a Scene over the scene box grown by 0.2 with
+    the surface-cell capacity and resolution test_resolution * scale, filled ONCE with n_gt_surface_points samples of
+    the mesh surface -> (gt_scene, gt_scene_pc [G,3] device)."""
+    gt_scene = Scene(settings.scene.x_min - f32(0.2), settings.scene.x_max + f32(0.2), settings.scene.grid_l,
+                     settings.scene.grid_w, settings.scene.grid_h, params.surface_cell_capacity,
+                     test_resolution * params.scene_scale_factor, params.n_proxy_points, device, seed=seed)
+    pts = sample_gt_surface(mesh.verts_host, mesh.faces_host, n_points or params.n_gt_surface_points, gt_scene.x_min,
+                            gt_scene.x_max, seed=seed)
+    gt_scene.fill_cells(torch.from_numpy(pts).to(device))
+    return gt_scene, gt_scene.return_entire_pt_cloud()
 
 
 def y_bins_for(verts_host, n_pieces=4):

@@ -296,10 +296,7 @@ def build_rollout(params, nbp, dataset, run, device, test_resolution=0.05, state
     mesh = sim_scene.load_scene(os.path.join(dataset.data_path, sd["scene_name"], sd["obj_name"]),
                                 params.scene_scale_factor, device)
     y_bins = sim_scene.y_bins_for(mesh.verts_host, 4)
-    gt = sim_scene.sample_gt_surface(mesh.verts_host, mesh.faces_host, params.n_gt_surface_points,
-                                     settings.scene.x_min - np.float32(0.2), settings.scene.x_max + np.float32(0.2),
-                                     test_resolution * params.scene_scale_factor, seed=seed)
-    gt_dev = torch.from_numpy(gt).to(device)
+    _, gt_dev = sim_scene.setup_gt_scene(params, settings, mesh, device, test_resolution, seed=seed)
     camera = setup_test_camera(params, mesh, settings.camera.start_positions[k], settings, device, seed=seed)
     ro = Rollout(params, nbp, camera, gt_dev, mesh, mesh, y_bins, device, state, seed, grid)
     ro.scene_name, ro.start = sd["scene_name"], k

@@ -174,6 +174,52 @@ def carve_update(proxy_pts, depth, mask, cam12_host, zfar, fov_range, tol, score
     _lib.check(rc, "nbp_carve_update_f32")
 
 
+def _scene_geom(scene):
+    import numpy as np
+    box = np.ascontiguousarray(scene.box6(), np.float32)
+    grid = np.ascontiguousarray(scene.grid3(), np.int32)
+    return box, grid, box.ctypes.data_as(C.POINTER(C.c_float)), grid.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def scene_fill_cells(scene, pts, n_point_min=0, seed=0, n_dev=None):
+    """Scene.fill_cells on the device store of `scene` (simulator/scene.py::Scene); pts [n,3] fp32 device."""
+    L = _lib.lib()
+    box, grid, bp, gp = _scene_geom(scene)
+    n = pts.shape[0]
+    ws = _workspace("scene_fill", L.nbp_scene_fill_workspace_bytes(bp, gp, scene.cell_capacity, n, scene.cell_resolution),
+                    pts.device)
+    rc = L.nbp_scene_fill_cells_f32(_lib.ptr(pts), n, _lib.ptr(n_dev), bp, gp, scene.cell_capacity,
+                                    float(scene.cell_resolution), int(n_point_min), int(seed) & 0xFFFFFFFF,
+                                    _lib.ptr(scene.cell_pts), _lib.ptr(scene.cell_count), _lib.ptr(ws), ws.numel(), _st())
+    _lib.check(rc, "nbp_scene_fill_cells_f32")
+
+
+def scene_gather(scene):
+    """Scene.return_entire_pt_cloud -> [G,3] device tensor (one sync to size the result)."""
+    cap_total = scene.n_cells * scene.cell_capacity
+    out = torch.empty(cap_total, 3, dtype=torch.float32, device=scene.cell_pts.device)
+    n_out = torch.zeros(1, dtype=torch.int64, device=out.device)
+    rc = _lib.lib().nbp_scene_gather_f32(_lib.ptr(scene.cell_pts), _lib.ptr(scene.cell_count), scene.n_cells,
+                                         scene.cell_capacity, _lib.ptr(out), cap_total, _lib.ptr(n_out), _st())
+    _lib.check(rc, "nbp_scene_gather_f32")
+    return out[:int(n_out.item())].clone()
+
+
+def scene_coverage(gt_scene, rec_scene, epsilon, out=None):
+    """-> int32 [2] device: (covered GT points, stored GT points)."""
+    L = _lib.lib()
+    box, grid, bp, gp = _scene_geom(gt_scene)
+    if out is None:
+        out = torch.empty(2, dtype=torch.int32, device=gt_scene.cell_pts.device)
+    ws = _workspace("scene_cov", L.nbp_scene_coverage_workspace_bytes(bp, gp, rec_scene.cell_capacity, float(epsilon)),
+                    out.device)
+    rc = L.nbp_scene_coverage_f32(_lib.ptr(gt_scene.cell_pts), _lib.ptr(gt_scene.cell_count), gt_scene.cell_capacity,
+                                  _lib.ptr(rec_scene.cell_pts), _lib.ptr(rec_scene.cell_count), rec_scene.cell_capacity,
+                                  bp, gp, float(epsilon), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _st())
+    _lib.check(rc, "nbp_scene_coverage_f32")
+    return out
+
+
 def append_points(dst, offset, pts_host):
     """dst[offset:offset+n] = pts (n <= 8 host points, passed in the kernel arguments)."""
     import numpy as np

@@ -403,11 +403,9 @@ def trajectory_collection(params, current_epoch, dataset, db_env, pc2img_size, v
                                     params.scene_scale_factor, device)
         y_bins = sim_scene.y_bins_for(mesh.verts_host, 4)
         seed = 7919 * current_epoch + si
-        gt = sim_scene.sample_gt_surface(mesh.verts_host, mesh.faces_host, n_gt_points or params.n_gt_surface_points,
-                                         settings.scene.x_min - np.float32(0.2), settings.scene.x_max + np.float32(0.2),
-                                         0.05 * params.scene_scale_factor, seed=seed)
+        _, gt_dev = sim_scene.setup_gt_scene(params, settings, mesh, device, 0.05, seed=seed, n_points=n_gt_points)
         camera = setup_test_camera(params, mesh, settings.camera.start_positions[0], settings, device, seed=seed)
-        ro = CollectionRollout(params, nbp, camera, torch.from_numpy(gt).to(device), mesh, y_bins, device, db_env, seed,
+        ro = CollectionRollout(params, nbp, camera, gt_dev, mesh, y_bins, device, db_env, seed,
                                pc2img_size[0], value_map_size[0], prediction_range)
         ro.run(n_poses, coverage_after_trajectory)
         stored += ro.n_stored

@@ -306,10 +306,91 @@ def gen_replan(utils, ltu, mu):
     print("replan: candidates", len(rows), "paths", plens)
 
 
+def gen_scene(mu):
+    """GT surface store: compute_mesh_face_area / sample_mesh_triangle /
+    sample_points_on_mesh_faces (macarons/utility/utils.py:1301-1455), get_scene_gt_surface (macarons_utils.py:612-637),
+    Scene.get_cells_for_each_pt / fill_cells / return_entire_pt_cloud and Cell.fill (macarons_utils.py:2952-3234) run
+    UNMODIFIED on CPU tensors; the only shim is Tensor.get_device() -> 'cpu' (the reference passes its result to
+    .to(), which rejects the -1 a CPU tensor reports).  The uniform draws the reference consumed are recorded (same
+    seed, same shapes, same order) so that a restatement can be fed the identical stream."""
+    import macarons.utility.utils as mutils
+    from macarons.utility.CustomGeometry import get_cartesian_coords
+    from nextbestpath_amd.simulator.mesh import make_maze_mesh
+    orig_get_device = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda self: "cpu"
+    try:
+        dev = "cpu"
+        v, f = make_maze_mesh(seed=2, cells=3, size=18.0, height=6.0, wall=0.6, tess=3.0)
+        verts, faces = torch.from_numpy(v), torch.from_numpy(f.astype(np.int64))
+        x_min, x_max = torch.tensor([-9.0, 0.0, -9.0]) - 0.2, torch.tensor([9.0, 6.0, 9.0]) + 0.2
+        n_pts = 3000
+
+        def scene(capacity, resolution):
+            return mu.Scene(x_min=x_min, x_max=x_max, grid_l=3, grid_w=1, grid_h=3, cell_capacity=capacity,
+                            cell_resolution=resolution, n_proxy_points=900, device=dev, feature_dim=0)
+
+        sc = scene(2000, 0.5)
+        areas = mutils.compute_mesh_face_area(verts, faces)
+        torch.manual_seed(21)
+        gt = mu.get_scene_gt_surface(sc, verts, faces, n_pts)
+        # the draws get_scene_gt_surface consumed: sample_mesh_triangle (one batch: 1e7 / n_faces >= n_pts), alpha, beta
+        torch.manual_seed(21)
+        u_face = torch.rand(n_pts, 1)
+        u_alpha = torch.rand(n_pts, 1)
+        u_beta = torch.rand(n_pts, 1)
+        _, inside = sc.get_pts_in_bounding_box(verts, return_mask=True)
+        cells_of = sc.get_cells_for_each_pt(gt)
+        # --- first fill (empty cells: no thinning), second fill (fp64 cdist thinning at the resolution), capacity cap
+        torch.manual_seed(22)
+        sc.fill_cells(gt)
+        keys = list(sc.cells.keys())
+        first = [sc.cells[k].cell_pts.clone() for k in keys]
+        entire_first = sc.return_entire_pt_cloud(return_features=False)
+        extra = gt[:1200] + 0.37 * torch.randn(1200, 3, generator=torch.Generator().manual_seed(23))
+        sc.fill_cells(extra)
+        second = [sc.cells[k].cell_pts.clone() for k in keys]
+        capped = scene(150, 0.5)
+        torch.manual_seed(24)
+        capped.fill_cells(gt)
+        cap_pts = [capped.cells[k].cell_pts.clone() for k in keys]
+        auto = mu.Cell(center=torch.tensor([[0.0, 3.0, 0.0]]), l=torch.tensor(6.0), w=torch.tensor(6.4), h=torch.tensor(6.0),
+                       capacity=None, resolution=0.5, device=dev)          # capacity derived from the resolution
+        auto2 = mu.Cell(center=torch.tensor([[0.0, 3.0, 0.0]]), l=torch.tensor(6.0), w=torch.tensor(6.4), h=torch.tensor(6.0),
+                        capacity=500, resolution=None, device=dev)         # resolution derived from the capacity
+        # --- get_cartesian_coords (CustomGeometry.py:5-24) as get_camera_RT calls it (macarons_utils.py:949-952)
+        g = torch.Generator().manual_seed(25)
+        elev = (torch.rand(64, 1, generator=g) * 180 - 90)
+        azim = (torch.rand(64, 1, generator=g) * 720 - 360)
+        elev[:5, 0] = torch.tensor([-90.0, 90.0, 0.0, -60.0, 30.0])
+        azim[:5, 0] = torch.tensor([0.0, 45.0, 180.0, 315.0, 360.0])
+        rays = -get_cartesian_coords(r=torch.ones(64, 1), elev=-1 * elev, azim=180.0 + azim, in_degrees=True)
+
+        def pack(lst):
+            return np.concatenate([t.numpy() for t in lst], 0), np.array([len(t) for t in lst])
+
+        p1, n1 = pack(first); p2, n2 = pack(second); p3, n3 = pack(cap_pts)
+        np.savez_compressed(os.path.join(HERE, "scene.npz"), verts=v, faces=f, x_min=x_min.numpy(), x_max=x_max.numpy(),
+                            areas=areas.numpy(), inside=inside.numpy(), u_face=u_face.numpy()[:, 0],
+                            u_alpha=u_alpha.numpy()[:, 0], u_beta=u_beta.numpy()[:, 0], gt=gt.numpy(),
+                            cells_of=cells_of.numpy(), cell_keys=np.array([eval(k) for k in keys]),
+                            first_pts=p1, first_n=n1, entire_first=entire_first.numpy(), extra=extra.numpy(),
+                            second_pts=p2, second_n=n2, cap_pts=p3, cap_n=n3,
+                            auto_capacity=auto.capacity, auto_resolution=auto2.resolution,
+                            cart_elev=elev.numpy()[:, 0], cart_azim=azim.numpy()[:, 0], cart_rays=rays.numpy())
+        print("scene: gt", tuple(gt.shape), "first", n1.tolist(), "second", n2.tolist(), "capped", n3.tolist(),
+              "auto", auto.capacity, auto2.resolution)
+    finally:
+        torch.Tensor.get_device = orig_get_device
+
+
 if __name__ == "__main__":
     model, utils, ltu, mu = import_reference()
+    if "--only-scene" in sys.argv:
+        gen_scene(mu)
+        sys.exit(0)
     gen_maps(utils)
     gen_planner(ltu, mu)
     gen_replan(utils, ltu, mu)
+    gen_scene(mu)
     gen_network(model)
     gen_training(model)

@@ -86,8 +86,7 @@ def test_multi_rollout_matches_single(hip, dataset, nbp_weights):
         sd = ds[si]
         settings = sc.Settings(sd["settings"], params.scene_scale_factor)
         mesh = sc.load_scene(os.path.join(ds.data_path, sd["scene_name"], sd["obj_name"]), params.scene_scale_factor, dev)
-        gt = torch.from_numpy(sc.sample_gt_surface(mesh.verts_host, mesh.faces_host, 20000, settings.scene.x_min - 0.2,
-                                                   settings.scene.x_max + 0.2, 0.5, seed=1)).to(dev)
+        _, gt = sc.setup_gt_scene(params, settings, mesh, dev, 0.05, seed=1, n_points=20000)
         cam = tp.setup_test_camera(params, mesh, settings.camera.start_positions[0], settings, dev, seed=seed)
         return tp.Rollout(params, net, cam, gt, mesh, mesh, sc.y_bins_for(mesh.verts_host, 4), dev, seed=seed)
 

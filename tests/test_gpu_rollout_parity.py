@@ -88,11 +88,11 @@ def _both_rollouts(tmp, cells, size, tess, scene_seed, seed, n_gt=6000):
     net.load_state_dict(sd, strict=True)
     net = net.to(D).eval()
     y_bins = sc.y_bins_for(mesh.verts_host, 4)
-    gt = sc.sample_gt_surface(mesh.verts_host, mesh.faces_host, n_gt, settings.scene.x_min - np.float32(0.2),
-                              settings.scene.x_max + np.float32(0.2), 0.5, seed=1)
+    _, gt_dev = sc.setup_gt_scene(params, settings, mesh, torch.device(D), 0.05, seed=1, n_points=n_gt)
+    gt = gt_dev.cpu().numpy()
     start = settings.camera.start_positions[0]
     cam = tp.setup_test_camera(params, mesh, start, settings, torch.device(D), seed=seed)
-    hip_ro = tp.Rollout(params, net, cam, torch.from_numpy(gt).to(D), mesh, mesh, y_bins, torch.device(D), seed=seed)
+    hip_ro = tp.Rollout(params, net, cam, gt_dev, mesh, mesh, y_bins, torch.device(D), seed=seed)
     dims = (settings.camera.pose_l, settings.camera.pose_w, settings.camera.pose_h, settings.camera.pose_n_elev,
             settings.camera.pose_n_azim)
     ora = OracleRollout(sd, mesh.verts_host, mesh.faces_host, gt, y_bins.numpy(), settings.camera.x_min, dims, start,
