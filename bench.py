@@ -4,18 +4,25 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one exploration step of one rollout (S1-S14 of SURVEY.md section 3.1; BASELINE.json
-configs[1]: AiMDoom_simple-like scene, 256x256 grid, B=1, fp32): coverage of the cloud so far,
-un-projection of 5 depth frames (256x456) into the cloud, fused map accumulation, ONE NBP forward,
-replanning when the path is exhausted / blocked, 4 rasterised frames along the move.  The scene is
-a seeded procedural maze (no AiMDoom data offline), the NBP weights are seeded synthetic; mesh,
-weights and buffers are resident in HBM before the timed region.  Rollouts are independent
-(SURVEY.md 8e): N ranks run N rollouts on N scenes -> weak scaling, no data-path collective.
+`--gpus N` without a torchrun environment launches the N ranks itself (one process per GPU, RCCL).
 
-Rank 0 prints ONE JSON line.  `value` = exploration steps/s over all ranks; `nbp_maps_per_s` = NBP
-forwards/s (the second half of BASELINE.json's metric); `roofline` = the dominant kernel (fp32 MFMA
-implicit-GEMM convolution) timed live with HIP events on the launch stream; `roofline_scatter` =
-the HBM-bound map accumulation; `cpu_baseline` = the reference's arithmetic on the host cores.
+One "step" = one exploration step of one rollout (S1-S14 of SURVEY.md section 3.1; BASELINE.json configs[1]:
+AiMDoom_simple-like scene, 256x256 grid, fp32): coverage of the cloud so far, un-projection of 5 depth frames (256x456)
+into the cloud, fused map accumulation, ONE NBP forward, replanning when the path is exhausted / blocked, 4 rasterised
+frames along the move.  The scene is a seeded procedural maze (no AiMDoom data offline), the NBP weights are seeded
+synthetic; mesh, weights and buffers are resident in HBM before the timed region.  Rollouts are independent
+(SURVEY.md 8e): every rank runs `--rollouts-per-gpu` rollouts on its own scenes -> weak scaling, no data-path collective.
+
+The timed window sits in the MIDDLE of the 101-step trajectory: the rollouts are advanced un-timed to step `--advance`
+(default 40: the cloud then holds ~1.2 M of its final ~3 M points), then W warm-up steps, then exactly K timed steps;
+`stages.windows` also reports an early (steps 5-25) and a late (steps 80-100) window of the same rollouts.
+
+Rank 0 prints ONE JSON line.  `value` = exploration steps/s over all ranks; `nbp_maps_per_s` = NBP forwards/s (the second
+half of BASELINE.json's metric); `roofline` = the dominant kernel (fp32 MFMA halo-tile convolution) timed live with HIP
+events on the launch stream, its HBM-side traffic measured live with rocprofv3 PMC passes over the same forward
+(tools/pmc_workload.py; falls back to the committed profile); `roofline_scatter` = the HBM-bound map accumulation;
+`stages` = the other kernels of the step and the configs[2] train step / configs[4] bf16 forward;
+`cpu_baseline` = the same step (raster + un-projection + maps + network + coverage) on the host cores.
 """
 from __future__ import annotations
 
@@ -23,6 +30,9 @@ import argparse
 import ctypes as C
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -30,11 +40,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
+N_POSES = 101
 TILE_NAMES = {1: "igemm_conv_kernel<2,2,2,2>(128x128)", 2: "igemm_conv_kernel<4,1,2,2>(256x64)",
               3: "igemm_conv_kernel<4,1,2,1>(256x32)", 4: "igemm_conv_kernel<2,2,2,1>(128x64)",
               5: "igemm_conv_kernel<1,4,2,1>(64x128)", 6: "conv3x3_halo_f32_kernel<4,2>(8x32 px x 128 ch)",
@@ -45,14 +54,32 @@ TILE_NAMES = {1: "igemm_conv_kernel<2,2,2,2>(128x128)", 2: "igemm_conv_kernel<4,
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--advance", type=int, default=40, help="un-timed exploration steps before the warm-up (mid-trajectory window)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the rocprofv3 PMC passes (use the committed profile)")
+    ap.add_argument("--no-extra-stages", action="store_true", help="skip the train-step / bf16 / window stages (profiling runs)")
     ap.add_argument("--layers", action="store_true", help="per-layer timing table to stderr")
     ap.add_argument("--faces", choices=["simple", "hard"], default="simple")
     ap.add_argument("--rollouts-per-gpu", type=int, default=8,
                     help="independent rollouts stepped in lock-step per GPU (their NBP forwards are one batched launch)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks on this node and relay rank 0's JSON line."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("NBP_DIST_BACKEND", "nccl") == "nccl":      # gloo = smoke mode, ranks share GPUs
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def timed_layers(packed, x, out1, out2, ws):
@@ -67,26 +94,79 @@ def timed_layers(packed, x, out1, out2, ws):
             for a in arr[:n.value]]
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM-side bytes per launch of `kernel_prefix` from the committed rocprofv3 PMC passes over the same workload
-    (tools/profile.sh -> profiles/r01/forward_f32_pmc_summary.csv): 2*FETCH_SIZE + WRITE_SIZE (KB -> bytes; the
-    factor 2 is the gfx950 correction for 16-B-per-lane loads, MI355X_MICROARCH.md).  None if no profile."""
+# ---------------------------------------------------------------------------------------------- HBM-side traffic
+def _pmc_means(csv_dir):
+    """{kernel name -> {counter -> mean per dispatch}} from rocprofv3 counter_collection csv files under csv_dir."""
     import csv
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "forward_f32_pmc_summary.csv")
-    if not os.path.exists(path):
+    import glob
+    acc = {}
+    for path in glob.glob(os.path.join(csv_dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                cell = acc.setdefault(row["Kernel_Name"].replace("void ", ""), {}).setdefault(row["Counter_Name"], [0, 0.0])
+                cell[0] += 1
+                cell[1] += float(row["Counter_Value"])
+    return {k: {c: s / n for c, (n, s) in v.items()} for k, v in acc.items()}
+
+
+def live_traffic(n_points):
+    """Runs tools/pmc_workload.py (the B=8, 256x256 fp32 forward + the map accumulation over n_points) under rocprofv3 with
+    ONE counter per pass (FETCH_SIZE and WRITE_SIZE cannot share a pass, MI355X_MICROARCH.md) and returns
+    {kernel prefix -> bytes per launch} with the guide's gfx950 correction: 2 * FETCH_SIZE + WRITE_SIZE (KB -> B)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="nbp_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    means = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out, counter)
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+               os.path.join(ROOT, "tools", "pmc_workload.py"), "--points", str(n_points)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} timed out"
+        if r.returncode != 0:
+            return None, f"rocprofv3 --pmc {counter} failed: {r.stderr[-300:]}"
+        for k, v in _pmc_means(d).items():
+            means.setdefault(k, {}).update(v)
+    shutil.rmtree(out, ignore_errors=True)
+    res = {}
+    for k, v in means.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            res[k.replace(" ", "")] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+    return res, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/pmc_workload.py in this run"
+
+
+def committed_traffic(kernel_prefix, which):
+    """Fallback: the same quantity from the committed rocprofv3 summaries (profiles/r02, else r01)."""
+    import csv
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, which)
+        if not os.path.exists(path):
+            continue
+        vals = {}
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row["kernel"].replace(" ", "").replace("(anonymousnamespace)::", "").startswith(kernel_prefix):
+                    vals[row["counter"]] = float(row["mean_per_dispatch"])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, f"profiles/{rnd}/{which} (committed)"
+    return None, None
+
+
+def pick_traffic(live, prefix):
+    if not live:
         return None
-    want = kernel_prefix.replace(" ", "")
-    vals = {}
-    with open(path) as fh:
-        for row in csv.DictReader(fh):
-            if row["kernel"].replace(" ", "").startswith(want):
-                vals[row["counter"]] = float(row["mean_per_dispatch"])
-    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    for k, v in live.items():
+        if k.replace("(anonymousnamespace)::", "").startswith(prefix):
+            return v
+    return None
 
 
 def ev_time(fn, reps=20):
+    import torch
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fn()
     e0.record()
@@ -99,6 +179,10 @@ def ev_time(fn, reps=20):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,11 +234,17 @@ def main():
         cam = tp.setup_test_camera(params, mesh, settings.camera.start_positions[0], settings, dev, seed=rank)
         return tp.Rollout(params, net, cam, gt, mesh, mesh, y_bins, dev, seed=8 + 16 * rank + k)
 
-    # ---- single-rollout rate (B = 1 forward, latency-style) on a short separate run, reported beside `value`
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- single-rollout rate (B = 1 forward, latency-style), mid-trajectory like the headline, reported beside `value`
     single = None
-    if rank == 0:
+    if rank == 0 and not args.no_extra_stages:
         r1 = make_rollout(15)
-        for _ in range(5):
+        for _ in range(args.advance):
             r1.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -167,27 +257,48 @@ def main():
     multi = tp.MultiRollout(rollouts, net, dev)
     ro, cam, mesh, y_bins, gt = rollouts[0], rollouts[0].camera, rollouts[0].mesh, rollouts[0].y_bins, rollouts[0].gt
 
-    for _ in range(args.warmup):
-        multi.step()
-    multi.flush()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    def run_steps(n):
+        for _ in range(n):
+            multi.step()
+        multi.flush()                      # every rollout has completed exactly n more exploration steps
+
+    def timed_window(n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        run_steps(n)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
+
+    def cloud_points():
+        return int(sum(int(r.st.cloud_count.item()) for r in rollouts) / len(rollouts))
+
+    windows = {}
+    done = 0
+    adv = max(0, args.advance)
+    if adv >= 25 and not args.no_extra_stages:          # early window of the same rollouts (what round 1 timed)
+        run_steps(5)
+        dt_e = timed_window(20)
+        windows["early"] = {"steps": [5, 25], "steps_per_s": round(20 * R / dt_e, 2), "cloud_points_end": cloud_points()}
+        done = 25
+    run_steps(adv - done)
+    run_steps(args.warmup)
+    first_step = adv + args.warmup
+    n0 = cloud_points()
+    sync_all()
     replans0 = sum(r.n_replans for r in rollouts)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        multi.step()
-    multi.flush()                      # every rollout has completed exactly `steps` exploration steps
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    run_steps(args.steps)
+    sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    n1 = cloud_points()
+    replans_timed = sum(r.n_replans for r in rollouts) - replans0
+    last_step = first_step + args.steps
+    windows["timed"] = {"steps": [first_step, last_step], "steps_per_s": round(args.steps * R / dt, 2),
+                        "cloud_points_start": n0, "cloud_points_end": n1}
 
     roofline = scatter = None
     stage = {}
@@ -215,17 +326,30 @@ def main():
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         cf = sum(r["flops"] for r in layer_rows if r["tile"] > 0)
         cm = sum(r["ms"] for r in layer_rows if r["tile"] > 0)
+
         # algorithmic bytes of those launches: sources + packed weights + output, each once
         def layer_bytes(r):
             taps = 1 if ".W_g" in r["name"] else 9
             src = r["M"] * (r["K"] // taps) / (4 if ".up.1" in r["name"] else 1)     # fused x2 upsample reads H/2 x W/2
             return 4.0 * (src + r["K"] * r["N"] + r["M"] * r["N"]) * (2 if "{1,2}" in r["name"] else 1)
         alg_bytes = sum(layer_bytes(r) for r in layer_rows if r["tile"] == dom)
-        traffic = pmc_traffic(TILE_NAMES[dom].split("(")[0]) if (R, S) == (8, 256) else None
+        # ---- stage timings on the state the rollout reached
+        n_pts = int(ro.st.cloud_count.item())
+        pose, _ = cam.get_pose_from_idx(cam.cam_idx)
+        live, live_src = (None, "disabled (--no-live-traffic)")
+        if world == 1 and not args.no_live_traffic:
+            live, live_src = live_traffic(n_pts)
+        dom_prefix = TILE_NAMES[dom].split("(")[0].replace(" ", "")
+        traffic = pick_traffic(live, dom_prefix) if (R, S) == (8, 256) else None
+        traffic_src = live_src
+        if traffic is None and (R, S) == (8, 256):
+            traffic, src2 = committed_traffic(dom_prefix, "forward_f32_pmc_summary.csv")
+            traffic_src = f"{src2}; live pass: {live_src}" if src2 else live_src
         roofline = {"bound": "mfma", "kernel": TILE_NAMES[dom], "achieved": round(achieved, 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
-                    "profiles/r01/forward_f32_pmc_summary.csv, same B=8 S=256 forward)",
+                    "traffic": None if traffic is None else round(traffic),
+                    "traffic_unit": "HBM-side bytes per launch: 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide)",
+                    "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(alg_bytes / d["launches"]),
                     "launches_per_forward": d["launches"],
                     "avg_launch_ms": round(d["ms"] / d["launches"], 5), "flops_per_launch": d["flops"] / d["launches"],
@@ -237,113 +361,144 @@ def main():
                 tf = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0
                 print(f'{r["name"]:24s} M={r["M"]:7d} N={r["N"]:5d} K={r["K"]:5d} tile={r["tile"]:2d} '
                       f'sk={r["split_k"]:2d} {r["ms"]*1e3:9.1f} us {tf:7.2f} TF', file=sys.stderr)
-        # ---- stage timings on the state the rollout reached
-        n_pts = int(ro.st.cloud_count.item())
-        pose, _ = cam.get_pose_from_idx(cam.cam_idx)
         ms_fwd = ev_time(lambda: net(x))
         fl = L.nbp_forward_flops(R, S)
         x1 = x[:1].contiguous()
         ms_fwd1 = ev_time(lambda: net(x1))
         stage["nbp_forward_b1"] = {"ms": round(ms_fwd1, 4), "maps_per_s": round(1e3 / ms_fwd1, 2),
-                                   "tflops": round(L.nbp_forward_flops(1, S) / (ms_fwd1 * 1e-3) / 1e12, 3)}
+                                   "tflops": round(L.nbp_forward_flops(1, S) / (ms_fwd1 * 1e-3) / 1e12, 3),
+                                   "frac_of_f32_mfma_peak": round(L.nbp_forward_flops(1, S) / (ms_fwd1 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
         stage["nbp_forward"] = {"ms": round(ms_fwd, 4), "batch": R, "maps_per_s": round(R * 1e3 / ms_fwd, 2),
                                 "tflops": round(fl / (ms_fwd * 1e-3) / 1e12, 3),
                                 "frac_of_f32_mfma_peak": round(fl / (ms_fwd * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+        # map accumulation: the HBM-bound scatter.  Event pair on the launch stream around `reps` launches; bytes =
+        # 12 N (every point read once) + 24 S^2 (six channels written once)
         ms_sc = ev_time(lambda: hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=ro.st.cloud_count,
                                                         out=ro.st.maps6))
         alg = 12 * n_pts + 6 * S * S * 4
+        sc_traffic = pick_traffic(live, "map_accumulate_kernel")
+        sc_src = live_src
+        if sc_traffic is None:
+            sc_traffic, src2 = committed_traffic("map_accumulate_kernel", "pmc_summary.csv")
+            sc_src = f"{src2}; live pass: {live_src}" if src2 else live_src
         scatter = {"bound": "hbm", "kernel": "map_accumulate_kernel", "achieved": round(alg / (ms_sc * 1e-3) / 1e9, 1),
                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(alg / (ms_sc * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                   "traffic": None, "points": n_pts, "algorithmic_bytes": alg, "ms": round(ms_sc, 4)}
+                   "traffic": None if sc_traffic is None else round(sc_traffic), "traffic_source": sc_src,
+                   "points": n_pts, "algorithmic_bytes": alg, "ms": round(ms_sc, 4),
+                   "note": "ms includes the 1.5 MB clear of the six channels; at this size the launch floor (~3 us) is "
+                           "already 2x the HBM time of the bytes"}
+        # the same kernel on a full-length cloud (3 M points, the end of a 101-step trajectory)
+        big = ro.st.cloud[:n_pts].repeat((3_000_000 + n_pts - 1) // max(n_pts, 1), 1)[:3_000_000].contiguous()
+        maps_big = torch.empty_like(ro.st.maps6)
+        ms_big = ev_time(lambda: hu.accumulate_step_maps(big, pose, y_bins, S, (-40, 40), out=maps_big))
+        alg_big = 12 * big.shape[0] + 6 * S * S * 4
+        scatter["at_3M_points"] = {"ms": round(ms_big, 4), "achieved": round(alg_big / (ms_big * 1e-3) / 1e9, 1),
+                                   "frac": round(alg_big / (ms_big * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        del big, maps_big
         cams4 = np.stack([f[1] for f in cam.frames[-4:]])
-        zb = torch.empty(4, params.image_height, params.image_width, device=dev)
-        ms_r = ev_time(lambda: hipops.raster_zbuf(mesh.verts, mesh.faces, cams4, params.image_height, params.image_width,
-                                                  bin_cap=mesh.bin_cap, out=zb))
-        stage["raster_4_frames"] = {"ms": round(ms_r, 4), "faces": int(mesh.faces.shape[0]),
-                                    "frames_per_s": round(4e3 / ms_r, 1)}
+        H_, W_ = params.image_height, params.image_width
+        zb = torch.empty(4, H_, W_, device=dev)
+        ms_r = ev_time(lambda: hipops.raster_zbuf(mesh.verts, mesh.faces, cams4, H_, W_, bin_cap=mesh.bin_cap, out=zb))
+        F_ = int(mesh.faces.shape[0])
+        rb = 4 * (36 * F_ + 4 * H_ * W_)
+        stage["raster_4_frames"] = {"ms": round(ms_r, 4), "faces": F_, "frames_per_s": round(4e3 / ms_r, 1),
+                                    "lower_bound_bytes": rb, "gbs_vs_lower_bound": round(rb / (ms_r * 1e-3) / 1e9, 2),
+                                    "note": "compute-bound (ray/triangle tests per tile); no roofline claim (SURVEY 8d)"}
         scratch = torch.zeros(200_000, 3, device=dev)
         cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 
         def unproj():
             cnt.zero_()
             hipops.unproject_append(zb, None, cams4, scratch, cnt, 0.05, 70.0, seed=1)
-        stage["unproject_4_frames"] = {"ms": round(ev_time(unproj), 4)}
+        ms_u = ev_time(unproj)
+        ub = 4 * (5 * H_ * W_) + 12 * int(cnt.item())
+        stage["unproject_4_frames"] = {"ms": round(ms_u, 4), "algorithmic_bytes": ub,
+                                       "gbs": round(ub / (ms_u * 1e-3) / 1e9, 2), "note": "launch-bound (4 small kernels)"}
         bbox = (gt.min(0).values.tolist(), gt.max(0).values.tolist())
         out = torch.zeros(2, dtype=torch.int32, device=dev)
-        stage["coverage"] = {"ms": round(ev_time(lambda: hipops.coverage_count(gt, ro.st.cloud, n_dev=ro.st.cloud_count,
-                                                                                n=ro.st.cloud.shape[0], bbox=bbox,
-                                                                                out=out)), 4),
-                             "gt_points": int(gt.shape[0])}
-        # BASELINE configs[4] forward (reported beside the headline, not part of `value`): 8 maps of 512x512
-        # through the bf16 network; fraction of the dense bf16 MFMA peak (2.5 PFLOP/s)
-        sd16 = {k: v.detach().clone() for k, v in net.state_dict().items()}
-        pk16 = packing.pack_state_dict(sd16, dev, bf16=True)
-        x5 = torch.zeros(8, 5, 512, 512, device=dev)
-        x5[:, :, 128:384, 128:384] = x[:1].expand(8, -1, -1, -1) if S == 256 else 0.0
-        ms16 = ev_time(lambda: packing.forward_packed(pk16, x5), reps=10)
-        fl16 = L.nbp_forward_flops(8, 512)
-        stage["config5_forward_bf16_512_b8"] = {"ms": round(ms16, 4), "maps_per_s": round(8e3 / ms16, 2),
-                                                "tflops": round(fl16 / (ms16 * 1e-3) / 1e12, 2),
-                                                "frac_of_bf16_mfma_peak": round(fl16 / (ms16 * 1e-3) / 1e12 / 2500.0, 4)}
-        pk16.free()
-        del x5, pk16
-        stage["replans_in_timed_region"] = sum(r.n_replans for r in rollouts) - replans0
-        stage["single_rollout_steps_per_s"] = round(single, 2)
+        ms_c = ev_time(lambda: hipops.coverage_count(gt, ro.st.cloud, n_dev=ro.st.cloud_count, n=ro.st.cloud.shape[0],
+                                                     bbox=bbox, out=out))
+        G_ = int(gt.shape[0])
+        M_ = min(n_pts, 2 * G_)
+        stage["coverage"] = {"ms": round(ms_c, 4), "gt_points": G_, "cloud_sample": M_,
+                             "algorithmic_bytes": 12 * (G_ + M_), "gbs": round(12 * (G_ + M_) / (ms_c * 1e-3) / 1e9, 2),
+                             "equivalent_pair_tests_per_s": round(G_ * M_ / (ms_c * 1e-3)),
+                             "note": "grid search instead of the reference's G x 2G cdist; launch/latency-bound"}
+        if not args.no_extra_stages:
+            # ---- late window of the same rollouts (steps 80-100: ~2.4-3 M points per cloud)
+            if last_step <= 80:
+                run_steps(80 - last_step)
+                dt_l = timed_window(20)
+                windows["late"] = {"steps": [80, 100], "steps_per_s": round(20 * R / dt_l, 2),
+                                   "cloud_points_end": cloud_points()}
+            # ---- BASELINE configs[4] forward (reported beside the headline, not part of `value`): 8 maps of 512x512
+            # through the bf16 network; fraction of the dense bf16 MFMA peak (2.5 PFLOP/s)
+            sd16 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+            pk16 = packing.pack_state_dict(sd16, dev, bf16=True)
+            x5 = torch.zeros(8, 5, 512, 512, device=dev)
+            x5[:, :, 128:384, 128:384] = x[:1].expand(8, -1, -1, -1) if S == 256 else 0.0
+            ms16 = ev_time(lambda: packing.forward_packed(pk16, x5), reps=10)
+            fl16 = L.nbp_forward_flops(8, 512)
+            stage["config5_forward_bf16_512_b8"] = {"ms": round(ms16, 4), "maps_per_s": round(8e3 / ms16, 2),
+                                                    "tflops": round(fl16 / (ms16 * 1e-3) / 1e12, 2),
+                                                    "frac_of_bf16_mfma_peak": round(fl16 / (ms16 * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
+            pk16.free()
+            del x5, pk16
+            # ---- BASELINE configs[2]: one training step (fwd + bwd + AdamW) on 32 maps of 256x256, fp32
+            try:
+                from nextbestpath_amd.networks import training as tr
+                from nextbestpath_amd.trainers.train_nbp_model import _collate, make_synthetic_experiences
+                torch.manual_seed(9)
+                tnet = NBP().to(dev).train()
+                opt = torch.optim.AdamW(tnet.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+                xs, gtl, coords, gains, bidx = _collate(make_synthetic_experiences(32, 256, seed=3), dev)
+
+                def train_step():
+                    a1, a2 = tnet(xs)
+                    loss = tnet.loss(tr.gather_values(a1, bidx, coords), gains, a2, gtl)
+                    loss.backward()
+                    opt.step()
+                    opt.zero_grad(set_to_none=True)
+                for _ in range(2):
+                    train_step()
+                torch.cuda.synchronize()
+                tt0 = time.perf_counter()
+                for _ in range(3):
+                    train_step()
+                torch.cuda.synchronize()
+                tdt = (time.perf_counter() - tt0) / 3
+                stage["config3_train_step_b32"] = {"ms": round(tdt * 1e3, 2), "maps_per_s": round(32 / tdt, 2),
+                                                   "tflops": round(32 * 546.9e9 / tdt / 1e12, 2),
+                                                   "frac_of_f32_mfma_peak": round(32 * 546.9e9 / tdt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                                   "flop_per_map": 546.9e9}
+                del tnet, opt, xs, gtl
+                torch.cuda.empty_cache()
+            except Exception as e:                      # the headline must not depend on the training stage
+                stage["config3_train_step_b32"] = {"error": repr(e)[:200]}
+        stage["replans_in_timed_region"] = replans_timed
+        if single is not None:
+            stage["single_rollout_steps_per_s"] = round(single, 2)
+        stage["windows"] = windows
+        stage["raster_spilled_tiles"] = int(sum(int(r.camera._overflow.item()) for r in rollouts))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import maps as omaps
-        from oracle import nbp_net
-        from oracle import planner as opl
-        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        xc = multi.net_in[0][:1].cpu()
-        best = None
-        with torch.no_grad():
-            for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
-                torch.set_num_threads(nt)
-                nbp_net.nbp_forward(sd, xc)
-                t0c = time.perf_counter()
-                nbp_net.nbp_forward(sd, xc)
-                tt = time.perf_counter() - t0c
-                if best is None or tt < best[1]:
-                    best = (nt, tt)
-            cores = best[0]
-            torch.set_num_threads(cores)
-            n_it, t0c = 0, time.perf_counter()
-            while time.perf_counter() - t0c < 8.0 and n_it < 50:
-                nbp_net.nbp_forward(sd, xc)
-                n_it += 1
-            cpu_fwd = (time.perf_counter() - t0c) / n_it
-        n_pts = int(ro.st.cloud_count.item())
-        sub = ro.st.cloud[:min(n_pts, 200_000)].cpu().numpy()
-        t0c = time.perf_counter()
-        omaps.accumulate_step_maps(sub, pose, y_bins.numpy(), S, (-40, 40))
-        cpu_map = (time.perf_counter() - t0c) * (n_pts / max(len(sub), 1))
-        gts = gt[:2000].cpu().numpy()
-        t0c = time.perf_counter()
-        opl.coverage(gts, ro.st.cloud[:min(n_pts, 100_000)].cpu().numpy())
-        cpu_cov = (time.perf_counter() - t0c) * (gt.shape[0] / 2000)
-        cpu = {"value": round(1.0 / (cpu_fwd + cpu_map + cpu_cov), 3), "unit": "steps/s", "cores": cores,
-               "kind": "port",
-               "sample": f"{n_it} NBP forwards at 256x256 B=1 with stock PyTorch CPU convs = the reference's own "
-                         f"arithmetic ({cores} threads, {cpu_fwd*1e3:.1f} ms each) + numpy map accumulation of "
-                         f"{len(sub)} points scaled to {n_pts} ({cpu_map*1e3:.1f} ms) + brute-force coverage of 2000 GT "
-                         f"points scaled to {gt.shape[0]} ({cpu_cov*1e3:.0f} ms); rendering/un-projection excluded "
-                         f"(PyTorch3D is not installable here), so this is an upper bound on the CPU step rate",
-               "nbp_maps_per_s": round(1.0 / cpu_fwd, 3)}
+        cpu = cpu_baseline(sd, multi, ro, cam, mesh, y_bins, gt, pose, params, S)
 
     if rank == 0:
         out = {
             "metric": "exploration steps/s (+ NBP maps/s) at 256x256", "value": round(args.steps * world * R / dt, 3),
             "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "note": f"ms_per_step is one lock-step step of {R} concurrent rollouts per GPU ({R} exploration steps)",
+            "note": f"ms_per_step is one lock-step step of {R} concurrent rollouts per GPU ({R} exploration steps); timed "
+                    f"window = steps {first_step}-{last_step} of the 101-step trajectory (clouds of {n0}-{n1} points)",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: AiMDoom_simple-like rollout (seeded procedural maze, "
                                    f"{int(mesh.faces.shape[0])} faces), 256x256 grid, {R} concurrent rollouts per GPU on "
                                    f"{R} scenes (NBP forwards batched), 5 depth frames of 256x456 per step per "
                                    "rollout, seeded synthetic NBP weights",
-                       "grid": S, "rollouts_per_gpu": R, "image": [params.image_height, params.image_width]},
+                       "grid": S, "rollouts_per_gpu": R, "image": [params.image_height, params.image_width],
+                       "window_steps": [first_step, last_step], "gt_points": int(gt.shape[0])},
             "nbp_maps_per_s": round(world * stage["nbp_forward"]["maps_per_s"], 2),
             "stages": stage, "roofline": roofline, "roofline_scatter": scatter, "cpu_baseline": cpu,
         }
@@ -351,6 +506,78 @@ def main():
     if dist is not None:
         dist.barrier()                  # keep every rank alive until rank 0 has printed
         dist.destroy_process_group()
+
+
+def cpu_baseline(sd, multi, ro, cam, mesh, y_bins, gt, pose, params, S):
+    """The same exploration step on the host cores, bounded to ~20-30 s: the rasteriser, un-projection and coverage are
+    the C restatements of oracle/csrc (OpenMP where the loop allows), the network is stock PyTorch CPU convolutions on
+    the same weights (= the reference's own arithmetic), the map accumulation is oracle/maps.py (numpy)."""
+    import numpy as np
+    import torch
+    from oracle import camera as ocam
+    from oracle import csim
+    from oracle import maps as omaps
+    from oracle import nbp_net
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    xc = multi.net_in[0][:1].cpu()
+    best = None
+    with torch.no_grad():
+        for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
+            torch.set_num_threads(nt)
+            nbp_net.nbp_forward(sd, xc)
+            t0c = time.perf_counter()
+            nbp_net.nbp_forward(sd, xc)
+            tt = time.perf_counter() - t0c
+            if best is None or tt < best[1]:
+                best = (nt, tt)
+        cores = best[0]
+        torch.set_num_threads(cores)
+        n_it, t0c = 0, time.perf_counter()
+        while time.perf_counter() - t0c < 6.0 and n_it < 50:
+            nbp_net.nbp_forward(sd, xc)
+            n_it += 1
+        cpu_fwd = (time.perf_counter() - t0c) / n_it
+    H_, W_ = params.image_height, params.image_width
+    verts, faces = mesh.verts_host, mesh.faces_host
+    # raster: the 4 frames of the last move (single thread: the face loop carries the z-buffer)
+    t0c = time.perf_counter()
+    zs = []
+    for _, cam12 in cam.frames[-4:]:
+        zs.append(csim.raster_zbuf(verts, faces, cam12[:9].reshape(3, 3), cam12[9:], H_, W_, ocam.TAN_HALF_FOV))
+    cpu_raster = time.perf_counter() - t0c
+    # un-projection + 5 % sub-sampling of 5 frames
+    t0c = time.perf_counter()
+    for k in range(5):
+        _, cam12 = cam.frames[-1 - (k % 4)]
+        ocam.partial_point_cloud(zs[k % 4], None, cam12[:9].reshape(3, 3), cam12[9:], 0.05, 70.0, seed=k)
+    cpu_unproj = time.perf_counter() - t0c
+    n_pts = int(ro.st.cloud_count.item())
+    cloud = ro.st.cloud[:n_pts].cpu().numpy()
+    t0c = time.perf_counter()
+    omaps.accumulate_step_maps(cloud, pose, y_bins.numpy(), S, (-40, 40))
+    cpu_map = time.perf_counter() - t0c
+    # coverage: G x 2G brute force like the reference's cdist; bounded by sub-sampling BOTH sides, scaled by the product
+    G = int(gt.shape[0])
+    M = min(n_pts, 2 * G)
+    gts = gt.cpu().numpy()
+    gs, ms_ = min(G, 12_000), min(M, 24_000)
+    t0c = time.perf_counter()
+    csim.coverage_count(gts[:gs], cloud[:ms_], 1.0, omp=True)
+    t_cov_s = time.perf_counter() - t0c
+    cpu_cov = t_cov_s * (G * M) / (gs * ms_)
+    total = cpu_fwd + cpu_raster + cpu_unproj + cpu_map + cpu_cov
+    return {"value": round(1.0 / total, 3), "unit": "steps/s", "cores": max(cores, avail), "kind": "port",
+            "threads_per_leg": {"nbp_forward": cores, "raster": 1, "unproject": 1, "map_accumulate": 1, "coverage": avail},
+            "sample": f"one exploration step at the rollout's current state ({n_pts} cloud points, {G} GT points): "
+                      f"{n_it} NBP forwards at 256x256 B=1 with stock PyTorch CPU convs ({cores} threads, {cpu_fwd*1e3:.0f} ms "
+                      f"each) + C raster of 4 frames, {len(faces)} faces (1 thread, {cpu_raster*1e3:.0f} ms) + numpy "
+                      f"un-projection of 5 frames ({cpu_unproj*1e3:.0f} ms) + numpy map accumulation of all {n_pts} points "
+                      f"({cpu_map*1e3:.0f} ms) + brute-force coverage {gs} x {ms_} pairs with OpenMP ({avail} threads, "
+                      f"{t_cov_s*1e3:.0f} ms) scaled by the pair count to {G} x {M} ({cpu_cov*1e3:.0f} ms)",
+            "legs_ms": {"nbp_forward": round(cpu_fwd * 1e3, 1), "raster": round(cpu_raster * 1e3, 1),
+                        "unproject": round(cpu_unproj * 1e3, 1), "map_accumulate": round(cpu_map * 1e3, 1),
+                        "coverage": round(cpu_cov * 1e3, 1)},
+            "nbp_maps_per_s": round(1.0 / cpu_fwd, 3)}
 
 
 if __name__ == "__main__":

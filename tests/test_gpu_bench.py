@@ -1,0 +1,38 @@
+"""GPU: bench.py's contract -- one JSON line with roofline + cpu_baseline objects, and `--gpus N` launching N ranks
+itself (here 2 ranks sharing the box's single GPU over gloo; RCCL needs one GPU per rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--advance", "2",
+                        "--rollouts-per-gpu", "2", "--no-live-traffic", "--no-extra-stages"] + extra,
+                       capture_output=True, text=True, timeout=1200, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line(hip):
+    d = _run([])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "steps/s" and d["value"] > 0
+    assert d["config"]["window_steps"] == [3, 6]
+    rf, sc, cpu = d["roofline"], d["roofline_scatter"], d["cpu_baseline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] <= 1 and rf["unit"] == "TFLOP/s"
+    assert sc["bound"] == "hbm" and 0 < sc["frac"] <= 1 and sc["unit"] == "GB/s"
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and set(cpu["legs_ms"]) == {"nbp_forward", "raster", "unproject",
+                                                                                 "map_accumulate", "coverage"}
+
+
+def test_bench_gpus_flag_launches_the_ranks(hip):
+    d = _run(["--gpus", "2", "--no-cpu-baseline"], env={"NBP_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 3 * 2 * 2 / (d["ms_per_step"] * 3e-3)) < 1e-3 * d["value"]

@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""The roofline workload alone, for rocprofv3 PMC passes (bench.py runs it under `rocprofv3 --pmc FETCH_SIZE` and
+`--pmc WRITE_SIZE`; tools/profile.sh under more counters): 2 forwards of 8 maps of 256x256 through the fp32 network --
+every launch of a conv kernel in this process belongs to that forward, so per-kernel means are per-launch figures on
+the basis of bench.py's roofline.achieved -- and 2 map accumulations over a wall-like cloud of --points points
+(y range of the mazes, so that all six channels are exercised)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nextbestpath_amd import _lib  # noqa: E402
+from nextbestpath_amd.networks import packing  # noqa: E402
+from nextbestpath_amd.utility import utils as hu  # noqa: E402
+from nextbestpath_amd.utility.synthetic import make_count_maps, make_nbp_state_dict, make_point_cloud  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=1_500_000)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--bf16", action="store_true")
+    a = ap.parse_args()
+    L = _lib.lib()
+    dev = torch.device("cuda")
+    packed = packing.pack_state_dict(make_nbp_state_dict(9), dev, bf16=a.bf16)
+    B, S = a.batch, a.size
+    x = make_count_maps(B, S, seed=1).to(dev)
+    o1 = torch.empty(B, 8, S // 4, S // 4, device=dev)
+    o2 = torch.empty(B, 1, S, S, device=dev)
+    nws = L.nbp_forward_workspace_bytes_bf16(B, S) if a.bf16 else L.nbp_forward_workspace_bytes(B, S)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    fwd = L.nbp_forward_bf16 if a.bf16 else L.nbp_forward_f32
+    for _ in range(2):
+        _lib.check(fwd(packed.handle, x.data_ptr(), B, S, o1.data_ptr(), o2.data_ptr(), ws.data_ptr(), ws.numel(),
+                       _lib.current_stream()), "forward")
+    if a.points > 0:
+        pc = make_point_cloud(a.points, seed=1, extent=32.0, y_range=(0.0, 12.0)).to(dev)
+        pose = np.array([1.0, 3.3, -2.0, 0, 0], np.float32)
+        ybins = torch.arange(0.5, 11.5 + 2.75, 2.75)
+        out = torch.empty(6, 256, 256, device=dev)
+        for _ in range(2):
+            hu.accumulate_step_maps(pc, pose, ybins, 256, (-40, 40), out=out)
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()
