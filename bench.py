@@ -416,14 +416,14 @@ def main():
                                        "gbs": round(ub / (ms_u * 1e-3) / 1e9, 2), "note": "launch-bound (4 small kernels)"}
         bbox = (gt.min(0).values.tolist(), gt.max(0).values.tolist())
         out = torch.zeros(2, dtype=torch.int32, device=dev)
-        ms_c = ev_time(lambda: hipops.coverage_count(gt, ro.st.cloud, n_dev=ro.st.cloud_count, n=ro.st.cloud.shape[0],
-                                                     bbox=bbox, out=out))
+        ms_c = ev_time(lambda: ro.cov_plan.count(ro.st.cloud, out, n_dev=ro.st.cloud_count, n=ro.st.cloud.shape[0], seed=1))
         G_ = int(gt.shape[0])
         M_ = min(n_pts, 2 * G_)
         stage["coverage"] = {"ms": round(ms_c, 4), "gt_points": G_, "cloud_sample": M_,
                              "algorithmic_bytes": 12 * (G_ + M_), "gbs": round(12 * (G_ + M_) / (ms_c * 1e-3) / 1e9, 2),
                              "equivalent_pair_tests_per_s": round(G_ * M_ / (ms_c * 1e-3)),
-                             "note": "grid search instead of the reference's G x 2G cdist; launch/latency-bound"}
+                             "note": "GT grid built once per rollout, one kernel per step over the sampled cloud points "
+                                     "(the reference: G x 2G cdist); launch/latency-bound"}
         if not args.no_extra_stages:
             # ---- late window of the same rollouts (steps 80-100: ~2.4-3 M points per cloud)
             if last_step <= 80:
@@ -542,13 +542,13 @@ def cpu_baseline(sd, multi, ro, cam, mesh, y_bins, gt, pose, params, S):
     # raster: the 4 frames of the last move (single thread: the face loop carries the z-buffer)
     t0c = time.perf_counter()
     zs = []
-    for _, cam12 in cam.frames[-4:]:
+    for _, cam12, _slot in cam.frames[-4:]:
         zs.append(csim.raster_zbuf(verts, faces, cam12[:9].reshape(3, 3), cam12[9:], H_, W_, ocam.TAN_HALF_FOV))
     cpu_raster = time.perf_counter() - t0c
     # un-projection + 5 % sub-sampling of 5 frames
     t0c = time.perf_counter()
     for k in range(5):
-        _, cam12 = cam.frames[-1 - (k % 4)]
+        _, cam12, _slot = cam.frames[-1 - (k % 4)]
         ocam.partial_point_cloud(zs[k % 4], None, cam12[:9].reshape(3, 3), cam12[9:], 0.05, 70.0, seed=k)
     cpu_unproj = time.perf_counter() - t0c
     n_pts = int(ro.st.cloud_count.item())

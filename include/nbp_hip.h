@@ -216,10 +216,9 @@ int nbp_unproject_append_f32(const float* depth, const unsigned char* mask_or_nu
 
 /* Camera.capture_image's depth output (mu:2743-2786): zbuf [n_frames,H,W] = view-space z of the
  * nearest face through each pixel centre (perspective-correct, faces clipped at z_clip), -1 where
- * no face.  Faces are binned into 8x8-pixel tiles with bin_cap list entries per tile.  No face is ever
- * dropped (the reference renders with max_faces_per_bin = 500000, macarons/testers/scene.py:440-446): a tile
- * whose bin overflows walks all faces of the frame instead (same result, slower) and
- * *overflow_flag (device int, caller zeroes it) counts such tiles so that the caller can raise bin_cap. */
+ * no face.  Faces are binned in two levels (8x8-pixel tiles inside 64x64-pixel coarse tiles) into lists with room for
+ * every face: no face is ever dropped (the reference renders with max_faces_per_bin = 500000,
+ * macarons/testers/scene.py:440-446).  bin_cap and overflow_flag are kept for ABI compatibility and ignored. */
 size_t nbp_raster_workspace_bytes(int n_faces, int n_frames, int H, int W, int bin_cap);
 int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* faces, int n_faces,
                         const float* cams12_host, int n_frames, int H, int W, float tan_half_fov,
@@ -312,6 +311,19 @@ int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3, long long 
                            const long long* N_dev_or_null, long long sample_k, unsigned seed,
                            float threshold, const float* bbox_lo_host, const float* bbox_hi_host,
                            int* count_out, int* m_out, void* ws, size_t ws_bytes, void* stream);
+/* The same count when the GT cloud is reused over many calls (one rollout): nbp_coverage_plan_build_f32 sorts gt into a
+ * grid once (plan = caller-owned device buffer of nbp_coverage_plan_bytes); nbp_coverage_count_planned_f32 then runs one
+ * kernel over the sampled cloud points.  It ADDS to *count_accum (caller zeroes it) and needs an `epoch` > 0 that differs
+ * between consecutive calls on the same plan (per-GT-point stamps instead of a clear). */
+size_t nbp_coverage_plan_bytes(const float* bbox_lo_host, const float* bbox_hi_host, float threshold, int G);
+size_t nbp_coverage_plan_workspace_bytes(const float* bbox_lo_host, const float* bbox_hi_host, float threshold, int G);
+int nbp_coverage_plan_build_f32(const float* gt3, int G, float threshold, const float* bbox_lo_host,
+                                const float* bbox_hi_host, void* plan, size_t plan_bytes, void* ws,
+                                size_t ws_bytes, void* stream);
+int nbp_coverage_count_planned_f32(void* plan, int G, float threshold, const float* bbox_lo_host,
+                                   const float* bbox_hi_host, const float* pc3, long long N,
+                                   const long long* N_dev_or_null, long long sample_k, unsigned seed,
+                                   unsigned epoch, int* count_accum, int* m_out, void* stream);
 
 /* ================================================================ A2-A3: training step
  * Kernels behind the autograd functions of nextbestpath_amd/networks/training.py, which replace

@@ -100,6 +100,11 @@ SIGNATURES["nbp_scene_fill_cells_f32"] = (_i, [_vp, _ll, _vp, _fpp, _ipp, _i, _d
 SIGNATURES["nbp_scene_gather_f32"] = (_i, [_vp, _vp, _i, _i, _vp, _ll, _vp, _vp])
 SIGNATURES["nbp_scene_coverage_workspace_bytes"] = (_sz, [_fpp, _ipp, _i, _d])
 SIGNATURES["nbp_scene_coverage_f32"] = (_i, [_vp, _vp, _i, _vp, _vp, _i, _fpp, _ipp, _d, _vp, _vp, _sz, _vp])
+SIGNATURES["nbp_coverage_plan_bytes"] = (_sz, [_fpp, _fpp, _f, _i])
+SIGNATURES["nbp_coverage_plan_workspace_bytes"] = (_sz, [_fpp, _fpp, _f, _i])
+SIGNATURES["nbp_coverage_plan_build_f32"] = (_i, [_vp, _i, _f, _fpp, _fpp, _vp, _sz, _vp, _sz, _vp])
+SIGNATURES["nbp_coverage_count_planned_f32"] = (_i, [_vp, _i, _f, _fpp, _fpp, _vp, _ll, _vp, _ll, C.c_uint, C.c_uint, _vp, _vp,
+                                                     _vp])
 SIGNATURES["nbp_slice_obstacle_f32"] = (_i, [_vp, _vp, _i, _f, _f, _f, _i, _f, _f, _f, _vp, _vp])
 
 _lock = threading.Lock()
@@ -156,6 +161,16 @@ def ptr(t) -> int:
     return t.data_ptr()
 
 
+_raw_stream = None
+
+
 def current_stream() -> int:
+    """Raw hipStream_t of torch's current stream on the current device (the fast private accessor: the public
+    torch.cuda.current_stream() builds a Stream object, ~9 us per call and ~25 calls per exploration step)."""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream

@@ -175,6 +175,71 @@ __global__ __launch_bounds__(256) void coverage_query_kernel(const float* __rest
     if ((threadIdx.x & 63) == 0 && fb) atomicAdd(count, __popcll(fb));
 }
 
+
+// ---- planned coverage: the GT cloud is static for a whole rollout, the reconstruction changes every step.  The GT points
+// are sorted into the grid ONCE (nbp_coverage_plan_build_f32); a step then runs ONE kernel over the sampled cloud points:
+// four lanes per cloud point walk the nine GT cell columns around it and stamp every GT point closer than the threshold
+// with the call's epoch (plain stores; a second tiny kernel tallies the stamps).  No per-step sort, no clears.
+__global__ __launch_bounds__(256) void points_bin_kernel(const float* __restrict__ pts, int n, Grid g, int* __restrict__ cell_of,
+                                                         int* __restrict__ slot_of, int* __restrict__ count) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c = grid_cell(g, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], nullptr);
+        cell_of[i] = c;
+        slot_of[i] = atomicAdd(&count[c], 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void points_scatter4_kernel(const float* __restrict__ pts, int n, const int* __restrict__ cell_of,
+                                                              const int* __restrict__ slot_of, const int* __restrict__ start,
+                                                              float4* __restrict__ sorted, unsigned* __restrict__ stamp) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        sorted[start[cell_of[i]] + slot_of[i]] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 0.f);
+        stamp[i] = 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void coverage_mark_kernel(const float* __restrict__ pc, const long long* __restrict__ n_dev,
+                                                            long long n_host, long long k, unsigned seed, Grid g, float thr,
+                                                            const float4* __restrict__ gt_sorted, const int* __restrict__ gt_start,
+                                                            unsigned* __restrict__ stamp, unsigned epoch,
+                                                            int* __restrict__ m_out) {
+    const long long N = n_dev ? *n_dev : n_host;
+    const long long M = N > k ? k : N;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *m_out = (int)M;
+    const unsigned bits = perm_bits((unsigned)N);
+    const int sub = threadIdx.x & 3;
+    for (long long j = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 2; j < M; j += ((long long)gridDim.x * blockDim.x) >> 2) {
+        const long long src = N > k ? (long long)perm_index((unsigned)j, (unsigned)N, bits, seed) : j;
+        const float x = pc[3 * src], y = pc[3 * src + 1], z = pc[3 * src + 2];
+        // unclamped cell: a cloud point outside the grid (= the GT box grown by thr) is farther than thr from every GT point
+        const float fi = floorf((x - g.lo[0]) * g.inv), fj = floorf((y - g.lo[1]) * g.inv), fk = floorf((z - g.lo[2]) * g.inv);
+        if (!(fi >= -1.f && fi <= (float)g.n[0] && fj >= -1.f && fj <= (float)g.n[1] && fk >= -1.f && fk <= (float)g.n[2])) continue;
+        const int ci = (int)fi, cj = (int)fj, ck = (int)fk;
+        const int d0 = max(ck - 1, 0), d1 = min(ck + 1, g.n[2] - 1);
+        if (d0 > d1) continue;
+        for (int col = sub; col < 9; col += 4) {
+            const int a = ci + col / 3 - 1, b = cj + col % 3 - 1;
+            if (a < 0 || a >= g.n[0] || b < 0 || b >= g.n[1]) continue;
+            const int base = (a * g.n[1] + b) * g.n[2];
+            const int hi = gt_start[base + d1 + 1];
+            for (int q = gt_start[base + d0]; q < hi; ++q) {
+                if (stamp[q] == epoch) continue;
+                const float4 t = gt_sorted[q];
+                const float ex = t.x - x, ey = t.y - y, ez = t.z - z;
+                if (sqrtf((ex * ex + ey * ey) + ez * ez) < thr) stamp[q] = epoch;     // plain store: every writer writes the
+            }                                                                          // same value (device-scope atomics run
+        }                                                                              // at ~5 G/s on this part: 30x slower)
+    }
+}
+
+__global__ __launch_bounds__(256) void coverage_tally_kernel(const unsigned* __restrict__ stamp, int G, unsigned epoch,
+                                                             int* __restrict__ count) {
+    int mine = 0;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < G; q += gridDim.x * blockDim.x) mine += stamp[q] == epoch ? 1 : 0;
+    for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+}
+
 }  // namespace
 
 extern "C" int nbp_fuse_obstacle_f32(const float* out2, const float* maps6, const float* traj, float threshold, int S,
@@ -267,5 +332,76 @@ extern "C" int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3,
     if ((rc = nbp_launch_status())) return rc;
     coverage_query_kernel<<<(unsigned)nbp_cdiv((long long)G * 16, 256), 256, 0, st>>>(gt3, G, g, threshold, sorted, start,
                                                                                     count_out);
+    return nbp_launch_status();
+}
+
+// ---- planned coverage (one GT grid per rollout)
+static void plan_carve(void* plan, size_t ncell, int G, int** start, float4** sorted, unsigned** stamp) {
+    char* p = (char*)(((uintptr_t)plan + 255) / 256 * 256);
+    *start = (int*)p; p += al256((ncell + 1) * 4);
+    *sorted = (float4*)p; p += al256((size_t)G * 16);
+    *stamp = (unsigned*)p;
+}
+
+extern "C" size_t nbp_coverage_plan_bytes(const float* bbox_lo_host, const float* bbox_hi_host, float threshold, int G) {
+    Grid g; size_t ncell;
+    if (!bbox_lo_host || !bbox_hi_host || !(threshold > 0) || G < 1) return 0;
+    if (coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell)) return 0;
+    return 256 + al256((ncell + 1) * 4) + al256((size_t)G * 16) + al256((size_t)G * 4);
+}
+
+extern "C" size_t nbp_coverage_plan_workspace_bytes(const float* bbox_lo_host, const float* bbox_hi_host, float threshold,
+                                                    int G) {
+    Grid g; size_t ncell;
+    if (!bbox_lo_host || !bbox_hi_host || !(threshold > 0) || G < 1) return 0;
+    if (coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell)) return 0;
+    return 256 + al256(ncell * 4) + al256((ncell / SCAN_TILE + 1) * 4) + 2 * al256((size_t)G * 4);
+}
+
+extern "C" int nbp_coverage_plan_build_f32(const float* gt3, int G, float threshold, const float* bbox_lo_host,
+                                           const float* bbox_hi_host, void* plan, size_t plan_bytes, void* ws, size_t ws_bytes,
+                                           void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!gt3 || !plan || !ws || !bbox_lo_host || !bbox_hi_host || G < 1 || !(threshold > 0), NBP_E_ARG);
+    Grid g; size_t ncell;
+    int rc = coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell);
+    if (rc) return rc;
+    NBP_RETURN_IF(plan_bytes < nbp_coverage_plan_bytes(bbox_lo_host, bbox_hi_host, threshold, G), NBP_E_WS);
+    NBP_RETURN_IF(ws_bytes < nbp_coverage_plan_workspace_bytes(bbox_lo_host, bbox_hi_host, threshold, G), NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    int* start; float4* sorted; unsigned* stamp;
+    plan_carve(plan, ncell, G, &start, &sorted, &stamp);
+    char* p = (char*)(((uintptr_t)ws + 255) / 256 * 256);
+    int* count = (int*)p; p += al256(ncell * 4);
+    int* tsum = (int*)p; p += al256((ncell / SCAN_TILE + 1) * 4);
+    int* cell_of = (int*)p; p += al256((size_t)G * 4);
+    int* slot_of = (int*)p;
+    hipError_t e = hipMemsetAsync(count, 0, ncell * 4, st);
+    if (e != hipSuccess) return (int)e;
+    const int grid = nbp_ew_grid(G, 256);
+    points_bin_kernel<<<grid, 256, 0, st>>>(gt3, G, g, cell_of, slot_of, count);
+    if ((rc = nbp_launch_status())) return rc;
+    if ((rc = grid_exclusive_scan(count, (long long)ncell, tsum, start, st))) return rc;
+    points_scatter4_kernel<<<grid, 256, 0, st>>>(gt3, G, cell_of, slot_of, start, sorted, stamp);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_coverage_count_planned_f32(void* plan, int G, float threshold, const float* bbox_lo_host,
+                                              const float* bbox_hi_host, const float* pc3, long long N,
+                                              const long long* N_dev_or_null, long long sample_k, unsigned seed,
+                                              unsigned epoch, int* count_accum, int* m_out, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!plan || !pc3 || !count_accum || !m_out || !bbox_lo_host || !bbox_hi_host, NBP_E_ARG);
+    NBP_RETURN_IF(G < 1 || N < 0 || sample_k < 1 || !(threshold > 0) || N > 0xffffffffll || epoch == 0, NBP_E_ARG);
+    Grid g; size_t ncell;
+    int rc = coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell);
+    if (rc) return rc;
+    int* start; float4* sorted; unsigned* stamp;
+    plan_carve(plan, ncell, G, &start, &sorted, &stamp);
+    const long long work = N_dev_or_null ? sample_k : (N < sample_k ? N : sample_k);
+    coverage_mark_kernel<<<nbp_ew_grid((work > 0 ? work : 1) * 4, 256), 256, 0, (hipStream_t)stream>>>(
+        pc3, N_dev_or_null, N, sample_k, seed, g, threshold, sorted, start, stamp, epoch, m_out);
+    if ((rc = nbp_launch_status())) return rc;
+    coverage_tally_kernel<<<(unsigned)(G < 16384 ? 1 : 16), 256, 0, (hipStream_t)stream>>>(stamp, G, epoch, count_accum);
     return nbp_launch_status();
 }

@@ -106,13 +106,98 @@ __global__ __launch_bounds__(256) void unproject_compact_kernel(const float* __r
     }
 }
 
+// K1 fast path (H*W a multiple of 4, 16-B aligned frames): 4096-pixel chunks, one 256-thread workgroup per chunk and frame,
+// 16 B per lane and load.  Pass a counts the valid pixels of every chunk; pass b recomputes the flags (the frame is L2
+// resident by then), ranks them inside the wave with three ballots over the per-lane counts (no barrier per 256 pixels as
+// in the generic kernels above), adds the [sub-chunk][wave] totals of the workgroup and the counts of the earlier chunks.
+constexpr int FAST_CHUNK = 4096;
+
+__device__ __forceinline__ unsigned quad_flags(const float4* __restrict__ d4, const uchar4* __restrict__ m4, int q, int nq,
+                                               float fov_range) {
+    if (q >= nq) return 0u;
+    const float4 z = d4[q];
+    if (m4) {
+        const uchar4 m = m4[q];
+        return (m.x != 0 && z.x < fov_range ? 1u : 0u) | (m.y != 0 && z.y < fov_range ? 2u : 0u) |
+               (m.z != 0 && z.z < fov_range ? 4u : 0u) | (m.w != 0 && z.w < fov_range ? 8u : 0u);
+    }
+    return (z.x > -1.f && z.x < fov_range ? 1u : 0u) | (z.y > -1.f && z.y < fov_range ? 2u : 0u) |
+           (z.z > -1.f && z.z < fov_range ? 4u : 0u) | (z.w > -1.f && z.w < fov_range ? 8u : 0u);
+}
+
+__global__ __launch_bounds__(256) void unproject_count4_kernel(const float* __restrict__ depth,
+                                                               const unsigned char* __restrict__ mask, int HW, int nblk,
+                                                               float fov_range, int* __restrict__ blk_count,
+                                                               int* __restrict__ done_ticket) {
+    __shared__ int wt[4];
+    const int f = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+    const float4* d4 = reinterpret_cast<const float4*>(depth + (size_t)f * HW);
+    const uchar4* m4 = mask ? reinterpret_cast<const uchar4*>(mask + (size_t)f * HW) : nullptr;
+    if (f == 0 && b == 0 && t == 0) *done_ticket = 0;      // ticket of the append kernel's "last block updates the size"
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c += __popc(quad_flags(d4, m4, b * 1024 + k * 256 + t, HW >> 2, fov_range));
+    for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
+    if ((t & 63) == 0) wt[t >> 6] = c;
+    __syncthreads();
+    if (t == 0) blk_count[f * nblk + b] = wt[0] + wt[1] + wt[2] + wt[3];
+}
+
+__global__ __launch_bounds__(256) void unproject_compact4_kernel(const float* __restrict__ depth,
+                                                                 const unsigned char* __restrict__ mask, int HW, int nblk,
+                                                                 float fov_range, double gather,
+                                                                 const int* __restrict__ blk_count, unsigned* __restrict__ list,
+                                                                 int* __restrict__ counts) {
+    __shared__ int tot[17];
+    __shared__ int base_s;
+    const int f = blockIdx.y, b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float4* d4 = reinterpret_cast<const float4*>(depth + (size_t)f * HW);
+    const uchar4* m4 = mask ? reinterpret_cast<const uchar4*>(mask + (size_t)f * HW) : nullptr;
+    unsigned* out = list + (size_t)f * HW;
+    unsigned fl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fl[k] = quad_flags(d4, m4, b * 1024 + k * 256 + t, HW >> 2, fov_range);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int rank[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = __popc(fl[k]);
+        const unsigned long long b0 = __ballot(n & 1), b1 = __ballot(n & 2), b2 = __ballot(n & 4);
+        rank[k] = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+        if (lane == 0) tot[k * 4 + wave] = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+    }
+    if (t == 0) {
+        int pre = 0, all = 0;
+        for (int k = 0; k < nblk; ++k) { const int v = blk_count[f * nblk + k]; all += v; if (k < b) pre += v; }
+        base_s = pre;
+        if (b == 0) {
+            counts[2 * f] = all;
+            counts[2 * f + 1] = (int)((double)all * gather);   // int(len(world_points) * gathering_factor)
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        int run = base_s;
+        for (int i = 0; i < 16; ++i) { const int v = tot[i]; tot[i] = run; run += v; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int pos = tot[k * 4 + wave] + rank[k];
+        const unsigned p0 = (unsigned)(b * 1024 + k * 256 + t) * 4u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (fl[k] & (1u << e)) out[pos++] = p0 + e;
+    }
+}
+
 // K2: gather the sub-sample and append it to the cloud at *cloud_count + sum of earlier frames.
 __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __restrict__ depth, CamSet cams,
                                                                int H, int W, float tanh_fov, unsigned seed,
                                                                const unsigned* __restrict__ list,
                                                                const int* __restrict__ counts, float* __restrict__ cloud,
-                                                               const long long* __restrict__ cloud_count,
-                                                               long long capacity) {
+                                                               long long* __restrict__ cloud_count,
+                                                               long long capacity, int n_frames, int* __restrict__ done_ticket) {
     const int f = blockIdx.y;
     const int HW = H * W;
     const int nvalid = counts[2 * f], nkeep = counts[2 * f + 1];
@@ -122,13 +207,28 @@ __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __re
     const unsigned sd = seed + 0x632BE5ABu * (unsigned)(f + 1);
     const Cam cam = cams.c[f];
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nkeep; j += gridDim.x * blockDim.x) {
-        if (base + j >= capacity) return;
+        if (base + j >= capacity) break;
         const unsigned pix = list[(size_t)f * HW + perm_index((unsigned)j, (unsigned)nvalid, bits, sd)];
         const int row = (int)(pix / (unsigned)W), col = (int)(pix - (unsigned)row * W);
         float o[3];
         unproject_pixel(row, col, depth[(size_t)f * HW + pix], H, W, tanh_fov, cam.R, cam.T, o);
         float* dst = cloud + (base + j) * 3;
         dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+    }
+    if (!done_ticket) return;
+    // The block that finishes last advances the cloud size: every block has read *cloud_count by then.
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(done_ticket, 1) == (int)(gridDim.x * gridDim.y) - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        long long n = *cloud_count;
+        for (int g = 0; g < n_frames; ++g) n += counts[2 * g + 1];
+        *cloud_count = n < capacity ? n : capacity;
+        *done_ticket = 0;
     }
 }
 
@@ -152,124 +252,158 @@ __device__ __forceinline__ void to_view(const float* p, const float* R, const fl
     o[2] = ((p[0] * R[2] + p[1] * R[5]) + p[2] * R[8]) + T[2];
 }
 
-// One thread per (face, frame): view transform, near-plane clip for the screen bbox (in tiles).
+// Two-level binning without capacity limits: fine tiles of 8x8 pixels (one wave), coarse tiles of 8x8 fine tiles.
+// raster_setup_kernel (one thread per face and frame) transforms the face, clips its screen box against the near plane and
+// appends (face id, fine-tile box) to the list of every coarse tile the box touches -- one wave-aggregated atomic per
+// wave and coarse tile; a coarse list has room for every face, so nothing is ever dropped (the reference renders with
+// max_faces_per_bin = 500000, macarons/testers/scene.py:440-446).  raster_tile_kernel: one wave per (fine tile, list
+// segment) scans its segment 64 entries at a time, ray-casts the faces whose box covers the tile and merges its 64 depths
+// into the z-buffer with atomicMin on the float bit pattern (positive floats order like unsigned ints), so a tile with
+// thousands of faces is shared by many waves instead of being one wave's tail.
+constexpr int COARSE = 8;              // fine tiles per coarse tile side
+constexpr int SEG = 4096;              // list entries per wave
+constexpr unsigned ZBUF_EMPTY = 0x7F7F7F7Fu;   // memset pattern, 3.39e38 as a float
+
+struct BinEntry { int face; unsigned box; };   // box = tx0 | tx1 << 8 | ty0 << 16 | ty1 << 24 (fine-tile coordinates)
+
 __global__ __launch_bounds__(256) void raster_setup_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
                                                            int n_faces, CamSet cams, int H, int W,
                                                            float tanh_fov, float zclip, FaceRec* __restrict__ recs,
-                                                           int4* __restrict__ tbox) {
+                                                           int ctiles_x, int ctiles_y, int* __restrict__ ccount,
+                                                           BinEntry* __restrict__ clist, unsigned* __restrict__ zbuf_bits) {
     const int fr = blockIdx.y;
     const int fi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (fi >= n_faces) return;
-    int4 box = make_int4(1, 0, 1, 0);                                            // empty (tx0 > tx1)
-    const Cam cam = cams.c[fr];
-    float v[3][3];
+    // z-buffer of this frame = "empty" (the tile kernel merges with atomicMin)
+    for (int p = fi; p < H * W; p += gridDim.x * blockDim.x) zbuf_bits[(size_t)fr * H * W + p] = ZBUF_EMPTY;
+    bool have = false;
+    int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
+    if (fi < n_faces) {
+        const Cam cam = cams.c[fr];
+        float v[3][3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) to_view(verts + 3 * (size_t)faces[3 * (size_t)fi + k], cam.R, cam.T, v[k]);
-    if (!(v[0][2] <= zclip && v[1][2] <= zclip && v[2][2] <= zclip)) {          // not entirely behind the clip plane
-        FaceRec r;
+        for (int k = 0; k < 3; ++k) to_view(verts + 3 * (size_t)faces[3 * (size_t)fi + k], cam.R, cam.T, v[k]);
+        if (!(v[0][2] <= zclip && v[1][2] <= zclip && v[2][2] <= zclip)) {          // not entirely behind the clip plane
+            FaceRec r;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { r.e1[c] = v[1][c] - v[0][c]; r.e2[c] = v[2][c] - v[0][c]; r.v0[c] = v[0][c]; }
-        // q = e1 x v0  (= (-v0) x e1),  tnum = e2 . q
-        r.q[0] = r.e1[1] * r.v0[2] - r.e1[2] * r.v0[1];
-        r.q[1] = r.e1[2] * r.v0[0] - r.e1[0] * r.v0[2];
-        r.q[2] = r.e1[0] * r.v0[1] - r.e1[1] * r.v0[0];
-        r.tnum = (r.e2[0] * r.q[0] + r.e2[1] * r.q[1]) + r.e2[2] * r.q[2];
-        r.pad[0] = r.pad[1] = r.pad[2] = 0.f;
-        // screen bbox of the part with z >= zclip (Sutherland-Hodgman against one plane)
-        const int s = H < W ? H : W;
-        float cmin = 1e30f, cmax = -1e30f, rmin = 1e30f, rmax = -1e30f;
-        auto emit = [&](float x, float y, float z) {
-            const float nx = x / (z * tanh_fov), ny = y / (z * tanh_fov);
-            const float col = ((float)W - (float)s * nx - 1.f) * 0.5f;   // ndc_x(col) = W/s - (2 col + 1)/s
-            const float row = ((float)H - (float)s * ny - 1.f) * 0.5f;
-            cmin = fminf(cmin, col); cmax = fmaxf(cmax, col); rmin = fminf(rmin, row); rmax = fmaxf(rmax, row);
-        };
+            for (int c = 0; c < 3; ++c) { r.e1[c] = v[1][c] - v[0][c]; r.e2[c] = v[2][c] - v[0][c]; r.v0[c] = v[0][c]; }
+            // q = e1 x v0  (= (-v0) x e1),  tnum = e2 . q
+            r.q[0] = r.e1[1] * r.v0[2] - r.e1[2] * r.v0[1];
+            r.q[1] = r.e1[2] * r.v0[0] - r.e1[0] * r.v0[2];
+            r.q[2] = r.e1[0] * r.v0[1] - r.e1[1] * r.v0[0];
+            r.tnum = (r.e2[0] * r.q[0] + r.e2[1] * r.q[1]) + r.e2[2] * r.q[2];
+            r.pad[0] = r.pad[1] = r.pad[2] = 0.f;
+            // screen bbox of the part with z >= zclip (Sutherland-Hodgman against one plane)
+            const int s = H < W ? H : W;
+            float cmin = 1e30f, cmax = -1e30f, rmin = 1e30f, rmax = -1e30f;
+            auto emit = [&](float x, float y, float z) {
+                const float nx = x / (z * tanh_fov), ny = y / (z * tanh_fov);
+                const float col = ((float)W - (float)s * nx - 1.f) * 0.5f;   // ndc_x(col) = W/s - (2 col + 1)/s
+                const float row = ((float)H - (float)s * ny - 1.f) * 0.5f;
+                cmin = fminf(cmin, col); cmax = fmaxf(cmax, col); rmin = fminf(rmin, row); rmax = fmaxf(rmax, row);
+            };
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float* a = v[k];
-            const float* b = v[(k + 1) % 3];
-            const bool ain = a[2] >= zclip, bin_ = b[2] >= zclip;
-            if (ain) emit(a[0], a[1], a[2]);
-            if (ain != bin_) {
-                const float t = (zclip - a[2]) / (b[2] - a[2]);
-                emit(a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), zclip);
+            for (int k = 0; k < 3; ++k) {
+                const float* a = v[k];
+                const float* b = v[(k + 1) % 3];
+                const bool ain = a[2] >= zclip, bin_ = b[2] >= zclip;
+                if (ain) emit(a[0], a[1], a[2]);
+                if (ain != bin_) {
+                    const float t = (zclip - a[2]) / (b[2] - a[2]);
+                    emit(a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), zclip);
+                }
             }
-        }
-        if (cmax >= cmin) {
-            int c0 = (int)floorf(fmaxf(cmin, -1e8f)) - 1, c1 = (int)ceilf(fminf(cmax, 1e8f)) + 1;
-            int r0 = (int)floorf(fmaxf(rmin, -1e8f)) - 1, r1 = (int)ceilf(fminf(rmax, 1e8f)) + 1;
-            c0 = max(c0, 0); r0 = max(r0, 0); c1 = min(c1, W - 1); r1 = min(r1, H - 1);
-            if (c0 <= c1 && r0 <= r1) {
-                recs[(size_t)fr * n_faces + fi] = r;
-                box = make_int4(c0 / TILE, c1 / TILE, r0 / TILE, r1 / TILE);
+            if (cmax >= cmin) {
+                int c0 = (int)floorf(fmaxf(cmin, -1e8f)) - 1, c1 = (int)ceilf(fminf(cmax, 1e8f)) + 1;
+                int r0 = (int)floorf(fmaxf(rmin, -1e8f)) - 1, r1 = (int)ceilf(fminf(rmax, 1e8f)) + 1;
+                c0 = max(c0, 0); r0 = max(r0, 0); c1 = min(c1, W - 1); r1 = min(r1, H - 1);
+                if (c0 <= c1 && r0 <= r1) {
+                    recs[(size_t)fr * n_faces + fi] = r;
+                    have = true;
+                    tx0 = c0 / TILE; tx1 = c1 / TILE; ty0 = r0 / TILE; ty1 = r1 / TILE;
+                }
             }
         }
     }
-    tbox[(size_t)fr * n_faces + fi] = box;
-}
-
-// One thread per (face, tile row, frame): appends the face to the tiles of that row of its bbox
-// (a big face no longer serialises ~2 k atomics in one thread).
-__global__ __launch_bounds__(256) void raster_bin_kernel(const int4* __restrict__ tbox, int n_faces, int tiles_x, int tiles_y,
-                                                         int bin_cap, int* __restrict__ tile_count,
-                                                         int* __restrict__ tile_list, int* __restrict__ overflow) {
-    const int fr = blockIdx.y;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)n_faces * tiles_y) return;
-    const int fi = (int)(t / tiles_y), ty = (int)(t - (long long)fi * tiles_y);
-    const int4 box = tbox[(size_t)fr * n_faces + fi];
-    if (box.x > box.y || ty < box.z || ty > box.w) return;
-    const int base = fr * tiles_x * tiles_y + ty * tiles_x;
-    for (int tx = box.x; tx <= box.y; ++tx) {
-        const int pos = atomicAdd(&tile_count[base + tx], 1);
-        if (pos < bin_cap) tile_list[(size_t)(base + tx) * bin_cap + pos] = fi;
-        else if (pos == bin_cap) atomicAdd(overflow, 1);      // number of spilled tiles (they fall back to a full face walk)
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const BinEntry e = {fi, (unsigned)tx0 | ((unsigned)tx1 << 8) | ((unsigned)ty0 << 16) | ((unsigned)ty1 << 24)};
+    const int nct = ctiles_x * ctiles_y;
+    // Up to 64 coarse tiles per pass: lane c first collects how many faces of this wave touch coarse tile c0 + c (ballots
+    // only), reserves that many list slots with ONE atomic -- all lanes' atomics are in flight together; a returning
+    // device-scope atomic per coarse tile in sequence was 10 us of pure latency -- then the entries are written.
+    for (int c0 = 0; c0 < nct; c0 += 64) {
+        const int npass = min(64, nct - c0);
+        int my_cnt = 0;
+        for (int c = 0; c < npass; ++c) {                                  // uniform loop: ballots need the whole wave
+            const int cx = (c0 + c) % ctiles_x, cy = (c0 + c) / ctiles_x;
+            const bool hit = have && tx0 <= cx * COARSE + COARSE - 1 && tx1 >= cx * COARSE && ty0 <= cy * COARSE + COARSE - 1 &&
+                             ty1 >= cy * COARSE;
+            const int n = __popcll(__ballot(hit));
+            if (lane == c) my_cnt = n;
+        }
+        int my_base = 0;
+        if (my_cnt > 0) my_base = atomicAdd(&ccount[fr * nct + c0 + lane], my_cnt);
+        for (int c = 0; c < npass; ++c) {
+            const int cx = (c0 + c) % ctiles_x, cy = (c0 + c) / ctiles_x;
+            const bool hit = have && tx0 <= cx * COARSE + COARSE - 1 && tx1 >= cx * COARSE && ty0 <= cy * COARSE + COARSE - 1 &&
+                             ty1 >= cy * COARSE;
+            const unsigned long long bal = __ballot(hit);
+            const int base = __shfl(my_base, c);
+            if (hit) clist[((size_t)fr * nct + c0 + c) * n_faces + base + __popcll(bal & lt)] = e;
+        }
     }
 }
 
-// One wave per 8x8 tile: faces staged 64 at a time through LDS, every lane ray-casts its pixel.
 __global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restrict__ recs, int n_faces, int H, int W,
-                                                         float tanh_fov, float zclip, int tiles_x, int tiles_y, int bin_cap,
-                                                         const int* __restrict__ tile_count, const int* __restrict__ tile_list,
-                                                         const int4* __restrict__ tbox, float* __restrict__ zbuf) {
+                                                         float tanh_fov, float zclip, int tiles_x, int tiles_y, int ctiles_x,
+                                                         int ctiles_y, const int* __restrict__ ccount,
+                                                         const BinEntry* __restrict__ clist, unsigned* __restrict__ zbuf_bits) {
+    __shared__ int hits[SEG];
     __shared__ __attribute__((aligned(16))) FaceRec sh[64];
     const int fr = blockIdx.y;
-    const int tile = blockIdx.x;
+    const int ntiles = tiles_x * tiles_y;
+    const int tile = blockIdx.x % ntiles, seg = blockIdx.x / ntiles;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int nct = ctiles_x * ctiles_y, ct = (ty / COARSE) * ctiles_x + tx / COARSE;
+    const int n = ccount[fr * nct + ct];
+    const int s0 = seg * SEG;
+    if (s0 >= n) return;
+    const int s1 = min(n, s0 + SEG);
     const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const BinEntry* lst = clist + ((size_t)fr * nct + ct) * n_faces;
+    // pass 1: the faces of this segment whose fine-tile box covers the tile (entry loads are independent: the compiler keeps
+    // several in flight), compacted into LDS
+    int nh = 0;
+#pragma unroll 4
+    for (int base = s0; base < s1; base += 64) {
+        bool in = false;
+        int face = 0;
+        if (base + lane < s1) {
+            const BinEntry e = lst[base + lane];
+            face = e.face;
+            in = tx >= (int)(e.box & 255u) && tx <= (int)((e.box >> 8) & 255u) && ty >= (int)((e.box >> 16) & 255u) &&
+                 ty <= (int)(e.box >> 24);
+        }
+        const unsigned long long bal = __ballot(in);
+        if (in) hits[nh + __popcll(bal & lt)] = face;
+        nh += __popcll(bal);
+    }
+    if (nh == 0) return;
     const int col = tx * TILE + (lane & 7), row = ty * TILE + (lane >> 3);
     const int s = H < W ? H : W;
     // pixel-centre ray in view space (PyTorch3D NDC: +X left, +Y up)
     const float ndc_x = ((float)W - (2.f * col + 1.f)) / (float)s;
     const float ndc_y = ((float)H - (2.f * row + 1.f)) / (float)s;
     const float dx = ndc_x * tanh_fov, dy = ndc_y * tanh_fov;   // dz = 1
-    const int t = fr * tiles_x * tiles_y + tile;
-    const int n_binned = tile_count[t];
-    // A bin that overflowed its capacity is NOT truncated (the reference's rasteriser never drops faces:
-    // max_faces_per_bin = 500000, macarons/testers/scene.py:440-446): the tile walks every face of the frame and
-    // keeps those whose tile box covers it -- same face set as an unbounded bin, only slower.
-    const bool spill = n_binned > bin_cap;
-    const int n = spill ? n_faces : n_binned;
-    const int* lst = tile_list + (size_t)t * bin_cap;
     const FaceRec* rb = recs + (size_t)fr * n_faces;
-    const int4* tb = tbox + (size_t)fr * n_faces;
     float zbest = 3.0e38f;
     const float eps = 1e-6f;
-    for (int base = 0; base < n; base += 64) {
-        int m = min(64, n - base);
+    // pass 2: 64 face records at a time through LDS (one gather round trip per 64 faces), every lane ray-casts its pixel
+    for (int hb = 0; hb < nh; hb += 64) {
+        const int m = min(64, nh - hb);
         __syncthreads();
-        if (!spill) {
-            if (lane < m) sh[lane] = rb[lst[base + lane]];
-        } else {
-            bool in = false;
-            if (lane < m) {
-                const int4 bx = tb[base + lane];
-                in = bx.x <= bx.y && tx >= bx.x && tx <= bx.y && ty >= bx.z && ty <= bx.w;
-            }
-            const unsigned long long bal = __ballot(in);
-            if (in) sh[__popcll(bal & ((1ull << lane) - 1ull))] = rb[base + lane];
-            m = __popcll(bal);
-        }
+        if (lane < m) sh[lane] = rb[hits[hb + lane]];
         __syncthreads();
         for (int k = 0; k < m; ++k) {
             const FaceRec& f = sh[k];
@@ -286,7 +420,12 @@ __global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restri
             if (u >= -eps && vv >= -eps && u + vv <= 1.f + eps && z > zclip && z < zbest) zbest = z;
         }
     }
-    if (row < H && col < W) zbuf[((size_t)fr * H + row) * W + col] = zbest < 1.0e38f ? zbest : -1.f;
+    if (row < H && col < W && zbest < 1.0e38f) atomicMin(&zbuf_bits[((size_t)fr * H + row) * W + col], __float_as_uint(zbest));
+}
+
+__global__ __launch_bounds__(256) void raster_finalize_kernel(float* __restrict__ zbuf, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        if (!(zbuf[i] < 1.0e38f)) zbuf[i] = -1.f;
 }
 
 // ------------------------------------------------------------------ ray / mesh tests (world space)
@@ -424,33 +563,46 @@ extern "C" int nbp_unproject_append_f32(const float* depth, const unsigned char*
     NBP_RETURN_IF(nblk > 4096, NBP_E_SHAPE);
     int* blk_count = (int*)(((uintptr_t)ws + 255) / 256 * 256);
     unsigned* list = (unsigned*)((char*)blk_count + ((size_t)n_frames * nblk * sizeof(int) + 255) / 256 * 256);
-    dim3 gc((unsigned)nblk, (unsigned)n_frames);
-    unproject_count_kernel<<<gc, 256, 0, st>>>(depth, mask_or_null, HW, nblk, fov_range, blk_count);
-    int rc = nbp_launch_status();
-    if (rc) return rc;
-    unproject_compact_kernel<<<gc, 256, 0, st>>>(depth, mask_or_null, HW, nblk, fov_range, gathering_factor, blk_count,
-                                                 list, counts2);
-    rc = nbp_launch_status();
-    if (rc) return rc;
     const CamSet cams = camset_from_host(cams12_host, n_frames);   // [F][12]: R row-major (9) then T (3)
     const int max_keep = (int)((double)H * W * gathering_factor) + 1;
     dim3 grid((unsigned)nbp_cdiv(max_keep, 256), (unsigned)n_frames);
-    unproject_append_kernel<<<grid, 256, 0, st>>>(depth, cams, H, W, tan_half_fov, seed, list, counts2, cloud,
-                                                  cloud_count, capacity);
-    rc = nbp_launch_status();
-    if (rc) return rc;
+    int rc;
+    const bool fast = (HW & 3) == 0 && ((uintptr_t)depth & 15) == 0 && (!mask_or_null || ((uintptr_t)mask_or_null & 3) == 0);
+    if (fast) {
+        // three launches: chunk counts (also resets the ticket), ordered compaction, gather + append + size update
+        const int nb4 = (int)nbp_cdiv(HW, FAST_CHUNK);             // <= nblk: the workspace is sized for 2048-pixel chunks
+        int* ticket = blk_count + (size_t)n_frames * nb4;
+        dim3 g4((unsigned)nb4, (unsigned)n_frames);
+        unproject_count4_kernel<<<g4, 256, 0, st>>>(depth, mask_or_null, HW, nb4, fov_range, blk_count, ticket);
+        if ((rc = nbp_launch_status())) return rc;
+        unproject_compact4_kernel<<<g4, 256, 0, st>>>(depth, mask_or_null, HW, nb4, fov_range, gathering_factor, blk_count, list,
+                                                      counts2);
+        if ((rc = nbp_launch_status())) return rc;
+        unproject_append_kernel<<<grid, 256, 0, st>>>(depth, cams, H, W, tan_half_fov, seed, list, counts2, cloud, cloud_count,
+                                                      capacity, n_frames, ticket);
+        return nbp_launch_status();
+    }
+    dim3 gc((unsigned)nblk, (unsigned)n_frames);
+    unproject_count_kernel<<<gc, 256, 0, st>>>(depth, mask_or_null, HW, nblk, fov_range, blk_count);
+    if ((rc = nbp_launch_status())) return rc;
+    unproject_compact_kernel<<<gc, 256, 0, st>>>(depth, mask_or_null, HW, nblk, fov_range, gathering_factor, blk_count,
+                                                 list, counts2);
+    if ((rc = nbp_launch_status())) return rc;
+    unproject_append_kernel<<<grid, 256, 0, st>>>(depth, cams, H, W, tan_half_fov, seed, list, counts2, cloud, cloud_count,
+                                                  capacity, n_frames, nullptr);
+    if ((rc = nbp_launch_status())) return rc;
     cloud_count_update_kernel<<<1, 64, 0, st>>>(counts2, n_frames, cloud_count, capacity);
     return nbp_launch_status();
 }
 
 extern "C" size_t nbp_raster_workspace_bytes(int n_faces, int n_frames, int H, int W, int bin_cap) {
-    if (n_faces < 1 || n_frames < 1 || H < 1 || W < 1 || bin_cap < 1) return 0;
-    const size_t tiles = (size_t)nbp_cdiv(W, TILE) * nbp_cdiv(H, TILE) * n_frames;
+    (void)bin_cap;
+    if (n_faces < 1 || n_frames < 1 || H < 1 || W < 1) return 0;
+    const size_t nct = (size_t)nbp_cdiv(nbp_cdiv(W, TILE), COARSE) * nbp_cdiv(nbp_cdiv(H, TILE), COARSE) * n_frames;
     size_t b = 256;
     b += ((size_t)n_frames * n_faces * sizeof(FaceRec) + 255) / 256 * 256;
-    b += ((size_t)n_frames * n_faces * sizeof(int4) + 255) / 256 * 256;
-    b += (tiles * sizeof(int) + 255) / 256 * 256;
-    b += (tiles * bin_cap * sizeof(int) + 255) / 256 * 256;
+    b += (nct * sizeof(int) + 255) / 256 * 256;
+    b += (nct * n_faces * sizeof(BinEntry) + 255) / 256 * 256;
     return b + 256;
 }
 
@@ -458,31 +610,33 @@ extern "C" int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* f
                                    int n_frames, int H, int W, float tan_half_fov, float z_clip, int bin_cap, float* zbuf,
                                    int* overflow_flag, void* ws, size_t ws_bytes, void* stream) {
     NBP_ENTER();
-    NBP_RETURN_IF(!verts || !faces || !cams12_host || !zbuf || !overflow_flag || !ws, NBP_E_ARG);
-    NBP_RETURN_IF(n_verts < 3 || n_faces < 1 || n_frames < 1 || n_frames > MAX_CAMS || H < 1 || W < 1 || bin_cap < 64, NBP_E_ARG);
+    (void)bin_cap; (void)overflow_flag;                      // kept for ABI compatibility: the lists cannot overflow
+    NBP_RETURN_IF(!verts || !faces || !cams12_host || !zbuf || !ws, NBP_E_ARG);
+    NBP_RETURN_IF(n_verts < 3 || n_faces < 1 || n_frames < 1 || n_frames > MAX_CAMS || H < 1 || W < 1, NBP_E_ARG);
+    const int tiles_x = (int)nbp_cdiv(W, TILE), tiles_y = (int)nbp_cdiv(H, TILE);
+    NBP_RETURN_IF(tiles_x > 256 || tiles_y > 256, NBP_E_SHAPE);          // fine-tile coordinates are packed in 8 bits
     NBP_RETURN_IF(ws_bytes < nbp_raster_workspace_bytes(n_faces, n_frames, H, W, bin_cap), NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;
-    const int tiles_x = (int)nbp_cdiv(W, TILE), tiles_y = (int)nbp_cdiv(H, TILE);
-    const size_t tiles = (size_t)tiles_x * tiles_y * n_frames;
+    const int ctiles_x = (int)nbp_cdiv(tiles_x, COARSE), ctiles_y = (int)nbp_cdiv(tiles_y, COARSE);
+    const size_t nct = (size_t)ctiles_x * ctiles_y * n_frames;
     char* p = (char*)(((uintptr_t)ws + 255) / 256 * 256);
     FaceRec* recs = (FaceRec*)p; p += ((size_t)n_frames * n_faces * sizeof(FaceRec) + 255) / 256 * 256;
-    int4* tbox = (int4*)p; p += ((size_t)n_frames * n_faces * sizeof(int4) + 255) / 256 * 256;
-    int* tile_count = (int*)p; p += (tiles * sizeof(int) + 255) / 256 * 256;
-    int* tile_list = (int*)p;
-    hipError_t e = hipMemsetAsync(tile_count, 0, tiles * sizeof(int), st);
+    int* ccount = (int*)p; p += (nct * sizeof(int) + 255) / 256 * 256;
+    BinEntry* clist = (BinEntry*)p;
+    hipError_t e = hipMemsetAsync(ccount, 0, nct * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
     dim3 g1((unsigned)nbp_cdiv(n_faces, 256), (unsigned)n_frames);
     raster_setup_kernel<<<g1, 256, 0, st>>>(verts, faces, n_faces, camset_from_host(cams12_host, n_frames), H, W,
-                                            tan_half_fov, z_clip, recs, tbox);
+                                            tan_half_fov, z_clip, recs, ctiles_x, ctiles_y, ccount, clist, (unsigned*)zbuf);
     int rc = nbp_launch_status();
     if (rc) return rc;
-    dim3 gb((unsigned)nbp_cdiv((long long)n_faces * tiles_y, 256), (unsigned)n_frames);
-    raster_bin_kernel<<<gb, 256, 0, st>>>(tbox, n_faces, tiles_x, tiles_y, bin_cap, tile_count, tile_list, overflow_flag);
-    rc = nbp_launch_status();
-    if (rc) return rc;
-    dim3 g2((unsigned)(tiles_x * tiles_y), (unsigned)n_frames);
-    raster_tile_kernel<<<g2, 64, 0, st>>>(recs, n_faces, H, W, tan_half_fov, z_clip, tiles_x, tiles_y, bin_cap, tile_count,
-                                          tile_list, tbox, zbuf);
+    const int nseg = (int)nbp_cdiv(n_faces, SEG);
+    dim3 g2((unsigned)(tiles_x * tiles_y * nseg), (unsigned)n_frames);
+    raster_tile_kernel<<<g2, 64, 0, st>>>(recs, n_faces, H, W, tan_half_fov, z_clip, tiles_x, tiles_y, ctiles_x, ctiles_y,
+                                          ccount, clist, (unsigned*)zbuf);
+    if ((rc = nbp_launch_status())) return rc;
+    const long long npx = (long long)n_frames * H * W;
+    raster_finalize_kernel<<<nbp_ew_grid(npx, 256), 256, 0, st>>>(zbuf, npx);
     return nbp_launch_status();
 }
 

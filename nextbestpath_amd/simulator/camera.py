@@ -26,10 +26,12 @@ def _cartesian(elev_deg, azim_deg):
     return np.array([np.cos(e) * np.sin(a), np.sin(e), np.cos(e) * np.cos(a)])
 
 
-def camera_RT(X_cam, V_cam):
-    """get_camera_RT (mu:940-957): look from X_cam along -cartesian(1, -elev, 180 + azim).
-    pytorch3d convention: R columns = camera x / y / z axes (row vectors), T = -X R."""
-    X = np.asarray(X_cam, np.float64).reshape(3)
+_R_CACHE = {}
+
+
+def _look_rotation(V_cam):
+    """Rotation of get_camera_RT (mu:940-957): look along -cartesian(1, -elev, 180 + azim); float64.
+    pytorch3d convention: R columns = camera x / y / z axes (row vectors)."""
     z = -_cartesian(-float(V_cam[0]), 180.0 + float(V_cam[1]))
     z = z / max(np.linalg.norm(z), 1e-5)
     up = np.array([0.0, 1.0, 0.0])
@@ -42,8 +44,22 @@ def camera_RT(X_cam, V_cam):
     x = x / nx
     y = np.cross(z, x)
     y = y / max(np.linalg.norm(y), 1e-5)
-    R = np.stack([x, y, z], axis=1)
-    return R.astype(f32), (-(X @ R)).astype(f32)
+    return np.stack([x, y, z], axis=1)
+
+
+def camera_RT(X_cam, V_cam):
+    """get_camera_RT (mu:940-957): R as above, T = -X R.  The rotation depends on (elev, azim) only and the lattice has
+    a few dozen distinct view directions (8 azimuths x 4 interpolation steps): it is memoised (the numpy cross / norm
+    calls were 20 % of the host time of a step); the arithmetic is unchanged."""
+    key = (float(V_cam[0]), float(V_cam[1]))
+    hit = _R_CACHE.get(key)
+    if hit is None:
+        R64 = _look_rotation(V_cam)
+        hit = (R64, R64.astype(f32))
+        if len(_R_CACHE) < 4096:
+            _R_CACHE[key] = hit
+    X = np.asarray(X_cam, np.float64).reshape(3)
+    return hit[1], (-(X @ hit[0])).astype(f32)
 
 
 class Camera:
@@ -70,8 +86,9 @@ class Camera:
         self.R_cam = None
         self.T_cam = None
         self.cam_idx_history = []                       # list of 5-int tuples
-        self.X_cam_history = np.zeros((0, 3), f32)
-        self.V_cam_history = np.zeros((0, 2), f32)
+        self._X_hist, self._V_hist = [], []             # rows; X_cam_history / V_cam_history stack them on demand
+        self._hist_cache = None
+        self._pose_cache = {}
         self.visited = set()
         self.n_frames_captured = 0
         self.frames = []                                # last frames: (zbuf [H,W] device view, cam12 host row)
@@ -82,9 +99,29 @@ class Camera:
         self._overflow = torch.zeros(1, dtype=torch.int32, device=device)
 
     # ------------------------------------------------------------------ lattice
+    @property
+    def X_cam_history(self):
+        if self._hist_cache is None or self._hist_cache[0] != len(self._X_hist):
+            self._hist_cache = (len(self._X_hist), np.asarray(self._X_hist, f32).reshape(-1, 3),
+                                np.asarray(self._V_hist, f32).reshape(-1, 2))
+        return self._hist_cache[1]
+
+    @property
+    def V_cam_history(self):
+        _ = self.X_cam_history
+        return self._hist_cache[2]
+
     def pose_from_idx(self, idx):
         """5-D pose (x, y, z, elev, azim) of lattice index (i, j, k, e, a) -- fp32 like mu:2315-2320."""
-        i, j, k, e, a = (int(v) for v in idx)
+        idx = tuple(int(v) for v in idx)
+        hit = self._pose_cache.get(idx)
+        if hit is None:
+            hit = self._pose_from_idx(idx)
+            self._pose_cache[idx] = hit
+        return hit.copy()
+
+    def _pose_from_idx(self, idx):
+        i, j, k, e, a = idx
         x_min = self.x_min_arg
         return np.array([x_min[0] + f32(i * self.l_step), x_min[1] + f32(3.3), x_min[2] + f32(k * self.h_step),
                          f32(-90.0) + (f32(180.0) * f32(1 + e)) / f32(self.pose_n_elev + 1),
@@ -150,8 +187,8 @@ class Camera:
             self.cam_idx_history.append(new_idx)
             self.visited.add(new_idx)
         self.X_cam, self.V_cam = X, V
-        self.X_cam_history = np.vstack([self.X_cam_history, X[None]])
-        self.V_cam_history = np.vstack([self.V_cam_history, V[None]])
+        self._X_hist.append(X)
+        self._V_hist.append(V)
         self.R_cam, self.T_cam = camera_RT(X, V)
 
     def initialize_camera(self, start_cam_idx):
@@ -176,7 +213,7 @@ class Camera:
         hipops.raster_zbuf(mesh.verts, mesh.faces, cams_host, self.image_height, self.image_width, bin_cap=mesh.bin_cap,
                            out=out, overflow=self._overflow)
         for i in range(n):
-            self.frames.append((out[i], cams_host[i].copy()))
+            self.frames.append((out[i], cams_host[i].copy(), slot + i))
         self.frames = self.frames[-8:]
         self.n_frames_captured += n
         return out
@@ -197,19 +234,23 @@ class Camera:
         """Stacks frames by negative offsets (e.g. [-1] = current, [-5,-4,-3,-2] = supervision batch):
         (depth [n,H,W] device, cams [n,12] HOST -- cameras travel as kernel arguments)."""
         sel = [self.frames[w] for w in which]
-        z = sel[0][0].unsqueeze(0) if len(sel) == 1 else torch.stack([s[0] for s in sel])
-        return z.contiguous(), np.stack([s[1] for s in sel]).astype(f32)
+        slots = [s[2] for s in sel]
+        if all(b == a + 1 for a, b in zip(slots, slots[1:])):
+            z = self._zbuf_ring[slots[0]:slots[0] + len(slots)]          # consecutive ring slots: a view, no copy kernel
+        else:
+            z = torch.stack([s[0] for s in sel])
+        return z, np.stack([s[1] for s in sel]).astype(f32)
 
     def trajectory_points(self):
         """X_cam_history on the device (for the trajectory channel); new poses are appended by a kernel whose
         arguments carry the points, so there is no blocking host->device copy in the step loop."""
-        n = len(self.X_cam_history)
+        n = len(self._X_hist)
         if n > self._traj_dev.shape[0]:
             grown = torch.zeros(2 * n, 3, dtype=torch.float32, device=self.device)
             grown[:self._traj_n] = self._traj_dev[:self._traj_n]
             self._traj_dev = grown
         while self._traj_n < n:
             k = min(8, n - self._traj_n)
-            hipops.append_points(self._traj_dev, self._traj_n, self.X_cam_history[self._traj_n:self._traj_n + k])
+            hipops.append_points(self._traj_dev, self._traj_n, np.asarray(self._X_hist[self._traj_n:self._traj_n + k], f32))
             self._traj_n += k
         return self._traj_dev[:n]

@@ -81,6 +81,7 @@ class Rollout:
         self.planner = LatticePlanner(camera, mesh_for_check, device, self.V, self.S, self.grid_range, rng=self.rng)
         self.gt = gt_scene_pc.contiguous()
         self.bbox = (self.gt.min(0).values.tolist(), self.gt.max(0).values.tolist())
+        self.cov_plan = hipops.CoveragePlan(self.gt, 1.0, 2, self.bbox)          # GT sorted once per rollout
         self.path, self.path_record = [], 0
         self.collision_list, self.passable_list, self.idx_history = [], [], []
         self.step_seed = seed * 1_000_003
@@ -94,9 +95,8 @@ class Rollout:
         st, camera, params, pose_i = self.st, self.camera, self.params, self.pose_i
         S, grid_range = self.S, self.grid_range
         net_in = st.net_in if net_in is None else net_in
-        hipops.coverage_count(self.gt, st.cloud, n_dev=st.cloud_count, n=st.cloud.shape[0], weight=2,
-                              seed=self.step_seed + 7 * pose_i, threshold=1.0, bbox=self.bbox,
-                              out=st.coverage_counts[pose_i % N_POSES])
+        self.cov_plan.count(st.cloud, st.coverage_counts[pose_i % N_POSES], n_dev=st.cloud_count, n=st.cloud.shape[0],
+                            seed=self.step_seed + 7 * pose_i, out_is_zero=pose_i < N_POSES)
         depth, cams = camera.frames_batch([-1])
         hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
                                 params.sensor_range, seed=self.step_seed + 11 * pose_i)
@@ -183,37 +183,66 @@ class MultiRollout:
         per = (R + n_groups - 1) // n_groups
         self.groups = [self.rollouts[i:i + per] for i in range(0, R, per)]
         self.net_in = [torch.zeros(len(g), 5, grid, grid, dtype=torch.float32, device=device) for g in self.groups]
-        self.events = [torch.cuda.Event() for _ in self.groups]
         self.inflight = [False] * len(self.groups)
-        # everything a rollout owns is only ever touched on its group's stream
+        # Streams.  Default: one HIP stream per group carries the group's small kernels and its batched forward.
+        # NBP_ROLLOUT_STREAMS=1 gives every ROLLOUT its own (high-priority) stream for its ~20 small kernels per step,
+        # chained to the group's forward by events.  Measured on MI355X (8 rollouts, rocprofv3 kernel trace): the GPU is
+        # throughput-bound either way -- two B=4 forwards (11.5 ms) + the small kernels (~1.7 ms of whole-GPU time) per
+        # lock-step; the convolutions hold every CU's registers and LDS, so a small kernel that "overlaps" simply takes
+        # CUs away from them.  Per-rollout streams (8 more queues, more events) measured 525 steps/s against 605, 3 or 4
+        # groups 592 / 572, 16 rollouts per GPU 604.
         main = torch.cuda.current_stream(device)
-        if streams and len(self.groups) >= 2:
-            self.streams = [torch.cuda.Stream(device) for _ in self.groups]
-            for st in self.streams:
+        multi = streams and len(self.groups) >= 2
+        self.per_rollout = multi and os.environ.get("NBP_ROLLOUT_STREAMS", "0") == "1"
+        if multi:
+            self.fwd_streams = [torch.cuda.Stream(device) for _ in self.groups]
+            if self.per_rollout:
+                self.rstreams = [[torch.cuda.Stream(device, priority=int(os.environ.get('NBP_SMALL_PRIO', '-1'))) for _ in g] for g in self.groups]
+            else:
+                self.rstreams = [[self.fwd_streams[gi]] * len(g) for gi, g in enumerate(self.groups)]
+            for st in self.fwd_streams + [x for g in self.rstreams for x in g]:
                 st.wait_stream(main)          # the rollouts were built on the caller's stream
         else:
-            self.streams = [main for _ in self.groups]
+            self.fwd_streams = [main for _ in self.groups]
+            self.rstreams = [[main] * len(g) for g in self.groups]
+        self.streams = self.fwd_streams
+        self.ev_pre = [[torch.cuda.Event() for _ in g] for g in self.groups]
+        self.ev_plan = [[torch.cuda.Event() for _ in g] for g in self.groups]
+        self.ev_fwd = [torch.cuda.Event() for _ in self.groups]
 
     def _launch(self, gi):
-        grp, net_in = self.groups[gi], self.net_in[gi]
-        with torch.cuda.stream(self.streams[gi]):
-            for i, r in enumerate(grp):
+        grp, net_in, fwd = self.groups[gi], self.net_in[gi], self.fwd_streams[gi]
+        for i, r in enumerate(grp):
+            with torch.cuda.stream(self.rstreams[gi][i]):
                 r.pre(net_in[i:i + 1])
+                if self.per_rollout:
+                    self.ev_pre[gi][i].record()
+        with torch.cuda.stream(fwd):
+            if self.per_rollout:
+                for ev in self.ev_pre[gi]:
+                    fwd.wait_event(ev)
             with torch.no_grad():
                 out1, out2 = self.nbp(net_in)
-            for i, r in enumerate(grp):
+            if self.per_rollout:
+                self.ev_fwd[gi].record()
+        for i, r in enumerate(grp):
+            st = self.rstreams[gi][i]
+            with torch.cuda.stream(st):
+                if self.per_rollout:
+                    st.wait_event(self.ev_fwd[gi])     # also orders the next pre() after this forward's read of net_in
+                    if r.need_replan:
+                        out1.record_stream(st); out2.record_stream(st)
                 r.plan_enqueue(out1[i], out2[i])
-            self.events[gi].record()
+                self.ev_plan[gi][i].record()
         self.inflight[gi] = True
 
     def _complete(self, gi):
         grp = self.groups[gi]
-        if any(r.need_replan for r in grp):
-            self.events[gi].synchronize()          # the GPU keeps running whatever was queued after the event
-        with torch.cuda.stream(self.streams[gi]):
-            for r in grp:
+        for i, r in enumerate(grp):
+            if r.need_replan:
+                self.ev_plan[gi][i].synchronize()      # the GPU keeps running whatever was queued after the event
+            with torch.cuda.stream(self.rstreams[gi][i]):
                 r.plan_finish()
-            for r in grp:
                 r.post()
         self.inflight[gi] = False
 
@@ -236,7 +265,7 @@ class MultiRollout:
             if self.inflight[gi]:
                 self._complete(gi)
         main = torch.cuda.current_stream()
-        for st in self.streams:
+        for st in set(self.fwd_streams) | {x for g in self.rstreams for x in g}:
             if st is not main:
                 main.wait_stream(st)           # later work on the caller's stream sees every rollout's results
 

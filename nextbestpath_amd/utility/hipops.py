@@ -23,12 +23,23 @@ _ws = {}
 
 def _workspace(tag, nbytes, device):
     # scratch is per (kind, device, STREAM): rollouts stepped on different streams run their kernels concurrently
-    key = (tag, str(device), _st())
+    key = (tag, device.index if device.index is not None else -1, _st())
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws[key] = w
     return w
+
+
+_ws_sizes = {}
+
+
+def _workspace_for(tag, size_key, size_fn, device):
+    """Workspace whose size only depends on `size_key`: the C size query runs once per key."""
+    n = _ws_sizes.get((tag, size_key))
+    if n is None:
+        n = _ws_sizes[(tag, size_key)] = int(size_fn())
+    return _workspace(tag, n, device)
 
 
 def cams12(R, T, device=None):
@@ -52,8 +63,8 @@ def unproject_append(depth, mask, cams, cloud, cloud_count, gathering_factor=0.0
     F_, H, W = depth.shape
     L = _lib.lib()
     keep, cam_ptr, _ = _cam_arg(cams)
-    counts = torch.empty(F_, 2, dtype=torch.int32, device=depth.device)
-    ws = _workspace("unproject", L.nbp_unproject_workspace_bytes(F_, H, W), depth.device)
+    ws = _workspace_for("unproject", (F_, H, W), lambda: L.nbp_unproject_workspace_bytes(F_, H, W) + 256, depth.device)
+    counts = ws[-64:].view(torch.int32).reshape(8, 2)[:F_]          # per-stream scratch: no allocation per call
     rc = L.nbp_unproject_append_f32(_lib.ptr(depth), _lib.ptr(mask), cam_ptr, F_, H, W, tan_half_fov,
                                     float(fov_range), float(gathering_factor), int(seed) & 0xFFFFFFFF,
                                     _lib.ptr(counts), _lib.ptr(cloud), _lib.ptr(cloud_count), cloud.shape[0],
@@ -71,7 +82,8 @@ def raster_zbuf(verts, faces, cams, H, W, bin_cap=2048, tan_half_fov=TAN_HALF_FO
         out = torch.empty(n, H, W, dtype=torch.float32, device=verts.device)
     if overflow is None:
         overflow = torch.zeros(1, dtype=torch.int32, device=verts.device)
-    ws = _workspace("raster", L.nbp_raster_workspace_bytes(faces.shape[0], n, H, W, bin_cap), verts.device)
+    nf = faces.shape[0]
+    ws = _workspace_for("raster", (nf, n, H, W), lambda: L.nbp_raster_workspace_bytes(nf, n, H, W, bin_cap), verts.device)
     rc = L.nbp_raster_zbuf_f32(_lib.ptr(verts), verts.shape[0], _lib.ptr(faces), faces.shape[0], cam_ptr, n, H,
                                W, tan_half_fov, z_clip, bin_cap, _lib.ptr(out), _lib.ptr(overflow), _lib.ptr(ws),
                                ws.numel(), _st())
@@ -160,6 +172,37 @@ def coverage_count(gt, pc, n_dev=None, n=None, weight=2, seed=0, threshold=1.0, 
                                   ws.numel(), _st())
     _lib.check(rc, "nbp_coverage_count_f32")
     return out
+
+
+class CoveragePlan:
+    """GT cloud sorted once into the coverage grid (one per rollout); `count` then costs one kernel per call."""
+
+    def __init__(self, gt, threshold=1.0, weight=2, bbox=None):
+        L = _lib.lib()
+        self.gt, self.G, self.thr, self.k = gt, gt.shape[0], float(threshold), int(gt.shape[0] * weight)
+        lo, hi = (gt.min(0).values.tolist(), gt.max(0).values.tolist()) if bbox is None else bbox
+        self.lo, self.hi = (C.c_float * 3)(*lo), (C.c_float * 3)(*hi)
+        self.plan = torch.empty(L.nbp_coverage_plan_bytes(self.lo, self.hi, self.thr, self.G), dtype=torch.uint8,
+                                device=gt.device)
+        ws = torch.empty(L.nbp_coverage_plan_workspace_bytes(self.lo, self.hi, self.thr, self.G), dtype=torch.uint8,
+                         device=gt.device)
+        rc = L.nbp_coverage_plan_build_f32(_lib.ptr(gt), self.G, self.thr, self.lo, self.hi, _lib.ptr(self.plan),
+                                           self.plan.numel(), _lib.ptr(ws), ws.numel(), _st())
+        _lib.check(rc, "nbp_coverage_plan_build_f32")
+        self.epoch = 0
+        self._m = torch.zeros(1, dtype=torch.int32, device=gt.device)
+
+    def count(self, pc, out, n_dev=None, n=None, seed=0, out_is_zero=False):
+        """Adds the covered-GT count to out[0] (int32 device; zeroed first unless out_is_zero), out[1] = sample size."""
+        if not out_is_zero:
+            out[0:1].zero_()
+        self.epoch += 1
+        N = pc.shape[0] if n is None else int(n)
+        rc = _lib.lib().nbp_coverage_count_planned_f32(_lib.ptr(self.plan), self.G, self.thr, self.lo, self.hi, _lib.ptr(pc), N,
+                                                       _lib.ptr(n_dev), self.k, int(seed) & 0xFFFFFFFF, self.epoch,
+                                                       out[0:1].data_ptr(), out[1:2].data_ptr(), _st())
+        _lib.check(rc, "nbp_coverage_count_planned_f32")
+        return out
 
 
 def carve_update(proxy_pts, depth, mask, cam12_host, zfar, fov_range, tol, score_threshold, n_inside, n_behind, occ,

@@ -258,6 +258,7 @@ class CollectionRollout:
         self.planner = LatticePlanner(camera, mesh, device, value_size, grid, grid_range, rng=self.rng)
         self.gt = gt_scene_pc.contiguous()
         self.bbox = (self.gt.min(0).values.tolist(), self.gt.max(0).values.tolist())
+        self.cov_plan = hipops.CoveragePlan(self.gt, 1.0, 2, self.bbox)
         self.gen = torch.Generator().manual_seed(seed)
         self.seed = seed * 1_000_003
         # check_camera_in_mesh for every lattice position, once per scene (static mesh)
@@ -274,8 +275,7 @@ class CollectionRollout:
     def _observe(self, pose_i):
         st, cam, params = self.st, self.camera, self.params
         out = st.coverage_counts[pose_i % st.coverage_counts.shape[0]]
-        hipops.coverage_count(self.gt, st.cloud, n_dev=st.cloud_count, n=st.cloud.shape[0], weight=2,
-                              seed=self.seed + 7 * pose_i, threshold=1.0, bbox=self.bbox, out=out)
+        self.cov_plan.count(st.cloud, out, n_dev=st.cloud_count, n=st.cloud.shape[0], seed=self.seed + 7 * pose_i)
         cov = float(np.float32(out[0].item()) / np.float32(len(self.gt)))
         return cov
 

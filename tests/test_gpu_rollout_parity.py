@@ -168,20 +168,25 @@ def test_hip_rollout_equals_oracle_rollout_hard_scene(hip, tmp_path):
     assert 20_000 <= F <= 50_000, F
     _step_both_and_compare(hip_ro, ora, 10)
     assert int(hip_ro.camera._overflow.item()) == 0
-    for zb, cam12 in hip_ro.camera.frames[-4:]:
+    for zb, cam12, _slot in hip_ro.camera.frames[-4:]:
         want = csim.raster_zbuf(mesh.verts_host, mesh.faces_host, cam12[:9].reshape(3, 3), cam12[9:], zb.shape[0],
                                 zb.shape[1], ocam.TAN_HALF_FOV)
         assert np.array_equal(zb.cpu().numpy(), want)
 
 
-def test_raster_spilled_bins_keep_every_face(hip, tmp_path):
-    """A bin capacity far below the faces per tile: tiles fall back to walking all faces; the z-buffer is the same."""
+def test_raster_never_drops_faces_whatever_the_bin_capacity(hip, tmp_path):
+    """The face lists have room for every face (no capacity parameter matters any more): a 29 k-face scene seen along its
+    corridors gives the oracle's z-buffer bit for bit, and the legacy bin_cap argument changes nothing."""
     from nextbestpath_amd.utility import hipops as ho
     from oracle import camera as ocam
+    from oracle import csim
     params, settings, mesh = _scene(str(tmp_path), 12, 7.2, 0.15, 101)
-    R, T = ocam.camera_RT([3.0, 3.3, -6.0], [0.0, 100.0])
-    cams = ho.cams12(R[None], T[None])
+    poses = [([3.0, 3.3, -6.0], [0.0, 100.0]), ([-20.0, 3.3, 14.0], [-30.0, 10.0]), ([0.0, 11.0, 0.0], [60.0, 200.0])]
+    RT = [ocam.camera_RT(x, v) for x, v in poses]
+    cams = ho.cams12(np.stack([r for r, _ in RT]), np.stack([t for _, t in RT]))
     big, ov0 = ho.raster_zbuf(mesh.verts, mesh.faces, cams, 256, 456, bin_cap=8192)
     small, ov1 = ho.raster_zbuf(mesh.verts, mesh.faces, cams, 256, 456, bin_cap=64)
-    assert int(ov0.item()) == 0 and int(ov1.item()) > 0
-    assert torch.equal(big, small)
+    assert int(ov0.item()) == 0 and int(ov1.item()) == 0 and torch.equal(big, small)
+    for i, (R, T) in enumerate(RT):
+        want = csim.raster_zbuf(mesh.verts_host, mesh.faces_host, R, T, 256, 456, ocam.TAN_HALF_FOV)
+        assert np.array_equal(big[i].cpu().numpy(), want), i

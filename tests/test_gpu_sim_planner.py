@@ -242,9 +242,9 @@ def test_edge_arguments_never_crash(hip):
     lab = hipops.slice_obstacle(verts, faces, 1.0, 0.0, 0.0); sync()
     assert float(lab.sum()) == 0.0                      # vertices ON the plane count as the positive side: no crossing
     cams = np.concatenate([np.eye(3, dtype=np.float32).reshape(1, 9), np.zeros((1, 3), np.float32)], 1)
-    with pytest.raises(_lib.NbpHipError):                # bins hold at least one 64-face batch
-        hipops.raster_zbuf(verts, faces, cams, 16, 24, bin_cap=1)
+    z1, _ = hipops.raster_zbuf(verts, faces, cams, 16, 24, bin_cap=1); sync()      # the legacy capacity argument is ignored
     z, ovf = hipops.raster_zbuf(verts, faces, cams, 16, 24, bin_cap=64); sync()
+    assert torch.equal(z, z1)
     assert z.shape == (1, 16, 24) and torch.isfinite(z).all() and int(ovf) == 0
     seg = torch.tensor([[0, 0, 0, 0, 0, 0], [0, 0, 0, 5, 5, 5]], dtype=torch.float32, device=dev)   # zero-length segment
     hit = hipops.segments_hit_mesh(verts, faces, seg); sync()
@@ -332,6 +332,21 @@ def test_coverage_random_clouds_vs_oracle(hip, seed):
     out = ho.coverage_count(torch.from_numpy(gt).to(D), torch.from_numpy(pc).to(D), seed=seed).cpu().numpy()
     _, cnt = opl.coverage(gt, pc, seed=seed)
     assert out[1] == len(pc) and out[0] == cnt, (out, cnt)
+    # the rollout's variant (GT sorted once, one mark kernel per call, epoch stamps): same count on repeated calls,
+    # on a growing prefix of the cloud (device-side size) and on a sub-sampled one
+    plan = ho.CoveragePlan(torch.from_numpy(gt).to(D), 1.0, 2)
+    pcd = torch.from_numpy(pc).to(D)
+    res = torch.zeros(2, dtype=torch.int32, device=D)
+    for _ in range(2):
+        assert plan.count(pcd, res, seed=seed).cpu().tolist() == [cnt, len(pc)]
+    half = len(pc) // 2
+    nd = torch.tensor([half], dtype=torch.int64, device=D)
+    assert plan.count(pcd, res, n_dev=nd, seed=seed).cpu().tolist() == [opl.coverage(gt, pc[:half], seed=seed)[1], half]
+    big = np.concatenate([pc, pc + np.float32(0.25), pc - np.float32(0.5)], 0)[:2 * G + 50]
+    if len(big) > 2 * G:
+        want = opl.coverage(gt, big, seed=seed + 1)[1]
+        assert plan.count(torch.from_numpy(big).to(D), res, seed=seed + 1).cpu().tolist() == [want, 2 * G]
+        assert ho.coverage_count(torch.from_numpy(gt).to(D), torch.from_numpy(big).to(D), seed=seed + 1).cpu().tolist() == [want, 2 * G]
 
 
 @pytest.mark.parametrize("seed", [31, 32, 33])
