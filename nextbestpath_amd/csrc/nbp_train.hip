@@ -39,9 +39,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
             const long long r_end = r_begin + rows_per_block < M ? r_begin + rows_per_block : M;
             float mu = 0.f, is = 0.f;
             if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+            if (MODE == 0) mu = a[c];          // shift = the first row: sums of (x - k), (x - k)^2 do not cancel when |mean| >> std
             for (long long r = r_begin + rsub; r < r_end; r += rpb) {
                 const float v = a[r * C + c];
-                if (MODE == 0) { s0 += v; s1 += v * v; }
+                if (MODE == 0) { const float d = v - mu; s0 += d; s1 += d * d; }
                 if (MODE == 1) {
                     float dz = v;                                   // a = dy
                     if (relu && !(y[r * C + c] > 0.f)) dz = 0.f;
@@ -84,9 +85,10 @@ __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict
         if (rsub < rpb && c < C4) {
             f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
             if (MODE == 1) { mu = reinterpret_cast<const f32x4*>(mean)[c]; is = reinterpret_cast<const f32x4*>(invstd)[c]; }
+            if (MODE == 0) mu = a4[c];         // shift = the first row (see colreduce_kernel)
             auto step = [&](long long r) {
                 const f32x4 v = a4[r * C4 + c];
-                if (MODE == 0) { s0 += v; s1 += v * v; }
+                if (MODE == 0) { const f32x4 d = v - mu; s0 += d; s1 += d * d; }
                 if (MODE == 1) {
                     f32x4 dz = v;
                     if (relu) {
@@ -128,8 +130,11 @@ __device__ __forceinline__ void colsum_pair(const float* __restrict__ part, int 
     *s0_out = s0; *s1_out = s1;
 }
 
-// finalize MODE 0: mean, biased var -> invstd; running stats (momentum, unbiased var)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, long long M, float eps,
+// finalize MODE 0 (partials are sums of (x - k), (x - k)^2 with k = x[0][c]): mean = k + s0/M, biased var = s1/M - (s0/M)^2
+// -> invstd; running stats (momentum, unbiased var).  Shifted sums: fp32 partials lose ~1e-7 (1 + ((mean-k)/std)^2) of
+// the variance instead of 1e-7 mean^2/var (torch uses Welford).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ x_first_row,
+                                                          const float* __restrict__ part, int nblk, int C, long long M, float eps,
                                                           float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var) {
     __shared__ double sh[8][2][32];
@@ -137,8 +142,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     double s0, s1;
     colsum_pair(part, nblk, C, c, ks, sh, &s0, &s1);
     if (c >= C || ks != 0) return;
-    const double mu = s0 / (double)M;
-    double var = s1 / (double)M - mu * mu;
+    const double dm = s0 / (double)M;
+    const double mu = (double)x_first_row[c] + dm;
+    double var = s1 / (double)M - dm * dm;
     if (var < 0) var = 0;
     mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -729,7 +735,10 @@ __global__ void gather_values_kernel(const float* __restrict__ out1, const long 
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     const long long* q = coords + 4 * (long long)k;
-    pred[k] = out1[((q[0] * Cc + q[1]) * Hh + q[2]) * Ww + q[3]];
+    // (channel, row, col) are range-checked here, the batch index by the caller (the kernel does not know B); replay records
+    // may come from a reference-format store written elsewhere
+    const bool ok = q[0] >= 0 && q[1] >= 0 && q[1] < Cc && q[2] >= 0 && q[2] < Hh && q[3] >= 0 && q[3] < Ww;
+    pred[k] = ok ? out1[((q[0] * Cc + q[1]) * Hh + q[2]) * Ww + q[3]] : 0.f;
 }
 // scatter-add grad into d_out1 (zeroed by the caller); duplicates accumulate (index_put accumulate=True semantics)
 __global__ void scatter_values_kernel(const float* __restrict__ dpred, const long long* __restrict__ coords, int K, int Cc, int Hh,
@@ -737,6 +746,7 @@ __global__ void scatter_values_kernel(const float* __restrict__ dpred, const lon
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     const long long* q = coords + 4 * (long long)k;
+    if (!(q[0] >= 0 && q[1] >= 0 && q[1] < Cc && q[2] >= 0 && q[2] < Hh && q[3] >= 0 && q[3] < Ww)) return;
     atomicAdd(&dout1[((q[0] * Cc + q[1]) * Hh + q[2]) * Ww + q[3]], dpred[k]);
 }
 // partial sums of (p-t)^2 (mode 0) or BCE(p,t) with log clamped at -100 (mode 1, torch semantics)
@@ -805,7 +815,7 @@ extern "C" int nbp_bn_train_forward_f32(const float* x, long long M, int C, cons
     else colreduce_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, rpb, part);
     int rc = nbp_launch_status();
     if (rc) return rc;
-    bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, M, eps, momentum, mean, invstd, running_mean,
+    bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(x, part, nblk, C, M, eps, momentum, mean, invstd, running_mean,
                                                                   running_var);
     if ((rc = nbp_launch_status())) return rc;
     if (C % 4 == 0) bn_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(x, M * C / 4, C / 4, mean, invstd, gamma, beta, relu, y);
@@ -1041,7 +1051,9 @@ extern "C" int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, 
 extern "C" int nbp_gather_values_f32(const float* out1_nchw, const long long* coords_bcxy, int K, int C, int H, int W, float* pred,
                                      void* stream) {
     NBP_ENTER();
-    NBP_RETURN_IF(!out1_nchw || !coords_bcxy || !pred || K < 1, NBP_E_ARG);
+    NBP_RETURN_IF(K < 0, NBP_E_ARG);
+    if (K == 0) return 0;                                  // a batch without value targets is legal (empty gather)
+    NBP_RETURN_IF(!out1_nchw || !coords_bcxy || !pred, NBP_E_ARG);
     gather_values_kernel<<<(unsigned)nbp_cdiv(K, 256), 256, 0, (hipStream_t)stream>>>(out1_nchw, coords_bcxy, K, C, H, W, pred);
     return nbp_launch_status();
 }
@@ -1049,7 +1061,9 @@ extern "C" int nbp_gather_values_f32(const float* out1_nchw, const long long* co
 extern "C" int nbp_scatter_values_f32(const float* dpred, const long long* coords_bcxy, int K, int C, int H, int W,
                                       float* dout1_nchw_zeroed, void* stream) {
     NBP_ENTER();
-    NBP_RETURN_IF(!dpred || !coords_bcxy || !dout1_nchw_zeroed || K < 1, NBP_E_ARG);
+    NBP_RETURN_IF(K < 0, NBP_E_ARG);
+    if (K == 0) return 0;
+    NBP_RETURN_IF(!dpred || !coords_bcxy || !dout1_nchw_zeroed, NBP_E_ARG);
     scatter_values_kernel<<<(unsigned)nbp_cdiv(K, 256), 256, 0, (hipStream_t)stream>>>(dpred, coords_bcxy, K, C, H, W,
                                                                                         dout1_nchw_zeroed);
     return nbp_launch_status();

@@ -50,6 +50,12 @@ def _collate(batch_data, device):
     xs = torch.cat([torch.from_numpy(np.copy(d["current_model_input"])) for d in batch_data]).to(device)
     gt = torch.cat([torch.from_numpy(np.copy(d["current_gt_2d_layout"])) for d in batch_data]).to(device)
     coords = [torch.from_numpy(np.copy(d["target_value_map_pixel"])) for d in batch_data]
+    # the reference indexes predicted_value_map[b, c, x, y] (nbp_utils.py:379), which raises on a bad coordinate; the
+    # device gather has no exception path, so replay records (possibly written elsewhere) are range-checked here
+    V = xs.shape[-1] // 4
+    for d, c in zip(batch_data, coords):
+        if c.numel() and (c.min() < 0 or c[:, 0].max() >= 8 or c[:, 1:].max() >= V):
+            raise IndexError(f"target_value_map_pixel out of range for an [8,{V},{V}] value map (pose_i={d.get('pose_i')})")
     gains = torch.cat([torch.from_numpy(np.copy(d["actual_coverage_gain"])) for d in batch_data]).to(device)
     sizes = torch.tensor([len(c) for c in coords])
     bidx = torch.repeat_interleave(torch.arange(len(coords)), sizes).to(device)
@@ -112,18 +118,25 @@ def _mean_over_ranks(x: float, device) -> float:
 
 
 def train_experience_data(training_set_db, params, optimizer, nbp, device, current_epoch):
-    """ref nbp_utils.py:340-395 (GradScaler without autocast is the identity scale for fp32; omitted)."""
+    """ref nbp_utils.py:340-395 (GradScaler without autocast is the identity scale for fp32; omitted).  As in the
+    reference the early poses (pose_i <= 10) are dropped INSIDE each batch during epoch 1 (:348-362), a batch left empty
+    is skipped before the optimiser-step test (:364-365), and the step fires every 8 non-empty batches or on the batch
+    that reaches the end of the set (:385).  Under torchrun the ranks agree on "empty" and on the batch count, because
+    the step contains the gradient all-reduce."""
     random.shuffle(training_set_db)
-    if current_epoch == 1:                   # ref :350: early poses are skipped during the first training epoch
-        training_set_db = [d for d in training_set_db if d["pose_i"] > 10] or training_set_db
     training_loss, accumulated, updates = [], 0.0, 0
     accumulation_steps = 8
     bs = params.nbp_batch_size
     n_batches = _common_count((len(training_set_db) + bs - 1) // bs, device)
+    multi_rank = _dist() is not None
     for bi in range(n_batches):
-        i = bi * bs
-        batch = training_set_db[i:i + bs]
-        if not batch:
+        batch = training_set_db[bi * bs:(bi + 1) * bs]
+        if current_epoch == 1:
+            batch = [d for d in batch if d["pose_i"] > 10]
+        have = 1 if batch else 0
+        if multi_rank:
+            have = _common_count(have, device)
+        if not have:
             continue
         xs, gt, coords, gains, bidx = _collate(batch, device)
         out1, out2 = nbp(xs)
@@ -139,6 +152,21 @@ def train_experience_data(training_set_db, params, optimizer, nbp, device, curre
             training_loss.append(accumulated / accumulation_steps)
             accumulated, updates = 0.0, 0
     return training_loss
+
+
+def sync_buffers(nbp):
+    """BatchNorm running statistics are per rank during training; before validation / checkpointing they are averaged so
+    that every rank evaluates (and rank 0 saves) the same eval-mode network.  No-op without torch.distributed."""
+    dist = _dist()
+    if dist is None:
+        return
+    world = dist.get_world_size()
+    for name, buf in nbp.named_buffers():
+        if buf.dtype.is_floating_point:
+            t = buf.data if dist.get_backend() == "nccl" else buf.data.cpu()
+            dist.all_reduce(t)
+            buf.data.copy_(t / world)
+        # num_batches_tracked: identical on every rank (same number of forward passes)
 
 
 def validation_model(training_set_db, params, nbp, device):
@@ -161,7 +189,9 @@ def train_nbp(training_set_db, params, optimizer, nbp, device, current_epoch, va
     tl, vl = [], []
     for _ in range(num_epochs):
         nbp.train()
-        tl.append(float(np.mean(train_experience_data(training_set_db, params, optimizer, nbp, device, current_epoch))))
+        losses = train_experience_data(training_set_db, params, optimizer, nbp, device, current_epoch)
+        tl.append(float(np.mean(losses)) if losses else float("nan"))
+        sync_buffers(nbp)
         nbp.eval()
         with torch.no_grad():
             vl.append(_mean_over_ranks(validation_model(validation_data, params, nbp, device), device))
@@ -226,7 +256,7 @@ def run_training_nbp(params):
         if epoch == 0:
             validation = nu.store_validation_data(env, getattr(params, "n_validation", 1200))
             continue
-        db = nu.read_combined_data(env)
+        db = nu.read_combined_data(env, sample_m=None) if epoch == 1 else nu.read_combined_data(env)   # ref :436-440
         # every rank must take the same branch (the training loop below contains collectives)
         if _common_count(1 if (db and validation) else 0, device) == 0:
             continue
