@@ -278,6 +278,16 @@ size_t nbp_scene_coverage_workspace_bytes(const float* box6_host, const int* gri
 int nbp_scene_coverage_f32(const float* gt_pts, const int* gt_count, int capacity_gt, const float* rec_pts,
                            const int* rec_count, int capacity_rec, const float* box6_host, const int* grid3_host,
                            double epsilon, int* covered_and_total2, void* ws, size_t ws_bytes, void* stream);
+/* Camera.get_points_in_fov (mu:2849-2884) for n_cams cameras (host [n_cams,12]): mask[cam][i] = 1 iff point i projects
+ * inside the image, lies in front of the camera and closer than fov_range to its centre; any[cam] = 1 iff some point
+ * does (Camera.is_fov_empty over the mesh vertices, mu:2672-2688).  Either output may be null. */
+int nbp_points_in_fov_u8(const float* pts3, int P, const float* cams12_host, int n_cams, int H, int W,
+                         float tan_half_fov, float fov_range, unsigned char* mask_or_null, int* any_or_null,
+                         void* stream);
+/* out3[j] = pc3[perm(j)], j < min(N, k): the first k points of a seeded random permutation of the cloud
+ * (fill_surface_scene, mu:715-716); *m_out (device) = their number. */
+int nbp_sample_points_f32(const float* pc3, long long N, const long long* N_dev_or_null, long long k, unsigned seed,
+                          float* out3, long long* m_out, void* stream);
 /* dst[offset + i] = pts3_host[i] for i < n <= 8 (the camera trajectory buffer, without a blocking copy). */
 int nbp_append_points_f32(float* dst, long long offset, const float* pts3_host, int n, void* stream);
 /* Host mirror of the sampling bijection (driver / tests). */

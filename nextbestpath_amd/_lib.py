@@ -105,6 +105,8 @@ SIGNATURES["nbp_coverage_plan_workspace_bytes"] = (_sz, [_fpp, _fpp, _f, _i])
 SIGNATURES["nbp_coverage_plan_build_f32"] = (_i, [_vp, _i, _f, _fpp, _fpp, _vp, _sz, _vp, _sz, _vp])
 SIGNATURES["nbp_coverage_count_planned_f32"] = (_i, [_vp, _i, _f, _fpp, _fpp, _vp, _ll, _vp, _ll, C.c_uint, C.c_uint, _vp, _vp,
                                                      _vp])
+SIGNATURES["nbp_points_in_fov_u8"] = (_i, [_vp, _i, _fpp, _i, _i, _i, _f, _f, _vp, _vp, _vp])
+SIGNATURES["nbp_sample_points_f32"] = (_i, [_vp, _ll, _vp, _ll, C.c_uint, _vp, _vp, _vp])
 SIGNATURES["nbp_slice_obstacle_f32"] = (_i, [_vp, _vp, _i, _f, _f, _f, _i, _f, _f, _f, _vp, _vp])
 
 _lock = threading.Lock()

@@ -479,6 +479,42 @@ __global__ __launch_bounds__(256) void axis_ray_count_kernel(const float* __rest
         if (ray_tri(pts + 3 * (size_t)k, dirs[ax], a, b, c) >= 0.f) atomicAdd(&counts[3 * k + ax], 1);
 }
 
+// Camera.get_points_in_fov (mu:2849-2884): NDC inside the corners of the reference's NDC tables (mu:2270-2279), in front
+// of the camera, closer than fov_range to the camera centre.  Also returns the view-space point and its NDC.
+__device__ __forceinline__ bool point_in_fov(const float* p, const Cam& cam, int H, int W, float tanh_fov, float fov_range,
+                                             float* v, float* nx_out, float* ny_out) {
+    to_view(p, cam.R, cam.T, v);
+    // camera centre C = -T R^T
+    const float cx = -((cam.T[0] * cam.R[0] + cam.T[1] * cam.R[1]) + cam.T[2] * cam.R[2]);
+    const float cy = -((cam.T[0] * cam.R[3] + cam.T[1] * cam.R[4]) + cam.T[2] * cam.R[5]);
+    const float cz = -((cam.T[0] * cam.R[6] + cam.T[1] * cam.R[7]) + cam.T[2] * cam.R[8]);
+    const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+    const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const int s = H < W ? H : W;
+    const float nx = v[0] / (v[2] * tanh_fov), ny = v[1] / (v[2] * tanh_fov);
+    const float max_x = (float)((double)W / s), min_x = max_x - ((float)(W - 1) / (float)(s - 1)) * 2.f;
+    const float max_y = (float)((double)H / s), min_y = max_y - ((float)(H - 1) / (float)(s - 1)) * 2.f;
+    *nx_out = nx; *ny_out = ny;
+    return nx >= min_x && nx <= max_x && ny >= min_y && ny <= max_y && v[2] > 0.f && dist < fov_range;
+}
+
+// mask[cam][i] = point i inside the field of view of camera cam (get_points_in_fov); any[cam] = some point is
+// (is_fov_empty, mu:2672-2688, over the mesh vertices).  grid.y = camera.
+__global__ __launch_bounds__(256) void points_in_fov_kernel(const float* __restrict__ pts, int P, CamSet cams, int H, int W,
+                                                            float tanh_fov, float fov_range, unsigned char* __restrict__ mask,
+                                                            int* __restrict__ any) {
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool in = false;
+    if (i < P) {
+        const float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+        float v[3], nx, ny;
+        in = point_in_fov(p, cams.c[c], H, W, tanh_fov, fov_range, v, &nx, &ny);
+        if (mask) mask[(size_t)c * P + i] = in ? 1 : 0;
+    }
+    if (any && __ballot(in) && (threadIdx.x & 63) == 0) any[c] = 1;      // plain store: every writer writes 1
+}
+
 // ------------------------------------------------------------------ depth-map space carving (A20)
 // One thread per proxy point: frustum + range test, bilinear depth lookup (torch grid_sample
 // semantics: align_corners = False, border padding; invalid pixels read as 1.1 zfar), counters.
@@ -491,20 +527,9 @@ __global__ __launch_bounds__(256) void carve_update_kernel(const float* __restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
-    float v[3];
-    to_view(p, cam.R, cam.T, v);
-    // camera centre C = -T R^T
-    const float cx = -((cam.T[0] * cam.R[0] + cam.T[1] * cam.R[1]) + cam.T[2] * cam.R[2]);
-    const float cy = -((cam.T[0] * cam.R[3] + cam.T[1] * cam.R[4]) + cam.T[2] * cam.R[5]);
-    const float cz = -((cam.T[0] * cam.R[6] + cam.T[1] * cam.R[7]) + cam.T[2] * cam.R[8]);
-    const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
-    const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+    float v[3], nx, ny;
+    const bool in_fov = point_in_fov(p, cam, H, W, tanh_fov, fov_range, v, &nx, &ny);
     const int s = H < W ? H : W;
-    const float nx = v[0] / (v[2] * tanh_fov), ny = v[1] / (v[2] * tanh_fov);
-    // frustum bounds = corners of the reference's NDC tables (mu:2270-2279)
-    const float max_x = (float)((double)W / s), min_x = max_x - ((float)(W - 1) / (float)(s - 1)) * 2.f;
-    const float max_y = (float)((double)H / s), min_y = max_y - ((float)(H - 1) / (float)(s - 1)) * 2.f;
-    const bool in_fov = nx >= min_x && nx <= max_x && ny >= min_y && ny <= max_y && v[2] > 0.f && dist < fov_range;
     if (!in_fov) return;
     // grid_sample coordinates (mu:2929-2944): gx = -(s/W) ndc_x, gy = -(s/H) ndc_y
     const float gx = (-(float)s / (float)W) * nx, gy = (-(float)s / (float)H) * ny;
@@ -678,6 +703,28 @@ extern "C" int nbp_carve_update_f32(const float* proxy_pts3, int P, const float*
         proxy_pts3, P, depth, mask_or_null, cam, H, W, tan_half_fov, zfar, fov_range, tol, score_threshold, n_inside,
         n_behind, occ, out_of_field);
     return nbp_launch_status();
+}
+
+extern "C" int nbp_points_in_fov_u8(const float* pts3, int P, const float* cams12_host, int n_cams, int H, int W,
+                                    float tan_half_fov, float fov_range, unsigned char* mask_or_null, int* any_or_null,
+                                    void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!pts3 || !cams12_host || (!mask_or_null && !any_or_null) || P < 1 || n_cams < 1 || H < 2 || W < 2, NBP_E_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    for (int c0 = 0; c0 < n_cams; c0 += MAX_CAMS) {                      // cameras travel in the kernel arguments, 8 at a time
+        const int nc = n_cams - c0 < MAX_CAMS ? n_cams - c0 : MAX_CAMS;
+        if (any_or_null) {
+            hipError_t e = hipMemsetAsync(any_or_null + c0, 0, (size_t)nc * sizeof(int), st);
+            if (e != hipSuccess) return (int)e;
+        }
+        dim3 g((unsigned)nbp_cdiv(P, 256), (unsigned)nc);
+        points_in_fov_kernel<<<g, 256, 0, st>>>(pts3, P, camset_from_host(cams12_host + 12 * (size_t)c0, nc), H, W, tan_half_fov,
+                                                fov_range, mask_or_null ? mask_or_null + (size_t)c0 * P : nullptr,
+                                                any_or_null ? any_or_null + c0 : nullptr);
+        int rc = nbp_launch_status();
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // dst[offset + i] = pts[i], i < n <= 8: the points ride in the kernel arguments (camera trajectory).

@@ -154,6 +154,35 @@ class Camera:
                 out.add((ni, j, nk, e, (a + da) % self.pose_n_azim))
         return sorted(out)
 
+    def get_neighboring_poses_2d(self, pose_idx=None):
+        """mu:2447-2471: same arithmetic as get_neighboring_poses (the y and elevation shifts are undone)."""
+        return self.get_neighboring_poses(self.cam_idx if pose_idx is None else pose_idx)
+
+    def cam12_of_pose(self, pose):
+        R, T = camera_RT(pose[:3], pose[3:])
+        return np.concatenate([R.reshape(-1), T.reshape(-1)]).astype(f32)
+
+    def get_valid_neighbors(self, neighbor_indices, mesh):
+        """mu:2528-2556: the unvisited neighbours whose field of view contains a mesh vertex (is_fov_empty, :2672-2688,
+        range 5 zfar) -- all of them tested in ONE launch -- or, when there is none, the visited ones."""
+        new = [n for n in neighbor_indices if tuple(n) not in self.visited]
+        visited = [n for n in neighbor_indices if tuple(n) in self.visited]
+        if new:
+            cams = np.stack([self.cam12_of_pose(self.pose_from_idx(n)) for n in new])
+            _, any_ = hipops.points_in_fov(mesh.verts, cams, self.image_height, self.image_width, 5 * self.zfar,
+                                           want_mask=False)
+            new = [n for n, a in zip(new, any_.cpu().tolist()) if a]
+        return new if new else visited
+
+    def get_points_in_fov(self, pts, return_mask=False, cam12=None, fov_range=None):
+        """mu:2849-2884 for the current camera (or a [12] host camera): the points inside the field of view."""
+        cam12 = self.cam12_of_pose(np.concatenate([self.X_cam, self.V_cam])) if cam12 is None else cam12
+        rng = 1.1 * self.zfar if fov_range is None else fov_range
+        mask, _ = hipops.points_in_fov(pts.contiguous(), cam12[None], self.image_height, self.image_width,
+                                       1e30 if fov_range is None else rng)
+        m = mask[0].bool()
+        return (pts[m], m) if return_mask else pts[m]
+
     # ------------------------------------------------------------------ motion
     def _interp(self, new_idx, step):
         """Pose at interpolation step `step` of the move cam_idx -> new_idx (mu:2590-2632), fp32."""

@@ -225,6 +225,42 @@ class Scene:
                             self.out_of_field)
 
 
+def fill_surface_scene(surface_scene, full_pc, n_dev=None, random_sampling_max_size=200000, min_n_points_per_cell_fill=3,
+                       progressive_fill=True, max_n_points_per_fill=1000, seed=0):
+    """mu:691-753: empty the scene and refill it from a shuffled subset of the cloud, progressively (chunks thinned
+    against what the earlier chunks stored).  The reference's torch.randperm becomes the seeded index bijection; one
+    device sync (the subset size decides the number of chunks, as len(full_pc) does in the reference)."""
+    from ..utility import hipops
+    sample, m = hipops.sample_points(full_pc, random_sampling_max_size, seed=seed, n_dev=n_dev)
+    sample = sample[:int(m.item())]
+    surface_scene.empty_cells()
+    if not progressive_fill:
+        surface_scene.fill_cells(sample, n_point_min=min_n_points_per_cell_fill)
+        return
+    n_fill = random_sampling_max_size // max_n_points_per_fill + (1 if random_sampling_max_size % max_n_points_per_fill else 0)
+    for q in range(n_fill):
+        lo = q * max_n_points_per_fill
+        hi = lo + max_n_points_per_fill
+        chunk = sample[lo:-1] if q == random_sampling_max_size // max_n_points_per_fill else sample[lo:hi]   # ref :741-742
+        if len(chunk):
+            surface_scene.fill_cells(chunk, n_point_min=min_n_points_per_cell_fill)
+
+
+def setup_test_scenes(params, settings, mesh, device, test_resolution=0.05, seed=0, n_gt_points=None):
+    """setup_test_scene (macarons/testers/scene.py:119-217): gt_scene (filled with the GT surface), covered_scene,
+    surface_scene (resolution derived from the capacity) and proxy_scene (proxy points initialised)."""
+    x_min, x_max = settings.scene.x_min - f32(0.2), settings.scene.x_max + f32(0.2)
+    g = (settings.scene.grid_l, settings.scene.grid_w, settings.scene.grid_h)
+    gt_scene, _ = setup_gt_scene(params, settings, mesh, device, test_resolution, seed, n_gt_points)
+    covered = Scene(x_min, x_max, *g, params.surface_cell_capacity, test_resolution * params.scene_scale_factor,
+                    params.n_proxy_points, device, seed=seed + 1)
+    surface = Scene(x_min, x_max, *g, params.surface_cell_capacity, None, params.n_proxy_points, device, seed=seed + 2)
+    proxy = Scene(x_min, x_max, *g, params.proxy_cell_capacity, params.proxy_cell_resolution, params.n_proxy_points, device,
+                  score_threshold=params.score_threshold, seed=seed + 3)
+    proxy.initialize_proxy_points()
+    return gt_scene, covered, surface, proxy
+
+
 def setup_gt_scene(params, settings, mesh, device, test_resolution=0.05, seed=0, n_points=None):
     """setup_test_scene's gt_scene (macarons/testers/scene.py:139-177): a Scene over the scene box grown by 0.2 with
     the surface-cell capacity and resolution test_resolution * scale, filled ONCE with n_gt_surface_points samples of

@@ -263,6 +263,29 @@ def scene_coverage(gt_scene, rec_scene, epsilon, out=None):
     return out
 
 
+def points_in_fov(pts, cams, H, W, fov_range, want_mask=True, tan_half_fov=TAN_HALF_FOV):
+    """Camera.get_points_in_fov for n cameras (host [n,12]) -> (mask uint8 [n,P] or None, any int32 [n])."""
+    keep, cam_ptr, n = _cam_arg(cams)
+    P = pts.shape[0]
+    mask = torch.empty(n, P, dtype=torch.uint8, device=pts.device) if want_mask else None
+    any_ = torch.empty(n, dtype=torch.int32, device=pts.device)
+    rc = _lib.lib().nbp_points_in_fov_u8(_lib.ptr(pts), P, cam_ptr, n, H, W, tan_half_fov, float(fov_range), _lib.ptr(mask),
+                                         _lib.ptr(any_), _st())
+    _lib.check(rc, "nbp_points_in_fov_u8")
+    return mask, any_
+
+
+def sample_points(pc, k, seed=0, n_dev=None, n=None):
+    """The first k points of a seeded random permutation of pc[:n] -> (out [k,3] device, m int64[1] device)."""
+    N = pc.shape[0] if n is None else int(n)
+    out = torch.empty(min(int(k), N), 3, dtype=torch.float32, device=pc.device)
+    m = torch.zeros(1, dtype=torch.int64, device=pc.device)
+    rc = _lib.lib().nbp_sample_points_f32(_lib.ptr(pc), N, _lib.ptr(n_dev), int(k), int(seed) & 0xFFFFFFFF, _lib.ptr(out),
+                                          _lib.ptr(m), _st())
+    _lib.check(rc, "nbp_sample_points_f32")
+    return out, m
+
+
 def append_points(dst, offset, pts_host):
     """dst[offset:offset+n] = pts (n <= 8 host points, passed in the kernel arguments)."""
     import numpy as np

@@ -26,11 +26,13 @@ def cartesian(r, elev_deg, azim_deg):
     return np.stack([r * np.cos(e) * np.sin(a), r * np.sin(e), r * np.cos(e) * np.cos(a)], -1)
 
 
-def look_at_RT(eye, at, up=(0.0, 1.0, 0.0)):
+def look_at_RT(eye, at, up=(0.0, 1.0, 0.0), direction=None):
     """pytorch3d look_at_view_transform: z = normalize(at-eye), x = normalize(up x z), y = z x x;
-    R has those axes as COLUMNS (row-vector convention), T = -eye R."""
+    R has those axes as COLUMNS (row-vector convention), T = -eye R.  `direction` (= at - eye in exact arithmetic)
+    can be given directly: forming at = eye + d and subtracting eye again perturbs d by ~1e-16 in float64 (by ~1e-7 in
+    the library's fp32), which only shows where a rotation entry is exactly 0."""
     eye, at, up = np.asarray(eye, np.float64), np.asarray(at, np.float64), np.asarray(up, np.float64)
-    z = at - eye
+    z = at - eye if direction is None else np.asarray(direction, np.float64)
     z = z / max(np.linalg.norm(z), 1e-5)
     x = np.cross(up, z)
     nx = np.linalg.norm(x)
@@ -51,7 +53,7 @@ def camera_RT(X_cam, V_cam):
     """get_camera_RT (mu:940-957): rays = -cartesian(1, -elev, 180 + azim); look at X + rays."""
     rays = -cartesian(1.0, -float(V_cam[0]), 180.0 + float(V_cam[1]))
     X = np.asarray(X_cam, np.float64)
-    return look_at_RT(X, X + rays)
+    return look_at_RT(X, X + rays, direction=rays)
 
 
 def ndc_tables(H, W):
@@ -105,6 +107,25 @@ def pose_lattice(x_min, pose_l, pose_w, pose_h, n_elev, n_azim):
     poses[:, 3] = f32(-90.0) + (f32(180.0) * (1 + idx[:, 3]).astype(f32)) / f32(n_elev + 1)
     poses[:, 4] = (f32(360.0) * idx[:, 4].astype(f32)) / f32(n_azim)
     return idx, poses
+
+
+def points_in_fov(pts, R, T, H, W, fov_range):
+    """Camera.get_points_in_fov (mu:2849-2884): boolean mask (fp32, kernel op order; same test as carve_update)."""
+    s = min(H, W)
+    R, T = np.asarray(R, f32), np.asarray(T, f32)
+    p = np.asarray(pts, f32)
+    v = np.empty_like(p)
+    for j in range(3):
+        v[:, j] = ((p[:, 0] * R[0, j] + p[:, 1] * R[1, j]) + p[:, 2] * R[2, j]) + T[j]
+    C = np.array([-((T[0] * R[j, 0] + T[1] * R[j, 1]) + T[2] * R[j, 2]) for j in range(3)], f32)
+    d = p - C
+    dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=f32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        nx = v[:, 0] / (v[:, 2] * TAN_HALF_FOV)
+        ny = v[:, 1] / (v[:, 2] * TAN_HALF_FOV)
+    max_x = f32(W / s); min_x = max_x - (f32(W - 1) / f32(s - 1)) * f32(2)
+    max_y = f32(H / s); min_y = max_y - (f32(H - 1) / f32(s - 1)) * f32(2)
+    return (nx >= min_x) & (nx <= max_x) & (ny >= min_y) & (ny <= max_y) & (v[:, 2] > 0) & (dist < f32(fov_range))
 
 
 def carve_update(pts, depth, mask, R, T, zfar, fov_range, tol, score_thr, n_inside, n_behind, occ, out_of_field):

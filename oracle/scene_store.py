@@ -84,8 +84,11 @@ class Cell:
         if len(add) <= n_point_min:
             return
         if len(self.pts) > 0:
-            d = add.astype(np.float64)[:, None, :] - self.pts.astype(np.float64)[None, :, :]
-            dist = np.sqrt((d * d).sum(-1)).min(-1)
+            stored = self.pts.astype(np.float64)
+            dist = np.empty(len(add))
+            for i in range(0, len(add), 256):                       # blocks: the full matrix would not fit for 30 k x 20 k
+                d = add[i:i + 256].astype(np.float64)[:, None, :] - stored[None, :, :]
+                dist[i:i + 256] = np.sqrt((d * d).sum(-1)).min(-1)
             add = add[dist > self.resolution]
         allp = np.concatenate([self.pts, add], 0)
         if len(allp) > self.capacity:

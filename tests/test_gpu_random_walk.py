@@ -1,0 +1,97 @@
+"""GPU parity of the random-walk baseline rollout against its CPU restatement
+(oracle/random_walk.py): same scene, seeds and proxy points -> the same poses, the same coverage values (exact: ratios of
+integer counts), the same carving state, the same point stores."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+D = "cuda"
+
+
+def _rows(a):
+    a = np.asarray(a)
+    return a[np.lexsort(a.T[::-1])]
+
+
+def test_points_in_fov_and_sampling_vs_oracle(hip):
+    from nextbestpath_amd.utility import hipops as ho
+    from oracle import camera as ocam
+    from oracle import sampling
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(-40, 40, (5000, 3)).astype(np.float32)
+    poses = [([1.0, 3.3, -2.0], [0.0, 45.0]), ([4.0, 3.3, 9.0], [30.0, 200.0]), ([-7.0, 3.3, 1.0], [-60.0, 315.0])] * 4
+    RT = [ocam.camera_RT(x, v) for x, v in poses]                      # 12 cameras: two argument batches of 8
+    cams = ho.cams12(np.stack([r for r, _ in RT]), np.stack([t for _, t in RT]))
+    mask, any_ = ho.points_in_fov(torch.from_numpy(pts).to(D), cams, 256, 456, 30.0)
+    for i, (R, T) in enumerate(RT):
+        want = ocam.points_in_fov(pts, R, T, 256, 456, 30.0)
+        assert np.array_equal(mask[i].cpu().numpy().astype(bool), want) and bool(any_[i].item()) == bool(want.any())
+    _, none = ho.points_in_fov(torch.from_numpy(pts + 1000).to(D), cams[:1], 256, 456, 30.0, want_mask=False)
+    assert int(none.item()) == 0
+    out, m = ho.sample_points(torch.from_numpy(pts).to(D), 1200, seed=9)
+    assert int(m.item()) == 1200 and np.array_equal(out.cpu().numpy(), pts[sampling.perm_index(np.arange(1200), 5000, 9)])
+    out, m = ho.sample_points(torch.from_numpy(pts).to(D), 9000, seed=9, n_dev=torch.tensor([700], device=D))
+    assert int(m.item()) == 700 and np.array_equal(out[:700].cpu().numpy(), pts[sampling.perm_index(np.arange(700), 700, 9)])
+
+
+def test_random_walk_rollout_equals_oracle(hip, tmp_path):
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.simulator.mesh import make_maze_scene
+    from nextbestpath_amd.testers import nbp_planning as tp
+    from nextbestpath_amd.testers.random_walk_planning import RandomWalkRollout
+    from oracle.random_walk import OracleRandomWalk
+    make_maze_scene(str(tmp_path / "m"), seed=3, cells=6, size=3.6, height=1.2, tess=0.3)
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    params.image_height, params.image_width = 128, 228                  # a quarter of the pixels: the numpy oracle is slow
+    params.n_proxy_points, params.n_gt_surface_points = 6000, 8000
+    params.recompute_surface_every_n_loop, params.max_points_per_progressive_fill = 4, 3000
+    dev = torch.device(D)
+    ds = sc.SceneDataset(str(tmp_path), ["m"])
+    settings = sc.Settings(ds[0]["settings"], params.scene_scale_factor)
+    mesh = sc.load_scene(os.path.join(str(tmp_path), "m", ds[0]["obj_name"]), params.scene_scale_factor, dev)
+    seed = 4
+    gt_scene, covered, surface, proxy = sc.setup_test_scenes(params, settings, mesh, dev, 0.05, seed=seed)
+    gt_pts = sc.sample_gt_surface(mesh.verts_host, mesh.faces_host, params.n_gt_surface_points, gt_scene.x_min, gt_scene.x_max,
+                                  seed=seed)
+    start = settings.camera.start_positions[0]
+    cam = tp.setup_test_camera(params, mesh, start, settings, dev, seed=seed)
+    ro = RandomWalkRollout(params, cam, gt_scene, surface, proxy, covered, mesh, dev, 0.05, seed=seed)
+    op = dict(n_interp=params.n_interpolation_steps, surface_cell_capacity=params.surface_cell_capacity, test_resolution=0.05,
+              scale=params.scene_scale_factor, gathering_factor=params.gathering_factor, sensor_range=params.sensor_range,
+              zfar=params.zfar, carving_tolerance=params.carving_tolerance, score_threshold=params.score_threshold,
+              recompute_every=params.recompute_surface_every_n_loop, n_gt_surface_points=params.n_gt_surface_points,
+              max_points_per_fill=params.max_points_per_progressive_fill)
+    dims = (settings.camera.pose_l, settings.camera.pose_w, settings.camera.pose_h, settings.camera.pose_n_elev,
+            settings.camera.pose_n_azim)
+    ora = OracleRandomWalk(mesh.verts_host, mesh.faces_host, settings.camera.x_min, dims, start, cam.cam_idx_history[0],
+                           (gt_scene.x_min, gt_scene.x_max), (gt_scene.grid_l, gt_scene.grid_w, gt_scene.grid_h), op,
+                           proxy.proxy_points.cpu().numpy(), gt_pts, seed, (seed, seed + 1, seed + 2), H=128, W=228)
+    assert np.array_equal(_rows(gt_scene.return_entire_pt_cloud().cpu().numpy()), _rows(ora.gt.return_entire_pt_cloud()))
+    n_steps = 9
+    sizes = []
+    for s in range(n_steps):
+        ro.step()
+        ora.step()
+        assert cam.cam_idx_history == ora.cam.cam_idx_history, s
+        assert ro.coverage_evolution[-1] == ora.coverage_evolution[-1], (s, ro.coverage_evolution[-1], ora.coverage_evolution[-1])
+        assert int(ro.full_count.item()) == len(ora.full_pc), s
+        sizes.append(len(ora.full_pc))
+    assert ro.coverage_evolution[0] > 0.0 and ro.coverage_evolution[-1] > ro.coverage_evolution[0]
+    n = len(ora.full_pc)
+    got = ro.full_pc[:n].cpu().numpy()
+    bad = np.nonzero((got != ora.full_pc).any(1))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], bad[-5:], got[bad[:3]], ora.full_pc[bad[:3]], sizes)
+    for name, dev_scene, o_scene in (("covered", covered, ora.covered), ("surface", surface, ora.surface)):
+        assert dev_scene.cell_count.cpu().tolist() == [len(c.pts) for c in o_scene.cells.values()], name
+        for key, cell in zip(dev_scene.cell_keys(), o_scene.cells.values()):
+            assert np.array_equal(_rows(dev_scene.cell_points(key).cpu().numpy()), _rows(cell.pts)), (name, key)
+    for got, want in ((proxy.proxy_n_inside_fov, ora.n_inside), (proxy.proxy_n_behind_depth, ora.n_behind),
+                      (proxy.proxy_supervision_occ, ora.occ), (proxy.out_of_field, ora.oof)):
+        assert np.array_equal(got.cpu().numpy().reshape(-1), want)
+    assert 0 < float(proxy.out_of_field.sum()) < params.n_proxy_points            # some points seen, some never
+    assert float(proxy.proxy_supervision_occ.min()) == 0.0                         # free space was carved
