@@ -25,15 +25,18 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
                                                         const float* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ rows,
                                                         long long M, int C, int relu, long long rows_per_block,
-                                                        float* __restrict__ part) {
-    // thread t owns channel c = t % CT (CT = min(C,256) rounded), and rows r = t / CT + k * (256 / CT)
+                                                        double* __restrict__ part) {
+    // thread t owns channel c = t % CT (CT = min(C,256) rounded), and rows r = t / CT + k * (256 / CT).
+    // Sums are carried in DOUBLE from the first add to the per-block partial (torch's CPU BatchNorm accumulates in double
+    // too): the backward combines them as dz - mean(dz) - xhat mean(dz xhat), which cancels to 1e-4 of |dz| over the
+    // constant background of a count map -- fp32 partial sums left 1e-2 relative error in the encoder gradients.
     const int CT = C < 256 ? C : 256;
     const int rpb = 256 / CT;                         // rows processed per pass
     const int c_local = threadIdx.x % CT, rsub = threadIdx.x / CT;
-    __shared__ float sh0[256], sh1[256];
+    __shared__ double sh0[256], sh1[256];
     for (int c0 = 0; c0 < C; c0 += CT) {
         const int c = c0 + c_local;
-        float s0 = 0.f, s1 = 0.f;
+        double s0 = 0.0, s1 = 0.0;
         if (rsub < rpb && c < C) {
             const long long r_begin = (long long)blockIdx.x * rows_per_block;
             const long long r_end = r_begin + rows_per_block < M ? r_begin + rows_per_block : M;
@@ -42,13 +45,13 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
             if (MODE == 0) mu = a[c];          // shift = the first row: sums of (x - k), (x - k)^2 do not cancel when |mean| >> std
             for (long long r = r_begin + rsub; r < r_end; r += rpb) {
                 const float v = a[r * C + c];
-                if (MODE == 0) { const float d = v - mu; s0 += d; s1 += d * d; }
+                if (MODE == 0) { const double d = (double)v - (double)mu; s0 += d; s1 += d * d; }
                 if (MODE == 1) {
                     float dz = v;                                   // a = dy
                     if (relu && !(y[r * C + c] > 0.f)) dz = 0.f;
-                    s0 += dz; s1 += dz * ((b[r * C + c] - mu) * is); // b = x
+                    s0 += (double)dz; s1 += (double)dz * (((double)b[r * C + c] - (double)mu) * (double)is); // b = x
                 }
-                if (MODE == 2) s0 += (rows ? rows[r] : 1.f) * v;
+                if (MODE == 2) s0 += (double)(rows ? rows[r] : 1.f) * (double)v;
             }
         }
         sh0[threadIdx.x] = s0; sh1[threadIdx.x] = s1;
@@ -64,16 +67,19 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 
 // Same reduction for C % 4 == 0 with 16-B loads: thread t owns four channels (float4 column t % CT) and the rows
 // rsub + k * rpb of its block, four rows in flight per iteration.  The scalar kernel above keeps C = 1 (psi BatchNorm).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x4 to_d4(f32x4 v) { return f64x4{(double)v[0], (double)v[1], (double)v[2], (double)v[3]}; }
+
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          const float* __restrict__ y, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ rows,
                                                          long long M, int C4, int relu, long long rows_per_block,
-                                                         float* __restrict__ part) {
+                                                         double* __restrict__ part) {
     const int CT = C4 < 256 ? C4 : 256;
     const int rpb = 256 / CT;
     const int c_local = threadIdx.x % CT, rsub = threadIdx.x / CT;
-    __shared__ f32x4 sh0[256], sh1[256];
+    __shared__ f64x4 sh0[256], sh1[256];
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
     const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
@@ -81,14 +87,14 @@ __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict
     const long long r_end = r_begin + rows_per_block < M ? r_begin + rows_per_block : M;
     for (int c0 = 0; c0 < C4; c0 += CT) {
         const int c = c0 + c_local;
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        f64x4 s0 = {0.0, 0.0, 0.0, 0.0}, s1 = {0.0, 0.0, 0.0, 0.0};
         if (rsub < rpb && c < C4) {
-            f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
-            if (MODE == 1) { mu = reinterpret_cast<const f32x4*>(mean)[c]; is = reinterpret_cast<const f32x4*>(invstd)[c]; }
-            if (MODE == 0) mu = a4[c];         // shift = the first row (see colreduce_kernel)
+            f64x4 mu = {0.0, 0.0, 0.0, 0.0}, is = {0.0, 0.0, 0.0, 0.0};
+            if (MODE == 1) { mu = to_d4(reinterpret_cast<const f32x4*>(mean)[c]); is = to_d4(reinterpret_cast<const f32x4*>(invstd)[c]); }
+            if (MODE == 0) mu = to_d4(a4[c]);  // shift = the first row (see colreduce_kernel)
             auto step = [&](long long r) {
                 const f32x4 v = a4[r * C4 + c];
-                if (MODE == 0) { const f32x4 d = v - mu; s0 += d; s1 += d * d; }
+                if (MODE == 0) { const f64x4 d = to_d4(v) - mu; s0 += d; s1 += d * d; }
                 if (MODE == 1) {
                     f32x4 dz = v;
                     if (relu) {
@@ -96,9 +102,10 @@ __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict
 #pragma unroll
                         for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
                     }
-                    s0 += dz; s1 += dz * ((b4[r * C4 + c] - mu) * is);
+                    const f64x4 dzd = to_d4(dz);
+                    s0 += dzd; s1 += dzd * ((to_d4(b4[r * C4 + c]) - mu) * is);
                 }
-                if (MODE == 2) s0 += v * (rows ? rows[r] : 1.f);
+                if (MODE == 2) s0 += to_d4(v) * (double)(rows ? rows[r] : 1.f);
             };
             long long r = r_begin + rsub;
             for (; r + 3 * rpb < r_end; r += 4 * rpb) { step(r); step(r + rpb); step(r + 2 * rpb); step(r + 3 * rpb); }
@@ -108,8 +115,8 @@ __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict
         __syncthreads();
         if (rsub == 0 && c < C4) {
             for (int k = 1; k < rpb; ++k) { s0 += sh0[k * CT + c_local]; s1 += sh1[k * CT + c_local]; }
-            reinterpret_cast<f32x4*>(part + ((long long)blockIdx.x * 2 + 0) * C4 * 4)[c] = s0;
-            reinterpret_cast<f32x4*>(part + ((long long)blockIdx.x * 2 + 1) * C4 * 4)[c] = s1;
+            reinterpret_cast<f64x4*>(part + ((long long)blockIdx.x * 2 + 0) * C4 * 4)[c] = s0;
+            reinterpret_cast<f64x4*>(part + ((long long)blockIdx.x * 2 + 1) * C4 * 4)[c] = s1;
         }
         __syncthreads();
     }
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict
 // Column sums of the per-block partials part[k][2][C]: a 256-thread block owns 32 channels; thread (c, ks) adds the
 // rows k = ks, ks + 8, ... in double (fixed order), the 8 slices meet in LDS in a fixed order: deterministic, and
 // nblk / 8 dependent loads per thread instead of nblk.
-__device__ __forceinline__ void colsum_pair(const float* __restrict__ part, int nblk, int C, int c, int ks, double (*sh)[2][32],
+__device__ __forceinline__ void colsum_pair(const double* __restrict__ part, int nblk, int C, int c, int ks, double (*sh)[2][32],
                                             double* s0_out, double* s1_out) {
     double s0 = 0, s1 = 0;
     if (c < C)
@@ -134,9 +141,10 @@ __device__ __forceinline__ void colsum_pair(const float* __restrict__ part, int 
 // -> invstd; running stats (momentum, unbiased var).  Shifted sums: fp32 partials lose ~1e-7 (1 + ((mean-k)/std)^2) of
 // the variance instead of 1e-7 mean^2/var (torch uses Welford).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ x_first_row,
-                                                          const float* __restrict__ part, int nblk, int C, long long M, float eps,
+                                                          const double* __restrict__ part, int nblk, int C, long long M, float eps,
                                                           float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                                          float* __restrict__ run_mean, float* __restrict__ run_var) {
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          double* __restrict__ stat_d) {
     __shared__ double sh[8][2][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), ks = threadIdx.x >> 5;
     double s0, s1;
@@ -148,6 +156,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     if (var < 0) var = 0;
     mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    stat_d[c] = mu; stat_d[C + c] = 1.0 / sqrt(var + (double)eps);      // unrounded, for the forward normalisation
     if (run_mean) {
         const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
         run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mu);
@@ -156,8 +165,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 
 // finalize generic: out0[c] (+ out1[c]) = sum over blocks
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C,
-                                                              float* __restrict__ out0, float* __restrict__ out1) {
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ part, int nblk, int C,
+                                                              float* __restrict__ out0, float* __restrict__ out1,
+                                                              double* __restrict__ out_d = nullptr) {
     __shared__ double sh[8][2][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), ks = threadIdx.x >> 5;
     double s0, s1;
@@ -165,50 +175,56 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     if (c >= C || ks != 0) return;
     if (out0) out0[c] = (float)s0;
     if (out1) out1[c] = (float)s1;
+    if (out_d) { out_d[c] = s0; out_d[C + c] = s1; }          // unrounded sums for the backward apply
 }
 
+// y = (x - mean) invstd gamma + beta evaluated per element in double from the unrounded statistics and rounded once: the
+// forward noise decides how many ReLU masks flip against an exact evaluation (each flip moves a gradient tensor by ~1e-4).
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long long total, int C,
-                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const double* __restrict__ stat_d,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int relu, float* __restrict__ y) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
-        float v = (x[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        float v = (float)(((double)x[i] - stat_d[c]) * stat_d[C + c] * (double)gamma[c] + (double)beta[c]);
         if (relu) v = fmaxf(v, 0.f);
         y[i] = v;
     }
 }
 
-// dx = gamma*invstd/M * (M*dz - dbeta - xhat*dgamma)
+// dx = gamma*invstd/M * (M*dz - dbeta - xhat*dgamma), evaluated per element in double from the unrounded sums (sums[0..C) =
+// dbeta, sums[C..2C) = dgamma) and rounded once, like torch's CPU kernel (accscalar_t = double): the bracket cancels.
 __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 const float* __restrict__ y, long long total, int C,
                                                                 long long M, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma,
-                                                                const float* __restrict__ dgamma,
-                                                                const float* __restrict__ dbeta, int relu,
+                                                                const double* __restrict__ sums, int relu,
                                                                 float* __restrict__ dx) {
-    const float invM = 1.f / (float)M;
+    const double invM = 1.0 / (double)M;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         float dz = dy[i];
         if (relu && !(y[i] > 0.f)) dz = 0.f;
-        const float xhat = (x[i] - mean[c]) * invstd[c];
-        dx[i] = gamma[c] * invstd[c] * (dz - invM * (dbeta[c] + xhat * dgamma[c]));
+        const double is = (double)invstd[c];
+        const double xhat = ((double)x[i] - (double)mean[c]) * is;
+        dx[i] = (float)((double)gamma[c] * is * ((double)dz - invM * (sums[c] + xhat * sums[C + c])));
     }
 }
 
 __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict__ x, long long total4, int C4,
-                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const double* __restrict__ stat_d,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int relu, float* __restrict__ y) {
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
     f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    const f64x4* mu4 = reinterpret_cast<const f64x4*>(stat_d);
+    const f64x4* is4 = reinterpret_cast<const f64x4*>(stat_d + 4 * (size_t)C4);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
-        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c], is = reinterpret_cast<const f32x4*>(invstd)[c];
-        const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c], bt = reinterpret_cast<const f32x4*>(beta)[c];
-        f32x4 v = (x4[i] - mu) * is * g + bt;
+        const f64x4 g = to_d4(reinterpret_cast<const f32x4*>(gamma)[c]), bt = to_d4(reinterpret_cast<const f32x4*>(beta)[c]);
+        const f64x4 r = (to_d4(x4[i]) - mu4[c]) * is4[c] * g + bt;
+        f32x4 v = {(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -222,27 +238,28 @@ __global__ __launch_bounds__(256) void bn_backward_apply4_kernel(const float* __
                                                                  long long M, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd,
                                                                  const float* __restrict__ gamma,
-                                                                 const float* __restrict__ dgamma,
-                                                                 const float* __restrict__ dbeta, int relu,
+                                                                 const double* __restrict__ sums, int relu,
                                                                  float* __restrict__ dx) {
-    const float invM = 1.f / (float)M;
+    const double invM = 1.0 / (double)M;
     const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
     f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
+    const f64x4* db4 = reinterpret_cast<const f64x4*>(sums);
+    const f64x4* dg4 = reinterpret_cast<const f64x4*>(sums + 4 * (size_t)C4);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
-        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c], is = reinterpret_cast<const f32x4*>(invstd)[c];
-        const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c];
-        const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[c], db = reinterpret_cast<const f32x4*>(dbeta)[c];
+        const f64x4 mu = to_d4(reinterpret_cast<const f32x4*>(mean)[c]), is = to_d4(reinterpret_cast<const f32x4*>(invstd)[c]);
+        const f64x4 g = to_d4(reinterpret_cast<const f32x4*>(gamma)[c]);
         f32x4 dz = dy4[i];
         if (relu) {
             const f32x4 yy = y4[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
         }
-        const f32x4 xhat = (x4[i] - mu) * is;
-        dx4[i] = g * is * (dz - invM * (db + xhat * dg));
+        const f64x4 xhat = (to_d4(x4[i]) - mu) * is;
+        const f64x4 r = g * is * (to_d4(dz) - invM * (db4[c] + xhat * dg4[c]));
+        dx4[i] = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
     }
 }
 
@@ -798,7 +815,7 @@ inline int blocks_for_rows(long long M, long long* rows_per_block) {
 extern "C" size_t nbp_colreduce_workspace_bytes(long long M, int C) {
     long long rpb;
     const int nblk = blocks_for_rows(M, &rpb);
-    return (size_t)nblk * 2 * C * sizeof(float) + 256;
+    return (size_t)nblk * 2 * C * sizeof(double) + (size_t)2 * C * sizeof(double) + 512;
 }
 
 extern "C" int nbp_bn_train_forward_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
@@ -810,16 +827,17 @@ extern "C" int nbp_bn_train_forward_f32(const float* x, long long M, int C, cons
     hipStream_t st = (hipStream_t)stream;
     long long rpb;
     const int nblk = blocks_for_rows(M, &rpb);
-    float* part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
+    double* part = (double*)(((uintptr_t)ws + 255) / 256 * 256);
     if (C % 4 == 0) colreduce4_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C / 4, 0, rpb, part);
     else colreduce_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, rpb, part);
     int rc = nbp_launch_status();
     if (rc) return rc;
+    double* stat_d = part + (((size_t)nblk * 2 * C + 31) / 32 * 32);        // [2][C] unrounded mean, invstd (32-B aligned)
     bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(x, part, nblk, C, M, eps, momentum, mean, invstd, running_mean,
-                                                                  running_var);
+                                                                  running_var, stat_d);
     if ((rc = nbp_launch_status())) return rc;
-    if (C % 4 == 0) bn_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(x, M * C / 4, C / 4, mean, invstd, gamma, beta, relu, y);
-    else bn_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(x, M * C, C, mean, invstd, gamma, beta, relu, y);
+    if (C % 4 == 0) bn_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(x, M * C / 4, C / 4, stat_d, gamma, beta, relu, y);
+    else bn_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(x, M * C, C, stat_d, gamma, beta, relu, y);
     return nbp_launch_status();
 }
 
@@ -833,19 +851,20 @@ extern "C" int nbp_bn_train_backward_f32(const float* dy, const float* x, const 
     hipStream_t st = (hipStream_t)stream;
     long long rpb;
     const int nblk = blocks_for_rows(M, &rpb);
-    float* part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
+    double* part = (double*)(((uintptr_t)ws + 255) / 256 * 256);
     if (C % 4 == 0) colreduce4_kernel<1><<<nblk, 256, 0, st>>>(dy, x, y_or_null, mean, invstd, nullptr, M, C / 4, relu, rpb, part);
     else colreduce_kernel<1><<<nblk, 256, 0, st>>>(dy, x, y_or_null, mean, invstd, nullptr, M, C, relu, rpb, part);
     int rc = nbp_launch_status();
     if (rc) return rc;
-    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, dbeta, dgamma);
+    double* sums = part + (((size_t)nblk * 2 * C + 31) / 32 * 32);          // [2][C] unrounded dbeta, dgamma (32-B aligned)
+    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, dbeta, dgamma, sums);
     if ((rc = nbp_launch_status())) return rc;
     if (C % 4 == 0)
         bn_backward_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(dy, x, y_or_null, M * C / 4, C / 4, M, mean, invstd,
-                                                                              gamma, dgamma, dbeta, relu, dx);
+                                                                              gamma, sums, relu, dx);
     else
         bn_backward_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(dy, x, y_or_null, M * C, C, M, mean, invstd, gamma,
-                                                                         dgamma, dbeta, relu, dx);
+                                                                         sums, relu, dx);
     return nbp_launch_status();
 }
 
@@ -858,7 +877,7 @@ extern "C" int nbp_colsum_f32(const float* x, const float* rows_or_null, long lo
     hipStream_t st = (hipStream_t)stream;
     long long rpb;
     const int nblk = blocks_for_rows(M, &rpb);
-    float* part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
+    double* part = (double*)(((uintptr_t)ws + 255) / 256 * 256);
     if (C % 4 == 0) colreduce4_kernel<2><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, rows_or_null, M, C / 4, 0, rpb, part);
     else colreduce_kernel<2><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, rows_or_null, M, C, 0, rpb, part);
     int rc = nbp_launch_status();

@@ -85,19 +85,18 @@ def gen_network(model):
         print(tag, "out1", float(o1.abs().max()), "out2", float(o2.min()), float(o2.max()))
 
 
-def gen_training(model):
+def gen_training(model, B=2, S=32, K=7, tag="S32B2"):
     """Train-mode forward (batch-statistics BatchNorm), NBP.loss, parameter gradients and the running statistics
-    after one forward of the REFERENCE module: pins oracle/nbp_net.py's train path and nbp_loss."""
+    after one forward of the REFERENCE module: pins oracle/nbp_net.py's train path and nbp_loss.  S32B2 is the small
+    (ill-conditioned: the bottleneck BatchNorm sees 8 samples) case, S128B4 the well-conditioned one (256 samples)."""
     from nextbestpath_amd.utility.synthetic import make_nbp_state_dict, make_count_maps
     torch.set_num_threads(8)
     sd = make_nbp_state_dict(9)
     net = model.NBP()
     net.load_state_dict(sd, strict=True)
     net.train()
-    B, S = 2, 32
     x = make_count_maps(B, S, seed=31)
     g = torch.Generator().manual_seed(32)
-    K = 7
     coords = torch.stack([torch.randint(0, B, (K,), generator=g), torch.randint(0, 8, (K,), generator=g),
                           torch.randint(0, S // 4, (K,), generator=g), torch.randint(0, S // 4, (K,), generator=g)], 1)
     gains = torch.rand(K, generator=g) * 5
@@ -118,11 +117,11 @@ def gen_training(model):
         grads[kk] = gflat[::stride].float().numpy()
         grads[kk + "__stats"] = np.array([stride, float(gflat.sum()), float(gflat.abs().sum())])
     bufs = dict(net.named_buffers())
-    np.savez_compressed(os.path.join(HERE, "nbp_train_S32B2.npz"), x=x.numpy(), coords=coords.numpy(), gains=gains.numpy(),
+    np.savez_compressed(os.path.join(HERE, f"nbp_train_{tag}.npz"), x=x.numpy(), coords=coords.numpy(), gains=gains.numpy(),
                         gt=gt.numpy(), out1=o1.detach().numpy(), out2=o2.detach().numpy(), loss=float(loss),
                         grad_keys=np.array(keys), run_mean_Conv1=bufs["Conv1.conv.1.running_mean"].numpy(),
                         run_var_Up5_2=bufs["Up5_2.up.2.running_var"].numpy(), **grads)
-    print("train: loss", float(loss), "|grad Conv1|", float(named[keys[0]].grad.abs().max()))
+    print(f"train {tag}: loss", float(loss), "|grad Conv1|", float(named[keys[0]].grad.abs().max()))
 
 
 def gen_maps(utils):
@@ -388,9 +387,13 @@ if __name__ == "__main__":
     if "--only-scene" in sys.argv:
         gen_scene(mu)
         sys.exit(0)
+    if "--only-train-large" in sys.argv:
+        gen_training(model, B=4, S=128, K=40, tag="S128B4")
+        sys.exit(0)
     gen_maps(utils)
     gen_planner(ltu, mu)
     gen_replan(utils, ltu, mu)
     gen_scene(mu)
     gen_network(model)
     gen_training(model)
+    gen_training(model, B=4, S=128, K=40, tag="S128B4")

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import maps as omaps
@@ -79,10 +80,12 @@ def test_maps_edge_cases():
     assert out[:5].sum() == 1
 
 
-def test_training_oracle_vs_reference(nbp_weights, golden_dir):
+@pytest.mark.parametrize("tag", ["S32B2", "S128B4"])
+def test_training_oracle_vs_reference(nbp_weights, golden_dir, tag):
     """Train-mode forward, NBP.loss and parameter gradients of the REFERENCE module (tests/golden/make_golden.py::
-    gen_training) reproduced by the oracle's functional restatement + autograd."""
-    g = _load(golden_dir, "nbp_train_S32B2.npz")
+    gen_training) reproduced by the oracle's functional restatement + autograd (small ill-conditioned and
+    well-conditioned fixture)."""
+    g = _load(golden_dir, f"nbp_train_{tag}.npz")
     sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
           for k, v in nbp_weights.items()}
     x, coords = torch.from_numpy(g["x"]), torch.from_numpy(g["coords"])
