@@ -225,6 +225,40 @@ int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* faces, int n
                         float z_clip, int bin_cap, float* zbuf, int* overflow_flag, void* ws,
                         size_t ws_bytes, void* stream);
 
+/* The same render with colours (mu:2743-2763): rgb [n_frames,H,W,3] = ambient x barycentric interpolation of the winning
+ * face's vertex colours vcolors3 [V,3] (SoftPhongShader under AmbientLights on a TexturesVertex mesh), white background,
+ * then torchvision's adjust_contrast(contrast_factor) (identity for 1); zbuf as above.  ws >= nbp_raster_rgb_workspace_bytes. */
+size_t nbp_raster_rgb_workspace_bytes(int n_faces, int n_frames, int H, int W);
+int nbp_raster_rgbz_f32(const float* verts, int n_verts, const int* faces, int n_faces, const float* vcolors3,
+                        const float* cams12_host, int n_frames, int H, int W, float tan_half_fov, float z_clip,
+                        float ambient, float contrast_factor, float* zbuf, float* rgb, void* ws, size_t ws_bytes,
+                        void* stream);
+/* nbp_unproject_append_f32 that also appends the colours of the kept pixels (rgb [n_frames,H,W,3]) to cloud_rgb
+ * [capacity,3] at the same indices (compute_partial_point_cloud with images, mu:2840-2845). */
+int nbp_unproject_append_rgb_f32(const float* depth, const unsigned char* mask_or_null, const float* rgb,
+                                 const float* cams12_host, int n_frames, int H, int W, float tan_half_fov,
+                                 float fov_range, double gathering_factor, unsigned seed, int* counts2,
+                                 float* cloud, float* cloud_rgb, long long* cloud_count, long long capacity,
+                                 void* ws, size_t ws_bytes, void* stream);
+
+/* Deferred shading (the step loop's form of the colour render): the rasteriser also returns zface [n_frames,H,W] u64 =
+ * (depth bits << 32 | nearest face), ~0 for background; colours are then evaluated only where they are consumed --
+ * nbp_shade_image_f32 gives the whole rgb image (contrast_factor must be 1: a contrast change needs the eager
+ * nbp_raster_rgbz_f32), nbp_unproject_append_shaded_f32 shades just the kept pixels (about 5 %) while appending them.
+ * Both rebuild the face record with the rasteriser's arithmetic: colours are bit-identical to nbp_raster_rgbz_f32's. */
+int nbp_raster_zface_f32(const float* verts, int n_verts, const int* faces, int n_faces, const float* cams12_host,
+                         int n_frames, int H, int W, float tan_half_fov, float z_clip, float* zbuf, void* zface,
+                         void* ws, size_t ws_bytes, void* stream);
+int nbp_shade_image_f32(const void* zface, const float* verts, const int* faces, const float* vcolors3,
+                        const float* cams12_host, int n_frames, int H, int W, float tan_half_fov, float ambient,
+                        float contrast_factor, float* rgb, void* stream);
+int nbp_unproject_append_shaded_f32(const float* depth, const unsigned char* mask_or_null, const void* zface,
+                                    const float* verts, const int* faces, const float* vcolors3,
+                                    const float* cams12_host, int n_frames, int H, int W, float tan_half_fov,
+                                    float fov_range, double gathering_factor, unsigned seed, float ambient,
+                                    int* counts2, float* cloud, float* cloud_rgb, long long* cloud_count,
+                                    long long capacity, void* ws, size_t ws_bytes, void* stream);
+
 /* line_segment_mesh_intersection (mu:120-151): hit[e] = 1 iff the ray from segs6[e][0:3] towards
  * segs6[e][3:6] meets a triangle at distance < |segment|. */
 int nbp_segments_hit_mesh_f32(const float* verts, const int* faces, int n_faces, const float* segs6,

@@ -107,6 +107,14 @@ SIGNATURES["nbp_coverage_count_planned_f32"] = (_i, [_vp, _i, _f, _fpp, _fpp, _v
                                                      _vp])
 SIGNATURES["nbp_points_in_fov_u8"] = (_i, [_vp, _i, _fpp, _i, _i, _i, _f, _f, _vp, _vp, _vp])
 SIGNATURES["nbp_sample_points_f32"] = (_i, [_vp, _ll, _vp, _ll, C.c_uint, _vp, _vp, _vp])
+SIGNATURES["nbp_raster_rgb_workspace_bytes"] = (_sz, [_i, _i, _i, _i])
+SIGNATURES["nbp_raster_rgbz_f32"] = (_i, [_vp, _i, _vp, _i, _vp, _fpp, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _sz, _vp])
+SIGNATURES["nbp_unproject_append_rgb_f32"] = (_i, [_vp, _vp, _vp, _fpp, _i, _i, _i, _f, _f, _d, C.c_uint, _vp, _vp, _vp, _vp, _ll,
+                                                   _vp, _sz, _vp])
+SIGNATURES["nbp_raster_zface_f32"] = (_i, [_vp, _i, _vp, _i, _fpp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp])
+SIGNATURES["nbp_shade_image_f32"] = (_i, [_vp, _vp, _vp, _vp, _fpp, _i, _i, _i, _f, _f, _f, _vp, _vp])
+SIGNATURES["nbp_unproject_append_shaded_f32"] = (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _fpp, _i, _i, _i, _f, _f, _d, C.c_uint, _f,
+                                                      _vp, _vp, _vp, _vp, _ll, _vp, _sz, _vp])
 SIGNATURES["nbp_slice_obstacle_f32"] = (_i, [_vp, _vp, _i, _f, _f, _f, _i, _f, _f, _f, _vp, _vp])
 
 _lock = threading.Lock()

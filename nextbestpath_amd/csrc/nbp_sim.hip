@@ -23,6 +23,48 @@ struct Cam { float R[9]; float T[3]; };
 constexpr int MAX_CAMS = 8;
 struct CamSet { Cam c[MAX_CAMS]; };   // cameras travel in the kernel arguments (no H2D copy, no sync)
 
+__device__ __forceinline__ void to_view(const float* p, const float* R, const float* T, float* o) {
+    // X_view = X_world R + T (row vector): o_j = sum_k p_k R[k][j] + T_j
+    o[0] = ((p[0] * R[0] + p[1] * R[3]) + p[2] * R[6]) + T[0];
+    o[1] = ((p[0] * R[1] + p[1] * R[4]) + p[2] * R[7]) + T[1];
+    o[2] = ((p[0] * R[2] + p[1] * R[5]) + p[2] * R[8]) + T[2];
+}
+
+// Colour of pixel (row, col) of a frame whose nearest face there is fi: the face record is rebuilt from the mesh with the
+// arithmetic of raster_setup_kernel (bit-identical e1, e2, v0, q), the barycentrics come from the same ray cast as the depth,
+// colour = ambient x interpolated vertex colours (SoftPhongShader under AmbientLights on a TexturesVertex mesh).
+__device__ __forceinline__ void shade_pixel(const float* __restrict__ verts, const int* __restrict__ faces,
+                                            const float* __restrict__ vcolors, const Cam& cam, int fi, int row, int col, int H,
+                                            int W, float tanh_fov, float ambient, float* rgb3) {
+    float v[3][3];
+    const int i0 = faces[3 * (size_t)fi], i1 = faces[3 * (size_t)fi + 1], i2 = faces[3 * (size_t)fi + 2];
+    to_view(verts + 3 * (size_t)i0, cam.R, cam.T, v[0]);
+    to_view(verts + 3 * (size_t)i1, cam.R, cam.T, v[1]);
+    to_view(verts + 3 * (size_t)i2, cam.R, cam.T, v[2]);
+    float e1[3], e2[3], q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { e1[c] = v[1][c] - v[0][c]; e2[c] = v[2][c] - v[0][c]; }
+    q[0] = e1[1] * v[0][2] - e1[2] * v[0][1];
+    q[1] = e1[2] * v[0][0] - e1[0] * v[0][2];
+    q[2] = e1[0] * v[0][1] - e1[1] * v[0][0];
+    const int s = H < W ? H : W;
+    const float dx = (((float)W - (2.f * col + 1.f)) / (float)s) * tanh_fov;
+    const float dy = (((float)H - (2.f * row + 1.f)) / (float)s) * tanh_fov;
+    const float p0 = dy * e2[2] - e2[1];
+    const float p1 = e2[0] - dx * e2[2];
+    const float p2 = dx * e2[1] - dy * e2[0];
+    const float inv = 1.f / ((e1[0] * p0 + e1[1] * p1) + e1[2] * p2);
+    const float u = -((v[0][0] * p0 + v[0][1] * p1) + v[0][2] * p2) * inv;
+    const float vv = ((dx * q[0] + dy * q[1]) + q[2]) * inv;
+    const float w0 = (1.f - u) - vv;
+    const float* c0 = vcolors + 3 * (size_t)i0;
+    const float* c1 = vcolors + 3 * (size_t)i1;
+    const float* c2 = vcolors + 3 * (size_t)i2;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgb3[k] = ambient * ((w0 * c0[k] + u * c1[k]) + vv * c2[k]);
+}
+
+
 // Pixel (row, col) with view-space depth z -> world point.  fp32 op order is part of the
 // contract with oracle/camera.py (no FMA contraction in this file).
 __device__ __forceinline__ void unproject_pixel(int row, int col, float z, int H, int W, float tanh_fov,
@@ -197,7 +239,11 @@ __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __re
                                                                const unsigned* __restrict__ list,
                                                                const int* __restrict__ counts, float* __restrict__ cloud,
                                                                long long* __restrict__ cloud_count,
-                                                               long long capacity, int n_frames, int* __restrict__ done_ticket) {
+                                                               long long capacity, int n_frames, int* __restrict__ done_ticket,
+                                                               const float* __restrict__ rgb, float* __restrict__ cloud_rgb,
+                                                               const unsigned long long* __restrict__ zface,
+                                                               const float* __restrict__ verts, const int* __restrict__ faces,
+                                                               const float* __restrict__ vcolors, float ambient) {
     const int f = blockIdx.y;
     const int HW = H * W;
     const int nvalid = counts[2 * f], nkeep = counts[2 * f + 1];
@@ -214,6 +260,18 @@ __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __re
         unproject_pixel(row, col, depth[(size_t)f * HW + pix], H, W, tanh_fov, cam.R, cam.T, o);
         float* dst = cloud + (base + j) * 3;
         dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+        if (cloud_rgb) {                                   // the colours of the kept pixels (mu:2840-2845)
+            float* cd = cloud_rgb + (base + j) * 3;
+            if (zface) {                                   // deferred shading: only the ~5 % of pixels that are kept
+                const unsigned long long zf = zface[(size_t)f * HW + pix];
+                float c[3] = {1.f, 1.f, 1.f};
+                if (zf != ~0ull) shade_pixel(verts, faces, vcolors, cam, (int)(unsigned)zf, row, col, H, W, tanh_fov, ambient, c);
+                cd[0] = c[0]; cd[1] = c[1]; cd[2] = c[2];
+            } else {
+                const float* c = rgb + 3 * ((size_t)f * HW + pix);
+                cd[0] = c[0]; cd[1] = c[1]; cd[2] = c[2];
+            }
+        }
     }
     if (!done_ticket) return;
     // The block that finishes last advances the cloud size: every block has read *cloud_count by then.
@@ -245,13 +303,6 @@ __global__ void cloud_count_update_kernel(const int* __restrict__ counts, int F,
 constexpr int TILE = 8;            // 8x8 pixel tiles, one wave per tile
 struct FaceRec { float e1[3], e2[3], v0[3], q[3], tnum, pad[3]; };   // 64 bytes
 
-__device__ __forceinline__ void to_view(const float* p, const float* R, const float* T, float* o) {
-    // X_view = X_world R + T (row vector): o_j = sum_k p_k R[k][j] + T_j
-    o[0] = ((p[0] * R[0] + p[1] * R[3]) + p[2] * R[6]) + T[0];
-    o[1] = ((p[0] * R[1] + p[1] * R[4]) + p[2] * R[7]) + T[1];
-    o[2] = ((p[0] * R[2] + p[1] * R[5]) + p[2] * R[8]) + T[2];
-}
-
 // Two-level binning without capacity limits: fine tiles of 8x8 pixels (one wave), coarse tiles of 8x8 fine tiles.
 // raster_setup_kernel (one thread per face and frame) transforms the face, clips its screen box against the near plane and
 // appends (face id, fine-tile box) to the list of every coarse tile the box touches -- one wave-aggregated atomic per
@@ -270,11 +321,13 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const float* __restri
                                                            int n_faces, CamSet cams, int H, int W,
                                                            float tanh_fov, float zclip, FaceRec* __restrict__ recs,
                                                            int ctiles_x, int ctiles_y, int* __restrict__ ccount,
-                                                           BinEntry* __restrict__ clist, unsigned* __restrict__ zbuf_bits) {
+                                                           BinEntry* __restrict__ clist, unsigned* __restrict__ zbuf_bits,
+                                                           unsigned long long* __restrict__ zface) {
     const int fr = blockIdx.y;
     const int fi = blockIdx.x * blockDim.x + threadIdx.x;
-    // z-buffer of this frame = "empty" (the tile kernel merges with atomicMin)
-    for (int p = fi; p < H * W; p += gridDim.x * blockDim.x) zbuf_bits[(size_t)fr * H * W + p] = ZBUF_EMPTY;
+    // z-buffer (or the (z, face) buffer of the colour path) of this frame = "empty": the tile kernel merges with atomicMin
+    if (zface) for (int p = fi; p < H * W; p += gridDim.x * blockDim.x) zface[(size_t)fr * H * W + p] = ~0ull;
+    else for (int p = fi; p < H * W; p += gridDim.x * blockDim.x) zbuf_bits[(size_t)fr * H * W + p] = ZBUF_EMPTY;
     bool have = false;
     int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
     if (fi < n_faces) {
@@ -357,7 +410,8 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const float* __restri
 __global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restrict__ recs, int n_faces, int H, int W,
                                                          float tanh_fov, float zclip, int tiles_x, int tiles_y, int ctiles_x,
                                                          int ctiles_y, const int* __restrict__ ccount,
-                                                         const BinEntry* __restrict__ clist, unsigned* __restrict__ zbuf_bits) {
+                                                         const BinEntry* __restrict__ clist, unsigned* __restrict__ zbuf_bits,
+                                                         unsigned long long* __restrict__ zface) {
     __shared__ int hits[SEG];
     __shared__ __attribute__((aligned(16))) FaceRec sh[64];
     const int fr = blockIdx.y;
@@ -398,6 +452,7 @@ __global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restri
     const float dx = ndc_x * tanh_fov, dy = ndc_y * tanh_fov;   // dz = 1
     const FaceRec* rb = recs + (size_t)fr * n_faces;
     float zbest = 3.0e38f;
+    int fbest = -1;
     const float eps = 1e-6f;
     // pass 2: 64 face records at a time through LDS (one gather round trip per 64 faces), every lane ray-casts its pixel
     for (int hb = 0; hb < nh; hb += 64) {
@@ -417,15 +472,63 @@ __global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restri
             const float u = -((f.v0[0] * p0 + f.v0[1] * p1) + f.v0[2] * p2) * inv;
             const float vv = ((dx * f.q[0] + dy * f.q[1]) + f.q[2]) * inv;
             const float z = f.tnum * inv;
-            if (u >= -eps && vv >= -eps && u + vv <= 1.f + eps && z > zclip && z < zbest) zbest = z;
+            // equal depths (shared edges): the lowest face id wins, whatever the order of the lists (for the colours)
+            if (u >= -eps && vv >= -eps && u + vv <= 1.f + eps && z > zclip) {
+                const int fid = hits[hb + k];
+                if (z < zbest || (z == zbest && fid < fbest)) { zbest = z; fbest = fid; }
+            }
         }
     }
-    if (row < H && col < W && zbest < 1.0e38f) atomicMin(&zbuf_bits[((size_t)fr * H + row) * W + col], __float_as_uint(zbest));
+    if (row < H && col < W && zbest < 1.0e38f) {
+        const size_t pix = ((size_t)fr * H + row) * W + col;
+        if (zface) atomicMin(&zface[pix], ((unsigned long long)__float_as_uint(zbest) << 32) | (unsigned)fbest);
+        else atomicMin(&zbuf_bits[pix], __float_as_uint(zbest));
+    }
 }
 
 __global__ __launch_bounds__(256) void raster_finalize_kernel(float* __restrict__ zbuf, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         if (!(zbuf[i] < 1.0e38f)) zbuf[i] = -1.f;
+}
+
+// Shading of Camera.capture_image (mu:2743-2763): SoftPhongShader under AmbientLights = ambient x texel, the texel being
+// the barycentric interpolation of the winning face's vertex colours (TexturesVertex; perspective-correct barycentrics =
+// those of the view-space ray cast), white background; then the z-buffer value.  One thread per pixel recomputes the
+// barycentrics of its winning face from the face record.  gray_sum[frame] accumulates the luminance for adjust_contrast.
+__global__ __launch_bounds__(256) void raster_shade_kernel(const unsigned long long* __restrict__ zface,
+                                                           const float* __restrict__ verts, const int* __restrict__ faces,
+                                                           const float* __restrict__ vcolors, CamSet cams, int H, int W,
+                                                           float tanh_fov, float ambient, float* __restrict__ zbuf_or_null,
+                                                           float* __restrict__ rgb_or_null, double* __restrict__ gray_sum) {
+    const int fr = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    float gray = 0.f;
+    if (p < H * W) {
+        const size_t pix = (size_t)fr * H * W + p;
+        const unsigned long long zf = zface[pix];
+        float c[3] = {1.f, 1.f, 1.f};
+        if (zbuf_or_null) zbuf_or_null[pix] = zf != ~0ull ? __uint_as_float((unsigned)(zf >> 32)) : -1.f;
+        if (rgb_or_null) {
+            if (zf != ~0ull) shade_pixel(verts, faces, vcolors, cams.c[fr], (int)(unsigned)zf, p / W, p % W, H, W, tanh_fov, ambient, c);
+            rgb_or_null[3 * pix] = c[0]; rgb_or_null[3 * pix + 1] = c[1]; rgb_or_null[3 * pix + 2] = c[2];
+            gray = (0.299f * c[0] + 0.587f * c[1]) + 0.114f * c[2];
+        }
+    }
+    if (!gray_sum) return;
+    double gs = (double)gray;
+    for (int o = 32; o; o >>= 1) gs += __shfl_xor(gs, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&gray_sum[fr], gs);
+}
+
+// torchvision adjust_contrast (mu:2760): out = clamp(factor * img + (1 - factor) * mean(gray), 0, 1)
+__global__ __launch_bounds__(256) void contrast_kernel(float* __restrict__ rgb, int HW3, const double* __restrict__ gray_sum,
+                                                       int HW, float factor) {
+    const int fr = blockIdx.y;
+    const float mean = (float)(gray_sum[fr] / (double)HW);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW3; i += gridDim.x * blockDim.x) {
+        const float v = factor * rgb[(size_t)fr * HW3 + i] + (1.f - factor) * mean;
+        rgb[(size_t)fr * HW3 + i] = fminf(fmaxf(v, 0.f), 1.f);
+    }
 }
 
 // ------------------------------------------------------------------ ray / mesh tests (world space)
@@ -573,11 +676,50 @@ static CamSet camset_from_host(const float* cams12_host, int n) {
     return cs;
 }
 
+struct ShadeSrc { const unsigned long long* zface; const float* verts; const int* faces; const float* vcolors; float ambient; };
+static int unproject_launch(const float* depth, const unsigned char* mask_or_null, const float* cams12_host, int n_frames, int H,
+                            int W, float tan_half_fov, float fov_range, double gathering_factor, unsigned seed, int* counts2,
+                            float* cloud, long long* cloud_count, long long capacity, void* ws, size_t ws_bytes, void* stream,
+                            const float* rgb_or_null, float* cloud_rgb_or_null, ShadeSrc sh = ShadeSrc{nullptr, nullptr, nullptr, nullptr, 0.f});
+
 extern "C" int nbp_unproject_append_f32(const float* depth, const unsigned char* mask_or_null, const float* cams12_host,
                                         int n_frames, int H, int W, float tan_half_fov, float fov_range,
                                         double gathering_factor, unsigned seed, int* counts2, float* cloud,
                                         long long* cloud_count, long long capacity, void* ws, size_t ws_bytes,
                                         void* stream) {
+    NBP_ENTER();
+    return unproject_launch(depth, mask_or_null, cams12_host, n_frames, H, W, tan_half_fov, fov_range, gathering_factor, seed,
+                            counts2, cloud, cloud_count, capacity, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int nbp_unproject_append_rgb_f32(const float* depth, const unsigned char* mask_or_null, const float* rgb,
+                                            const float* cams12_host, int n_frames, int H, int W, float tan_half_fov,
+                                            float fov_range, double gathering_factor, unsigned seed, int* counts2, float* cloud,
+                                            float* cloud_rgb, long long* cloud_count, long long capacity, void* ws,
+                                            size_t ws_bytes, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!rgb || !cloud_rgb, NBP_E_ARG);
+    return unproject_launch(depth, mask_or_null, cams12_host, n_frames, H, W, tan_half_fov, fov_range, gathering_factor, seed,
+                            counts2, cloud, cloud_count, capacity, ws, ws_bytes, stream, rgb, cloud_rgb);
+}
+
+extern "C" int nbp_unproject_append_shaded_f32(const float* depth, const unsigned char* mask_or_null, const void* zface,
+                                               const float* verts, const int* faces, const float* vcolors3,
+                                               const float* cams12_host, int n_frames, int H, int W, float tan_half_fov,
+                                               float fov_range, double gathering_factor, unsigned seed, float ambient,
+                                               int* counts2, float* cloud, float* cloud_rgb, long long* cloud_count,
+                                               long long capacity, void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!zface || !verts || !faces || !vcolors3 || !cloud_rgb, NBP_E_ARG);
+    return unproject_launch(depth, mask_or_null, cams12_host, n_frames, H, W, tan_half_fov, fov_range, gathering_factor, seed,
+                            counts2, cloud, cloud_count, capacity, ws, ws_bytes, stream, nullptr, cloud_rgb,
+                            ShadeSrc{(const unsigned long long*)zface, verts, faces, vcolors3, ambient});
+}
+
+static int unproject_launch(const float* depth, const unsigned char* mask_or_null, const float* cams12_host, int n_frames, int H,
+                            int W, float tan_half_fov, float fov_range, double gathering_factor, unsigned seed, int* counts2,
+                            float* cloud, long long* cloud_count, long long capacity, void* ws, size_t ws_bytes, void* stream,
+                            const float* rgb_or_null, float* cloud_rgb_or_null, ShadeSrc sh) {
     NBP_ENTER();
     NBP_RETURN_IF(!depth || !cams12_host || !counts2 || !cloud || !cloud_count || !ws, NBP_E_ARG);
     NBP_RETURN_IF(n_frames < 1 || n_frames > MAX_CAMS || H < 2 || W < 2 || capacity < 1, NBP_E_ARG);
@@ -604,7 +746,8 @@ extern "C" int nbp_unproject_append_f32(const float* depth, const unsigned char*
                                                       counts2);
         if ((rc = nbp_launch_status())) return rc;
         unproject_append_kernel<<<grid, 256, 0, st>>>(depth, cams, H, W, tan_half_fov, seed, list, counts2, cloud, cloud_count,
-                                                      capacity, n_frames, ticket);
+                                                      capacity, n_frames, ticket, rgb_or_null, cloud_rgb_or_null, sh.zface, sh.verts, sh.faces,
+                                                      sh.vcolors, sh.ambient);
         return nbp_launch_status();
     }
     dim3 gc((unsigned)nblk, (unsigned)n_frames);
@@ -614,21 +757,90 @@ extern "C" int nbp_unproject_append_f32(const float* depth, const unsigned char*
                                                  list, counts2);
     if ((rc = nbp_launch_status())) return rc;
     unproject_append_kernel<<<grid, 256, 0, st>>>(depth, cams, H, W, tan_half_fov, seed, list, counts2, cloud, cloud_count,
-                                                  capacity, n_frames, nullptr);
+                                                  capacity, n_frames, nullptr, rgb_or_null, cloud_rgb_or_null, sh.zface, sh.verts, sh.faces,
+                                                  sh.vcolors, sh.ambient);
     if ((rc = nbp_launch_status())) return rc;
     cloud_count_update_kernel<<<1, 64, 0, st>>>(counts2, n_frames, cloud_count, capacity);
     return nbp_launch_status();
 }
 
-extern "C" size_t nbp_raster_workspace_bytes(int n_faces, int n_frames, int H, int W, int bin_cap) {
-    (void)bin_cap;
+static size_t raster_ws_bytes(int n_faces, int n_frames, int H, int W, bool rgb) {
     if (n_faces < 1 || n_frames < 1 || H < 1 || W < 1) return 0;
     const size_t nct = (size_t)nbp_cdiv(nbp_cdiv(W, TILE), COARSE) * nbp_cdiv(nbp_cdiv(H, TILE), COARSE) * n_frames;
     size_t b = 256;
     b += ((size_t)n_frames * n_faces * sizeof(FaceRec) + 255) / 256 * 256;
     b += (nct * sizeof(int) + 255) / 256 * 256;
     b += (nct * n_faces * sizeof(BinEntry) + 255) / 256 * 256;
+    if (rgb) b += ((size_t)n_frames * H * W * 8 + 255) / 256 * 256 + 256;
     return b + 256;
+}
+
+extern "C" size_t nbp_raster_workspace_bytes(int n_faces, int n_frames, int H, int W, int bin_cap) {
+    (void)bin_cap;
+    return raster_ws_bytes(n_faces, n_frames, H, W, false);
+}
+
+extern "C" size_t nbp_raster_rgb_workspace_bytes(int n_faces, int n_frames, int H, int W) {
+    return raster_ws_bytes(n_faces, n_frames, H, W, true);
+}
+
+static int raster_launch(const float* verts, int n_verts, const int* faces, int n_faces, const float* cams12_host, int n_frames,
+                         int H, int W, float tan_half_fov, float z_clip, float* zbuf, const float* vcolors, float ambient,
+                         float contrast, float* rgb, void* ws, size_t ws_bytes, void* stream,
+                         unsigned long long* zface_out = nullptr) {
+    NBP_RETURN_IF(!verts || !faces || !cams12_host || !zbuf || !ws, NBP_E_ARG);
+    NBP_RETURN_IF(n_verts < 3 || n_faces < 1 || n_frames < 1 || n_frames > MAX_CAMS || H < 1 || W < 1, NBP_E_ARG);
+    const int tiles_x = (int)nbp_cdiv(W, TILE), tiles_y = (int)nbp_cdiv(H, TILE);
+    NBP_RETURN_IF(tiles_x > 256 || tiles_y > 256, NBP_E_SHAPE);          // fine-tile coordinates are packed in 8 bits
+    NBP_RETURN_IF(ws_bytes < raster_ws_bytes(n_faces, n_frames, H, W, rgb != nullptr && !zface_out), NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    const int ctiles_x = (int)nbp_cdiv(tiles_x, COARSE), ctiles_y = (int)nbp_cdiv(tiles_y, COARSE);
+    const size_t nct = (size_t)ctiles_x * ctiles_y * n_frames;
+    char* p = (char*)(((uintptr_t)ws + 255) / 256 * 256);
+    FaceRec* recs = (FaceRec*)p; p += ((size_t)n_frames * n_faces * sizeof(FaceRec) + 255) / 256 * 256;
+    int* ccount = (int*)p; p += (nct * sizeof(int) + 255) / 256 * 256;
+    BinEntry* clist = (BinEntry*)p; p += (nct * n_faces * sizeof(BinEntry) + 255) / 256 * 256;
+    unsigned long long* zface = nullptr;
+    double* gray = nullptr;
+    const long long npx = (long long)n_frames * H * W;
+    if (zface_out) {
+        zface = zface_out;
+        gray = (double*)p;                                     // 8 doubles fit the workspace's slack
+    } else if (rgb) {
+        zface = (unsigned long long*)p; p += ((size_t)npx * 8 + 255) / 256 * 256;
+        gray = (double*)p;
+    }
+    hipError_t e = hipMemsetAsync(ccount, 0, nct * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    dim3 g1((unsigned)nbp_cdiv(n_faces, 256), (unsigned)n_frames);
+    raster_setup_kernel<<<g1, 256, 0, st>>>(verts, faces, n_faces, camset_from_host(cams12_host, n_frames), H, W,
+                                            tan_half_fov, z_clip, recs, ctiles_x, ctiles_y, ccount, clist, (unsigned*)zbuf, zface);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    const bool need_gray = rgb && contrast != 1.f;            // adjust_contrast(1) is the identity: no luminance sum needed
+    if (need_gray) {
+        e = hipMemsetAsync(gray, 0, (size_t)n_frames * sizeof(double), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int nseg = (int)nbp_cdiv(n_faces, SEG);
+    dim3 g2((unsigned)(tiles_x * tiles_y * nseg), (unsigned)n_frames);
+    raster_tile_kernel<<<g2, 64, 0, st>>>(recs, n_faces, H, W, tan_half_fov, z_clip, tiles_x, tiles_y, ctiles_x, ctiles_y,
+                                          ccount, clist, (unsigned*)zbuf, zface);
+    if ((rc = nbp_launch_status())) return rc;
+    if (!zface) {
+        raster_finalize_kernel<<<nbp_ew_grid(npx, 256), 256, 0, st>>>(zbuf, npx);
+        return nbp_launch_status();
+    }
+    dim3 g3((unsigned)nbp_cdiv((long long)H * W, 256), (unsigned)n_frames);
+    raster_shade_kernel<<<g3, 256, 0, st>>>(zface, verts, faces, vcolors, camset_from_host(cams12_host, n_frames), H, W,
+                                            tan_half_fov, ambient, zbuf, rgb, need_gray ? gray : nullptr);
+    if ((rc = nbp_launch_status())) return rc;
+    if (need_gray) {
+        dim3 g4((unsigned)nbp_ew_grid((long long)H * W * 3, 256), (unsigned)n_frames);
+        contrast_kernel<<<g4, 256, 0, st>>>(rgb, H * W * 3, gray, H * W, contrast);
+        rc = nbp_launch_status();
+    }
+    return rc;
 }
 
 extern "C" int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* faces, int n_faces, const float* cams12_host,
@@ -636,32 +848,40 @@ extern "C" int nbp_raster_zbuf_f32(const float* verts, int n_verts, const int* f
                                    int* overflow_flag, void* ws, size_t ws_bytes, void* stream) {
     NBP_ENTER();
     (void)bin_cap; (void)overflow_flag;                      // kept for ABI compatibility: the lists cannot overflow
-    NBP_RETURN_IF(!verts || !faces || !cams12_host || !zbuf || !ws, NBP_E_ARG);
-    NBP_RETURN_IF(n_verts < 3 || n_faces < 1 || n_frames < 1 || n_frames > MAX_CAMS || H < 1 || W < 1, NBP_E_ARG);
-    const int tiles_x = (int)nbp_cdiv(W, TILE), tiles_y = (int)nbp_cdiv(H, TILE);
-    NBP_RETURN_IF(tiles_x > 256 || tiles_y > 256, NBP_E_SHAPE);          // fine-tile coordinates are packed in 8 bits
-    NBP_RETURN_IF(ws_bytes < nbp_raster_workspace_bytes(n_faces, n_frames, H, W, bin_cap), NBP_E_WS);
-    hipStream_t st = (hipStream_t)stream;
-    const int ctiles_x = (int)nbp_cdiv(tiles_x, COARSE), ctiles_y = (int)nbp_cdiv(tiles_y, COARSE);
-    const size_t nct = (size_t)ctiles_x * ctiles_y * n_frames;
-    char* p = (char*)(((uintptr_t)ws + 255) / 256 * 256);
-    FaceRec* recs = (FaceRec*)p; p += ((size_t)n_frames * n_faces * sizeof(FaceRec) + 255) / 256 * 256;
-    int* ccount = (int*)p; p += (nct * sizeof(int) + 255) / 256 * 256;
-    BinEntry* clist = (BinEntry*)p;
-    hipError_t e = hipMemsetAsync(ccount, 0, nct * sizeof(int), st);
-    if (e != hipSuccess) return (int)e;
-    dim3 g1((unsigned)nbp_cdiv(n_faces, 256), (unsigned)n_frames);
-    raster_setup_kernel<<<g1, 256, 0, st>>>(verts, faces, n_faces, camset_from_host(cams12_host, n_frames), H, W,
-                                            tan_half_fov, z_clip, recs, ctiles_x, ctiles_y, ccount, clist, (unsigned*)zbuf);
-    int rc = nbp_launch_status();
-    if (rc) return rc;
-    const int nseg = (int)nbp_cdiv(n_faces, SEG);
-    dim3 g2((unsigned)(tiles_x * tiles_y * nseg), (unsigned)n_frames);
-    raster_tile_kernel<<<g2, 64, 0, st>>>(recs, n_faces, H, W, tan_half_fov, z_clip, tiles_x, tiles_y, ctiles_x, ctiles_y,
-                                          ccount, clist, (unsigned*)zbuf);
-    if ((rc = nbp_launch_status())) return rc;
-    const long long npx = (long long)n_frames * H * W;
-    raster_finalize_kernel<<<nbp_ew_grid(npx, 256), 256, 0, st>>>(zbuf, npx);
+    return raster_launch(verts, n_verts, faces, n_faces, cams12_host, n_frames, H, W, tan_half_fov, z_clip, zbuf, nullptr, 0.f,
+                         1.f, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int nbp_raster_rgbz_f32(const float* verts, int n_verts, const int* faces, int n_faces, const float* vcolors3,
+                                   const float* cams12_host, int n_frames, int H, int W, float tan_half_fov, float z_clip,
+                                   float ambient, float contrast_factor, float* zbuf, float* rgb, void* ws, size_t ws_bytes,
+                                   void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!vcolors3 || !rgb, NBP_E_ARG);
+    return raster_launch(verts, n_verts, faces, n_faces, cams12_host, n_frames, H, W, tan_half_fov, z_clip, zbuf, vcolors3,
+                         ambient, contrast_factor, rgb, ws, ws_bytes, stream);
+}
+
+extern "C" int nbp_raster_zface_f32(const float* verts, int n_verts, const int* faces, int n_faces, const float* cams12_host,
+                                    int n_frames, int H, int W, float tan_half_fov, float z_clip, float* zbuf, void* zface,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!zface, NBP_E_ARG);
+    return raster_launch(verts, n_verts, faces, n_faces, cams12_host, n_frames, H, W, tan_half_fov, z_clip, zbuf, nullptr, 0.f,
+                         1.f, nullptr, ws, ws_bytes, stream, (unsigned long long*)zface);
+}
+
+extern "C" int nbp_shade_image_f32(const void* zface, const float* verts, const int* faces, const float* vcolors3,
+                                   const float* cams12_host, int n_frames, int H, int W, float tan_half_fov, float ambient,
+                                   float contrast_factor, float* rgb, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!zface || !verts || !faces || !vcolors3 || !cams12_host || !rgb, NBP_E_ARG);
+    NBP_RETURN_IF(n_frames < 1 || n_frames > MAX_CAMS || H < 1 || W < 1, NBP_E_ARG);
+    NBP_RETURN_IF(contrast_factor != 1.f, NBP_E_SHAPE);        // a contrast change needs the luminance mean: nbp_raster_rgbz_f32
+    dim3 g3((unsigned)nbp_cdiv((long long)H * W, 256), (unsigned)n_frames);
+    raster_shade_kernel<<<g3, 256, 0, (hipStream_t)stream>>>((const unsigned long long*)zface, verts, faces, vcolors3,
+                                                             camset_from_host(cams12_host, n_frames), H, W, tan_half_fov,
+                                                             ambient, nullptr, rgb, nullptr);
     return nbp_launch_status();
 }
 

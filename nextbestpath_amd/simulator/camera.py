@@ -13,6 +13,8 @@ and azimuth wrap :2590-2632, look-at :940-957 (pytorch3d look_at_view_transform 
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -64,7 +66,8 @@ def camera_RT(X_cam, V_cam):
 
 class Camera:
     def __init__(self, x_min, x_max, pose_l, pose_w, pose_h, pose_n_elev, pose_n_azim, n_interpolation_steps,
-                 zfar, image_height, image_width, device, gathering_factor=0.05, sensor_range=70.0, seed=0):
+                 zfar, image_height, image_width, device, gathering_factor=0.05, sensor_range=70.0, seed=0,
+                 ambient_light_intensity=0.85, contrast_factor=1.0, render_rgb=True):
         self.x_min_arg = np.asarray(x_min, f32)
         self.x_min = self.x_min_arg + f32(3)             # mu:2230-2231 (kept for parity of attributes)
         self.x_max = np.asarray(x_max, f32) - f32(3)
@@ -76,6 +79,11 @@ class Camera:
         self.device = device
         self.gathering_factor, self.sensor_range = gathering_factor, sensor_range
         self.seed = int(seed)
+        self.ambient, self.contrast_factor = float(ambient_light_intensity), float(contrast_factor)
+        self.render_rgb = render_rgb and os.environ.get("NBP_RENDER_RGB", "1") != "0"      # A/B switch
+        self._rgb_ring = None
+        self._zface_ring = None
+        self._mesh = None
         self.l_step = self.h_step = 3
         # ---- lattice (mu:2295-2320); flat order = cartesian product order (i, j, k, e, a)
         self.dims = (self.pose_l, self.pose_w, self.pose_h, self.pose_n_elev, self.pose_n_azim)
@@ -239,8 +247,24 @@ class Camera:
         slot = self._cursor
         self._cursor += n
         out = ring[slot:slot + n]
-        hipops.raster_zbuf(mesh.verts, mesh.faces, cams_host, self.image_height, self.image_width, bin_cap=mesh.bin_cap,
-                           out=out, overflow=self._overflow)
+        self._mesh = mesh
+        if self.render_rgb and getattr(mesh, "colors", None) is not None and self.contrast_factor == 1.0:
+            # depth AND the nearest face per pixel: the colours of the reference's renderer (mu:2743-2763) are a pure
+            # function of (face, pixel, camera, mesh), so they are evaluated where they are consumed -- for the ~5 % of
+            # pixels the un-projection keeps (colour_source), or as whole images on request (frames_rgb)
+            if self._zface_ring is None:
+                self._zface_ring = torch.empty(16, self.image_height, self.image_width, dtype=torch.int64, device=self.device)
+            hipops.raster_zface(mesh.verts, mesh.faces, cams_host, self.image_height, self.image_width, out_z=out,
+                                out_zface=self._zface_ring[slot:slot + n])
+        elif self.render_rgb and getattr(mesh, "colors", None) is not None:
+            # a contrast change needs every pixel's luminance: eager colour render, colours in a ring beside the depths
+            if self._rgb_ring is None:
+                self._rgb_ring = torch.empty(16, self.image_height, self.image_width, 3, dtype=torch.float32, device=self.device)
+            hipops.raster_rgbz(mesh.verts, mesh.faces, mesh.colors, cams_host, self.image_height, self.image_width,
+                               self.ambient, self.contrast_factor, out_z=out, out_rgb=self._rgb_ring[slot:slot + n])
+        else:
+            hipops.raster_zbuf(mesh.verts, mesh.faces, cams_host, self.image_height, self.image_width, bin_cap=mesh.bin_cap,
+                               out=out, overflow=self._overflow)
         for i in range(n):
             self.frames.append((out[i], cams_host[i].copy(), slot + i))
         self.frames = self.frames[-8:]
@@ -269,6 +293,36 @@ class Camera:
         else:
             z = torch.stack([s[0] for s in sel])
         return z, np.stack([s[1] for s in sel]).astype(f32)
+
+    def _ring_view(self, ring, which):
+        slots = [self.frames[w][2] for w in which]
+        if all(b == a + 1 for a, b in zip(slots, slots[1:])):
+            return ring[slots[0]:slots[0] + len(slots)]
+        return torch.stack([ring[k] for k in slots])
+
+    def frames_rgb(self, which):
+        """Colour images of the same frames [n,H,W,3] (None when the camera renders depth only)."""
+        if self._zface_ring is not None:
+            m = self._mesh
+            cams = np.stack([self.frames[w][1] for w in which]).astype(f32)
+            return hipops.shade_image(self._ring_view(self._zface_ring, which), m.verts, m.faces, m.colors, cams, self.ambient)
+        if self._rgb_ring is None:
+            return None
+        return self._ring_view(self._rgb_ring, which)
+
+    def colour_source(self, which):
+        """Keyword arguments that make hipops.unproject_append carry the colours of these frames: {} when the camera renders
+        depth only, shade=(nearest faces, mesh, ambient) in the deferred form, rgb=images after an eager colour render."""
+        if self._zface_ring is not None:
+            m = self._mesh
+            return {"shade": (self._ring_view(self._zface_ring, which), m.verts, m.faces, m.colors, self.ambient)}
+        if self._rgb_ring is not None:
+            return {"rgb": self._ring_view(self._rgb_ring, which)}
+        return {}
+
+    @property
+    def renders_colours(self):
+        return self._zface_ring is not None or self._rgb_ring is not None
 
     def trajectory_points(self):
         """X_cam_history on the device (for the trajectory channel); new poses are appended by a kernel whose

@@ -10,15 +10,18 @@ import os
 import numpy as np
 
 
-def load_obj(path):
+def load_obj(path, with_colors=False):
     """Vertices [V,3] fp32 and triangle faces [F,3] int32 (polygons are fan-triangulated;
-    negative / slash-separated indices handled).  Texture and normal records are ignored."""
-    verts, faces = [], []
+    negative / slash-separated indices handled).  Texture and normal records are ignored.  with_colors: also the
+    per-vertex colours [V,3] of "v x y z r g b" records -- 0.5 gray where a record has none, which is what the reference
+    gives an untextured mesh (macarons_utils.py:596-606, TexturesVertex of 0.5)."""
+    verts, faces, cols = [], [], []
     with open(path) as fh:
         for line in fh:
             if line.startswith("v "):
                 p = line.split()
                 verts.append((float(p[1]), float(p[2]), float(p[3])))
+                cols.append((float(p[4]), float(p[5]), float(p[6])) if len(p) >= 7 else (0.5, 0.5, 0.5))
             elif line.startswith("f "):
                 idx = []
                 for tok in line.split()[1:]:
@@ -26,12 +29,19 @@ def load_obj(path):
                     idx.append(i - 1 if i > 0 else len(verts) + i)
                 for k in range(1, len(idx) - 1):
                     faces.append((idx[0], idx[k], idx[k + 1]))
-    return np.asarray(verts, np.float32).reshape(-1, 3), np.asarray(faces, np.int32).reshape(-1, 3)
+    v, f = np.asarray(verts, np.float32).reshape(-1, 3), np.asarray(faces, np.int32).reshape(-1, 3)
+    if with_colors:
+        return v, f, np.asarray(cols, np.float32).reshape(-1, 3)
+    return v, f
 
 
-def save_obj(path, verts, faces):
+def save_obj(path, verts, faces, colors=None):
     with open(path, "w") as fh:
-        for v in verts:
+        for i, v in enumerate(verts):
+            if colors is not None:
+                c = colors[i]
+                fh.write(f"v {v[0]:.6f} {v[1]:.6f} {v[2]:.6f} {c[0]:.4f} {c[1]:.4f} {c[2]:.4f}\n")
+                continue
             fh.write(f"v {v[0]:.6f} {v[1]:.6f} {v[2]:.6f}\n")
         for f in faces:
             fh.write(f"f {f[0] + 1} {f[1] + 1} {f[2] + 1}\n")
@@ -116,14 +126,24 @@ def make_maze_mesh(seed=0, cells=10, size=60.0, height=12.0, wall=0.6, tess=2.5,
     return b.arrays()
 
 
-def make_maze_scene(scene_dir, seed=0, cells=10, size=6.0, height=1.2, tess=0.25, n_starts=1, scale=10.0, hull="slab"):
+def vertex_colors_for(verts, seed=0):
+    """Deterministic per-vertex colours for the procedural mazes (smooth in space, so interpolation is exercised)."""
+    v = np.asarray(verts, np.float64)
+    ph = 0.37 * seed
+    c = np.stack([0.5 + 0.4 * np.sin(1.3 * v[:, 0] + ph), 0.5 + 0.4 * np.sin(2.1 * v[:, 1] + 1.0 + ph),
+                  0.5 + 0.4 * np.sin(0.9 * v[:, 2] + 2.0 + ph)], 1)
+    return np.round(c, 4).astype(np.float32)
+
+
+def make_maze_scene(scene_dir, seed=0, cells=10, size=6.0, height=1.2, tess=0.25, n_starts=1, scale=10.0, hull="slab",
+                    colors=True):
     """Writes <scene_dir>/<name>.obj + settings.json in UNSCALED units (the drivers multiply by
     scene_scale_factor = 10 on load, like the reference: nbp_planning.py:442,455) with the
     reference's settings schema (macarons/utility/macarons_utils.py:2152-2190)."""
     os.makedirs(scene_dir, exist_ok=True)
     v, f = make_maze_mesh(seed, cells, size, height, wall=0.06, tess=tess, hull=hull)
     name = os.path.basename(os.path.normpath(scene_dir))
-    save_obj(os.path.join(scene_dir, name + ".obj"), v, f)
+    save_obj(os.path.join(scene_dir, name + ".obj"), v, f, vertex_colors_for(v, seed) if colors else None)
     half = size / 2.0
     lattice = int((size * scale - 6.0) // 3.0) + 1          # 3-unit lattice inside [x_min+3, x_max-3] (scaled)
     rng = np.random.default_rng(seed + 1000)

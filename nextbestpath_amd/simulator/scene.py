@@ -72,14 +72,17 @@ class DeviceMesh:
     verts_host: np.ndarray
     faces_host: np.ndarray
     bin_cap: int = 4096
+    colors: torch.Tensor = None          # [V,3] fp32 device vertex colours (0.5 gray for untextured meshes)
+    colors_host: np.ndarray = None
 
 
 def load_scene(mesh_path, scene_scale_factor, device):
     """load_scene (mu:554-572) + the trimesh twin (nbp_planning.py:454-455): one scaled mesh for
     rendering AND for the collision tests."""
-    v, f = load_obj(mesh_path)
+    v, f, c = load_obj(mesh_path, with_colors=True)
     v = (v * f32(scene_scale_factor)).astype(f32)
-    return DeviceMesh(torch.from_numpy(v).to(device), torch.from_numpy(f).to(device), v, f)
+    return DeviceMesh(torch.from_numpy(v).to(device), torch.from_numpy(f).to(device), v, f,
+                      colors=torch.from_numpy(c).to(device), colors_host=c)
 
 
 def face_areas(verts, faces):

@@ -39,6 +39,7 @@ class RolloutState:
     def __init__(self, device, capacity=3_400_000, grid=256):
         self.device = device
         self.cloud = torch.zeros(capacity, 3, dtype=torch.float32, device=device)
+        self.cloud_rgb = torch.zeros(capacity, 3, dtype=torch.float32, device=device)        # full_pc_colors (ref :39)
         self.cloud_count = torch.zeros(1, dtype=torch.int64, device=device)
         self.coverage_counts = torch.zeros(N_POSES, 2, dtype=torch.int32, device=device)
         self.maps6 = torch.zeros(6, grid, grid, dtype=torch.float32, device=device)
@@ -51,7 +52,9 @@ def setup_test_camera(params, mesh, start_cam_idx, settings, device, seed=0):
     cam = Camera(settings.camera.x_min, settings.camera.x_max, settings.camera.pose_l, settings.camera.pose_w,
                  settings.camera.pose_h, settings.camera.pose_n_elev, settings.camera.pose_n_azim,
                  params.n_interpolation_steps, params.zfar, params.image_height, params.image_width, device,
-                 params.gathering_factor, params.sensor_range, seed=seed)
+                 params.gathering_factor, params.sensor_range, seed=seed,
+                 ambient_light_intensity=getattr(params, "ambient_light_intensity", 0.85),
+                 contrast_factor=getattr(settings.camera, "contrast_factor", 1.0))
     start = tuple(int(v) for v in start_cam_idx)
     neigh = cam.get_neighboring_poses(start)
     segs = torch.from_numpy(np.stack([np.concatenate([cam.pose_from_idx(n)[:3], cam.pose_from_idx(start)[:3]])
@@ -98,8 +101,10 @@ class Rollout:
         self.cov_plan.count(st.cloud, st.coverage_counts[pose_i % N_POSES], n_dev=st.cloud_count, n=st.cloud.shape[0],
                             seed=self.step_seed + 7 * pose_i, out_is_zero=pose_i < N_POSES)
         depth, cams = camera.frames_batch([-1])
+        colour = camera.colour_source([-1])
         hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
-                                params.sensor_range, seed=self.step_seed + 11 * pose_i)
+                                params.sensor_range, seed=self.step_seed + 11 * pose_i,
+                                cloud_rgb=st.cloud_rgb if colour else None, **colour)
         self.pose, _ = camera.get_pose_from_idx(camera.cam_idx)
         hu.accumulate_step_maps(st.cloud, self.pose, self.y_bins, S, grid_range, n_dev=st.cloud_count, out=st.maps6)
         traj2d = hu.transform_points_to_n_pieces(camera.trajectory_points(), self.pose)
@@ -144,8 +149,10 @@ class Rollout:
         self.idx_history.append(tuple(camera.cam_idx))
         camera.move_and_capture(self.mesh, next_idx)
         depth, cams = camera.frames_batch([-5, -4, -3, -2])
+        colour = camera.colour_source([-5, -4, -3, -2])
         hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
-                                params.sensor_range, seed=self.step_seed + 11 * pose_i + 5)
+                                params.sensor_range, seed=self.step_seed + 11 * pose_i + 5,
+                                cloud_rgb=st.cloud_rgb if colour else None, **colour)
         self.path_record += 1
         self.pose_i += 1
 
@@ -281,7 +288,8 @@ def compute_nbp_trajectory(params, nbp, camera, gt_scene_pc, mesh, mesh_for_chec
     coverage_evolution = ro.coverage_evolution(n_poses)
     n_cloud = int(ro.st.cloud_count.item())
     print("Time: ", time.time() - t1)
-    return coverage_evolution, camera.X_cam_history, camera.V_cam_history, ro.st.cloud[:n_cloud], None
+    colors = ro.st.cloud_rgb[:n_cloud] if camera.renders_colours else None
+    return coverage_evolution, camera.X_cam_history, camera.V_cam_history, ro.st.cloud[:n_cloud], colors
 
 
 def load_params(path):

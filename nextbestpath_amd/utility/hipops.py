@@ -57,7 +57,7 @@ def _cam_arg(cams):
 
 
 def unproject_append(depth, mask, cams, cloud, cloud_count, gathering_factor=0.05, fov_range=70.0, seed=0,
-                     tan_half_fov=TAN_HALF_FOV):
+                     tan_half_fov=TAN_HALF_FOV, rgb=None, cloud_rgb=None, shade=None):
     """depth [F,H,W] fp32, mask [F,H,W] uint8|None, cams host [F,12]; appends to cloud [cap,3] at the
     device counter cloud_count (int64[1]).  Returns counts [F,2] int32 (device)."""
     F_, H, W = depth.shape
@@ -65,6 +65,22 @@ def unproject_append(depth, mask, cams, cloud, cloud_count, gathering_factor=0.0
     keep, cam_ptr, _ = _cam_arg(cams)
     ws = _workspace_for("unproject", (F_, H, W), lambda: L.nbp_unproject_workspace_bytes(F_, H, W) + 256, depth.device)
     counts = ws[-64:].view(torch.int32).reshape(8, 2)[:F_]          # per-stream scratch: no allocation per call
+    if shade is not None:      # deferred shading: (zface [F,H,W] int64, verts, faces, vcolors, ambient) -> colours of kept pixels
+        zface, verts, faces, vcolors, ambient = shade
+        rc = L.nbp_unproject_append_shaded_f32(_lib.ptr(depth), _lib.ptr(mask), _lib.ptr(zface), _lib.ptr(verts), _lib.ptr(faces),
+                                               _lib.ptr(vcolors), cam_ptr, F_, H, W, tan_half_fov, float(fov_range),
+                                               float(gathering_factor), int(seed) & 0xFFFFFFFF, float(ambient),
+                                               _lib.ptr(counts), _lib.ptr(cloud), _lib.ptr(cloud_rgb), _lib.ptr(cloud_count),
+                                               cloud.shape[0], _lib.ptr(ws), ws.numel(), _st())
+        _lib.check(rc, "nbp_unproject_append_shaded_f32")
+        return counts
+    if rgb is not None:        # colours of the kept pixels ride along (compute_partial_point_cloud with images)
+        rc = L.nbp_unproject_append_rgb_f32(_lib.ptr(depth), _lib.ptr(mask), _lib.ptr(rgb), cam_ptr, F_, H, W, tan_half_fov,
+                                            float(fov_range), float(gathering_factor), int(seed) & 0xFFFFFFFF,
+                                            _lib.ptr(counts), _lib.ptr(cloud), _lib.ptr(cloud_rgb), _lib.ptr(cloud_count),
+                                            cloud.shape[0], _lib.ptr(ws), ws.numel(), _st())
+        _lib.check(rc, "nbp_unproject_append_rgb_f32")
+        return counts
     rc = L.nbp_unproject_append_f32(_lib.ptr(depth), _lib.ptr(mask), cam_ptr, F_, H, W, tan_half_fov,
                                     float(fov_range), float(gathering_factor), int(seed) & 0xFFFFFFFF,
                                     _lib.ptr(counts), _lib.ptr(cloud), _lib.ptr(cloud_count), cloud.shape[0],
@@ -89,6 +105,54 @@ def raster_zbuf(verts, faces, cams, H, W, bin_cap=2048, tan_half_fov=TAN_HALF_FO
                                ws.numel(), _st())
     _lib.check(rc, "nbp_raster_zbuf_f32")
     return out, overflow
+
+
+def raster_rgbz(verts, faces, vcolors, cams, H, W, ambient=0.85, contrast=1.0, tan_half_fov=TAN_HALF_FOV, z_clip=Z_CLIP,
+                out_z=None, out_rgb=None):
+    """Camera.capture_image with colours -> (zbuf [n,H,W], rgb [n,H,W,3])."""
+    L = _lib.lib()
+    keep, cam_ptr, n = _cam_arg(cams)
+    if out_z is None:
+        out_z = torch.empty(n, H, W, dtype=torch.float32, device=verts.device)
+    if out_rgb is None:
+        out_rgb = torch.empty(n, H, W, 3, dtype=torch.float32, device=verts.device)
+    nf = faces.shape[0]
+    ws = _workspace_for("raster_rgb", (nf, n, H, W), lambda: L.nbp_raster_rgb_workspace_bytes(nf, n, H, W), verts.device)
+    rc = L.nbp_raster_rgbz_f32(_lib.ptr(verts), verts.shape[0], _lib.ptr(faces), nf, _lib.ptr(vcolors), cam_ptr, n, H, W,
+                               tan_half_fov, z_clip, float(ambient), float(contrast), _lib.ptr(out_z), _lib.ptr(out_rgb),
+                               _lib.ptr(ws), ws.numel(), _st())
+    _lib.check(rc, "nbp_raster_rgbz_f32")
+    return out_z, out_rgb
+
+
+def raster_zface(verts, faces, cams, H, W, tan_half_fov=TAN_HALF_FOV, z_clip=Z_CLIP, out_z=None, out_zface=None):
+    """Depth render that also returns zface [n,H,W] int64 = (depth bits << 32 | nearest face), -1 for background: the
+    input of the deferred colour evaluation (shade_image / unproject_append(shade=...))."""
+    L = _lib.lib()
+    keep, cam_ptr, n = _cam_arg(cams)
+    if out_z is None:
+        out_z = torch.empty(n, H, W, dtype=torch.float32, device=verts.device)
+    if out_zface is None:
+        out_zface = torch.empty(n, H, W, dtype=torch.int64, device=verts.device)
+    nf = faces.shape[0]
+    ws = _workspace_for("raster", (nf, n, H, W), lambda: L.nbp_raster_workspace_bytes(nf, n, H, W, 0), verts.device)
+    rc = L.nbp_raster_zface_f32(_lib.ptr(verts), verts.shape[0], _lib.ptr(faces), nf, cam_ptr, n, H, W, tan_half_fov, z_clip,
+                                _lib.ptr(out_z), _lib.ptr(out_zface), _lib.ptr(ws), ws.numel(), _st())
+    _lib.check(rc, "nbp_raster_zface_f32")
+    return out_z, out_zface
+
+
+def shade_image(zface, verts, faces, vcolors, cams, ambient=0.85, tan_half_fov=TAN_HALF_FOV, out=None):
+    """rgb [n,H,W,3] of frames rendered by raster_zface (bit-identical to raster_rgbz with contrast 1)."""
+    L = _lib.lib()
+    keep, cam_ptr, n = _cam_arg(cams)
+    _, H, W = zface.shape
+    if out is None:
+        out = torch.empty(n, H, W, 3, dtype=torch.float32, device=verts.device)
+    rc = L.nbp_shade_image_f32(_lib.ptr(zface), _lib.ptr(verts), _lib.ptr(faces), _lib.ptr(vcolors), cam_ptr, n, H, W,
+                               tan_half_fov, float(ambient), 1.0, _lib.ptr(out), _st())
+    _lib.check(rc, "nbp_shade_image_f32")
+    return out
 
 
 def segments_hit_mesh(verts, faces, segs):

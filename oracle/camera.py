@@ -80,9 +80,9 @@ def unproject(depth, R, T):
     return out.reshape(-1, 3)
 
 
-def partial_point_cloud(depth, mask, R, T, gathering_factor, fov_range, seed, frame_index=0):
+def partial_point_cloud(depth, mask, R, T, gathering_factor, fov_range, seed, frame_index=0, rgb=None):
     """compute_partial_point_cloud with the seeded bijection instead of torch.randperm.
-    Returns (points [n_keep,3], n_valid)."""
+    Returns (points [n_keep,3], n_valid), or (points, n_valid, colours [n_keep,3]) when the image rgb [H,W,3] is given."""
     H, W = depth.shape
     m = (depth > -1) if mask is None else (mask != 0)
     valid = m.reshape(-1) & (depth.reshape(-1) < f32(fov_range))
@@ -91,6 +91,8 @@ def partial_point_cloud(depth, mask, R, T, gathering_factor, fov_range, seed, fr
     n_keep = int(n_valid * gathering_factor)
     sd = (seed + 0x632BE5AB * (frame_index + 1)) & sampling.M32
     sel = lst[sampling.perm_index(np.arange(n_keep), n_valid, sd)] if n_keep else lst[:0]
+    if rgb is not None:
+        return unproject(depth, R, T)[sel], n_valid, np.asarray(rgb, f32).reshape(-1, 3)[sel]
     return unproject(depth, R, T)[sel], n_valid
 
 

@@ -24,6 +24,9 @@ def lib(omp=False):
         L.oracle_raster_zbuf.argtypes = [fp, C.c_int, ip, C.c_int, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float,
                                          C.c_float, fp]
         L.oracle_raster_zbuf.restype = None
+        L.oracle_raster_rgbz.argtypes = [fp, C.c_int, ip, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float,
+                                         C.c_float, C.c_float, C.c_float, fp, fp]
+        L.oracle_raster_rgbz.restype = None
         L.oracle_unproject.argtypes = [fp, C.c_int, C.c_int, C.c_float, fp, fp, fp]
         L.oracle_unproject.restype = None
         L.oracle_coverage_count.argtypes = [fp, C.c_longlong, fp, C.c_longlong, C.c_float]
@@ -45,6 +48,18 @@ def raster_zbuf(verts, faces, R, T, H, W, tan_half_fov, z_clip=0.5, eps=1e-6):
     lib().oracle_raster_zbuf(_fp(v), len(v), f.ctypes.data_as(C.POINTER(C.c_int)), len(f), _fp(R), _fp(T), H, W,
                              float(tan_half_fov), float(z_clip), float(eps), _fp(out))
     return out
+
+
+def raster_rgbz(verts, faces, colors, R, T, H, W, tan_half_fov, ambient=0.85, contrast=1.0, z_clip=0.5, eps=1e-6):
+    v = np.ascontiguousarray(verts, f32)
+    f = np.ascontiguousarray(faces, np.int32)
+    c = np.ascontiguousarray(colors, f32)
+    R = np.ascontiguousarray(R, f32).reshape(9)
+    T = np.ascontiguousarray(T, f32).reshape(3)
+    z, rgb = np.empty((H, W), f32), np.empty((H, W, 3), f32)
+    lib().oracle_raster_rgbz(_fp(v), len(v), f.ctypes.data_as(C.POINTER(C.c_int)), len(f), _fp(c), _fp(R), _fp(T), H, W,
+                             float(tan_half_fov), float(z_clip), float(eps), float(ambient), float(contrast), _fp(z), _fp(rgb))
+    return z, rgb
 
 
 def unproject(depth, R, T, tan_half_fov):

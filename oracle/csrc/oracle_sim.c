@@ -20,15 +20,14 @@ static void to_view(const float* p, const float* R, const float* T, float* o) {
     for (int j = 0; j < 3; ++j) o[j] = ((p[0] * R[0 + j] + p[1] * R[3 + j]) + p[2] * R[6 + j]) + T[j];
 }
 
-void oracle_raster_zbuf(const float* verts, int n_verts, const int* faces, int n_faces, const float* R, const float* T,
-                        int H, int W, float tan_half_fov, float z_clip, float eps, float* zbuf) {
-    (void)n_verts;
+static void raster_core(const float* verts, const int* faces, int n_faces, const float* R, const float* T, int H, int W,
+                        float tan_half_fov, float z_clip, float eps, float* zbuf, float* ub, float* vb, int* fb) {
     const int s = H < W ? H : W;
     float* dxs = (float*)malloc(sizeof(float) * (size_t)W);
     float* dys = (float*)malloc(sizeof(float) * (size_t)H);
     for (int c = 0; c < W; ++c) dxs[c] = ((float)W - (2.f * (float)c + 1.f)) / (float)s * tan_half_fov;
     for (int r = 0; r < H; ++r) dys[r] = ((float)H - (2.f * (float)r + 1.f)) / (float)s * tan_half_fov;
-    for (size_t i = 0; i < (size_t)H * W; ++i) zbuf[i] = 3.0e38f;
+    for (size_t i = 0; i < (size_t)H * W; ++i) { zbuf[i] = 3.0e38f; if (fb) fb[i] = -1; }
     for (int fi = 0; fi < n_faces; ++fi) {
         float v[3][3];
         for (int k = 0; k < 3; ++k) to_view(verts + 3 * (size_t)faces[3 * (size_t)fi + k], R, T, v[k]);
@@ -70,13 +69,57 @@ void oracle_raster_zbuf(const float* verts, int n_verts, const int* faces, int n
                 const float u = -((v0[0] * p0 + v0[1] * p1) + v0[2] * p2) * inv;
                 const float vv = ((dx * q[0] + dy * q[1]) + q[2]) * inv;
                 const float z = tnum * inv;
-                if (u >= -eps && vv >= -eps && u + vv <= 1.f + eps && z > z_clip && z < zrow[c]) zrow[c] = z;
+                if (u >= -eps && vv >= -eps && u + vv <= 1.f + eps && z > z_clip && z < zrow[c]) {
+                    zrow[c] = z;
+                    if (fb) { const size_t i = (size_t)r * W + c; fb[i] = fi; ub[i] = u; vb[i] = vv; }
+                }
             }
         }
     }
+    free(dxs); free(dys);
+}
+
+void oracle_raster_zbuf(const float* verts, int n_verts, const int* faces, int n_faces, const float* R, const float* T,
+                        int H, int W, float tan_half_fov, float z_clip, float eps, float* zbuf) {
+    (void)n_verts;
+    raster_core(verts, faces, n_faces, R, T, H, W, tan_half_fov, z_clip, eps, zbuf, NULL, NULL, NULL);
     for (size_t i = 0; i < (size_t)H * W; ++i)
         if (!(zbuf[i] < 1.0e38f)) zbuf[i] = -1.f;
-    free(dxs); free(dys);
+}
+
+/* == oracle/raster.py::raster_rgbz: depth + ambient x interpolated vertex colours, white background, adjust_contrast. */
+void oracle_raster_rgbz(const float* verts, int n_verts, const int* faces, int n_faces, const float* colors, const float* R,
+                        const float* T, int H, int W, float tan_half_fov, float z_clip, float eps, float ambient, float contrast,
+                        float* zbuf, float* rgb) {
+    (void)n_verts;
+    const size_t n = (size_t)H * W;
+    float* ub = (float*)malloc(sizeof(float) * n);
+    float* vb = (float*)malloc(sizeof(float) * n);
+    int* fb = (int*)malloc(sizeof(int) * n);
+    raster_core(verts, faces, n_faces, R, T, H, W, tan_half_fov, z_clip, eps, zbuf, ub, vb, fb);
+    double gsum = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        float c[3] = {1.f, 1.f, 1.f};
+        if (fb[i] >= 0) {
+            const int* f = faces + 3 * (size_t)fb[i];
+            const float w0 = (1.f - ub[i]) - vb[i];
+            for (int k = 0; k < 3; ++k)
+                c[k] = ambient * ((w0 * colors[3 * (size_t)f[0] + k] + ub[i] * colors[3 * (size_t)f[1] + k]) +
+                                  vb[i] * colors[3 * (size_t)f[2] + k]);
+        } else {
+            zbuf[i] = -1.f;
+        }
+        rgb[3 * i] = c[0]; rgb[3 * i + 1] = c[1]; rgb[3 * i + 2] = c[2];
+        gsum += (double)((0.299f * c[0] + 0.587f * c[1]) + 0.114f * c[2]);
+    }
+    if (contrast != 1.f) {
+        const float mean = (float)(gsum / (double)n);
+        for (size_t i = 0; i < 3 * n; ++i) {
+            const float v = contrast * rgb[i] + (1.f - contrast) * mean;
+            rgb[i] = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+        }
+    }
+    free(ub); free(vb); free(fb);
 }
 
 /* All pixels of one depth frame -> world points [H*W,3] (oracle/camera.py::unproject). */

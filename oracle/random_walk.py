@@ -53,14 +53,14 @@ class OracleRandomWalk:
     def _partial(self, which, seed):
         out = []
         for fi, w in enumerate(which):
-            z, R, T = self.cam.frames[w]
+            z, R, T = self.cam.frames[w][:3]
             pts, _ = ocam.partial_point_cloud(z, None, R, T, self.p["gathering_factor"], self.p["sensor_range"], seed & sampling.M32,
                                               frame_index=fi)
             out.append(pts)
         return np.concatenate(out, 0)
 
     def _carve(self, w):
-        z, R, T = self.cam.frames[w]
+        z, R, T = self.cam.frames[w][:3]
         ocam.carve_update(self.proxy, z, None, R, T, self.p["zfar"], self.p["sensor_range"], self.p["carving_tolerance"],
                           self.p["score_threshold"], self.n_inside, self.n_behind, self.occ, self.oof)
 

@@ -48,3 +48,55 @@ def raster_zbuf(verts, faces, R, T, H, W, tan_half_fov, z_clip=0.5, eps=1e-6):
             hit = ok & (u >= -f32(eps)) & (v >= -f32(eps)) & (u + v <= f32(1) + f32(eps)) & (z > zc) & (z < zb)
         zb = np.where(hit, z, zb)
     return np.where(zb < 1.0e38, zb, f32(-1)).astype(f32)
+
+
+def raster_rgbz(verts, faces, colors, R, T, H, W, tan_half_fov, ambient=0.85, contrast=1.0, z_clip=0.5, eps=1e-6):
+    """Depth and colours (Camera.capture_image, mu:2743-2763; PARITY UNPINNED like the depth): SoftPhongShader under
+    AmbientLights on a TexturesVertex mesh = ambient x barycentric interpolation of the winning face's vertex colours
+    (perspective-correct barycentrics = those of the view-space ray cast), white background; the soft-blend terms of
+    softmax_rgb_blend vanish for faces_per_pixel=1, sigma=gamma=1e-4 and z <= sensor range; torchvision adjust_contrast.
+    Equal depths: the lowest face index wins (first strict improvement in index order).  -> (zbuf, rgb [H,W,3])."""
+    vv = to_view(verts, R, T)
+    s = min(H, W)
+    col = np.arange(W, dtype=f32)[None, :]
+    row = np.arange(H, dtype=f32)[:, None]
+    dx = ((f32(W) - (f32(2) * col + f32(1))) / f32(s) * f32(tan_half_fov)) + np.zeros((H, 1), f32)
+    dy = ((f32(H) - (f32(2) * row + f32(1))) / f32(s) * f32(tan_half_fov)) + np.zeros((1, W), f32)
+    zb = np.full((H, W), 3.0e38, f32)
+    ub, vb = np.zeros((H, W), f32), np.zeros((H, W), f32)
+    fb = np.full((H, W), -1, np.int64)
+    zc = f32(z_clip)
+    for fi, f in enumerate(np.asarray(faces)):
+        v0, v1, v2 = vv[f[0]], vv[f[1]], vv[f[2]]
+        if v0[2] <= zc and v1[2] <= zc and v2[2] <= zc:
+            continue
+        e1, e2 = v1 - v0, v2 - v0
+        q = np.array([e1[1] * v0[2] - e1[2] * v0[1], e1[2] * v0[0] - e1[0] * v0[2], e1[0] * v0[1] - e1[1] * v0[0]], f32)
+        tnum = (e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]
+        p0 = dy * e2[2] - e2[1]
+        p1 = e2[0] - dx * e2[2]
+        p2 = dx * e2[1] - dy * e2[0]
+        det = (e1[0] * p0 + e1[1] * p1) + e1[2] * p2
+        ok = np.abs(det) >= f32(1e-12)
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            inv = f32(1) / det
+            u = -((v0[0] * p0 + v0[1] * p1) + v0[2] * p2) * inv
+            v = ((dx * q[0] + dy * q[1]) + q[2]) * inv
+            z = tnum * inv
+            hit = ok & (u >= -f32(eps)) & (v >= -f32(eps)) & (u + v <= f32(1) + f32(eps)) & (z > zc) & (z < zb)
+        zb = np.where(hit, z, zb)
+        ub, vb = np.where(hit, u, ub), np.where(hit, v, vb)
+        fb = np.where(hit, fi, fb)
+    have = fb >= 0
+    fa = np.asarray(faces)[np.maximum(fb, 0)]
+    c = np.asarray(colors, f32)
+    w0 = (f32(1) - ub) - vb
+    rgb = np.ones((H, W, 3), f32)
+    for k in range(3):
+        tex = (w0 * c[fa[..., 0], k] + ub * c[fa[..., 1], k]) + vb * c[fa[..., 2], k]
+        rgb[..., k] = np.where(have, f32(ambient) * tex, f32(1))
+    if contrast != 1.0:
+        gray = (f32(0.299) * rgb[..., 0] + f32(0.587) * rgb[..., 1]) + f32(0.114) * rgb[..., 2]
+        mean = f32(gray.astype(np.float64).sum() / (H * W))
+        rgb = np.clip(f32(contrast) * rgb + (f32(1) - f32(contrast)) * mean, 0, 1).astype(f32)
+    return np.where(zb < 1.0e38, zb, f32(-1)).astype(f32), rgb

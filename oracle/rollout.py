@@ -33,7 +33,8 @@ f32 = np.float32
 class OracleCamera:
     """Pose lattice (mu:2283-2327), interpolated motion (mu:2590-2632), frame list (zbuf, R, T)."""
 
-    def __init__(self, x_min, pose_l, pose_w, pose_h, n_elev, n_azim, n_interp, H, W):
+    def __init__(self, x_min, pose_l, pose_w, pose_h, n_elev, n_azim, n_interp, H, W, colors=None, ambient=0.85, contrast=1.0):
+        self.colors, self.ambient, self.contrast = colors, ambient, contrast
         self.x_min = np.asarray(x_min, f32)
         self.dims = (int(pose_l), int(pose_w), int(pose_h), int(n_elev), int(n_azim))
         self.n_interp, self.H, self.W = int(n_interp), int(H), int(W)
@@ -89,8 +90,13 @@ class OracleCamera:
         self.R, self.T = ocam.camera_RT(self.X, self.V)
 
     def capture(self, verts, faces):
-        z = csim.raster_zbuf(verts, faces, self.R, self.T, self.H, self.W, ocam.TAN_HALF_FOV)
-        self.frames.append((z, self.R.copy(), self.T.copy()))
+        if self.colors is not None:
+            z, rgb = csim.raster_rgbz(verts, faces, self.colors, self.R, self.T, self.H, self.W, ocam.TAN_HALF_FOV, self.ambient,
+                                      self.contrast)
+            self.frames.append((z, self.R.copy(), self.T.copy(), rgb))
+        else:
+            z = csim.raster_zbuf(verts, faces, self.R, self.T, self.H, self.W, ocam.TAN_HALF_FOV)
+            self.frames.append((z, self.R.copy(), self.T.copy()))
         self.frames = self.frames[-8:]
 
     def move_and_capture(self, verts, faces, next_idx):
@@ -101,14 +107,16 @@ class OracleCamera:
 
 class OracleRollout:
     def __init__(self, sd, verts, faces, gt, y_bins, cam_x_min, dims, start_idx, seed, S=256, n_interp=4, H=256, W=456,
-                 gathering_factor=0.05, sensor_range=70.0):
+                 gathering_factor=0.05, sensor_range=70.0, colors=None, ambient=0.85, contrast=1.0):
         self.sd, self.verts, self.faces = sd, np.asarray(verts, f32), np.asarray(faces, np.int32)
         self.gt, self.y_bins = np.asarray(gt, f32), np.asarray(y_bins, f32)
         self.S, self.V, self.grid_range = S, S // 4, (-40 * S // 256, 40 * S // 256)
         self.gf, self.sensor_range = gathering_factor, sensor_range
         self.rng = random.Random(seed)
         self.step_seed = seed * 1_000_003
-        cam = self.cam = OracleCamera(cam_x_min, dims[0], dims[1], dims[2], dims[3], dims[4], n_interp, H, W)
+        cam = self.cam = OracleCamera(cam_x_min, dims[0], dims[1], dims[2], dims[3], dims[4], n_interp, H, W, colors, ambient,
+                                      contrast)
+        self.full_rgb = np.zeros((0, 3), f32)
         # ---- setup_test_camera (scene.py:465-488)
         start = tuple(int(v) for v in start_idx)
         first = None
@@ -136,8 +144,13 @@ class OracleRollout:
     # ------------------------------------------------------------------ pieces
     def _append_frames(self, which, seed):
         for fi, w in enumerate(which):
-            z, R, T = self.cam.frames[w]
-            pts, _ = ocam.partial_point_cloud(z, None, R, T, self.gf, self.sensor_range, seed, frame_index=fi)
+            fr = self.cam.frames[w]
+            z, R, T = fr[0], fr[1], fr[2]
+            if len(fr) > 3:            # colours of the kept pixels ride along (full_pc_colors, nbp_planning.py:106,353)
+                pts, _, col = ocam.partial_point_cloud(z, None, R, T, self.gf, self.sensor_range, seed, frame_index=fi, rgb=fr[3])
+                self.full_rgb = np.concatenate([self.full_rgb, col], 0)
+            else:
+                pts, _ = ocam.partial_point_cloud(z, None, R, T, self.gf, self.sensor_range, seed, frame_index=fi)
             self.full_pc = np.concatenate([self.full_pc, pts], 0)
 
     def _segment_hits(self, a3, b3):

@@ -98,7 +98,8 @@ def _both_rollouts(tmp, cells, size, tess, scene_seed, seed, n_gt=6000):
     ora = OracleRollout(sd, mesh.verts_host, mesh.faces_host, gt, y_bins.numpy(), settings.camera.x_min, dims, start,
                         seed, S=256, n_interp=params.n_interpolation_steps, H=params.image_height,
                         W=params.image_width, gathering_factor=params.gathering_factor,
-                        sensor_range=params.sensor_range)
+                        sensor_range=params.sensor_range, colors=mesh.colors_host, ambient=params.ambient_light_intensity,
+                        contrast=settings.camera.contrast_factor)
     return hip_ro, ora, mesh
 
 
@@ -140,6 +141,8 @@ def _step_both_and_compare(hip_ro, ora, n_steps):
         assert sizes[-1][0] == len(ora.full_pc), f"step {s}: cloud size {sizes[-1][0]} vs {len(ora.full_pc)}"
     n = len(ora.full_pc)
     assert torch.equal(hip_ro.st.cloud[:n].cpu(), torch.from_numpy(ora.full_pc))          # bit-exact cloud
+    assert len(ora.full_rgb) == n and torch.equal(hip_ro.st.cloud_rgb[:n].cpu(), torch.from_numpy(ora.full_rgb))   # and colours
+    assert 0.0 < float(ora.full_rgb.min()) and float(ora.full_rgb.std()) > 0.01              # interpolated, not constant
     assert np.array_equal(hip_ro.camera.X_cam_history, np.stack(ora.cam.X_hist))
     assert np.array_equal(hip_ro.camera.V_cam_history, np.stack(ora.cam.V_hist))
     counts = hip_ro.st.coverage_counts[:n_steps, 0].cpu().numpy().tolist()
@@ -172,6 +175,53 @@ def test_hip_rollout_equals_oracle_rollout_hard_scene(hip, tmp_path):
         want = csim.raster_zbuf(mesh.verts_host, mesh.faces_host, cam12[:9].reshape(3, 3), cam12[9:], zb.shape[0],
                                 zb.shape[1], ocam.TAN_HALF_FOV)
         assert np.array_equal(zb.cpu().numpy(), want)
+
+
+def test_colour_render_vs_oracle(hip, tmp_path):
+    """Camera.capture_image's colour output (ambient x interpolated vertex colours, white background, adjust_contrast) and the
+    colours carried by the un-projected points, bit-exact against oracle/raster.py::raster_rgbz (via its C twin)."""
+    from nextbestpath_amd.utility import hipops as ho
+    from oracle import camera as ocam
+    from oracle import csim
+    params, settings, mesh = _scene(str(tmp_path), 6, 3.6, 0.3, 7)
+    poses = [([3.0, 3.3, -6.0], [0.0, 100.0]), ([0.0, 40.0, 0.0], [-89.0, 10.0]), ([0.0, 30.0, 60.0], [10.0, 0.0])]   # inside, above, outside
+    RT = [ocam.camera_RT(x, v) for x, v in poses]
+    cams = ho.cams12(np.stack([r for r, _ in RT]), np.stack([t for _, t in RT]))
+    for contrast in (1.0, 1.4):
+        z, rgb = ho.raster_rgbz(mesh.verts, mesh.faces, mesh.colors, cams, 256, 456, 0.85, contrast)
+        zo, _ = ho.raster_zbuf(mesh.verts, mesh.faces, cams, 256, 456)
+        assert torch.equal(z, zo)                                              # the colour path renders the same depths
+        bg = 0
+        for i, (R, T) in enumerate(RT):
+            wz, wrgb = csim.raster_rgbz(mesh.verts_host, mesh.faces_host, mesh.colors_host, R, T, 256, 456, ocam.TAN_HALF_FOV, 0.85,
+                                        contrast)
+            assert np.array_equal(z[i].cpu().numpy(), wz), i
+            got = rgb[i].cpu().numpy()
+            assert np.array_equal(got, wrgb), (i, contrast, np.abs(got - wrgb).max())
+            bg += int((wz < 0).sum())
+        assert bg > 1000                                                       # white background pixels were exercised
+    # colours of the sub-sampled points
+    z, rgb = ho.raster_rgbz(mesh.verts, mesh.faces, mesh.colors, cams, 256, 456, 0.85, 1.0)
+    cloud, crgb = torch.zeros(60000, 3, device=D), torch.zeros(60000, 3, device=D)
+    cnt = torch.zeros(1, dtype=torch.int64, device=D)
+    ho.unproject_append(z, None, cams, cloud, cnt, 0.05, 70.0, seed=4, rgb=rgb, cloud_rgb=crgb)
+    want_p, want_c = [], []
+    for i, (R, T) in enumerate(RT):
+        p, _, c = ocam.partial_point_cloud(z[i].cpu().numpy(), None, R, T, 0.05, 70.0, 4, frame_index=i, rgb=rgb[i].cpu().numpy())
+        want_p.append(p); want_c.append(c)
+    n = int(cnt.item())
+    assert n == sum(len(p) for p in want_p) > 1000
+    assert np.array_equal(cloud[:n].cpu().numpy(), np.concatenate(want_p)) and np.array_equal(crgb[:n].cpu().numpy(), np.concatenate(want_c))
+    # the deferred form the step loop uses: nearest face per pixel now, colours where they are consumed -- same bits
+    z2, zface = ho.raster_zface(mesh.verts, mesh.faces, cams, 256, 456)
+    assert torch.equal(z2, z)
+    assert torch.equal((zface == -1), (z < 0)) and int((zface[z >= 0] & 0xFFFFFFFF).max()) < mesh.faces.shape[0]
+    assert torch.equal(ho.shade_image(zface, mesh.verts, mesh.faces, mesh.colors, cams, 0.85), rgb)
+    cloud2, crgb2 = torch.zeros_like(cloud), torch.zeros_like(crgb)
+    cnt2 = torch.zeros_like(cnt)
+    ho.unproject_append(z2, None, cams, cloud2, cnt2, 0.05, 70.0, seed=4, cloud_rgb=crgb2,
+                        shade=(zface, mesh.verts, mesh.faces, mesh.colors, 0.85))
+    assert int(cnt2.item()) == n and torch.equal(cloud2, cloud) and torch.equal(crgb2, crgb)
 
 
 def test_raster_never_drops_faces_whatever_the_bin_capacity(hip, tmp_path):

@@ -70,6 +70,8 @@ def main():
     H, W = params.image_height, params.image_width
     zb = torch.empty(4, H, W, device=dev)
     print(f"raster 4 frames: {ev(lambda: hipops.raster_zbuf(mesh.verts, mesh.faces, cams4, H, W, out=zb)):.1f} us")
+    rgbbuf = torch.empty(4, H, W, 3, device=dev)
+    print(f"raster+colours 4 frames: {ev(lambda: hipops.raster_rgbz(mesh.verts, mesh.faces, mesh.colors, cams4, H, W, out_z=zb, out_rgb=rgbbuf)):.1f} us")
     print(f"raster 1 frame : {ev(lambda: hipops.raster_zbuf(mesh.verts, mesh.faces, cams4[:1], H, W, out=zb[:1])):.1f} us")
     scratch = torch.zeros(400_000, 3, device=dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -77,6 +79,12 @@ def main():
     def unproj(k):
         cnt.zero_()
         hipops.unproject_append(zb[:k], None, cams4[:k], scratch, cnt, 0.05, 70.0, seed=1)
+    crgb = torch.zeros(400_000, 3, device=dev)
+
+    def unproj_rgb(k):
+        cnt.zero_()
+        hipops.unproject_append(zb[:k], None, cams4[:k], scratch, cnt, 0.05, 70.0, seed=1, rgb=rgbbuf[:k], cloud_rgb=crgb)
+    print(f"unproject+colours 4 frames: {ev(lambda: unproj_rgb(4)):.1f} us")
     print(f"unproject 4 frames: {ev(lambda: unproj(4)):.1f} us (incl. a 8-B clear);  1 frame: {ev(lambda: unproj(1)):.1f} us")
     x = ro.st.net_in
     print(f"NBP forward B=1: {ev(lambda: net(x), 20):.1f} us")
