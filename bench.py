@@ -48,7 +48,10 @@ TILE_NAMES = {1: "igemm_conv_kernel<2,2,2,2>(128x128)", 2: "igemm_conv_kernel<4,
               3: "igemm_conv_kernel<4,1,2,1>(256x32)", 4: "igemm_conv_kernel<2,2,2,1>(128x64)",
               5: "igemm_conv_kernel<1,4,2,1>(64x128)", 6: "conv3x3_halo_f32_kernel<4,2>(8x32 px x 128 ch)",
               7: "conv3x3_halo_f32_kernel<2,2>(8x32 px x 64 ch)", 8: "conv3x3_halo_f32_kernel<4,1>(4x32 px x 128 ch)",
-              9: "conv3x3_halo_f32_kernel<2,1>(4x32 px x 64 ch)"}
+              9: "conv3x3_halo_f32_kernel<2,1>(4x32 px x 64 ch)",
+              10: "conv3x3_halo_split16_kernel<true>(8x32 px x 64 ch; fp32 operands as 3 bf16 pieces, 6 bf16 MFMAs per product)"}
+SPLIT_TILE = 10
+TIMED = {"fp32": "nbp_forward_timed_f32", "fp32_split": "nbp_forward_timed_split_f32", "bf16": "nbp_forward_timed_bf16"}
 
 
 def parse():
@@ -87,9 +90,10 @@ def timed_layers(packed, x, out1, out2, ws):
     arr = (_lib.LayerTiming * 128)()
     n = C.c_int(0)
     B, _, S, _ = x.shape
-    rc = _lib.lib().nbp_forward_timed_f32(packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(),
-                                          ws.data_ptr(), ws.numel(), _lib.current_stream(), arr, 128, C.byref(n))
-    _lib.check(rc, "nbp_forward_timed_f32")
+    fn = TIMED[packed.precision]
+    rc = getattr(_lib.lib(), fn)(packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), _lib.current_stream(), arr, 128, C.byref(n))
+    _lib.check(rc, fn)
     return [dict(name=a.name.decode(), flops=a.flops, ms=a.ms, tile=a.tile, split_k=a.split_k, M=a.M, N=a.N, K=a.K)
             for a in arr[:n.value]]
 
@@ -109,7 +113,7 @@ def _pmc_means(csv_dir):
     return {k: {c: s / n for c, (n, s) in v.items()} for k, v in acc.items()}
 
 
-def live_traffic(n_points):
+def live_traffic(n_points, precision="fp32"):
     """Runs tools/pmc_workload.py (the B=8, 256x256 fp32 forward + the map accumulation over n_points) under rocprofv3 with
     ONE counter per pass (FETCH_SIZE and WRITE_SIZE cannot share a pass, MI355X_MICROARCH.md) and returns
     {kernel prefix -> bytes per launch} with the guide's gfx950 correction: 2 * FETCH_SIZE + WRITE_SIZE (KB -> B)."""
@@ -122,7 +126,7 @@ def live_traffic(n_points):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(out, counter)
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
-               os.path.join(ROOT, "tools", "pmc_workload.py"), "--points", str(n_points)]
+               os.path.join(ROOT, "tools", "pmc_workload.py"), "--points", str(n_points), "--precision", precision]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
         except subprocess.TimeoutExpired:
@@ -308,7 +312,7 @@ def main():
         packed = net._ensure_packed(dev)
         o1 = torch.empty(R, 8, S // 4, S // 4, device=dev)
         o2 = torch.empty(R, 1, S, S, device=dev)
-        ws = packing._workspace(R, S, dev)
+        ws = packing._workspace(R, S, dev, packed.precision)
         reps, acc = 5, {}
         for r in range(reps + 1):
             rows = timed_layers(packed, x, o1, o2, ws)
@@ -338,15 +342,22 @@ def main():
         pose, _ = cam.get_pose_from_idx(cam.cam_idx)
         live, live_src = (None, "disabled (--no-live-traffic)")
         if world == 1 and not args.no_live_traffic:
-            live, live_src = live_traffic(n_pts)
+            live, live_src = live_traffic(n_pts, packed.precision)
         dom_prefix = TILE_NAMES[dom].split("(")[0].replace(" ", "")
         traffic = pick_traffic(live, dom_prefix) if (R, S) == (8, 256) else None
         traffic_src = live_src
         if traffic is None and (R, S) == (8, 256):
-            traffic, src2 = committed_traffic(dom_prefix, "forward_f32_pmc_summary.csv")
+            traffic, src2 = committed_traffic(dom_prefix, "forward_split_pmc_summary.csv" if dom == SPLIT_TILE
+                                              else "forward_f32_pmc_summary.csv")
             traffic_src = f"{src2}; live pass: {live_src}" if src2 else live_src
+        # the split kernel issues six bf16 MFMAs per fp32 product: its ceiling is the dense bf16 peak / 6 of ALGORITHMIC flops
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if dom == SPLIT_TILE else PEAK_F32_MFMA_TFLOPS
         roofline = {"bound": "mfma", "kernel": TILE_NAMES[dom], "achieved": round(achieved, 3),
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "peak": round(peak, 2), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    "peak_basis": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per product (algorithmic fp32 flops)"
+                                   if dom == SPLIT_TILE else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                    "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "issued_mfma_tflops": round(achieved * (6 if dom == SPLIT_TILE else 1), 1),
                     "traffic": None if traffic is None else round(traffic),
                     "traffic_unit": "HBM-side bytes per launch: 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide)",
                     "traffic_source": traffic_src,
@@ -355,7 +366,7 @@ def main():
                     "avg_launch_ms": round(d["ms"] / d["launches"], 5), "flops_per_launch": d["flops"] / d["launches"],
                     "note": "avg_launch_ms: HIP event pair per layer on the launch stream (a split-K layer includes its reduce)",
                     "all_igemm_tflops": round(cf / (cm * 1e-3) / 1e12, 3),
-                    "all_igemm_frac": round(cf / (cm * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                    "all_igemm_frac_of_f32_mfma_peak": round(cf / (cm * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
         if args.layers:
             for r in layer_rows:
                 tf = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0
@@ -369,8 +380,16 @@ def main():
                                    "tflops": round(L.nbp_forward_flops(1, S) / (ms_fwd1 * 1e-3) / 1e12, 3),
                                    "frac_of_f32_mfma_peak": round(L.nbp_forward_flops(1, S) / (ms_fwd1 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
         stage["nbp_forward"] = {"ms": round(ms_fwd, 4), "batch": R, "maps_per_s": round(R * 1e3 / ms_fwd, 2),
-                                "tflops": round(fl / (ms_fwd * 1e-3) / 1e12, 3),
+                                "tflops": round(fl / (ms_fwd * 1e-3) / 1e12, 3), "conv_precision": net.conv_precision,
                                 "frac_of_f32_mfma_peak": round(fl / (ms_fwd * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+        if net.conv_precision != "fp32" and not args.no_extra_stages:
+            # the same forward on the fp32 MFMA pipe (NBP_CONV_PRECISION=fp32 makes it the rollouts' path)
+            pk32 = packing.pack_state_dict(sd, dev, precision="fp32")
+            ms32 = ev_time(lambda: packing.forward_packed(pk32, x))
+            stage["nbp_forward_fp32_pipe"] = {"ms": round(ms32, 4), "batch": R, "maps_per_s": round(R * 1e3 / ms32, 2),
+                                              "tflops": round(fl / (ms32 * 1e-3) / 1e12, 3),
+                                              "frac_of_f32_mfma_peak": round(fl / (ms32 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+            pk32.free()
         # map accumulation: the HBM-bound scatter.  Event pair on the launch stream around `reps` launches; bytes =
         # 12 N (every point read once) + 24 S^2 (six channels written once)
         ms_sc = ev_time(lambda: hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=ro.st.cloud_count,
@@ -497,6 +516,11 @@ def main():
                                    f"{int(mesh.faces.shape[0])} faces), 256x256 grid, {R} concurrent rollouts per GPU on "
                                    f"{R} scenes (NBP forwards batched), 5 depth frames of 256x456 per step per "
                                    "rollout, seeded synthetic NBP weights",
+                       "conv_arithmetic": {"fp32_split": "fp32 tensors; 3x3 convolutions cut every fp32 operand exactly into 3 bf16 "
+                                                         "pieces and evaluate the product as 6 exact bf16 MFMAs with fp32 "
+                                                         "accumulation (error vs fp64 <= the fp32 MFMA pipe's: "
+                                                         "tests/test_gpu_split.py)",
+                                           "fp32": "fp32 MFMA pipe"}.get(net.conv_precision, net.conv_precision),
                        "grid": S, "rollouts_per_gpu": R, "image": [params.image_height, params.image_width],
                        "window_steps": [first_step, last_step], "gt_points": int(gt.shape[0])},
             "nbp_maps_per_s": round(world * stage["nbp_forward"]["maps_per_s"], 2),

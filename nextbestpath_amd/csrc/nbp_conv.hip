@@ -22,38 +22,6 @@
 #include <cstdlib>
 
 
-struct IgemmArgs {
-    const float* src0;
-    const float* src1;
-    int C0, C1;        // channels of each source (multiples of 32; C1 may be 0)
-    int cc0;           // C0 / 32
-    int ups;           // 1: sources are [B,H/2,W/2,C] read through x2 nearest upsample
-    int H, W;          // output spatial size
-    int Hs, Ws;        // source spatial size
-    int taps;          // 1 (1x1) or 9 (3x3)
-    const float* wpk;  // [(C0+C1)/32][taps][N][32]
-    int N;
-    const float* scale;
-    const float* shift;
-    int relu;
-    float* out;        // split_k==1: [M][N] final; else partial [split][M][N]
-    long long M;
-    int split_k;
-    int chunks_total;
-    int chunks_per_split;
-    unsigned bytes0, bytes1;   // byte sizes of src0 / src1 (buffer-descriptor range, < 2 GiB)
-    unsigned bytesw;           // byte size of the packed weights (halo kernel streams them through a descriptor)
-    float* partial;    // split-K scratch [group][split][M][N]
-    // second problem of a grouped launch (same shapes, other tensors): blockIdx.z >= split_k
-    int groups;
-    const float* g_src0;
-    const float* g_src1;
-    const float* g_wpk;
-    const float* g_scale;
-    const float* g_shift;
-    float* g_out;
-    int xcd_remap;     // 1: workgroups of one XCD take a contiguous run of (m, n) tiles (n fastest)
-};
 
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IgemmArgs a) {

@@ -22,6 +22,8 @@ struct Table {
     size_t w_off[NBP_N_CONV];   // float offsets into the packed buffer
     size_t s_off[NBP_N_CONV], t_off[NBP_N_CONV];
     size_t total_floats;
+    size_t w3_off[NBP_N_CONV];  // byte offsets of the split planes (3x3 layers), after the fp32 pack
+    size_t total3_bytes;
     Table() {
         int i = 0;
         const int enc[5] = {64, 128, 256, 512, 1024};
@@ -59,6 +61,12 @@ struct Table {
             t_off[j] = take(s.cout);
         }
         total_floats = off;
+        size_t off3 = 0;
+        for (int j = 0; j < NBP_N_CONV; ++j) {
+            w3_off[j] = off3;
+            if (L[j].kind == K_CONV3) off3 += ((size_t)L[j].cout * L[j].cin * 9 * 6 + 255) / 256 * 256;
+        }
+        total3_bytes = off3;
     }
 };
 const Table& table() { static Table t; return t; }
@@ -88,6 +96,8 @@ struct nbp_weights {
     const float* scale[NBP_N_CONV];
     const float* shift[NBP_N_CONV];
     int bf16;
+    const void* w3[NBP_N_CONV];     // split handle: hi/mid/lo bf16 planes of the 3x3 layers (nbp_split.hip)
+    int split;
 };
 
 extern "C" int nbp_abi_version(void) {
@@ -110,10 +120,10 @@ extern "C" size_t nbp_packed_weights_bytes(void) { return table().total_floats *
 
 static int pack_weights_impl(const void* const* w_host_array, const void* const* scale_host_array,
                              const void* const* shift_host_array, void* packed, size_t packed_bytes, void* stream,
-                             nbp_weights** handle_out, bool bf16) {
+                             nbp_weights** handle_out, bool bf16, bool split = false) {
     NBP_RETURN_IF(!w_host_array || !scale_host_array || !shift_host_array || !packed || !handle_out, NBP_E_ARG);
     const Table& T = table();
-    NBP_RETURN_IF(packed_bytes < T.total_floats * sizeof(float), NBP_E_WS);
+    NBP_RETURN_IF(packed_bytes < T.total_floats * sizeof(float) + (split ? T.total3_bytes : 0), NBP_E_WS);
     for (int i = 0; i < NBP_N_CONV; ++i) {
         NBP_RETURN_IF(!w_host_array[i] || !scale_host_array[i], NBP_E_ARG);
         NBP_RETURN_IF(T.L[i].kind != K_ATT_X && !shift_host_array[i], NBP_E_ARG);
@@ -123,6 +133,8 @@ static int pack_weights_impl(const void* const* w_host_array, const void* const*
     nbp_weights* h = (nbp_weights*)calloc(1, sizeof(nbp_weights));
     NBP_RETURN_IF(!h, NBP_E_ARG);
     h->bf16 = bf16 ? 1 : 0;
+    h->split = split ? 1 : 0;
+    char* base3 = (char*)packed + T.total_floats * sizeof(float);
     int rc = 0;
     for (int i = 0; i < NBP_N_CONV && !rc; ++i) {
         const LayerSpec& s = T.L[i];
@@ -150,6 +162,10 @@ static int pack_weights_impl(const void* const* w_host_array, const void* const*
                           : nbp_pack_conv_weight(w, s.cout, s.cin, 3, nullptr, 0, s.cin, wd, st);
                 if (!rc) rc = copy_f32(sc, sd, s.cout, st);
                 if (!rc) rc = copy_f32(sh, td, s.cout, st);
+                if (!rc && split) {
+                    h->w3[i] = base3 + T.w3_off[i];
+                    rc = nbp_pack_conv_weight_split_launch(w, s.cout, s.cin, 3, nullptr, 0, s.cin, base3 + T.w3_off[i], st);
+                }
                 break;
             case K_ATT_G: {
                 // joint GEMM over K=[g|x]: scale folded into the weights, epilogue scale = 1
@@ -192,6 +208,16 @@ extern "C" int nbp_pack_weights_bf16(const void* const* w_host_array, const void
     NBP_ENTER();
     return pack_weights_impl(w_host_array, scale_host_array, shift_host_array, packed, packed_bytes, stream, handle_out,
                              true);
+}
+
+// fp32 pack + the hi/mid/lo bf16 planes of every 3x3 layer: the handle serves nbp_forward_f32 and nbp_forward_split_f32
+extern "C" size_t nbp_packed_weights_bytes_split(void) { return table().total_floats * sizeof(float) + table().total3_bytes; }
+extern "C" int nbp_pack_weights_split(const void* const* w_host_array, const void* const* scale_host_array,
+                                      const void* const* shift_host_array, void* packed, size_t packed_bytes,
+                                      void* stream, nbp_weights** handle_out) {
+    NBP_ENTER();
+    return pack_weights_impl(w_host_array, scale_host_array, shift_host_array, packed, packed_bytes, stream, handle_out,
+                             false, true);
 }
 
 extern "C" void nbp_free_weights(nbp_weights* handle) { free(handle); }
@@ -251,8 +277,9 @@ struct PathF32 {
     static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0) {
         return nbp_plan_conv(M, N, chunks, 0, 0, groups, H, H, ksize);
     }
-    static int conv(const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks, int N, void* ws, size_t wsb,
-                    hipStream_t st) {
+    static constexpr int MODE = 0;
+    static int conv(const nbp_weights*, const int*, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks,
+                    int N, void* ws, size_t wsb, hipStream_t st) {
         return nbp_conv_igemm_launch_g(o, o2, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st);
     }
     static int first(const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {
@@ -267,6 +294,24 @@ struct PathF32 {
         return nbp_final_1x1_f32(in, B, H, H, C, w, no, sc, sh, sig, out, st);
     }
 };
+// fp32 tensors; the 3x3 layers the split kernel takes run on the bf16 matrix pipe (exact hi/mid/lo operand splitting),
+// everything else is PathF32's
+struct PathSplit : PathF32 {
+    static constexpr int MODE = 2;
+    static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0) {
+        const ConvPlan p = nbp_plan_conv_split(M, N, chunks, 0, groups, H, H, ksize);
+        return p.tile ? p : PathF32::plan(M, N, chunks, groups, H, ksize);
+    }
+    static int conv(const nbp_weights* h, const int* li, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H,
+                    int ks, int N, void* ws, size_t wsb, hipStream_t st) {
+        const ConvPlan p = nbp_plan_conv_split((long long)B * H * H, N, (C0 + C1) / 32 * ks * ks, 0, o2 ? 2 : 1, H, H, ks);
+        if (!p.tile) return PathF32::conv(h, li, o, o2, C0, C1, ups, B, H, ks, N, ws, wsb, st);
+        Ops a = o, b = o2 ? *o2 : o;
+        a.wpk = (const float*)h->w3[li[0]];
+        if (o2) b.wpk = (const float*)h->w3[li[1]];
+        return nbp_conv_split_launch_g(a, o2 ? &b : nullptr, C0, C1, ups, B, H, H, ks, N, 1, 0, ws, wsb, st);
+    }
+};
 struct PathBF16 {
     typedef bf16_t T;
     typedef ConvOperandsH Ops;
@@ -274,8 +319,9 @@ struct PathBF16 {
     static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0) {
         return nbp_plan_conv_bf16(M, N, chunks, 0, 0, groups, H, H, ksize);
     }
-    static int conv(const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks, int N, void* ws, size_t wsb,
-                    hipStream_t st) {
+    static constexpr int MODE = 1;
+    static int conv(const nbp_weights*, const int*, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks,
+                    int N, void* ws, size_t wsb, hipStream_t st) {
         return nbp_conv_igemm_bf16_launch_g(o, o2, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st);
     }
     static int first(const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {
@@ -336,7 +382,7 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
         Ops o[2];
         for (int g = 0; g < ng; ++g)
             o[g] = Ops{s0[g], s1 ? s1[g] : nullptr, (const T*)h->w[li[g]], h->scale[li[g]], h->shift[li[g]], out[g]};
-        rc = P::conv(o[0], ng == 2 ? &o[1] : nullptr, C0, C1, ups, B, Hh, ksize, N, skws, skbytes, st);
+        rc = P::conv(h, li, o[0], ng == 2 ? &o[1] : nullptr, C0, C1, ups, B, Hh, ksize, N, skws, skbytes, st);
         if (tm && !rc) {
             const long long M = (long long)B * Hh * Hh;
             const int K = (C0 + C1) * ksize * ksize;
@@ -448,7 +494,7 @@ static int forward_impl(const nbp_weights* handle, const float* x, int B, int S,
                         size_t ws_bytes, void* stream, nbp_layer_timing* timings_host, int max_entries,
                         int* n_entries_host) {
     NBP_RETURN_IF(!handle || !x || !out1 || !out2 || !ws, NBP_E_ARG);
-    NBP_RETURN_IF(handle->bf16 != (sizeof(typename P::T) == 2 ? 1 : 0), NBP_E_ARG);   // handle packed for the other path
+    NBP_RETURN_IF(handle->bf16 != (P::MODE == 1 ? 1 : 0) || (P::MODE == 2 && !handle->split), NBP_E_ARG);   // handle packed for another path
     NBP_RETURN_IF(B < 1, NBP_E_ARG);
     NBP_RETURN_IF(S < 16 || S % 16, NBP_E_SHAPE);
     NBP_RETURN_IF(ws_bytes < workspace_bytes_impl<P>(B, S), NBP_E_WS);
@@ -473,6 +519,21 @@ extern "C" int nbp_forward_f32(const nbp_weights* handle, const float* x, int B,
                                void* ws, size_t ws_bytes, void* stream) {
     NBP_ENTER();
     return forward_impl<PathF32>(handle, x, B, S, out1, out2, ws, ws_bytes, stream, nullptr, 0, nullptr);
+}
+
+extern "C" size_t nbp_forward_workspace_bytes_split(int B, int S) { return workspace_bytes_impl<PathSplit>(B, S); }
+extern "C" int nbp_forward_split_f32(const nbp_weights* handle, const float* x, int B, int S, float* out1, float* out2,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
+    return forward_impl<PathSplit>(handle, x, B, S, out1, out2, ws, ws_bytes, stream, nullptr, 0, nullptr);
+}
+extern "C" int nbp_forward_timed_split_f32(const nbp_weights* handle, const float* x, int B, int S, float* out1,
+                                           float* out2, void* ws, size_t ws_bytes, void* stream,
+                                           nbp_layer_timing* timings_host, int max_entries, int* n_entries_host) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!timings_host || !n_entries_host, NBP_E_ARG);
+    return forward_impl<PathSplit>(handle, x, B, S, out1, out2, ws, ws_bytes, stream, timings_host, max_entries,
+                                   n_entries_host);
 }
 
 extern "C" int nbp_forward_bf16(const nbp_weights* handle, const float* x, int B, int S, float* out1, float* out2,

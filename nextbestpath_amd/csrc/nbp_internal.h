@@ -7,16 +7,58 @@ typedef unsigned short bf16_t;   // bf16 storage
 enum { NBP_TILE_AUTO = 0, NBP_TILE_128x128 = 1, NBP_TILE_256x64 = 2, NBP_TILE_256x32 = 3, NBP_TILE_128x64 = 4,
        NBP_TILE_64x128 = 5,
        NBP_TILE_HALO_128 = 6, NBP_TILE_HALO_64 = 7,
-       NBP_TILE_HALO4_128 = 8, NBP_TILE_HALO4_64 = 9 };   // fp32 only: 4x32-pixel tiles   // 8x32-pixel halo-tile kernels (3x3 only), BN = 128 / 64
+       NBP_TILE_HALO4_128 = 8, NBP_TILE_HALO4_64 = 9,
+       NBP_TILE_SPLIT_HALO_64 = 10 };   // nbp_split.hip: 8x32-pixel halo tiles, BN = 64, bf16x3 matrix pipe   // fp32 only: 4x32-pixel tiles   // 8x32-pixel halo-tile kernels (3x3 only), BN = 128 / 64
 struct TileInfo { int bm, bn; };
 struct ConvPlan { int tile; int split_k; int chunks_per_split; };
 
 // fp32 path (nbp_conv.hip)
+// kernel arguments of the fp32-activation convolutions (nbp_conv.hip, nbp_split.hip)
+struct IgemmArgs {
+    const float* src0;
+    const float* src1;
+    int C0, C1;        // channels of each source (multiples of 32; C1 may be 0)
+    int cc0;           // C0 / 32
+    int ups;           // 1: sources are [B,H/2,W/2,C] read through x2 nearest upsample
+    int H, W;          // output spatial size
+    int Hs, Ws;        // source spatial size
+    int taps;          // 1 (1x1) or 9 (3x3)
+    const float* wpk;  // [(C0+C1)/32][taps][N][32]
+    int N;
+    const float* scale;
+    const float* shift;
+    int relu;
+    float* out;        // split_k==1: [M][N] final; else partial [split][M][N]
+    long long M;
+    int split_k;
+    int chunks_total;
+    int chunks_per_split;
+    unsigned bytes0, bytes1;   // byte sizes of src0 / src1 (buffer-descriptor range, < 2 GiB)
+    unsigned bytesw;           // byte size of the packed weights (halo kernel streams them through a descriptor)
+    float* partial;    // split-K scratch [group][split][M][N]
+    // second problem of a grouped launch (same shapes, other tensors): blockIdx.z >= split_k
+    int groups;
+    const float* g_src0;
+    const float* g_src1;
+    const float* g_wpk;
+    const float* g_scale;
+    const float* g_shift;
+    float* g_out;
+    int xcd_remap;     // 1: workgroups of one XCD take a contiguous run of (m, n) tiles (n fastest)
+};
 struct ConvOperands { const float* src0; const float* src1; const float* wpk; const float* scale; const float* shift; float* out; };
 ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k, int groups, int H = 0, int W = 0,
                        int ksize = 0);
 int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C0, int C1, int ups, int B, int H, int W,
                             int ksize, int N, int relu, int split_k, int tile, void* ws, size_t ws_bytes, hipStream_t st);
+
+// split path (nbp_split.hip): fp32 tensors, 3x3 layers on the bf16 matrix pipe through exact hi/mid/lo operand splitting;
+// wpk of the operands = the bf16 planes of nbp_pack_conv_weight_split_launch.  plan.tile == 0: layer not taken.
+ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize);
+int nbp_conv_split_launch_g(const ConvOperands& o, const ConvOperands* o2, int C0, int C1, int ups, int B, int H, int W,
+                            int ksize, int N, int relu, int split_k, void* ws, size_t ws_bytes, hipStream_t st);
+int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
+                                      int c_total, void* dst, hipStream_t st);
 
 // bf16 path (nbp_bf16.hip); K chunks are 64 channels
 struct ConvOperandsH { const bf16_t* src0; const bf16_t* src1; const bf16_t* wpk; const float* scale; const float* shift; bf16_t* out; };

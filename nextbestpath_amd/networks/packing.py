@@ -48,8 +48,13 @@ def fold_affine(sd, conv, bn, eps=1e-5):
 class PackedWeights:
     """Owns the device buffer and the C handle; freed explicitly or on GC."""
 
-    def __init__(self, handle, buf, keep, bf16=False):
-        self.handle, self.buf, self.keep, self.bf16 = handle, buf, keep, bf16
+    def __init__(self, handle, buf, keep, bf16=False, precision=None):
+        self.handle, self.buf, self.keep = handle, buf, keep
+        self.precision = precision or ("bf16" if bf16 else "fp32")
+
+    @property
+    def bf16(self):
+        return self.precision == "bf16"
 
     def free(self):
         if self.handle:
@@ -63,8 +68,19 @@ class PackedWeights:
             pass
 
 
-def pack_state_dict(sd, device, bf16: bool = False) -> PackedWeights:
-    """bf16=True packs for nbp_forward_bf16 (bf16 conv weights / activations, fp32 accumulate and epilogues)."""
+PRECISIONS = ("fp32", "fp32_split", "bf16")
+_PACK = {"fp32": ("nbp_pack_weights", "nbp_packed_weights_bytes"), "bf16": ("nbp_pack_weights_bf16", "nbp_packed_weights_bytes"),
+         "fp32_split": ("nbp_pack_weights_split", "nbp_packed_weights_bytes_split")}
+_FWD = {"fp32": ("nbp_forward_f32", "nbp_forward_workspace_bytes"), "bf16": ("nbp_forward_bf16", "nbp_forward_workspace_bytes_bf16"),
+        "fp32_split": ("nbp_forward_split_f32", "nbp_forward_workspace_bytes_split")}
+
+
+def pack_state_dict(sd, device, bf16: bool = False, precision: str = None) -> PackedWeights:
+    """precision: "fp32" (fp32 MFMA), "fp32_split" (fp32 tensors, 3x3 layers as six exact bf16 MFMAs per product -- the
+    same accuracy at 2.67x the matrix rate; its handle also serves "fp32"), "bf16" (bf16 conv weights / activations, fp32
+    accumulate and epilogues; nbp_forward_bf16).  bf16=True is the older spelling of precision="bf16"."""
+    precision = precision or ("bf16" if bf16 else "fp32")
+    assert precision in PRECISIONS, precision
     L = _lib.lib()
     layers = canonical_layers()
     ws, ss, ts, keep = [], [], [], []
@@ -78,32 +94,32 @@ def pack_state_dict(sd, device, bf16: bool = False) -> PackedWeights:
         t = shift.to(torch.float32).to(device).contiguous()
         keep += [w, s, t]
         ws.append(w.data_ptr()); ss.append(s.data_ptr()); ts.append(t.data_ptr())
-    nbytes = L.nbp_packed_weights_bytes()
+    nbytes = getattr(L, _PACK[precision][1])()
     buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
     arr = lambda v: (C.c_void_p * 48)(*v)
     handle = C.c_void_p()
     with torch.cuda.device(device):
-        fn = L.nbp_pack_weights_bf16 if bf16 else L.nbp_pack_weights
+        fn = getattr(L, _PACK[precision][0])
         rc = fn(arr(ws), arr(ss), arr(ts), buf.data_ptr(), nbytes, _lib.current_stream(), C.byref(handle))
         _lib.check(rc, "nbp_pack_weights")
         torch.cuda.current_stream().synchronize()   # sources in `keep` may now be released
-    return PackedWeights(handle, buf, None, bf16)
+    return PackedWeights(handle, buf, None, precision=precision)
 
 
 def pack_eval_weights(module, device) -> PackedWeights:
-    return pack_state_dict(module.state_dict(), device, bf16=getattr(module, "conv_precision", "fp32") == "bf16")
+    return pack_state_dict(module.state_dict(), device, precision=getattr(module, "conv_precision", "fp32"))
 
 
 _ws_cache = {}
 
 
-def _workspace(B, S, device, bf16=False):
+def _workspace(B, S, device, precision="fp32"):
     # one workspace per (shape, stream): forwards enqueued on different streams may run concurrently
-    key = (B, S, str(device), bf16, torch.cuda.current_stream(device).cuda_stream)
+    key = (B, S, str(device), precision, torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None:
         L = _lib.lib()
-        n = L.nbp_forward_workspace_bytes_bf16(B, S) if bf16 else L.nbp_forward_workspace_bytes(B, S)
+        n = getattr(L, _FWD[precision][1])(B, S)
         if n == 0:
             raise _lib.NbpHipError(f"unsupported NBP input size B={B} S={S}")
         ws = torch.empty(n, dtype=torch.uint8, device=device)
@@ -114,17 +130,21 @@ def _workspace(B, S, device, bf16=False):
     return ws
 
 
-def forward_packed(packed: PackedWeights, x: torch.Tensor):
+def forward_packed(packed: PackedWeights, x: torch.Tensor, precision: str = None):
+    """precision overrides the handle's own only where the handle allows it ("fp32" on a "fp32_split" handle)."""
+    precision = precision or packed.precision
+    if precision != packed.precision and not (precision == "fp32" and packed.precision == "fp32_split"):
+        raise ValueError(f"weights packed for {packed.precision!r} cannot run the {precision!r} forward")
     B, _, S, _ = x.shape
     x = x.contiguous().float()
     out1 = torch.empty(B, 8, S // 4, S // 4, dtype=torch.float32, device=x.device)
     out2 = torch.empty(B, 1, S, S, dtype=torch.float32, device=x.device)
-    ws = _workspace(B, S, x.device, packed.bf16)
-    fn = _lib.lib().nbp_forward_bf16 if packed.bf16 else _lib.lib().nbp_forward_f32
+    ws = _workspace(B, S, x.device, precision)
+    fn = getattr(_lib.lib(), _FWD[precision][0])
     with torch.cuda.device(x.device):
         rc = fn(packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(), ws.data_ptr(), ws.numel(),
                 _lib.current_stream())
-    _lib.check(rc, "nbp_forward_bf16" if packed.bf16 else "nbp_forward_f32")
+    _lib.check(rc, _FWD[precision][0])
     return out1, out2
 
 

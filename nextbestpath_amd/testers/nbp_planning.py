@@ -376,7 +376,7 @@ def run_many(params, nbp, dataset, runs, device, seeds, test_resolution=0.05, n_
 def test_nbp_planning(params_file, model_file, results_json_file, numGPU, test_scenes, test_resolution=0.05,
                       use_perfect_depth_map=False, compute_collision=False, load_json=False, dataset_path=None,
                       nbp_weights=None, configs_dir=None, results_dir=None, n_poses=N_POSES, seed=8, torch_seed=9,
-                      rollouts_per_gpu=8, grid_size=256, nbp_precision="fp32"):
+                      rollouts_per_gpu=8, grid_size=256, nbp_precision=None):
     """Same arguments as the reference (nbp_planning.py:364-374); `grid_size` / `nbp_precision` select
     BASELINE.json configs[4] (512 grid at the same 0.3125 units per pixel, bf16 convolutions).  Under torchrun the flattened
     (scene, start pose) runs are sharded round-robin over the ranks and the coverage curves are
@@ -400,8 +400,9 @@ def test_nbp_planning(params_file, model_file, results_json_file, numGPU, test_s
         print("[nbp] no checkpoint at", nbp_weights, "-> seeded synthetic weights")
         nbp.load_state_dict(make_explorer_state_dict(torch_seed))
     nbp.to(device).eval()
-    assert nbp_precision in ("fp32", "bf16"), nbp_precision
-    nbp.conv_precision = nbp_precision
+    assert nbp_precision in (None, "fp32", "fp32_split", "bf16"), nbp_precision
+    if nbp_precision is not None:           # None: the model's default ("fp32_split")
+        nbp.conv_precision = nbp_precision
     dataset = sim_scene.SceneDataset(dataset_path, test_scenes)
     runs = list_runs(dataset, params)
     mine = shard(runs, rank, world)

@@ -128,6 +128,7 @@ def _module(nbp_weights):
     from nextbestpath_amd.networks.nbp_model import NBP
     net = NBP()
     net.load_state_dict(nbp_weights, strict=True)
+    net.conv_precision = "fp32"        # this file: the fp32 MFMA pipe (tests/test_gpu_split.py: the default split path)
     return net.cuda().eval()
 
 

@@ -1,0 +1,150 @@
+"""GPU parity of the split path: fp32 convolutions whose products run on the bf16 matrix pipe as six exact bf16 MFMAs per
+product (nbp_split.hip).  It is an fp32 path -- same tensors, same 1e-4 bar against the torch-fp32 oracle and the reference's
+golden vectors as nbp_forward_f32 -- and its error against fp64 must not exceed the fp32 MFMA path's (both are measured)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_helpers import conv3x3_split, conv_igemm, nchw, nhwc, pack_conv, pack_conv_split
+from nextbestpath_amd import _lib
+from oracle import nbp_net
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def test_weight_planes_sum_to_the_weight_exactly(hip):
+    """hi + mid + lo == w bit for bit (three pieces of 8 significand bits); layout [chunk of 16 channels][tap][plane]
+    [k half][N][8] (the default kernel's; NBP_SPLIT_VARIANT=32 packs [chunk of 32][tap][plane][N][32])."""
+    if os.environ.get("NBP_SPLIT_VARIANT") == "32":
+        pytest.skip("layout of the default variant")
+    w = (_rand(64, 96, 3, 3, seed=1) * torch.logspace(-6, 3, 96).view(1, -1, 1, 1)).cuda().contiguous()
+    planes = pack_conv_split(w).view(6, 9, 3, 2, 64, 8)        # chunk16, tap, plane, k half, n, c
+    f = (planes.to(torch.int32) << 16).view(torch.float32)
+    total = (f[:, :, 0].double() + f[:, :, 1].double() + f[:, :, 2].double()).float()      # exact in fp64, then exact in fp32
+    want = w.view(64, 6, 2, 8, 9).permute(1, 4, 2, 0, 3)       # [chunk16][tap][k half][n][c]
+    assert torch.equal(total, want)
+    # pieces are ordered: truncation leaves at most 8 significant bits each
+    assert bool((f[:, :, 1].abs() <= f[:, :, 0].abs() * 2.0 ** -7).all()) and bool((f[:, :, 2].abs() <= f[:, :, 1].abs() * 2.0 ** -7 + 1e-45).all())
+
+
+# (B, H, W, C0, C1, N, ups, split_k)
+CASES = [
+    (1, 16, 32, 64, 0, 128, 0, 1),      # image borders on every side, two n blocks
+    (2, 8, 64, 96, 0, 64, 0, 1),        # three chunks, two images
+    (1, 8, 16, 64, 0, 128, 1, 1),       # fused x2 nearest upsample (16 x 32 output)
+    (1, 16, 32, 32, 64, 256, 0, 1),     # fused concat
+    (3, 24, 96, 32, 0, 64, 0, 1),       # 3 x 3 tiles per image: an interior tile without padding
+    (1, 8, 32, 256, 0, 128, 0, 4),      # split-K over whole chunks (8 chunks / 4)
+    (1, 16, 32, 96, 64, 64, 0, 2),      # ragged split (5 chunks / 2) across the concat seam
+    (2, 32, 32, 128, 0, 128, 0, 0),     # automatic split-K, B = 2 at 32 x 32
+]
+
+
+@pytest.mark.parametrize("dual", ["1", "0"])
+@pytest.mark.parametrize("case", CASES)
+def test_conv3x3_split_vs_fp64_and_fp32_path(hip, case, dual, monkeypatch):
+    B, H, W, C0, C1, N, ups, split_k = case
+    if dual == "0" and case is not CASES[0]:
+        pytest.skip("single-accumulator variant: one case (the switch is read once per process)")
+    dev = "cuda"
+    x0 = _rand(B, C0, H, W, seed=1)
+    x1 = _rand(B, C1, H, W, seed=2) if C1 else None
+    w = _rand(N, C0 + C1, 3, 3, seed=3, scale=(6.0 / ((C0 + C1) * 9)) ** 0.5)
+    scale = _rand(N, seed=4) * 0.2 + 1.0
+    shift = _rand(N, seed=5) * 0.1
+    xin = x0 if x1 is None else torch.cat((x0, x1), 1)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2)
+    ref = F.relu(F.conv2d(xin.double(), w.double(), None, padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    wd = w.to(dev).contiguous()
+    x0d, x1d = nhwc(x0).to(dev), None if x1 is None else nhwc(x1).to(dev)
+    scd, shd = scale.to(dev), shift.to(dev)
+    got = nchw(conv3x3_split(x0d, x1d, ups, pack_conv_split(wd), N, scd, shd, True, split_k)).cpu().double()
+    f32 = nchw(conv_igemm(x0d, x1d, ups, pack_conv(wd), N, 3, scd, shd, True, 0, 0)).cpu().double()
+    assert got.shape == ref.shape
+    e_split, e_f32 = (got - ref).abs(), (f32 - ref).abs()
+    assert e_split.max().item() < 4e-6 and e_split.max().item() <= 2.0 * e_f32.max().item() + 1e-7, (e_split.max(), e_f32.max())
+    assert e_split.pow(2).mean().sqrt().item() <= 1.2 * e_f32.pow(2).mean().sqrt().item() + 1e-9
+
+
+def test_split_kernel_refuses_what_it_does_not_take(hip):
+    dev = "cuda"
+    x = torch.zeros(1, 16, 16, 64, device=dev)                          # 16 wide: no 32-pixel tile
+    sc = torch.ones(64, device=dev)
+    planes = torch.zeros(2 * 9 * 3 * 64 * 32, dtype=torch.int16, device=dev)
+    with pytest.raises(_lib.NbpHipError):
+        conv3x3_split(x, None, 0, planes, 64, sc, sc, True)
+    with pytest.raises(_lib.NbpHipError):
+        conv3x3_split(torch.zeros(1, 8, 32, 64, device=dev), None, 0, planes, 32, sc[:32], sc[:32], True)   # N % 64
+
+
+def _module(nbp_weights, precision):
+    from nextbestpath_amd.networks.nbp_model import NBP
+    net = NBP()
+    net.load_state_dict(nbp_weights, strict=True)
+    net.conv_precision = precision
+    return net.cuda().eval()
+
+
+@pytest.fixture(scope="module")
+def nets(nbp_weights):
+    return _module(nbp_weights, "fp32_split"), _module(nbp_weights, "fp32")
+
+
+@pytest.mark.parametrize("tag", ["S32", "S64B2", "S128"])
+def test_split_forward_vs_reference_golden(hip, nets, golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"nbp_fwd_{tag}.npz"))
+    with torch.no_grad():
+        o1, o2 = nets[0](torch.from_numpy(g["x"]).cuda())
+    o1, o2 = o1.cpu().numpy(), o2.cpu().numpy()
+    assert np.abs(o1 - g["out1"]).max() < TOL and np.abs(o2 - g["out2"]).max() < TOL
+    B = o1.shape[0]
+    assert np.array_equal(o1.max(1).reshape(B, -1).argmax(1), g["out1"].max(1).reshape(B, -1).argmax(1))
+    assert np.array_equal(o1.reshape(B, 8, -1).argmax(2), g["out1"].reshape(B, 8, -1).argmax(2))
+    assert np.array_equal(o2 >= 0.13, g["out2"] >= 0.13)
+
+
+@pytest.mark.parametrize("B,S", [(1, 256), (4, 256), (2, 96), (3, 64), (1, 512)])
+def test_split_forward_vs_oracle_and_fp32_path(hip, nets, nbp_weights, B, S):
+    """Against the torch-fp32 CPU oracle at the 1e-4 bar, and next to the fp32 MFMA path against an fp64 evaluation of the
+    same network: the split path's error is not larger."""
+    from nextbestpath_amd.utility.synthetic import make_count_maps
+    x = make_count_maps(B, S, seed=40 + S + B)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    with torch.no_grad():
+        o1, o2 = nets[0](x.cuda())
+        f1, f2 = nets[1](x.cuda())
+        r1, r2 = nbp_net.nbp_forward(nbp_weights, x)
+    assert (o1.cpu() - r1).abs().max() < TOL and (o2.cpu() - r2).abs().max() < TOL
+    assert torch.equal(o1.cpu().amax(1).flatten(1).argmax(1), r1.amax(1).flatten(1).argmax(1))
+    if S <= 256 and B <= 2:
+        sd64 = {k: v.double() for k, v in nbp_weights.items()}
+        with torch.no_grad():
+            d1, d2 = nbp_net.nbp_forward(sd64, x.double())
+        for o, f, d in ((o1, f1, d1), (o2, f2, d2)):
+            es, ef = (o.cpu().double() - d).abs(), (f.cpu().double() - d).abs()
+            assert es.max().item() <= 2.0 * ef.max().item() + 1e-7, (es.max().item(), ef.max().item())
+            assert es.mean().item() <= 1.25 * ef.mean().item() + 1e-9, (es.mean().item(), ef.mean().item())
+
+
+def test_split_handle_also_runs_the_fp32_forward(hip, nets, nbp_weights):
+    from nextbestpath_amd.networks import packing
+    from nextbestpath_amd.utility.synthetic import make_count_maps
+    x = make_count_maps(2, 64, seed=9).cuda()
+    pk = packing.pack_state_dict(nbp_weights, "cuda", precision="fp32_split")
+    a1, a2 = packing.forward_packed(pk, x, precision="fp32")
+    with torch.no_grad():
+        f1, f2 = nets[1](x)
+    assert torch.equal(a1, f1) and torch.equal(a2, f2)
+    pk32 = packing.pack_state_dict(nbp_weights, "cuda", precision="fp32")
+    with pytest.raises(ValueError):
+        packing.forward_packed(pk32, x, precision="fp32_split")

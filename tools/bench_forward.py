@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Whole-network forward timing through nbp_forward_timed_{f32,bf16}: per-layer table + totals.
-    python tools/bench_forward.py [--bf16] [--batch 8] [--size 512] [--reps 10]"""
+"""Whole-network forward timing through nbp_forward_timed_{f32,split_f32,bf16}: per-layer table + totals.
+    python tools/bench_forward.py [--bf16 | --split] [--batch 8] [--size 512] [--reps 10]"""
 import argparse
 import ctypes as C
 import os
@@ -17,6 +17,7 @@ from nextbestpath_amd.utility.synthetic import make_count_maps, make_nbp_state_d
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--split", action="store_true", help="fp32 tensors, 3x3 layers as six exact bf16 MFMAs per product")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--reps", type=int, default=10)
@@ -24,15 +25,16 @@ def main():
     a = ap.parse_args()
     L = _lib.lib()
     dev = torch.device("cuda")
-    packed = packing.pack_state_dict(make_nbp_state_dict(9), dev, bf16=a.bf16)
+    prec = "bf16" if a.bf16 else ("fp32_split" if a.split else "fp32")
+    packed = packing.pack_state_dict(make_nbp_state_dict(9), dev, precision=prec)
     B, S = a.batch, a.size
     x = make_count_maps(B, S, seed=1).to(dev)
     o1 = torch.empty(B, 8, S // 4, S // 4, device=dev)
     o2 = torch.empty(B, 1, S, S, device=dev)
-    nws = L.nbp_forward_workspace_bytes_bf16(B, S) if a.bf16 else L.nbp_forward_workspace_bytes(B, S)
+    nws = getattr(L, packing._FWD[prec][1])(B, S)
     ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-    fwd = L.nbp_forward_bf16 if a.bf16 else L.nbp_forward_f32
-    timed = L.nbp_forward_timed_bf16 if a.bf16 else L.nbp_forward_timed_f32
+    fwd = getattr(L, packing._FWD[prec][0])
+    timed = getattr(L, {"fp32": "nbp_forward_timed_f32", "bf16": "nbp_forward_timed_bf16", "fp32_split": "nbp_forward_timed_split_f32"}[prec])
 
     def run():
         _lib.check(fwd(packed.handle, x.data_ptr(), B, S, o1.data_ptr(), o2.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -66,7 +68,7 @@ def main():
                   f"{m*1e3:9.1f} us {tf:8.1f} TF")
     igemm = sum(sorted(r["ms"])[len(r["ms"]) // 2] for r in acc.values() if r["tile"] > 0)
     other = sum(sorted(r["ms"])[len(r["ms"]) // 2] for r in acc.values() if r["tile"] <= 0)
-    print(f"{'bf16' if a.bf16 else 'f32'} B={B} S={S}: {ms:.3f} ms/forward  {B/ms*1e3:.1f} maps/s  {fl/ms/1e9:.1f} TF "
+    print(f"{prec} B={B} S={S}: {ms:.3f} ms/forward  {B/ms*1e3:.1f} maps/s  {fl/ms/1e9:.1f} TF "
           f"(event-bracketed: igemm {igemm:.3f} ms, other kernels {other:.3f} ms; workspace {nws/2**20:.0f} MiB)")
 
 

@@ -24,17 +24,19 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--precision", default=None, choices=packing.PRECISIONS)
     a = ap.parse_args()
+    prec = a.precision or ("bf16" if a.bf16 else "fp32")
     L = _lib.lib()
     dev = torch.device("cuda")
-    packed = packing.pack_state_dict(make_nbp_state_dict(9), dev, bf16=a.bf16)
+    packed = packing.pack_state_dict(make_nbp_state_dict(9), dev, precision=prec)
     B, S = a.batch, a.size
     x = make_count_maps(B, S, seed=1).to(dev)
     o1 = torch.empty(B, 8, S // 4, S // 4, device=dev)
     o2 = torch.empty(B, 1, S, S, device=dev)
-    nws = L.nbp_forward_workspace_bytes_bf16(B, S) if a.bf16 else L.nbp_forward_workspace_bytes(B, S)
+    nws = getattr(L, packing._FWD[prec][1])(B, S)
     ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-    fwd = L.nbp_forward_bf16 if a.bf16 else L.nbp_forward_f32
+    fwd = getattr(L, packing._FWD[prec][0])
     for _ in range(2):
         _lib.check(fwd(packed.handle, x.data_ptr(), B, S, o1.data_ptr(), o2.data_ptr(), ws.data_ptr(), ws.numel(),
                        _lib.current_stream()), "forward")
