@@ -13,6 +13,8 @@ the parameter gradients have the reference's shapes.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _lib
@@ -74,6 +76,42 @@ def _igemm(src0, src1, ups, wpk, N, ksize, scale, shift, relu):
     return out
 
 
+# 3x3 convolutions of the forward and of the data gradient on the bf16 matrix pipe through exact hi/mid/lo operand
+# splitting (csrc/nbp_split.hip: the fp32 pipe's accuracy at 2.67x its rate); NBP_TRAIN_SPLIT=0 keeps the fp32 MFMA pipe.
+_SPLIT = os.environ.get("NBP_TRAIN_SPLIT", "1") != "0"
+
+
+def _split_ok(H, W, N, ksize):
+    return _SPLIT and ksize == 3 and H % 8 == 0 and W % 32 == 0 and N % 64 == 0
+
+
+def _pack_split(w_oihw, n_pad, c_total):
+    """OIHW fp32 [N, C, 3, 3] -> hi/mid/lo bf16 planes for N padded to n_pad rows and C to c_total channels (zeros)."""
+    N, C, k, _ = w_oihw.shape
+    planes = torch.zeros(c_total // 16 * 9 * 6 * n_pad * 8, dtype=torch.int16, device=w_oihw.device)
+    # the pack kernel indexes rows by the padded count: give it a zero-padded weight when N < n_pad
+    if N != n_pad:
+        wp = torch.zeros(n_pad, C, k, k, dtype=torch.float32, device=w_oihw.device)
+        wp[:N] = w_oihw
+        w_oihw = wp
+    _chk(_lib.lib().nbp_pack_conv_weight_split(_lib.ptr(w_oihw), n_pad, C, 3, None, 0, c_total, _lib.ptr(planes), _st()),
+         "pack_split")
+    return planes
+
+
+def _conv_split(src0, src1, ups, planes, N, scale, shift, relu):
+    L = _lib.lib()
+    B, Hs, Ws, C0 = src0.shape
+    H, W = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
+    C1 = 0 if src1 is None else src1.shape[3]
+    out = torch.empty(B, H, W, N, dtype=torch.float32, device=src0.device)
+    ws = _ws(L.nbp_conv_split_workspace_bytes(B, H, W, N, 0), src0.device)
+    _chk(L.nbp_conv3x3_split_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, _lib.ptr(planes), N,
+                                 _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), 0, _lib.ptr(ws), ws.numel(),
+                                 _st()), "conv3x3_split")
+    return out
+
+
 class ConvFn(torch.autograd.Function):
     """y = conv_k(cat(x0, x1) [x2 nearest-upsampled]) + bias; weight OIHW [N, c_real, k, k].
     x0 / x1 channel counts are multiples of 64 (c_real < C0 only for the zero-padded network input)."""
@@ -86,13 +124,17 @@ class ConvFn(torch.autograd.Function):
         C1 = 0 if x1 is None else x1.shape[3]
         Ctot, Np = C0 + C1, _up(N)
         dev = x0.device
-        wpk = torch.empty(Ctot // 32 * k * k * Np * 32, dtype=torch.float32, device=dev)
         w = weight.detach().contiguous()
-        _chk(L.nbp_pack_conv_weight_padded(_lib.ptr(w), N, c_real, k, Ctot, Np, _lib.ptr(wpk), _st()), "pack_fwd")
         scale = torch.ones(Np, dtype=torch.float32, device=dev)
         shift = torch.zeros(Np, dtype=torch.float32, device=dev)
         shift[:N] = bias.detach()
-        y = _igemm(x0, x1, ups, wpk, Np, k, scale, shift, False)
+        H, W = (x0.shape[1] * 2, x0.shape[2] * 2) if ups else (x0.shape[1], x0.shape[2])
+        if _split_ok(H, W, Np, k):
+            y = _conv_split(x0, x1, ups, _pack_split(w, Np, Ctot), Np, scale, shift, False)
+        else:
+            wpk = torch.empty(Ctot // 32 * k * k * Np * 32, dtype=torch.float32, device=dev)
+            _chk(L.nbp_pack_conv_weight_padded(_lib.ptr(w), N, c_real, k, Ctot, Np, _lib.ptr(wpk), _st()), "pack_fwd")
+            y = _igemm(x0, x1, ups, wpk, Np, k, scale, shift, False)
         ctx.save_for_backward(x0, x1 if x1 is not None else torch.empty(0, device=dev), w)
         ctx.meta = (N, c_real, k, C0, C1, Np, bool(ups), x1 is not None)
         return _slice_channels(y, 0, N)
@@ -115,11 +157,16 @@ class ConvFn(torch.autograd.Function):
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             Ctot = C0 + C1
-            wt = torch.empty(Np // 32 * k * k * Ctot * 32, dtype=torch.float32, device=dev)
-            _chk(L.nbp_pack_conv_weight_dgrad(_lib.ptr(w), N, c_real, k, Ctot, Np, _lib.ptr(wt), _st()), "pack_dgrad")
             one = torch.ones(Ctot, dtype=torch.float32, device=dev)
             zero = torch.zeros(Ctot, dtype=torch.float32, device=dev)
-            dx = _igemm(dy, None, False, wt, Ctot, k, one, zero, False)            # [B,H,W,Ctot] at output resolution
+            if _split_ok(H, W, Ctot, k):
+                # dx = conv3x3(dy, w^T with the taps reversed): output channels = the (padded) input channels
+                wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()                # [c_real, N, 3, 3]
+                dx = _conv_split(dy, None, False, _pack_split(wt, Ctot, Np), Ctot, one, zero, False)
+            else:
+                wt = torch.empty(Np // 32 * k * k * Ctot * 32, dtype=torch.float32, device=dev)
+                _chk(L.nbp_pack_conv_weight_dgrad(_lib.ptr(w), N, c_real, k, Ctot, Np, _lib.ptr(wt), _st()), "pack_dgrad")
+                dx = _igemm(dy, None, False, wt, Ctot, k, one, zero, False)        # [B,H,W,Ctot] at output resolution
             if ups:
                 low = torch.empty(B, H // 2, W // 2, Ctot, dtype=torch.float32, device=dev)
                 _chk(L.nbp_sum2x2_f32(_lib.ptr(dx), B, H // 2, W // 2, Ctot, _lib.ptr(low), _st()), "sum2x2")
