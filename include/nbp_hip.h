@@ -115,7 +115,8 @@ int nbp_forward_timed_bf16(const nbp_weights* handle, const float* x, int B, int
  * Tensors, accumulation and epilogues are fp32 exactly as in nbp_forward_f32; inside the 3x3 kernels every fp32 operand is
  * cut EXACTLY into three bf16 pieces (hi + mid + lo = x) and the product is evaluated as six exact bf16 MFMAs (the three
  * dropped cross terms are < 2^-23 of the product): the same accuracy against fp64 as the fp32 MFMA chain at 2.67x its
- * rate.  Layers the split kernel does not take (1x1, 16x16 images) run nbp_forward_f32's kernels.  The handle of
+ * rate.  Layers the split kernel does not take (1x1 convolutions, images narrower than 16 pixels) run nbp_forward_f32's
+ * kernels.  The handle of
  * nbp_pack_weights_split (`packed` of nbp_packed_weights_bytes_split()) also serves nbp_forward_f32. */
 size_t nbp_packed_weights_bytes_split(void);
 int nbp_pack_weights_split(const void* const* w_host_array, const void* const* scale_host_array,
@@ -128,8 +129,9 @@ int nbp_forward_timed_split_f32(const nbp_weights* handle, const float* x, int B
                                 void* ws, size_t ws_bytes, void* stream, nbp_layer_timing* timings_host,
                                 int max_entries, int* n_entries_host);
 /* One 3x3 layer of that path (stride 1, zero padding 1; src1 / ups as nbp_conv_igemm_f32): w_planes from
- * nbp_pack_conv_weight_split = [chunk of 32 channels][tap][hi|mid|lo][N][32] bf16 (6 bytes per weight).  H % 8 == 0,
- * W % 32 == 0, N % 64 == 0, channel counts multiples of 32; NBP_E_SHAPE otherwise.  split_k 0 = automatic. */
+ * nbp_pack_conv_weight_split = [chunk of 16 channels][tap][hi|mid|lo][k half][N][8] bf16 (6 bytes per weight).  Images of
+ * 8 x 32 pixel tiles (H % 8 == 0, W % 32 == 0) or 16 x 16 pixel tiles (H % 16 == 0, W % 16 == 0), N % 64 == 0, channel
+ * counts multiples of 32; NBP_E_SHAPE otherwise.  split_k 0 = automatic. */
 int nbp_pack_conv_weight_split(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
                                int c_total, void* dst_planes, void* stream);
 size_t nbp_conv_split_workspace_bytes(int B, int H, int W, int N, int split_k);

@@ -56,7 +56,10 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsi
 // between barriers, with the next stage's weights DMA'd (buffer_load ... lds) behind it.  The next chunk's halo loads are
 // issued before the chunk's first stage and consumed (split + ds_write) after its last one.
 // DUAL: the five small products accumulate apart from hi x hi and join it once at the end.
-template <bool DUAL>
+// TW = tile width: 32 (8 x 32 pixel tiles; a 32-pixel MFMA row block = one image row) or 16 (16 x 16 pixel tiles for the
+// 16-pixel-wide levels; a row block = two image rows of 16, whose second half-group of a ds_read_b128 lands 2 slots off
+// the conflict-free pattern: 18-pixel halo rows).
+template <bool DUAL, int TW>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_split16_kernel(IgemmArgs a) {
     int zs = blockIdx.z;        // split-K slice (of 16-channel chunks), then the group
     if (zs >= a.split_k) {
@@ -64,7 +67,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         a.src0 = a.g_src0; a.src1 = a.g_src1; a.wpk = a.g_wpk; a.scale = a.g_scale; a.shift = a.g_shift; a.out = a.g_out;
     }
     constexpr int TM = 2, TN = 2, BN = 64;
-    constexpr int HW_ = 34, HPIX = 340;
+    constexpr int TH = 256 / TW, RPB = 32 / TW;               // tile height; image rows per 32-pixel row block
+    constexpr int HW_ = TW + 2, HPIX = (TH + 2) * HW_;        // 10 x 34 = 340 / 18 x 18 = 324 halo pixels
     constexpr int RS = 344 * 16 + 64;                          // bytes between (plane, k half) regions (+64: ds_write banks)
     constexpr int HALO_BYTES = 6 * RS;
     constexpr int WB = 18 * 1024;                              // one stage: 3 taps x 3 planes x 2 k halves x 64 rows x 16 B
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     char* const wbuf = ldsb + HALO_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_x = a.W >> 5, tiles_y = a.H >> 3;
+    const int tiles_x = a.W / TW, tiles_y = a.H / TH;
     unsigned tile = blockIdx.x, nt = blockIdx.y;
     if (a.xcd_remap) {
         const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, T = gridDim.x * gridDim.y;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y;
     const int b = tile / tiles_y;
-    const int y0 = ty * 8, x0 = tx * 32;
+    const int y0 = ty * TH, x0 = tx * TW;
     const int n0 = nt * BN;
 
     // halo staging: piece f = tid + 256 k is channels 4 (f & 3) .. + 3 of halo pixel f >> 2
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
 
     const int khalf = lane >> 5;
-    const int hbase = (TM * wave) * HW_ + (lane & 31);
+    const int hbase = (TM * wave * RPB + ((lane & 31) / TW)) * HW_ + ((lane & 31) % TW);
     const char* const arow = halo + khalf * RS + hbase * 16;               // + plane * 2 RS + halo-row shift * 16
     const int brow = khalf * 1024 + (lane & 31) * 16;                      // + (tap * 6 + plane * 2) KB + N tile * 512
 
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
-                        xp[i][p] = *reinterpret_cast<const u32x4*>(arow + p * (2 * RS) + ((row + i) * HW_ + tt) * 16);
+                        xp[i][p] = *reinterpret_cast<const u32x4*>(arow + p * (2 * RS) + ((row + i * RPB) * HW_ + tt) * 16);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -233,10 +237,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (final_out) { sc = a.scale[n]; sh = a.shift[n]; }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const long long mrow = ((long long)b * a.H + y0 + TM * wave + i) * a.W + x0;
+            const long long mrow = ((long long)b * a.H + y0 + (TM * wave + i) * RPB) * a.W + x0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int px = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int pb = (r & 3) + 8 * (r >> 2) + 4 * khalf;              // pixel of the 32-pixel row block
+                const int px = (pb / TW) * a.W + (pb % TW);
                 float v = acc[i][j][r];
                 if constexpr (DUAL) v += accs[i][j][r];
                 if (final_out) {
@@ -296,23 +301,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_split_kernel(const float* _
     }
 }
 
-template <bool DUAL>
+template <bool DUAL, int TW>
 int launch_split16(const IgemmArgs& a, hipStream_t st) {
     constexpr size_t smem = 6 * (size_t)(344 * 16 + 64) + 2 * (size_t)18 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_split16_kernel<DUAL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_split16_kernel<DUAL, TW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((unsigned)(a.M / 256), (unsigned)(a.N / 64), (unsigned)(a.split_k * a.groups));
-    conv3x3_halo_split16_kernel<DUAL><<<grid, 256, smem, st>>>(a);
+    conv3x3_halo_split16_kernel<DUAL, TW><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 
-bool split_halo_ok(int H, int W, int N, int ksize) {
-    return ksize == 3 && H >= 8 && W >= 32 && H % 8 == 0 && (W & 31) == 0 && N % 64 == 0;
+// tile width the layer runs with: 32 (8 x 32 pixel tiles), 16 (16 x 16) or 0 (not taken)
+int split_tile_width(int H, int W, int N, int ksize) {
+    if (ksize != 3 || N % 64) return 0;
+    if (H >= 8 && H % 8 == 0 && W >= 32 && W % 32 == 0) return 32;
+    if (H >= 16 && H % 16 == 0 && W >= 16 && W % 16 == 0) return 16;
+    return 0;
 }
 
 }  // namespace
@@ -322,7 +331,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
     ConvPlan p{0, 1, chunks_total};
     static const int allow = [] { const char* e = getenv("NBP_SPLIT_HALO"); return e ? atoi(e) : 1; }();
     static const int min_blocks = [] { const char* e = getenv("NBP_SPLIT_MIN_BLOCKS"); return e ? atoi(e) : 512; }();
-    if (!allow || !split_halo_ok(H, W, N, ksize)) return p;
+    if (!allow || !split_tile_width(H, W, N, ksize)) return p;
     const int cc = chunks_total / 9 * 2;      // the kernel's K chunks are 16 channels (chunks_total counts (32 channels, tap))
     const long long blocks = (M / 256) * (N / 64) * groups;
     int sk = split_k;
@@ -374,7 +383,9 @@ int nbp_conv_split_launch_g(const ConvOperands& o, const ConvOperands* o2, int C
     }
     static const int dual = [] { const char* e = getenv("NBP_SPLIT_DUAL"); return e ? atoi(e) : 1; }();
     a.chunks_total = (C0 + C1) / 16;                            // the kernel counts 16-channel chunks
-    int rc = dual ? launch_split16<true>(a, st) : launch_split16<false>(a, st);
+    const int tw = split_tile_width(H, W, N, ksize);
+    int rc = tw == 32 ? (dual ? launch_split16<true, 32>(a, st) : launch_split16<false, 32>(a, st))
+                      : (dual ? launch_split16<true, 16>(a, st) : launch_split16<false, 16>(a, st));
     if (rc) return rc;
     if (p.split_k > 1) {
         const long long MN = a.M * N;

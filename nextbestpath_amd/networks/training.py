@@ -82,7 +82,7 @@ _SPLIT = os.environ.get("NBP_TRAIN_SPLIT", "1") != "0"
 
 
 def _split_ok(H, W, N, ksize):
-    return _SPLIT and ksize == 3 and H % 8 == 0 and W % 32 == 0 and N % 64 == 0
+    return _SPLIT and ksize == 3 and N % 64 == 0 and ((H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0))
 
 
 def _pack_split(w_oihw, n_pad, c_total):

@@ -46,6 +46,9 @@ CASES = [
     (1, 8, 32, 256, 0, 128, 0, 4),      # split-K over whole chunks (8 chunks / 4)
     (1, 16, 32, 96, 64, 64, 0, 2),      # ragged split (5 chunks / 2) across the concat seam
     (2, 32, 32, 128, 0, 128, 0, 0),     # automatic split-K, B = 2 at 32 x 32
+    (2, 16, 16, 64, 0, 128, 0, 1),      # 16 x 16 pixel tiles (the bottleneck level of a 256 grid): one tile per image
+    (1, 32, 48, 96, 32, 64, 0, 2),      # 16 x 16 tiles, 2 x 3 per image, concat + split-K
+    (1, 8, 8, 512, 0, 1024, 1, 0),      # 16 x 16 tiles + fused upsample + automatic split-K over 32 chunks
 ]
 
 
@@ -78,7 +81,7 @@ def test_conv3x3_split_vs_fp64_and_fp32_path(hip, case, dual, monkeypatch):
 
 def test_split_kernel_refuses_what_it_does_not_take(hip):
     dev = "cuda"
-    x = torch.zeros(1, 16, 16, 64, device=dev)                          # 16 wide: no 32-pixel tile
+    x = torch.zeros(1, 8, 24, 64, device=dev)                           # 24 wide: neither 32- nor 16-pixel tiles
     sc = torch.ones(64, device=dev)
     planes = torch.zeros(2 * 9 * 3 * 64 * 32, dtype=torch.int16, device=dev)
     with pytest.raises(_lib.NbpHipError):
