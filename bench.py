@@ -49,7 +49,7 @@ TILE_NAMES = {1: "igemm_conv_kernel<2,2,2,2>(128x128)", 2: "igemm_conv_kernel<4,
               5: "igemm_conv_kernel<1,4,2,1>(64x128)", 6: "conv3x3_halo_f32_kernel<4,2>(8x32 px x 128 ch)",
               7: "conv3x3_halo_f32_kernel<2,2>(8x32 px x 64 ch)", 8: "conv3x3_halo_f32_kernel<4,1>(4x32 px x 128 ch)",
               9: "conv3x3_halo_f32_kernel<2,1>(4x32 px x 64 ch)",
-              10: "conv3x3_halo_split16_kernel<true>(8x32 px x 64 ch; fp32 operands as 3 bf16 pieces, 6 bf16 MFMAs per product)"}
+              10: "conv3x3_halo_split16_kernel<true, 32>(8x32 px x 64 ch; fp32 operands as 3 bf16 pieces, 6 bf16 MFMAs per product)"}
 SPLIT_TILE = 10
 TIMED = {"fp32": "nbp_forward_timed_f32", "fp32_split": "nbp_forward_timed_split_f32", "bf16": "nbp_forward_timed_bf16"}
 

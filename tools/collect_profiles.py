@@ -8,7 +8,8 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 pairs = [("kernel_stats.csv", "kernel_stats.csv"), ("pmc_summary.csv", "pmc_summary.csv"), ("bench.json", "bench.json"),
-         ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("fwd_f32/kernel_stats.csv", "forward_f32_kernel_stats.csv"),
+         ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("fwd_split/kernel_stats.csv", "forward_split_kernel_stats.csv"),
+         ("fwd_split/pmc_summary.csv", "forward_split_pmc_summary.csv"), ("fwd_f32/kernel_stats.csv", "forward_f32_kernel_stats.csv"),
          ("fwd_f32/pmc_summary.csv", "forward_f32_pmc_summary.csv"), ("fwd_bf16/kernel_stats.csv", "forward_bf16_kernel_stats.csv"),
          ("fwd_bf16/pmc_summary.csv", "forward_bf16_pmc_summary.csv"), ("train/kernel_stats.csv", "train_kernel_stats.csv")]
 for a, b in pairs:
