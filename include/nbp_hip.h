@@ -111,13 +111,13 @@ int nbp_forward_timed_bf16(const nbp_weights* handle, const float* x, int B, int
                            float* out2, void* ws, size_t ws_bytes, void* stream,
                            nbp_layer_timing* timings_host, int max_entries, int* n_entries_host);
 
-/* ---- fp32 forward with the 3x3 convolutions on the bf16 matrix pipe ("split" path, nbp_split.hip).
+/* ---- fp32 forward with the 3x3 convolutions on the 16-bit matrix pipe ("split" path, nbp_split.hip).
  * Tensors, accumulation and epilogues are fp32 exactly as in nbp_forward_f32; inside the 3x3 kernels every fp32 operand is
- * cut EXACTLY into three bf16 pieces (hi + mid + lo = x) and the product is evaluated as six exact bf16 MFMAs (the three
- * dropped cross terms are < 2^-23 of the product): the same accuracy against fp64 as the fp32 MFMA chain at 2.67x its
- * rate.  Layers the split kernel does not take (1x1 convolutions, images narrower than 16 pixels) run nbp_forward_f32's
- * kernels.  The handle of
- * nbp_pack_weights_split (`packed` of nbp_packed_weights_bytes_split()) also serves nbp_forward_f32. */
+ * scaled by a power of two taken from its tensor's max |x| and cut into two fp16 pieces (hi + lo = s x up to 2^-23), and
+ * the product is evaluated as three exact fp16 MFMAs (the dropped lo x lo is < 2^-22 of the product): error against fp64
+ * not above the fp32 MFMA chain's at 5.3x its matrix rate.  Layers the split kernel does not take
+ * (1x1 convolutions, images that are not multiples of 16 x 32 / 16 x 16 pixels) run nbp_forward_f32's kernels.  The handle
+ * of nbp_pack_weights_split (`packed` of nbp_packed_weights_bytes_split()) also serves nbp_forward_f32. */
 size_t nbp_packed_weights_bytes_split(void);
 int nbp_pack_weights_split(const void* const* w_host_array, const void* const* scale_host_array,
                            const void* const* shift_host_array, void* packed, size_t packed_bytes, void* stream,
@@ -128,16 +128,23 @@ int nbp_forward_split_f32(const nbp_weights* handle, const float* x, int B, int 
 int nbp_forward_timed_split_f32(const nbp_weights* handle, const float* x, int B, int S, float* out1, float* out2,
                                 void* ws, size_t ws_bytes, void* stream, nbp_layer_timing* timings_host,
                                 int max_entries, int* n_entries_host);
-/* One 3x3 layer of that path (stride 1, zero padding 1; src1 / ups as nbp_conv_igemm_f32): w_planes from
- * nbp_pack_conv_weight_split = [chunk of 16 channels][tap][hi|mid|lo][k half][N][8] bf16 (6 bytes per weight).  Images of
- * 8 x 32 pixel tiles (H % 8 == 0, W % 32 == 0) or 16 x 16 pixel tiles (H % 16 == 0, W % 16 == 0), N % 64 == 0, channel
- * counts multiples of 32; NBP_E_SHAPE otherwise.  split_k 0 = automatic. */
+/* One 3x3 layer of that path (stride 1, zero padding 1; src1 / ups as nbp_conv_igemm_f32).
+ * nbp_pack_conv_weight_split: planes [chunk of 16 channels][tap][hi|lo][k half][N][8] fp16 (4 bytes per weight; zero the
+ * buffer first when C < c_total) scaled by 2^(12 - floor(log2 max|w|)); wamax_out = device word that receives max |w * scale|
+ * (float bits).  c_off must be 0 (one scale per layer).
+ * nbp_conv3x3_split_f32: images of 16 x 32 pixel tiles with N % 64 == 0, or of 16 x 16 pixel tiles with N % 128 == 0; channel
+ * counts multiples of 32; NBP_E_SHAPE otherwise.  amax_in = device word with max |x| over src0 and src1 (float bits; a
+ * bound is enough), NULL = computed here (one more pass over the inputs); amax_out (or NULL) receives max |out| by atomicMax:
+ * zero it before, and hand it to the consumer layer as its amax_in.  nbp_amax_f32 is that pass on its own.  split_k 0 =
+ * automatic; ws >= nbp_conv_split_workspace_bytes. */
 int nbp_pack_conv_weight_split(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
-                               int c_total, void* dst_planes, void* stream);
+                               int c_total, void* dst_planes, void* wamax_out, void* stream);
+int nbp_amax_f32(const float* x, long long n, void* amax_inout, void* stream);
 size_t nbp_conv_split_workspace_bytes(int B, int H, int W, int N, int split_k);
 int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
-                          const void* w_planes, int N, const float* scale, const float* shift, int relu, float* out,
-                          int split_k, void* ws, size_t ws_bytes, void* stream);
+                          const void* w_planes, const void* wamax, int N, const float* scale, const float* shift, int relu,
+                          float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws,
+                          size_t ws_bytes, void* stream);
 /* Single bf16 layer: as nbp_conv_igemm_f32 with bf16 (uint16 storage) NHWC sources / output, C0, C1 multiples
  * of 64, w_packed from nbp_pack_conv_weight_bf16 ([(c_off+c)/64][tap][N][64] bf16), fp32 scale / shift. */
 int nbp_conv_igemm_bf16(const unsigned short* src0, int C0, const unsigned short* src1, int C1, int ups,

@@ -22,7 +22,7 @@ struct Table {
     size_t w_off[NBP_N_CONV];   // float offsets into the packed buffer
     size_t s_off[NBP_N_CONV], t_off[NBP_N_CONV];
     size_t total_floats;
-    size_t w3_off[NBP_N_CONV];  // byte offsets of the split planes (3x3 layers), after the fp32 pack
+    size_t w3_off[NBP_N_CONV];  // byte offsets of the split planes (3x3 layers) in the split region after the fp32 pack
     size_t total3_bytes;
     Table() {
         int i = 0;
@@ -61,10 +61,10 @@ struct Table {
             t_off[j] = take(s.cout);
         }
         total_floats = off;
-        size_t off3 = 0;
+        size_t off3 = 256;           // head of the split region: max |w| of each layer (NBP_N_CONV words)
         for (int j = 0; j < NBP_N_CONV; ++j) {
             w3_off[j] = off3;
-            if (L[j].kind == K_CONV3) off3 += ((size_t)L[j].cout * L[j].cin * 9 * 6 + 255) / 256 * 256;
+            if (L[j].kind == K_CONV3) off3 += ((size_t)L[j].cout * L[j].cin * 9 * 4 + 255) / 256 * 256;
         }
         total3_bytes = off3;
     }
@@ -96,7 +96,8 @@ struct nbp_weights {
     const float* scale[NBP_N_CONV];
     const float* shift[NBP_N_CONV];
     int bf16;
-    const void* w3[NBP_N_CONV];     // split handle: hi/mid/lo bf16 planes of the 3x3 layers (nbp_split.hip)
+    const void* w3[NBP_N_CONV];     // split handle: hi/lo fp16 planes of the 3x3 layers (nbp_split.hip)
+    const unsigned* wamax[NBP_N_CONV];      // ... and max |w| of each (device words, float bits)
     int split;
 };
 
@@ -164,7 +165,9 @@ static int pack_weights_impl(const void* const* w_host_array, const void* const*
                 if (!rc) rc = copy_f32(sh, td, s.cout, st);
                 if (!rc && split) {
                     h->w3[i] = base3 + T.w3_off[i];
-                    rc = nbp_pack_conv_weight_split_launch(w, s.cout, s.cin, 3, nullptr, 0, s.cin, base3 + T.w3_off[i], st);
+                    h->wamax[i] = (const unsigned*)base3 + i;
+                    rc = nbp_pack_conv_weight_split_launch(w, s.cout, s.cin, 3, nullptr, 0, s.cin, base3 + T.w3_off[i],
+                                                           (unsigned*)base3 + i, st);
                 }
                 break;
             case K_ATT_G: {
@@ -270,65 +273,121 @@ struct Timer {
 };
 
 // The two arithmetic paths behind the same driver: element type of the activations, K-chunk width, launchers.
+struct NoCtx { int init(Bump&, hipStream_t, bool) { return 0; } };
 struct PathF32 {
     typedef float T;
     typedef ConvOperands Ops;
+    typedef NoCtx Ctx;
     static constexpr int CHUNK = 32;
     static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0) {
         return nbp_plan_conv(M, N, chunks, 0, 0, groups, H, H, ksize);
     }
     static constexpr int MODE = 0;
-    static int conv(const nbp_weights*, const int*, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks,
+    template <typename C>
+    static int conv(C&, const nbp_weights*, const int*, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks,
                     int N, void* ws, size_t wsb, hipStream_t st) {
         return nbp_conv_igemm_launch_g(o, o2, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st);
     }
-    static int first(const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {
+    template <typename C>
+    static int first(C&, const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {
         return nbp_conv_first_f32(x, B, s, s, (const float*)h->w[0], h->scale[0], h->shift[0], out, st);
     }
-    static int pool(const T* in, int B, int H, int C, T* out, hipStream_t st) { return nbp_maxpool2_nhwc_f32(in, B, H, H, C, out, st); }
-    static int gate(const T* q, int F, const float* w, const float* s2, const T* x, int C, long long M, T* out, hipStream_t st) {
-        return nbp_psi_gate_f32(q, F, w, s2, x, C, M, out, st);
+    template <typename C>
+    static int pool(C&, const T* in, int B, int H, int Cn, T* out, hipStream_t st) { return nbp_maxpool2_nhwc_f32(in, B, H, H, Cn, out, st); }
+    template <typename C>
+    static int gate(C&, const T* q, int F, const float* w, const float* s2, const T* x, int Cn, long long M, T* out, hipStream_t st) {
+        return nbp_psi_gate_f32(q, F, w, s2, x, Cn, M, out, st);
     }
     static int head(const T* in, int B, int H, int C, const float* w, int no, const float* sc, const float* sh, int sig,
                     float* out, hipStream_t st) {
         return nbp_final_1x1_f32(in, B, H, H, C, w, no, sc, sh, sig, out, st);
     }
 };
-// fp32 tensors; the 3x3 layers the split kernel takes run on the bf16 matrix pipe (exact hi/mid/lo operand splitting),
-// everything else is PathF32's
+// fp32 tensors; the 3x3 layers the split kernel takes run on the fp16 matrix pipe (two-piece operand splitting, scales from
+// each tensor's max |x|), everything else is PathF32's.  AmaxBook keeps one device word per activation tensor: written by the
+// split kernel that produces the tensor, inherited through max-pool and the attention gate (|out| <= |in|), computed by a
+// standalone pass for tensors that come from the other kernels (first convolution; 1x1 / odd-size fallbacks).
+struct AmaxBook {
+    unsigned* slots = nullptr;
+    int next = 0, n = 0;
+    hipStream_t st = nullptr;
+    const void* key[128];
+    unsigned* val[128];
+    int init(Bump& bp, hipStream_t s, bool dry) {
+        st = s; next = n = 0;
+        slots = bp.take<unsigned>(128);
+        return dry ? 0 : (int)hipMemsetAsync(slots, 0, 128 * sizeof(unsigned), st);
+    }
+    unsigned* find(const void* p) const {
+        for (int i = n - 1; i >= 0; --i) if (key[i] == p) return val[i];
+        return nullptr;
+    }
+    void bind(const void* p, unsigned* v) { if (n < 128) { key[n] = p; val[n] = v; ++n; } }
+    unsigned* fresh(const void* p) { unsigned* v = next < 128 ? slots + next++ : nullptr; if (v) bind(p, v); return v; }
+    void alias(const void* p, const void* of) { if (unsigned* v = find(of)) bind(p, v); }
+    int ensure(const float* p, long long count, const unsigned** out) {
+        unsigned* v = find(p);
+        int rc = 0;
+        if (!v) {
+            v = fresh(p);
+            if (!v) return NBP_E_WS;
+            rc = nbp_amax_launch(p, count, v, st);
+        }
+        *out = v;
+        return rc;
+    }
+};
 struct PathSplit : PathF32 {
+    typedef AmaxBook Ctx;
     static constexpr int MODE = 2;
     static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0) {
         const ConvPlan p = nbp_plan_conv_split(M, N, chunks, 0, groups, H, H, ksize);
         return p.tile ? p : PathF32::plan(M, N, chunks, groups, H, ksize);
     }
-    static int conv(const nbp_weights* h, const int* li, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H,
-                    int ks, int N, void* ws, size_t wsb, hipStream_t st) {
+    static int conv(Ctx& ctx, const nbp_weights* h, const int* li, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B,
+                    int H, int ks, int N, void* ws, size_t wsb, hipStream_t st) {
         const ConvPlan p = nbp_plan_conv_split((long long)B * H * H, N, (C0 + C1) / 32 * ks * ks, 0, o2 ? 2 : 1, H, H, ks);
-        if (!p.tile) return PathF32::conv(h, li, o, o2, C0, C1, ups, B, H, ks, N, ws, wsb, st);
-        Ops a = o, b = o2 ? *o2 : o;
-        a.wpk = (const float*)h->w3[li[0]];
-        if (o2) b.wpk = (const float*)h->w3[li[1]];
-        return nbp_conv_split_launch_g(a, o2 ? &b : nullptr, C0, C1, ups, B, H, H, ks, N, 1, 0, ws, wsb, st);
+        if (!p.tile) return PathF32::conv(ctx, h, li, o, o2, C0, C1, ups, B, H, ks, N, ws, wsb, st);
+        const long long hw = (long long)B * (ups ? H / 2 : H) * (ups ? H / 2 : H);
+        ConvOperandsSplit s[2];
+        for (int g = 0; g < (o2 ? 2 : 1); ++g) {
+            const Ops& q = g ? *o2 : o;
+            s[g] = ConvOperandsSplit{q.src0, q.src1, h->w3[li[g]], q.scale, q.shift, q.out, nullptr, nullptr, h->wamax[li[g]], nullptr};
+            int rc = ctx.ensure(q.src0, hw * C0, &s[g].amax0);
+            if (!rc && C1) rc = ctx.ensure(q.src1, hw * C1, &s[g].amax1);
+            if (rc) return rc;
+            s[g].amax_out = ctx.fresh(q.out);
+        }
+        return nbp_conv_split_launch_g(s[0], o2 ? &s[1] : nullptr, C0, C1, ups, B, H, H, ks, N, 1, 0, ws, wsb, st);
+    }
+    static int pool(Ctx& ctx, const T* in, int B, int H, int Cn, T* out, hipStream_t st) {
+        ctx.alias(out, in);
+        return nbp_maxpool2_nhwc_f32(in, B, H, H, Cn, out, st);
+    }
+    static int gate(Ctx& ctx, const T* q, int F, const float* w, const float* s2, const T* x, int Cn, long long M, T* out,
+                    hipStream_t st) {
+        ctx.alias(out, x);
+        return nbp_psi_gate_f32(q, F, w, s2, x, Cn, M, out, st);
     }
 };
 struct PathBF16 {
     typedef bf16_t T;
     typedef ConvOperandsH Ops;
+    typedef NoCtx Ctx;
     static constexpr int CHUNK = 64;
     static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0) {
         return nbp_plan_conv_bf16(M, N, chunks, 0, 0, groups, H, H, ksize);
     }
     static constexpr int MODE = 1;
-    static int conv(const nbp_weights*, const int*, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks,
+    static int conv(Ctx&, const nbp_weights*, const int*, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks,
                     int N, void* ws, size_t wsb, hipStream_t st) {
         return nbp_conv_igemm_bf16_launch_g(o, o2, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st);
     }
-    static int first(const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {
+    static int first(Ctx&, const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {
         return nbp_conv_first_bf16_launch(x, B, s, s, (const float*)h->w[0], h->scale[0], h->shift[0], out, st);
     }
-    static int pool(const T* in, int B, int H, int C, T* out, hipStream_t st) { return nbp_maxpool2_bf16_launch(in, B, H, H, C, out, st); }
-    static int gate(const T* q, int F, const float* w, const float* s2, const T* x, int C, long long M, T* out, hipStream_t st) {
+    static int pool(Ctx&, const T* in, int B, int H, int C, T* out, hipStream_t st) { return nbp_maxpool2_bf16_launch(in, B, H, H, C, out, st); }
+    static int gate(Ctx&, const T* q, int F, const float* w, const float* s2, const T* x, int C, long long M, T* out, hipStream_t st) {
         return nbp_psi_gate_bf16_launch(q, F, w, s2, x, C, M, out, st);
     }
     static int head(const T* in, int B, int H, int C, const float* w, int no, const float* sc, const float* sh, int sig,
@@ -374,6 +433,8 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
     }
     float* skws = bp.take<float>(sk ? sk : 64);
     const size_t skbytes = sk * sizeof(float);
+    typename P::Ctx ctx;
+    rc = ctx.init(bp, st, dry);
 
     // one (ng = 1) or two (ng = 2: decoder 1 next to decoder 2) same-shaped convolutions per launch
     auto conv2 = [&](const char* name, int ng, const int* li, const T* const* s0, int C0, const T* const* s1,
@@ -382,7 +443,7 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
         Ops o[2];
         for (int g = 0; g < ng; ++g)
             o[g] = Ops{s0[g], s1 ? s1[g] : nullptr, (const T*)h->w[li[g]], h->scale[li[g]], h->shift[li[g]], out[g]};
-        rc = P::conv(h, li, o[0], ng == 2 ? &o[1] : nullptr, C0, C1, ups, B, Hh, ksize, N, skws, skbytes, st);
+        rc = P::conv(ctx, h, li, o[0], ng == 2 ? &o[1] : nullptr, C0, C1, ups, B, Hh, ksize, N, skws, skbytes, st);
         if (tm && !rc) {
             const long long M = (long long)B * Hh * Hh;
             const int K = (C0 + C1) * ksize * ksize;
@@ -412,11 +473,11 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
         T* a = bp.take<T>(n);
         T* b = bp.take<T>(n);
         if (e == 0) {
-            if (!dry && !rc) rc = P::first(x, B, s, h, a, st);
+            if (!dry && !rc) rc = P::first(ctx, x, B, s, h, a, st);
             stamp("Conv1.conv.0(first)", 2.0 * B * s * s * 64 * 45, (long long)B * s * s, 64, 45);
         } else {
             T* pooled = bp.take<T>((size_t)B * s * s * enc[e - 1]);
-            if (!dry && !rc) rc = P::pool(prev, B, 2 * s, enc[e - 1], pooled, st);
+            if (!dry && !rc) rc = P::pool(ctx, prev, B, 2 * s, enc[e - 1], pooled, st);
             snprintf(nm, sizeof nm, "Maxpool%d", e);
             stamp(nm, 0, (long long)B * s * s, enc[e - 1], 0);
             snprintf(nm, sizeof nm, "Conv%d.conv.0", e + 1);
@@ -459,7 +520,7 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
         snprintf(nm, sizeof nm, "Att%d_%s.W_g+W_x", Lv, tag);
         shifted(1, l); conv2(nm, ng, l, (const T* const*)dd, co, xsa, co, 0, sr, 1, co / 2, q);  // relu(W_g g + W_x x)
         for (int g = 0; g < ng && !dry && !rc; ++g)
-            rc = P::gate(q[g], co / 2, (const float*)h->w[lis[g] + 3], h->scale[lis[g] + 3], xs, co, M, ag[g], st);
+            rc = P::gate(ctx, q[g], co / 2, (const float*)h->w[lis[g] + 3], h->scale[lis[g] + 3], xs, co, M, ag[g], st);
         snprintf(nm, sizeof nm, "Att%d_%s.psi*x", Lv, tag);
         stamp(nm, 2.0 * ng * M * (co / 2), M, 1, co / 2);
         snprintf(nm, sizeof nm, "Up_conv%d_%s.conv.0", Lv, tag);

@@ -8,7 +8,7 @@ enum { NBP_TILE_AUTO = 0, NBP_TILE_128x128 = 1, NBP_TILE_256x64 = 2, NBP_TILE_25
        NBP_TILE_64x128 = 5,
        NBP_TILE_HALO_128 = 6, NBP_TILE_HALO_64 = 7,
        NBP_TILE_HALO4_128 = 8, NBP_TILE_HALO4_64 = 9,
-       NBP_TILE_SPLIT_HALO_64 = 10 };   // nbp_split.hip: 8x32-pixel halo tiles, BN = 64, bf16x3 matrix pipe   // fp32 only: 4x32-pixel tiles   // 8x32-pixel halo-tile kernels (3x3 only), BN = 128 / 64
+       NBP_TILE_SPLIT_HALO_64 = 10 };   // nbp_split.hip: 16x32 / 16x16-pixel halo tiles on the fp16 matrix pipe   // fp32 only: 4x32-pixel tiles   // 8x32-pixel halo-tile kernels (3x3 only), BN = 128 / 64
 struct TileInfo { int bm, bn; };
 struct ConvPlan { int tile; int split_k; int chunks_per_split; };
 
@@ -52,13 +52,20 @@ ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split
 int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C0, int C1, int ups, int B, int H, int W,
                             int ksize, int N, int relu, int split_k, int tile, void* ws, size_t ws_bytes, hipStream_t st);
 
-// split path (nbp_split.hip): fp32 tensors, 3x3 layers on the bf16 matrix pipe through exact hi/mid/lo operand splitting;
-// wpk of the operands = the bf16 planes of nbp_pack_conv_weight_split_launch.  plan.tile == 0: layer not taken.
+// split path (nbp_split.hip): fp32 tensors, 3x3 layers on the fp16 matrix pipe through two-piece operand splitting.
+// planes / wamax from nbp_pack_conv_weight_split_launch; amax0 / amax1 = device words holding max |x| (float bits) of the
+// sources (amax1 unused without a second source); amax_out (may be null) receives max |out| by atomicMax (caller zeroes it).
+// plan.tile == 0: layer not taken.
+struct ConvOperandsSplit {
+    const float* src0; const float* src1; const void* planes; const float* scale; const float* shift; float* out;
+    const unsigned* amax0; const unsigned* amax1; const unsigned* wamax; unsigned* amax_out;
+};
 ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize);
-int nbp_conv_split_launch_g(const ConvOperands& o, const ConvOperands* o2, int C0, int C1, int ups, int B, int H, int W,
+int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C0, int C1, int ups, int B, int H, int W,
                             int ksize, int N, int relu, int split_k, void* ws, size_t ws_bytes, hipStream_t st);
 int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
-                                      int c_total, void* dst, hipStream_t st);
+                                      int c_total, void* dst, unsigned* wamax_out, hipStream_t st);
+int nbp_amax_launch(const float* x, long long n, unsigned* amax_inout, hipStream_t st);
 
 // bf16 path (nbp_bf16.hip); K chunks are 64 channels
 struct ConvOperandsH { const bf16_t* src0; const bf16_t* src1; const bf16_t* wpk; const float* scale; const float* shift; bf16_t* out; };

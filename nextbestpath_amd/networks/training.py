@@ -76,39 +76,42 @@ def _igemm(src0, src1, ups, wpk, N, ksize, scale, shift, relu):
     return out
 
 
-# 3x3 convolutions of the forward and of the data gradient on the bf16 matrix pipe through exact hi/mid/lo operand
-# splitting (csrc/nbp_split.hip: the fp32 pipe's accuracy at 2.67x its rate); NBP_TRAIN_SPLIT=0 keeps the fp32 MFMA pipe.
+# 3x3 convolutions of the forward and of the data gradient on the fp16 matrix pipe through two-piece operand splitting
+# (csrc/nbp_split.hip: the fp32 pipe's accuracy at 5.3x its matrix rate); NBP_TRAIN_SPLIT=0 keeps the fp32 MFMA pipe.
 _SPLIT = os.environ.get("NBP_TRAIN_SPLIT", "1") != "0"
 
 
 def _split_ok(H, W, N, ksize):
-    return _SPLIT and ksize == 3 and N % 64 == 0 and ((H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0))
+    return _SPLIT and ksize == 3 and H % 16 == 0 and ((W % 32 == 0 and N % 64 == 0) or (W % 16 == 0 and N % 128 == 0))
 
 
 def _pack_split(w_oihw, n_pad, c_total):
-    """OIHW fp32 [N, C, 3, 3] -> hi/mid/lo bf16 planes for N padded to n_pad rows and C to c_total channels (zeros)."""
+    """OIHW fp32 [N, C, 3, 3] -> (hi/lo fp16 planes for N padded to n_pad rows and C to c_total channels, max |w| word)."""
     N, C, k, _ = w_oihw.shape
-    planes = torch.zeros(c_total // 16 * 9 * 6 * n_pad * 8, dtype=torch.int16, device=w_oihw.device)
+    planes = torch.zeros(c_total // 16 * 9 * 4 * n_pad * 8, dtype=torch.int16, device=w_oihw.device)
+    wamax = torch.zeros(1, dtype=torch.int32, device=w_oihw.device)
     # the pack kernel indexes rows by the padded count: give it a zero-padded weight when N < n_pad
     if N != n_pad:
         wp = torch.zeros(n_pad, C, k, k, dtype=torch.float32, device=w_oihw.device)
         wp[:N] = w_oihw
         w_oihw = wp
-    _chk(_lib.lib().nbp_pack_conv_weight_split(_lib.ptr(w_oihw), n_pad, C, 3, None, 0, c_total, _lib.ptr(planes), _st()),
-         "pack_split")
-    return planes
+    _chk(_lib.lib().nbp_pack_conv_weight_split(_lib.ptr(w_oihw), n_pad, C, 3, None, 0, c_total, _lib.ptr(planes), _lib.ptr(wamax),
+                                               _st()), "pack_split")
+    return planes, wamax
 
 
-def _conv_split(src0, src1, ups, planes, N, scale, shift, relu):
+def _conv_split(src0, src1, ups, packed, N, scale, shift, relu):
     L = _lib.lib()
+    planes, wamax = packed
     B, Hs, Ws, C0 = src0.shape
     H, W = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     C1 = 0 if src1 is None else src1.shape[3]
     out = torch.empty(B, H, W, N, dtype=torch.float32, device=src0.device)
     ws = _ws(L.nbp_conv_split_workspace_bytes(B, H, W, N, 0), src0.device)
-    _chk(L.nbp_conv3x3_split_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, _lib.ptr(planes), N,
-                                 _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), 0, _lib.ptr(ws), ws.numel(),
-                                 _st()), "conv3x3_split")
+    # max |x| of the inputs is taken inside the call (amax_in NULL): autograd hands tensors over without their history
+    _chk(L.nbp_conv3x3_split_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, _lib.ptr(planes), _lib.ptr(wamax), N,
+                                 _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), None, None, 0, _lib.ptr(ws),
+                                 ws.numel(), _st()), "conv3x3_split")
     return out
 
 

@@ -75,29 +75,31 @@ def conv_igemm_bf16(src0, src1, ups, wpk, N, ksize, scale, shift, relu, split_k=
     return out
 
 
-# ---- split path (fp32 tensors; 3x3 layers on the bf16 matrix pipe through exact hi/mid/lo operand splitting)
-def pack_conv_split(w_oihw, scale=None, c_off=0, c_total=None, dst=None):
+# ---- split path (fp32 tensors; 3x3 layers on the fp16 matrix pipe through two-piece operand splitting)
+def pack_conv_split(w_oihw, scale=None, c_total=None):
+    """-> (planes int16 [c_total/16 * 9 * 4 * N * 8], wamax int32[1] = float bits of max |w|)."""
     L = _lib.lib()
     N, C, k, _ = w_oihw.shape
     c_total = c_total or C
-    if dst is None:
-        dst = torch.zeros(c_total // 32 * k * k * 3 * N * 32, dtype=torch.int16, device=w_oihw.device)
-    rc = L.nbp_pack_conv_weight_split(_lib.ptr(w_oihw), N, C, k, _lib.ptr(scale), c_off, c_total, _lib.ptr(dst), stream())
+    dst = torch.zeros(c_total // 16 * k * k * 4 * N * 8, dtype=torch.int16, device=w_oihw.device)
+    wamax = torch.zeros(1, dtype=torch.int32, device=w_oihw.device)
+    rc = L.nbp_pack_conv_weight_split(_lib.ptr(w_oihw), N, C, k, _lib.ptr(scale), 0, c_total, _lib.ptr(dst), _lib.ptr(wamax), stream())
     _lib.check(rc, "pack_split")
-    return dst
+    return dst, wamax
 
 
-def conv3x3_split(src0, src1, ups, planes, N, scale, shift, relu, split_k=0):
-    """src*: NHWC cuda fp32 tensors [B,Hs,Ws,C]; returns NHWC fp32 [B,H,W,N]."""
+def conv3x3_split(src0, src1, ups, packed, N, scale, shift, relu, split_k=0, amax_in=None, amax_out=None):
+    """src*: NHWC cuda fp32 tensors [B,Hs,Ws,C]; packed = pack_conv_split(...); returns NHWC fp32 [B,H,W,N]."""
     L = _lib.lib()
+    planes, wamax = packed
     B, Hs, Ws, C0 = src0.shape
     H, W = (Hs * 2, Ws * 2) if ups else (Hs, Ws)
     C1 = 0 if src1 is None else src1.shape[3]
     out = torch.empty(B, H, W, N, dtype=torch.float32, device=src0.device)
     nws = L.nbp_conv_split_workspace_bytes(B, H, W, N, split_k)
     ws = torch.empty(max(nws, 256), dtype=torch.uint8, device=src0.device)
-    rc = L.nbp_conv3x3_split_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, _lib.ptr(planes), N,
-                                 _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), split_k, _lib.ptr(ws),
-                                 ws.numel(), stream())
+    rc = L.nbp_conv3x3_split_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, _lib.ptr(planes), _lib.ptr(wamax), N,
+                                 _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), _lib.ptr(amax_in), _lib.ptr(amax_out),
+                                 split_k, _lib.ptr(ws), ws.numel(), stream())
     _lib.check(rc, "conv3x3_split")
     return out

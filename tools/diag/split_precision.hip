@@ -20,14 +20,44 @@ __device__ inline void split3(float x, unsigned short& h, unsigned short& m, uns
     h = xb >> 16; m = r1b >> 16; l = __float_as_uint(r2) >> 16;
 }
 
-// mode 0: fp32 MFMA; 1: 6 terms one accumulator (small first); 2: 6 terms, two accumulators; 3: 9 terms; 4: 3 terms
-__global__ void gemm_kernel(const float* A, const float* B, int K, int mode, float* C) {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// x scaled by 2^sa = hi + lo, two fp16 pieces by round-to-nearest (x - hi is exact; lo carries 11 of the remaining 13 bits)
+__device__ inline void split2h(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x;
+    l = (_Float16)(x - (float)h);
+}
+
+// mode 0: fp32 MFMA; 1: 6 terms one accumulator (small first); 2: 6 terms, two accumulators; 3: 9 terms; 4: 3 terms;
+// 5: two fp16 pieces, 3 MFMAs (lo hi, hi lo, hi hi), operands pre-scaled by powers of two; 6: the same with two accumulators
+__global__ void gemm_kernel(const float* A, const float* B, int K, int mode, float* C, float scaleA, float scaleB) {
     const int lane = threadIdx.x, row = lane & 31, kh = lane >> 5;
     f32x16 acc, acc2;
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
     if (mode == 0) {
         for (int k = 0; k < K; k += 2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[row * K + k + kh], B[(k + kh) * 32 + row], acc, 0, 0, 0);
+    } else if (mode >= 5) {
+        // per-tensor power-of-two scales: max |A| -> [2^12, 2^13), max |B| -> [2^12, 2^13)
+        const float sa = scaleA, sb = scaleB;
+        for (int k = 0; k < K; k += 16) {
+            f16x8 ah, al, bh, bl;
+            for (int e = 0; e < 8; ++e) {
+                _Float16 h, l;
+                split2h(A[row * K + k + 8 * kh + e] * sa, h, l); ah[e] = h; al[e] = l;
+                split2h(B[(k + 8 * kh + e) * 32 + row] * sb, h, l); bh[e] = h; bl[e] = l;
+            }
+            if (mode == 5) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+            } else {
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+            }
+        }
+        const float inv = 1.f / (sa * sb);
+        for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + acc2[r]) * inv;
     } else {
         for (int k = 0; k < K; k += 16) {
             u16x8 a[3], b[3];
@@ -51,14 +81,15 @@ __global__ void gemm_kernel(const float* A, const float* B, int K, int mode, flo
 }
 
 int main() {
-    for (int K : {1152, 9216}) {
-        for (int dist = 0; dist < 2; ++dist) {
+    for (int K : {576, 1152, 9216}) {
+        for (int dist = 0; dist < 4; ++dist) {
             std::vector<float> A(32 * K), B(K * 32);
             srand(7 + dist);
             auto rnd = [&]() { double u = (rand() + 1.0) / (RAND_MAX + 2.0), v = (rand() + 1.0) / (RAND_MAX + 2.0);
                                return std::sqrt(-2 * std::log(u)) * std::cos(6.283185307179586 * v); };
-            for (auto& x : A) x = (float)(dist ? std::fabs(rnd()) : rnd());     // dist 1: non-negative activations (after ReLU)
-            for (auto& x : B) x = (float)(rnd() * 0.05);
+            auto uni = [&]() { return 2.0 * rand() / RAND_MAX - 1.0; };
+            for (auto& x : A) x = (float)(dist == 3 ? uni() : dist == 1 ? std::fabs(rnd()) : dist == 2 ? rnd() * std::pow(10.0, -6.0 * rand() / RAND_MAX) : rnd());     // 1: non-negative (after ReLU); 2: magnitudes over 6 decades
+            for (auto& x : B) x = (float)(dist == 3 ? uni() * 0.1 : rnd() * 0.05);
             std::vector<double> ref(1024, 0.0), mag(1024, 0.0);
             for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) {
                 double s = 0, m = 0;
@@ -69,8 +100,12 @@ int main() {
             hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dC, 4096);
             hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
             hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
-            for (int mode = 0; mode < 5; ++mode) {
-                gemm_kernel<<<1, 64>>>(dA, dB, K, mode, dC);
+            float ma = 0, mb = 0;
+            for (auto x : A) ma = std::fmax(ma, std::fabs(x));
+            for (auto x : B) mb = std::fmax(mb, std::fabs(x));
+            const float sA = std::exp2(12 - std::floor(std::log2(ma))), sB = std::exp2(12 - std::floor(std::log2(mb)));
+            for (int mode = 0; mode < 7; ++mode) {
+                gemm_kernel<<<1, 64>>>(dA, dB, K, mode, dC, sA, sB);
                 std::vector<float> C(1024);
                 hipMemcpy(C.data(), dC, 4096, hipMemcpyDeviceToHost);
                 double mx = 0, rms = 0, bias = 0;
