@@ -41,7 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
-PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 = dense fp16 (v_mfma_f32_32x32x16_{bf16,f16})
 PEAK_HBM_GBS = 8000.0
 N_POSES = 101
 TILE_NAMES = {1: "igemm_conv_kernel<2,2,2,2>(128x128)", 2: "igemm_conv_kernel<4,1,2,2>(256x64)",
@@ -49,7 +49,7 @@ TILE_NAMES = {1: "igemm_conv_kernel<2,2,2,2>(128x128)", 2: "igemm_conv_kernel<4,
               5: "igemm_conv_kernel<1,4,2,1>(64x128)", 6: "conv3x3_halo_f32_kernel<4,2>(8x32 px x 128 ch)",
               7: "conv3x3_halo_f32_kernel<2,2>(8x32 px x 64 ch)", 8: "conv3x3_halo_f32_kernel<4,1>(4x32 px x 128 ch)",
               9: "conv3x3_halo_f32_kernel<2,1>(4x32 px x 64 ch)",
-              10: "conv3x3_halo_split16_kernel<true, 32>(8x32 px x 64 ch; fp32 operands as 3 bf16 pieces, 6 bf16 MFMAs per product)"}
+              10: "conv3x3_halo_h2_kernel<32, 4, 2>(16x32 px x 64 ch; fp32 operands as 2 scaled fp16 pieces, 3 fp16 MFMAs per product)"}
 SPLIT_TILE = 10
 TIMED = {"fp32": "nbp_forward_timed_f32", "fp32_split": "nbp_forward_timed_split_f32", "bf16": "nbp_forward_timed_bf16"}
 
@@ -350,14 +350,14 @@ def main():
             traffic, src2 = committed_traffic(dom_prefix, "forward_split_pmc_summary.csv" if dom == SPLIT_TILE
                                               else "forward_f32_pmc_summary.csv")
             traffic_src = f"{src2}; live pass: {live_src}" if src2 else live_src
-        # the split kernel issues six bf16 MFMAs per fp32 product: its ceiling is the dense bf16 peak / 6 of ALGORITHMIC flops
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if dom == SPLIT_TILE else PEAK_F32_MFMA_TFLOPS
+        # the split kernel issues three fp16 MFMAs per fp32 product: its ceiling is the dense fp16 peak / 3 of ALGORITHMIC flops
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if dom == SPLIT_TILE else PEAK_F32_MFMA_TFLOPS
         roofline = {"bound": "mfma", "kernel": TILE_NAMES[dom], "achieved": round(achieved, 3),
                     "peak": round(peak, 2), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "peak_basis": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per product (algorithmic fp32 flops)"
+                    "peak_basis": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product (algorithmic fp32 flops)"
                                    if dom == SPLIT_TILE else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    "issued_mfma_tflops": round(achieved * (6 if dom == SPLIT_TILE else 1), 1),
+                    "issued_mfma_tflops": round(achieved * (3 if dom == SPLIT_TILE else 1), 1),
                     "traffic": None if traffic is None else round(traffic),
                     "traffic_unit": "HBM-side bytes per launch: 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide)",
                     "traffic_source": traffic_src,
@@ -516,10 +516,10 @@ def main():
                                    f"{int(mesh.faces.shape[0])} faces), 256x256 grid, {R} concurrent rollouts per GPU on "
                                    f"{R} scenes (NBP forwards batched), 5 depth frames of 256x456 per step per "
                                    "rollout, seeded synthetic NBP weights",
-                       "conv_arithmetic": {"fp32_split": "fp32 tensors; 3x3 convolutions cut every fp32 operand exactly into 3 bf16 "
-                                                         "pieces and evaluate the product as 6 exact bf16 MFMAs with fp32 "
-                                                         "accumulation (error vs fp64 <= the fp32 MFMA pipe's: "
-                                                         "tests/test_gpu_split.py)",
+                       "conv_arithmetic": {"fp32_split": "fp32 tensors; 3x3 convolutions scale every fp32 operand by a per-tensor power "
+                                                         "of two, cut it into 2 fp16 pieces and evaluate the product as 3 exact "
+                                                         "fp16 MFMAs with fp32 accumulation (error vs fp64 <= the fp32 MFMA "
+                                                         "pipe's: tests/test_gpu_split.py)",
                                            "fp32": "fp32 MFMA pipe"}.get(net.conv_precision, net.conv_precision),
                        "grid": S, "rollouts_per_gpu": R, "image": [params.image_height, params.image_width],
                        "window_steps": [first_step, last_step], "gt_points": int(gt.shape[0])},

@@ -100,8 +100,9 @@ class NBP(nn.Module):
         self._packed_key = None
         self._tensors = None
         # eval-mode arithmetic of the convolutions (tensors are fp32 in all but "bf16"):
-        #   "fp32_split" (default) fp32 operands cut exactly into three bf16 pieces, six exact bf16 MFMAs per product, fp32
-        #                accumulation: the accuracy of the fp32 pipe (measured against fp64) at 2.67x its matrix rate;
+        #   "fp32_split" (default) fp32 operands scaled by a per-tensor power of two and cut into two fp16 pieces, three exact
+        #                fp16 MFMAs per product, fp32 accumulation: the accuracy of the fp32 pipe (measured against fp64) at
+        #                5.3x its matrix rate;
         #   "fp32"       the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32);
         #   "bf16"       bf16 activations and weights (BASELINE configs[4]).
         # All but "bf16" meet the 1e-4 parity bar.  NBP_CONV_PRECISION overrides the default (A/B measurements).

@@ -76,8 +76,8 @@ _FWD = {"fp32": ("nbp_forward_f32", "nbp_forward_workspace_bytes"), "bf16": ("nb
 
 
 def pack_state_dict(sd, device, bf16: bool = False, precision: str = None) -> PackedWeights:
-    """precision: "fp32" (fp32 MFMA), "fp32_split" (fp32 tensors, 3x3 layers as six exact bf16 MFMAs per product -- the
-    same accuracy at 2.67x the matrix rate; its handle also serves "fp32"), "bf16" (bf16 conv weights / activations, fp32
+    """precision: "fp32" (fp32 MFMA), "fp32_split" (fp32 tensors, 3x3 layers as three exact fp16 MFMAs per product on
+    two-piece operands -- the same accuracy at 5.3x the matrix rate; its handle also serves "fp32"), "bf16" (bf16 conv weights / activations, fp32
     accumulate and epilogues; nbp_forward_bf16).  bf16=True is the older spelling of precision="bf16"."""
     precision = precision or ("bf16" if bf16 else "fp32")
     assert precision in PRECISIONS, precision

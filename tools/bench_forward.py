@@ -17,7 +17,7 @@ from nextbestpath_amd.utility.synthetic import make_count_maps, make_nbp_state_d
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bf16", action="store_true")
-    ap.add_argument("--split", action="store_true", help="fp32 tensors, 3x3 layers as six exact bf16 MFMAs per product")
+    ap.add_argument("--split", action="store_true", help="fp32 tensors, 3x3 layers as three exact fp16 MFMAs per product (two-piece operands)")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--reps", type=int, default=10)
