@@ -133,10 +133,11 @@ int nbp_forward_timed_split_f32(const nbp_weights* handle, const float* x, int B
  * buffer first when C < c_total) scaled by 2^(12 - floor(log2 max|w|)); wamax_out = device word that receives max |w * scale|
  * (float bits).  c_off must be 0 (one scale per layer).
  * nbp_conv3x3_split_f32: images of 16 x 32 pixel tiles with N % 64 == 0, or of 16 x 16 pixel tiles with N % 128 == 0; channel
- * counts multiples of 32; NBP_E_SHAPE otherwise.  amax_in = device word with max |x| over src0 and src1 (float bits; a
- * bound is enough), NULL = computed here (one more pass over the inputs); amax_out (or NULL) receives max |out| by atomicMax:
- * zero it before, and hand it to the consumer layer as its amax_in.  nbp_amax_f32 is that pass on its own.  split_k 0 =
- * automatic; ws >= nbp_conv_split_workspace_bytes. */
+ * counts multiples of 32; NBP_E_SHAPE otherwise.  amax_in = 64 device words (256 B) whose maximum is max |x| over src0 and
+ * src1 (float bits; a bound is enough), NULL = computed here (one more pass over the inputs); amax_out (or NULL) = 64 words
+ * that receive max |out| by atomicMax spread over the words: zero them before, and hand them to the consumer layer as its
+ * amax_in.  nbp_amax_f32 is that pass on its own (same 64-word convention).  split_k 0 = automatic;
+ * ws >= nbp_conv_split_workspace_bytes. */
 int nbp_pack_conv_weight_split(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
                                int c_total, void* dst_planes, void* wamax_out, void* stream);
 int nbp_amax_f32(const float* x, long long n, void* amax_inout, void* stream);

@@ -315,15 +315,15 @@ struct AmaxBook {
     unsigned* val[128];
     int init(Bump& bp, hipStream_t s, bool dry) {
         st = s; next = n = 0;
-        slots = bp.take<unsigned>(128);
-        return dry ? 0 : (int)hipMemsetAsync(slots, 0, 128 * sizeof(unsigned), st);
+        slots = bp.take<unsigned>(128 * 64);       // 64 words per tensor (nbp_split.hip: AMAX_WORDS)
+        return dry ? 0 : (int)hipMemsetAsync(slots, 0, 128 * 64 * sizeof(unsigned), st);
     }
     unsigned* find(const void* p) const {
         for (int i = n - 1; i >= 0; --i) if (key[i] == p) return val[i];
         return nullptr;
     }
     void bind(const void* p, unsigned* v) { if (n < 128) { key[n] = p; val[n] = v; ++n; } }
-    unsigned* fresh(const void* p) { unsigned* v = next < 128 ? slots + next++ : nullptr; if (v) bind(p, v); return v; }
+    unsigned* fresh(const void* p) { unsigned* v = next < 128 ? slots + 64 * next++ : nullptr; if (v) bind(p, v); return v; }
     void alias(const void* p, const void* of) { if (unsigned* v = find(of)) bind(p, v); }
     int ensure(const float* p, long long count, const unsigned** out) {
         unsigned* v = find(p);

@@ -51,19 +51,31 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsi
     l = __builtin_bit_cast(unsigned, f16x2{l0, l1});
 }
 
+// max |x| of a tensor lives in AMAX_WORDS words (float bits; the tensor's max is the max over them): same-address device
+// atomics run at ~0.3 G/s on this part (16 k waves finishing together = 55 us), so writers spread over the words by
+// workgroup id and readers take the max of all of them with one 256-B load per wave.
+constexpr int AMAX_WORDS = 64;
 __device__ __forceinline__ void wave_amax(float mx, unsigned* out) {
 #pragma unroll
     for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));    // non-negative floats order like their bits
+    // non-negative floats order like their bits
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(out + ((blockIdx.x * 4u + (threadIdx.x >> 6) + blockIdx.y * 17u + blockIdx.z * 29u) & (AMAX_WORDS - 1)), __float_as_uint(mx));
 }
-// one atomic per 256-thread workgroup (same-address device atomics run at ~0.3 G/s on this part)
-__device__ __forceinline__ void block_amax(float mx, unsigned* out) {
+__device__ __forceinline__ void block_amax(float mx, unsigned* out, unsigned words = AMAX_WORDS) {
     __shared__ float part[4];
 #pragma unroll
     for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+    if (threadIdx.x == 0)
+        atomicMax(out + (blockIdx.x & (words - 1)), __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+}
+__device__ __forceinline__ unsigned read_amax(const unsigned* slot) {     // every lane returns the max over the words
+    unsigned v = slot[threadIdx.x & (AMAX_WORDS - 1)];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { const unsigned u = __shfl_xor(v, o); v = u > v ? u : v; }
+    return v;
 }
 
 struct SplitOps {
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int n0 = nt * BN;
 
     // operand scales (exact powers of two) from the tensors' max |.|
-    const unsigned ma0 = *o.amax0, ma1 = o.amax1 ? *o.amax1 : 0u;
+    const unsigned ma0 = read_amax(o.amax0), ma1 = o.amax1 ? read_amax(o.amax1) : 0u;
     const int ea = amax_exponent(ma0 > ma1 ? ma0 : ma1), ew = amax_exponent(*o.wamax);
     const float sa = pow2f(12 - ea);
     const float inv = pow2f(ea + ew - 24);
@@ -281,34 +293,63 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (final_out && o.amax_out) wave_amax(mx, o.amax_out);
 }
 
+// Grid-stride over float4s of the output, two positions per thread and iteration, the slices' loads of both issued together
+// (four slices at a time) and added in slice order -- a serial load-add chain costs one memory round trip per slice, and
+// one float4 per thread is bound by the wave launch rate (measured: 31 us serial / 56 us one-per-thread / see DESIGN.md).
 __global__ __launch_bounds__(256) void splitk_reduce_split_kernel(const float* __restrict__ partial_all, int split_k,
-                                                                  long long MN, int N, SplitOps o0, SplitOps o1, int relu) {
-    const float* partial = partial_all + (long long)blockIdx.y * split_k * MN;
-    const SplitOps& o = blockIdx.y ? o1 : o0;
+                                                                  unsigned MN, unsigned N, SplitOps o0, SplitOps o1, int relu) {
+    const float* partial = partial_all + (size_t)blockIdx.y * split_k * MN;
+    const float* scale = blockIdx.y ? o1.scale : o0.scale;
+    const float* shift = blockIdx.y ? o1.shift : o0.shift;
+    float* out = blockIdx.y ? o1.out : o0.out;
+    unsigned* amax_out = blockIdx.y ? o1.amax_out : o0.amax_out;
+    const unsigned stride = gridDim.x * 256u * 4u;
     float mx = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < MN / 4; i += (long long)gridDim.x * blockDim.x) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(partial + i * 4);
-        for (int s = 1; s < split_k; ++s) {
-            const f32x4 u = *reinterpret_cast<const f32x4*>(partial + s * MN + i * 4);
-            v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
-        }
-        const int n = (int)((i * 4) % N);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(o.scale + n);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(o.shift + n);
+    for (unsigned i0 = (blockIdx.x * 256u + threadIdx.x) * 4u; i0 < MN; i0 += 2 * stride) {
+        const unsigned i1 = i0 + stride;
+        const bool two = i1 < MN;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(partial + i0);
+        f32x4 v1 = two ? *reinterpret_cast<const f32x4*>(partial + i1) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 1; s0 < split_k; s0 += 4) {
+            f32x4 u0[4], u1[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = v[e] * sc[e] + sh[e];          // the partial sums already carry 1 / (s_x s_w)
-            if (relu) v[e] = fmaxf(v[e], 0.f);
-            mx = fmaxf(mx, fabsf(v[e]));
+            for (int k = 0; k < 4; ++k) {
+                const bool in = s0 + k < split_k;
+                const float* ps = partial + (size_t)(s0 + k) * MN;
+                u0[k] = in ? *reinterpret_cast<const f32x4*>(ps + i0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                u1[k] = in && two ? *reinterpret_cast<const f32x4*>(ps + i1) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (s0 + k < split_k) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] += u0[k][e]; v1[e] += u1[k][e]; }
+                }
         }
-        *reinterpret_cast<f32x4*>(o.out + i * 4) = v;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h && !two) break;
+            const unsigned i = h ? i1 : i0;
+            f32x4 v = h ? v1 : v0;
+            const unsigned n = i % N;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + n);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = v[e] * sc[e] + sh[e];          // the partial sums already carry 1 / (s_x s_w)
+                if (relu) v[e] = fmaxf(v[e], 0.f);
+                mx = fmaxf(mx, fabsf(v[e]));
+            }
+            *reinterpret_cast<f32x4*>(out + i) = v;
+        }
     }
-    if (o.amax_out) block_amax(mx, o.amax_out);
+    if (amax_out) block_amax(mx, amax_out);
 }
 
 // max |x| (float bits, atomicMax: the caller zeroes the slot); optional per-row scale for weights [N][per_row]
+// words = 64 (activation convention) or 1 (max |w| of a layer)
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long n, const float* __restrict__ row_scale,
-                                                   long long per_row, unsigned* __restrict__ out) {
+                                                   long long per_row, unsigned* __restrict__ out, unsigned words) {
     float mx = 0.f;
     if (!row_scale && (n & 3) == 0 && ((uintptr_t)x & 15) == 0) {
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += (long long)gridDim.x * blockDim.x) {
@@ -319,7 +360,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
             mx = fmaxf(mx, fabsf(row_scale ? x[i] * row_scale[i / per_row] : x[i]));
     }
-    block_amax(mx, out);
+    block_amax(mx, out, words);
 }
 
 // planes [chunk of 16 channels][tap][hi|lo][k half][N][8 fp16] of w[n][c][tap] * (scale ? scale[n] : 1) * 2^(12 - e_w)
@@ -393,7 +434,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
 
 int nbp_amax_launch(const float* x, long long n, unsigned* amax_inout, hipStream_t st) {
     if (n <= 0) return 0;
-    amax_kernel<<<min(nbp_ew_grid(n / 4 + 1, 256), 1024), 256, 0, st>>>(x, n, nullptr, 1, amax_inout);
+    amax_kernel<<<min(nbp_ew_grid(n / 4 + 1, 256), 1024), 256, 0, st>>>(x, n, nullptr, 1, amax_inout, AMAX_WORDS);
     return nbp_launch_status();
 }
 
@@ -439,8 +480,9 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     if (rc) return rc;
     if (p.split_k > 1) {
         const long long MN = a.M * N;
-        dim3 grid((unsigned)nbp_ew_grid(MN / 4, 256), (unsigned)groups);
-        splitk_reduce_split_kernel<<<grid, 256, 0, st>>>((const float*)ws, p.split_k, MN, N, a.g[0], a.g[1], relu);
+        NBP_RETURN_IF(MN >= (1ll << 31), NBP_E_SHAPE);
+        dim3 grid((unsigned)min(nbp_cdiv(MN / 4, 256 * 4), 1024ll), (unsigned)groups);     // >= 4 float4s per thread
+        splitk_reduce_split_kernel<<<grid, 256, 0, st>>>((const float*)ws, p.split_k, (unsigned)MN, (unsigned)N, a.g[0], a.g[1], relu);
         rc = nbp_launch_status();
     }
     return rc;
@@ -455,7 +497,7 @@ int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksi
     const long long total = (long long)N * C * ksize * ksize;
     hipError_t e = hipMemsetAsync(wamax_out, 0, sizeof(unsigned), st);
     if (e != hipSuccess) return (int)e;
-    amax_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(w_oihw, total, scale_or_null, (long long)C * ksize * ksize, wamax_out);
+    amax_kernel<<<min(nbp_ew_grid(total, 256), 256), 256, 0, st>>>(w_oihw, total, scale_or_null, (long long)C * ksize * ksize, wamax_out, 1u);
     pack_conv_weight_h2_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(w_oihw, N, C, ksize * ksize, scale_or_null, c_off, wamax_out,
                                                                        (unsigned short*)dst);
     return nbp_launch_status();
@@ -489,7 +531,7 @@ extern "C" int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src
     const unsigned* amax = (const unsigned*)amax_in_or_null;
     if (!amax) {                // max |x| over both sources, into the head of the workspace
         unsigned* slot = (unsigned*)ws;
-        hipError_t e = hipMemsetAsync(slot, 0, sizeof(unsigned), st);
+        hipError_t e = hipMemsetAsync(slot, 0, 256, st);
         if (e != hipSuccess) return (int)e;
         const long long hw = (long long)B * (ups ? H / 2 : H) * (ups ? W / 2 : W);
         int rc = nbp_amax_launch(src0, hw * C0, slot, st);

@@ -81,10 +81,11 @@ def test_conv3x3_split_vs_fp64_and_fp32_path(hip, case, mag):
     assert e_split.max().item() < 4e-6 * mag and e_split.max().item() <= 3.0 * e_f32.max().item() + 1e-7 * mag, (e_split.max(), e_f32.max())
     assert e_split.pow(2).mean().sqrt().item() <= 1.2 * e_f32.pow(2).mean().sqrt().item() + 1e-9 * mag
     # max |out| reported through amax_out == the tensor's max, and feeding it back as amax_in changes nothing
-    amax_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    amax_out = torch.zeros(64, dtype=torch.int32, device=dev)           # 64 words per tensor; the max is the max over them
     got2 = conv3x3_split(x0d, x1d, ups, pack_conv_split(wd), N, scd, shd, True, split_k, amax_out=amax_out)
-    assert amax_out.view(torch.float32).item() == got2.abs().max().item()
-    amax_in = torch.tensor([max(x0d.abs().max().item(), 0 if x1d is None else x1d.abs().max().item())], dtype=torch.float32, device=dev)
+    assert amax_out.view(torch.float32).max().item() == got2.abs().max().item()
+    amax_in = torch.zeros(64, dtype=torch.float32, device=dev)
+    amax_in[5] = max(x0d.abs().max().item(), 0 if x1d is None else x1d.abs().max().item())
     got3 = conv3x3_split(x0d, x1d, ups, pack_conv_split(wd), N, scd, shd, True, split_k, amax_in=amax_in.view(torch.int32))
     assert torch.equal(got2, got3)
 

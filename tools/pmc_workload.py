@@ -40,6 +40,7 @@ def main():
     for _ in range(2):
         _lib.check(fwd(packed.handle, x.data_ptr(), B, S, o1.data_ptr(), o2.data_ptr(), ws.data_ptr(), ws.numel(),
                        _lib.current_stream()), "forward")
+    torch.cuda.synchronize()       # host allocations / copies below must not overlap the forwards (they stall running kernels)
     if a.points > 0:
         pc = make_point_cloud(a.points, seed=1, extent=32.0, y_range=(0.0, 12.0)).to(dev)
         pose = np.array([1.0, 3.3, -2.0, 0, 0], np.float32)
