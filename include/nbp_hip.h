@@ -141,6 +141,16 @@ int nbp_forward_timed_split_f32(const nbp_weights* handle, const float* x, int B
 int nbp_pack_conv_weight_split(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
                                int c_total, void* dst_planes, void* wamax_out, void* stream);
 int nbp_amax_f32(const float* x, long long n, void* amax_inout, void* stream);
+/* up_conv (x2 nearest upsample + 3x3 convolution, nbp_model.py:25-33) as four 2x2 convolutions of the low-resolution input, one
+ * per output parity, with pre-summed weights (16 tap-products per low-resolution pixel instead of 36).
+ * nbp_pack_upconv_weight_split: planes [parity][chunk of 16][4 taps][hi|lo][k half][N][8] fp16 (64 N C bytes); the sums are
+ * formed in double and split directly.
+ * nbp_upconv3x3_split_f32: src [B,H/2,W/2,C] -> out [B,H,W,N]; the low-resolution image must tile (H/2 % 16 == 0 and W/2 % 32 == 0
+ * with N % 64 == 0, or W/2 % 16 == 0 with N % 128 == 0), NBP_E_SHAPE otherwise; other arguments as nbp_conv3x3_split_f32. */
+int nbp_pack_upconv_weight_split(const float* w_oihw, int N, int C, void* dst_planes, void* wamax_out, void* stream);
+int nbp_upconv3x3_split_f32(const float* src, int C, int B, int H, int W, const void* planes_up, const void* wamax_up, int N,
+                            const float* scale, const float* shift, int relu, float* out, const void* amax_in_or_null,
+                            void* amax_out_or_null, int split_k, void* ws, size_t ws_bytes, void* stream);
 size_t nbp_conv_split_workspace_bytes(int B, int H, int W, int N, int split_k);
 int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
                           const void* w_planes, const void* wamax, int N, const float* scale, const float* shift, int relu,

@@ -96,6 +96,8 @@ SIGNATURES["nbp_forward_split_f32"] = SIGNATURES["nbp_forward_f32"]
 SIGNATURES["nbp_forward_timed_split_f32"] = SIGNATURES["nbp_forward_timed_f32"]
 SIGNATURES["nbp_pack_conv_weight_split"] = (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp])
 SIGNATURES["nbp_amax_f32"] = (_i, [_vp, _ll, _vp, _vp])
+SIGNATURES["nbp_pack_upconv_weight_split"] = (_i, [_vp, _i, _i, _vp, _vp, _vp])
+SIGNATURES["nbp_upconv3x3_split_f32"] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp])
 SIGNATURES["nbp_conv_split_workspace_bytes"] = SIGNATURES["nbp_conv_igemm_workspace_bytes"]
 SIGNATURES["nbp_conv3x3_split_f32"] = (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp,
                                             _sz, _vp])

@@ -23,6 +23,9 @@ struct Table {
     size_t s_off[NBP_N_CONV], t_off[NBP_N_CONV];
     size_t total_floats;
     size_t w3_off[NBP_N_CONV];  // byte offsets of the split planes (3x3 layers) in the split region after the fp32 pack
+    size_t w3u_off[NBP_N_CONV]; // ... of the parity filters of the up_conv layers (is_up)
+    bool is_up[NBP_N_CONV];
+    int up_rank[NBP_N_CONV];    // 0..5 among the up_conv layers (its max |w| word is header word NBP_N_CONV + rank)
     size_t total3_bytes;
     Table() {
         int i = 0;
@@ -33,7 +36,10 @@ struct Table {
             L[i++] = {K_CONV3, enc[e], enc[e], 3};
             cin = enc[e];
         }
+        for (int j = 0; j < NBP_N_CONV; ++j) { is_up[j] = false; up_rank[j] = -1; }
+        int n_up = 0;
         auto level = [&](int ci, int co) {
+            is_up[i] = true; up_rank[i] = n_up++;
             L[i++] = {K_CONV3, ci, co, 3};         // Up{L}_d.up.1
             L[i++] = {K_ATT_G, co, co / 2, 1};     // Att W_g
             L[i++] = {K_ATT_X, co, co / 2, 1};     // Att W_x
@@ -65,6 +71,10 @@ struct Table {
         for (int j = 0; j < NBP_N_CONV; ++j) {
             w3_off[j] = off3;
             if (L[j].kind == K_CONV3) off3 += ((size_t)L[j].cout * L[j].cin * 9 * 4 + 255) / 256 * 256;
+        }
+        for (int j = 0; j < NBP_N_CONV; ++j) {
+            w3u_off[j] = off3;
+            if (is_up[j]) off3 += ((size_t)L[j].cout * L[j].cin * 16 * 4 + 255) / 256 * 256;
         }
         total3_bytes = off3;
     }
@@ -98,6 +108,8 @@ struct nbp_weights {
     int bf16;
     const void* w3[NBP_N_CONV];     // split handle: hi/lo fp16 planes of the 3x3 layers (nbp_split.hip)
     const unsigned* wamax[NBP_N_CONV];      // ... and max |w| of each (device words, float bits)
+    const void* w3u[NBP_N_CONV];            // up_conv layers: planes of the four parity filters (null elsewhere)
+    const unsigned* wamax_u[NBP_N_CONV];
     int split;
 };
 
@@ -168,6 +180,12 @@ static int pack_weights_impl(const void* const* w_host_array, const void* const*
                     h->wamax[i] = (const unsigned*)base3 + i;
                     rc = nbp_pack_conv_weight_split_launch(w, s.cout, s.cin, 3, nullptr, 0, s.cin, base3 + T.w3_off[i],
                                                            (unsigned*)base3 + i, st);
+                    if (!rc && T.is_up[i]) {
+                        h->w3u[i] = base3 + T.w3u_off[i];
+                        h->wamax_u[i] = (const unsigned*)base3 + NBP_N_CONV + T.up_rank[i];
+                        rc = nbp_pack_upconv_weight_split_launch(w, s.cout, s.cin, base3 + T.w3u_off[i],
+                                                                 (unsigned*)base3 + NBP_N_CONV + T.up_rank[i], st);
+                    }
                 }
                 break;
             case K_ATT_G: {
@@ -279,7 +297,8 @@ struct PathF32 {
     typedef ConvOperands Ops;
     typedef NoCtx Ctx;
     static constexpr int CHUNK = 32;
-    static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0) {
+    static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0, int ups = 0) {
+        (void)ups;
         return nbp_plan_conv(M, N, chunks, 0, 0, groups, H, H, ksize);
     }
     static constexpr int MODE = 0;
@@ -340,19 +359,20 @@ struct AmaxBook {
 struct PathSplit : PathF32 {
     typedef AmaxBook Ctx;
     static constexpr int MODE = 2;
-    static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0) {
-        const ConvPlan p = nbp_plan_conv_split(M, N, chunks, 0, groups, H, H, ksize);
+    static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0, int ups = 0) {
+        const ConvPlan p = nbp_plan_conv_split(M, N, chunks, 0, groups, H, H, ksize, ups);
         return p.tile ? p : PathF32::plan(M, N, chunks, groups, H, ksize);
     }
     static int conv(Ctx& ctx, const nbp_weights* h, const int* li, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B,
                     int H, int ks, int N, void* ws, size_t wsb, hipStream_t st) {
-        const ConvPlan p = nbp_plan_conv_split((long long)B * H * H, N, (C0 + C1) / 32 * ks * ks, 0, o2 ? 2 : 1, H, H, ks);
+        const ConvPlan p = nbp_plan_conv_split((long long)B * H * H, N, (C0 + C1) / 32 * ks * ks, 0, o2 ? 2 : 1, H, H, ks, ups);
         if (!p.tile) return PathF32::conv(ctx, h, li, o, o2, C0, C1, ups, B, H, ks, N, ws, wsb, st);
         const long long hw = (long long)B * (ups ? H / 2 : H) * (ups ? H / 2 : H);
         ConvOperandsSplit s[2];
         for (int g = 0; g < (o2 ? 2 : 1); ++g) {
             const Ops& q = g ? *o2 : o;
-            s[g] = ConvOperandsSplit{q.src0, q.src1, h->w3[li[g]], q.scale, q.shift, q.out, nullptr, nullptr, h->wamax[li[g]], nullptr};
+            s[g] = ConvOperandsSplit{q.src0, q.src1, h->w3[li[g]], q.scale, q.shift, q.out, nullptr, nullptr, h->wamax[li[g]], nullptr,
+                                     h->w3u[li[g]], h->wamax_u[li[g]]};
             int rc = ctx.ensure(q.src0, hw * C0, &s[g].amax0);
             if (!rc && C1) rc = ctx.ensure(q.src1, hw * C1, &s[g].amax1);
             if (rc) return rc;
@@ -375,7 +395,8 @@ struct PathBF16 {
     typedef ConvOperandsH Ops;
     typedef NoCtx Ctx;
     static constexpr int CHUNK = 64;
-    static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0) {
+    static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0, int ups = 0) {
+        (void)ups;
         return nbp_plan_conv_bf16(M, N, chunks, 0, 0, groups, H, H, ksize);
     }
     static constexpr int MODE = 1;
@@ -397,8 +418,8 @@ struct PathBF16 {
 };
 
 template <typename P>
-size_t splitk_scratch_floats(long long M, int N, int cin_total, int taps, int groups, int H) {
-    ConvPlan p = P::plan(M, N, cin_total / P::CHUNK * taps, groups, H, taps == 9 ? 3 : 1);
+size_t splitk_scratch_floats(long long M, int N, int cin_total, int taps, int groups, int H, int ups = 0) {
+    ConvPlan p = P::plan(M, N, cin_total / P::CHUNK * taps, groups, H, taps == 9 ? 3 : 1, ups);
     return p.split_k > 1 ? (size_t)groups * p.split_k * M * N : 0;
 }
 
@@ -424,6 +445,7 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
             if (e < 4) {   // decoder level at this resolution: co = enc[e], ci = enc[e+1]
                 for (int g = 1; g <= 2; ++g) {      // levels 5 and 4 run both decoders in one grouped launch
                     sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e + 1], 9, g, s));
+                    sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e + 1], 9, g, s, 1));       // Up{L}.up.1 reads through the upsample
                     sk = max(sk, splitk_scratch_floats<P>(M, enc[e], enc[e], 9, g, s));
                     sk = max(sk, splitk_scratch_floats<P>(M, enc[e], 2 * enc[e], 9, g, s));
                     sk = max(sk, splitk_scratch_floats<P>(M, enc[e] / 2, 2 * enc[e], 1, g, s));
@@ -447,7 +469,7 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
         if (tm && !rc) {
             const long long M = (long long)B * Hh * Hh;
             const int K = (C0 + C1) * ksize * ksize;
-            ConvPlan p = P::plan(M, N, K / P::CHUNK, ng, Hh, ksize);
+            ConvPlan p = P::plan(M, N, K / P::CHUNK, ng, Hh, ksize, ups);
             tm->mark(name, 2.0 * ng * M * N * K, p.tile, p.split_k, M, N, K);
         }
     };

@@ -8,7 +8,7 @@ enum { NBP_TILE_AUTO = 0, NBP_TILE_128x128 = 1, NBP_TILE_256x64 = 2, NBP_TILE_25
        NBP_TILE_64x128 = 5,
        NBP_TILE_HALO_128 = 6, NBP_TILE_HALO_64 = 7,
        NBP_TILE_HALO4_128 = 8, NBP_TILE_HALO4_64 = 9,
-       NBP_TILE_SPLIT_HALO_64 = 10 };   // nbp_split.hip: 16x32 / 16x16-pixel halo tiles on the fp16 matrix pipe   // fp32 only: 4x32-pixel tiles   // 8x32-pixel halo-tile kernels (3x3 only), BN = 128 / 64
+       NBP_TILE_SPLIT_HALO_64 = 10, NBP_TILE_SPLIT_UP = 11 };   // nbp_split.hip: 16x32 / 16x16-pixel halo tiles on the fp16 matrix pipe   // fp32 only: 4x32-pixel tiles   // 8x32-pixel halo-tile kernels (3x3 only), BN = 128 / 64
 struct TileInfo { int bm, bn; };
 struct ConvPlan { int tile; int split_k; int chunks_per_split; };
 
@@ -59,8 +59,10 @@ int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C
 struct ConvOperandsSplit {
     const float* src0; const float* src1; const void* planes; const float* scale; const float* shift; float* out;
     const unsigned* amax0; const unsigned* amax1; const unsigned* wamax; unsigned* amax_out;
+    const void* planes_up; const unsigned* wamax_up;     // up_conv layers: the parity filters (nbp_pack_upconv_weight_split_launch) or null
 };
-ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize);
+ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize, int ups = 0);
+int nbp_pack_upconv_weight_split_launch(const float* w_oihw, int N, int C, void* dst, unsigned* wamax_out, hipStream_t st);
 int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C0, int C1, int ups, int B, int H, int W,
                             int ksize, int N, int relu, int split_k, void* ws, size_t ws_bytes, hipStream_t st);
 int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,

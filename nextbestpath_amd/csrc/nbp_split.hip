@@ -103,17 +103,26 @@ struct SplitArgs {
 // 64 / 70 KB of LDS: two workgroups per CU.  One MFMA K step (16 channels) per tap; a stage is 3 taps = 72 MFMAs per wave
 // between barriers, with the next stage's weights DMA'd (buffer_load ... lds) behind it.  The next chunk's halo loads are
 // issued before the chunk's first stage and consumed (split + ds_write) after its last one.
-template <int TW, int TM, int TN>
+// PH (the x2-nearest-upsample + 3x3 convolution of up_conv, nbp_model.py:25-33): the four output parities (y & 1, x & 1) are four
+// 2x2 convolutions of the LOW-resolution input with pre-summed weights -- rows {v - 1 + py, v + py}, filter rows {W[-1], W[0] + W[1]}
+// for py = 0 and {W[-1] + W[0], W[1]} for py = 1, columns alike -- 16 tap-products per low-resolution pixel instead of 36.
+// A workgroup owns one parity of a 16 x TW low-resolution tile (blockIdx.z & 3), runs the 2 x 2 taps from the same halo planes
+// (stage = one row of 2 taps) and writes its outputs to (2 v + py, 2 u + px).
+template <int TW, int TM, int TN, bool PH>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_h2_kernel(SplitArgs a) {
     int zs = blockIdx.z;
+    const int py = PH ? (zs >> 1) & 1 : 0, px = PH ? zs & 1 : 0;
+    if (PH) zs >>= 2;
+    const int zslice = zs;                                     // partial-sum slice: group * split_k + split
     const SplitOps& o = zs >= a.split_k ? a.g[1] : a.g[0];
     if (zs >= a.split_k) zs -= a.split_k;
+    constexpr int ROWS = PH ? 2 : 3, TPR = PH ? 2 : 3, TAPS = ROWS * TPR;      // filter rows = stages per chunk; taps per row
     constexpr int BN = TN * 32, NB = BN / 64;
     constexpr int RPB = 32 / TW, TH = 4 * TM * RPB;            // image rows per 32-pixel row block; tile height (16)
     constexpr int HW_ = TW + 2, HPIX = (TH + 2) * HW_;         // 18 x 34 = 612 / 18 x 18 = 324 halo pixels
     constexpr int RS = (HPIX + 7) / 8 * 8 * 16 + 64;           // bytes between (plane, k half) regions (+64: ds_write banks)
     constexpr int HALO_BYTES = 4 * RS;
-    constexpr int WI = 12 * NB;                                // weight DMA instructions (64 rows x 16 B) per stage
+    constexpr int WI = TPR * 4 * NB;                           // weight DMA instructions (64 rows x 16 B) per stage
     constexpr int WB = WI * 1024;
     constexpr int NF = (HPIX * 4 + 255) / 256;                 // float4 pieces of the halo tile per thread
     static_assert(BN % 64 == 0 && TH == 16, "tile shape");
@@ -122,7 +131,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     char* const wbuf = ldsb + HALO_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+    const int Ht = PH ? a.Hs : a.H, Wt = PH ? a.Ws : a.W;     // the tile grid: output pixels, or low-resolution pixels for PH
+    const int tiles_x = Wt / TW, tiles_y = Ht / TH;
     unsigned tile = blockIdx.x, nt = blockIdx.y;
     if (a.xcd_remap) {      // XCD-contiguous runs of (pixel tile, channel block), channel block fastest (see nbp_conv.hip)
         const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, T = gridDim.x * gridDim.y;
@@ -152,8 +162,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int hr = f >> 2;
         const int hy = hr / HW_, hx = hr - hy * HW_;
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-        const bool ok = hr < HPIX && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-        hpix[k] = ok ? (b * a.Hs + (yy >> a.ups)) * a.Ws + (xx >> a.ups) : -1;
+        const bool ok = hr < HPIX && (unsigned)yy < (unsigned)Ht && (unsigned)xx < (unsigned)Wt;
+        hpix[k] = ok ? (PH ? (b * a.Hs + yy) * a.Ws + xx : (b * a.Hs + (yy >> a.ups)) * a.Ws + (xx >> a.ups)) : -1;
     }
     const int hdst0 = ((tid & 3) >> 1) * RS + (tid >> 2) * 16 + (tid & 1) * 8;      // piece k: + k * 64 pixels * 16 B
     const __amdgpu_buffer_rsrc_t rs0 =
@@ -188,17 +198,19 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             *reinterpret_cast<u32x2*>(halo + 2 * RS + hdst0 + k * 1024) = u32x2{l0, l1};
         }
     };
-    // weight stage u = chunk * 3 + filter row: WI DMA instructions of 64 rows x 16 B; wave w issues q = w, w + 4, ...
+    // weight stage u = chunk * ROWS + filter row: WI DMA instructions of 64 rows x 16 B; wave w issues q = w, w + 4, ...
     // q = (tap in row * 4 + plane * 2 + k half) * NB + 64-row block; packed planes are [chunk][tap][plane][k half][N][8 fp16]
     auto issue_w = [&](int u) {
-        const int c = u / 3, row = u - 3 * c;
+        const int c = u / ROWS, row = u - ROWS * c;
         char* dst = wbuf + (u & 1) * WB;
+        // PH: the four parities' planes follow each other, each [chunk][4 taps][plane][k half][N][8]
+        const long long pbase = PH ? (long long)(py * 2 + px) * a.chunks_total * TAPS * 4 * a.N : 0;
 #pragma unroll
         for (int k = 0; k < WI / 4; ++k) {
             const int q = wave + 4 * k;
             const int tt = q / (4 * NB), r = q - tt * (4 * NB);
             const int r4 = r / NB, nb = r - r4 * NB;
-            const unsigned woff = (unsigned)(((((long long)c * 9 + row * 3 + tt) * 4 + r4) * a.N + n0 + nb * 64 + lane) * 16);
+            const unsigned woff = (unsigned)((pbase + (((long long)c * TAPS + row * TPR + tt) * 4 + r4) * a.N + n0 + nb * 64 + lane) * 16);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + q * 1024), 16, woff, 0, 0, 0);
         }
     };
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int c_end = min(c_begin + a.chunks_per_split, a.chunks_total);
     if (c_begin < c_end) {
         load_halo(c_begin);
-        issue_w(c_begin * 3);
+        issue_w(c_begin * ROWS);
         store_halo();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -229,18 +241,18 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const bool more = c + 1 < c_end;
         if (more) load_halo(c + 1);
 #pragma unroll 1
-        for (int row = 0; row < 3; ++row) {
-            const int u = c * 3 + row;
-            if (row < 2 || more) issue_w(u + 1);
+        for (int row = 0; row < ROWS; ++row) {
+            const int u = c * ROWS + row;
+            if (row < ROWS - 1 || more) issue_w(u + 1);
             const char* Bt = wbuf + (u & 1) * WB + brow;
 #pragma unroll
-            for (int tt = 0; tt < 3; ++tt) {
+            for (int tt = 0; tt < TPR; ++tt) {
                 u32x4 xp[TM][2], wp[TN][2];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
-                        xp[i][p] = *reinterpret_cast<const u32x4*>(arow + p * (2 * RS) + ((row + i * RPB) * HW_ + tt) * 16);
+                        xp[i][p] = *reinterpret_cast<const u32x4*>(arow + p * (2 * RS) + ((row + py + i * RPB) * HW_ + tt + px) * 16);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
     // ---- epilogue (A = pixels, B = weights): col n = lane & 31, pixel of the row block = (r&3) + 8 (r>>2) + 4 (lane>>5)
     const bool final_out = (a.split_k == 1);
-    float* outp = final_out ? o.out : a.partial + (long long)blockIdx.z * a.M * a.N;
+    float* outp = final_out ? o.out : a.partial + (long long)zslice * a.M * a.N;
     float mx = 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -278,15 +290,16 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (final_out) { sc = o.scale[n] * inv; sh = o.shift[n]; }        // inv is a power of two: the product is exact
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const long long mrow = ((long long)b * a.H + y0 + (TM * wave + i) * RPB) * a.W + x0;
+            const long long mrow = PH ? ((long long)b * a.H + 2 * (y0 + (TM * wave + i) * RPB) + py) * a.W + 2 * x0 + px
+                                      : ((long long)b * a.H + y0 + (TM * wave + i) * RPB) * a.W + x0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pb = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                const int px = (pb / TW) * a.W + (pb % TW);
+                const int poff = PH ? 2 * ((pb / TW) * a.W + (pb % TW)) : (pb / TW) * a.W + (pb % TW);
                 float v = acc[i][j][r] * sc + sh;
                 if (final_out && a.relu) v = fmaxf(v, 0.f);
                 mx = fmaxf(mx, fabsf(v));
-                outp[(mrow + px) * a.N + n] = v;
+                outp[(mrow + poff) * a.N + n] = v;
             }
         }
     }
@@ -384,6 +397,46 @@ __global__ void pack_conv_weight_h2_kernel(const float* __restrict__ w, int N, i
     }
 }
 
+// up_conv weights for the parity kernels: Wc[py * 2 + px][n][c][r * 2 + t] = sum of w[n][c][dy][dx] over the filter rows R(py, r)
+// and columns R(px, t), R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1}, R(1,1) = {2} (indices 0..2 = offsets -1..1).  The sums
+// are formed in double and go straight into the two fp16 pieces (no fp32 rounding in between).
+__device__ __forceinline__ double upconv_combined(const double* v, int ph, int r, int t) {
+    const int py = ph >> 1, px = ph & 1;
+    const int y_lo = py == 0 ? (r == 0 ? 0 : 1) : (r == 0 ? 0 : 2), y_hi = py == 0 ? (r == 0 ? 0 : 2) : (r == 0 ? 1 : 2);
+    const int x_lo = px == 0 ? (t == 0 ? 0 : 1) : (t == 0 ? 0 : 2), x_hi = px == 0 ? (t == 0 ? 0 : 2) : (t == 0 ? 1 : 2);
+    double acc = 0.0;
+    for (int y = y_lo; y <= y_hi; ++y)
+        for (int x = x_lo; x <= x_hi; ++x) acc += v[y * 3 + x];
+    return acc;
+}
+// pass 0 (dst == nullptr): max |Wc| into wamax; pass 1: planes [parity][chunk of 16][4 taps][hi|lo][k half][N][8 fp16]
+__global__ __launch_bounds__(256) void pack_upconv_h2_kernel(const float* __restrict__ w, int N, int C, unsigned* __restrict__ wamax,
+                                                             unsigned short* __restrict__ dst) {
+    const long long NC = (long long)N * C;
+    const double sw = dst ? (double)pow2f(12 - amax_exponent(*wamax)) : 1.0;
+    float mx = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < NC; i += (long long)gridDim.x * blockDim.x) {
+        double v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = (double)w[i * 9 + k];
+        const int n = (int)(i / C), c = (int)(i % C);
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {
+                const double wc = upconv_combined(v, ph, tap >> 1, tap & 1);
+                if (!dst) { mx = fmaxf(mx, fabsf((float)wc)); continue; }
+                const double ws = wc * sw;
+                const _Float16 h = (_Float16)(float)ws;
+                const _Float16 l = (_Float16)(float)(ws - (double)(float)h);
+                const long long base = (((long long)ph * (C >> 4) + (c >> 4)) * 4 + tap) * 4 + ((c >> 3) & 1);
+                dst[((base + 0) * N + n) * 8 + (c & 7)] = __builtin_bit_cast(unsigned short, h);
+                dst[((base + 2) * N + n) * 8 + (c & 7)] = __builtin_bit_cast(unsigned short, l);
+            }
+    }
+    if (!dst) block_amax(mx, wamax, 1u);
+}
+
 // tile width the layer runs with: 32 (16 x 32 pixel tiles x 64 channels), 16 (16 x 16 x 128 channels) or 0 (not taken)
 int split_tile_width(int H, int W, int N, int ksize) {
     if (ksize != 3 || H < 16 || H % 16) return 0;
@@ -392,28 +445,49 @@ int split_tile_width(int H, int W, int N, int ksize) {
     return 0;
 }
 
-template <int TW, int TM, int TN>
+template <int TW, int TM, int TN, bool PH>
 int launch_h2(const SplitArgs& a, hipStream_t st) {
     constexpr int HPIX = 18 * (TW + 2), RS = (HPIX + 7) / 8 * 8 * 16 + 64, NB = TN / 2;
-    constexpr size_t smem = 4 * (size_t)RS + 2 * (size_t)12 * NB * 1024;
+    constexpr size_t smem = 4 * (size_t)RS + 2 * (size_t)(PH ? 8 : 12) * NB * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_h2_kernel<TW, TM, TN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_h2_kernel<TW, TM, TN, PH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((unsigned)(a.M / (16 * TW)), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups));
-    conv3x3_halo_h2_kernel<TW, TM, TN><<<grid, 256, smem, st>>>(a);
+    // PH: tiles of the low-resolution image, four parities in blockIdx.z (fastest)
+    dim3 grid((unsigned)(a.M / (PH ? 4 : 1) / (16 * TW)), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups * (PH ? 4 : 1)));
+    conv3x3_halo_h2_kernel<TW, TM, TN, PH><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 
 }  // namespace
 
 // tile == 0: the layer does not fit the split kernel (the caller runs the fp32 MFMA kernels on the fp32 pack)
-ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize) {
+// ups: the layer reads its input through the x2 nearest upsample; when the LOW-resolution image tiles, the parity kernels run
+// (tile id NBP_TILE_SPLIT_UP), otherwise the plain kernel with the upsample folded into its gather.
+ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize, int ups) {
     ConvPlan p{0, 1, chunks_total};
     static const int allow = [] { const char* e = getenv("NBP_SPLIT_HALO"); return e ? atoi(e) : 1; }();
+    static const int allow_up = [] { const char* e = getenv("NBP_SPLIT_UP"); return e ? atoi(e) : 1; }();
+    if (allow && allow_up && ups && !((H | W) & 1)) {
+        const int twu = split_tile_width(H / 2, W / 2, N, ksize);
+        if (twu) {
+            static const int min_blocks_up = [] { const char* e = getenv("NBP_SPLIT_MIN_BLOCKS"); return e ? atoi(e) : 256; }();
+            const int cc = chunks_total / 9 * 2;
+            const long long blocks = (M / 4 / (16 * twu)) * (N / (twu == 32 ? 64 : 128)) * groups * 4;
+            int sk = split_k;
+            if (sk <= 0) {
+                sk = 1;
+                while (blocks * sk < min_blocks_up && cc / (sk * 2) >= 4 && sk < 16) sk *= 2;
+            }
+            if (sk > cc) sk = cc;
+            const int per = (int)nbp_cdiv(cc, sk);
+            p.tile = NBP_TILE_SPLIT_UP; p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
+            return p;
+        }
+    }
     // one workgroup per CU without split-K beats two with it: the partial sums cost more than the idle barrier slots
     // (B = 4 forward 2.65 ms at 256, 2.85 at 512, 2.89 at 128)
     static const int min_blocks = [] { const char* e = getenv("NBP_SPLIT_MIN_BLOCKS"); return e ? atoi(e) : 256; }();
@@ -461,14 +535,26 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     const long long bw = (long long)(C0 + C1) * 9 * N * 4;
     NBP_RETURN_IF(b0 >= (1ll << 31) || b1 >= (1ll << 31) || bw >= (1ll << 31), NBP_E_SHAPE);   // 32-bit buffer offsets
     a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0; a.bytesw = (unsigned)bw;
-    const ConvPlan p = nbp_plan_conv_split(a.M, N, (C0 + C1) / 32 * 9, split_k, groups, H, W, ksize);
-    NBP_RETURN_IF(p.tile != NBP_TILE_SPLIT_HALO_64, NBP_E_SHAPE);
+    const bool have_up = ups && o.planes_up && o.wamax_up && (!o2 || (o2->planes_up && o2->wamax_up));
+    const ConvPlan p = nbp_plan_conv_split(a.M, N, (C0 + C1) / 32 * 9, split_k, groups, H, W, ksize, have_up ? 1 : 0);
+    NBP_RETURN_IF(p.tile != NBP_TILE_SPLIT_HALO_64 && p.tile != NBP_TILE_SPLIT_UP, NBP_E_SHAPE);
+    const bool ph = p.tile == NBP_TILE_SPLIT_UP;
     a.split_k = p.split_k; a.chunks_per_split = p.chunks_per_split;
     a.chunks_total = (C0 + C1) / 16;
-    const int tw = split_tile_width(H, W, N, ksize);
+    const int tw = ph ? split_tile_width(H / 2, W / 2, N, ksize) : split_tile_width(H, W, N, ksize);
+    if (ph) {
+        NBP_RETURN_IF(C1 != 0, NBP_E_SHAPE);
+        for (int g = 0; g < groups; ++g) {
+            const ConvOperandsSplit& sg = (g && o2) ? *o2 : o;
+            a.g[g].planes = sg.planes_up; a.g[g].wamax = sg.wamax_up;
+        }
+        const long long bwu = (long long)C0 * 16 * N * 4;
+        NBP_RETURN_IF(bwu >= (1ll << 31), NBP_E_SHAPE);
+        a.bytesw = (unsigned)bwu;
+    }
     {
         static const int forced = [] { const char* e = getenv("NBP_XCD_REMAP"); return e ? atoi(e) : -1; }();
-        const long long tiles = (a.M / (16 * tw)) * (N / (tw == 32 ? 64 : 128));
+        const long long tiles = (a.M / (ph ? 4 : 1) / (16 * tw)) * (N / (tw == 32 ? 64 : 128));
         a.xcd_remap = forced >= 0 ? forced : (tiles >= 512 ? 1 : 0);
     }
     a.partial = nullptr;
@@ -476,7 +562,8 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
         NBP_RETURN_IF(!ws || ws_bytes < (size_t)groups * p.split_k * a.M * N * sizeof(float), NBP_E_WS);
         a.partial = (float*)ws;
     }
-    int rc = tw == 32 ? launch_h2<32, 4, 2>(a, st) : launch_h2<16, 2, 4>(a, st);
+    int rc = ph ? (tw == 32 ? launch_h2<32, 4, 2, true>(a, st) : launch_h2<16, 2, 4, true>(a, st))
+                : (tw == 32 ? launch_h2<32, 4, 2, false>(a, st) : launch_h2<16, 2, 4, false>(a, st));
     if (rc) return rc;
     if (p.split_k > 1) {
         const long long MN = a.M * N;
@@ -500,6 +587,18 @@ int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksi
     amax_kernel<<<min(nbp_ew_grid(total, 256), 256), 256, 0, st>>>(w_oihw, total, scale_or_null, (long long)C * ksize * ksize, wamax_out, 1u);
     pack_conv_weight_h2_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(w_oihw, N, C, ksize * ksize, scale_or_null, c_off, wamax_out,
                                                                        (unsigned short*)dst);
+    return nbp_launch_status();
+}
+
+// Planes of the four parity filters of an up_conv layer: [parity][chunk][4 taps][plane][k half][N][8 fp16], one max |w| for all.
+int nbp_pack_upconv_weight_split_launch(const float* w_oihw, int N, int C, void* dst, unsigned* wamax_out, hipStream_t st) {
+    NBP_RETURN_IF(!w_oihw || !dst || !wamax_out, NBP_E_ARG);
+    NBP_RETURN_IF(N < 1 || C < 16 || C % 16, NBP_E_SHAPE);
+    hipError_t e = hipMemsetAsync(wamax_out, 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return (int)e;
+    const long long NC = (long long)N * C;
+    pack_upconv_h2_kernel<<<min(nbp_ew_grid(NC, 256), 256), 256, 0, st>>>(w_oihw, N, C, wamax_out, nullptr);
+    pack_upconv_h2_kernel<<<nbp_ew_grid(NC, 256), 256, 0, st>>>(w_oihw, N, C, wamax_out, (unsigned short*)dst);
     return nbp_launch_status();
 }
 
@@ -539,6 +638,36 @@ extern "C" int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src
         if (rc) return rc;
         amax = slot;
     }
-    ConvOperandsSplit o{src0, src1, w_planes, scale, shift, out, amax, amax, (const unsigned*)wamax, (unsigned*)amax_out_or_null};
+    ConvOperandsSplit o{src0, src1, w_planes, scale, shift, out, amax, amax, (const unsigned*)wamax, (unsigned*)amax_out_or_null,
+                        nullptr, nullptr};
     return nbp_conv_split_launch_g(o, nullptr, C0, C1, ups, B, H, W, 3, N, relu, split_k, (char*)ws + 256, ws_bytes - 256, st);
+}
+
+extern "C" int nbp_pack_upconv_weight_split(const float* w_oihw, int N, int C, void* dst_planes, void* wamax_out, void* stream) {
+    NBP_ENTER();
+    return nbp_pack_upconv_weight_split_launch(w_oihw, N, C, dst_planes, (unsigned*)wamax_out, (hipStream_t)stream);
+}
+
+extern "C" int nbp_upconv3x3_split_f32(const float* src, int C, int B, int H, int W, const void* planes_up, const void* wamax_up,
+                                       int N, const float* scale, const float* shift, int relu, float* out,
+                                       const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!ws || ws_bytes < 256 || !src || !planes_up || !wamax_up, NBP_E_WS);
+    NBP_RETURN_IF((H | W) & 1, NBP_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned* amax = (const unsigned*)amax_in_or_null;
+    if (!amax) {
+        unsigned* slot = (unsigned*)ws;
+        hipError_t e = hipMemsetAsync(slot, 0, 256, st);
+        if (e != hipSuccess) return (int)e;
+        const int rc = nbp_amax_launch(src, (long long)B * (H / 2) * (W / 2) * C, slot, st);
+        if (rc) return rc;
+        amax = slot;
+    }
+    // the plain planes are not needed when the parity kernels take the layer; NBP_E_SHAPE otherwise
+    NBP_RETURN_IF(nbp_plan_conv_split((long long)B * H * W, N, C / 32 * 9, split_k, 1, H, W, 3, 1).tile != NBP_TILE_SPLIT_UP, NBP_E_SHAPE);
+    ConvOperandsSplit o{src, nullptr, planes_up, scale, shift, out, amax, amax, (const unsigned*)wamax_up, (unsigned*)amax_out_or_null,
+                        planes_up, (const unsigned*)wamax_up};
+    return nbp_conv_split_launch_g(o, nullptr, C, 0, 1, B, H, W, 3, N, relu, split_k, (char*)ws + 256, ws_bytes - 256, st);
 }

@@ -103,3 +103,27 @@ def conv3x3_split(src0, src1, ups, packed, N, scale, shift, relu, split_k=0, ama
                                  split_k, _lib.ptr(ws), ws.numel(), stream())
     _lib.check(rc, "conv3x3_split")
     return out
+
+
+def pack_upconv_split(w_oihw):
+    """-> (parity planes int16 [4 * C/16 * 4 * 4 * N * 8], wamax int32[1])."""
+    L = _lib.lib()
+    N, C, _, _ = w_oihw.shape
+    dst = torch.zeros(4 * (C // 16) * 4 * 4 * N * 8, dtype=torch.int16, device=w_oihw.device)
+    wamax = torch.zeros(1, dtype=torch.int32, device=w_oihw.device)
+    _lib.check(L.nbp_pack_upconv_weight_split(_lib.ptr(w_oihw), N, C, _lib.ptr(dst), _lib.ptr(wamax), stream()), "pack_upconv")
+    return dst, wamax
+
+
+def upconv3x3_split(src, packed, N, scale, shift, relu, split_k=0):
+    """src NHWC [B,H/2,W/2,C] -> NHWC [B,H,W,N] (x2 nearest upsample + 3x3 convolution through the parity kernels)."""
+    L = _lib.lib()
+    planes, wamax = packed
+    B, Hs, Ws, C = src.shape
+    H, W = 2 * Hs, 2 * Ws
+    out = torch.empty(B, H, W, N, dtype=torch.float32, device=src.device)
+    ws = torch.empty(max(L.nbp_conv_split_workspace_bytes(B, H, W, N, split_k), 256), dtype=torch.uint8, device=src.device)
+    rc = L.nbp_upconv3x3_split_f32(_lib.ptr(src), C, B, H, W, _lib.ptr(planes), _lib.ptr(wamax), N, _lib.ptr(scale), _lib.ptr(shift),
+                                   int(relu), _lib.ptr(out), None, None, split_k, _lib.ptr(ws), ws.numel(), stream())
+    _lib.check(rc, "upconv3x3_split")
+    return out

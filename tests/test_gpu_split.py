@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from hip_helpers import conv3x3_split, conv_igemm, nchw, nhwc, pack_conv, pack_conv_split
+from hip_helpers import conv3x3_split, conv_igemm, nchw, nhwc, pack_conv, pack_conv_split, pack_upconv_split, upconv3x3_split
 from nextbestpath_amd import _lib
 from oracle import nbp_net
 
@@ -88,6 +88,37 @@ def test_conv3x3_split_vs_fp64_and_fp32_path(hip, case, mag):
     amax_in[5] = max(x0d.abs().max().item(), 0 if x1d is None else x1d.abs().max().item())
     got3 = conv3x3_split(x0d, x1d, ups, pack_conv_split(wd), N, scd, shd, True, split_k, amax_in=amax_in.view(torch.int32))
     assert torch.equal(got2, got3)
+
+
+# (B, Hs, Ws, C, N, split_k): low-resolution input size
+UP_CASES = [
+    (1, 16, 32, 64, 64, 1),        # one low-resolution tile -> 32 x 64 output, every border
+    (2, 32, 64, 96, 128, 1),       # 2 x 2 tiles, two images, two n blocks
+    (1, 16, 16, 64, 128, 1),       # 16 x 16 tiles x 128 channels
+    (1, 16, 32, 256, 64, 4),       # split-K
+    (2, 16, 16, 1024, 512, 0),     # Up5-like: automatic split-K
+]
+
+
+@pytest.mark.parametrize("case", UP_CASES)
+def test_upconv_parity_kernels_vs_fp64_and_fp32_path(hip, case):
+    """up_conv = x2 nearest upsample + 3x3 convolution, evaluated as four 2x2 convolutions of the low-resolution input with
+    pre-summed weights: against fp64 of the reference formulation (F.interpolate + conv2d), next to the fp32 pipe."""
+    B, Hs, Ws, C, N, split_k = case
+    dev = "cuda"
+    x = _rand(B, C, Hs, Ws, seed=1)
+    w = _rand(N, C, 3, 3, seed=3, scale=(6.0 / (C * 9)) ** 0.5)
+    scale = _rand(N, seed=4) * 0.2 + 1.0
+    shift = _rand(N, seed=5) * 0.1
+    ref = F.relu(F.conv2d(F.interpolate(x.double(), scale_factor=2), w.double(), None, padding=1) * scale.double().view(1, -1, 1, 1)
+                 + shift.double().view(1, -1, 1, 1))
+    wd, xd, scd, shd = w.to(dev).contiguous(), nhwc(x).to(dev), scale.to(dev), shift.to(dev)
+    got = nchw(upconv3x3_split(xd, pack_upconv_split(wd), N, scd, shd, True, split_k)).cpu().double()
+    f32 = nchw(conv_igemm(xd, None, 1, pack_conv(wd), N, 3, scd, shd, True, 1, 0)).cpu().double()
+    assert got.shape == ref.shape
+    e_split, e_f32 = (got - ref).abs(), (f32 - ref).abs()
+    assert e_split.max().item() < 4e-6 and e_split.max().item() <= 3.0 * e_f32.max().item() + 1e-7, (e_split.max(), e_f32.max())
+    assert e_split.pow(2).mean().sqrt().item() <= 1.2 * e_f32.pow(2).mean().sqrt().item() + 1e-9
 
 
 def test_split_kernel_refuses_what_it_does_not_take(hip):
