@@ -719,9 +719,26 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __restrict__ x, int B, int H, int W,
                                                               const float* __restrict__ w, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, float* __restrict__ out) {
+                                                              const float* __restrict__ shift, float* __restrict__ out,
+                                                              unsigned* __restrict__ amax_out) {
     conv_first_mfma_body<float>(x, B, H, W, w, scale, shift, out,
-                                [](float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; });
+                                [](float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }, amax_out);
+}
+
+// nbp_conv_first_f32 that also leaves max |out| in the 64 words of amax_out (zeroed by the caller); returns 1 in *did_amax
+// when the kernel that ran could do it (the 8 x 32-tile MFMA kernel), 0 otherwise
+int nbp_conv_first_amax_launch(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale, const float* shift,
+                               float* out_nhwc, unsigned* amax_out, int* did_amax, hipStream_t st) {
+    long long M = (long long)B * H * W;
+    static const int use_mfma = [] { const char* e = getenv("NBP_FIRST_MFMA"); return e ? atoi(e) : 1; }();
+    *did_amax = 0;
+    if (use_mfma && (H & 7) == 0 && (W & 31) == 0) {
+        conv_first_mfma_kernel<<<(unsigned)(M / 256 < 2048 ? M / 256 : 2048), 256, 0, st>>>(x_nchw, B, H, W, w_oihw, scale, shift, out_nhwc,
+                                                                                         amax_out);
+        *did_amax = amax_out ? 1 : 0;
+        return nbp_launch_status();
+    }
+    return nbp_conv_first_f32(x_nchw, B, H, W, w_oihw, scale, shift, out_nhwc, st);
 }
 
 extern "C" int nbp_conv_first_f32(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale,
@@ -733,7 +750,7 @@ extern "C" int nbp_conv_first_f32(const float* x_nchw, int B, int H, int W, cons
     static const int use_mfma = [] { const char* e = getenv("NBP_FIRST_MFMA"); return e ? atoi(e) : 1; }();
     if (use_mfma && (H & 7) == 0 && (W & 31) == 0) {     // 8 x 32 pixel tiles; other sizes take the VALU kernel below
         conv_first_mfma_kernel<<<(unsigned)(M / 256 < 2048 ? M / 256 : 2048), 256, 0, (hipStream_t)stream>>>(x_nchw, B, H, W, w_oihw, scale, shift,
-                                                                                   out_nhwc);
+                                                                                   out_nhwc, nullptr);
         return nbp_launch_status();
     }
     conv_first_kernel<<<(unsigned)nbp_cdiv(M, 64), 256, 0, (hipStream_t)stream>>>(x_nchw, B, H, W, w_oihw, scale,

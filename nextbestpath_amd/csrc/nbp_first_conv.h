@@ -10,7 +10,8 @@
 template <typename OutT, typename Store4>
 __device__ __forceinline__ void conv_first_mfma_body(const float* __restrict__ x, int B, int H, int W,
                                                      const float* __restrict__ w, const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, OutT* __restrict__ out, Store4 store4) {
+                                                     const float* __restrict__ shift, OutT* __restrict__ out, Store4 store4,
+                                                     unsigned* __restrict__ amax_out = nullptr) {
     constexpr int HW_ = 34, PLANE = 10 * HW_;            // 340 halo pixels per input channel
     __shared__ __attribute__((aligned(16))) float hal[5 * PLANE];
     __shared__ __attribute__((aligned(16))) float wl[46 * 64];   // [k][co], row 45 = 0
@@ -22,6 +23,7 @@ __device__ __forceinline__ void conv_first_mfma_body(const float* __restrict__ x
         wl[i] = k < 45 ? w[co * 45 + k] : 0.f;
     }
     const int kh = lane >> 5, ln = lane & 31;
+    float mx = 0.f;                                      // max |out| of this workgroup's tiles (split path: the next layer's scale)
   for (int tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
     int tile = tile_id;
     const int tx = tile % tiles_x; tile /= tiles_x;
@@ -72,9 +74,14 @@ __device__ __forceinline__ void conv_first_mfma_body(const float* __restrict__ x
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + n);
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][4 * rq + e] * sc[e] + sh[e], 0.f);
+                for (int e = 0; e < 4; ++e) { v[e] = fmaxf(acc[i][j][4 * rq + e] * sc[e] + sh[e], 0.f); mx = fmaxf(mx, v[e]); }
                 store4(out + m * 64 + n, v);
             }
     }
   }
+    if (amax_out) {     // one atomic per wave, spread over the 64 words of the tensor's slot (nbp_split.hip)
+#pragma unroll
+        for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) atomicMax(amax_out + ((blockIdx.x * 4u + wave) & 63u), __float_as_uint(mx));
+    }
 }

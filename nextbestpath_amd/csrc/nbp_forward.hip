@@ -380,6 +380,13 @@ struct PathSplit : PathF32 {
         }
         return nbp_conv_split_launch_g(s[0], o2 ? &s[1] : nullptr, C0, C1, ups, B, H, H, ks, N, 1, 0, ws, wsb, st);
     }
+    static int first(Ctx& ctx, const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {
+        unsigned* slot = ctx.fresh(out);
+        int did = 0;
+        const int rc = nbp_conv_first_amax_launch(x, B, s, s, (const float*)h->w[0], h->scale[0], h->shift[0], out, slot, &did, st);
+        if (!did && slot) --ctx.n;          // no max from this kernel: forget the binding, the consumer computes it
+        return rc;
+    }
     static int pool(Ctx& ctx, const T* in, int B, int H, int Cn, T* out, hipStream_t st) {
         ctx.alias(out, in);
         return nbp_maxpool2_nhwc_f32(in, B, H, H, Cn, out, st);

@@ -68,6 +68,8 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
 int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
                                       int c_total, void* dst, unsigned* wamax_out, hipStream_t st);
 int nbp_amax_launch(const float* x, long long n, unsigned* amax_inout, hipStream_t st);
+int nbp_conv_first_amax_launch(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale, const float* shift,
+                               float* out_nhwc, unsigned* amax_out, int* did_amax, hipStream_t st);
 
 // bf16 path (nbp_bf16.hip); K chunks are 64 channels
 struct ConvOperandsH { const bf16_t* src0; const bf16_t* src1; const bf16_t* wpk; const float* scale; const float* shift; bf16_t* out; };
