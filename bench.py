@@ -49,8 +49,10 @@ TILE_NAMES = {1: "igemm_conv_kernel<2,2,2,2>(128x128)", 2: "igemm_conv_kernel<4,
               5: "igemm_conv_kernel<1,4,2,1>(64x128)", 6: "conv3x3_halo_f32_kernel<4,2>(8x32 px x 128 ch)",
               7: "conv3x3_halo_f32_kernel<2,2>(8x32 px x 64 ch)", 8: "conv3x3_halo_f32_kernel<4,1>(4x32 px x 128 ch)",
               9: "conv3x3_halo_f32_kernel<2,1>(4x32 px x 64 ch)",
-              10: "conv3x3_halo_h2_kernel<32, 4, 2>(16x32 px x 64 ch; fp32 operands as 2 scaled fp16 pieces, 3 fp16 MFMAs per product)"}
+              10: "conv3x3_halo_h2_kernel<32, 4, 2, false>(16x32 px x 64 ch; fp32 operands as 2 scaled fp16 pieces, 3 fp16 MFMAs per product)",
+              11: "conv3x3_halo_h2_kernel<32, 4, 2, true>(up_conv as four 2x2 parity convolutions of the low-resolution input; same kernel body)"}
 SPLIT_TILE = 10
+SPLIT_TILES = (10, 11)
 TIMED = {"fp32": "nbp_forward_timed_f32", "fp32_split": "nbp_forward_timed_split_f32", "bf16": "nbp_forward_timed_bf16"}
 
 
@@ -347,17 +349,17 @@ def main():
         traffic = pick_traffic(live, dom_prefix) if (R, S) == (8, 256) else None
         traffic_src = live_src
         if traffic is None and (R, S) == (8, 256):
-            traffic, src2 = committed_traffic(dom_prefix, "forward_split_pmc_summary.csv" if dom == SPLIT_TILE
+            traffic, src2 = committed_traffic(dom_prefix, "forward_split_pmc_summary.csv" if dom in SPLIT_TILES
                                               else "forward_f32_pmc_summary.csv")
             traffic_src = f"{src2}; live pass: {live_src}" if src2 else live_src
         # the split kernel issues three fp16 MFMAs per fp32 product: its ceiling is the dense fp16 peak / 3 of ALGORITHMIC flops
-        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if dom == SPLIT_TILE else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if dom in SPLIT_TILES else PEAK_F32_MFMA_TFLOPS
         roofline = {"bound": "mfma", "kernel": TILE_NAMES[dom], "achieved": round(achieved, 3),
                     "peak": round(peak, 2), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "peak_basis": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product (algorithmic fp32 flops)"
-                                   if dom == SPLIT_TILE else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                                   if dom in SPLIT_TILES else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    "issued_mfma_tflops": round(achieved * (3 if dom == SPLIT_TILE else 1), 1),
+                    "issued_mfma_tflops": round(achieved * (3 if dom in SPLIT_TILES else 1), 1),
                     "traffic": None if traffic is None else round(traffic),
                     "traffic_unit": "HBM-side bytes per launch: 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide)",
                     "traffic_source": traffic_src,
