@@ -360,6 +360,9 @@ def main():
                                    if dom in SPLIT_TILES else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     "issued_mfma_tflops": round(achieved * (3 if dom in SPLIT_TILES else 1), 1),
+                    # a pure MFMA stream with random operand bits sustains 1709 TFLOP/s on this part (power-limited clocks;
+                    # tools/probes/mfma_f16_probe.hip, profiles/r02/mfma_f16_probe.txt): 2444 with all-ones operands
+                    "frac_of_sustained_mfma_stream": (round(achieved * 3 / 1709.0, 4) if dom in SPLIT_TILES else None),
                     "traffic": None if traffic is None else round(traffic),
                     "traffic_unit": "HBM-side bytes per launch: 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide)",
                     "traffic_source": traffic_src,
