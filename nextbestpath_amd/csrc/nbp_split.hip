@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const unsigned ma0 = read_amax(o.amax0), ma1 = o.amax1 ? read_amax(o.amax1) : 0u;
     const int ea = amax_exponent(ma0 > ma1 ? ma0 : ma1), ew = amax_exponent(*o.wamax);
     const float sa = pow2f(12 - ea);
-    const float inv = pow2f(ea + ew - 24);
+    const int einv = ea + ew - 24;                             // 1 / (s_x s_w) = 2^einv, applied with v_ldexp_f32 (any exponent)
 
     // halo staging: piece f = tid + 256 k is channels 4 (f & 3) .. + 3 of halo pixel f >> 2
     // (the LDS destination of piece k is ((f & 3) >> 1) RS + (f >> 2) 16 + (f & 1) 8: recomputed at the store, not kept)
@@ -286,8 +286,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 32 + (lane & 31);
-        float sc = inv, sh = 0.f;
-        if (final_out) { sc = o.scale[n] * inv; sh = o.shift[n]; }        // inv is a power of two: the product is exact
+        float sc = 1.f, sh = 0.f;
+        if (final_out) { sc = o.scale[n]; sh = o.shift[n]; }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const long long mrow = PH ? ((long long)b * a.H + 2 * (y0 + (TM * wave + i) * RPB) + py) * a.W + 2 * x0 + px
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int r = 0; r < 16; ++r) {
                 const int pb = (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 const int poff = PH ? 2 * ((pb / TW) * a.W + (pb % TW)) : (pb / TW) * a.W + (pb % TW);
-                float v = acc[i][j][r] * sc + sh;
+                float v = ldexpf(acc[i][j][r], einv) * sc + sh;
                 if (final_out && a.relu) v = fmaxf(v, 0.f);
                 mx = fmaxf(mx, fabsf(v));
                 outp[(mrow + poff) * a.N + n] = v;

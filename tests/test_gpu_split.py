@@ -121,6 +121,28 @@ def test_upconv_parity_kernels_vs_fp64_and_fp32_path(hip, case):
     assert e_split.pow(2).mean().sqrt().item() <= 1.2 * e_f32.pow(2).mean().sqrt().item() + 1e-9
 
 
+@pytest.mark.parametrize("mag", [0.0, 1e-30, 1e-12, 1e12, 1e25])
+def test_split_scales_cover_the_fp32_range(hip, mag):
+    """The per-tensor power-of-two scale keeps the fp16 pieces in range whatever the magnitude of the activations: all-zero
+    input gives exactly relu(shift); 1e-30 .. 1e25 give the fp32 pipe's relative accuracy (fp16 alone spans 6e-8 .. 65504)."""
+    dev = "cuda"
+    B, H, W, C, N = 1, 16, 32, 64, 64
+    x = _rand(B, C, H, W, seed=1) * mag
+    w = _rand(N, C, 3, 3, seed=3, scale=0.1)
+    scale = torch.ones(N)
+    shift = _rand(N, seed=5) * 0.1 * mag
+    ref = F.relu(F.conv2d(x.double(), w.double(), None, padding=1) + shift.double().view(1, -1, 1, 1))
+    xd, wd, scd, shd = nhwc(x).to(dev), w.to(dev).contiguous(), scale.to(dev), shift.to(dev)
+    got = nchw(conv3x3_split(xd, None, 0, pack_conv_split(wd), N, scd, shd, True, 1)).cpu().double()
+    if mag == 0.0:
+        assert torch.equal(got, ref)
+        return
+    f32 = nchw(conv_igemm(xd, None, 0, pack_conv(wd), N, 3, scd, shd, True, 1, 0)).cpu().double()
+    assert torch.isfinite(got).all()
+    e_split, e_f32 = (got - ref).abs().max().item(), (f32 - ref).abs().max().item()
+    assert e_split <= 3.0 * e_f32 + 1e-7 * mag, (e_split, e_f32)
+
+
 def test_split_kernel_refuses_what_it_does_not_take(hip):
     dev = "cuda"
     x = torch.zeros(1, 16, 24, 64, device=dev)                          # 24 wide: neither 32- nor 16-pixel tiles
