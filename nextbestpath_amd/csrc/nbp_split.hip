@@ -134,12 +134,28 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int Ht = PH ? a.Hs : a.H, Wt = PH ? a.Ws : a.W;     // the tile grid: output pixels, or low-resolution pixels for PH
     const int tiles_x = Wt / TW, tiles_y = Ht / TH;
     unsigned tile = blockIdx.x, nt = blockIdx.y;
-    if (a.xcd_remap) {      // XCD-contiguous runs of (pixel tile, channel block), channel block fastest (see nbp_conv.hip)
+    // Workgroups go round-robin to the 8 XCDs (each with its own L2) in linear-id order.  xcd_remap 1: an XCD takes a contiguous
+    // run of (pixel tile, channel block) pairs, channel block fastest -- activations cross the fabric once, every XCD streams
+    // all the weights.  xcd_remap 2 (weight-heavy layers): an XCD (or a group of 8 / gridDim.y XCDs) owns channel blocks, so the
+    // weights cross once and the activations once per owner.
+    if (a.xcd_remap == 1) {
         const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, T = gridDim.x * gridDim.y;
         const unsigned xcd = L & 7u, idx = L >> 3, q = T >> 3, r = T & 7u;
         const unsigned v = xcd * q + min(xcd, r) + idx;
         nt = v % gridDim.y;
         tile = v / gridDim.y;
+    } else if (a.xcd_remap == 2) {
+        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned xcd = L & 7u, idx = L >> 3, nbk = gridDim.y;
+        if (nbk >= 8u) {                    // nbk % 8 == 0 (launcher)
+            const unsigned per = nbk >> 3;
+            nt = xcd * per + idx % per;
+            tile = idx / per;
+        } else {                            // 8 % nbk == 0 and gridDim.x % (8 / nbk) == 0 (launcher)
+            const unsigned g = 8u / nbk;
+            nt = xcd / g;
+            tile = idx * g + xcd % g;
+        }
     }
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y;
@@ -554,8 +570,18 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     }
     {
         static const int forced = [] { const char* e = getenv("NBP_XCD_REMAP"); return e ? atoi(e) : -1; }();
-        const long long tiles = (a.M / (ph ? 4 : 1) / (16 * tw)) * (N / (tw == 32 ? 64 : 128));
-        a.xcd_remap = forced >= 0 ? forced : (tiles >= 512 ? 1 : 0);
+        const long long ptiles = a.M / (ph ? 4 : 1) / (16 * tw), nbk = N / (tw == 32 ? 64 : 128);
+        const long long tiles = ptiles * nbk;
+        // bytes that cross the fabric: mode 1 = 8 x weights + activations, mode 2 = weights + min(nbk, 8) x activations
+        const double wb = (double)(C0 + C1) * (ph ? 16 : 9) * N * 4, ab = (double)a.M / (ups ? 4 : 1) * (C0 + C1) * 4;
+        const bool fits2 = nbk >= 8 ? nbk % 8 == 0 : (8 % nbk == 0 && ptiles % (8 / nbk) == 0);
+        // (measured, B = 8: mode 2 cuts the fabric bytes of the 16-pixel-wide levels 3x -- 114 -> 39 MB and 266 -> 82 MB per launch --
+        // and raises them when the two sides are comparable, hence the factor 3; run time is the same either way)
+        const bool heavy = 7.0 * wb > ((nbk < 8 ? nbk : 8) - 1) * ab * 3.0;
+        int mode = tiles >= 512 ? 1 : 0;
+        if (fits2 && heavy && tiles >= 8) mode = 2;
+        if (forced >= 0) mode = (forced == 2 && !fits2) ? 0 : forced;
+        a.xcd_remap = mode;
     }
     a.partial = nullptr;
     if (p.split_k > 1) {
