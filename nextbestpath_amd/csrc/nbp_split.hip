@@ -578,7 +578,7 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
         // (measured, B = 8: mode 2 cuts the fabric bytes of the 16-pixel-wide levels 3x -- 114 -> 39 MB and 266 -> 82 MB per launch --
         // and raises them when the two sides are comparable, hence the factor 3; run time is the same either way)
         const bool heavy = 7.0 * wb > ((nbk < 8 ? nbk : 8) - 1) * ab * 3.0;
-        int mode = tiles >= 512 ? 1 : 0;
+        int mode = tiles >= 8 ? 1 : 0;      // (no run-time difference between the modes on this kernel: chosen by fabric bytes)
         if (fits2 && heavy && tiles >= 8) mode = 2;
         if (forced >= 0) mode = (forced == 2 && !fits2) ? 0 : forced;
         a.xcd_remap = mode;
