@@ -115,7 +115,7 @@ _ws_cache = {}
 
 def _workspace(B, S, device, precision="fp32"):
     # one workspace per (shape, stream): forwards enqueued on different streams may run concurrently
-    key = (B, S, str(device), precision, torch.cuda.current_stream(device).cuda_stream)
+    key = (B, S, device.index if isinstance(device, torch.device) else str(device), precision, _lib.current_stream())
     ws = _ws_cache.get(key)
     if ws is None:
         L = _lib.lib()
@@ -141,9 +141,14 @@ def forward_packed(packed: PackedWeights, x: torch.Tensor, precision: str = None
     out2 = torch.empty(B, 1, S, S, dtype=torch.float32, device=x.device)
     ws = _workspace(B, S, x.device, precision)
     fn = getattr(_lib.lib(), _FWD[precision][0])
-    with torch.cuda.device(x.device):
+    if torch.cuda.current_device() == x.device.index:       # the common case: no device-guard objects in the step loop
         rc = fn(packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(), ws.data_ptr(), ws.numel(),
                 _lib.current_stream())
+    else:
+        with torch.cuda.device(x.device):
+            ws = _workspace(B, S, x.device, precision)
+            rc = fn(packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(), ws.data_ptr(), ws.numel(),
+                    _lib.current_stream())
     _lib.check(rc, _FWD[precision][0])
     return out1, out2
 

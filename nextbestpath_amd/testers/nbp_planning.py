@@ -183,6 +183,7 @@ class MultiRollout:
 
     def __init__(self, rollouts, nbp, device, grid=None, streams=True, n_groups=None):
         self.rollouts, self.nbp = list(rollouts), nbp
+        self.device, self._packed = device, None
         grid = grid or self.rollouts[0].S
         R = len(self.rollouts)
         n_groups = n_groups or int(os.environ.get("NBP_ROLLOUT_GROUPS", "2"))
@@ -219,35 +220,61 @@ class MultiRollout:
 
     def _launch(self, gi):
         grp, net_in, fwd = self.groups[gi], self.net_in[gi], self.fwd_streams[gi]
+        if not self.per_rollout:
+            # one stream per group: a single stream guard around the whole group (a guard per rollout is ~10 us of host time)
+            with torch.cuda.stream(fwd):
+                for i, r in enumerate(grp):
+                    r.pre(net_in[i:i + 1])
+                with torch.no_grad():
+                    out1, out2 = self._forward(net_in)
+                for i, r in enumerate(grp):
+                    r.plan_enqueue(out1[i], out2[i])
+                    self.ev_plan[gi][i].record()
+            self.inflight[gi] = True
+            return
         for i, r in enumerate(grp):
             with torch.cuda.stream(self.rstreams[gi][i]):
                 r.pre(net_in[i:i + 1])
-                if self.per_rollout:
-                    self.ev_pre[gi][i].record()
+                self.ev_pre[gi][i].record()
         with torch.cuda.stream(fwd):
-            if self.per_rollout:
-                for ev in self.ev_pre[gi]:
-                    fwd.wait_event(ev)
+            for ev in self.ev_pre[gi]:
+                fwd.wait_event(ev)
             with torch.no_grad():
-                out1, out2 = self.nbp(net_in)
-            if self.per_rollout:
-                self.ev_fwd[gi].record()
+                out1, out2 = self._forward(net_in)
+            self.ev_fwd[gi].record()
         for i, r in enumerate(grp):
             st = self.rstreams[gi][i]
             with torch.cuda.stream(st):
-                if self.per_rollout:
-                    st.wait_event(self.ev_fwd[gi])     # also orders the next pre() after this forward's read of net_in
-                    if r.need_replan:
-                        out1.record_stream(st); out2.record_stream(st)
+                st.wait_event(self.ev_fwd[gi])     # also orders the next pre() after this forward's read of net_in
+                if r.need_replan:
+                    out1.record_stream(st); out2.record_stream(st)
                 r.plan_enqueue(out1[i], out2[i])
                 self.ev_plan[gi][i].record()
         self.inflight[gi] = True
 
+    def _forward(self, net_in):
+        """The rollouts evaluate a frozen network: its packed weights are looked up (and their staleness checked: 327 tensor
+        versions) once per lock-step, not once per forward."""
+        if self._packed is None:
+            return self.nbp(net_in)
+        from ..networks import packing
+        return packing.forward_packed(self._packed, net_in)
+
     def _complete(self, gi):
         grp = self.groups[gi]
+        if not self.per_rollout:
+            for i, r in enumerate(grp):
+                if r.need_replan:
+                    self.ev_plan[gi][i].synchronize()      # the GPU keeps running whatever was queued after the event
+            with torch.cuda.stream(self.fwd_streams[gi]):
+                for r in grp:
+                    r.plan_finish()
+                    r.post()
+            self.inflight[gi] = False
+            return
         for i, r in enumerate(grp):
             if r.need_replan:
-                self.ev_plan[gi][i].synchronize()      # the GPU keeps running whatever was queued after the event
+                self.ev_plan[gi][i].synchronize()
             with torch.cuda.stream(self.rstreams[gi][i]):
                 r.plan_finish()
                 r.post()
@@ -257,6 +284,8 @@ class MultiRollout:
         """One exploration step of every rollout (completions are deferred: a group is finished right after the
         next group has been launched, so the GPU always has another group's forward queued)."""
         G = len(self.groups)
+        ensure = getattr(self.nbp, "_ensure_packed", None)
+        self._packed = ensure(self.device) if ensure is not None and not self.nbp.training else None
         for gi in range(G):
             if self.inflight[gi]:
                 self._complete(gi)
