@@ -465,7 +465,9 @@ def main():
             fl16 = L.nbp_forward_flops(8, 512)
             stage["config5_forward_bf16_512_b8"] = {"ms": round(ms16, 4), "maps_per_s": round(8e3 / ms16, 2),
                                                     "tflops": round(fl16 / (ms16 * 1e-3) / 1e12, 2),
-                                                    "frac_of_bf16_mfma_peak": round(fl16 / (ms16 * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
+                                                    "frac_of_bf16_mfma_peak": round(fl16 / (ms16 * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                                    # 16-bit MFMA stream on random operands: 1709 TFLOP/s (mfma_f16_probe)
+                                                    "frac_of_sustained_mfma_stream": round(fl16 / (ms16 * 1e-3) / 1e12 / 1709.0, 4)}
             pk16.free()
             del x5, pk16
             # ---- BASELINE configs[2]: one training step (fwd + bwd + AdamW) on 32 maps of 256x256, fp32
