@@ -232,3 +232,23 @@ def test_rollout_on_tiny_scenes(hip, nbp_weights, tmp_path, cells, size):
     cov = ro.coverage_evolution(25)
     assert all(np.isfinite(cov)) and cov[-1] > 0.2          # a single room is mostly seen within a few steps
     assert len(ro.camera.cam_idx_history) >= 25
+
+
+def test_split_path_and_fp32_pipe_take_the_same_trajectory(hip, dataset, nbp_weights):
+    """The default eval path (3x3 convolutions as three fp16 MFMAs per product on two-piece operands) and the fp32 MFMA pipe drive
+    the same exploration: identical lattice path, coverage curve and cloud size over 40 steps (value maps differ at the 1e-6
+    level, goal cells do not)."""
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.testers import nbp_planning as tp
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    ds = sc.SceneDataset(dataset)
+    runs = tp.list_runs(ds, params)
+    res = {}
+    for prec in ("fp32_split", "fp32"):
+        net = _net(nbp_weights)
+        net.conv_precision = prec
+        with torch.no_grad():
+            res[prec] = tp.run_one(params, net, ds, runs[1], torch.device("cuda"), n_poses=40, seed=11)
+    a, b = res["fp32_split"], res["fp32"]
+    assert a["X_cam_history"] == b["X_cam_history"] and a["coverage"] == b["coverage"] and a["n_points"] == b["n_points"]
+    assert a["coverage"][-1] > 0.02
