@@ -18,7 +18,8 @@ The timed window sits in the MIDDLE of the 101-step trajectory: the rollouts are
 `stages.windows` also reports an early (steps 5-25) and a late (steps 80-100) window of the same rollouts.
 
 Rank 0 prints ONE JSON line.  `value` = exploration steps/s over all ranks; `nbp_maps_per_s` = NBP forwards/s (the second
-half of BASELINE.json's metric); `roofline` = the dominant kernel (fp32 MFMA halo-tile convolution) timed live with HIP
+half of BASELINE.json's metric, at the batch the lock-step forwards); `roofline` = the dominant kernel (the split 3x3
+convolution; the fp32 MFMA halo-tile convolution under NBP_CONV_PRECISION=fp32) timed live with HIP
 events on the launch stream, its HBM-side traffic measured live with rocprofv3 PMC passes over the same forward
 (tools/pmc_workload.py; falls back to the committed profile); `roofline_scatter` = the HBM-bound map accumulation;
 `stages` = the other kernels of the step and the configs[2] train step / configs[4] bf16 forward;
@@ -67,7 +68,7 @@ def parse():
     ap.add_argument("--no-extra-stages", action="store_true", help="skip the train-step / bf16 / window stages (profiling runs)")
     ap.add_argument("--layers", action="store_true", help="per-layer timing table to stderr")
     ap.add_argument("--faces", choices=["simple", "hard"], default="simple")
-    ap.add_argument("--rollouts-per-gpu", type=int, default=8,
+    ap.add_argument("--rollouts-per-gpu", type=int, default=16,
                     help="independent rollouts stepped in lock-step per GPU (their NBP forwards are one batched launch)")
     return ap.parse_args()
 
@@ -310,11 +311,12 @@ def main():
     stage = {}
     if rank == 0:
         # ---- the dominant kernel, per launch, with HIP events on the launch stream
-        x = torch.cat(multi.net_in)
+        x = multi.net_in[0]          # the batch the lock-step really forwards: one pipeline group (R / 2 maps)
+        Bf = int(x.shape[0])
         packed = net._ensure_packed(dev)
-        o1 = torch.empty(R, 8, S // 4, S // 4, device=dev)
-        o2 = torch.empty(R, 1, S, S, device=dev)
-        ws = packing._workspace(R, S, dev, packed.precision)
+        o1 = torch.empty(Bf, 8, S // 4, S // 4, device=dev)
+        o2 = torch.empty(Bf, 1, S, S, device=dev)
+        ws = packing._workspace(Bf, S, dev, packed.precision)
         reps, acc = 5, {}
         for r in range(reps + 1):
             rows = timed_layers(packed, x, o1, o2, ws)
@@ -346,9 +348,9 @@ def main():
         if world == 1 and not args.no_live_traffic:
             live, live_src = live_traffic(n_pts, packed.precision)
         dom_prefix = TILE_NAMES[dom].split("(")[0].replace(" ", "")
-        traffic = pick_traffic(live, dom_prefix) if (R, S) == (8, 256) else None
+        traffic = pick_traffic(live, dom_prefix) if (Bf, S) == (8, 256) else None
         traffic_src = live_src
-        if traffic is None and (R, S) == (8, 256):
+        if traffic is None and (Bf, S) == (8, 256):
             traffic, src2 = committed_traffic(dom_prefix, "forward_split_pmc_summary.csv" if dom in SPLIT_TILES
                                               else "forward_f32_pmc_summary.csv")
             traffic_src = f"{src2}; live pass: {live_src}" if src2 else live_src
@@ -378,20 +380,20 @@ def main():
                 print(f'{r["name"]:24s} M={r["M"]:7d} N={r["N"]:5d} K={r["K"]:5d} tile={r["tile"]:2d} '
                       f'sk={r["split_k"]:2d} {r["ms"]*1e3:9.1f} us {tf:7.2f} TF', file=sys.stderr)
         ms_fwd = ev_time(lambda: net(x))
-        fl = L.nbp_forward_flops(R, S)
+        fl = L.nbp_forward_flops(Bf, S)
         x1 = x[:1].contiguous()
         ms_fwd1 = ev_time(lambda: net(x1))
         stage["nbp_forward_b1"] = {"ms": round(ms_fwd1, 4), "maps_per_s": round(1e3 / ms_fwd1, 2),
                                    "tflops": round(L.nbp_forward_flops(1, S) / (ms_fwd1 * 1e-3) / 1e12, 3),
                                    "frac_of_f32_mfma_peak": round(L.nbp_forward_flops(1, S) / (ms_fwd1 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
-        stage["nbp_forward"] = {"ms": round(ms_fwd, 4), "batch": R, "maps_per_s": round(R * 1e3 / ms_fwd, 2),
+        stage["nbp_forward"] = {"ms": round(ms_fwd, 4), "batch": Bf, "maps_per_s": round(Bf * 1e3 / ms_fwd, 2),
                                 "tflops": round(fl / (ms_fwd * 1e-3) / 1e12, 3), "conv_precision": net.conv_precision,
                                 "frac_of_f32_mfma_peak": round(fl / (ms_fwd * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
         if net.conv_precision != "fp32" and not args.no_extra_stages:
             # the same forward on the fp32 MFMA pipe (NBP_CONV_PRECISION=fp32 makes it the rollouts' path)
             pk32 = packing.pack_state_dict(sd, dev, precision="fp32")
             ms32 = ev_time(lambda: packing.forward_packed(pk32, x))
-            stage["nbp_forward_fp32_pipe"] = {"ms": round(ms32, 4), "batch": R, "maps_per_s": round(R * 1e3 / ms32, 2),
+            stage["nbp_forward_fp32_pipe"] = {"ms": round(ms32, 4), "batch": Bf, "maps_per_s": round(Bf * 1e3 / ms32, 2),
                                               "tflops": round(fl / (ms32 * 1e-3) / 1e12, 3),
                                               "frac_of_f32_mfma_peak": round(fl / (ms32 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
             pk32.free()
