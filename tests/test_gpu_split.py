@@ -217,3 +217,19 @@ def test_split_handle_also_runs_the_fp32_forward(hip, nets, nbp_weights):
     pk32 = packing.pack_state_dict(nbp_weights, "cuda", precision="fp32")
     with pytest.raises(ValueError):
         packing.forward_packed(pk32, x, precision="fp32_split")
+
+
+@pytest.mark.parametrize("B,S", [(1, 64), (3, 96), (2, 160), (5, 192), (1, 320), (2, 384), (1, 448), (7, 128), (16, 64)])
+def test_split_forward_equals_fp32_pipe_over_sizes(hip, nets, B, S):
+    """Grids whose pyramid mixes the three routes of the split path (16 x 32 tiles, 16 x 16 tiles with >= 128 channels, parity
+    up-conv kernels) with the fp32-pipe fallbacks (levels that are not multiples of 16), odd batch sizes: both paths agree to
+    1e-4 of the output range and pick the same goal cells."""
+    from nextbestpath_amd.utility.synthetic import make_count_maps
+    x = make_count_maps(B, S, seed=300 + S + B).cuda()
+    with torch.no_grad():
+        o1, o2 = nets[0](x)
+        f1, f2 = nets[1](x)
+    rng = max(1.0, float(f1.abs().max()))
+    assert float((o1 - f1).abs().max()) < 1e-4 * rng and float((o2 - f2).abs().max()) < 1e-4
+    assert torch.equal(o1.amax(1).flatten(1).argmax(1), f1.amax(1).flatten(1).argmax(1))
+    assert torch.equal(o2 >= 0.13, f2 >= 0.13)
