@@ -100,11 +100,15 @@ double nbp_forward_flops(int B, int S);
  * are NHWC bf16, the 3x3 / attention-gate weights are bf16, accumulation and every epilogue (folded BatchNorm,
  * ReLU, sigmoid, psi gate) are fp32, and each stored activation is rounded once (nearest even).  It cannot
  * meet the 1e-4 fp32 tolerance (bf16 has 8 mantissa bits); tests/test_gpu_bf16.py states its tolerance.
- * nbp_pack_weights_bf16 takes exactly the inputs of nbp_pack_weights (`packed` of nbp_packed_weights_bytes()). */
+ * nbp_pack_weights_bf16 takes exactly the inputs of nbp_pack_weights (`packed` of nbp_packed_weights_bytes_bf16()). */
 int nbp_pack_weights_bf16(const void* const* w_host_array, const void* const* scale_host_array,
                           const void* const* shift_host_array, void* packed, size_t packed_bytes,
                           void* stream, nbp_weights** handle_out);
+size_t nbp_packed_weights_bytes_bf16(void);   /* `packed` of nbp_pack_weights_bf16: the common pack + the up_conv parity filters */
 size_t nbp_forward_workspace_bytes_bf16(int B, int S);
+/* up_conv parity filters in bf16 for nbp_conv_igemm_bf16 with tile 12 / 13 (8 x 32 low-resolution tiles x 128 / 64 channels;
+ * ups must be 1, C1 0): dst [parity][C/64][4 taps][N][64] bf16 = 32 N C bytes. */
+int nbp_pack_upconv_weight_bf16(const float* w_oihw, int N, int C, unsigned short* dst, void* stream);
 int nbp_forward_bf16(const nbp_weights* handle, const float* x, int B, int S, float* out1,
                      float* out2, void* ws, size_t ws_bytes, void* stream);
 int nbp_forward_timed_bf16(const nbp_weights* handle, const float* x, int B, int S, float* out1,

@@ -87,6 +87,8 @@ SIGNATURES["nbp_forward_timed_f32"] = (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz
                                             C.POINTER(_i)])
 SIGNATURES["nbp_forward_timed_bf16"] = SIGNATURES["nbp_forward_timed_f32"]
 SIGNATURES["nbp_pack_weights_bf16"] = SIGNATURES["nbp_pack_weights"]
+SIGNATURES["nbp_packed_weights_bytes_bf16"] = SIGNATURES["nbp_packed_weights_bytes"]
+SIGNATURES["nbp_pack_upconv_weight_bf16"] = (_i, [_vp, _i, _i, _vp, _vp])
 SIGNATURES["nbp_forward_workspace_bytes_bf16"] = SIGNATURES["nbp_forward_workspace_bytes"]
 SIGNATURES["nbp_forward_bf16"] = SIGNATURES["nbp_forward_f32"]
 SIGNATURES["nbp_packed_weights_bytes_split"] = SIGNATURES["nbp_packed_weights_bytes"]

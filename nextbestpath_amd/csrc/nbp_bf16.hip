@@ -218,9 +218,16 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmArgsH a) {
 // covers the other's halo reload.  Same K order as the implicit GEMM (chunk, tap, k): results are bit-identical.
 // TPS = filter taps per weight stage (= per barrier): the 64-channel variant pairs taps so that a wave still has 32 MFMAs
 // between barriers (its 16 per tap finish in 512 cycles, too close to the barrier + first-fragment latency).
-template <int TN, int TPS>
+// PH (up_conv = x2 nearest upsample + 3x3, nbp_model.py:25-33): the four output parities are four 2x2 convolutions of the
+// LOW-resolution input with pre-summed weights (nbp_split.hip has the fp32 form and the derivation); a workgroup owns one
+// parity (blockIdx.z & 3) of an 8 x 32 low-resolution tile and writes its outputs to (2 v + py, 2 u + px).
+template <int TN, int TPS, bool PH>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a) {
-    int zs = blockIdx.z;        // split-K slice (of 64-channel chunks), then the group
+    int zs = blockIdx.z;        // [parity,] split-K slice (of 64-channel chunks), then the group
+    const int py = PH ? (zs >> 1) & 1 : 0, px = PH ? zs & 1 : 0;
+    if (PH) zs >>= 2;
+    const int zslice = zs;
+    constexpr int TAPS = PH ? 4 : 9, TPR = PH ? 2 : 3;
     if (zs >= a.split_k) {
         zs -= a.split_k;
         a.src0 = a.g_src0; a.src1 = a.g_src1; a.wpk = a.g_wpk; a.scale = a.g_scale; a.shift = a.g_shift; a.out = a.g_out;
@@ -230,13 +237,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
     constexpr int HALO_ROWS = 344;             // 10 * 34 = 340 halo pixels, padded to 43 DMA instructions of 8 rows
     constexpr int HALO_BYTES = HALO_ROWS * 128;
     constexpr int WB = TPS * BN * 128;         // one weight stage: TPS taps x BN rows of 64 bf16
-    constexpr int NST = (9 + TPS - 1) / TPS;   // stages per 64-channel chunk
+    constexpr int NST = (TAPS + TPS - 1) / TPS;   // stages per 64-channel chunk
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const halo = lds;
     char* const wbuf = lds + HALO_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_x = a.W >> 5, tiles_y = a.H >> 3;
+    const int Ht = PH ? a.Hs : a.H, Wt = PH ? a.Ws : a.W;      // the tile grid: output pixels, or low-resolution pixels for PH
+    const int tiles_x = Wt >> 5, tiles_y = Ht >> 3;
     unsigned tile = blockIdx.x, nt = blockIdx.y;
     if (a.xcd_remap) {      // XCD-contiguous runs of (pixel tile, channel block), channel block fastest (see nbp_conv.hip)
         const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, T = gridDim.x * gridDim.y;
@@ -259,8 +267,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
         const int hr = 8 * q + (lane >> 3);
         const int hy = hr / HW_, hx = hr - hy * HW_;
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-        const bool ok = q < 43 && hr < 340 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-        hpix[i] = ok ? (b * a.Hs + (yy >> a.ups)) * a.Ws + (xx >> a.ups) : -1;
+        const bool ok = q < 43 && hr < 340 && (unsigned)yy < (unsigned)Ht && (unsigned)xx < (unsigned)Wt;
+        hpix[i] = ok ? (PH ? (b * a.Hs + yy) * a.Ws + xx : (b * a.Hs + (yy >> a.ups)) * a.Ws + (xx >> a.ups)) : -1;
     }
     const int hslot = lane & 7;                 // physical 16-B slot; logical = hslot ^ swz(halo row)
     const int lrow = tid >> 3;
@@ -288,14 +296,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
             }
         }
     };
+    // PH: the four parities' weights follow each other, each [chunk][4 taps][N][64]
+    const long long pbase = PH ? (long long)(py * 2 + px) * (a.chunks_total / TAPS) * TAPS : 0;
     auto issue_w = [&](int u) {      // u = chunk * NST + stage; the packed weights are [chunk][tap][N][64]
         const int cu = u / NST, su = u - cu * NST;
         char* dst = wbuf + (u & 1) * WB + wave * 1024;
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) {
             const int tap = su * TPS + tt;
-            if (tap < 9) {
-                const unsigned woff = (unsigned)(((long long)(cu * 9 + tap) * a.N + n0 + lrow) * 64 + wslot * 8) * 2u;
+            if (tap < TAPS) {
+                const unsigned woff = (unsigned)(((pbase + cu * TAPS + tap) * a.N + n0 + lrow) * 64 + wslot * 8) * 2u;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + tt * (BN * 128) + j * 4096), 16,
@@ -321,8 +331,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
     const int khalf = lane >> 5;
     const int hbase = (2 * wave) * HW_ + (lane & 31);     // halo row of this lane's pixel for tap (-1,-1), M tile 0
 
-    const int cc_begin = zs * (a.chunks_per_split / 9);
-    const int chunks = min(cc_begin + a.chunks_per_split / 9, a.chunks_total / 9);
+    const int cc_begin = zs * (a.chunks_per_split / TAPS);
+    const int chunks = min(cc_begin + a.chunks_per_split / TAPS, a.chunks_total / TAPS);
     const int u_total = chunks * NST;
     if (cc_begin < chunks) {
         issue_halo(cc_begin);
@@ -338,9 +348,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
 #pragma unroll
             for (int tt = 0; tt < TPS; ++tt) {
                 const int tap = st * TPS + tt;
-                if (tap < 9) {
+                if (tap < TAPS) {
                     const char* Bt = wbuf + (u & 1) * WB + tt * (BN * 128);
-                    const int hr0 = hbase + (tap / 3) * HW_ + (tap % 3);
+                    const int hr0 = hbase + (tap / TPR + py) * HW_ + (tap % TPR) + px;
                     const int hr1 = hr0 + HW_;
                     const int ar0 = hr0 * 128, as0 = (hr0 >> 1) & 7, ar1 = hr1 * 128, as1 = (hr1 >> 1) & 7;
 #pragma unroll
@@ -372,10 +382,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a)
 
     // ---- epilogue: lane = pixel (lane & 31) of image row y0 + 2 wave + i, four consecutive channels per quad
     const bool final_out = (a.split_k == 1);
-    float* part = final_out ? nullptr : a.partial + (long long)blockIdx.z * a.M * a.N;
+    float* part = final_out ? nullptr : a.partial + (long long)zslice * a.M * a.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const long long m = ((long long)b * a.H + y0 + 2 * wave + i) * a.W + x0 + (lane & 31);
+        const long long m = PH ? ((long long)b * a.H + 2 * (y0 + 2 * wave + i) + py) * a.W + 2 * (x0 + (lane & 31)) + px
+                               : ((long long)b * a.H + y0 + 2 * wave + i) * a.W + x0 + (lane & 31);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -431,6 +442,8 @@ static TileInfo tile_info_h(int tile) {
     switch (tile) {
         case NBP_TILE_HALO_128: return {256, 128};
         case NBP_TILE_HALO_64: return {256, 64};
+        case NBP_TILE_HALO_UP_128: return {256, 128};
+        case NBP_TILE_HALO_UP_64: return {256, 64};
         case NBP_TILE_128x128: return {128, 128};
         case NBP_TILE_256x64: return {256, 64};
         case NBP_TILE_256x32: return {256, 32};
@@ -445,8 +458,28 @@ static bool halo_ok(int H, int W, int N, int ksize, int bn) {
 }
 
 ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int split_k, int groups, int H, int W,
-                            int ksize) {
+                            int ksize, int ups) {
     ConvPlan p;
+    static const int allow_up = [] { const char* e = getenv("NBP_BF16_UP"); return e ? atoi(e) : 1; }();
+    if ((tile == NBP_TILE_AUTO && allow_up && ups && ksize == 3 && split_k <= 0) || tile == NBP_TILE_HALO_UP_128 ||
+        tile == NBP_TILE_HALO_UP_64) {
+        // up_conv as four parity convolutions of the low-resolution image (8 x 32 low-resolution tiles)
+        const int bn = tile == NBP_TILE_HALO_UP_128 ? 128 : tile == NBP_TILE_HALO_UP_64 ? 64 : (N % 128 == 0 ? 128 : 64);
+        if (!((H | W) & 1) && halo_ok(H / 2, W / 2, N, 3, bn)) {
+            static const int min_blocks_up = [] { const char* e = getenv("NBP_BF16_HALO_MIN"); return e ? atoi(e) : 128; }();
+            const long long blocks = (M / 4 / 256) * (N / bn) * groups * 4;
+            const int cc = chunks_total / 9;
+            int sk = split_k <= 0 ? 1 : split_k;
+            if (split_k <= 0) while (blocks * sk < min_blocks_up && cc / (sk * 2) >= 4 && sk < 16) sk *= 2;
+            if (sk > cc) sk = cc;
+            if (sk < 1) sk = 1;
+            const int per = cc > 0 ? (int)nbp_cdiv(cc, sk) : 1;
+            p.tile = bn == 128 ? NBP_TILE_HALO_UP_128 : NBP_TILE_HALO_UP_64;
+            p.split_k = cc > 0 ? (int)nbp_cdiv(cc, per) : 1; p.chunks_per_split = per * 4;      // kernel units: (chunk, 4 taps)
+            return p;
+        }
+        if (tile != NBP_TILE_AUTO) { p.tile = -1; p.split_k = 1; p.chunks_per_split = chunks_total; return p; }
+    }
     if (tile == NBP_TILE_AUTO && ksize == 3 && split_k <= 0) {
         // halo-tile kernel once tiles (x split-K over whole chunks) give >= ~128 workgroups
         // (threshold from tools/bench_forward.py sweeps at B = 1..8, S = 256 / 512)
@@ -497,18 +530,18 @@ ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int 
     return p;
 }
 
-template <int TN, int TPS>
+template <int TN, int TPS, bool PH = false>
 static int launch_halo(const IgemmArgsH& a, hipStream_t st) {
     constexpr size_t smem = 344 * 128 + 2 * (size_t)TPS * TN * 32 * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TN, TPS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TN, TPS, PH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((unsigned)(a.M / 256), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups));
-    conv3x3_halo_bf16_kernel<TN, TPS><<<grid, 256, smem, st>>>(a);
+    dim3 grid((unsigned)(a.M / (PH ? 4 : 1) / 256), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups * (PH ? 4 : 1)));
+    conv3x3_halo_bf16_kernel<TN, TPS, PH><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 
@@ -555,9 +588,20 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
         a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0; a.bytesw = (unsigned)bw;
     }
     a.chunks_total = (C0 + C1) / 64 * a.taps;
-    ConvPlan p = nbp_plan_conv_bf16(a.M, N, a.chunks_total, tile, split_k, groups, H, W, ksize);
+    const bool explicit_up = tile == NBP_TILE_HALO_UP_128 || tile == NBP_TILE_HALO_UP_64;
+    const bool have_up = ups && C1 == 0 && (explicit_up || (o.wpk_up && (!o2 || o2->wpk_up)));
+    ConvPlan p = nbp_plan_conv_bf16(a.M, N, a.chunks_total, tile, split_k, groups, H, W, ksize, have_up ? 1 : 0);
     TileInfo ti = tile_info_h(p.tile);
     NBP_RETURN_IF(ti.bm == 0 || N % ti.bn, NBP_E_SHAPE);
+    const bool ph = p.tile == NBP_TILE_HALO_UP_128 || p.tile == NBP_TILE_HALO_UP_64;
+    if (ph) {       // the parity filters: explicit tile id -> they are what wpk points at; automatic -> the operands' wpk_up
+        NBP_RETURN_IF(!have_up, NBP_E_SHAPE);
+        if (!explicit_up) { a.wpk = o.wpk_up; a.g_wpk = o2 ? o2->wpk_up : nullptr; }
+        a.chunks_total = C0 / 64 * 4;
+        const long long bwu = (long long)C0 * 16 * N * 2;
+        NBP_RETURN_IF(bwu >= (1ll << 31), NBP_E_SHAPE);
+        a.bytesw = (unsigned)bwu;
+    }
     if (p.tile == NBP_TILE_HALO_128 || p.tile == NBP_TILE_HALO_64)
         NBP_RETURN_IF(!halo_ok(H, W, N, ksize, ti.bn), NBP_E_SHAPE);
     a.split_k = p.split_k; a.chunks_per_split = p.chunks_per_split;
@@ -578,6 +622,8 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
         case NBP_TILE_128x64: rc = launch_igemm_h<2, 2, 2, 1>(a, st); break;
         case NBP_TILE_64x128: rc = launch_igemm_h<1, 4, 2, 1>(a, st); break;
         case NBP_TILE_HALO_128: rc = launch_halo<4, 1>(a, st); break;
+        case NBP_TILE_HALO_UP_128: rc = launch_halo<4, 1, true>(a, st); break;
+        case NBP_TILE_HALO_UP_64: rc = launch_halo<2, 2, true>(a, st); break;
         case NBP_TILE_HALO_64: {
             static const int tps = [] { const char* e = getenv("NBP_BF16_TPS"); return e ? atoi(e) : 2; }();
             rc = tps == 2 ? launch_halo<2, 2>(a, st) : launch_halo<2, 1>(a, st);
@@ -627,6 +673,43 @@ __global__ void pack_conv_weight_bf16_kernel(const float* __restrict__ w, int N,
         int cg = c_off + c;
         dst[(((long long)(cg >> 6) * taps + tap) * N + n) * 64 + (cg & 63)] = f2bf(v);
     }
+}
+
+// up_conv parity filters in bf16: dst[(((ph * C/64 + c/64) * 4 + tap) * N + n) * 64 + c%64] = bf16(sum in double of the 3x3 taps that
+// land on low-resolution tap (r, t) = (tap / 2, tap % 2) of parity ph = py * 2 + px): R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1},
+// R(1,1) = {2}
+__global__ void pack_upconv_weight_bf16_kernel(const float* __restrict__ w, int N, int C, bf16_t* __restrict__ dst) {
+    const long long NC = (long long)N * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < NC; i += (long long)gridDim.x * blockDim.x) {
+        double v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = (double)w[i * 9 + k];
+        const int n = (int)(i / C), c = (int)(i % C);
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {
+                const int py = ph >> 1, px = ph & 1, r = tap >> 1, t = tap & 1;
+                const int y_lo = py == 0 ? (r == 0 ? 0 : 1) : (r == 0 ? 0 : 2), y_hi = py == 0 ? (r == 0 ? 0 : 2) : (r == 0 ? 1 : 2);
+                const int x_lo = px == 0 ? (t == 0 ? 0 : 1) : (t == 0 ? 0 : 2), x_hi = px == 0 ? (t == 0 ? 0 : 2) : (t == 0 ? 1 : 2);
+                double acc = 0.0;
+                for (int y = y_lo; y <= y_hi; ++y)
+                    for (int x = x_lo; x <= x_hi; ++x) acc += v[y * 3 + x];
+                dst[((((long long)ph * (C >> 6) + (c >> 6)) * 4 + tap) * N + n) * 64 + (c & 63)] = f2bf((float)acc);
+            }
+    }
+}
+
+int nbp_pack_upconv_weight_bf16_launch(const float* w_oihw, int N, int C, bf16_t* dst, hipStream_t st) {
+    NBP_RETURN_IF(!w_oihw || !dst, NBP_E_ARG);
+    NBP_RETURN_IF(N < 1 || C < 64 || C % 64, NBP_E_SHAPE);
+    pack_upconv_weight_bf16_kernel<<<nbp_ew_grid((long long)N * C, 256), 256, 0, st>>>(w_oihw, N, C, dst);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_pack_upconv_weight_bf16(const float* w_oihw, int N, int C, bf16_t* dst, void* stream) {
+    NBP_ENTER();
+    return nbp_pack_upconv_weight_bf16_launch(w_oihw, N, C, dst, (hipStream_t)stream);
 }
 
 extern "C" int nbp_pack_conv_weight_bf16(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null,

@@ -27,6 +27,7 @@ struct Table {
     bool is_up[NBP_N_CONV];
     int up_rank[NBP_N_CONV];    // 0..5 among the up_conv layers (its max |w| word is header word NBP_N_CONV + rank)
     size_t total3_bytes;
+    size_t wup16_off[NBP_N_CONV], total_up16_bytes;
     Table() {
         int i = 0;
         const int enc[5] = {64, 128, 256, 512, 1024};
@@ -77,6 +78,12 @@ struct Table {
             if (is_up[j]) off3 += ((size_t)L[j].cout * L[j].cin * 16 * 4 + 255) / 256 * 256;
         }
         total3_bytes = off3;
+        size_t offu = 0;             // bf16 handle: parity filters of the up_conv layers, after the common pack
+        for (int j = 0; j < NBP_N_CONV; ++j) {
+            wup16_off[j] = offu;
+            if (is_up[j]) offu += ((size_t)L[j].cout * L[j].cin * 16 * 2 + 255) / 256 * 256;
+        }
+        total_up16_bytes = offu;
     }
 };
 const Table& table() { static Table t; return t; }
@@ -108,6 +115,7 @@ struct nbp_weights {
     int bf16;
     const void* w3[NBP_N_CONV];     // split handle: hi/lo fp16 planes of the 3x3 layers (nbp_split.hip)
     const unsigned* wamax[NBP_N_CONV];      // ... and max |w| of each (device words, float bits)
+    const void* wup16[NBP_N_CONV];          // bf16 handle, up_conv layers: the four parity filters (null elsewhere)
     const void* w3u[NBP_N_CONV];            // up_conv layers: planes of the four parity filters (null elsewhere)
     const unsigned* wamax_u[NBP_N_CONV];
     int split;
@@ -136,7 +144,8 @@ static int pack_weights_impl(const void* const* w_host_array, const void* const*
                              nbp_weights** handle_out, bool bf16, bool split = false) {
     NBP_RETURN_IF(!w_host_array || !scale_host_array || !shift_host_array || !packed || !handle_out, NBP_E_ARG);
     const Table& T = table();
-    NBP_RETURN_IF(packed_bytes < T.total_floats * sizeof(float) + (split ? T.total3_bytes : 0), NBP_E_WS);
+    NBP_RETURN_IF(packed_bytes < T.total_floats * sizeof(float) + (split ? T.total3_bytes : 0) + (bf16 ? T.total_up16_bytes : 0),
+                  NBP_E_WS);
     for (int i = 0; i < NBP_N_CONV; ++i) {
         NBP_RETURN_IF(!w_host_array[i] || !scale_host_array[i], NBP_E_ARG);
         NBP_RETURN_IF(T.L[i].kind != K_ATT_X && !shift_host_array[i], NBP_E_ARG);
@@ -175,6 +184,10 @@ static int pack_weights_impl(const void* const* w_host_array, const void* const*
                           : nbp_pack_conv_weight(w, s.cout, s.cin, 3, nullptr, 0, s.cin, wd, st);
                 if (!rc) rc = copy_f32(sc, sd, s.cout, st);
                 if (!rc) rc = copy_f32(sh, td, s.cout, st);
+                if (!rc && bf16 && T.is_up[i]) {
+                    h->wup16[i] = base3 + T.wup16_off[i];
+                    rc = nbp_pack_upconv_weight_bf16_launch(w, s.cout, s.cin, (bf16_t*)(base3 + T.wup16_off[i]), st);
+                }
                 if (!rc && split) {
                     h->w3[i] = base3 + T.w3_off[i];
                     h->wamax[i] = (const unsigned*)base3 + i;
@@ -240,6 +253,8 @@ extern "C" int nbp_pack_weights_split(const void* const* w_host_array, const voi
     return pack_weights_impl(w_host_array, scale_host_array, shift_host_array, packed, packed_bytes, stream, handle_out,
                              false, true);
 }
+
+extern "C" size_t nbp_packed_weights_bytes_bf16(void) { return table().total_floats * sizeof(float) + table().total_up16_bytes; }
 
 extern "C" void nbp_free_weights(nbp_weights* handle) { free(handle); }
 
@@ -403,13 +418,15 @@ struct PathBF16 {
     typedef NoCtx Ctx;
     static constexpr int CHUNK = 64;
     static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0, int ups = 0) {
-        (void)ups;
-        return nbp_plan_conv_bf16(M, N, chunks, 0, 0, groups, H, H, ksize);
+        return nbp_plan_conv_bf16(M, N, chunks, 0, 0, groups, H, H, ksize, ups);
     }
     static constexpr int MODE = 1;
-    static int conv(Ctx&, const nbp_weights*, const int*, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H, int ks,
-                    int N, void* ws, size_t wsb, hipStream_t st) {
-        return nbp_conv_igemm_bf16_launch_g(o, o2, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st);
+    static int conv(Ctx&, const nbp_weights* h, const int* li, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H,
+                    int ks, int N, void* ws, size_t wsb, hipStream_t st) {
+        Ops a = o, b = o2 ? *o2 : o;
+        a.wpk_up = (const bf16_t*)h->wup16[li[0]];
+        if (o2) b.wpk_up = (const bf16_t*)h->wup16[li[1]];
+        return nbp_conv_igemm_bf16_launch_g(a, o2 ? &b : nullptr, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st);
     }
     static int first(Ctx&, const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {
         return nbp_conv_first_bf16_launch(x, B, s, s, (const float*)h->w[0], h->scale[0], h->shift[0], out, st);

@@ -69,7 +69,7 @@ class PackedWeights:
 
 
 PRECISIONS = ("fp32", "fp32_split", "bf16")
-_PACK = {"fp32": ("nbp_pack_weights", "nbp_packed_weights_bytes"), "bf16": ("nbp_pack_weights_bf16", "nbp_packed_weights_bytes"),
+_PACK = {"fp32": ("nbp_pack_weights", "nbp_packed_weights_bytes"), "bf16": ("nbp_pack_weights_bf16", "nbp_packed_weights_bytes_bf16"),
          "fp32_split": ("nbp_pack_weights_split", "nbp_packed_weights_bytes_split")}
 _FWD = {"fp32": ("nbp_forward_f32", "nbp_forward_workspace_bytes"), "bf16": ("nbp_forward_bf16", "nbp_forward_workspace_bytes_bf16"),
         "fp32_split": ("nbp_forward_split_f32", "nbp_forward_workspace_bytes_split")}

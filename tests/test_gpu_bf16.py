@@ -96,6 +96,47 @@ def test_halo_kernel_is_bit_identical_to_implicit_gemm(hip, tile):
     assert torch.equal(a, b)
 
 
+# (B, Hs, Ws, C, N, split_k, tile): low-resolution input size; tile 12 = 128-channel blocks, 13 = 64-channel blocks
+UP_CASES = [(1, 8, 32, 64, 64, 1, 13), (2, 16, 64, 128, 128, 1, 12), (1, 8, 32, 256, 64, 2, 13), (2, 8, 32, 512, 256, 0, 12)]
+
+
+@pytest.mark.parametrize("case", UP_CASES)
+def test_upconv_parity_kernels_bf16_vs_exact(hip, case):
+    """up_conv (x2 nearest upsample + 3x3) as four 2x2 parity convolutions of the low-resolution input with pre-summed weights:
+    against the exact sum of the same bf16 operands (the bf16-rounded pre-summed filters), one-ulp bound as for the other layers;
+    and within bf16 noise of the reference formulation (F.interpolate + conv2d on bf16-rounded 3x3 weights)."""
+    B, Hs, Ws, C, N, split_k, tile = case
+    dev = "cuda"
+    x = rbf(_rand(B, C, Hs, Ws, seed=31))
+    w = _rand(N, C, 3, 3, seed=32, scale=(6.0 / (C * 9)) ** 0.5)
+    scale = _rand(N, seed=33) * 0.2 + 1.0
+    shift = _rand(N, seed=34) * 0.1
+    # exact reference of what the kernel is asked to compute
+    R = {(0, 0): [0], (0, 1): [1, 2], (1, 0): [0, 1], (1, 1): [2]}
+    acc = torch.zeros(B, N, 2 * Hs, 2 * Ws, dtype=torch.float64)
+    xp = F.pad(x.double(), (1, 1, 1, 1))
+    for py in range(2):
+        for px in range(2):
+            wc = torch.zeros(N, C, 2, 2, dtype=torch.float64)
+            for r in range(2):
+                for t in range(2):
+                    wc[:, :, r, t] = sum(w[:, :, y, xx].double() for y in R[(py, r)] for xx in R[(px, t)])
+            full = F.conv2d(xp, rbf(wc.float()).double())                    # [B, N, Hs + 1, Ws + 1]
+            acc[:, :, py::2, px::2] = full[:, :, py:py + Hs, px:px + Ws]
+    ref = F.relu(acc.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    planes = torch.zeros(4 * (C // 64) * 4 * N * 64, dtype=torch.bfloat16, device=dev)
+    _lib.check(hip.nbp_pack_upconv_weight_bf16(_lib.ptr(w.to(dev).contiguous()), N, C, _lib.ptr(planes), stream()), "pack_upconv_bf16")
+    out = conv_igemm_bf16(nhwc(x).to(dev).to(torch.bfloat16), None, 1, planes, N, 3, scale.to(dev), shift.to(dev), True, split_k, tile)
+    torch.cuda.synchronize()
+    got = nchw(out.float()).cpu()
+    err = (got - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -7 + 1e-3).all()), f"max err {err.max().item()}"
+    assert (got == rbf(ref)).float().mean().item() > 0.97
+    direct = F.relu(F.conv2d(F.interpolate(x.double(), scale_factor=2), rbf(w).double(), None, padding=1).float() * scale.view(1, -1, 1, 1)
+                    + shift.view(1, -1, 1, 1))
+    assert float((got - direct).abs().max()) < 3e-2 * max(1.0, float(direct.abs().max()))
+
+
 def test_halo_kernel_shape_errors(hip):
     dev = "cuda"
     x = torch.zeros(1, 12, 32, 64, device=dev, dtype=torch.bfloat16)     # H % 8 != 0
