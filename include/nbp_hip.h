@@ -119,8 +119,9 @@ int nbp_forward_timed_bf16(const nbp_weights* handle, const float* x, int B, int
  * Tensors, accumulation and epilogues are fp32 exactly as in nbp_forward_f32; inside the 3x3 kernels every fp32 operand is
  * scaled by a power of two taken from its tensor's max |x| and cut into two fp16 pieces (hi + lo = s x up to 2^-23), and
  * the product is evaluated as three exact fp16 MFMAs (the dropped lo x lo is < 2^-22 of the product): error against fp64
- * not above the fp32 MFMA chain's at 5.3x its matrix rate.  Layers the split kernel does not take
- * (1x1 convolutions, images that are not multiples of 16 x 32 / 16 x 16 pixels) run nbp_forward_f32's kernels.  The handle
+ * not above the fp32 MFMA chain's at 5.3x its matrix rate; up_conv layers run as four 2x2 parity
+ * convolutions of the low-resolution input, the attention gates' joint 1x1 GEMM on the same split scheme.  Layers the split
+ * kernels do not take (images that are not multiples of 16 x 32 / 16 x 16 pixels, psi, the heads) run nbp_forward_f32's kernels.  The handle
  * of nbp_pack_weights_split (`packed` of nbp_packed_weights_bytes_split()) also serves nbp_forward_f32. */
 size_t nbp_packed_weights_bytes_split(void);
 int nbp_pack_weights_split(const void* const* w_host_array, const void* const* scale_host_array,

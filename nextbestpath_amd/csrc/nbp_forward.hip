@@ -28,6 +28,8 @@ struct Table {
     int up_rank[NBP_N_CONV];    // 0..5 among the up_conv layers (its max |w| word is header word NBP_N_CONV + rank)
     size_t total3_bytes;
     size_t wup16_off[NBP_N_CONV], total_up16_bytes;
+    size_t w1_off[NBP_N_CONV];  // split region: planes of the attention gates' joint 1x1 GEMM (K_ATT_G layers)
+    int gate_rank[NBP_N_CONV];  // its max |w| word: header word NBP_N_CONV + 6 + rank
     Table() {
         int i = 0;
         const int enc[5] = {64, 128, 256, 512, 1024};
@@ -77,6 +79,11 @@ struct Table {
             w3u_off[j] = off3;
             if (is_up[j]) off3 += ((size_t)L[j].cout * L[j].cin * 16 * 4 + 255) / 256 * 256;
         }
+        int n_gate = 0;
+        for (int j = 0; j < NBP_N_CONV; ++j) {
+            w1_off[j] = off3; gate_rank[j] = -1;
+            if (L[j].kind == K_ATT_G) { gate_rank[j] = n_gate++; off3 += ((size_t)L[j].cout * L[j].cin * 2 * 4 + 255) / 256 * 256; }
+        }
         total3_bytes = off3;
         size_t offu = 0;             // bf16 handle: parity filters of the up_conv layers, after the common pack
         for (int j = 0; j < NBP_N_CONV; ++j) {
@@ -116,6 +123,8 @@ struct nbp_weights {
     const void* w3[NBP_N_CONV];     // split handle: hi/lo fp16 planes of the 3x3 layers (nbp_split.hip)
     const unsigned* wamax[NBP_N_CONV];      // ... and max |w| of each (device words, float bits)
     const void* wup16[NBP_N_CONV];          // bf16 handle, up_conv layers: the four parity filters (null elsewhere)
+    const void* w1[NBP_N_CONV];             // split handle, attention gates: planes of the joint 1x1 GEMM (null elsewhere)
+    const unsigned* wamax1[NBP_N_CONV];
     const void* w3u[NBP_N_CONV];            // up_conv layers: planes of the four parity filters (null elsewhere)
     const unsigned* wamax_u[NBP_N_CONV];
     int split;
@@ -214,6 +223,12 @@ static int pack_weights_impl(const void* const* w_host_array, const void* const*
                 }
                 if (!rc) rc = fill_f32(sd, 1.0f, s.cout, st);
                 if (!rc) rc = copy_f32(sh, td, s.cout, st);
+                if (!rc && split) {
+                    h->w1[i] = base3 + T.w1_off[i];
+                    h->wamax1[i] = (const unsigned*)base3 + NBP_N_CONV + 6 + T.gate_rank[i];
+                    rc = nbp_pack_gate_weight_split_launch(w, sc, wx, scx, s.cout, s.cin, base3 + T.w1_off[i],
+                                                           (unsigned*)base3 + NBP_N_CONV + 6 + T.gate_rank[i], st);
+                }
                 break;
             }
             case K_ATT_X:
@@ -380,6 +395,21 @@ struct PathSplit : PathF32 {
     }
     static int conv(Ctx& ctx, const nbp_weights* h, const int* li, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B,
                     int H, int ks, int N, void* ws, size_t wsb, hipStream_t st) {
+        static const int allow_gate = [] { const char* e = getenv("NBP_SPLIT_GATE"); return e ? atoi(e) : 1; }();
+        if (allow_gate && ks == 1 && C1 == C0 && C0 % 64 == 0 && !ups && h->w1[li[0]] && (!o2 || h->w1[li[1]])) {
+            // attention gate: relu([g | x] W + b) as one 1x1 GEMM on the split scheme
+            const long long M = (long long)B * H * H;
+            ConvOperandsSplit s[2];
+            for (int g = 0; g < (o2 ? 2 : 1); ++g) {
+                const Ops& q = g ? *o2 : o;
+                s[g] = ConvOperandsSplit{q.src0, q.src1, h->w1[li[g]], q.scale, q.shift, q.out, nullptr, nullptr, h->wamax1[li[g]], nullptr,
+                                         nullptr, nullptr};
+                int rc = ctx.ensure(q.src0, M * C0, &s[g].amax0);
+                if (!rc) rc = ctx.ensure(q.src1, M * C1, &s[g].amax1);
+                if (rc) return rc;
+            }
+            return nbp_gate1x1_split_launch_g(s[0], o2 ? &s[1] : nullptr, C0, M, N, 1, st);
+        }
         const ConvPlan p = nbp_plan_conv_split((long long)B * H * H, N, (C0 + C1) / 32 * ks * ks, 0, o2 ? 2 : 1, H, H, ks, ups);
         if (!p.tile) return PathF32::conv(ctx, h, li, o, o2, C0, C1, ups, B, H, ks, N, ws, wsb, st);
         const long long hw = (long long)B * (ups ? H / 2 : H) * (ups ? H / 2 : H);

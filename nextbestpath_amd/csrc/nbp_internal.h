@@ -69,6 +69,11 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
 int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
                                       int c_total, void* dst, unsigned* wamax_out, hipStream_t st);
 int nbp_amax_launch(const float* x, long long n, unsigned* amax_inout, hipStream_t st);
+// attention gates (1x1 over K = [src0 | src1], both C channels) on the split scheme
+int nbp_pack_gate_weight_split_launch(const float* wg, const float* scale_g, const float* wx, const float* scale_x, int N, int C,
+                                      void* dst, unsigned* wamax_out, hipStream_t st);
+int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C, long long M, int N, int relu,
+                               hipStream_t st);
 int nbp_conv_first_amax_launch(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale, const float* shift,
                                float* out_nhwc, unsigned* amax_out, int* did_amax, hipStream_t st);
 

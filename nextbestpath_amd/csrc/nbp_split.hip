@@ -322,6 +322,131 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (final_out && o.amax_out) wave_amax(mx, o.amax_out);
 }
 
+// ------------------------------------------------------------------ 1x1 convolution over K = [src0 | src1] (the attention gates)
+// q = relu([g | x] W + b), next_best_path/networks/nbp_model.py:44-53 (W_g and W_x as one GEMM, BN scales folded into W).
+// These layers are HBM-bound (K = 2 co is small), so the activations are NOT staged in LDS: a workgroup owns 128 pixels x BN
+// (<= 128) channels, a wave 32 pixels x BN; each lane loads the 8 + 8 channels of its pixel for the two K steps of a 32-channel
+// stage straight from global memory (the two k halves of a pixel are adjacent lanes' 32-byte pieces: whole 128-B lines),
+// scales and splits them in registers, and the weights of the stage ([k step][hi|lo][k half][BN rows][8 fp16]) stream through a
+// double buffer in LDS by DMA.  Three exact fp16 MFMAs per product as in the 3x3 kernel.
+struct GateArgs {
+    SplitOps g[2];
+    int C, N, relu;             // channels of EACH source; output channels (N % 32 == 0)
+    long long M;
+    unsigned bytes0, bytesw;
+    int groups;
+};
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
+    const SplitOps& o = a.g[blockIdx.z];
+    constexpr int BN = TN * 32;
+    constexpr int WST = 8 * BN * 16;                           // bytes of one weight stage: 2 k steps x 2 planes x 2 k halves x BN rows
+    constexpr int WI = WST / 1024;                             // DMA instructions per stage (64 rows x 16 B each)
+    extern __shared__ __attribute__((aligned(16))) char wbuf[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long m = (long long)blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int n0 = blockIdx.y * BN, khalf = lane >> 5;
+    const unsigned ma0 = read_amax(o.amax0), ma1 = read_amax(o.amax1);
+    const int ea = amax_exponent(ma0 > ma1 ? ma0 : ma1), ew = amax_exponent(*o.wamax);
+    const float sa = pow2f(12 - ea);
+    const int einv = ea + ew - 24;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.src0), 0, a.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.src1), 0, a.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(o.planes), 0, a.bytesw, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int stages0 = a.C >> 5, stages = stages0 * 2;        // 32-channel stages: source 0 then source 1
+    const unsigned prow = m < a.M ? (unsigned)(m * a.C) * 4u : OOB;
+
+    // The pixel's channels are prefetched three stages ahead (a ring of four register sets): a stage is only ~0.3 us of MFMAs,
+    // a load from HBM 1-2 us.  The weights (L2-resident, shared by every workgroup) are DMA'd one stage ahead.
+    constexpr int D = 4;
+    u32x4 xr[D][2][2];                                         // [ring slot][k step][16-byte piece]
+    auto load_x = [&](int st, int slot) {
+        const bool first = st < stages0;
+        const unsigned cb = (unsigned)((first ? st : st - stages0) * 32 + khalf * 8) * 4u;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned off = (prow == OOB || st >= stages) ? OOB : prow + cb + ks * 64 + h * 16;
+                xr[slot][ks][h] = first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0);
+            }
+    };
+    // weight stage st: planes [chunk of 16 = 2 st + ks][1 tap][plane][k half][N][8]; LDS image [ks][plane][k half][BN rows][16 B]
+    auto issue_w = [&](int st) {
+        char* dst = wbuf + (st & 1) * WST;
+#pragma unroll
+        for (int k = 0; k < (WI + 3) / 4; ++k) {
+            const int q = wave + 4 * k;
+            if (q < WI) {
+                constexpr int PER = BN / 64 > 0 ? BN / 64 : 1;  // 64-row blocks per (ks, plane, kh)
+                const int r8 = BN >= 64 ? q / PER : q * 2 + (lane >> 5), nb = BN >= 64 ? q - (q / PER) * PER : 0;
+                const int row = BN >= 64 ? nb * 64 + lane : (lane & 31);
+                const int ks = r8 >> 2, r4 = r8 & 3;
+                const unsigned woff = (unsigned)((((long long)(2 * st + ks) * 4 + r4) * a.N + n0 + row) * 16);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + q * 1024), 16, woff, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    issue_w(0);
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) load_x(d, d);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int base = 0; base < stages; base += D) {            // stages % 4 == 0 (launcher: C % 64 == 0)
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int st = base + u;
+            if (st + 1 < stages) issue_w(st + 1);
+            load_x(st + D - 1, (u + D - 1) % D);               // past the end: out-of-range offsets (zeros), never used
+            const char* Bt = wbuf + (st & 1) * WST + khalf * (BN * 16) + (lane & 31) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f32x4 v0 = __builtin_bit_cast(f32x4, xr[u][ks][0]), v1 = __builtin_bit_cast(f32x4, xr[u][ks][1]);
+                unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+                split_pair(v0[0] * sa, v0[1] * sa, h0, l0); split_pair(v0[2] * sa, v0[3] * sa, h1, l1);
+                split_pair(v1[0] * sa, v1[1] * sa, h2, l2); split_pair(v1[2] * sa, v1[3] * sa, h3, l3);
+                const u32x4 xh = u32x4{h0, h1, h2, h3}, xl = u32x4{l0, l1, l2, l3};
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const u32x4 wh = *reinterpret_cast<const u32x4*>(Bt + ((ks * 2 + 0) * 2) * (BN * 16) + j * 512);
+                    const u32x4 wl = *reinterpret_cast<const u32x4*>(Bt + ((ks * 2 + 1) * 2) * (BN * 16) + j * 512);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xl), __builtin_bit_cast(f16x8, wh), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xh), __builtin_bit_cast(f16x8, wl), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xh), __builtin_bit_cast(f16x8, wh), acc[j], 0, 0, 0);
+                }
+            }
+            // the next stage's weights have landed once everything but the four pixel loads issued after them is back
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    // D[pixel][n]: col n = lane & 31, pixel = (r & 3) + 8 (r >> 2) + 4 khalf of the wave's 32
+    const long long mw = (long long)blockIdx.x * 128 + wave * 32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32 + (lane & 31);
+        const float sc = o.scale[n], sh = o.shift[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long mm = mw + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (mm < a.M) {
+                float v = ldexpf(acc[j][r], einv) * sc + sh;
+                if (a.relu) v = fmaxf(v, 0.f);
+                o.out[mm * a.N + n] = v;
+            }
+        }
+    }
+}
+
 // Grid-stride over float4s of the output, two positions per thread and iteration, the slices' loads of both issued together
 // (four slices at a time) and added in slice order -- a serial load-add chain costs one memory round trip per slice, and
 // one float4 per thread is bound by the wave launch rate (measured: 31 us serial / 56 us one-per-thread / see DESIGN.md).
@@ -625,6 +750,48 @@ int nbp_pack_upconv_weight_split_launch(const float* w_oihw, int N, int C, void*
     const long long NC = (long long)N * C;
     pack_upconv_h2_kernel<<<min(nbp_ew_grid(NC, 256), 256), 256, 0, st>>>(w_oihw, N, C, wamax_out, nullptr);
     pack_upconv_h2_kernel<<<nbp_ew_grid(NC, 256), 256, 0, st>>>(w_oihw, N, C, wamax_out, (unsigned short*)dst);
+    return nbp_launch_status();
+}
+
+// ---- attention gates: q = relu([g | x] W + b) as one 1x1 GEMM over K = 2 C on the split scheme
+int nbp_pack_gate_weight_split_launch(const float* wg, const float* scale_g, const float* wx, const float* scale_x, int N, int C,
+                                      void* dst, unsigned* wamax_out, hipStream_t st) {
+    NBP_RETURN_IF(!wg || !wx || !dst || !wamax_out, NBP_E_ARG);
+    NBP_RETURN_IF(N < 32 || N % 32 || C < 32 || C % 32, NBP_E_SHAPE);
+    hipError_t e = hipMemsetAsync(wamax_out, 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return (int)e;
+    const long long total = (long long)N * C;
+    const int grid = min(nbp_ew_grid(total, 256), 256);
+    amax_kernel<<<grid, 256, 0, st>>>(wg, total, scale_g, C, wamax_out, 1u);
+    amax_kernel<<<grid, 256, 0, st>>>(wx, total, scale_x, C, wamax_out, 1u);
+    pack_conv_weight_h2_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(wg, N, C, 1, scale_g, 0, wamax_out, (unsigned short*)dst);
+    pack_conv_weight_h2_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(wx, N, C, 1, scale_x, C, wamax_out, (unsigned short*)dst);
+    return nbp_launch_status();
+}
+
+// planes: nbp_pack_gate_weight_split_launch; amax0 / amax1: the 64-word slots of the two sources; out [M][N] fp32
+int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C, long long M, int N, int relu,
+                               hipStream_t st) {
+    const int groups = o2 ? 2 : 1;
+    NBP_RETURN_IF(!o.src0 || !o.src1 || !o.planes || !o.scale || !o.shift || !o.out || !o.amax0 || !o.amax1 || !o.wamax, NBP_E_ARG);
+    NBP_RETURN_IF(o2 && (!o2->src0 || !o2->src1 || !o2->planes || !o2->out || !o2->amax0 || !o2->amax1 || !o2->wamax), NBP_E_ARG);
+    NBP_RETURN_IF(C < 64 || C % 64 || N < 32 || N % 32 || M < 1, NBP_E_SHAPE);
+    const long long b0 = M * C * 4, bw = 2ll * C * N * 4;
+    NBP_RETURN_IF(b0 >= (1ll << 31) || bw >= (1ll << 31), NBP_E_SHAPE);
+    GateArgs a;
+    for (int g = 0; g < 2; ++g) {
+        const ConvOperandsSplit& s = (g && o2) ? *o2 : o;
+        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, s.amax1, s.wamax, nullptr};
+    }
+    a.C = C; a.N = N; a.relu = relu; a.M = M; a.bytes0 = (unsigned)b0; a.bytesw = (unsigned)bw; a.groups = groups;
+    // 128-channel blocks only when they alone fill the chip twice; otherwise more, narrower workgroups
+    int bn = N % 128 == 0 ? 128 : (N % 64 == 0 ? 64 : 32);
+    if (bn == 128 && nbp_cdiv(M, 128) * (N / 128) * groups < 512) bn = 64;
+    dim3 grid((unsigned)nbp_cdiv(M, 128), (unsigned)(N / bn), (unsigned)groups);
+    const size_t smem = 2 * (size_t)8 * bn * 16;
+    if (bn == 128) gate1x1_h2_kernel<4><<<grid, 256, smem, st>>>(a);
+    else if (bn == 64) gate1x1_h2_kernel<2><<<grid, 256, smem, st>>>(a);
+    else gate1x1_h2_kernel<1><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 
