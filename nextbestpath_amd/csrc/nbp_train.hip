@@ -622,7 +622,7 @@ struct WgradHaloArgs {
 typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
 
 __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(WgradHaloArgs a) {
-    constexpr int HW_ = 34, XROWS = 136, XBYTES = 144 * 256;     // 4 x 34 halo pixels x 64 floats (36 DMA slots of 4 rows)
+    constexpr int HW_ = 34, XBYTES = 144 * 256;     // 4 x 34 halo pixels x 64 floats (36 DMA slots of 4 rows)
     extern __shared__ __attribute__((aligned(16))) char wlds[];
     char* const xs = wlds;
     char* const ys = wlds + XBYTES;                               // 64 pixels x 64 floats
