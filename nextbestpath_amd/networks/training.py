@@ -115,6 +115,30 @@ def _conv_split(src0, src1, ups, packed, N, scale, shift, relu):
     return out
 
 
+def _upconv_ok(Hs, Ws, N):
+    """up_conv layers (x2 nearest upsample + 3x3): four 2x2 parity convolutions of the low-resolution input when it tiles."""
+    return _SPLIT and Hs % 16 == 0 and ((Ws % 32 == 0 and N % 64 == 0) or (Ws % 16 == 0 and N % 128 == 0))
+
+
+def _upconv_split(src, w_oihw, n_pad, scale, shift):
+    L = _lib.lib()
+    N, C, _, _ = w_oihw.shape
+    B, Hs, Ws, C0 = src.shape
+    if N != n_pad or C != C0:       # zero rows / channels up to the padded counts
+        wp = torch.zeros(n_pad, C0, 3, 3, dtype=torch.float32, device=w_oihw.device)
+        wp[:N, :C] = w_oihw
+        w_oihw = wp
+    planes = torch.empty(4 * (C0 // 16) * 4 * 4 * n_pad * 8, dtype=torch.int16, device=src.device)
+    wamax = torch.zeros(1, dtype=torch.int32, device=src.device)
+    _chk(L.nbp_pack_upconv_weight_split(_lib.ptr(w_oihw), n_pad, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_upconv")
+    H, W = 2 * Hs, 2 * Ws
+    out = torch.empty(B, H, W, n_pad, dtype=torch.float32, device=src.device)
+    ws = _ws(L.nbp_conv_split_workspace_bytes(B, H, W, n_pad, 0), src.device)
+    _chk(L.nbp_upconv3x3_split_f32(_lib.ptr(src), C0, B, H, W, _lib.ptr(planes), _lib.ptr(wamax), n_pad, _lib.ptr(scale),
+                                   _lib.ptr(shift), 0, _lib.ptr(out), None, None, 0, _lib.ptr(ws), ws.numel(), _st()), "upconv3x3_split")
+    return out
+
+
 class ConvFn(torch.autograd.Function):
     """y = conv_k(cat(x0, x1) [x2 nearest-upsampled]) + bias; weight OIHW [N, c_real, k, k].
     x0 / x1 channel counts are multiples of 64 (c_real < C0 only for the zero-padded network input)."""
@@ -132,7 +156,9 @@ class ConvFn(torch.autograd.Function):
         shift = torch.zeros(Np, dtype=torch.float32, device=dev)
         shift[:N] = bias.detach()
         H, W = (x0.shape[1] * 2, x0.shape[2] * 2) if ups else (x0.shape[1], x0.shape[2])
-        if _split_ok(H, W, Np, k):
+        if ups and k == 3 and x1 is None and _upconv_ok(x0.shape[1], x0.shape[2], Np):
+            y = _upconv_split(x0, w, Np, scale, shift)
+        elif _split_ok(H, W, Np, k):
             y = _conv_split(x0, x1, ups, _pack_split(w, Np, Ctot), Np, scale, shift, False)
         else:
             wpk = torch.empty(Ctot // 32 * k * k * Np * 32, dtype=torch.float32, device=dev)
