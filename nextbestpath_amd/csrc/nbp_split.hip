@@ -253,6 +253,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    __builtin_amdgcn_s_setprio(2);
     for (int c = c_begin; c < c_end; ++c) {
         const bool more = c + 1 < c_end;
         if (more) load_halo(c + 1);
@@ -290,8 +291,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             __syncthreads();
         }
         if (more) {                     // every wave is past its last read of this chunk's planes
+            __builtin_amdgcn_s_setprio(0);      // the staging pass yields issue slots to the co-resident workgroup's MFMAs (1 %)
             store_halo();
             __syncthreads();
+            __builtin_amdgcn_s_setprio(2);
         }
     }
 
