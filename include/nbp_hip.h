@@ -397,6 +397,29 @@ int nbp_score_candidates_f32(const float* pos3, int P, float cx, float cz, const
 int nbp_edges_blocked_u8(const float* obst, int S, float lo, float hi, float cx, float cz,
                          const float* pos3, const int* edges2, int E, unsigned char* blocked,
                          void* stream);
+/* HOST function (no kernel, no stream): the candidate loop of nbp_planning.py:233-249 around
+ * generate_Dijkstra_path (long_term_utils.py:334-418) on the position lattice, after the three kernels above
+ * and their device->host copies.  Nodes 0..P-1 in lexicographic (i,j,k) order (idx3 [P,3], pos3 [P,3] world
+ * positions); directed edges edges2 [E,2] grouped by source node in the reference's neighbour order
+ * (+x,-x,+z,-z), edge_first [P+1] = first edge of each node.  An edge is usable iff pass_mask[q] or (not
+ * blocked[q] and not coll_mask[q]) (ref :350-360); the search tree is the reference's uniform-cost tree (heap
+ * ordered by (cost, tuple), came_from fixed at first discovery).  Candidates cand[] are tried in order (already
+ * sorted by the caller: stable, score descending): path to the candidate, per node the best-valued heading of
+ * out1 [8,V,V] at the node's value cell (cell = rint((-(p - c) - lo) * sc) in fp32) that hist5 [n_hist,5] does
+ * not hold yet (ref :390-413), first node dropped (ref :416); when check_first_edge and the first edge crosses
+ * the mesh (mesh_hit [E]) the pair is reported in new_coll2 (node ids a,b; the caller appends [a,b] and [b,a] to
+ * its collision list) and the next candidate is tried on the rebuilt tree.  Outputs: *path_len = number of nodes
+ * written to path_nodes / path_heads (0 = candidate is the start node; -1 = "None": the last candidate tried
+ * was unreachable, or there was none); *goal = accepted candidate or -1.  *path_len = -2: a path node lies
+ * outside the value map, where the reference draws a random heading -- the caller runs its own (Python) form of
+ * this function so that the draw comes from the rollout's random stream; nothing was modified. */
+int nbp_plan_search_host(int P, const int* idx3, const float* pos3, int E, const int* edges2,
+                         const int* edge_first, const unsigned char* mesh_hit, const unsigned char* blocked,
+                         const unsigned char* coll_mask, const unsigned char* pass_mask, const int* cand,
+                         int n_cand, int start_id, float cx, float cz, const float* out1, int V, float lo,
+                         float sc, const int* hist5, int n_hist, int check_first_edge, int max_path,
+                         int* path_nodes, int* path_heads, int* path_len, int* goal, int* new_coll2,
+                         int max_new_coll, int* n_new_coll);
 /* calculate_coverage_percentage (long_term_utils.py:437-468): *count_out = #{g : min_j |gt_g - s_j|
  * < threshold} where s = the cloud, or a seeded random subset of sample_k points of it when it
  * has more (random_sample_pc, :437-447); *m_out = number of points used.  bbox_* = bounds of gt. */

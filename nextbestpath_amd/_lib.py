@@ -71,6 +71,8 @@ SIGNATURES = {
     "nbp_fuse_obstacle_f32": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "nbp_score_candidates_f32": (_i, [_vp, _i, _f, _f, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "nbp_edges_blocked_u8": (_i, [_vp, _i, _f, _f, _f, _f, _vp, _vp, _i, _vp, _vp]),
+    "nbp_plan_search_host": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _i, _f, _f,
+                                  _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "nbp_coverage_workspace_bytes": (_sz, [C.POINTER(_f), C.POINTER(_f), _f, _ll]),
     "nbp_coverage_count_f32": (_i, [_vp, _i, _vp, _ll, _vp, _ll, C.c_uint, _f, C.POINTER(_f), C.POINTER(_f), _vp, _vp,
                                     _vp, _sz, _vp]),

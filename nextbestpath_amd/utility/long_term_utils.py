@@ -3,11 +3,14 @@ function names and argument meaning; the per-pixel / per-edge Python loops of th
 replaced by one kernel launch each (csrc/nbp_planner.hip, csrc/nbp_sim.hip)."""
 from __future__ import annotations
 
+import ctypes as C
+import os
 import random
 
 import numpy as np
 import torch
 
+from .. import _lib
 from . import hipops, planner_host
 from .utils import _pose_xyz
 
@@ -99,6 +102,24 @@ class LatticePlanner:
         self.edges_dev = torch.tensor(edges, dtype=torch.int32, device=device)
         segs = np.concatenate([self.xyz[[a for a, _ in edges]], self.xyz[[b for _, b in edges]]], 1).astype(np.float32)
         self.mesh_hit = hipops.segments_hit_mesh(mesh.verts, mesh.faces, torch.from_numpy(segs).to(device)).cpu().numpy()
+        # host search in C++ (nbp_plan_search_host): the graph as flat int32 arrays, the two edge lists of the rollout as
+        # masks that follow the (append-only) Python lists incrementally
+        P, E = len(self.idx3), len(edges)
+        self.idx3_list = [tuple(t) for t in self.idx3.tolist()]
+        self._idx3_i32 = np.ascontiguousarray(self.idx3, np.int32)
+        self._xyz_f32 = np.ascontiguousarray(self.xyz, np.float32)
+        self._edges_i32 = np.asarray(edges, np.int32).reshape(-1, 2)
+        self._edge_first = np.zeros(P + 1, np.int32)
+        np.cumsum(np.bincount(self._edges_i32[:, 0], minlength=P), out=self._edge_first[1:])
+        self._mesh_hit_u8 = np.ascontiguousarray(self.mesh_hit, np.uint8)
+        self._coll_mask, self._pass_mask = np.zeros(E, np.uint8), np.zeros(E, np.uint8)
+        self._coll_src, self._coll_n, self._pass_src, self._pass_n = None, 0, None, 0
+        self._skip_pin, self._skip_any = None, False
+        self._hist = np.zeros((256, 5), np.int32)
+        self._hist_n = 0
+        self._path_nodes, self._path_heads = np.zeros(P + 1, np.int32), np.zeros(P + 1, np.int32)
+        self._new_coll = np.zeros(2 * (P + 1), np.int32)        # at most one failed first edge per candidate
+        self.native_search = os.environ.get("NBP_PLAN_SEARCH", "native") != "python"
 
     def _staging(self, *tensors):
         if getattr(self, "_stg", None) is None:
@@ -119,17 +140,65 @@ class LatticePlanner:
                 ok[q] = True
         return ok
 
+    def _edge_q(self, a, b):
+        return self.edge_id.get((self.node_index.get(tuple(a), -1), self.node_index.get(tuple(b), -1)))
+
+    def _sync_collisions(self, collision_list):
+        """Brings the collision edge mask and the skipped-goal mask up to date with the rollout's list (entries of two
+        positions are edges, entries of three numbers are goal positions that led into a collision: nbp_planning.py:147-149)."""
+        if self._skip_pin is None:
+            self._skip_pin = torch.zeros(len(self.idx3), dtype=torch.uint8).pin_memory()
+            self._skip_np = self._skip_pin.numpy()
+        if self._coll_src is not collision_list or self._coll_n > len(collision_list):
+            self._coll_mask[:] = 0
+            self._skip_np[:] = 0
+            self._coll_src, self._coll_n, self._skip_any = collision_list, 0, False
+        for e in collision_list[self._coll_n:]:
+            if len(e) == 2:
+                q = self._edge_q(e[0], e[1])
+                if q is not None:
+                    self._coll_mask[q] = 1
+            elif len(e) == 3:
+                n = self.node_index.get(tuple(e))
+                self._skip_any = True              # the reference's set is non-empty even for a position off the lattice
+                if n is not None:
+                    self._skip_np[n] = 1
+        self._coll_n = len(collision_list)
+
+    def _sync_passable(self, passable_list):
+        if self._pass_src is not passable_list or self._pass_n > len(passable_list):
+            self._pass_mask[:] = 0
+            self._pass_src, self._pass_n = passable_list, 0
+        for a, b in passable_list[self._pass_n:]:
+            q = self._edge_q(a, b)
+            if q is not None:
+                self._pass_mask[q] = 1
+        self._pass_n = len(passable_list)
+
+    def _history(self):
+        """cam_idx_history as an int32 [n,5] array, converted incrementally (the list only grows)."""
+        h = self.camera.cam_idx_history
+        n = len(h)
+        if n < self._hist_n:
+            self._hist_n = 0
+        if n > len(self._hist):
+            grown = np.zeros((2 * n, 5), np.int32)
+            grown[:self._hist_n] = self._hist[:self._hist_n]
+            self._hist = grown
+        if n > self._hist_n:
+            self._hist[self._hist_n:n] = np.asarray(h[self._hist_n:n], np.int32).reshape(-1, 5)
+            self._hist_n = n
+        return self._hist, n
+
     # ---- replanning in two halves so that several rollouts can share ONE stream synchronisation
     def replan_enqueue(self, pose, out1, out2, maps6, traj_img, collision_list):
         """Launches obstacle fusion, candidate scoring and the all-edges mask, then starts the pinned
         device->host copies.  Nothing here blocks the host."""
         obst, fullproj = hipops.fuse_obstacle(out2.reshape(self.S, self.S), maps6, traj_img.reshape(self.S, self.S))
-        coll_pos = {tuple(e) for e in collision_list if len(e) == 3}
-        skip = None
-        if coll_pos:
-            skip_h = np.fromiter((tuple(t) in coll_pos for t in self.idx3.tolist()), dtype=np.uint8, count=len(self.idx3))
-            self._skip_pin = torch.from_numpy(skip_h).pin_memory()
-            skip = self._skip_pin.to(self.device, non_blocking=True)
+        self._sync_collisions(collision_list)
+        # goals that led into a collision are not proposed again; the pinned mask is only written between a step's stream
+        # synchronisation and the next enqueue, never while a copy is in flight
+        skip = self._skip_pin.to(self.device, non_blocking=True) if self._skip_any else None
         o1 = out1.reshape(8, self.V, self.V)
         valid, cell, score = hipops.score_candidates(self.pos_dev, pose, o1, fullproj, skip, self.grid_range)
         blocked = hipops.edges_blocked(obst, pose, self.pos_dev, self.edges_dev, self.grid_range)
@@ -140,14 +209,52 @@ class LatticePlanner:
 
     def replan_finish(self, collision_list, passable_list, check_first_edge=True):
         """Host half (after a stream synchronisation): stable sort, search, heading choice, first-edge test."""
-        cam = self.camera
         pose, stg = self._pending
-        valid_h, score_h = stg[0].numpy().astype(bool), stg[1].numpy().copy()
+        valid_h, score_h = stg[0].numpy(), stg[1].numpy()
+        cand = np.nonzero(valid_h)[0]
+        cand = cand[np.argsort(-score_h[cand], kind="stable")]               # stable, descending (ref :233)
+        self.last_candidates, self.last_goal = cand.tolist(), None           # introspection for the parity tests
+        if self.native_search:
+            path = self._search_native(pose, stg, cand, collision_list, passable_list, check_first_edge)
+            if path is not NotImplemented:
+                return path
+        return self._search_python(pose, stg, self.last_candidates, collision_list, passable_list, check_first_edge)
+
+    def _search_native(self, pose, stg, cand, collision_list, passable_list, check_first_edge):
+        """The candidate loop in C++ (csrc/nbp_plan_host.cpp); NotImplemented when a path node lies outside the value map
+        (random heading from the rollout's Python stream: the Python form below handles that replan from the start)."""
+        self._sync_collisions(collision_list)
+        self._sync_passable(passable_list)
+        hist, n_hist = self._history()
+        cand32 = np.ascontiguousarray(cand, np.int32)
+        lo, hi = self.grid_range
+        plen, goal, n_new = C.c_int(0), C.c_int(0), C.c_int(0)
+        P, E = len(self.idx3_list), len(self._edges_i32)
+        rc = _lib.lib().nbp_plan_search_host(
+            P, self._idx3_i32.ctypes.data, self._xyz_f32.ctypes.data, E, self._edges_i32.ctypes.data,
+            self._edge_first.ctypes.data, self._mesh_hit_u8.ctypes.data, stg[2].data_ptr(), self._coll_mask.ctypes.data,
+            self._pass_mask.ctypes.data, cand32.ctypes.data, len(cand32), self.node_index[tuple(self.camera.cam_idx[:3])],
+            float(np.float32(pose[0])), float(np.float32(pose[2])), stg[3].data_ptr(), self.V, float(np.float32(lo)),
+            float(np.float32(self.V / (hi - lo))), hist.ctypes.data, n_hist, int(bool(check_first_edge)), P,
+            self._path_nodes.ctypes.data, self._path_heads.ctypes.data, C.byref(plen), C.byref(goal),
+            self._new_coll.ctypes.data, len(self._new_coll) // 2, C.byref(n_new))
+        _lib.check(rc, "nbp_plan_search_host")
+        if plen.value == -2:
+            return NotImplemented
+        for a, b in self._new_coll[:2 * n_new.value].reshape(-1, 2).tolist():
+            A, B = list(self.idx3_list[a]), list(self.idx3_list[b])
+            collision_list.append([A, B])
+            collision_list.append([B, A])
+        self.last_goal = goal.value if goal.value >= 0 else None
+        if plen.value < 0:
+            return None
+        L = plen.value
+        return [[*self.idx3_list[n], 2, h] for n, h in zip(self._path_nodes[:L].tolist(), self._path_heads[:L].tolist())]
+
+    def _search_python(self, pose, stg, cand, collision_list, passable_list, check_first_edge):
+        cam = self.camera
         blocked_h = stg[2].numpy().astype(bool)
         out1_h = stg[3].numpy().copy()
-        cand = np.nonzero(valid_h)[0]
-        cand = cand[np.argsort(-score_h[cand], kind="stable")].tolist()      # stable, descending (ref :233)
-        self.last_candidates, self.last_goal = cand, None                    # introspection for the parity tests
         start_id = self.node_index[tuple(cam.cam_idx[:3])]
         hist = np.asarray(cam.cam_idx_history, np.int64).reshape(-1, 5)
         tree, tree_version = None, -1

@@ -13,7 +13,7 @@ params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_tr
 tmp = tempfile.mkdtemp()
 net = NBP(); net.load_state_dict(make_explorer_state_dict(9)); net = net.to(dev).eval()
 ros = []
-for k in range(8):
+for k in range(int(os.environ.get("R", "8"))):
     make_maze_scene(os.path.join(tmp, f"m{k}"), seed=100 + k, cells=10, size=6.0, height=1.2, tess=0.25)
     ros.append(tp.build_rollout(params, net, sc.SceneDataset(tmp, [f"m{k}"]), (0, 0), dev, seed=8 + k))
 multi = tp.MultiRollout(ros, net, dev)
