@@ -313,6 +313,7 @@ struct FaceRec { float e1[3], e2[3], v0[3], q[3], tnum, pad[3]; };   // 64 bytes
 // thousands of faces is shared by many waves instead of being one wave's tail.
 constexpr int COARSE = 8;              // fine tiles per coarse tile side
 constexpr int SEG = 4096;              // list entries per wave
+constexpr int HITS = 1024;             // ... taken through LDS in pieces of this many
 constexpr unsigned ZBUF_EMPTY = 0x7F7F7F7Fu;   // memset pattern, 3.39e38 as a float
 
 struct BinEntry { int face; unsigned box; };   // box = tx0 | tx1 << 8 | ty0 << 16 | ty1 << 24 (fine-tile coordinates)
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restri
                                                          int ctiles_y, const int* __restrict__ ccount,
                                                          const BinEntry* __restrict__ clist, unsigned* __restrict__ zbuf_bits,
                                                          unsigned long long* __restrict__ zface) {
-    __shared__ int hits[SEG];
+    __shared__ int hits[HITS];
     __shared__ __attribute__((aligned(16))) FaceRec sh[64];
     const int fr = blockIdx.y;
     const int ntiles = tiles_x * tiles_y;
@@ -426,24 +427,6 @@ __global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restri
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const BinEntry* lst = clist + ((size_t)fr * nct + ct) * n_faces;
-    // pass 1: the faces of this segment whose fine-tile box covers the tile (entry loads are independent: the compiler keeps
-    // several in flight), compacted into LDS
-    int nh = 0;
-#pragma unroll 4
-    for (int base = s0; base < s1; base += 64) {
-        bool in = false;
-        int face = 0;
-        if (base + lane < s1) {
-            const BinEntry e = lst[base + lane];
-            face = e.face;
-            in = tx >= (int)(e.box & 255u) && tx <= (int)((e.box >> 8) & 255u) && ty >= (int)((e.box >> 16) & 255u) &&
-                 ty <= (int)(e.box >> 24);
-        }
-        const unsigned long long bal = __ballot(in);
-        if (in) hits[nh + __popcll(bal & lt)] = face;
-        nh += __popcll(bal);
-    }
-    if (nh == 0) return;
     const int col = tx * TILE + (lane & 7), row = ty * TILE + (lane >> 3);
     const int s = H < W ? H : W;
     // pixel-centre ray in view space (PyTorch3D NDC: +X left, +Y up)
@@ -454,30 +437,54 @@ __global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restri
     float zbest = 3.0e38f;
     int fbest = -1;
     const float eps = 1e-6f;
-    // pass 2: 64 face records at a time through LDS (one gather round trip per 64 faces), every lane ray-casts its pixel
-    for (int hb = 0; hb < nh; hb += 64) {
-        const int m = min(64, nh - hb);
-        __syncthreads();
-        if (lane < m) sh[lane] = rb[hits[hb + lane]];
-        __syncthreads();
-        for (int k = 0; k < m; ++k) {
-            const FaceRec& f = sh[k];
-            // p = d x e2 ; det = e1 . p ; u = (-v0 . p)/det ; v = (d . q)/det ; z = tnum/det
-            const float p0 = dy * f.e2[2] - f.e2[1];
-            const float p1 = f.e2[0] - dx * f.e2[2];
-            const float p2 = dx * f.e2[1] - dy * f.e2[0];
-            const float det = (f.e1[0] * p0 + f.e1[1] * p1) + f.e1[2] * p2;
-            if (fabsf(det) < 1e-12f) continue;
-            const float inv = 1.f / det;
-            const float u = -((f.v0[0] * p0 + f.v0[1] * p1) + f.v0[2] * p2) * inv;
-            const float vv = ((dx * f.q[0] + dy * f.q[1]) + f.q[2]) * inv;
-            const float z = f.tnum * inv;
-            // equal depths (shared edges): the lowest face id wins, whatever the order of the lists (for the colours)
-            if (u >= -eps && vv >= -eps && u + vv <= 1.f + eps && z > zclip) {
-                const int fid = hits[hb + k];
-                if (z < zbest || (z == zbest && fid < fbest)) { zbest = z; fbest = fid; }
+    // The segment goes through in pieces of HITS entries: the hit list of a piece is 4 KB of LDS instead of 16 KB for
+    // the whole segment, so 20 waves instead of 8 are resident per CU (the kernel is a chain of dependent round trips
+    // -- count, entries, records -- and lives on having many waves in flight).
+    for (int c0 = s0; c0 < s1; c0 += HITS) {
+        const int c1 = min(s1, c0 + HITS);
+        // pass 1: the faces of this piece whose fine-tile box covers the tile (entry loads are independent: the compiler
+        // keeps several in flight), compacted into LDS
+        int nh = 0;
+#pragma unroll 4
+        for (int base = c0; base < c1; base += 64) {
+            bool in = false;
+            int face = 0;
+            if (base + lane < c1) {
+                const BinEntry e = lst[base + lane];
+                face = e.face;
+                in = tx >= (int)(e.box & 255u) && tx <= (int)((e.box >> 8) & 255u) && ty >= (int)((e.box >> 16) & 255u) &&
+                     ty <= (int)(e.box >> 24);
+            }
+            const unsigned long long bal = __ballot(in);
+            if (in) hits[nh + __popcll(bal & lt)] = face;
+            nh += __popcll(bal);
+        }
+        // pass 2: 64 face records at a time through LDS (one gather round trip per 64 faces), every lane ray-casts its pixel
+        for (int hb = 0; hb < nh; hb += 64) {
+            const int m = min(64, nh - hb);
+            __syncthreads();
+            if (lane < m) sh[lane] = rb[hits[hb + lane]];
+            __syncthreads();
+            for (int k = 0; k < m; ++k) {
+                const FaceRec& f = sh[k];
+                // p = d x e2 ; det = e1 . p ; u = (-v0 . p)/det ; v = (d . q)/det ; z = tnum/det
+                const float p0 = dy * f.e2[2] - f.e2[1];
+                const float p1 = f.e2[0] - dx * f.e2[2];
+                const float p2 = dx * f.e2[1] - dy * f.e2[0];
+                const float det = (f.e1[0] * p0 + f.e1[1] * p1) + f.e1[2] * p2;
+                if (fabsf(det) < 1e-12f) continue;
+                const float inv = 1.f / det;
+                const float u = -((f.v0[0] * p0 + f.v0[1] * p1) + f.v0[2] * p2) * inv;
+                const float vv = ((dx * f.q[0] + dy * f.q[1]) + f.q[2]) * inv;
+                const float z = f.tnum * inv;
+                // equal depths (shared edges): the lowest face id wins, whatever the order of the lists (for the colours)
+                if (u >= -eps && vv >= -eps && u + vv <= 1.f + eps && z > zclip) {
+                    const int fid = hits[hb + k];
+                    if (z < zbest || (z == zbest && fid < fbest)) { zbest = z; fbest = fid; }
+                }
             }
         }
+        __syncthreads();                                        // the next piece overwrites hits[]
     }
     if (row < H && col < W && zbest < 1.0e38f) {
         const size_t pix = ((size_t)fr * H + row) * W + col;

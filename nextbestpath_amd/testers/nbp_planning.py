@@ -192,35 +192,32 @@ class MultiRollout:
         self.groups = [self.rollouts[i:i + per] for i in range(0, R, per)]
         self.net_in = [torch.zeros(len(g), 5, grid, grid, dtype=torch.float32, device=device) for g in self.groups]
         self.inflight = [False] * len(self.groups)
-        # Streams.  Default: one HIP stream per group carries the group's small kernels and its batched forward.
-        # NBP_ROLLOUT_STREAMS=1 gives every ROLLOUT its own (high-priority) stream for its ~20 small kernels per step,
-        # chained to the group's forward by events.  Measured on MI355X (8 rollouts, rocprofv3 kernel trace): the GPU is
-        # throughput-bound either way -- two B=4 forwards (11.5 ms) + the small kernels (~1.7 ms of whole-GPU time) per
-        # lock-step; the convolutions hold every CU's registers and LDS, so a small kernel that "overlaps" simply takes
-        # CUs away from them.  Per-rollout streams (8 more queues, more events) measured 525 steps/s against 605, 3 or 4
-        # groups 592 / 572, 16 rollouts per GPU 604.
+        # Streams.  One HIP stream per group carries the group's small kernels and its batched forward.
+        # NBP_ROLLOUT_STREAMS = k > 0 (A/B switch) adds k side streams per group for the rollouts' ~20 small kernels per step
+        # (rollout i on side stream i % k), chained to the forward by one event per side stream.  Measured on MI355X (16
+        # rollouts, split path): 1843-1883 steps/s without side streams, 1380-1394 with k = 1, 1772-1800 with k = 2,
+        # 1667-1683 with k = 4 -- every cross-stream event dependency costs more than the overlap returns (k = 1 adds
+        # nothing but the two dependencies per group and lock-step and loses 2.9 ms of 8.6), and the convolutions hold
+        # every CU's registers and LDS, so a small kernel that "overlaps" takes CUs away from them anyway.
         main = torch.cuda.current_stream(device)
         multi = streams and len(self.groups) >= 2
-        self.per_rollout = multi and os.environ.get("NBP_ROLLOUT_STREAMS", "0") == "1"
+        k = int(os.environ.get("NBP_ROLLOUT_STREAMS", "0")) if multi else 0
         if multi:
             self.fwd_streams = [torch.cuda.Stream(device) for _ in self.groups]
-            if self.per_rollout:
-                self.rstreams = [[torch.cuda.Stream(device, priority=int(os.environ.get('NBP_SMALL_PRIO', '-1'))) for _ in g] for g in self.groups]
-            else:
-                self.rstreams = [[self.fwd_streams[gi]] * len(g) for gi, g in enumerate(self.groups)]
-            for st in self.fwd_streams + [x for g in self.rstreams for x in g]:
+            self.side = [[torch.cuda.Stream(device) for _ in range(min(k, len(g)))] for g in self.groups]
+            for st in self.fwd_streams + [x for g in self.side for x in g]:
                 st.wait_stream(main)          # the rollouts were built on the caller's stream
         else:
             self.fwd_streams = [main for _ in self.groups]
-            self.rstreams = [[main] * len(g) for g in self.groups]
+            self.side = [[] for _ in self.groups]
         self.streams = self.fwd_streams
-        self.ev_pre = [[torch.cuda.Event() for _ in g] for g in self.groups]
-        self.ev_plan = [[torch.cuda.Event() for _ in g] for g in self.groups]
+        self.ev_pre = [[torch.cuda.Event() for _ in sd] for sd in self.side]
+        self.ev_plan = [[torch.cuda.Event() for _ in (sd or g)] for sd, g in zip(self.side, self.groups)]
         self.ev_fwd = [torch.cuda.Event() for _ in self.groups]
 
     def _launch(self, gi):
-        grp, net_in, fwd = self.groups[gi], self.net_in[gi], self.fwd_streams[gi]
-        if not self.per_rollout:
+        grp, net_in, fwd, side = self.groups[gi], self.net_in[gi], self.fwd_streams[gi], self.side[gi]
+        if not side:
             # one stream per group: a single stream guard around the whole group (a guard per rollout is ~10 us of host time)
             with torch.cuda.stream(fwd):
                 for i, r in enumerate(grp):
@@ -232,24 +229,25 @@ class MultiRollout:
                     self.ev_plan[gi][i].record()
             self.inflight[gi] = True
             return
-        for i, r in enumerate(grp):
-            with torch.cuda.stream(self.rstreams[gi][i]):
-                r.pre(net_in[i:i + 1])
-                self.ev_pre[gi][i].record()
+        k = len(side)
+        for si, st in enumerate(side):
+            with torch.cuda.stream(st):
+                for i in range(si, len(grp), k):
+                    grp[i].pre(net_in[i:i + 1])
+                self.ev_pre[gi][si].record()
         with torch.cuda.stream(fwd):
             for ev in self.ev_pre[gi]:
                 fwd.wait_event(ev)
             with torch.no_grad():
                 out1, out2 = self._forward(net_in)
             self.ev_fwd[gi].record()
-        for i, r in enumerate(grp):
-            st = self.rstreams[gi][i]
+        for si, st in enumerate(side):
             with torch.cuda.stream(st):
                 st.wait_event(self.ev_fwd[gi])     # also orders the next pre() after this forward's read of net_in
-                if r.need_replan:
-                    out1.record_stream(st); out2.record_stream(st)
-                r.plan_enqueue(out1[i], out2[i])
-                self.ev_plan[gi][i].record()
+                out1.record_stream(st); out2.record_stream(st)
+                for i in range(si, len(grp), k):
+                    grp[i].plan_enqueue(out1[i], out2[i])
+                self.ev_plan[gi][si].record()
         self.inflight[gi] = True
 
     def _forward(self, net_in):
@@ -261,8 +259,8 @@ class MultiRollout:
         return packing.forward_packed(self._packed, net_in)
 
     def _complete(self, gi):
-        grp = self.groups[gi]
-        if not self.per_rollout:
+        grp, side = self.groups[gi], self.side[gi]
+        if not side:
             for i, r in enumerate(grp):
                 if r.need_replan:
                     self.ev_plan[gi][i].synchronize()      # the GPU keeps running whatever was queued after the event
@@ -272,12 +270,15 @@ class MultiRollout:
                     r.post()
             self.inflight[gi] = False
             return
-        for i, r in enumerate(grp):
-            if r.need_replan:
-                self.ev_plan[gi][i].synchronize()
-            with torch.cuda.stream(self.rstreams[gi][i]):
-                r.plan_finish()
-                r.post()
+        k = len(side)
+        for si, st in enumerate(side):
+            mine = grp[si::k]
+            if any(r.need_replan for r in mine):
+                self.ev_plan[gi][si].synchronize()         # the GPU keeps running whatever was queued after the event
+            with torch.cuda.stream(st):
+                for r in mine:
+                    r.plan_finish()
+                    r.post()
         self.inflight[gi] = False
 
     def step(self):
@@ -301,7 +302,7 @@ class MultiRollout:
             if self.inflight[gi]:
                 self._complete(gi)
         main = torch.cuda.current_stream()
-        for st in set(self.fwd_streams) | {x for g in self.rstreams for x in g}:
+        for st in set(self.fwd_streams) | {x for g in self.side for x in g}:
             if st is not main:
                 main.wait_stream(st)           # later work on the caller's stream sees every rollout's results
 
