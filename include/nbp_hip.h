@@ -243,6 +243,16 @@ int nbp_point_position_i64(const float* pts2d, long long K, int S0, int S1, floa
 int nbp_map_accumulate_f32(const float* points, long long N, const long long* N_dev_or_null, float cx,
                            float cy, float cz, const float* bounds_host, int n_bounds, float band_lo,
                            float band_hi, int S, float lo, float hi, float* out6, void* stream);
+/* The "observation -> network input" stage of one exploration step (nbp_planning.py:114-137) in one call:
+ * nbp_map_accumulate_f32 into out6, the trajectory channel (camera positions so far, transformed like the cloud:
+ * (-(z - cz), -(x - cx)), counted per cell as nbp_map_points_to_imgs_f32 does) into net_in5[4], and
+ * net_in5[0..3] = out6[0..3]; net_in5 = one [5,S,S] map of the network's input batch.  traj_pts = device history of
+ * camera positions with n_traj_old valid points; traj_fresh_host = up to 8 new positions (host, passed in the kernel
+ * arguments), appended to traj_pts[n_traj_old ..] by the same launch.  Two memsets, one kernel, one copy. */
+int nbp_step_maps_f32(const float* points, long long N, const long long* N_dev_or_null, float cx, float cy,
+                      float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi, int S,
+                      float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
+                      int n_traj_fresh, float* out6, float* net_in5, void* stream);
 
 /* ================================================================ A14-A17: simulator
  * PyTorch3D / trimesh conventions restated (third-party; parity with the libraries unpinned):

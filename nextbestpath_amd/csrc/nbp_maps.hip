@@ -93,14 +93,37 @@ __device__ __forceinline__ void accumulate_point(float x, float y, float z, floa
     if (band_lo < y && y < band_hi) agg_add<SLOT_BITS>(keys, cnts, 5 * S * S + cell, out);
 }
 
+// Trajectory channel of the network input (nbp_planning.py:129-137: the camera positions so far, transformed like the
+// cloud and counted per cell): done by ONE extra workgroup of the accumulation launch.  pts = device history (n_old points
+// valid), fresh = up to 8 new positions riding in the kernel arguments (appended to pts here), out = [S,S] zeroed.
+struct TrajArgs { float* pts; float* out; int n_old, n_fresh; float fresh[24]; };
+
 template <int AGG_POINTS, int SLOT_BITS, int THREADS>
 __global__ __launch_bounds__(THREADS) void map_accumulate_kernel(const float* __restrict__ p, long long N,
                                                              const long long* __restrict__ n_dev, float cx, float cz,
                                                              Bounds bd, float band_lo, float band_hi, int S, float lo,
-                                                             float sc, float* __restrict__ out) {
+                                                             float sc, float* __restrict__ out, TrajArgs tr) {
     constexpr int AGG_SLOTS = 1 << SLOT_BITS;
     __shared__ int keys[AGG_SLOTS];
     __shared__ int cnts[AGG_SLOTS];
+    if (tr.out && blockIdx.x == gridDim.x - 1) {                    // the trajectory workgroup (appended to the grid)
+        for (int i = threadIdx.x; i < tr.n_old + tr.n_fresh; i += THREADS) {
+            float x, z;
+            if (i < tr.n_old) {
+                x = tr.pts[3 * i]; z = tr.pts[3 * i + 2];
+            } else {
+                float y = 0.f;
+                x = z = 0.f;
+#pragma unroll
+                for (int f = 0; f < 8; ++f)
+                    if (i - tr.n_old == f) { x = tr.fresh[3 * f]; y = tr.fresh[3 * f + 1]; z = tr.fresh[3 * f + 2]; }
+                tr.pts[3 * i] = x; tr.pts[3 * i + 1] = y; tr.pts[3 * i + 2] = z;
+            }
+            int i0, i1;
+            if (cell_of(-(z - cz), -(x - cx), lo, sc, sc, S, S, i0, i1)) atomicAdd(tr.out + i0 * S + i1, 1.0f);
+        }
+        return;
+    }
     if (n_dev) N = *n_dev;                       // cloud size lives on the device (no host sync per step)
     const long long first = (long long)blockIdx.x * AGG_POINTS;
     if (first >= N) return;
@@ -188,6 +211,37 @@ extern "C" int nbp_map_accumulate_f32(const float* points, long long N, const lo
     // table is shared by 16 waves in flight (26 us for 1.3 M points; 256-thread workgroups: 37 us; smaller
     // point batches flush more distinct keys to L2 and lose)
     map_accumulate_kernel<8192, 13, 1024><<<(unsigned)nbp_cdiv(N, 8192), 1024, 0, st>>>(
-        points, N, N_dev_or_null, cx, cz, bd, band_lo, band_hi, S, lo, grid_scale(S, lo, hi), out6);
+        points, N, N_dev_or_null, cx, cz, bd, band_lo, band_hi, S, lo, grid_scale(S, lo, hi), out6, TrajArgs{});
     return nbp_launch_status();
+}
+
+extern "C" int nbp_step_maps_f32(const float* points, long long N, const long long* N_dev_or_null, float cx, float cy,
+                                 float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi, int S,
+                                 float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
+                                 int n_traj_fresh, float* out6, float* net_in5, void* stream) {
+    NBP_ENTER();
+    (void)cy;
+    NBP_RETURN_IF(!out6 || !net_in5 || !traj_pts || N < 0 || S < 1 || !(hi > lo), NBP_E_ARG);
+    NBP_RETURN_IF(n_bounds < 0 || n_bounds > 8 || (n_bounds > 0 && !bounds_host), NBP_E_ARG);
+    NBP_RETURN_IF(n_traj_old < 0 || n_traj_fresh < 0 || n_traj_fresh > 8 || (n_traj_fresh > 0 && !traj_fresh_host), NBP_E_ARG);
+    NBP_RETURN_IF(N > 0 && (!points || ((uintptr_t)points & 3) != 0), NBP_E_ARG);
+    NBP_RETURN_IF((long long)6 * S * S >= (1ll << 31), NBP_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t SS = (size_t)S * S;
+    hipError_t e = hipMemsetAsync(out6, 0, 6 * SS * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(net_in5 + 4 * SS, 0, SS * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    Bounds bd;
+    for (int k = 0; k < 8; ++k) bd.b[k] = k < n_bounds ? bounds_host[k] : 0.f;
+    bd.n = n_bounds;
+    TrajArgs tr;
+    tr.pts = traj_pts; tr.out = net_in5 + 4 * SS; tr.n_old = n_traj_old; tr.n_fresh = n_traj_fresh;
+    for (int i = 0; i < 24; ++i) tr.fresh[i] = i < 3 * n_traj_fresh ? traj_fresh_host[i] : 0.f;
+    map_accumulate_kernel<8192, 13, 1024><<<(unsigned)nbp_cdiv(N, 8192) + 1, 1024, 0, st>>>(
+        points, N, N_dev_or_null, cx, cz, bd, band_lo, band_hi, S, lo, grid_scale(S, lo, hi), out6, tr);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    e = hipMemcpyAsync(net_in5, out6, 4 * SS * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return e == hipSuccess ? 0 : (int)e;
 }

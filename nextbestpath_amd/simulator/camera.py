@@ -324,6 +324,22 @@ class Camera:
     def renders_colours(self):
         return self._zface_ring is not None or self._rgb_ring is not None
 
+    def trajectory_pending(self):
+        """(device history buffer, number of valid points in it, host array of the <= 8 positions not on the device yet) for
+        utils.step_maps, whose kernel appends them; a longer backlog is flushed here first."""
+        n = len(self._X_hist)
+        if n > self._traj_dev.shape[0]:
+            grown = torch.zeros(2 * n, 3, dtype=torch.float32, device=self.device)
+            grown[:self._traj_n] = self._traj_dev[:self._traj_n]
+            self._traj_dev = grown
+        while n - self._traj_n > 8:
+            hipops.append_points(self._traj_dev, self._traj_n, np.asarray(self._X_hist[self._traj_n:self._traj_n + 8], f32))
+            self._traj_n += 8
+        n_old = self._traj_n
+        fresh = np.asarray(self._X_hist[n_old:n], f32).reshape(-1, 3)
+        self._traj_n = n
+        return self._traj_dev, n_old, fresh
+
     def trajectory_points(self):
         """X_cam_history on the device (for the trajectory channel); new poses are appended by a kernel whose
         arguments carry the points, so there is no blocking host->device copy in the step loop."""

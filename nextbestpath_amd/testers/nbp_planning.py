@@ -106,11 +106,19 @@ class Rollout:
                                 params.sensor_range, seed=self.step_seed + 11 * pose_i,
                                 cloud_rgb=st.cloud_rgb if colour else None, **colour)
         self.pose, _ = camera.get_pose_from_idx(camera.cam_idx)
-        hu.accumulate_step_maps(st.cloud, self.pose, self.y_bins, S, grid_range, n_dev=st.cloud_count, out=st.maps6)
-        traj2d = hu.transform_points_to_n_pieces(camera.trajectory_points(), self.pose)
-        self.traj_img = hu.map_points_to_n_imgs(traj2d, (S, S), grid_range)
-        net_in[0, :4] = st.maps6[:4]
-        net_in[0, 4] = self.traj_img[0]
+        # S5-S7 in one call: six maps, trajectory channel, network input (was seven launches: accumulate_step_maps,
+        # transform_points_to_n_pieces, map_points_to_n_imgs and two copies)
+        if os.environ.get("NBP_STEP_MAPS", "1") == "1":
+            traj_dev, n_old, fresh = camera.trajectory_pending()
+            hu.step_maps(st.cloud, self.pose, self.y_bins, S, grid_range, traj_dev, n_old, fresh, st.maps6, net_in[0],
+                         n_dev=st.cloud_count)
+            self.traj_img = net_in[0, 4]               # stays valid until this rollout's next pre()
+        else:
+            hu.accumulate_step_maps(st.cloud, self.pose, self.y_bins, S, grid_range, n_dev=st.cloud_count, out=st.maps6)
+            traj2d = hu.transform_points_to_n_pieces(camera.trajectory_points(), self.pose)
+            self.traj_img = hu.map_points_to_n_imgs(traj2d, (S, S), grid_range)
+            net_in[0, :4] = st.maps6[:4]
+            net_in[0, 4] = self.traj_img[0]
         path = self.path
         if pose_i == 0 or not path or self.path_record + 1 > len(path):
             self.need_replan = True

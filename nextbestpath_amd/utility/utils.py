@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
+import numpy as np
 import torch
 
 from .. import _lib
@@ -97,3 +98,30 @@ def accumulate_step_maps(full_pc, camera_pose, y_bins, grid_size=256, grid_range
                                                out.data_ptr(), _lib.current_stream())
     _lib.check(rc, "nbp_map_accumulate_f32")
     return out
+
+
+def step_maps(full_pc, camera_pose, y_bins, grid_size, grid_range, traj_dev, n_traj_old, traj_fresh, out6, net_in5,
+              band=0.1, n_dev=None):
+    """accumulate_step_maps + the trajectory channel + the copy of the four slabs into the network input, in one call
+    (nbp_step_maps_f32: two memsets, one kernel, one copy instead of seven launches).  traj_dev: device [cap,3] history
+    of camera positions, n_traj_old of them valid; traj_fresh: host [k<=8,3] new positions, appended by the kernel.
+    out6 [6,S,S]; net_in5 [5,S,S] (one map of the network's input batch)."""
+    _need_cuda(full_pc, "step_maps")
+    cx, cy, cz = _pose_xyz(camera_pose)
+    bounds = [float(v) for v in (y_bins.tolist() if isinstance(y_bins, torch.Tensor) else y_bins)][:-1]
+    if len(bounds) > 8:
+        raise ValueError("at most 8 slab boundaries")
+    S = int(grid_size)
+    if tuple(out6.shape) != (6, S, S) or tuple(net_in5.shape) != (5, S, S) or not net_in5.is_contiguous():
+        raise ValueError("step_maps: out6 [6,S,S] and a contiguous net_in5 [5,S,S] expected")
+    arr = (C.c_float * max(len(bounds), 1))(*bounds)
+    fresh = np.ascontiguousarray(np.asarray(traj_fresh, np.float32).reshape(-1, 3))
+    if n_traj_old + len(fresh) > traj_dev.shape[0]:
+        raise ValueError("step_maps: the trajectory buffer is too small")
+    # thresholds exactly as the reference forms them: python double +-0.1, then fp32 compare
+    band_hi, band_lo = float(np.float32(cy + band)), float(np.float32(cy - band))
+    rc = _lib.lib().nbp_step_maps_f32(full_pc.data_ptr(), full_pc.shape[0], None if n_dev is None else n_dev.data_ptr(),
+                                      cx, cy, cz, arr, len(bounds), band_lo, band_hi, S, float(grid_range[0]),
+                                      float(grid_range[1]), traj_dev.data_ptr(), int(n_traj_old), fresh.ctypes.data,
+                                      len(fresh), out6.data_ptr(), net_in5.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "nbp_step_maps_f32")

@@ -70,3 +70,46 @@ def test_full_size_properties(hip):
     assert torch.equal(a + b, full)
     # idempotence / determinism
     assert torch.equal(hu.accumulate_step_maps(pc, pose, ybins, 512, (-80, 80)), full)
+
+
+@pytest.mark.parametrize("N,n_old,n_fresh,S", [(0, 0, 1, 256), (1000, 0, 8, 256), (250_003, 37, 4, 256), (250_003, 300, 0, 256),
+                                               (50_000, 2000, 5, 512)])
+def test_step_maps_is_the_separate_calls(hip, golden_dir, N, n_old, n_fresh, S):
+    """nbp_step_maps_f32 (six maps + trajectory channel + network input in one call) against the reference-API functions it
+    replaces in the step loop, themselves pinned to the golden vectors above; the fresh trajectory points are appended to the
+    device history by the same launch; a device-resident cloud size is honoured; nothing outside the outputs is touched."""
+    gr = (-40 * S // 256, 40 * S // 256)
+    pc = make_point_cloud(max(N, 1), seed=N + 3, extent=35.0 * S / 256).cuda()
+    pose = np.array([2.5, 13.3, -4.0, 0, 0], np.float32)
+    ybins = torch.arange(0.5, 29.5 + 7.25, 7.25)
+    rng = np.random.default_rng(N + n_old)
+    traj = (rng.standard_normal((n_old + n_fresh, 3)) * 25 * S / 256).astype(np.float32)
+    traj[:, 1] = 1.5
+    if n_old + n_fresh > 3:
+        traj[-1] = traj[0]                                   # a revisited position counts twice
+        traj[1] = [1e4, 0, 0]                                # off the map: dropped
+    cap = n_old + n_fresh + 3
+    traj_dev = torch.full((cap, 3), 7.0, device="cuda")
+    traj_dev[:n_old] = torch.from_numpy(traj[:n_old]).cuda()
+    n_dev = torch.tensor([N], dtype=torch.int64, device="cuda")
+    guard = torch.full((2, 5 * S * S + 2), -3.0, device="cuda")
+    net_in = guard[0, 1:-1].view(5, S, S)
+    net_in.fill_(9.0)
+    out6 = torch.full((6, S, S), 5.0, device="cuda")
+    hu.step_maps(pc, pose, ybins, S, gr, traj_dev, n_old, traj[n_old:], out6, net_in, n_dev=n_dev)
+    want6 = hu.accumulate_step_maps(pc[:N] if N else pc[:0], torch.from_numpy(pose), ybins, S, gr)
+    assert torch.equal(out6, want6)
+    assert torch.equal(net_in[:4], want6[:4])
+    if n_old + n_fresh:
+        t2d = hu.transform_points_to_n_pieces(torch.from_numpy(traj).cuda(), pose)
+        want_t = hu.map_points_to_n_imgs(t2d, (S, S), gr)[0]
+    else:
+        want_t = torch.zeros(S, S, device="cuda")
+    assert torch.equal(net_in[4], want_t)
+    assert torch.equal(traj_dev[:n_old + n_fresh].cpu(), torch.from_numpy(traj))
+    assert bool((traj_dev[n_old + n_fresh:] == 7.0).all())
+    assert bool((guard[0, 0] == -3.0) & (guard[0, -1] == -3.0) & (guard[1] == -3.0).all())
+    with pytest.raises(ValueError):
+        hu.step_maps(pc, pose, ybins, S, gr, traj_dev[:1], 1, traj[:1], out6, net_in)
+    with pytest.raises(Exception):
+        hu.step_maps(pc, pose, ybins, S, gr, traj_dev, 0, np.zeros((9, 3), np.float32), out6, net_in)
