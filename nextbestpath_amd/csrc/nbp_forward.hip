@@ -321,7 +321,13 @@ struct Timer {
 };
 
 // The two arithmetic paths behind the same driver: element type of the activations, K-chunk width, launchers.
-struct NoCtx { int init(Bump&, hipStream_t, bool) { return 0; } };
+struct NoCtx {
+    int init(Bump&, hipStream_t, bool) { return 0; }
+    void offer_gated(void*, void*) {}
+    bool took_gated() { return false; }
+    void offer_pool(void*) {}
+    bool took_pool() { return false; }
+};
 struct PathF32 {
     typedef float T;
     typedef ConvOperands Ops;
@@ -374,6 +380,17 @@ struct AmaxBook {
     void bind(const void* p, unsigned* v) { if (n < 128) { key[n] = p; val[n] = v; ++n; } }
     unsigned* fresh(const void* p) { unsigned* v = next < 128 ? slots + 64 * next++ : nullptr; if (v) bind(p, v); return v; }
     void alias(const void* p, const void* of) { if (unsigned* v = find(of)) bind(p, v); }
+    // the decoder offers the gated tensors before it launches a gate's 1x1 GEMM; a launch that runs the psi tail in its
+    // epilogue (nbp_split.hip) takes them, and the separate psi kernel is skipped
+    float* gated[2] = {nullptr, nullptr};
+    bool gated_taken = false;
+    void offer_gated(void* g0, void* g1) { gated[0] = (float*)g0; gated[1] = (float*)g1; gated_taken = false; }
+    bool took_gated() { const bool t = gated_taken; gated[0] = gated[1] = nullptr; gated_taken = false; return t; }
+    // same for the max-pool after an encoder block: offered before the block's second conv, taken by a launch without split-K
+    float* pool = nullptr;
+    bool pool_taken = false;
+    void offer_pool(void* p) { pool = (float*)p; pool_taken = false; }
+    bool took_pool() { const bool t = pool_taken; pool = nullptr; pool_taken = false; return t; }
     int ensure(const float* p, long long count, const unsigned** out) {
         unsigned* v = find(p);
         int rc = 0;
@@ -408,7 +425,18 @@ struct PathSplit : PathF32 {
                 if (!rc) rc = ctx.ensure(q.src1, M * C1, &s[g].amax1);
                 if (rc) return rc;
             }
-            return nbp_gate1x1_split_launch_g(s[0], o2 ? &s[1] : nullptr, C0, M, N, 1, st);
+            GatePsi psi;
+            for (int g = 0; g < 2; ++g) {
+                const int l = li[(g && o2) ? 1 : 0] + 2;                      // the gate's psi layer follows W_g, W_x
+                psi.wpsi[g] = (const float*)h->w[l]; psi.st[g] = h->scale[l]; psi.gated[g] = ctx.gated[(g && o2) ? 1 : 0];
+            }
+            int fused = 0;
+            const int rc = nbp_gate1x1_split_launch_g(s[0], o2 ? &s[1] : nullptr, C0, M, N, 1, st, ctx.gated[0] ? &psi : nullptr, &fused);
+            if (fused) {
+                ctx.gated_taken = true;
+                for (int g = 0; g < (o2 ? 2 : 1); ++g) ctx.alias(ctx.gated[g], (g ? *o2 : o).src1);      // |x psi| <= |x|
+            }
+            return rc;
         }
         const ConvPlan p = nbp_plan_conv_split((long long)B * H * H, N, (C0 + C1) / 32 * ks * ks, 0, o2 ? 2 : 1, H, H, ks, ups);
         if (!p.tile) return PathF32::conv(ctx, h, li, o, o2, C0, C1, ups, B, H, ks, N, ws, wsb, st);
@@ -423,7 +451,15 @@ struct PathSplit : PathF32 {
             if (rc) return rc;
             s[g].amax_out = ctx.fresh(q.out);
         }
-        return nbp_conv_split_launch_g(s[0], o2 ? &s[1] : nullptr, C0, C1, ups, B, H, H, ks, N, 1, 0, ws, wsb, st);
+        float* pools[2] = {ctx.pool, nullptr};
+        int pooled = 0;
+        const int rc = nbp_conv_split_launch_g(s[0], o2 ? &s[1] : nullptr, C0, C1, ups, B, H, H, ks, N, 1, 0, ws, wsb, st,
+                                               (ctx.pool && !o2) ? pools : nullptr, &pooled);
+        if (pooled) {
+            ctx.pool_taken = true;
+            ctx.alias(ctx.pool, o.out);                 // max-pool of a tensor: its max bounds the pooled one
+        }
+        return rc;
     }
     static int first(Ctx& ctx, const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {
         unsigned* slot = ctx.fresh(out);
@@ -543,6 +579,8 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
     int li = 0;
     int s = S;
     const T* prev = nullptr;
+    T* pooled_next = nullptr;
+    bool pool_fused = false;
     for (int e = 0; e < 5; ++e) {
         const int co = enc[e];
         const size_t n = (size_t)B * s * s * co;
@@ -552,15 +590,20 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
             if (!dry && !rc) rc = P::first(ctx, x, B, s, h, a, st);
             stamp("Conv1.conv.0(first)", 2.0 * B * s * s * 64 * 45, (long long)B * s * s, 64, 45);
         } else {
-            T* pooled = bp.take<T>((size_t)B * s * s * enc[e - 1]);
-            if (!dry && !rc) rc = P::pool(ctx, prev, B, 2 * s, enc[e - 1], pooled, st);
+            T* pooled = pooled_next;
+            if (!dry && !rc && !pool_fused) rc = P::pool(ctx, prev, B, 2 * s, enc[e - 1], pooled, st);
             snprintf(nm, sizeof nm, "Maxpool%d", e);
             stamp(nm, 0, (long long)B * s * s, enc[e - 1], 0);
             snprintf(nm, sizeof nm, "Conv%d.conv.0", e + 1);
             conv(nm, li, pooled, enc[e - 1], nullptr, 0, 0, s, 3, co, a);
         }
         snprintf(nm, sizeof nm, "Conv%d.conv.3", e + 1);
+        if (e < 4) {                                  // the block's max-pool is offered to the conv's epilogue (split path)
+            pooled_next = bp.take<T>((size_t)B * (s / 2) * (s / 2) * co);
+            ctx.offer_pool(pooled_next);
+        }
         conv(nm, li + 1, a, co, nullptr, 0, 0, s, 3, co, b);
+        pool_fused = ctx.took_pool();
         li += 2;
         skip[e] = b; prev = b;
         if (e < 4) s /= 2;
@@ -594,8 +637,10 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
         snprintf(nm, sizeof nm, "Up%d_%s.up.1", Lv, tag);
         shifted(0, l); conv2(nm, ng, l, src, ci, nullptr, 0, 1, sr, 3, co, dd);                    // upsample + conv3x3
         snprintf(nm, sizeof nm, "Att%d_%s.W_g+W_x", Lv, tag);
+        ctx.offer_gated(ag[0], ng == 2 ? ag[1] : nullptr);
         shifted(1, l); conv2(nm, ng, l, (const T* const*)dd, co, xsa, co, 0, sr, 1, co / 2, q);  // relu(W_g g + W_x x)
-        for (int g = 0; g < ng && !dry && !rc; ++g)
+        const bool psi_fused = ctx.took_gated();            // the split path's gate kernel may have run the tail itself
+        for (int g = 0; g < ng && !dry && !rc && !psi_fused; ++g)
             rc = P::gate(ctx, q[g], co / 2, (const float*)h->w[lis[g] + 3], h->scale[lis[g] + 3], xs, co, M, ag[g], st);
         snprintf(nm, sizeof nm, "Att%d_%s.psi*x", Lv, tag);
         stamp(nm, 2.0 * ng * M * (co / 2), M, 1, co / 2);

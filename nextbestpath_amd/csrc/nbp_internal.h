@@ -64,16 +64,23 @@ struct ConvOperandsSplit {
 };
 ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize, int ups = 0);
 int nbp_pack_upconv_weight_split_launch(const float* w_oihw, int N, int C, void* dst, unsigned* wamax_out, hipStream_t st);
+// pool_out != null offers the 2x2 max-pool of the output(s) [B,H/2,W/2,N]; *pooled tells whether the launch wrote it (only
+// without split-K) -- if not, the caller runs nbp_maxpool2_nhwc_f32 as before
 int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C0, int C1, int ups, int B, int H, int W,
-                            int ksize, int N, int relu, int split_k, void* ws, size_t ws_bytes, hipStream_t st);
+                            int ksize, int N, int relu, int split_k, void* ws, size_t ws_bytes, hipStream_t st,
+                            float* const* pool_out = nullptr, int* pooled = nullptr);
 int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
                                       int c_total, void* dst, unsigned* wamax_out, hipStream_t st);
 int nbp_amax_launch(const float* x, long long n, unsigned* amax_inout, hipStream_t st);
 // attention gates (1x1 over K = [src0 | src1], both C channels) on the split scheme
 int nbp_pack_gate_weight_split_launch(const float* wg, const float* scale_g, const float* wx, const float* scale_x, int N, int C,
                                       void* dst, unsigned* wamax_out, hipStream_t st);
+// psi != null offers the gate's tail (per group: psi weights [N], {scale, shift}, gated output [M,C] = src1 * psi); *fused tells
+// whether the launch took it (a workgroup must hold all N columns of its pixels) -- if not, q is written and the caller runs
+// nbp_psi_gate_f32 as before
+struct GatePsi { const float* wpsi[2]; const float* st[2]; float* gated[2]; };
 int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C, long long M, int N, int relu,
-                               hipStream_t st);
+                               hipStream_t st, const GatePsi* psi = nullptr, int* fused = nullptr);
 int nbp_conv_first_amax_launch(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale, const float* shift,
                                float* out_nhwc, unsigned* amax_out, int* did_amax, hipStream_t st);
 

@@ -81,6 +81,7 @@ __device__ __forceinline__ unsigned read_amax(const unsigned* slot) {     // eve
 struct SplitOps {
     const float* src0; const float* src1; const void* planes; const float* scale; const float* shift; float* out;
     const unsigned* amax0; const unsigned* amax1; const unsigned* wamax; unsigned* amax_out;
+    float* pool_out;            // not null: the 2x2 max-pool of the output (nbp_model.py:113-123) is written as well [B,H/2,W/2,N]
 };
 struct SplitArgs {
     SplitOps g[2];              // blockIdx.z >= split_k: the second problem of a grouped launch
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int n = n0 + j * 32 + (lane & 31);
         float sc = 1.f, sh = 0.f;
         if (final_out) { sc = o.scale[n]; sh = o.shift[n]; }
+        float vals[TM][16];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const long long mrow = PH ? ((long long)b * a.H + 2 * (y0 + (TM * wave + i) * RPB) + py) * a.W + 2 * x0 + px
@@ -319,6 +321,33 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 if (final_out && a.relu) v = fmaxf(v, 0.f);
                 mx = fmaxf(mx, fabsf(v));
                 outp[(mrow + poff) * a.N + n] = v;
+                vals[i][r] = v;
+            }
+        }
+        // 2x2 max-pool of the same values: the four pixels of a window are registers of ONE lane (a wave's row blocks are
+        // consecutive image rows; registers r, r + 1 are neighbouring columns; with 16-pixel rows r + 8 is the row below)
+        if (!PH && final_out && o.pool_out) {
+            const int Hp = a.H >> 1, Wp = a.W >> 1;
+            if constexpr (TW == 32) {
+#pragma unroll
+                for (int i = 0; i < TM; i += 2) {
+                    const long long prow = ((long long)b * Hp + ((y0 + TM * wave + i) >> 1)) * Wp + (x0 >> 1);
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int xo = ((r & 3) + 8 * (r >> 2) + 4 * khalf) >> 1;
+                        o.pool_out[(prow + xo) * a.N + n] = fmaxf(fmaxf(vals[i][r], vals[i][r + 1]), fmaxf(vals[i + 1][r], vals[i + 1][r + 1]));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const long long prow = ((long long)b * Hp + ((y0 + (TM * wave + i) * RPB) >> 1)) * Wp + (x0 >> 1);
+#pragma unroll
+                    for (int r = 0; r < 8; r += 2) {
+                        const int xo = ((r & 3) + 8 * (r >> 2) + 4 * khalf) >> 1;
+                        o.pool_out[(prow + xo) * a.N + n] = fmaxf(fmaxf(vals[i][r], vals[i][r + 1]), fmaxf(vals[i][r + 8], vals[i][r + 9]));
+                    }
+                }
             }
         }
     }
@@ -338,9 +367,14 @@ struct GateArgs {
     long long M;
     unsigned bytes0, bytesw;
     int groups;
+    // PSI form (a workgroup holds all N columns of its pixels): the gate's tail runs in the epilogue -- psi = sigmoid((q . wpsi)
+    // * st[0] + st[1]) (nbp_model.py:54-58), gated = src1 * psi (ref :60) -- and q itself is never written
+    const float* wpsi[2];
+    const float* st[2];
+    float* gated[2];
 };
 
-template <int TN>
+template <int TN, bool PSI>
 __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
     const SplitOps& o = a.g[blockIdx.z];
     constexpr int BN = TN * 32;
@@ -434,6 +468,70 @@ __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
     }
     // D[pixel][n]: col n = lane & 31, pixel = (r & 3) + 8 (r >> 2) + 4 khalf of the wave's 32
     const long long mw = (long long)blockIdx.x * 128 + wave * 32;
+    if constexpr (PSI) {
+        // q . wpsi per pixel: per-lane partial sums over this lane's TN columns, then a reduce-scatter over the 32 lanes of the
+        // half wave (16 values -> 8 -> 4 -> 2 -> 1 with masks 16, 8, 4, 2, then a plain exchange with mask 1): 16 shuffles
+        // instead of 80, and lane l ends with the sum of pixel register r = (l & 31) >> 1
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = j * 32 + (lane & 31);
+            const float sc = o.scale[n], sh = o.shift[n], wp = a.wpsi[blockIdx.z][n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = ldexpf(acc[j][r], einv) * sc + sh;
+                if (a.relu) v = fmaxf(v, 0.f);
+                p[r] = fmaf(v, wp, p[r]);
+            }
+        }
+        float p8[8], p4[4], p2[2];
+        {
+            const bool up = lane & 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p8[i] = (up ? p[8 + i] : p[i]) + __shfl_xor(up ? p[i] : p[8 + i], 16);
+        }
+        {
+            const bool up = lane & 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p4[i] = (up ? p8[4 + i] : p8[i]) + __shfl_xor(up ? p8[i] : p8[4 + i], 8);
+        }
+        {
+            const bool up = lane & 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) p2[i] = (up ? p4[2 + i] : p4[i]) + __shfl_xor(up ? p4[i] : p4[2 + i], 4);
+        }
+        float dot;
+        {
+            const bool up = lane & 2;
+            dot = (up ? p2[1] : p2[0]) + __shfl_xor(up ? p2[0] : p2[1], 2);
+        }
+        dot += __shfl_xor(dot, 1);
+        const float z = dot * a.st[blockIdx.z][0] + a.st[blockIdx.z][1];
+        const float psi = 1.f / (1.f + expf(-z));
+        float* psil = reinterpret_cast<float*>(wbuf) + wave * 32;      // the weight buffers are free: the loop ended on a barrier
+        const int r = (lane & 31) >> 1;
+        if (!(lane & 1)) psil[(r & 3) + 8 * (r >> 2) + 4 * khalf] = psi;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // same wave wrote what it reads
+        // gated = x * psi: the wave's 32 pixels x C channels as float4s, 1 KB contiguous per instruction; x = source 1, read a
+        // moment ago as the second half of K (L2 / MALL hits)
+        const int C4 = a.C >> 2, total = 32 * C4;
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(o.src1) + mw * C4;
+        f32x4* g4 = reinterpret_cast<f32x4*>(a.gated[blockIdx.z]) + mw * C4;
+        const long long lim = (a.M - mw) * C4;                            // float4s of this wave that exist
+#pragma unroll 1
+        for (int i0 = lane; i0 < total; i0 += 256) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; if (i < total && i < lim) v[u] = x4[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 64 * u;
+                if (i < total && i < lim) { const float ps = psil[i / C4]; g4[i] = v[u] * ps; }
+            }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 32 + (lane & 31);
@@ -447,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
                 o.out[mm * a.N + n] = v;
             }
         }
+    }
     }
 }
 
@@ -658,7 +757,8 @@ int nbp_amax_launch(const float* x, long long n, unsigned* amax_inout, hipStream
 
 // Returns NBP_E_SHAPE for layers the kernel does not take.
 int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C0, int C1, int ups, int B, int H, int W,
-                            int ksize, int N, int relu, int split_k, void* ws, size_t ws_bytes, hipStream_t st) {
+                            int ksize, int N, int relu, int split_k, void* ws, size_t ws_bytes, hipStream_t st,
+                            float* const* pool_out, int* pooled) {
     const int groups = o2 ? 2 : 1;
     NBP_RETURN_IF(!o.src0 || !o.planes || !o.scale || !o.shift || !o.out || !o.amax0 || !o.wamax, NBP_E_ARG);
     NBP_RETURN_IF(o2 && (!o2->src0 || !o2->planes || !o2->scale || !o2->shift || !o2->out || !o2->amax0 || !o2->wamax), NBP_E_ARG);
@@ -669,7 +769,7 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     SplitArgs a;
     for (int g = 0; g < 2; ++g) {
         const ConvOperandsSplit& s = (g && o2) ? *o2 : o;
-        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, C1 ? s.amax1 : nullptr, s.wamax, s.amax_out};
+        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, C1 ? s.amax1 : nullptr, s.wamax, s.amax_out, nullptr};
     }
     a.C0 = C0; a.C1 = C1; a.ups = ups ? 1 : 0;
     a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W;
@@ -716,6 +816,13 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
         NBP_RETURN_IF(!ws || ws_bytes < (size_t)groups * p.split_k * a.M * N * sizeof(float), NBP_E_WS);
         a.partial = (float*)ws;
     }
+    // the max-pool that follows an encoder block rides in the epilogue when the launch writes final values (no split-K)
+    static const int allow_pool = [] { const char* e = getenv("NBP_CONV_POOL"); return e ? atoi(e) : 1; }();
+    const bool with_pool = allow_pool && pool_out && pool_out[0] && (groups == 1 || pool_out[1]) && p.split_k == 1 && !ph && !ups &&
+                           !((H | W) & 1);
+    if (pooled) *pooled = with_pool;
+    if (with_pool)
+        for (int g = 0; g < groups; ++g) a.g[g].pool_out = pool_out[g];
     int rc = ph ? (tw == 32 ? launch_h2<32, 4, 2, true>(a, st) : launch_h2<16, 2, 4, true>(a, st))
                 : (tw == 32 ? launch_h2<32, 4, 2, false>(a, st) : launch_h2<16, 2, 4, false>(a, st));
     if (rc) return rc;
@@ -774,7 +881,7 @@ int nbp_pack_gate_weight_split_launch(const float* wg, const float* scale_g, con
 
 // planes: nbp_pack_gate_weight_split_launch; amax0 / amax1: the 64-word slots of the two sources; out [M][N] fp32
 int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C, long long M, int N, int relu,
-                               hipStream_t st) {
+                               hipStream_t st, const GatePsi* psi, int* fused) {
     const int groups = o2 ? 2 : 1;
     NBP_RETURN_IF(!o.src0 || !o.src1 || !o.planes || !o.scale || !o.shift || !o.out || !o.amax0 || !o.amax1 || !o.wamax, NBP_E_ARG);
     NBP_RETURN_IF(o2 && (!o2->src0 || !o2->src1 || !o2->planes || !o2->out || !o2->amax0 || !o2->amax1 || !o2->wamax), NBP_E_ARG);
@@ -784,17 +891,28 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
     GateArgs a;
     for (int g = 0; g < 2; ++g) {
         const ConvOperandsSplit& s = (g && o2) ? *o2 : o;
-        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, s.amax1, s.wamax, nullptr};
+        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, s.amax1, s.wamax, nullptr, nullptr};
+        const int gi = g < groups ? g : 0;
+        a.wpsi[g] = psi ? psi->wpsi[gi] : nullptr; a.st[g] = psi ? psi->st[gi] : nullptr; a.gated[g] = psi ? psi->gated[gi] : nullptr;
     }
     a.C = C; a.N = N; a.relu = relu; a.M = M; a.bytes0 = (unsigned)b0; a.bytesw = (unsigned)bw; a.groups = groups;
     // 128-channel blocks only when they alone fill the chip twice; otherwise more, narrower workgroups
     int bn = N % 128 == 0 ? 128 : (N % 64 == 0 ? 64 : 32);
     if (bn == 128 && nbp_cdiv(M, 128) * (N / 128) * groups < 512) bn = 64;
+    // the gate's tail (psi, x * psi) runs in the epilogue when a workgroup holds every column of its pixels
+    static const int allow_psi = [] { const char* e = getenv("NBP_GATE_PSI"); return e ? atoi(e) : 1; }();
+    const bool with_psi = allow_psi && psi && bn == N && psi->wpsi[0] && psi->st[0] && psi->gated[0] &&
+                          (groups == 1 || (psi->wpsi[1] && psi->st[1] && psi->gated[1]));
+    if (fused) *fused = with_psi;
     dim3 grid((unsigned)nbp_cdiv(M, 128), (unsigned)(N / bn), (unsigned)groups);
     const size_t smem = 2 * (size_t)8 * bn * 16;
-    if (bn == 128) gate1x1_h2_kernel<4><<<grid, 256, smem, st>>>(a);
-    else if (bn == 64) gate1x1_h2_kernel<2><<<grid, 256, smem, st>>>(a);
-    else gate1x1_h2_kernel<1><<<grid, 256, smem, st>>>(a);
+    if (with_psi) {
+        if (bn == 128) gate1x1_h2_kernel<4, true><<<grid, 256, smem, st>>>(a);
+        else if (bn == 64) gate1x1_h2_kernel<2, true><<<grid, 256, smem, st>>>(a);
+        else gate1x1_h2_kernel<1, true><<<grid, 256, smem, st>>>(a);
+    } else if (bn == 128) gate1x1_h2_kernel<4, false><<<grid, 256, smem, st>>>(a);
+    else if (bn == 64) gate1x1_h2_kernel<2, false><<<grid, 256, smem, st>>>(a);
+    else gate1x1_h2_kernel<1, false><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 

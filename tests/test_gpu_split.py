@@ -250,3 +250,39 @@ def test_split_forward_under_rescaled_inputs(hip, nets, mag):
     # the obstacle head is a sigmoid of logits that scale with the input: at 1e4 one fp32 ulp of a logit is already 1e-3
     assert float((o2 - f2).abs().max()) < (1e-4 if mag <= 1 else 5e-3)
     assert torch.equal(o1.amax(1).flatten(1).argmax(1), f1.amax(1).flatten(1).argmax(1))
+
+
+_FUSION_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from nextbestpath_amd.networks import packing
+from nextbestpath_amd.utility.synthetic import make_count_maps, make_explorer_state_dict
+dev = torch.device("cuda")
+packed = packing.pack_state_dict(make_explorer_state_dict(9), dev, precision="fp32_split")
+for B, S in ((8, 256), (3, 128), (1, 64)):
+    o1, o2 = packing.forward_packed(packed, make_count_maps(B, S, seed=B).to(dev))
+    torch.save((o1.cpu(), o2.cpu()), f"{sys.argv[2]}_{B}_{S}.pt")
+"""
+
+
+def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
+    """The encoder's max-pools ride in the producing convolution's epilogue and the attention gates' psi tail in the gate
+    GEMM's (NBP_CONV_POOL / NBP_GATE_PSI = 0 switch back to the separate kernels; the switches are read once per process, hence
+    the subprocesses).  The pooled tensor is the max of the same four values: bit-identical outputs.  The fused psi sums
+    q . w_psi in another order: equal to fp32 rounding of a 32..128-term dot product."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fwd.py"
+    script.write_text(_FUSION_SCRIPT)
+    outs = {}
+    for tag, env in (("both", {}), ("nopool", {"NBP_CONV_POOL": "0"}), ("nopsi", {"NBP_GATE_PSI": "0"})):
+        subprocess.run([sys.executable, str(script), root, str(tmp_path / tag)], check=True, env={**os.environ, **env},
+                       timeout=600)
+        outs[tag] = {k: torch.load(tmp_path / f"{tag}_{k[0]}_{k[1]}.pt") for k in ((8, 256), (3, 128), (1, 64))}
+    for k, (o1, o2) in outs["both"].items():
+        p1, p2 = outs["nopool"][k]
+        assert torch.equal(o1, p1) and torch.equal(o2, p2), k
+        q1, q2 = outs["nopsi"][k]
+        assert float((o1 - q1).abs().max()) <= 2e-5 * max(1.0, float(q1.abs().max())), k
+        assert float((o2 - q2).abs().max()) <= 2e-5, k
