@@ -200,10 +200,13 @@ __global__ __launch_bounds__(256) void points_scatter4_kernel(const float* __res
 
 template <int LANES, int UNROLL>
 __global__ __launch_bounds__(256) void coverage_mark_kernel(const float* __restrict__ pc, const long long* __restrict__ n_dev,
-                                                            long long n_host, long long k, unsigned seed, Grid g, float thr,
+                                                            long long n_host, long long k, unsigned seed, Grid g, float d2max,
                                                             const float4* __restrict__ gt_sorted, const int* __restrict__ gt_start,
                                                             unsigned* __restrict__ stamp, unsigned epoch,
                                                             int* __restrict__ m_out) {
+    // d2max = the largest float whose square root is below the threshold (sq_below, host): d2 <= d2max is the reference's
+    // cdist(...) < threshold decision exactly (sqrtf is monotone and correctly rounded on both sides) without the ~12
+    // instructions of a correctly rounded square root per point pair -- the kernel is bound by those pair tests
     const long long N = n_dev ? *n_dev : n_host;
     const long long M = N > k ? k : N;
     if (blockIdx.x == 0 && threadIdx.x == 0) *m_out = (int)M;
@@ -235,14 +238,14 @@ __global__ __launch_bounds__(256) void coverage_mark_kernel(const float* __restr
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     const float ex = t[u].x - x, ey = t[u].y - y, ez = t[u].z - z;
-                    if (sp[u] != epoch && sqrtf((ex * ex + ey * ey) + ez * ez) < thr) stamp[q + u] = epoch;
+                    if (sp[u] != epoch && (ex * ex + ey * ey) + ez * ez <= d2max) stamp[q + u] = epoch;
                 }
             }
             for (; q < hi; ++q) {
                 if (stamp[q] == epoch) continue;
                 const float4 t = gt_sorted[q];
                 const float ex = t.x - x, ey = t.y - y, ez = t.z - z;
-                if (sqrtf((ex * ex + ey * ey) + ez * ez) < thr) stamp[q] = epoch;     // plain store: every writer writes the
+                if ((ex * ex + ey * ey) + ez * ez <= d2max) stamp[q] = epoch;          // plain store: every writer writes the
             }                                                                          // same value (device-scope atomics run
         }                                                                              // at ~5 G/s on this part: 30x slower)
     }
@@ -352,6 +355,14 @@ extern "C" int nbp_coverage_count_f32(const float* gt3, int G, const float* pc3,
 }
 
 // ---- planned coverage (one GT grid per rollout)
+// Largest float x with sqrtf(x) < thr (thr > 0 finite): the squared-distance form of `distance < thr`.
+static float sq_below(float thr) {
+    float x = thr * thr;
+    while (sqrtf(x) >= thr) x = nextafterf(x, 0.f);
+    while (sqrtf(nextafterf(x, INFINITY)) < thr) x = nextafterf(x, INFINITY);
+    return x;
+}
+
 static void plan_carve(void* plan, size_t ncell, int G, int** start, float4** sorted, unsigned** stamp) {
     char* p = (char*)(((uintptr_t)plan + 255) / 256 * 256);
     *start = (int*)p; p += al256((ncell + 1) * 4);
@@ -419,7 +430,7 @@ extern "C" int nbp_coverage_count_planned_f32(void* plan, int G, float threshold
     // 8 or 16 lanes per point or 8 points per iteration measure the same (the kernel is then bound by the ~50 M
     // point-pair tests, not by the chains)
     coverage_mark_kernel<4, 4><<<nbp_ew_grid((work > 0 ? work : 1) * 4, 256), 256, 0, (hipStream_t)stream>>>(
-        pc3, N_dev_or_null, N, sample_k, seed, g, threshold, sorted, start, stamp, epoch, m_out);
+        pc3, N_dev_or_null, N, sample_k, seed, g, sq_below(threshold), sorted, start, stamp, epoch, m_out);
     if ((rc = nbp_launch_status())) return rc;
     coverage_tally_kernel<<<(unsigned)(G < 16384 ? 1 : 16), 256, 0, (hipStream_t)stream>>>(stamp, G, epoch, count_accum);
     return nbp_launch_status();

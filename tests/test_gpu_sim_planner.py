@@ -349,6 +349,29 @@ def test_coverage_random_clouds_vs_oracle(hip, seed):
         assert ho.coverage_count(torch.from_numpy(gt).to(D), torch.from_numpy(big).to(D), seed=seed + 1).cpu().tolist() == [want, 2 * G]
 
 
+@pytest.mark.parametrize("thr", [1.0, 0.7, 1.37])
+def test_coverage_threshold_boundary_is_the_square_root_one(hip, thr):
+    """The planned kernel tests d^2 <= (largest float whose square root is below the threshold) instead of sqrt(d^2) < thr:
+    GT points whose distance from a cloud point straddles the threshold ulp by ulp, along an axis and along a diagonal, must be
+    counted exactly as the square-root form of the oracle (and of the one-shot kernel) counts them."""
+    t = np.float32(thr)
+    steps = np.arange(-40, 41)
+    d = np.array([t], np.float32).view(np.int32)[0] + steps
+    d = d.astype(np.int32).view(np.float32)                                     # thr +- 40 ulps
+    gt_axis = np.stack([d + np.float32(3.0), np.full_like(d, 2.0), np.full_like(d, -1.0)], 1)
+    diag = (d / np.float32(np.sqrt(3.0))).astype(np.float32)
+    gt_diag = np.stack([diag + np.float32(30.0), diag + np.float32(2.0), diag - np.float32(1.0)], 1)
+    gt = np.concatenate([gt_axis, gt_diag]).astype(np.float32)
+    pc = np.array([[3.0, 2.0, -1.0], [30.0, 2.0, -1.0]], np.float32)
+    _, want = opl.coverage(gt, pc, threshold=thr)
+    assert 0 < want < len(gt)
+    gtd, pcd = torch.from_numpy(gt).to(D), torch.from_numpy(pc).to(D)
+    plan = ho.CoveragePlan(gtd, thr, 2)
+    res = torch.zeros(2, dtype=torch.int32, device=D)
+    assert plan.count(pcd, res, seed=0).cpu().tolist() == [want, 2]
+    assert ho.coverage_count(gtd, pcd, seed=0, threshold=thr).cpu().tolist() == [want, 2]
+
+
 @pytest.mark.parametrize("seed", [31, 32, 33])
 def test_planner_kernels_random_vs_oracle(hip, seed):
     """Random maps, random lattice positions partly outside the window, random skip flags: candidate scoring (one wave
