@@ -327,6 +327,8 @@ struct NoCtx {
     bool took_gated() { return false; }
     void offer_pool(void*) {}
     bool took_pool() { return false; }
+    void offer_head(const float*, const float*, const float*, float*) {}
+    bool took_head() { return false; }
 };
 struct PathF32 {
     typedef float T;
@@ -391,6 +393,11 @@ struct AmaxBook {
     bool pool_taken = false;
     void offer_pool(void* p) { pool = (float*)p; pool_taken = false; }
     bool took_pool() { const bool t = pool_taken; pool = nullptr; pool_taken = false; return t; }
+    // and for the sigmoid head after decoder 2's last convolution
+    ConvHead head = {nullptr, nullptr, nullptr, nullptr};
+    bool head_taken = false;
+    void offer_head(const float* w, const float* sc, const float* sh, float* out) { head = ConvHead{w, sc, sh, out}; head_taken = false; }
+    bool took_head() { const bool t = head_taken; head = ConvHead{nullptr, nullptr, nullptr, nullptr}; head_taken = false; return t; }
     int ensure(const float* p, long long count, const unsigned** out) {
         unsigned* v = find(p);
         int rc = 0;
@@ -452,9 +459,11 @@ struct PathSplit : PathF32 {
             s[g].amax_out = ctx.fresh(q.out);
         }
         float* pools[2] = {ctx.pool, nullptr};
-        int pooled = 0;
+        int pooled = 0, headed = 0;
         const int rc = nbp_conv_split_launch_g(s[0], o2 ? &s[1] : nullptr, C0, C1, ups, B, H, H, ks, N, 1, 0, ws, wsb, st,
-                                               (ctx.pool && !o2) ? pools : nullptr, &pooled);
+                                               (ctx.pool && !o2) ? pools : nullptr, &pooled, (ctx.head.out && !o2) ? &ctx.head : nullptr,
+                                               &headed);
+        if (headed) ctx.head_taken = true;
         if (pooled) {
             ctx.pool_taken = true;
             ctx.alias(ctx.pool, o.out);                 // max-pool of a tensor: its max bounds the pooled one
@@ -613,6 +622,7 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
     // launch (decoder 1 = group 0, decoder 2 = group 1), which doubles the workgroups per launch at
     // B = 1 and halves the split-K factor.  Decoder 2 then continues alone through levels 3 and 2.
     const int li_d1 = 10, li_d2 = 22;
+    bool head2_fused = false;
     const T* cur[2] = {skip[4], skip[4]};
     for (int Lv = 5; Lv >= 2; --Lv) {
         const int ng = Lv >= 4 ? 2 : 1;
@@ -647,7 +657,9 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
         snprintf(nm, sizeof nm, "Up_conv%d_%s.conv.0", Lv, tag);
         shifted(4, l); conv2(nm, ng, l, (const T* const*)ag, co, (const T* const*)dd, co, 0, sr, 3, co, u);
         snprintf(nm, sizeof nm, "Up_conv%d_%s.conv.3", Lv, tag);
+        if (Lv == 2 && !dry) ctx.offer_head((const float*)h->w[47], h->scale[47], h->shift[47], out2);   // Final2 consumes this layer alone
         shifted(5, l); conv2(nm, ng, l, (const T* const*)u, co, nullptr, 0, 0, sr, 3, co, o);
+        if (Lv == 2) head2_fused = ctx.took_head();
         for (int g = 0; g < ng; ++g) cur[g0 + g] = o[g];
         if (Lv == 4) {
             if (!dry && !rc)
@@ -655,7 +667,7 @@ int run_forward(const nbp_weights* h, const float* x, int B, int S, float* out1,
             stamp("Final1", 2.0 * B * (S / 4) * (S / 4) * 8 * 256, (long long)B * (S / 4) * (S / 4), 8, 256);
         }
     }
-    if (!dry && !rc)
+    if (!dry && !rc && !head2_fused)
         rc = P::head(cur[1], B, S, 64, (const float*)h->w[47], 1, h->scale[47], h->shift[47], 1, out2, st);
     stamp("Final2", 2.0 * B * S * S * 64, (long long)B * S * S, 1, 64);
     return rc;

@@ -64,11 +64,15 @@ struct ConvOperandsSplit {
 };
 ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize, int ups = 0);
 int nbp_pack_upconv_weight_split_launch(const float* w_oihw, int N, int C, void* dst, unsigned* wamax_out, hipStream_t st);
+// head != null offers the one-channel sigmoid head that alone consumes a 64-channel layer: out1[m] = sigmoid((out[m,:] . w) * scale[0]
+// + shift[0]); *headed tells whether the launch wrote it INSTEAD of `out` -- if not, the caller runs nbp_final_1x1_f32 as before
+struct ConvHead { const float* w; const float* scale; const float* shift; float* out; };
 // pool_out != null offers the 2x2 max-pool of the output(s) [B,H/2,W/2,N]; *pooled tells whether the launch wrote it (only
 // without split-K) -- if not, the caller runs nbp_maxpool2_nhwc_f32 as before
 int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C0, int C1, int ups, int B, int H, int W,
                             int ksize, int N, int relu, int split_k, void* ws, size_t ws_bytes, hipStream_t st,
-                            float* const* pool_out = nullptr, int* pooled = nullptr);
+                            float* const* pool_out = nullptr, int* pooled = nullptr, const struct ConvHead* head = nullptr,
+                            int* headed = nullptr);
 int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
                                       int c_total, void* dst, unsigned* wamax_out, hipStream_t st);
 int nbp_amax_launch(const float* x, long long n, unsigned* amax_inout, hipStream_t st);

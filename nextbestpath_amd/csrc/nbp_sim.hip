@@ -312,7 +312,9 @@ struct FaceRec { float e1[3], e2[3], v0[3], q[3], tnum, pad[3]; };   // 64 bytes
 // into the z-buffer with atomicMin on the float bit pattern (positive floats order like unsigned ints), so a tile with
 // thousands of faces is shared by many waves instead of being one wave's tail.
 constexpr int COARSE = 8;              // fine tiles per coarse tile side
-constexpr int SEG = 4096;              // list entries per wave
+constexpr int SEG_DEFAULT = 16384;     // list entries per wave (NBP_RASTER_SEG): with the hit list taken through LDS in pieces a wave can walk a
+                                       // whole coarse list, and the empty extra segments of shorter ones cost 1-3 us (4096: 50.3 / 65.1 us for 4 frames of
+                                       // the 8 k / 29 k-face scenes, 32768: 49.0 / 62.9)
 constexpr int HITS = 1024;             // ... taken through LDS in pieces of this many
 constexpr unsigned ZBUF_EMPTY = 0x7F7F7F7Fu;   // memset pattern, 3.39e38 as a float
 
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restri
                                                          float tanh_fov, float zclip, int tiles_x, int tiles_y, int ctiles_x,
                                                          int ctiles_y, const int* __restrict__ ccount,
                                                          const BinEntry* __restrict__ clist, unsigned* __restrict__ zbuf_bits,
-                                                         unsigned long long* __restrict__ zface) {
+                                                         unsigned long long* __restrict__ zface, int SEG) {
     __shared__ int hits[HITS];
     __shared__ __attribute__((aligned(16))) FaceRec sh[64];
     const int fr = blockIdx.y;
@@ -829,10 +831,11 @@ static int raster_launch(const float* verts, int n_verts, const int* faces, int 
         e = hipMemsetAsync(gray, 0, (size_t)n_frames * sizeof(double), st);
         if (e != hipSuccess) return (int)e;
     }
+    static const int SEG = [] { const char* v = getenv("NBP_RASTER_SEG"); return v && atoi(v) >= 1024 ? atoi(v) / 1024 * 1024 : SEG_DEFAULT; }();
     const int nseg = (int)nbp_cdiv(n_faces, SEG);
     dim3 g2((unsigned)(tiles_x * tiles_y * nseg), (unsigned)n_frames);
     raster_tile_kernel<<<g2, 64, 0, st>>>(recs, n_faces, H, W, tan_half_fov, z_clip, tiles_x, tiles_y, ctiles_x, ctiles_y,
-                                          ccount, clist, (unsigned*)zbuf, zface);
+                                          ccount, clist, (unsigned*)zbuf, zface, SEG);
     if ((rc = nbp_launch_status())) return rc;
     if (!zface) {
         raster_finalize_kernel<<<nbp_ew_grid(npx, 256), 256, 0, st>>>(zbuf, npx);

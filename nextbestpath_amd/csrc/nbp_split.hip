@@ -82,6 +82,9 @@ struct SplitOps {
     const float* src0; const float* src1; const void* planes; const float* scale; const float* shift; float* out;
     const unsigned* amax0; const unsigned* amax1; const unsigned* wamax; unsigned* amax_out;
     float* pool_out;            // not null: the 2x2 max-pool of the output (nbp_model.py:113-123) is written as well [B,H/2,W/2,N]
+    // not null (N == 64 == the tile's columns): the layer feeds only the one-channel sigmoid head (Final2, nbp_model.py:108,
+    // :158-159): head_out[m] = sigmoid((out[m, :] . head_w) * head_ss[0] + head_ss[1]) is written INSTEAD of out
+    const float* head_w; const float* head_ss[2]; float* head_out;
 };
 struct SplitArgs {
     SplitOps g[2];              // blockIdx.z >= split_k: the second problem of a grouped launch
@@ -303,11 +306,21 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const bool final_out = (a.split_k == 1);
     float* outp = final_out ? o.out : a.partial + (long long)zslice * a.M * a.N;
     float mx = 0.f;
+    constexpr bool HEADABLE = !PH && TN == 2;              // 64 columns = all channels of the head's input in one wave
+    const bool head = HEADABLE && final_out && o.head_out;
+    float hp[HEADABLE ? TM : 1][16];
+    if constexpr (HEADABLE) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hp[i][r] = 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 32 + (lane & 31);
         float sc = 1.f, sh = 0.f;
         if (final_out) { sc = o.scale[n]; sh = o.shift[n]; }
+        const float hw = head ? o.head_w[n] : 0.f;
         float vals[TM][16];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -320,8 +333,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 float v = ldexpf(acc[i][j][r], einv) * sc + sh;
                 if (final_out && a.relu) v = fmaxf(v, 0.f);
                 mx = fmaxf(mx, fabsf(v));
-                outp[(mrow + poff) * a.N + n] = v;
+                if (!head) outp[(mrow + poff) * a.N + n] = v;
                 vals[i][r] = v;
+                if constexpr (HEADABLE) hp[i][r] = fmaf(v, hw, hp[i][r]);
             }
         }
         // 2x2 max-pool of the same values: the four pixels of a window are registers of ONE lane (a wave's row blocks are
@@ -348,6 +362,39 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                         o.pool_out[(prow + xo) * a.N + n] = fmaxf(fmaxf(vals[i][r], vals[i][r + 1]), fmaxf(vals[i][r + 8], vals[i][r + 9]));
                     }
                 }
+            }
+        }
+    }
+    if constexpr (HEADABLE) {
+        if (head) {
+            // per row block: reduce-scatter of the 16 per-lane partial dot products over the 32 lanes of the half wave (as in the
+            // gate kernel's psi tail): lane l ends with pixel register r = (l & 31) >> 1
+            const float hs = o.head_ss[0][0], ht = o.head_ss[1][0];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float p8[8], p4[4], p2[2];
+                {
+                    const bool up = lane & 16;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) p8[k] = (up ? hp[i][8 + k] : hp[i][k]) + __shfl_xor(up ? hp[i][k] : hp[i][8 + k], 16);
+                }
+                {
+                    const bool up = lane & 8;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) p4[k] = (up ? p8[4 + k] : p8[k]) + __shfl_xor(up ? p8[k] : p8[4 + k], 8);
+                }
+                {
+                    const bool up = lane & 4;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) p2[k] = (up ? p4[2 + k] : p4[k]) + __shfl_xor(up ? p4[k] : p4[2 + k], 4);
+                }
+                const bool up = lane & 2;
+                float dot = (up ? p2[1] : p2[0]) + __shfl_xor(up ? p2[0] : p2[1], 2);
+                dot += __shfl_xor(dot, 1);
+                const int r = (lane & 31) >> 1;
+                const int pb = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const long long mrow = ((long long)b * a.H + y0 + (TM * wave + i) * RPB) * a.W + x0;
+                if (!(lane & 1)) o.head_out[mrow + (pb / TW) * a.W + (pb % TW)] = 1.f / (1.f + expf(-(dot * hs + ht)));
             }
         }
     }
@@ -758,7 +805,7 @@ int nbp_amax_launch(const float* x, long long n, unsigned* amax_inout, hipStream
 // Returns NBP_E_SHAPE for layers the kernel does not take.
 int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C0, int C1, int ups, int B, int H, int W,
                             int ksize, int N, int relu, int split_k, void* ws, size_t ws_bytes, hipStream_t st,
-                            float* const* pool_out, int* pooled) {
+                            float* const* pool_out, int* pooled, const ConvHead* head, int* headed) {
     const int groups = o2 ? 2 : 1;
     NBP_RETURN_IF(!o.src0 || !o.planes || !o.scale || !o.shift || !o.out || !o.amax0 || !o.wamax, NBP_E_ARG);
     NBP_RETURN_IF(o2 && (!o2->src0 || !o2->planes || !o2->scale || !o2->shift || !o2->out || !o2->amax0 || !o2->wamax), NBP_E_ARG);
@@ -769,7 +816,7 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     SplitArgs a;
     for (int g = 0; g < 2; ++g) {
         const ConvOperandsSplit& s = (g && o2) ? *o2 : o;
-        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, C1 ? s.amax1 : nullptr, s.wamax, s.amax_out, nullptr};
+        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, C1 ? s.amax1 : nullptr, s.wamax, s.amax_out, nullptr, nullptr, {nullptr, nullptr}, nullptr};
     }
     a.C0 = C0; a.C1 = C1; a.ups = ups ? 1 : 0;
     a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W;
@@ -823,6 +870,12 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     if (pooled) *pooled = with_pool;
     if (with_pool)
         for (int g = 0; g < groups; ++g) a.g[g].pool_out = pool_out[g];
+    // the one-channel sigmoid head that consumes this layer alone (Final2) rides in the epilogue instead of the layer's own store
+    static const int allow_head = [] { const char* e = getenv("NBP_CONV_HEAD"); return e ? atoi(e) : 1; }();
+    const bool with_head = allow_head && head && head->w && head->scale && head->shift && head->out && groups == 1 && p.split_k == 1 &&
+                           !ph && tw == 32 && N == 64 && relu;
+    if (headed) *headed = with_head;
+    if (with_head) { a.g[0].head_w = head->w; a.g[0].head_ss[0] = head->scale; a.g[0].head_ss[1] = head->shift; a.g[0].head_out = head->out; }
     int rc = ph ? (tw == 32 ? launch_h2<32, 4, 2, true>(a, st) : launch_h2<16, 2, 4, true>(a, st))
                 : (tw == 32 ? launch_h2<32, 4, 2, false>(a, st) : launch_h2<16, 2, 4, false>(a, st));
     if (rc) return rc;
@@ -891,7 +944,7 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
     GateArgs a;
     for (int g = 0; g < 2; ++g) {
         const ConvOperandsSplit& s = (g && o2) ? *o2 : o;
-        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, s.amax1, s.wamax, nullptr, nullptr};
+        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, s.amax1, s.wamax, nullptr, nullptr, nullptr, {nullptr, nullptr}, nullptr};
         const int gi = g < groups ? g : 0;
         a.wpsi[g] = psi ? psi->wpsi[gi] : nullptr; a.st[g] = psi ? psi->st[gi] : nullptr; a.gated[g] = psi ? psi->gated[gi] : nullptr;
     }

@@ -266,8 +266,8 @@ for B, S in ((8, 256), (3, 128), (1, 64)):
 
 
 def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
-    """The encoder's max-pools ride in the producing convolution's epilogue and the attention gates' psi tail in the gate
-    GEMM's (NBP_CONV_POOL / NBP_GATE_PSI = 0 switch back to the separate kernels; the switches are read once per process, hence
+    """The encoder's max-pools and the one-channel sigmoid head ride in the producing convolution's epilogue and the attention
+    gates' psi tail in the gate GEMM's (NBP_CONV_POOL / NBP_CONV_HEAD / NBP_GATE_PSI = 0 switch back to the separate kernels; the switches are read once per process, hence
     the subprocesses).  The pooled tensor is the max of the same four values: bit-identical outputs.  The fused psi sums
     q . w_psi in another order: equal to fp32 rounding of a 32..128-term dot product."""
     import subprocess
@@ -276,7 +276,7 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
     script = tmp_path / "fwd.py"
     script.write_text(_FUSION_SCRIPT)
     outs = {}
-    for tag, env in (("both", {}), ("nopool", {"NBP_CONV_POOL": "0"}), ("nopsi", {"NBP_GATE_PSI": "0"})):
+    for tag, env in (("both", {}), ("nopool", {"NBP_CONV_POOL": "0"}), ("nopsi", {"NBP_GATE_PSI": "0"}), ("nohead", {"NBP_CONV_HEAD": "0"})):
         subprocess.run([sys.executable, str(script), root, str(tmp_path / tag)], check=True, env={**os.environ, **env},
                        timeout=600)
         outs[tag] = {k: torch.load(tmp_path / f"{tag}_{k[0]}_{k[1]}.pt") for k in ((8, 256), (3, 128), (1, 64))}
@@ -286,3 +286,5 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
         q1, q2 = outs["nopsi"][k]
         assert float((o1 - q1).abs().max()) <= 2e-5 * max(1.0, float(q1.abs().max())), k
         assert float((o2 - q2).abs().max()) <= 2e-5, k
+        r1, r2 = outs["nohead"][k]                            # Final2 in the last convolution's epilogue: out1 untouched
+        assert torch.equal(o1, r1) and float((o2 - r2).abs().max()) <= 2e-6, k
