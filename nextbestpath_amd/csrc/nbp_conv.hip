@@ -725,6 +725,15 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
                                 [](float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }, amax_out);
 }
 
+// Workgroups of the 8 x 32-tile kernel: it loops over tiles, and a workgroup's fixed cost (launch, weights into LDS, cold
+// instruction fetch: ~11 us of the ~19 us a one-tile workgroup takes) is paid once per workgroup, so no more workgroups than
+// two per CU (NBP_FIRST_GRID overrides)
+static unsigned first_grid(long long M) {
+    static const int cap = [] { const char* e = getenv("NBP_FIRST_GRID"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    const long long tiles = M / 256;
+    return (unsigned)(tiles < cap ? tiles : cap);
+}
+
 // nbp_conv_first_f32 that also leaves max |out| in the 64 words of amax_out (zeroed by the caller); returns 1 in *did_amax
 // when the kernel that ran could do it (the 8 x 32-tile MFMA kernel), 0 otherwise
 int nbp_conv_first_amax_launch(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale, const float* shift,
@@ -733,8 +742,7 @@ int nbp_conv_first_amax_launch(const float* x_nchw, int B, int H, int W, const f
     static const int use_mfma = [] { const char* e = getenv("NBP_FIRST_MFMA"); return e ? atoi(e) : 1; }();
     *did_amax = 0;
     if (use_mfma && (H & 7) == 0 && (W & 31) == 0) {
-        conv_first_mfma_kernel<<<(unsigned)(M / 256 < 2048 ? M / 256 : 2048), 256, 0, st>>>(x_nchw, B, H, W, w_oihw, scale, shift, out_nhwc,
-                                                                                         amax_out);
+        conv_first_mfma_kernel<<<first_grid(M), 256, 0, st>>>(x_nchw, B, H, W, w_oihw, scale, shift, out_nhwc, amax_out);
         *did_amax = amax_out ? 1 : 0;
         return nbp_launch_status();
     }
@@ -749,8 +757,7 @@ extern "C" int nbp_conv_first_f32(const float* x_nchw, int B, int H, int W, cons
     long long M = (long long)B * H * W;
     static const int use_mfma = [] { const char* e = getenv("NBP_FIRST_MFMA"); return e ? atoi(e) : 1; }();
     if (use_mfma && (H & 7) == 0 && (W & 31) == 0) {     // 8 x 32 pixel tiles; other sizes take the VALU kernel below
-        conv_first_mfma_kernel<<<(unsigned)(M / 256 < 2048 ? M / 256 : 2048), 256, 0, (hipStream_t)stream>>>(x_nchw, B, H, W, w_oihw, scale, shift,
-                                                                                   out_nhwc, nullptr);
+        conv_first_mfma_kernel<<<first_grid(M), 256, 0, (hipStream_t)stream>>>(x_nchw, B, H, W, w_oihw, scale, shift, out_nhwc, nullptr);
         return nbp_launch_status();
     }
     conv_first_kernel<<<(unsigned)nbp_cdiv(M, 64), 256, 0, (hipStream_t)stream>>>(x_nchw, B, H, W, w_oihw, scale,
