@@ -112,6 +112,15 @@ struct SplitArgs {
 // for py = 0 and {W[-1] + W[0], W[1]} for py = 1, columns alike -- 16 tap-products per low-resolution pixel instead of 36.
 // A workgroup owns one parity of a 16 x TW low-resolution tile (blockIdx.z & 3), runs the 2 x 2 taps from the same halo planes
 // (stage = one row of 2 taps) and writes its outputs to (2 v + py, 2 u + px).
+#ifdef NBP_DBG_TS
+// debug build only (tools/diag/conv_timeline.py): time stamps of one wave at the phase boundaries of the stage loop
+__device__ unsigned long long nbp_dbg_ts[8192];
+__device__ unsigned nbp_dbg_n;
+#define NBP_WALL(tag) do { if (dbg_on) { const unsigned k_ = dbg_i++; if (k_ < 4000) { nbp_dbg_ts[2 * k_] = (unsigned long long)(tag); nbp_dbg_ts[2 * k_ + 1] = wall_clock64(); } } } while (0)
+#define NBP_TS(tag) do { if (dbg_on) { const unsigned k_ = dbg_i++; if (k_ < 4000) { nbp_dbg_ts[2 * k_] = (unsigned long long)(tag); nbp_dbg_ts[2 * k_ + 1] = __builtin_readcyclecounter(); } } } while (0)
+#else
+#define NBP_TS(tag) do {} while (0)
+#endif
 template <int TW, int TM, int TN, bool PH>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_h2_kernel(SplitArgs a) {
     int zs = blockIdx.z;
@@ -135,6 +144,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     char* const wbuf = ldsb + HALO_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef NBP_DBG_TS
+    const bool dbg_on = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 64;
+    unsigned dbg_i = 0;
+    NBP_WALL(100); NBP_TS(101);
+#endif
     const int Ht = PH ? a.Hs : a.H, Wt = PH ? a.Ws : a.W;     // the tile grid: output pixels, or low-resolution pixels for PH
     const int tiles_x = Wt / TW, tiles_y = Ht / TH;
     unsigned tile = blockIdx.x, nt = blockIdx.y;
@@ -264,6 +278,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll 1
         for (int row = 0; row < ROWS; ++row) {
             const int u = c * ROWS + row;
+            NBP_TS(1);
             if (row < ROWS - 1 || more) issue_w(u + 1);
             const char* Bt = wbuf + (u & 1) * WB + brow;
 #pragma unroll
@@ -291,13 +306,18 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xp[i][PX[v]]),
                                                                                __builtin_bit_cast(f16x8, wp[j][PW[v]]), acc[i][j], 0, 0, 0);
             }
+            NBP_TS(2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            NBP_TS(3);
             __syncthreads();
+            NBP_TS(4);
         }
         if (more) {                     // every wave is past its last read of this chunk's planes
             __builtin_amdgcn_s_setprio(0);      // the staging pass yields issue slots to the co-resident workgroup's MFMAs (1 %)
             store_halo();
+            NBP_TS(5);
             __syncthreads();
+            NBP_TS(6);
             __builtin_amdgcn_s_setprio(2);
         }
     }
@@ -399,7 +419,20 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
     }
     if (final_out && o.amax_out) wave_amax(mx, o.amax_out);
+#ifdef NBP_DBG_TS
+    NBP_TS(7);
+    NBP_TS(102); NBP_WALL(103);
+    if (dbg_on) nbp_dbg_n = dbg_i;
+#endif
 }
+
+#ifdef NBP_DBG_TS
+extern "C" int nbp_dbg_read(unsigned long long* host, unsigned* n) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(n, HIP_SYMBOL(nbp_dbg_n), sizeof(unsigned));
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nbp_dbg_ts), sizeof(unsigned long long) * 8192);
+}
+#endif
 
 // ------------------------------------------------------------------ 1x1 convolution over K = [src0 | src1] (the attention gates)
 // q = relu([g | x] W + b), next_best_path/networks/nbp_model.py:44-53 (W_g and W_x as one GEMM, BN scales folded into W).
