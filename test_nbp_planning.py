@@ -19,7 +19,7 @@ if __name__ == "__main__":
     parser.add_argument("-c", "--config", type=str, help="name of the config file in configs/test/")
     parser.add_argument("--n-poses", type=int, default=101)
     parser.add_argument("--rollouts-per-gpu", type=int, default=None,
-                        help="concurrent rollouts per GPU (batched NBP forward); default: the config's value or 8")
+                        help="concurrent rollouts per GPU (batched NBP forward); default: the config's value or 24")
     args = parser.parse_args()
     p = load_params(os.path.join(test_configs_dir, args.config or "test_via_nbp_model.json"))
     ds = p.dataset_path if os.path.isabs(p.dataset_path) else os.path.join(dir_path, p.dataset_path)
@@ -32,5 +32,5 @@ if __name__ == "__main__":
                           configs_dir=os.path.join(dir_path, "configs/macarons"),
                           results_dir=os.path.join(dir_path, "data"), n_poses=args.n_poses,
                           seed=getattr(p, "random_seed", 8), torch_seed=getattr(p, "torch_seed", 9),
-                          rollouts_per_gpu=args.rollouts_per_gpu or getattr(p, "rollouts_per_gpu", 8), grid_size=getattr(p, "grid_size", 256),
+                          rollouts_per_gpu=args.rollouts_per_gpu or getattr(p, "rollouts_per_gpu", 24), grid_size=getattr(p, "grid_size", 256),
                           nbp_precision=getattr(p, "nbp_precision", "fp32"))
