@@ -76,6 +76,9 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
 int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
                                       int c_total, void* dst, unsigned* wamax_out, hipStream_t st);
 int nbp_amax_launch(const float* x, long long n, unsigned* amax_inout, hipStream_t st);
+// 3x3 weight gradient on the split scheme: partial sums [splits][9][C0 + C1][N]; amax3 = 3 x 64 words of scratch
+int nbp_wgrad_split_launch(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W, const float* dy, int N,
+                           int n_tiles, int splits, unsigned* amax3, float* part, hipStream_t st);
 // attention gates (1x1 over K = [src0 | src1], both C channels) on the split scheme
 int nbp_pack_gate_weight_split_launch(const float* wg, const float* scale_g, const float* wx, const float* scale_x, int N, int C,
                                       void* dst, unsigned* wamax_out, hipStream_t st);

@@ -629,6 +629,150 @@ __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ 3x3 weight gradient on the split scheme
+// dW[tap][ci][co] = sum over pixels of X[pixel + tap][ci] dY[pixel][co] (training, nbp_utils.py:383-395 through autograd): the
+// reduction runs over PIXELS, so both MFMA operands need 8 consecutive pixels of one channel per lane while the tensors are
+// channel-contiguous (NHWC).  gfx950's transpose read does that turn for free: the tile sits in LDS as it comes from memory --
+// fp16 hi / lo planes [32-channel half][pixel][32 channels], 64 B per pixel -- and ds_read_b64_tr_b16 hands lane i of a 16-lane
+// group column i of a [4 pixels][16 channels] block (lane address = pixel row 4 (l >> 4) + ((l & 15) >> 2), channels 4 (l & 3) ..:
+// tools/probes/tr16_probe.hip), i.e. exactly a quarter of a 32x32x16 MFMA fragment; a filter tap is a ROW offset of the
+// X plane, so no shifted copies.  64-B rows put the four pixel rows of a block on banks 0 / 16 / 32 / 48 and the second
+// 16-channel group 8 banks further: conflict-free.
+// Workgroup = 64 (ci) x 64 (co) block of dW for all nine taps (wave = 32 x 32, nine accumulator tiles), walking 2 x 32-pixel
+// tiles like wgrad_halo_kernel (nbp_train.hip); per tile the 4 x 34 halo of X and the 64 pixels of dY go global -> registers ->
+// scale by 2^(12 - e), split -> LDS; a 16-pixel K step is 2 + 2 transpose reads per operand and three exact MFMAs.
+struct WgradSplitArgs {
+    const float* src0; const float* src1;
+    int C0, C1, ups, H, W, Hs, Ws;
+    const float* dy; int N;
+    unsigned bytes0, bytes1, bytesy;
+    int co_tiles, n_tiles, splits;
+    const unsigned* amax0; const unsigned* amax1; const unsigned* amaxy;
+    float* part;           // [split][tap][Ctot][N]
+};
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+
+__device__ __forceinline__ f16x8 tr_frag(const char* p) {      // 8 consecutive pixel rows (p, p + 4 rows) of this lane's channel
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(p));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(p + 256));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(f16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
+    constexpr int HW_ = 34, HP = 4 * HW_;                      // halo pixels of a 2 x 32 tile
+    constexpr int XPL = HP * 64, YPL = 64 * 64;                // bytes of one (plane, channel half) region
+    constexpr int XB = 4 * XPL;                                // X: [plane][half] regions, then dY alike
+    extern __shared__ __attribute__((aligned(16))) char wl[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1, kh = lane >> 5, ln = lane & 31;
+    const int ci0 = (blockIdx.x / a.co_tiles) * 64, co0 = (blockIdx.x % a.co_tiles) * 64;
+    const int Ctot = a.C0 + a.C1;
+    const bool first = ci0 < a.C0;
+    const int Cs = first ? a.C0 : a.C1;
+    const int cbase = first ? ci0 : ci0 - a.C0;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(first ? a.src0 : a.src1), 0, first ? a.bytes0 : a.bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.bytesy, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int tiles_x = a.W >> 5, tiles_y = a.H >> 1;
+    const int ex = amax_exponent(read_amax(first ? a.amax0 : a.amax1)), ey = amax_exponent(read_amax(a.amaxy));
+    const float sx = pow2f(12 - ex), sy = pow2f(12 - ey);
+    const int einv = ex + ey - 24;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // staging roles: item f = tid + 256 k is the float4 of channels 4 (f & 15) .. + 3 of pixel f >> 4
+    const int c4 = tid & 15;
+    const int sdst = (c4 >> 3) * 1 /* half */;                    // region half; byte offset inside the pixel row: (c4 & 7) * 8
+    // fragment lane offsets: pixel row 8 kh + ((lane & 15) >> 2) (+ 4 for the second read), channels 16 ((lane >> 4) & 1) + 4 (lane & 3)
+    const int loff = (8 * kh + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const char* const xa_hi = wl + (0 * 2 + wi) * XPL + loff;
+    const char* const xa_lo = wl + (1 * 2 + wi) * XPL + loff;
+    const char* const yb_hi = wl + XB + (0 * 2 + wj) * YPL + loff;
+    const char* const yb_lo = wl + XB + (1 * 2 + wj) * YPL + loff;
+
+    for (int tile = blockIdx.y; tile < a.n_tiles; tile += a.splits) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int b = t / tiles_y;
+        const int y0 = ty * 2, x0 = tx * 32;
+        u32x4 xr[9], yr[4];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {          // X halo: 136 pixels x 16 float4
+            const int f = tid + 256 * k;
+            const int hr = f >> 4;
+            const int hy = hr / HW_, hx = hr - hy * HW_;
+            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            const bool ok = hr < HP && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)(((b * a.Hs + (yy >> a.ups)) * a.Ws + (xx >> a.ups)) * Cs + cbase + c4 * 4) * 4u : OOB;
+            xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {          // dY: 64 pixels x 16 float4
+            const int pz = (tid + 256 * k) >> 4;
+            const long long m = ((long long)b * a.H + y0 + (pz >> 5)) * a.W + x0 + (pz & 31);
+            yr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (unsigned)((m * a.N + co0 + c4 * 4) * 4), 0, 0);
+        }
+        __syncthreads();                       // every wave is done with the previous tile's planes
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int hr = (tid + 256 * k) >> 4;
+            if (hr >= HP) continue;
+            const f32x4 v = __builtin_bit_cast(f32x4, xr[k]);
+            unsigned h0, l0, h1, l1;
+            split_pair(v[0] * sx, v[1] * sx, h0, l0);
+            split_pair(v[2] * sx, v[3] * sx, h1, l1);
+            char* d = wl + sdst * XPL + hr * 64 + (c4 & 7) * 8;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + 2 * XPL) = u32x2{l0, l1};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pz = (tid + 256 * k) >> 4;
+            const f32x4 v = __builtin_bit_cast(f32x4, yr[k]);
+            unsigned h0, l0, h1, l1;
+            split_pair(v[0] * sy, v[1] * sy, h0, l0);
+            split_pair(v[2] * sy, v[3] * sy, h1, l1);
+            char* d = wl + XB + sdst * YPL + pz * 64 + (c4 & 7) * 8;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + 2 * YPL) = u32x2{l0, l1};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int p0 = r * 32 + 16 * s;                               // first of the step's 16 pixels
+                const f16x8 bh = tr_frag(yb_hi + p0 * 64), bl = tr_frag(yb_lo + p0 * 64);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int hp0 = (r + tap / 3) * HW_ + 16 * s + tap % 3;   // halo pixel of (row r + dy, column 16 s + dx)
+                    const f16x8 ah = tr_frag(xa_hi + hp0 * 64), al = tr_frag(xa_lo + hp0 * 64);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[tap], 0, 0, 0);
+                }
+            }
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        float* out = a.part + (((long long)blockIdx.y * 9 + tap) * Ctot) * a.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            out[(long long)ci * a.N + co0 + wj * 32 + ln] = ldexpf(acc[tap][r], einv);
+        }
+    }
+}
+
 // Grid-stride over float4s of the output, two positions per thread and iteration, the slices' loads of both issued together
 // (four slices at a time) and added in slice order -- a serial load-add chain costs one memory round trip per slice, and
 // one float4 per thread is bound by the wave launch rate (measured: 31 us serial / 56 us one-per-thread / see DESIGN.md).
@@ -999,6 +1143,36 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
     } else if (bn == 128) gate1x1_h2_kernel<4, false><<<grid, 256, smem, st>>>(a);
     else if (bn == 64) gate1x1_h2_kernel<2, false><<<grid, 256, smem, st>>>(a);
     else gate1x1_h2_kernel<1, false><<<grid, 256, smem, st>>>(a);
+    return nbp_launch_status();
+}
+
+// Partial sums [splits][9][C0 + C1][N] of the 3x3 weight gradient (the caller reduces them: wgrad_reduce_kernel, nbp_train.hip).
+// amax3 = 3 x 64 zeroed words of scratch: max |src0|, max |src1|, max |dY| are computed here.
+int nbp_wgrad_split_launch(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W, const float* dy, int N,
+                           int n_tiles, int splits, unsigned* amax3, float* part, hipStream_t st) {
+    const int Hs = ups ? H / 2 : H, Ws = ups ? W / 2 : W;
+    const long long b0 = (long long)B * Hs * Ws * C0 * 4, b1 = (long long)B * Hs * Ws * C1 * 4, by = (long long)B * H * W * N * 4;
+    NBP_RETURN_IF(b0 >= (1ll << 31) || b1 >= (1ll << 31) || by >= (1ll << 31), NBP_E_SHAPE);
+    hipError_t e = hipMemsetAsync(amax3, 0, 3 * AMAX_WORDS * sizeof(unsigned), st);
+    if (e != hipSuccess) return (int)e;
+    int rc = nbp_amax_launch(src0, b0 / 4, amax3, st);
+    if (!rc && C1) rc = nbp_amax_launch(src1, b1 / 4, amax3 + AMAX_WORDS, st);
+    if (!rc) rc = nbp_amax_launch(dy, by / 4, amax3 + 2 * AMAX_WORDS, st);
+    if (rc) return rc;
+    WgradSplitArgs a;
+    a.src0 = src0; a.src1 = src1 ? src1 : src0; a.C0 = C0; a.C1 = C1; a.ups = ups ? 1 : 0; a.H = H; a.W = W; a.Hs = Hs; a.Ws = Ws;
+    a.dy = dy; a.N = N; a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0; a.bytesy = (unsigned)by;
+    a.co_tiles = N / 64; a.n_tiles = n_tiles; a.splits = splits;
+    a.amax0 = amax3; a.amax1 = amax3 + AMAX_WORDS; a.amaxy = amax3 + 2 * AMAX_WORDS; a.part = part;
+    constexpr int smem = 4 * (4 * 34 * 64) + 4 * (64 * 64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(((C0 + C1) / 64) * (N / 64)), (unsigned)splits);
+    wgrad_split_kernel<<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 

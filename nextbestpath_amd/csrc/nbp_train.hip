@@ -1005,7 +1005,7 @@ extern "C" size_t nbp_conv_wgrad_workspace_bytes(int B, int H, int W, int C0, in
         wgrad_halo_plan(B, H, W, C0 + C1, N, &nt, &hs);
         if (hs > sp) sp = hs;
     }
-    return (size_t)sp * ksize * ksize * (C0 + C1) * N * sizeof(float) + 256;
+    return (size_t)sp * ksize * ksize * (C0 + C1) * N * sizeof(float) + 256 + 1024;     // + max-|.| scratch of the split form
 }
 
 // dW [n_real][c_real][k][k] (OIHW) of out = conv(cat(src0, src1) [upsampled]) given dY [B,H,W,N].
@@ -1064,6 +1064,35 @@ extern "C" int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, 
     if (rc) return rc;
     const long long total = (long long)n_real * c_real * a.taps;
     wgrad_reduce_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(a.part, sp, a.taps, C0 + C1, N, c_real, n_real, dw);
+    return nbp_launch_status();
+}
+
+// (nbp_split.hip)
+int nbp_wgrad_split_launch(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W, const float* dy, int N,
+                           int n_tiles, int splits, unsigned* amax3, float* part, hipStream_t st);
+
+// The same gradient with the products on the fp16 matrix pipe (two-piece operands, three exact MFMAs per product, fp32
+// accumulation; nbp_split.hip: wgrad_split_kernel) for the 3x3 layers the halo-tile form takes; everything else falls through
+// to nbp_conv_wgrad_f32.  Workspace: nbp_conv_wgrad_workspace_bytes (it includes the 768 B of max-|.| scratch).
+extern "C" int nbp_conv_wgrad_split_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
+                                        int ksize, const float* dy, int N, int c_real, int n_real, float* dw, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    const bool take = ksize == 3 && wgrad_halo_ok(H, W, ksize) && (long long)B * H * W * N * 4 < (1ll << 31) && src0 && dy && dw &&
+                      ws && B >= 1 && C0 >= 64 && C0 % 64 == 0 && C1 >= 0 && C1 % 64 == 0 && N >= 64 && N % 64 == 0 &&
+                      (C1 == 0 || src1) && !(ups && ((H | W) & 1));
+    if (!take) return nbp_conv_wgrad_f32(src0, C0, src1, C1, ups, B, H, W, ksize, dy, N, c_real, n_real, dw, ws, ws_bytes, stream);
+    NBP_ENTER();
+    NBP_RETURN_IF(c_real < 1 || c_real > C0 + C1 || n_real < 1 || n_real > N, NBP_E_ARG);
+    int n_tiles, splits;
+    wgrad_halo_plan(B, H, W, C0 + C1, N, &n_tiles, &splits);
+    NBP_RETURN_IF(ws_bytes < (size_t)splits * 9 * (C0 + C1) * N * sizeof(float) + 256 + 1024, NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* amax3 = (unsigned*)(((uintptr_t)ws + 255) / 256 * 256);
+    float* part = (float*)((char*)amax3 + 1024);
+    int rc = nbp_wgrad_split_launch(src0, C0, src1, C1, ups, B, H, W, dy, N, n_tiles, splits, amax3, part, st);
+    if (rc) return rc;
+    const long long total = (long long)n_real * c_real * 9;
+    wgrad_reduce_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(part, splits, 9, C0 + C1, N, c_real, n_real, dw);
     return nbp_launch_status();
 }
 

@@ -79,6 +79,7 @@ def _igemm(src0, src1, ups, wpk, N, ksize, scale, shift, relu):
 # 3x3 convolutions of the forward and of the data gradient on the fp16 matrix pipe through two-piece operand splitting
 # (csrc/nbp_split.hip: the fp32 pipe's accuracy at 5.3x its matrix rate); NBP_TRAIN_SPLIT=0 keeps the fp32 MFMA pipe.
 _SPLIT = os.environ.get("NBP_TRAIN_SPLIT", "1") != "0"
+_WGRAD_SPLIT = os.environ.get("NBP_TRAIN_WGRAD_SPLIT", "1") == "1"      # A/B: weight gradients on the fp32 pipe
 
 
 def _split_ok(H, W, N, ksize):
@@ -181,8 +182,10 @@ class ConvFn(torch.autograd.Function):
         db = _colsum(dy.view(M, Np))[:N].clone()
         dw = torch.empty(N, c_real, k, k, dtype=torch.float32, device=dev)
         ws = _ws(L.nbp_conv_wgrad_workspace_bytes(B, H, W, C0, C1, Np, k), dev)
-        _chk(L.nbp_conv_wgrad_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, int(ups), B, H, W, k, _lib.ptr(dy), Np, c_real, N,
-                                  _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _st()), "conv_wgrad")
+        # the 3x3 weight gradients take the split scheme too (the entry point falls through to the fp32 pipe for the rest)
+        wgrad = L.nbp_conv_wgrad_split_f32 if _SPLIT and _WGRAD_SPLIT else L.nbp_conv_wgrad_f32
+        _chk(wgrad(_lib.ptr(x0), C0, _lib.ptr(x1), C1, int(ups), B, H, W, k, _lib.ptr(dy), Np, c_real, N,
+                   _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _st()), "conv_wgrad")
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             Ctot = C0 + C1

@@ -306,21 +306,24 @@ def test_trainer_loop_reduces_loss(hip, tmp_path):
     assert v1 < v0, (v0, v1)           # a few AdamW steps on its own data must reduce MSE + BCE
 
 
-@pytest.mark.parametrize("shape", [(4, 64, 128, 0, 128, 0), (2, 32, 64, 64, 64, 0), (2, 64, 128, 0, 64, 1)])
-def test_wgrad_halo_kernel_vs_fp64(hip, shape):
-    """The 3x3 weight gradient at sizes where the halo-tile kernel runs (W % 32 == 0), incl. fused concat and
-    upsample, against an fp64 CPU reference: fp32 accumulation over up to 16 k pixels stays within 5e-6 relative."""
+@pytest.mark.parametrize("entry", ["nbp_conv_wgrad_f32", "nbp_conv_wgrad_split_f32"])
+@pytest.mark.parametrize("shape", [(4, 64, 128, 0, 128, 0), (2, 32, 64, 64, 64, 0), (2, 64, 128, 0, 64, 1), (1, 32, 64, 128, 128, 0)])
+def test_wgrad_halo_kernel_vs_fp64(hip, shape, entry):
+    """The 3x3 weight gradient at sizes where the halo-tile kernels run (W % 32 == 0), incl. fused concat and
+    upsample, against an fp64 CPU reference: fp32 accumulation over up to 16 k pixels stays within 5e-6 relative -- on the fp32
+    MFMA pipe and in the split form (two fp16 pieces per operand, three exact MFMAs per product, transpose reads from LDS),
+    whose operands of different magnitude per source (x1 = 1e-3 x0, dY = 1e4) also exercise the per-tensor scales."""
     from nextbestpath_amd import _lib
     B, H, C0, C1, N, ups = shape
     torch.manual_seed(0)
     Hs = H // 2 if ups else H
     x0 = torch.randn(B, Hs, Hs, C0, device="cuda")
-    x1 = torch.randn(B, Hs, Hs, C1, device="cuda") if C1 else None
-    dy = torch.randn(B, H, H, N, device="cuda")
+    x1 = torch.randn(B, Hs, Hs, C1, device="cuda") * 1e-3 if C1 else None
+    dy = torch.randn(B, H, H, N, device="cuda") * 1e4
     dw = torch.empty(N, C0 + C1, 3, 3, device="cuda")
     ws = torch.empty(hip.nbp_conv_wgrad_workspace_bytes(B, H, H, C0, C1, N, 3), dtype=torch.uint8, device="cuda")
-    rc = hip.nbp_conv_wgrad_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, ups, B, H, H, 3, _lib.ptr(dy), N, C0 + C1, N,
-                                _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _lib.current_stream())
+    rc = getattr(hip, entry)(_lib.ptr(x0), C0, _lib.ptr(x1), C1, ups, B, H, H, 3, _lib.ptr(dy), N, C0 + C1, N,
+                             _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _lib.current_stream())
     assert rc == 0
     torch.cuda.synchronize()
     xin = x0 if x1 is None else torch.cat((x0, x1), 3)
@@ -328,7 +331,10 @@ def test_wgrad_halo_kernel_vs_fp64(hip, shape):
     if ups:
         xin = torch.nn.functional.interpolate(xin, scale_factor=2)
     ref = torch.nn.grad.conv2d_weight(xin, (N, C0 + C1, 3, 3), dy.permute(0, 3, 1, 2).double().cpu(), padding=1)
-    assert (dw.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6
+    d = (dw.cpu().double() - ref).abs()
+    assert d[:, :C0].max().item() / ref[:, :C0].abs().max().item() < 5e-6
+    if C1:                                              # the second source has its own scale: its block is judged on its own
+        assert d[:, C0:].max().item() / ref[:, C0:].abs().max().item() < 5e-6
 
 
 def test_training_step_vs_reference_golden(hip, nbp_weights, golden_dir):
@@ -488,9 +494,10 @@ def test_train_step_config3_shape_b32_256(hip, nbp_weights):
     assert float(np.median(rels)) < 2e-2, float(np.median(rels))
 
 
-def test_wgrad_entry_point_fuzz(hip):
-    """40 seeded random shapes through nbp_conv_wgrad_f32 (halo-tile kernel where the image allows, tap-per-workgroup
-    kernel otherwise, 1x1 and 3x3, concat, upsample, channel padding): refused or right."""
+@pytest.mark.parametrize("entry", ["nbp_conv_wgrad_f32", "nbp_conv_wgrad_split_f32"])
+def test_wgrad_entry_point_fuzz(hip, entry):
+    """40 seeded random shapes through nbp_conv_wgrad_f32 / nbp_conv_wgrad_split_f32 (halo-tile kernel where the image allows,
+    tap-per-workgroup kernel otherwise, 1x1 and 3x3, concat, upsample, channel padding): refused or right."""
     from nextbestpath_amd import _lib
     rng = np.random.default_rng(77)
     ok = refused = 0
@@ -513,8 +520,8 @@ def test_wgrad_entry_point_fuzz(hip):
         dw = torch.zeros(n_real, c_real, k, k, device="cuda")
         nws = hip.nbp_conv_wgrad_workspace_bytes(B, H, W, C0, C1, N, k)
         ws = torch.empty(max(nws, 256), dtype=torch.uint8, device="cuda")
-        rc = hip.nbp_conv_wgrad_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, ups, B, H, W, k, _lib.ptr(dy), N, c_real, n_real,
-                                    _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _lib.current_stream())
+        rc = getattr(hip, entry)(_lib.ptr(x0), C0, _lib.ptr(x1), C1, ups, B, H, W, k, _lib.ptr(dy), N, c_real, n_real,
+                                 _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _lib.current_stream())
         torch.cuda.synchronize()
         if rc != 0:
             refused += 1
