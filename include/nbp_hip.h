@@ -502,10 +502,12 @@ int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, int C1, int
                        size_t ws_bytes, void* stream);
 /* nbp_conv_wgrad_f32 with the products of the 3x3 layers on the fp16 matrix pipe: every fp32 operand (X, dY) scaled by a
  * power of two from its tensor's max |.| (computed inside), cut into two fp16 pieces, three exact MFMAs per product, fp32
- * accumulation (the scheme of nbp_conv3x3_split_f32; error vs fp64 <= the fp32 MFMA pipe's).  Same arguments and
- * workspace; layers the split kernel does not take (1x1, W % 32 != 0) run nbp_conv_wgrad_f32. */
+ * accumulation (the scheme of nbp_conv3x3_split_f32; error vs fp64 <= the fp32 MFMA pipe's).  amax*_or_null: 64-word max-|.|
+ * slots (nbp_amax_f32) of src0 / src1 / dy when the caller has them (any upper bound of the tensor's max works: e.g. the forward's
+ * joint slot for both sources), else taken inside.  Same other arguments and workspace; layers the split kernel does not take (1x1, W % 32 != 0) run nbp_conv_wgrad_f32. */
 int nbp_conv_wgrad_split_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
-                             int ksize, const float* dy, int N, int c_real, int n_real, float* dw, void* ws,
+                             int ksize, const float* dy, int N, int c_real, int n_real, float* dw,
+                             const void* amax0_or_null, const void* amax1_or_null, const void* amaxy_or_null, void* ws,
                              size_t ws_bytes, void* stream);
 /* Sparse value targets (nbp_utils.py:373-379): pred[k] = out1[b,c,x,y], coords [K,4] int64; and the
  * scatter-add of its gradient into a zeroed d_out1. */

@@ -66,7 +66,7 @@ SIGNATURES = {
     "nbp_pack_conv_weight_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "nbp_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "nbp_conv_wgrad_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "nbp_conv_wgrad_split_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "nbp_conv_wgrad_split_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "nbp_gather_values_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "nbp_scatter_values_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "nbp_loss_f32": (_i, [_i, _vp, _vp, _ll, _f, _vp, _vp, _vp, _sz, _vp]),

@@ -78,7 +78,8 @@ int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksi
 int nbp_amax_launch(const float* x, long long n, unsigned* amax_inout, hipStream_t st);
 // 3x3 weight gradient on the split scheme: partial sums [splits][9][C0 + C1][N]; amax3 = 3 x 64 words of scratch
 int nbp_wgrad_split_launch(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W, const float* dy, int N,
-                           int n_tiles, int splits, unsigned* amax3, float* part, hipStream_t st);
+                           int n_tiles, int splits, unsigned* amax3, const unsigned* amax0_in, const unsigned* amax1_in,
+                           const unsigned* amaxy_in, float* part, hipStream_t st);
 // attention gates (1x1 over K = [src0 | src1], both C channels) on the split scheme
 int nbp_pack_gate_weight_split_launch(const float* wg, const float* scale_g, const float* wx, const float* scale_x, int N, int C,
                                       void* dst, unsigned* wamax_out, hipStream_t st);

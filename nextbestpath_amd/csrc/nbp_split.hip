@@ -1149,21 +1149,24 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
 // Partial sums [splits][9][C0 + C1][N] of the 3x3 weight gradient (the caller reduces them: wgrad_reduce_kernel, nbp_train.hip).
 // amax3 = 3 x 64 zeroed words of scratch: max |src0|, max |src1|, max |dY| are computed here.
 int nbp_wgrad_split_launch(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W, const float* dy, int N,
-                           int n_tiles, int splits, unsigned* amax3, float* part, hipStream_t st) {
+                           int n_tiles, int splits, unsigned* amax3, const unsigned* amax0_in, const unsigned* amax1_in,
+                           const unsigned* amaxy_in, float* part, hipStream_t st) {
     const int Hs = ups ? H / 2 : H, Ws = ups ? W / 2 : W;
     const long long b0 = (long long)B * Hs * Ws * C0 * 4, b1 = (long long)B * Hs * Ws * C1 * 4, by = (long long)B * H * W * N * 4;
     NBP_RETURN_IF(b0 >= (1ll << 31) || b1 >= (1ll << 31) || by >= (1ll << 31), NBP_E_SHAPE);
     hipError_t e = hipMemsetAsync(amax3, 0, 3 * AMAX_WORDS * sizeof(unsigned), st);
     if (e != hipSuccess) return (int)e;
-    int rc = nbp_amax_launch(src0, b0 / 4, amax3, st);
-    if (!rc && C1) rc = nbp_amax_launch(src1, b1 / 4, amax3 + AMAX_WORDS, st);
-    if (!rc) rc = nbp_amax_launch(dy, by / 4, amax3 + 2 * AMAX_WORDS, st);
+    // a max the caller already has (the forward's input slot, the data gradient's) saves a pass over the tensor
+    int rc = amax0_in ? 0 : nbp_amax_launch(src0, b0 / 4, amax3, st);
+    if (!rc && C1 && !amax1_in) rc = nbp_amax_launch(src1, b1 / 4, amax3 + AMAX_WORDS, st);
+    if (!rc && !amaxy_in) rc = nbp_amax_launch(dy, by / 4, amax3 + 2 * AMAX_WORDS, st);
     if (rc) return rc;
     WgradSplitArgs a;
     a.src0 = src0; a.src1 = src1 ? src1 : src0; a.C0 = C0; a.C1 = C1; a.ups = ups ? 1 : 0; a.H = H; a.W = W; a.Hs = Hs; a.Ws = Ws;
     a.dy = dy; a.N = N; a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0; a.bytesy = (unsigned)by;
     a.co_tiles = N / 64; a.n_tiles = n_tiles; a.splits = splits;
-    a.amax0 = amax3; a.amax1 = amax3 + AMAX_WORDS; a.amaxy = amax3 + 2 * AMAX_WORDS; a.part = part;
+    a.amax0 = amax0_in ? amax0_in : amax3; a.amax1 = amax1_in ? amax1_in : amax3 + AMAX_WORDS;
+    a.amaxy = amaxy_in ? amaxy_in : amax3 + 2 * AMAX_WORDS; a.part = part;
     constexpr int smem = 4 * (4 * 34 * 64) + 4 * (64 * 64);
     static bool attr_set = false;
     if (!attr_set) {

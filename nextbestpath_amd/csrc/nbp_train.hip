@@ -1069,13 +1069,15 @@ extern "C" int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, 
 
 // (nbp_split.hip)
 int nbp_wgrad_split_launch(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W, const float* dy, int N,
-                           int n_tiles, int splits, unsigned* amax3, float* part, hipStream_t st);
+                           int n_tiles, int splits, unsigned* amax3, const unsigned* amax0_in, const unsigned* amax1_in,
+                           const unsigned* amaxy_in, float* part, hipStream_t st);
 
 // The same gradient with the products on the fp16 matrix pipe (two-piece operands, three exact MFMAs per product, fp32
 // accumulation; nbp_split.hip: wgrad_split_kernel) for the 3x3 layers the halo-tile form takes; everything else falls through
 // to nbp_conv_wgrad_f32.  Workspace: nbp_conv_wgrad_workspace_bytes (it includes the 768 B of max-|.| scratch).
 extern "C" int nbp_conv_wgrad_split_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
-                                        int ksize, const float* dy, int N, int c_real, int n_real, float* dw, void* ws,
+                                        int ksize, const float* dy, int N, int c_real, int n_real, float* dw,
+                                        const void* amax0_or_null, const void* amax1_or_null, const void* amaxy_or_null, void* ws,
                                         size_t ws_bytes, void* stream) {
     const bool take = ksize == 3 && wgrad_halo_ok(H, W, ksize) && (long long)B * H * W * N * 4 < (1ll << 31) && src0 && dy && dw &&
                       ws && B >= 1 && C0 >= 64 && C0 % 64 == 0 && C1 >= 0 && C1 % 64 == 0 && N >= 64 && N % 64 == 0 &&
@@ -1089,7 +1091,8 @@ extern "C" int nbp_conv_wgrad_split_f32(const float* src0, int C0, const float* 
     hipStream_t st = (hipStream_t)stream;
     unsigned* amax3 = (unsigned*)(((uintptr_t)ws + 255) / 256 * 256);
     float* part = (float*)((char*)amax3 + 1024);
-    int rc = nbp_wgrad_split_launch(src0, C0, src1, C1, ups, B, H, W, dy, N, n_tiles, splits, amax3, part, st);
+    int rc = nbp_wgrad_split_launch(src0, C0, src1, C1, ups, B, H, W, dy, N, n_tiles, splits, amax3, (const unsigned*)amax0_or_null,
+                                    (const unsigned*)amax1_or_null, (const unsigned*)amaxy_or_null, part, st);
     if (rc) return rc;
     const long long total = (long long)n_real * c_real * 9;
     wgrad_reduce_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(part, splits, 9, C0 + C1, N, c_real, n_real, dw);

@@ -101,7 +101,17 @@ def _pack_split(w_oihw, n_pad, c_total):
     return planes, wamax
 
 
-def _conv_split(src0, src1, ups, packed, N, scale, shift, relu):
+def _amax_slot(*tensors):
+    """64-word max-|.| slot (csrc/nbp_split.hip) over the given tensors: one streaming pass each, shared by every kernel that
+    scales them (forward + weight gradient for a layer's inputs; data + weight gradient for its output gradient)."""
+    slot = torch.zeros(64, dtype=torch.int32, device=tensors[0].device)
+    for t in tensors:
+        if t is not None and t.numel():
+            _chk(_lib.lib().nbp_amax_f32(_lib.ptr(t), t.numel(), _lib.ptr(slot), _st()), "amax")
+    return slot
+
+
+def _conv_split(src0, src1, ups, packed, N, scale, shift, relu, amax=None):
     L = _lib.lib()
     planes, wamax = packed
     B, Hs, Ws, C0 = src0.shape
@@ -109,9 +119,9 @@ def _conv_split(src0, src1, ups, packed, N, scale, shift, relu):
     C1 = 0 if src1 is None else src1.shape[3]
     out = torch.empty(B, H, W, N, dtype=torch.float32, device=src0.device)
     ws = _ws(L.nbp_conv_split_workspace_bytes(B, H, W, N, 0), src0.device)
-    # max |x| of the inputs is taken inside the call (amax_in NULL): autograd hands tensors over without their history
+    # max |x| of the inputs: the caller's slot, else taken inside the call (autograd hands tensors over without their history)
     _chk(L.nbp_conv3x3_split_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, _lib.ptr(planes), _lib.ptr(wamax), N,
-                                 _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), None, None, 0, _lib.ptr(ws),
+                                 _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), _lib.ptr(amax), None, 0, _lib.ptr(ws),
                                  ws.numel(), _st()), "conv3x3_split")
     return out
 
@@ -121,7 +131,7 @@ def _upconv_ok(Hs, Ws, N):
     return _SPLIT and Hs % 16 == 0 and ((Ws % 32 == 0 and N % 64 == 0) or (Ws % 16 == 0 and N % 128 == 0))
 
 
-def _upconv_split(src, w_oihw, n_pad, scale, shift):
+def _upconv_split(src, w_oihw, n_pad, scale, shift, amax=None):
     L = _lib.lib()
     N, C, _, _ = w_oihw.shape
     B, Hs, Ws, C0 = src.shape
@@ -136,7 +146,7 @@ def _upconv_split(src, w_oihw, n_pad, scale, shift):
     out = torch.empty(B, H, W, n_pad, dtype=torch.float32, device=src.device)
     ws = _ws(L.nbp_conv_split_workspace_bytes(B, H, W, n_pad, 0), src.device)
     _chk(L.nbp_upconv3x3_split_f32(_lib.ptr(src), C0, B, H, W, _lib.ptr(planes), _lib.ptr(wamax), n_pad, _lib.ptr(scale),
-                                   _lib.ptr(shift), 0, _lib.ptr(out), None, None, 0, _lib.ptr(ws), ws.numel(), _st()), "upconv3x3_split")
+                                   _lib.ptr(shift), 0, _lib.ptr(out), _lib.ptr(amax), None, 0, _lib.ptr(ws), ws.numel(), _st()), "upconv3x3_split")
     return out
 
 
@@ -157,15 +167,19 @@ class ConvFn(torch.autograd.Function):
         shift = torch.zeros(Np, dtype=torch.float32, device=dev)
         shift[:N] = bias.detach()
         H, W = (x0.shape[1] * 2, x0.shape[2] * 2) if ups else (x0.shape[1], x0.shape[2])
+        xmax = None                      # joint max-|.| slot of the inputs: taken once, reused by the weight gradient
         if ups and k == 3 and x1 is None and _upconv_ok(x0.shape[1], x0.shape[2], Np):
-            y = _upconv_split(x0, w, Np, scale, shift)
+            xmax = _amax_slot(x0)
+            y = _upconv_split(x0, w, Np, scale, shift, xmax)
         elif _split_ok(H, W, Np, k):
-            y = _conv_split(x0, x1, ups, _pack_split(w, Np, Ctot), Np, scale, shift, False)
+            xmax = _amax_slot(x0, x1)
+            y = _conv_split(x0, x1, ups, _pack_split(w, Np, Ctot), Np, scale, shift, False, xmax)
         else:
             wpk = torch.empty(Ctot // 32 * k * k * Np * 32, dtype=torch.float32, device=dev)
             _chk(L.nbp_pack_conv_weight_padded(_lib.ptr(w), N, c_real, k, Ctot, Np, _lib.ptr(wpk), _st()), "pack_fwd")
             y = _igemm(x0, x1, ups, wpk, Np, k, scale, shift, False)
         ctx.save_for_backward(x0, x1 if x1 is not None else torch.empty(0, device=dev), w)
+        ctx.xmax = xmax
         ctx.meta = (N, c_real, k, C0, C1, Np, bool(ups), x1 is not None)
         return _slice_channels(y, 0, N)
 
@@ -183,9 +197,15 @@ class ConvFn(torch.autograd.Function):
         dw = torch.empty(N, c_real, k, k, dtype=torch.float32, device=dev)
         ws = _ws(L.nbp_conv_wgrad_workspace_bytes(B, H, W, C0, C1, Np, k), dev)
         # the 3x3 weight gradients take the split scheme too (the entry point falls through to the fp32 pipe for the rest)
-        wgrad = L.nbp_conv_wgrad_split_f32 if _SPLIT and _WGRAD_SPLIT else L.nbp_conv_wgrad_f32
-        _chk(wgrad(_lib.ptr(x0), C0, _lib.ptr(x1), C1, int(ups), B, H, W, k, _lib.ptr(dy), Np, c_real, N,
-                   _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _st()), "conv_wgrad")
+        dymax = None
+        if _SPLIT and _WGRAD_SPLIT:
+            dymax = _amax_slot(dy) if k == 3 else None        # shared with the data gradient below
+            _chk(L.nbp_conv_wgrad_split_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, int(ups), B, H, W, k, _lib.ptr(dy), Np, c_real, N,
+                                            _lib.ptr(dw), _lib.ptr(ctx.xmax), _lib.ptr(ctx.xmax), _lib.ptr(dymax), _lib.ptr(ws),
+                                            ws.numel(), _st()), "conv_wgrad_split")
+        else:
+            _chk(L.nbp_conv_wgrad_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, int(ups), B, H, W, k, _lib.ptr(dy), Np, c_real, N,
+                                      _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _st()), "conv_wgrad")
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             Ctot = C0 + C1
@@ -194,7 +214,7 @@ class ConvFn(torch.autograd.Function):
             if _split_ok(H, W, Ctot, k):
                 # dx = conv3x3(dy, w^T with the taps reversed): output channels = the (padded) input channels
                 wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()                # [c_real, N, 3, 3]
-                dx = _conv_split(dy, None, False, _pack_split(wt, Ctot, Np), Ctot, one, zero, False)
+                dx = _conv_split(dy, None, False, _pack_split(wt, Ctot, Np), Ctot, one, zero, False, dymax)
             else:
                 wt = torch.empty(Np // 32 * k * k * Ctot * 32, dtype=torch.float32, device=dev)
                 _chk(L.nbp_pack_conv_weight_dgrad(_lib.ptr(w), N, c_real, k, Ctot, Np, _lib.ptr(wt), _st()), "pack_dgrad")

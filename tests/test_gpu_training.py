@@ -322,8 +322,9 @@ def test_wgrad_halo_kernel_vs_fp64(hip, shape, entry):
     dy = torch.randn(B, H, H, N, device="cuda") * 1e4
     dw = torch.empty(N, C0 + C1, 3, 3, device="cuda")
     ws = torch.empty(hip.nbp_conv_wgrad_workspace_bytes(B, H, H, C0, C1, N, 3), dtype=torch.uint8, device="cuda")
+    extra = (None, None, None) if "split" in entry else ()
     rc = getattr(hip, entry)(_lib.ptr(x0), C0, _lib.ptr(x1), C1, ups, B, H, H, 3, _lib.ptr(dy), N, C0 + C1, N,
-                             _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _lib.current_stream())
+                             _lib.ptr(dw), *extra, _lib.ptr(ws), ws.numel(), _lib.current_stream())
     assert rc == 0
     torch.cuda.synchronize()
     xin = x0 if x1 is None else torch.cat((x0, x1), 3)
@@ -520,8 +521,9 @@ def test_wgrad_entry_point_fuzz(hip, entry):
         dw = torch.zeros(n_real, c_real, k, k, device="cuda")
         nws = hip.nbp_conv_wgrad_workspace_bytes(B, H, W, C0, C1, N, k)
         ws = torch.empty(max(nws, 256), dtype=torch.uint8, device="cuda")
+        extra = (None, None, None) if "split" in entry else ()
         rc = getattr(hip, entry)(_lib.ptr(x0), C0, _lib.ptr(x1), C1, ups, B, H, W, k, _lib.ptr(dy), N, c_real, n_real,
-                                 _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _lib.current_stream())
+                                 _lib.ptr(dw), *extra, _lib.ptr(ws), ws.numel(), _lib.current_stream())
         torch.cuda.synchronize()
         if rc != 0:
             refused += 1

@@ -20,8 +20,9 @@ for B, H, C0, C1, N, ups, c_real, n_real in shapes:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for k in range(2):
             e0.record()
+            extra = (None, None, None) if "split" in entry else ()
             rc = getattr(L, entry)(_lib.ptr(x0), C0, _lib.ptr(x1), C1, ups, B, H, H, 3, _lib.ptr(dy), N, c_real, n_real,
-                                   _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _lib.current_stream())
+                                   _lib.ptr(dw), *extra, _lib.ptr(ws), ws.numel(), _lib.current_stream())
             e1.record()
         torch.cuda.synchronize()
         assert rc == 0, (entry, rc)
