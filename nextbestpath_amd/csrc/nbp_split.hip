@@ -661,9 +661,12 @@ __device__ __forceinline__ f16x8 tr_frag(const char* p) {      // 8 consecutive 
     return __builtin_bit_cast(f16x8, v);
 }
 
+// TW = tile width: 2 x 32 pixels, or 4 x 16 for the 16-pixel-wide level
+template <int TW>
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
-    constexpr int HW_ = 34, HP = 4 * HW_;                      // halo pixels of a 2 x 32 tile
-    constexpr int XPL = HP * 64, YPL = 64 * 64;                // bytes of one (plane, channel half) region
+    constexpr int TR = 64 / TW, HW_ = TW + 2, HP = (TR + 2) * HW_;      // tile rows; halo pixels of the tile
+    constexpr int NX = (HP * 16 + 255) / 256;                          // float4 items of the X halo per thread
+    constexpr int XPL = HP * 64, YPL = 64 * 64;                        // bytes of one (plane, channel half) region
     constexpr int XB = 4 * XPL;                                // X: [plane][half] regions, then dY alike
     extern __shared__ __attribute__((aligned(16))) char wl[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
         const_cast<float*>(first ? a.src0 : a.src1), 0, first ? a.bytes0 : a.bytes1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.bytesy, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    const int tiles_x = a.W >> 5, tiles_y = a.H >> 1;
+    const int tiles_x = a.W / TW, tiles_y = a.H / TR;
     const int ex = amax_exponent(read_amax(first ? a.amax0 : a.amax1)), ey = amax_exponent(read_amax(a.amaxy));
     const float sx = pow2f(12 - ex), sy = pow2f(12 - ey);
     const int einv = ex + ey - 24;
@@ -703,10 +706,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
         const int b = t / tiles_y;
-        const int y0 = ty * 2, x0 = tx * 32;
-        u32x4 xr[9], yr[4];
+        const int y0 = ty * TR, x0 = tx * TW;
+        u32x4 xr[NX], yr[4];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {          // X halo: 136 pixels x 16 float4
+        for (int k = 0; k < NX; ++k) {         // X halo: HP pixels x 16 float4
             const int f = tid + 256 * k;
             const int hr = f >> 4;
             const int hy = hr / HW_, hx = hr - hy * HW_;
@@ -718,12 +721,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {          // dY: 64 pixels x 16 float4
             const int pz = (tid + 256 * k) >> 4;
-            const long long m = ((long long)b * a.H + y0 + (pz >> 5)) * a.W + x0 + (pz & 31);
+            const long long m = ((long long)b * a.H + y0 + pz / TW) * a.W + x0 + pz % TW;
             yr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (unsigned)((m * a.N + co0 + c4 * 4) * 4), 0, 0);
         }
         __syncthreads();                       // every wave is done with the previous tile's planes
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k < NX; ++k) {
             const int hr = (tid + 256 * k) >> 4;
             if (hr >= HP) continue;
             const f32x4 v = __builtin_bit_cast(f32x4, xr[k]);
@@ -747,10 +750,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < TR; ++r)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int p0 = r * 32 + 16 * s;                               // first of the step's 16 pixels
+            for (int s = 0; s < TW / 16; ++s) {
+                const int p0 = r * TW + 16 * s;                               // first of the step's 16 pixels
                 const f16x8 bh = tr_frag(yb_hi + p0 * 64), bl = tr_frag(yb_lo + p0 * 64);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
@@ -1167,15 +1170,21 @@ int nbp_wgrad_split_launch(const float* src0, int C0, const float* src1, int C1,
     a.co_tiles = N / 64; a.n_tiles = n_tiles; a.splits = splits;
     a.amax0 = amax0_in ? amax0_in : amax3; a.amax1 = amax1_in ? amax1_in : amax3 + AMAX_WORDS;
     a.amaxy = amaxy_in ? amaxy_in : amax3 + 2 * AMAX_WORDS; a.part = part;
-    constexpr int smem = 4 * (4 * 34 * 64) + 4 * (64 * 64);
+    const bool wide = W % 32 == 0 && H % 2 == 0;              // 2 x 32 tiles, else 4 x 16 (nbp_wgrad_split_ok)
+    const int smem = wide ? 4 * (4 * 34 * 64) + 4 * (64 * 64) : 4 * (6 * 18 * 64) + 4 * (64 * 64);
     static bool attr_set = false;
     if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                4 * (4 * 34 * 64) + 4 * (64 * 64));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    4 * (6 * 18 * 64) + 4 * (64 * 64));
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((unsigned)(((C0 + C1) / 64) * (N / 64)), (unsigned)splits);
-    wgrad_split_kernel<<<grid, 256, smem, st>>>(a);
+    if (wide) wgrad_split_kernel<32><<<grid, 256, smem, st>>>(a);
+    else wgrad_split_kernel<16><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 

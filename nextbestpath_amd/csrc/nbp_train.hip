@@ -1004,6 +1004,10 @@ extern "C" size_t nbp_conv_wgrad_workspace_bytes(int B, int H, int W, int C0, in
         int nt, hs;
         wgrad_halo_plan(B, H, W, C0 + C1, N, &nt, &hs);
         if (hs > sp) sp = hs;
+    } else if (ksize == 3 && H >= 4 && W >= 16 && !(H & 3) && !(W & 15)) {      // the split form's 4 x 16 tiles
+        int nt, hs;
+        wgrad_halo_plan(B, H / 2, W * 2, C0 + C1, N, &nt, &hs);
+        if (hs > sp) sp = hs;
     }
     return (size_t)sp * ksize * ksize * (C0 + C1) * N * sizeof(float) + 256 + 1024;     // + max-|.| scratch of the split form
 }
@@ -1079,14 +1083,15 @@ extern "C" int nbp_conv_wgrad_split_f32(const float* src0, int C0, const float* 
                                         int ksize, const float* dy, int N, int c_real, int n_real, float* dw,
                                         const void* amax0_or_null, const void* amax1_or_null, const void* amaxy_or_null, void* ws,
                                         size_t ws_bytes, void* stream) {
-    const bool take = ksize == 3 && wgrad_halo_ok(H, W, ksize) && (long long)B * H * W * N * 4 < (1ll << 31) && src0 && dy && dw &&
+    const bool wide = wgrad_halo_ok(H, W, ksize), narrow = !wide && ksize == 3 && H >= 4 && W >= 16 && !(H & 3) && !(W & 15);
+    const bool take = ksize == 3 && (wide || narrow) && (long long)B * H * W * N * 4 < (1ll << 31) && src0 && dy && dw &&
                       ws && B >= 1 && C0 >= 64 && C0 % 64 == 0 && C1 >= 0 && C1 % 64 == 0 && N >= 64 && N % 64 == 0 &&
                       (C1 == 0 || src1) && !(ups && ((H | W) & 1));
     if (!take) return nbp_conv_wgrad_f32(src0, C0, src1, C1, ups, B, H, W, ksize, dy, N, c_real, n_real, dw, ws, ws_bytes, stream);
     NBP_ENTER();
     NBP_RETURN_IF(c_real < 1 || c_real > C0 + C1 || n_real < 1 || n_real > N, NBP_E_ARG);
     int n_tiles, splits;
-    wgrad_halo_plan(B, H, W, C0 + C1, N, &n_tiles, &splits);
+    wgrad_halo_plan(B, wide ? H : H / 2, wide ? W : W * 2, C0 + C1, N, &n_tiles, &splits);      // 64-pixel tiles either way
     NBP_RETURN_IF(ws_bytes < (size_t)splits * 9 * (C0 + C1) * N * sizeof(float) + 256 + 1024, NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;
     unsigned* amax3 = (unsigned*)(((uintptr_t)ws + 255) / 256 * 256);

@@ -307,10 +307,11 @@ def test_trainer_loop_reduces_loss(hip, tmp_path):
 
 
 @pytest.mark.parametrize("entry", ["nbp_conv_wgrad_f32", "nbp_conv_wgrad_split_f32"])
-@pytest.mark.parametrize("shape", [(4, 64, 128, 0, 128, 0), (2, 32, 64, 64, 64, 0), (2, 64, 128, 0, 64, 1), (1, 32, 64, 128, 128, 0)])
+@pytest.mark.parametrize("shape", [(4, 64, 128, 0, 128, 0), (2, 32, 64, 64, 64, 0), (2, 64, 128, 0, 64, 1), (1, 32, 64, 128, 128, 0),
+                                   (3, 16, 128, 0, 64, 0), (2, 16, 128, 128, 128, 0), (2, 16, 128, 0, 64, 1)])
 def test_wgrad_halo_kernel_vs_fp64(hip, shape, entry):
     """The 3x3 weight gradient at sizes where the halo-tile kernels run (W % 32 == 0), incl. fused concat and
-    upsample, against an fp64 CPU reference: fp32 accumulation over up to 16 k pixels stays within 5e-6 relative -- on the fp32
+    upsample (and at W = 16, where the split form walks 4 x 16 tiles), against an fp64 CPU reference: fp32 accumulation over up to 16 k pixels stays within 5e-6 relative -- on the fp32
     MFMA pipe and in the split form (two fp16 pieces per operand, three exact MFMAs per product, transpose reads from LDS),
     whose operands of different magnitude per source (x1 = 1e-3 x0, dY = 1e4) also exercise the per-tensor scales."""
     from nextbestpath_amd import _lib
@@ -505,7 +506,7 @@ def test_wgrad_entry_point_fuzz(hip, entry):
     for trial in range(40):
         B = int(rng.integers(1, 3))
         H = int(rng.choice([2, 4, 6, 8]))
-        W = int(rng.choice([2, 8, 32, 64]))
+        W = int(rng.choice([2, 8, 16, 32, 64]))
         C0 = int(rng.choice([64, 128]))
         C1 = int(rng.choice([0, 0, 64]))
         N = int(rng.choice([64, 128]))
