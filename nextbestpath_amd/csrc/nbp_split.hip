@@ -750,20 +750,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < TR; ++r)
+        for (int r = 0; r < TR; ++r) {
+            // the row offset is made opaque to the compiler: left visible, it keeps the fragments of the halo rows that tile rows r
+            // and r + 1 share ((r, dy + 1) = (r + 1, dy)) in registers across the r iterations and spills 36 dwords around the
+            // staging; re-reading them costs 48 more transpose reads per tile and is 1.5x faster (1.20 -> 0.78 ms at 256^2, 64 x 64)
+            int rofs = r * HW_ * 64;
+            asm volatile("" : "+v"(rofs));
 #pragma unroll
             for (int s = 0; s < TW / 16; ++s) {
                 const int p0 = r * TW + 16 * s;                               // first of the step's 16 pixels
                 const f16x8 bh = tr_frag(yb_hi + p0 * 64), bl = tr_frag(yb_lo + p0 * 64);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    const int hp0 = (r + tap / 3) * HW_ + 16 * s + tap % 3;   // halo pixel of (row r + dy, column 16 s + dx)
-                    const f16x8 ah = tr_frag(xa_hi + hp0 * 64), al = tr_frag(xa_lo + hp0 * 64);
+                    const int hp0 = (tap / 3) * HW_ + 16 * s + tap % 3;       // halo pixel of (row r + dy, column 16 s + dx), less row r
+                    const f16x8 ah = tr_frag(xa_hi + rofs + hp0 * 64), al = tr_frag(xa_lo + rofs + hp0 * 64);
                     acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[tap], 0, 0, 0);
                     acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[tap], 0, 0, 0);
                     acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[tap], 0, 0, 0);
                 }
             }
+        }
     }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
