@@ -719,16 +719,26 @@ static void wgrad_halo_plan(int B, int H, int W, int Ctot, int N, int* n_tiles, 
 }
 
 // dW OIHW [N][Creal][taps] = sum_s part[s][tap][ci][co]   (ci < Creal: padded input channels are dropped)
+// One thread per (tap, ci, co) with co fastest: the reads of the `splits` slices are coalesced (the OIHW order made consecutive
+// threads read Ctot * N floats apart: 104 us per call for 75 MB of partials); four slices in flight, added in slice order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int taps, int Ctot, int N,
                                                            int Creal, int Nreal, float* __restrict__ dw) {
     const long long total = (long long)Nreal * Creal * taps;
+    const long long slice = (long long)taps * Ctot * N;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int tap = (int)(i % taps);
-        long long t = i / taps;
-        const int ci = (int)(t % Creal), co = (int)(t / Creal);
+        const int co = (int)(i % Nreal);
+        long long t = i / Nreal;
+        const int ci = (int)(t % Creal), tap = (int)(t / Creal);
+        const float* p = part + ((long long)tap * Ctot + ci) * N + co;
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(((long long)k * taps + tap) * Ctot + ci) * N + co];
-        dw[i] = s;
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {
+            const float v0 = p[(long long)k * slice], v1 = p[(long long)(k + 1) * slice], v2 = p[(long long)(k + 2) * slice],
+                        v3 = p[(long long)(k + 3) * slice];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < splits; ++k) s += p[(long long)k * slice];
+        dw[((long long)co * Creal + ci) * taps + tap] = s;
     }
 }
 
