@@ -975,6 +975,11 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
     if (sk <= 0) {      // split-K over whole chunks until one workgroup per CU exists (each slice keeps >= 64 channels)
         sk = 1;
         while (blocks * sk < min_blocks && cc / (sk * 2) >= 4 && sk < 16) sk *= 2;
+        // one more halving of K towards two workgroups per CU, but only while a slice keeps >= deep_chunks 16-channel chunks: the
+        // fixed cost of a workgroup (first halo, epilogue, its share of the reduce) is ~1.5 chunks (NBP_SPLIT_DEEP, 0 = off; measured
+        // B = 12: 5.07 -> 5.02 ms, B = 8 / 1 unchanged, B = 4 +0.6 %; with 8 chunks B = 4 loses 2.5 %)
+        static const int deep = [] { const char* e = getenv("NBP_SPLIT_DEEP"); return e ? atoi(e) : 16; }();
+        if (deep > 0 && blocks * sk < 2 * min_blocks && cc / (sk * 2) >= deep && sk < 16) sk *= 2;
     }
     if (sk > cc) sk = cc;
     const int per = (int)nbp_cdiv(cc, sk);
