@@ -296,14 +296,18 @@ def test_trainer_loop_reduces_loss(hip, tmp_path):
     with torch.no_grad():
         v0 = T.validation_model(db[:8], params, net, D)
     net.train()
-    losses = []
-    for ep in range(3):
-        losses += T.train_experience_data(list(db), params, opt, net, D, current_epoch=2)
+    per_epoch = []
+    for ep in range(4):
+        per_epoch.append(T.train_experience_data(list(db), params, opt, net, D, current_epoch=2))
     net.eval()
     with torch.no_grad():
         v1 = T.validation_model(db[:8], params, net, D)
+    losses = [v for e in per_epoch for v in e]
     assert all(np.isfinite(losses)) and np.isfinite(v0) and np.isfinite(v1)
-    assert v1 < v0, (v0, v1)           # a few AdamW steps on its own data must reduce MSE + BCE
+    # AdamW steps on its own data must reduce MSE + BCE: judged on the train-mode losses of the last epoch against the first
+    # (the eval-mode loss right after a handful of steps rides on BatchNorm running statistics that have barely moved from their
+    # initial values and was seen on either side of v0 from run to run)
+    assert np.mean(per_epoch[-1]) < np.mean(per_epoch[0]), (per_epoch[0], per_epoch[-1], v0, v1)
 
 
 @pytest.mark.parametrize("entry", ["nbp_conv_wgrad_f32", "nbp_conv_wgrad_split_f32"])
