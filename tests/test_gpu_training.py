@@ -287,7 +287,8 @@ def test_trainer_loop_reduces_loss(hip, tmp_path):
     import types
     from nextbestpath_amd.networks.nbp_model import NBP
     from nextbestpath_amd.trainers import train_nbp_model as T
-    torch.manual_seed(3)
+    import random
+    torch.manual_seed(3); random.seed(3); np.random.seed(3)      # the batch order is shuffled with the global generators, as in the reference
     params = types.SimpleNamespace(nbp_batch_size=4)
     db = T.make_synthetic_experiences(16, S=64, seed=5)
     net = NBP().to(D)
