@@ -89,7 +89,9 @@ def _split_ok(H, W, N, ksize):
 def _pack_split(w_oihw, n_pad, c_total):
     """OIHW fp32 [N, C, 3, 3] -> (hi/lo fp16 planes for N padded to n_pad rows and C to c_total channels, max |w| word)."""
     N, C, k, _ = w_oihw.shape
-    planes = torch.zeros(c_total // 16 * 9 * 4 * n_pad * 8, dtype=torch.int16, device=w_oihw.device)
+    # the pack kernel writes every plane entry of the channels it is given: only padded channels need the zero fill
+    alloc = torch.zeros if C != c_total else torch.empty
+    planes = alloc(c_total // 16 * 9 * 4 * n_pad * 8, dtype=torch.int16, device=w_oihw.device)
     wamax = torch.zeros(1, dtype=torch.int32, device=w_oihw.device)
     # the pack kernel indexes rows by the padded count: give it a zero-padded weight when N < n_pad
     if N != n_pad:
@@ -99,6 +101,18 @@ def _pack_split(w_oihw, n_pad, c_total):
     _chk(_lib.lib().nbp_pack_conv_weight_split(_lib.ptr(w_oihw), n_pad, C, 3, None, 0, c_total, _lib.ptr(planes), _lib.ptr(wamax),
                                                _st()), "pack_split")
     return planes, wamax
+
+
+_CONST = {}
+
+
+def _const(value, n, device):
+    """Read-only vector of n copies of `value` (epilogue scales / shifts that are all ones or zeros): one fill per size, not per call."""
+    key = (float(value), int(n), str(device))
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full((n,), float(value), dtype=torch.float32, device=device)
+    return t
 
 
 def _amax_slot(*tensors):
@@ -163,7 +177,7 @@ class ConvFn(torch.autograd.Function):
         Ctot, Np = C0 + C1, _up(N)
         dev = x0.device
         w = weight.detach().contiguous()
-        scale = torch.ones(Np, dtype=torch.float32, device=dev)
+        scale = _const(1.0, Np, dev)
         shift = torch.zeros(Np, dtype=torch.float32, device=dev)
         shift[:N] = bias.detach()
         H, W = (x0.shape[1] * 2, x0.shape[2] * 2) if ups else (x0.shape[1], x0.shape[2])
@@ -209,8 +223,7 @@ class ConvFn(torch.autograd.Function):
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             Ctot = C0 + C1
-            one = torch.ones(Ctot, dtype=torch.float32, device=dev)
-            zero = torch.zeros(Ctot, dtype=torch.float32, device=dev)
+            one, zero = _const(1.0, Ctot, dev), _const(0.0, Ctot, dev)
             if _split_ok(H, W, Ctot, k):
                 # dx = conv3x3(dy, w^T with the taps reversed): output channels = the (padded) input channels
                 wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()                # [c_real, N, 3, 3]
