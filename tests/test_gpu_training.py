@@ -344,6 +344,46 @@ def test_wgrad_halo_kernel_vs_fp64(hip, shape, entry):
         assert d[:, C0:].max().item() / ref[:, C0:].abs().max().item() < 5e-6
 
 
+def test_wgrad_split_with_the_callers_amax_slots(hip):
+    """nbp_conv_wgrad_split_f32 with the max-|.| slots handed in (as networks/training.py does: the forward's JOINT slot for both
+    sources, the data gradient's slot for dY) against the slots taken inside, and against fp64; a slot that overstates the max
+    (any upper bound is a valid scale) must still give the fp32-level answer."""
+    from nextbestpath_amd import _lib
+    B, H, C0, C1, N = 2, 32, 64, 64, 64
+    torch.manual_seed(4)
+    x0 = torch.randn(B, H, H, C0, device="cuda")
+    x1 = torch.randn(B, H, H, C1, device="cuda") * 0.05
+    dy = torch.randn(B, H, H, N, device="cuda") * 3e-3
+    ws = torch.empty(hip.nbp_conv_wgrad_workspace_bytes(B, H, H, C0, C1, N, 3), dtype=torch.uint8, device="cuda")
+
+    def slot(*ts, factor=1.0):
+        s = torch.zeros(64, dtype=torch.int32, device="cuda")
+        for t in ts:
+            t = t * factor if factor != 1.0 else t
+            assert hip.nbp_amax_f32(_lib.ptr(t.contiguous()), t.numel(), _lib.ptr(s), _lib.current_stream()) == 0
+        return s
+
+    def run(a0, a1, ay):
+        dw = torch.empty(N, C0 + C1, 3, 3, device="cuda")
+        rc = hip.nbp_conv_wgrad_split_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, 0, B, H, H, 3, _lib.ptr(dy), N, C0 + C1, N, _lib.ptr(dw),
+                                          _lib.ptr(a0), _lib.ptr(a1), _lib.ptr(ay), _lib.ptr(ws), ws.numel(), _lib.current_stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        return dw.cpu().double()
+
+    xin = torch.cat((x0, x1), 3).permute(0, 3, 1, 2).double().cpu()
+    ref = torch.nn.grad.conv2d_weight(xin, (N, C0 + C1, 3, 3), dy.permute(0, 3, 1, 2).double().cpu(), padding=1)
+    inside = run(None, None, None)
+    joint = slot(x0, x1)
+    given = run(joint, joint, slot(dy))
+    loose = run(slot(x0, x1, factor=37.0), slot(x0, x1, factor=37.0), slot(dy, factor=5.0))
+    for got in (inside, given, loose):
+        assert (got[:, :C0] - ref[:, :C0]).abs().max() / ref[:, :C0].abs().max() < 5e-6
+    # the second source is 20x smaller than the joint max: its block loses those bits of the hi piece, not more
+    assert (given[:, C0:] - ref[:, C0:]).abs().max() / ref[:, C0:].abs().max() < 5e-5
+    assert (inside[:, C0:] - ref[:, C0:]).abs().max() / ref[:, C0:].abs().max() < 5e-6
+
+
 def test_training_step_vs_reference_golden(hip, nbp_weights, golden_dir):
     """HIP train-mode forward + loss against the REFERENCE module's own outputs (tests/golden/nbp_train_S32B2.npz);
     gradients (ill conditioned at this size, see above) in relative L2 over the strided samples."""
