@@ -130,7 +130,10 @@ def _step_both_and_compare(hip_ro, ora, n_steps):
         d1, d2 = d1[0].numpy(), d2[0, 0].numpy()
         rng1 = max(1.0, float(np.abs(d1).max()))
         e_hip, e_cpu = np.abs(h1 - d1), np.abs(o1 - d1)
-        assert e_hip.max() <= 5e-4 * rng1 and e_hip.mean() <= 2e-6 * rng1, (s, e_hip.max(), e_hip.mean(), rng1)
+        # (an input on which fp32 itself is ill conditioned -- seen at step 20 of another scene: stock torch fp32 2.6 off on a
+        # range of 3968, 100x its usual error, the fp32 MFMA pipe 11, the split path 9 -- is judged against torch's error there)
+        assert e_hip.max() <= max(5e-4 * rng1, 8.0 * e_cpu.max()) and e_hip.mean() <= max(2e-6 * rng1, 8.0 * e_cpu.mean()), \
+            (s, e_hip.max(), e_hip.mean(), e_cpu.max(), e_cpu.mean(), rng1)
         # (one accumulation chain per output on the matrix pipe; the CPU library accumulates in blocks: 3-7x its mean error)
         assert e_hip.mean() <= 8.0 * e_cpu.mean() + 1e-7 * rng1, (s, e_hip.mean(), e_cpu.mean())
         assert np.abs(h2 - d2).max() < 1e-4
