@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="skip the rocprofv3 PMC passes (use the committed profile)")
     ap.add_argument("--no-extra-stages", action="store_true", help="skip the train-step / bf16 / window stages (profiling runs)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling stage (configs[3]: 40 fixed hard scenes)")
+    ap.add_argument("--strong-scenes", type=int, default=40)
+    ap.add_argument("--strong-advance", type=int, default=10, help="un-timed steps before the strong-scaling window")
     ap.add_argument("--layers", action="store_true", help="per-layer timing table to stderr")
     ap.add_argument("--faces", choices=["simple", "hard"], default="simple")
     ap.add_argument("--rollouts-per-gpu", type=int, default=24,
@@ -148,9 +151,9 @@ def live_traffic(n_points, precision="fp32", batch=12):
 
 
 def committed_traffic(kernel_prefix, which):
-    """Fallback: the same quantity from the committed rocprofv3 summaries (profiles/r02, else r01)."""
+    """Fallback: the same quantity from the newest committed rocprofv3 summaries (profiles/r03, r02, r01)."""
     import csv
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, which)
         if not os.path.exists(path):
             continue
@@ -197,7 +200,8 @@ def main():
     dist = None
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     backend = os.environ.get("NBP_DIST_BACKEND", "nccl")      # "gloo" only to smoke-test N > 1 on a 1-GPU box
-    if world > 1:
+    if world > 1 or all(k in os.environ for k in ("WORLD_SIZE", "RANK", "MASTER_ADDR", "MASTER_PORT")):
+        # under torchrun also with ONE rank: barrier and max-over-ranks then run through RCCL on the single GPU
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -228,12 +232,13 @@ def main():
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()
 
-    def make_rollout(k):
-        name = f"maze{k}"
-        if args.faces == "hard":
-            make_maze_scene(os.path.join(tmp, name), seed=100 + 16 * rank + k, cells=12, size=7.2, height=1.2, tess=0.15)
+    def make_rollout(k, hard=(args.faces == "hard"), scene_seed=None, name=None):
+        name = name or f"maze{k}"
+        scene_seed = 100 + 16 * rank + k if scene_seed is None else scene_seed
+        if hard:
+            make_maze_scene(os.path.join(tmp, name), seed=scene_seed, cells=12, size=7.2, height=1.2, tess=0.15)
         else:
-            make_maze_scene(os.path.join(tmp, name), seed=100 + 16 * rank + k, cells=10, size=6.0, height=1.2, tess=0.25)
+            make_maze_scene(os.path.join(tmp, name), seed=scene_seed, cells=10, size=6.0, height=1.2, tess=0.25)
         ds = sc.SceneDataset(tmp, [name])
         settings = sc.Settings(ds[0]["settings"], params.scene_scale_factor)
         mesh = sc.load_scene(os.path.join(tmp, name, ds[0]["obj_name"]), params.scene_scale_factor, dev)
@@ -292,21 +297,88 @@ def main():
     run_steps(args.warmup)
     first_step = adv + args.warmup
     n0 = cloud_points()
-    sync_all()
+    def timed_steps(n):
+        """n lock-steps bracketed by barrier + synchronize on both sides, MAX over ranks (the contract's timed region)"""
+        sync_all()
+        t0 = time.perf_counter()
+        run_steps(n)
+        sync_all()
+        d = time.perf_counter() - t0
+        mine = d
+        if dist is not None:
+            tt = torch.tensor([d], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt.item())
+        return d, mine
+
     replans0 = sum(r.n_replans for r in rollouts)
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, _ = timed_steps(args.steps)
     n1 = cloud_points()
     replans_timed = sum(r.n_replans for r in rollouts) - replans0
     last_step = first_step + args.steps
     windows["timed"] = {"steps": [first_step, last_step], "steps_per_s": round(args.steps * R / dt, 2),
                         "cloud_points_start": n0, "cloud_points_end": n1}
+    # ---- the same rollouts on the strict fp32 MFMA pipe (v_mfma_f32_32x32x2_f32; NBP_CONV_PRECISION=fp32 makes it the headline
+    # path): a shorter window right after the headline's, reported as value_fp32_pipe
+    fp32_pipe = None
+    if net.conv_precision != "fp32" and not args.no_extra_stages:
+        default_precision = net.conv_precision
+        torch.cuda.synchronize()        # nothing in flight on the pack that the switch replaces
+        net.conv_precision = "fp32"
+        k32 = max(2, min(10, args.steps // 2))
+        run_steps(2)                    # the first step re-packs the weights for the fp32 pipe (outside the timed window)
+        dt32, _ = timed_steps(k32)
+        torch.cuda.synchronize()
+        net.conv_precision = default_precision
+        run_steps(1)                    # back on the default pack
+        fp32_pipe = {"value": round(k32 * world * R / dt32, 3), "unit": "steps/s", "steps": k32,
+                     "window_steps": [last_step + 2, last_step + 2 + k32], "ms_per_step": round(dt32 / k32 * 1e3, 4),
+                     "conv_arithmetic": "fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), everything else identical"}
+        last_step += 3 + k32
+
+    # ---- strong scaling (BASELINE configs[3]): a FIXED set of 40 AiMDoom_hard-like scenes (12 x 12 cells, ~30 k faces), scene i on
+    # rank i % world -- the partitioning of test_nbp_planning.py -- every rank steps its share in lock-step; the job's time is the
+    # slowest rank's.  Reported beside the weak-scaling headline so that one `--gpus N` sweep yields both curves.
+    strong = None
+    if not args.no_strong:
+        n_scenes = args.strong_scenes
+        mine_ids = list(range(rank, n_scenes, world))
+        s_rollouts = [make_rollout(i, hard=True, scene_seed=5000 + i, name=f"hard{i}") for i in mine_ids]
+        faces_mine = [int(r.mesh.faces.shape[0]) for r in s_rollouts]
+        s_multi = tp.MultiRollout(s_rollouts, net, dev) if s_rollouts else None
+
+        def s_steps(n):
+            if s_multi is not None:
+                for _ in range(n):
+                    s_multi.step()
+                s_multi.flush()
+        s_steps(args.strong_advance)
+        sync_all()
+        t0s = time.perf_counter()
+        s_steps(args.steps)
+        torch.cuda.synchronize()
+        mine_s = time.perf_counter() - t0s          # this rank's own time (before the barrier): the imbalance measure
+        sync_all()
+        dts = time.perf_counter() - t0s
+        per_rank = [mine_s]
+        if dist is not None:
+            cdev = dev if backend == "nccl" else "cpu"
+            tt = torch.tensor([dts], device=cdev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = float(tt.item())
+            allr = [torch.zeros(1, device=cdev, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(allr, torch.tensor([mine_s], device=cdev, dtype=torch.float64))
+            per_rank = [float(t.item()) for t in allr]
+        strong = {"workload": f"configs[3]: {n_scenes} fixed AiMDoom_hard-like scenes (seeds 5000..{5000 + n_scenes - 1}, 12 x 12 cells, "
+                              f"{min(faces_mine) if faces_mine else 0}-{max(faces_mine) if faces_mine else 0} faces on rank 0), scene i on "
+                              "rank i % n_gpus, 256x256 grid, default conv arithmetic",
+                  "scaling": "strong", "value": round(n_scenes * args.steps / dts, 3), "unit": "steps/s", "n_gpus": world,
+                  "steps": args.steps, "advance": args.strong_advance, "ms_per_step": round(dts / args.steps * 1e3, 4),
+                  "scenes_per_rank": [len(range(r, n_scenes, world)) for r in range(world)],
+                  "per_rank_s": [round(v, 5) for v in per_rank],
+                  "imbalance_max_over_mean": round(max(per_rank) / (sum(per_rank) / len(per_rank)), 4)}
+        del s_rollouts, s_multi
+        torch.cuda.empty_cache()
 
     roofline = scatter = None
     stage = {}
@@ -333,8 +405,14 @@ def main():
         dom = max(by_tile, key=lambda k: by_tile[k]["flops"])
         d = by_tile[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        # FLOP accounting: `flops` of a row is the REFERENCE FORMULATION's (2 M N K of the layer as nbp_model.py states it); the
+        # up_conv layers run as four 2x2 parity convolutions of the low-resolution input and EXECUTE 4/9 of that
+        def executed(r):
+            return r["flops"] * (4.0 / 9.0 if r["tile"] == 11 else 1.0)
         cf = sum(r["flops"] for r in layer_rows if r["tile"] > 0)
+        cfx = sum(executed(r) for r in layer_rows if r["tile"] > 0)
         cm = sum(r["ms"] for r in layer_rows if r["tile"] > 0)
+        exec_factor = sum(executed(r) for r in layer_rows) / max(sum(r["flops"] for r in layer_rows), 1.0)
 
         # algorithmic bytes of those launches: sources + packed weights + output, each once
         def layer_bytes(r):
@@ -361,7 +439,9 @@ def main():
                     "peak": round(peak, 2), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "peak_basis": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product (algorithmic fp32 flops)"
                                    if dom in SPLIT_TILES else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
-                    "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "frac_basis": "executed == algorithmic FLOPs for this kernel (plain 3x3 layers; the parity up_conv kernel is "
+                                  "listed under by_kernel with both counts)",
+                    "speedup_vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 3),
                     "issued_mfma_tflops": round(achieved * (3 if dom in SPLIT_TILES else 1), 1),
                     # a pure MFMA stream with random operand bits sustains 1709 TFLOP/s on this part (power-limited clocks;
                     # tools/probes/mfma_f16_probe.hip, profiles/r02/mfma_f16_probe.txt): 2444 with all-ones operands
@@ -373,8 +453,15 @@ def main():
                     "launches_per_forward": d["launches"],
                     "avg_launch_ms": round(d["ms"] / d["launches"], 5), "flops_per_launch": d["flops"] / d["launches"],
                     "note": "avg_launch_ms: HIP event pair per layer on the launch stream (a split-K layer includes its reduce)",
-                    "all_igemm_tflops": round(cf / (cm * 1e-3) / 1e12, 3),
-                    "all_igemm_frac_of_f32_mfma_peak": round(cf / (cm * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                    "all_conv_tflops_executed": round(cfx / (cm * 1e-3) / 1e12, 3),
+                    "all_conv_frac_executed": round(cfx / (cm * 1e-3) / 1e12 / peak, 4),
+                    "all_conv_tflops_reference_formulation": round(cf / (cm * 1e-3) / 1e12, 3),
+                    "by_kernel": {TILE_NAMES.get(k, str(k)).split("(")[0]: {
+                        "launches": v["launches"], "ms": round(v["ms"], 4),
+                        "tflops_executed": round(v["flops"] * (4.0 / 9.0 if k == 11 else 1.0) / (v["ms"] * 1e-3) / 1e12, 2),
+                        "frac_executed": round(v["flops"] * (4.0 / 9.0 if k == 11 else 1.0) / (v["ms"] * 1e-3) / 1e12 / peak, 4),
+                        "tflops_reference_formulation": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                        for k, v in sorted(by_tile.items())}}
         if args.layers:
             for r in layer_rows:
                 tf = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0
@@ -384,19 +471,19 @@ def main():
         fl = L.nbp_forward_flops(Bf, S)
         x1 = x[:1].contiguous()
         ms_fwd1 = ev_time(lambda: net(x1))
-        stage["nbp_forward_b1"] = {"ms": round(ms_fwd1, 4), "maps_per_s": round(1e3 / ms_fwd1, 2),
-                                   "tflops": round(L.nbp_forward_flops(1, S) / (ms_fwd1 * 1e-3) / 1e12, 3),
-                                   "frac_of_f32_mfma_peak": round(L.nbp_forward_flops(1, S) / (ms_fwd1 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
-        stage["nbp_forward"] = {"ms": round(ms_fwd, 4), "batch": Bf, "maps_per_s": round(Bf * 1e3 / ms_fwd, 2),
-                                "tflops": round(fl / (ms_fwd * 1e-3) / 1e12, 3), "conv_precision": net.conv_precision,
-                                "frac_of_f32_mfma_peak": round(fl / (ms_fwd * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+        def fwd_stage(ms, B_, flops_ref, factor, pk):
+            tf_ref = flops_ref / (ms * 1e-3) / 1e12
+            return {"ms": round(ms, 4), "batch": B_, "maps_per_s": round(B_ * 1e3 / ms, 2),
+                    "tflops_reference_formulation": round(tf_ref, 3), "tflops_executed": round(tf_ref * factor, 3),
+                    "frac_executed_of_conv_ceiling": round(tf_ref * factor / pk, 4), "conv_ceiling_tflops": round(pk, 2),
+                    "executed_over_reference_flops": round(factor, 4)}
+        stage["nbp_forward_b1"] = fwd_stage(ms_fwd1, 1, L.nbp_forward_flops(1, S), exec_factor, peak)
+        stage["nbp_forward"] = dict(fwd_stage(ms_fwd, Bf, fl, exec_factor, peak), conv_precision=net.conv_precision)
         if net.conv_precision != "fp32" and not args.no_extra_stages:
             # the same forward on the fp32 MFMA pipe (NBP_CONV_PRECISION=fp32 makes it the rollouts' path)
             pk32 = packing.pack_state_dict(sd, dev, precision="fp32")
             ms32 = ev_time(lambda: packing.forward_packed(pk32, x))
-            stage["nbp_forward_fp32_pipe"] = {"ms": round(ms32, 4), "batch": Bf, "maps_per_s": round(Bf * 1e3 / ms32, 2),
-                                              "tflops": round(fl / (ms32 * 1e-3) / 1e12, 3),
-                                              "frac_of_f32_mfma_peak": round(fl / (ms32 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+            stage["nbp_forward_fp32_pipe"] = fwd_stage(ms32, Bf, fl, 1.0, PEAK_F32_MFMA_TFLOPS)   # no parity form on this pipe
             pk32.free()
         # map accumulation: the HBM-bound scatter.  Event pair on the launch stream around `reps` launches; bytes =
         # 12 N (every point read once) + 24 S^2 (six channels written once)
@@ -466,11 +553,12 @@ def main():
             x5[:, :, 128:384, 128:384] = x[:1].expand(8, -1, -1, -1) if S == 256 else 0.0
             ms16 = ev_time(lambda: packing.forward_packed(pk16, x5), reps=10)
             fl16 = L.nbp_forward_flops(8, 512)
-            stage["config5_forward_bf16_512_b8"] = {"ms": round(ms16, 4), "maps_per_s": round(8e3 / ms16, 2),
-                                                    "tflops": round(fl16 / (ms16 * 1e-3) / 1e12, 2),
-                                                    "frac_of_bf16_mfma_peak": round(fl16 / (ms16 * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
-                                                    # 16-bit MFMA stream on random operands: 1709 TFLOP/s (mfma_f16_probe)
-                                                    "frac_of_sustained_mfma_stream": round(fl16 / (ms16 * 1e-3) / 1e12 / 1709.0, 4)}
+            # executed / reference FLOPs of the bf16 forward: its six up_conv layers take the parity form (4/9 of 4.832 GMAC each
+            # of the 91.206 GMAC per 256^2 map; the ratio is size independent)
+            f16 = 1.0 - (6 * 4.832 * 5.0 / 9.0) / 91.206 if os.environ.get("NBP_BF16_UP", "1") != "0" else 1.0
+            stage["config5_forward_bf16_512_b8"] = dict(fwd_stage(ms16, 8, fl16, f16, PEAK_BF16_MFMA_TFLOPS),
+                                                        # 16-bit MFMA stream on random operands: 1709 TFLOP/s (mfma_f16_probe)
+                                                        frac_executed_of_sustained_mfma_stream=round(fl16 * f16 / (ms16 * 1e-3) / 1e12 / 1709.0, 4))
             pk16.free()
             del x5, pk16
             # ---- BASELINE configs[2]: one training step (fwd + bwd + AdamW) on 32 maps of 256x256, fp32
@@ -497,9 +585,10 @@ def main():
                 torch.cuda.synchronize()
                 tdt = (time.perf_counter() - tt0) / 3
                 stage["config3_train_step_b32"] = {"ms": round(tdt * 1e3, 2), "maps_per_s": round(32 / tdt, 2),
-                                                   "tflops": round(32 * 546.9e9 / tdt / 1e12, 2),
-                                                   "frac_of_f32_mfma_peak": round(32 * 546.9e9 / tdt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                                   "flop_per_map": 546.9e9}
+                                                   "tflops_reference_formulation": round(32 * 546.9e9 / tdt / 1e12, 2),
+                                                   "frac_of_split_ceiling_reference_formulation":
+                                                       round(32 * 546.9e9 / tdt / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4),
+                                                   "flop_per_map_reference_formulation": 546.9e9}
                 del tnet, opt, xs, gtl
                 torch.cuda.empty_cache()
             except Exception as e:                      # the headline must not depend on the training stage
@@ -522,6 +611,10 @@ def main():
             "note": f"ms_per_step is one lock-step step of {R} concurrent rollouts per GPU ({R} exploration steps); timed "
                     f"window = steps {first_step}-{last_step} of the 101-step trajectory (clouds of {n0}-{n1} points)",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_detail": {"fp32_split": "fp32 tensors and accumulation; 3x3 / gate products as 3 exact fp16 MFMAs on two-piece "
+                                           "operands (22 significand bits per operand)", "fp32": "fp32 MFMA pipe",
+                             "bf16": "bf16 tensors, fp32 accumulation"}.get(net.conv_precision, net.conv_precision),
+            "value_fp32_pipe": None if fp32_pipe is None else fp32_pipe["value"], "fp32_pipe": fp32_pipe,
             "config": {"workload": "configs[1]: AiMDoom_simple-like rollout (seeded procedural maze, "
                                    f"{int(mesh.faces.shape[0])} faces), 256x256 grid, {R} concurrent rollouts per GPU on "
                                    f"{R} scenes (NBP forwards batched), 5 depth frames of 256x456 per step per "
@@ -535,6 +628,8 @@ def main():
                        "window_steps": [first_step, last_step], "gt_points": int(gt.shape[0])},
             "nbp_maps_per_s": round(world * stage["nbp_forward"]["maps_per_s"], 2),
             "stages": stage, "roofline": roofline, "roofline_scatter": scatter, "cpu_baseline": cpu,
+            "strong_scaling": strong,
+            "distributed": None if dist is None else {"backend": dist.get_backend(), "world": world},
         }
         print(json.dumps(out))
     if dist is not None:
@@ -573,23 +668,45 @@ def cpu_baseline(sd, multi, ro, cam, mesh, y_bins, gt, pose, params, S):
         cpu_fwd = (time.perf_counter() - t0c) / n_it
     H_, W_ = params.image_height, params.image_width
     verts, faces = mesh.verts_host, mesh.faces_host
-    # raster: the 4 frames of the last move (single thread: the face loop carries the z-buffer)
-    t0c = time.perf_counter()
-    zs = []
-    for _, cam12, _slot in cam.frames[-4:]:
-        zs.append(csim.raster_zbuf(verts, faces, cam12[:9].reshape(3, 3), cam12[9:], H_, W_, ocam.TAN_HALF_FOV))
-    cpu_raster = time.perf_counter() - t0c
-    # un-projection + 5 % sub-sampling of 5 frames
-    t0c = time.perf_counter()
-    for k in range(5):
-        _, cam12, _slot = cam.frames[-1 - (k % 4)]
-        ocam.partial_point_cloud(zs[k % 4], None, cam12[:9].reshape(3, 3), cam12[9:], 0.05, 70.0, seed=k)
-    cpu_unproj = time.perf_counter() - t0c
+
+    def best_of(variants):
+        """(label, seconds, result) of the fastest variant; every variant runs twice, the second run is timed"""
+        best_v = None
+        for label, fn in variants:
+            fn()
+            t0v = time.perf_counter()
+            res = fn()
+            tv = time.perf_counter() - t0v
+            if best_v is None or tv < best_v[1]:
+                best_v = (label, tv, res)
+        return best_v
+    # raster: the 4 frames of the last move; (frame, 16-row band) tasks over OpenMP threads (a band owns its pixels, so the
+    # result is the single-threaded one bit for bit), beside the single-threaded loop -- the faster one counts
+    cams = [f[1] for f in cam.frames[-4:]]
+    Rs, Ts = np.stack([c[:9] for c in cams]), np.stack([c[9:] for c in cams])
+    env_threads = os.environ.get("OMP_NUM_THREADS")
+    r_label, cpu_raster, zs = best_of([
+        ("1 thread", lambda: csim.raster_zbuf_frames(verts, faces, Rs, Ts, H_, W_, ocam.TAN_HALF_FOV, band_rows=H_, omp=False)),
+        (f"OpenMP {env_threads or avail} threads", lambda: csim.raster_zbuf_frames(verts, faces, Rs, Ts, H_, W_, ocam.TAN_HALF_FOV,
+                                                                                 band_rows=16, omp=True))])
+    # un-projection + 5 % sub-sampling of 5 frames: one frame per thread (numpy releases the GIL in its array loops)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def unproject5(pool):
+        def one(k):
+            c12 = cams[-1 - (k % 4)]
+            return ocam.partial_point_cloud(zs[3 - (k % 4)], None, c12[:9].reshape(3, 3), c12[9:], 0.05, 70.0, seed=k)
+        return list(pool.map(one, range(5))) if pool else [one(k) for k in range(5)]
+    with ThreadPoolExecutor(5) as pool:
+        u_label, cpu_unproj, _ = best_of([("1 thread", lambda: unproject5(None)), ("5 threads", lambda: unproject5(pool))])
     n_pts = int(ro.st.cloud_count.item())
     cloud = ro.st.cloud[:n_pts].cpu().numpy()
-    t0c = time.perf_counter()
-    omaps.accumulate_step_maps(cloud, pose, y_bins.numpy(), S, (-40, 40))
-    cpu_map = time.perf_counter() - t0c
+    yb = y_bins.numpy()
+    m_label, cpu_map, _ = best_of(
+        [("numpy, 1 thread", lambda: omaps.accumulate_step_maps(cloud, pose, yb, S, (-40, 40))),
+         ("C, 1 thread", lambda: csim.accumulate_step_maps(cloud, pose, yb, S, (-40, 40), omp=False))] +
+        [(f"C, OpenMP {t} threads", (lambda t=t: csim.accumulate_step_maps(cloud, pose, yb, S, (-40, 40), omp=True, max_threads=t)))
+         for t in sorted({min(avail, c) for c in (4, 16, 64)})])
     # coverage: G x 2G brute force like the reference's cdist; bounded by sub-sampling BOTH sides, scaled by the product
     G = int(gt.shape[0])
     M = min(n_pts, 2 * G)
@@ -601,12 +718,14 @@ def cpu_baseline(sd, multi, ro, cam, mesh, y_bins, gt, pose, params, S):
     cpu_cov = t_cov_s * (G * M) / (gs * ms_)
     total = cpu_fwd + cpu_raster + cpu_unproj + cpu_map + cpu_cov
     return {"value": round(1.0 / total, 3), "unit": "steps/s", "cores": max(cores, avail), "kind": "port",
-            "threads_per_leg": {"nbp_forward": cores, "raster": 1, "unproject": 1, "map_accumulate": 1, "coverage": avail},
+            "threads_per_leg": {"nbp_forward": cores, "raster": r_label, "unproject": u_label, "map_accumulate": m_label,
+                                "coverage": avail},
+            "note": "every leg is the fastest of the thread counts tried on this host (host's best, not a scalar port)",
             "sample": f"one exploration step at the rollout's current state ({n_pts} cloud points, {G} GT points): "
                       f"{n_it} NBP forwards at 256x256 B=1 with stock PyTorch CPU convs ({cores} threads, {cpu_fwd*1e3:.0f} ms "
-                      f"each) + C raster of 4 frames, {len(faces)} faces (1 thread, {cpu_raster*1e3:.0f} ms) + numpy "
-                      f"un-projection of 5 frames ({cpu_unproj*1e3:.0f} ms) + numpy map accumulation of all {n_pts} points "
-                      f"({cpu_map*1e3:.0f} ms) + brute-force coverage {gs} x {ms_} pairs with OpenMP ({avail} threads, "
+                      f"each) + C raster of 4 frames, {len(faces)} faces ({r_label}, {cpu_raster*1e3:.0f} ms) + numpy "
+                      f"un-projection of 5 frames ({u_label}, {cpu_unproj*1e3:.0f} ms) + map accumulation of all {n_pts} points "
+                      f"({m_label}, {cpu_map*1e3:.0f} ms) + brute-force coverage {gs} x {ms_} pairs with OpenMP ({avail} threads, "
                       f"{t_cov_s*1e3:.0f} ms) scaled by the pair count to {G} x {M} ({cpu_cov*1e3:.0f} ms)",
             "legs_ms": {"nbp_forward": round(cpu_fwd * 1e3, 1), "raster": round(cpu_raster * 1e3, 1),
                         "unproject": round(cpu_unproj * 1e3, 1), "map_accumulate": round(cpu_map * 1e3, 1),

@@ -55,6 +55,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsi
 // atomics run at ~0.3 G/s on this part (16 k waves finishing together = 55 us), so writers spread over the words by
 // workgroup id and readers take the max of all of them with one 256-B load per wave.
 constexpr int AMAX_WORDS = 64;
+#define NBP_SPLIT_MAX_K_DEFAULT 0
 __device__ __forceinline__ void wave_amax(float mx, unsigned* out) {
 #pragma unroll
     for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -940,6 +941,18 @@ int launch_h2(const SplitArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// Accuracy-driven split-K: one fp32 accumulator sees 3 roundings per 16 k (three MFMAs), and the distance of a chain's result to
+// the exact sum grows like K_chain / sqrt(steps per k) (measured, tools/diag/chain_error.py: a K = 9216 chain sits 4.5x further from
+// fp64 than stock torch CPU fp32 -- whose GEMM accumulates in blocks -- a K = 576 one 1.5x).  Chains are therefore bounded to
+// NBP_SPLIT_MAX_K products (taps x channels) whatever the occupancy says: slices beyond the occupancy-driven count exist for accuracy.
+static int chain_bounded_split(int sk, int cc, int taps) {
+    static const int max_k = [] { const char* e = getenv("NBP_SPLIT_MAX_K"); return e ? atoi(e) : NBP_SPLIT_MAX_K_DEFAULT; }();
+    if (max_k <= 0) return sk;
+    const int max_chunks = max_k / (16 * taps) > 1 ? max_k / (16 * taps) : 1;
+    const int need = (int)nbp_cdiv(cc, max_chunks);
+    return need > sk ? need : sk;
+}
+
 // tile == 0: the layer does not fit the split kernel (the caller runs the fp32 MFMA kernels on the fp32 pack)
 // ups: the layer reads its input through the x2 nearest upsample; when the LOW-resolution image tiles, the parity kernels run
 // (tile id NBP_TILE_SPLIT_UP), otherwise the plain kernel with the upsample folded into its gather.
@@ -958,6 +971,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
                 sk = 1;
                 while (blocks * sk < min_blocks_up && cc / (sk * 2) >= 4 && sk < 16) sk *= 2;
             }
+            if (split_k <= 0) sk = chain_bounded_split(sk, cc, 4);
             if (sk > cc) sk = cc;
             const int per = (int)nbp_cdiv(cc, sk);
             p.tile = NBP_TILE_SPLIT_UP; p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
@@ -980,6 +994,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
         // B = 12: 5.07 -> 5.02 ms, B = 8 / 1 unchanged, B = 4 +0.6 %; with 8 chunks B = 4 loses 2.5 %)
         static const int deep = [] { const char* e = getenv("NBP_SPLIT_DEEP"); return e ? atoi(e) : 16; }();
         if (deep > 0 && blocks * sk < 2 * min_blocks && cc / (sk * 2) >= deep && sk < 16) sk *= 2;
+        sk = chain_bounded_split(sk, cc, 9);
     }
     if (sk > cc) sk = cc;
     const int per = (int)nbp_cdiv(cc, sk);

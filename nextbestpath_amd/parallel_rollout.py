@@ -15,11 +15,13 @@ import torch
 
 
 def init_distributed():
-    """(rank, world, local_rank); initialises torch.distributed when launched under torchrun."""
+    """(rank, world, local_rank); initialises torch.distributed when launched under torchrun -- also with ONE rank
+    (`torchrun --nproc-per-node 1`): the collectives then run through RCCL on the single GPU, which is how the `nccl`
+    path is exercised on a 1-GPU box (tests/test_gpu_rccl.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or under_torchrun():
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -30,9 +32,20 @@ def init_distributed():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             else:       # gloo: CPU-only hosts, or several ranks sharing one GPU (NBP_DIST_BACKEND=gloo) in tests
                 dist.init_process_group("gloo")
+            if rank == 0 and os.environ.get("NBP_TRACE_DIST"):
+                print(f"[dist] backend {dist.get_backend()} world {dist.get_world_size()}", flush=True)
     if torch.cuda.is_available():
         local_rank = local_rank % torch.cuda.device_count()
     return rank, world, local_rank
+
+
+def under_torchrun():
+    return all(k in os.environ for k in ("WORLD_SIZE", "RANK", "MASTER_ADDR", "MASTER_PORT"))
+
+
+def group_is_up():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
 
 
 def collective_device(device):
@@ -68,8 +81,9 @@ def gather_results(results, runs, rank, world, device, n_poses):
     """All ranks call this; every rank gets the list of {run_id, coverage, final, auc, scene, start}
     in run order (only the coverage metrics travel; pose histories stay in the per-rank results)."""
     rows = runs_per_rank(len(runs), world)
-    local = torch.from_numpy(pack_results(results, runs, n_poses, rows)).to(collective_device(device) if world > 1 else device)
-    if world > 1:
+    collective = world > 1 or group_is_up()          # a 1-rank process group still goes through the backend
+    local = torch.from_numpy(pack_results(results, runs, n_poses, rows)).to(collective_device(device) if collective else device)
+    if collective:
         import torch.distributed as dist
         buf = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(buf, local)

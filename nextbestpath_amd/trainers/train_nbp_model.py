@@ -67,7 +67,7 @@ BUCKET_BYTES = 64 << 20      # xGMI rings are per-link bound (~153 GB/s): 4 buck
 
 def _dist():
     import torch.distributed as dist
-    return dist if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+    return dist if dist.is_available() and dist.is_initialized() else None      # also a 1-rank group (RCCL on one GPU)
 
 
 def allreduce_gradients(nbp):

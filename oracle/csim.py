@@ -24,6 +24,12 @@ def lib(omp=False):
         L.oracle_raster_zbuf.argtypes = [fp, C.c_int, ip, C.c_int, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float,
                                          C.c_float, fp]
         L.oracle_raster_zbuf.restype = None
+        L.oracle_raster_zbuf_frames.argtypes = [fp, C.c_int, ip, C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                C.c_float, C.c_int, fp]
+        L.oracle_raster_zbuf_frames.restype = None
+        L.oracle_accumulate_step_maps.argtypes = [fp, C.c_longlong, C.c_float, C.c_float, fp, C.c_int, C.c_int, C.c_float,
+                                                  C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, fp]
+        L.oracle_accumulate_step_maps.restype = None
         L.oracle_raster_rgbz.argtypes = [fp, C.c_int, ip, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float,
                                          C.c_float, C.c_float, C.c_float, fp, fp]
         L.oracle_raster_rgbz.restype = None
@@ -47,6 +53,31 @@ def raster_zbuf(verts, faces, R, T, H, W, tan_half_fov, z_clip=0.5, eps=1e-6):
     out = np.empty((H, W), f32)
     lib().oracle_raster_zbuf(_fp(v), len(v), f.ctypes.data_as(C.POINTER(C.c_int)), len(f), _fp(R), _fp(T), H, W,
                              float(tan_half_fov), float(z_clip), float(eps), _fp(out))
+    return out
+
+
+def raster_zbuf_frames(verts, faces, Rs, Ts, H, W, tan_half_fov, z_clip=0.5, eps=1e-6, band_rows=16, omp=True):
+    """[n_frames,H,W] z-buffers; (frame, row band) tasks over the host's threads with omp=True.  == raster_zbuf per frame."""
+    v = np.ascontiguousarray(verts, f32)
+    f = np.ascontiguousarray(faces, np.int32)
+    Rs = np.ascontiguousarray(Rs, f32).reshape(-1, 9)
+    Ts = np.ascontiguousarray(Ts, f32).reshape(-1, 3)
+    out = np.empty((len(Rs), H, W), f32)
+    lib(omp).oracle_raster_zbuf_frames(_fp(v), len(v), f.ctypes.data_as(C.POINTER(C.c_int)), len(f), len(Rs), _fp(Rs), _fp(Ts), H, W,
+                                       float(tan_half_fov), float(z_clip), float(eps), int(band_rows), _fp(out))
+    return out
+
+
+def accumulate_step_maps(full_pc, camera_pose, y_bins, S=256, grid_range=(-40, 40), band=0.1, n_pieces=4, omp=True, max_threads=0):
+    """== oracle/maps.py::accumulate_step_maps ([6,S,S] fp32 counts), threads over the cloud with omp=True."""
+    p = np.ascontiguousarray(full_pc, f32).reshape(-1, 3)
+    bounds = np.ascontiguousarray(np.asarray(y_bins, f32)[:-1])
+    lo, hi = grid_range
+    cy = float(f32(camera_pose[1]))
+    out = np.empty((6, S, S), f32)
+    lib(omp).oracle_accumulate_step_maps(_fp(p), len(p), float(f32(camera_pose[0])), float(f32(camera_pose[2])), _fp(bounds),
+                                         len(bounds), n_pieces, float(f32(cy - band)), float(f32(cy + band)), S, float(f32(lo)),
+                                         float(f32(S / (hi - lo))), int(max_threads), _fp(out))
     return out
 
 

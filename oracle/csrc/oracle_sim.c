@@ -15,19 +15,24 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 static void to_view(const float* p, const float* R, const float* T, float* o) {
     for (int j = 0; j < 3; ++j) o[j] = ((p[0] * R[0 + j] + p[1] * R[3 + j]) + p[2] * R[6 + j]) + T[j];
 }
 
-static void raster_core(const float* verts, const int* faces, int n_faces, const float* R, const float* T, int H, int W,
-                        float tan_half_fov, float z_clip, float eps, float* zbuf, float* ub, float* vb, int* fb) {
+/* rows [rlo, rhi) of the image only (a band owns its pixels: bands can run on different threads, the face order per pixel
+ * -- hence the result -- is that of the whole-image loop) */
+static void raster_rows(const float* verts, const int* faces, int n_faces, const float* R, const float* T, int H, int W,
+                        float tan_half_fov, float z_clip, float eps, float* zbuf, float* ub, float* vb, int* fb, int rlo, int rhi) {
     const int s = H < W ? H : W;
     float* dxs = (float*)malloc(sizeof(float) * (size_t)W);
     float* dys = (float*)malloc(sizeof(float) * (size_t)H);
     for (int c = 0; c < W; ++c) dxs[c] = ((float)W - (2.f * (float)c + 1.f)) / (float)s * tan_half_fov;
     for (int r = 0; r < H; ++r) dys[r] = ((float)H - (2.f * (float)r + 1.f)) / (float)s * tan_half_fov;
-    for (size_t i = 0; i < (size_t)H * W; ++i) { zbuf[i] = 3.0e38f; if (fb) fb[i] = -1; }
+    for (size_t i = (size_t)rlo * W; i < (size_t)rhi * W; ++i) { zbuf[i] = 3.0e38f; if (fb) fb[i] = -1; }
     for (int fi = 0; fi < n_faces; ++fi) {
         float v[3][3];
         for (int k = 0; k < 3; ++k) to_view(verts + 3 * (size_t)faces[3 * (size_t)fi + k], R, T, v[k]);
@@ -48,6 +53,9 @@ static void raster_core(const float* verts, const int* faces, int n_faces, const
             if (r1 > H - 1) r1 = H - 1;
             if (c0 > c1 || r0 > r1) continue;
         }
+        if (r0 < rlo) r0 = rlo;
+        if (r1 > rhi - 1) r1 = rhi - 1;
+        if (r0 > r1) continue;
         float e1[3], e2[3], q[3];
         for (int c = 0; c < 3; ++c) { e1[c] = v[1][c] - v[0][c]; e2[c] = v[2][c] - v[0][c]; }
         const float* v0 = v[0];
@@ -77,6 +85,32 @@ static void raster_core(const float* verts, const int* faces, int n_faces, const
         }
     }
     free(dxs); free(dys);
+}
+
+static void raster_core(const float* verts, const int* faces, int n_faces, const float* R, const float* T, int H, int W,
+                        float tan_half_fov, float z_clip, float eps, float* zbuf, float* ub, float* vb, int* fb) {
+    raster_rows(verts, faces, n_faces, R, T, H, W, tan_half_fov, z_clip, eps, zbuf, ub, vb, fb, 0, H);
+}
+
+/* n_frames z-buffers [n_frames][H][W], cameras Rs [n_frames][9] / Ts [n_frames][3]; (frame, band of `band_rows` rows) tasks
+ * over OpenMP threads when compiled with -fopenmp (bench.py's cpu_baseline); identical to oracle_raster_zbuf per frame. */
+void oracle_raster_zbuf_frames(const float* verts, int n_verts, const int* faces, int n_faces, int n_frames, const float* Rs,
+                               const float* Ts, int H, int W, float tan_half_fov, float z_clip, float eps, int band_rows,
+                               float* zbufs) {
+    (void)n_verts;
+    if (band_rows < 1) band_rows = H;
+    const int bands = (H + band_rows - 1) / band_rows;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int t = 0; t < n_frames * bands; ++t) {
+        const int f = t / bands, b = t % bands;
+        const int rlo = b * band_rows, rhi = rlo + band_rows < H ? rlo + band_rows : H;
+        float* z = zbufs + (size_t)f * H * W;
+        raster_rows(verts, faces, n_faces, Rs + 9 * f, Ts + 3 * f, H, W, tan_half_fov, z_clip, eps, z, NULL, NULL, NULL, rlo, rhi);
+        for (size_t i = (size_t)rlo * W; i < (size_t)rhi * W; ++i)
+            if (!(z[i] < 1.0e38f)) z[i] = -1.f;
+    }
 }
 
 void oracle_raster_zbuf(const float* verts, int n_verts, const int* faces, int n_faces, const float* R, const float* T,
@@ -154,4 +188,56 @@ long long oracle_coverage_count(const float* gt, long long G, const float* pc, l
         if (M > 0 && sqrtf(best) < threshold) ++cnt;
     }
     return cnt;
+}
+
+/* == oracle/maps.py::accumulate_step_maps (utils.py:166-223 + the slab split / height band of nbp_planning.py:114-127,178-183):
+ * out [6][S][S] counts.  bounds = y_bins[:-1] (nb entries; slab = #bounds < y, minus 1), lo_t / hi_t = the height band's
+ * open interval, scale = (float)(S / (hi - lo)).  Threads own private count planes that are summed at the end (counts are
+ * integers < 2^24: any summation order gives the same floats). */
+void oracle_accumulate_step_maps(const float* pts, long long n, float cx, float cz, const float* bounds, int nb, int n_pieces,
+                                 float lo_t, float hi_t, int S, float lo, float scale, int max_threads, float* out) {
+    const size_t plane = (size_t)S * S;
+    int nt = 1;
+#ifdef _OPENMP
+    nt = omp_get_max_threads();
+    if (max_threads > 0 && nt > max_threads) nt = max_threads;
+#else
+    (void)max_threads;
+#endif
+    unsigned** priv = (unsigned**)calloc((size_t)nt, sizeof(unsigned*));
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nt)
+#endif
+    {
+        int me = 0, team = 1;
+#ifdef _OPENMP
+        me = omp_get_thread_num(); team = omp_get_num_threads();
+#endif
+        unsigned* mine = priv[me] = (unsigned*)calloc(6 * plane, sizeof(unsigned));
+        const long long i0 = n * me / team, i1 = n * (me + 1) / team;
+        for (long long i = i0; i < i1; ++i) {
+            const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+            const float fr = rintf((-(z - cz) - lo) * scale), fc = rintf((-(x - cx) - lo) * scale);
+            if (!(fr >= 0.f && fr < (float)S && fc >= 0.f && fc < (float)S)) continue;
+            const size_t cell = (size_t)fr * S + (size_t)fc;
+            int bin = -1;
+            for (int k = 0; k < nb; ++k) bin += bounds[k] < y;
+            mine[(size_t)((bin < 0 || bin >= n_pieces) ? 4 : bin) * plane + cell] += 1u;
+            if (y < hi_t && y > lo_t) mine[5 * plane + cell] += 1u;
+        }
+#ifdef _OPENMP
+#pragma omp barrier
+#endif
+        const size_t c0 = 6 * plane * (size_t)me / (size_t)team, c1 = 6 * plane * (size_t)(me + 1) / (size_t)team;
+        for (size_t c = c0; c < c1; ++c) {
+            unsigned acc = 0;
+            for (int t = 0; t < team; ++t) acc += priv[t][c];
+            out[c] = (float)acc;
+        }
+#ifdef _OPENMP
+#pragma omp barrier
+#endif
+        free(mine);
+    }
+    free(priv);
 }

@@ -64,3 +64,33 @@ def test_single_process_path():
     res = [{"run_id": i, "coverage": [0.0, 0.5 * (i + 1)]} for i in range(2)]
     out = pr.gather_results(res, runs, 0, 1, torch.device("cpu"), 2)
     assert [o["final"] for o in out] == [0.5, 1.0]
+
+
+def _worker_one(port, q):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from nextbestpath_amd import parallel_rollout as pr
+    from nextbestpath_amd.trainers import train_nbp_model as tm
+    r, w, _ = pr.init_distributed()                      # a 1-rank torchrun environment still builds the process group
+    ok = dist.is_initialized() and dist.get_world_size() == 1 and pr.group_is_up()
+    res = [{"run_id": i, "coverage": [0.0, 0.25 * (i + 1)]} for i in range(2)]
+    out = pr.gather_results(res, [(0, 0), (1, 0)], r, w, torch.device("cpu"), 2)      # through the backend's all_gather
+    lin = torch.nn.Linear(3, 2)
+    for p in lin.parameters():
+        p.grad = torch.ones_like(p)
+    tm.allreduce_gradients(lin)
+    q.put((ok, [o["final"] for o in out], tm._common_count(4, torch.device("cpu")), tm._mean_over_ranks(0.5, torch.device("cpu")),
+           [float(p.grad.sum()) for p in lin.parameters()]))
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_still_runs_the_collectives():
+    """`torchrun --nproc-per-node 1`: the group is built and every collective goes through the backend (on a GPU box this is the
+    RCCL exercise of tests/test_gpu_rccl.py; here gloo)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_one, args=(_free_port(), q))
+    p.start()
+    ok, finals, cc, mo, gs = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and ok and finals == [0.25, 0.5] and cc == 4 and mo == 0.5 and gs == [6.0, 2.0]

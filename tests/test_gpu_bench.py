@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(extra, env=None):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--advance", "2",
-                        "--rollouts-per-gpu", "2", "--no-live-traffic", "--no-extra-stages"] + extra,
+                        "--rollouts-per-gpu", "2", "--no-live-traffic", "--no-extra-stages", "--strong-scenes", "3", "--strong-advance", "1"] + extra,
                        capture_output=True, text=True, timeout=1200, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -28,6 +28,8 @@ def test_bench_single_gpu_line(hip):
     rf, sc, cpu = d["roofline"], d["roofline_scatter"], d["cpu_baseline"]
     assert rf["bound"] == "mfma" and 0 < rf["frac"] <= 1 and rf["unit"] == "TFLOP/s"
     assert sc["bound"] == "hbm" and 0 < sc["frac"] <= 1 and sc["unit"] == "GB/s"
+    assert d["strong_scaling"]["scenes_per_rank"] == [3] and d["strong_scaling"]["value"] > 0
+    assert d["value_fp32_pipe"] is None         # --no-extra-stages: no fp32-pipe window
     assert cpu["kind"] == "port" and cpu["value"] > 0 and set(cpu["legs_ms"]) == {"nbp_forward", "raster", "unproject",
                                                                                  "map_accumulate", "coverage"}
 
@@ -36,3 +38,6 @@ def test_bench_gpus_flag_launches_the_ranks(hip):
     d = _run(["--gpus", "2", "--no-cpu-baseline"], env={"NBP_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 3 * 2 * 2 / (d["ms_per_step"] * 3e-3)) < 1e-3 * d["value"]
+    st = d["strong_scaling"]                # 3 fixed hard scenes over 2 ranks: 2 + 1, the job's time is the slower rank's
+    assert st["scaling"] == "strong" and st["scenes_per_rank"] == [2, 1] and len(st["per_rank_s"]) == 2
+    assert abs(st["value"] - 3 * 3 / (st["ms_per_step"] * 3e-3)) < 1e-3 * st["value"] and st["imbalance_max_over_mean"] >= 1.0

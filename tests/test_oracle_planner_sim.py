@@ -287,3 +287,29 @@ def test_obj_loader_formats(tmp_path):
     save_obj(str(q), v, f)
     v2, f2 = load_obj(str(q))
     assert np.array_equal(v, v2) and np.array_equal(f, f2)
+
+
+def test_threaded_c_twins_equal_the_scalar_restatements():
+    """bench.py's cpu_baseline runs the raster and the map accumulation on the host's threads: (frame, row band) tasks and
+    per-thread count planes must give the single-threaded / numpy results bit for bit."""
+    from nextbestpath_amd.simulator.mesh import make_maze_mesh
+    from nextbestpath_amd.utility.synthetic import make_point_cloud
+    from oracle import camera as ocam
+    from oracle import csim
+    from oracle import maps as omaps
+    verts, faces = make_maze_mesh(seed=2, cells=4, size=24.0, height=12.0, tess=3.0)[:2]
+    poses = [([3.0, 3.3, -6.0], [0.0, 100.0]), ([0.0, 40.0, 0.0], [-89.0, 10.0]), ([1.0, 3.3, 2.0], [0.0, 200.0])]
+    RT = [ocam.camera_RT(x, v) for x, v in poses]
+    Rs, Ts = np.stack([r for r, _ in RT]), np.stack([t for _, t in RT])
+    one = [csim.raster_zbuf(verts, faces, R, T, 64, 114, ocam.TAN_HALF_FOV) for R, T in RT]
+    for omp, band in ((False, 64), (True, 16), (True, 7)):
+        fr = csim.raster_zbuf_frames(verts, faces, Rs, Ts, 64, 114, ocam.TAN_HALF_FOV, band_rows=band, omp=omp)
+        assert all(np.array_equal(fr[i], one[i]) for i in range(3)), (omp, band)
+    assert (one[0] > 0).sum() > 100
+    pc = make_point_cloud(60_000, seed=3).numpy()
+    pose = np.array([1.0, 13.3, -2.0, 0, 0], np.float32)
+    for ybins in (np.arange(0.5, 29.5 + 7.25, 7.25, dtype=np.float32), np.array([0.5, 5, 10, 15, 20, 25], np.float32)):
+        want = omaps.accumulate_step_maps(pc, pose, ybins, S=128)
+        for omp, nt in ((False, 0), (True, 0), (True, 3)):
+            assert np.array_equal(csim.accumulate_step_maps(pc, pose, ybins, S=128, omp=omp, max_threads=nt), want), (omp, nt)
+    assert want.sum() > 1000
