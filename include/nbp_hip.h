@@ -157,6 +157,12 @@ int nbp_upconv3x3_split_f32(const float* src, int C, int B, int H, int W, const 
                             const float* scale, const float* shift, int relu, float* out, const void* amax_in_or_null,
                             void* amax_out_or_null, int split_k, void* ws, size_t ws_bytes, void* stream);
 size_t nbp_conv_split_workspace_bytes(int B, int H, int W, int N, int split_k);
+/* The same for split_k = 0 as the planner will actually run the layer (C = C0 + C1 input channels): its split-K count is
+ * returned through split_k_out (may be NULL; 0 = the layer is not taken by the split kernel).  Slices exist for occupancy
+ * (small grids) and for accuracy: an accumulation chain is bounded to NBP_SPLIT_MAX_K_SMALL (576) products where a slice of
+ * the output is <= 64 MB and to NBP_SPLIT_MAX_K (2304) elsewhere, so that the result's distance to the exact sum does not
+ * grow with the batch size. */
+size_t nbp_conv_split_planned_workspace_bytes(int B, int H, int W, int C, int N, int ups, int* split_k_out);
 int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
                           const void* w_planes, const void* wamax, int N, const float* scale, const float* shift, int relu,
                           float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws,
@@ -347,6 +353,30 @@ int nbp_carve_update_f32(const float* proxy_pts3, int P, const float* depth,
                          float tan_half_fov, float zfar, float fov_range, float tol,
                          float score_threshold, float* n_inside, float* n_behind, float* occ,
                          float* out_of_field, void* stream);
+/* View-state vectors of the proxy points -- compute_view_state (macarons/utility/scone_utils.py:799-862) as
+ * Scene.update_proxy_view_states applies it (macarons/utility/macarons_utils.py:3268-3327): for every selected point and every
+ * camera position x_view_host [n_view <= 8][3] (HOST array), the direction point -> camera in spherical coordinates
+ * (macarons/utility/CustomGeometry.py:27-45) is rounded to the nearest of n_elev x n_azim directions and
+ * view_states[point][n_elev * n_azim] gets a 1.0 there (the reference's `+= ...; heaviside`, i.e. OR).  A point is selected
+ * when mask_or_null[i] != 0 (NULL = all) and sd_or_null[i] < distance_to_surface (NULL = no such test).
+ * nbp_carve_view_update_f32 = nbp_carve_update_f32 + that update for ONE camera at x_cam_host[3] in the same launch, over the
+ * points inside the field of view with signed distance < distance_to_surface (macarons/testers/scene.py:598-607);
+ * fov_mask_or_null [P] / sd_or_null [P] receive the field-of-view mask and the signed distances (sd only where the mask is 1). */
+int nbp_view_state_update_f32(const float* pts3, int P, const unsigned char* mask_or_null, const float* sd_or_null,
+                              float distance_to_surface, const float* x_view_host, int n_view, int n_elev, int n_azim,
+                              float* view_states, void* stream);
+/* Geometric coverage-gain model for candidate poses (stand-in for the unreleased SCONE predictor the reference calls at
+ * macarons/testers/scene.py:640-670): gains[c] = number of proxy points inside candidate c's field of view (cams12_host [n][12],
+ * range fov_range) with occ > 0.5 whose view-state bit for the direction towards x_cams_host[c] is still 0. */
+int nbp_view_gain_i32(const float* pts3, int P, const float* occ, const float* view_states, const float* cams12_host,
+                      const float* x_cams_host, int n_cams, int n_elev, int n_azim, int H, int W, float tan_half_fov,
+                      float fov_range, int* gains, void* stream);
+int nbp_carve_view_update_f32(const float* proxy_pts3, int P, const float* depth, const unsigned char* mask_or_null,
+                              const float* cam12_host, int H, int W, float tan_half_fov, float zfar, float fov_range,
+                              float tol, float score_threshold, float* n_inside, float* n_behind, float* occ,
+                              float* out_of_field, const float* x_cam_host, int n_elev, int n_azim,
+                              float distance_to_surface, float* view_states, unsigned char* fov_mask_or_null,
+                              float* sd_or_null, void* stream);
 /* ---- Scene / Cell point store (MACARONS scene objects, macarons/utility/macarons_utils.py:2952-3234), device resident.
  * store_pts [n_cells][capacity][3] fp32 + store_count [n_cells] int32, n_cells = grid3[0]*grid3[1]*grid3[2] in the
  * cartesian product order (i_l, i_w, i_h) of Scene.__init__ (:3063-3066); box6_host = x_min[3], x_max[3] of the scene.

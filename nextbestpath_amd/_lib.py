@@ -48,6 +48,10 @@ SIGNATURES = {
     "nbp_segments_hit_mesh_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "nbp_axis_ray_counts_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "nbp_carve_update_f32": (_i, [_vp, _i, _vp, _vp, C.POINTER(_f), _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "nbp_view_state_update_f32": (_i, [_vp, _i, _vp, _vp, _f, C.POINTER(_f), _i, _i, _i, _vp, _vp]),
+    "nbp_view_gain_i32": (_i, [_vp, _i, _vp, _vp, C.POINTER(_f), C.POINTER(_f), _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
+    "nbp_carve_view_update_f32": (_i, [_vp, _i, _vp, _vp, C.POINTER(_f), _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
+                                       C.POINTER(_f), _i, _i, _f, _vp, _vp, _vp, _vp]),
     "nbp_append_points_f32": (_i, [_vp, _ll, C.POINTER(_f), _i, _vp]),
     "nbp_perm_index_host": (C.c_uint, [C.c_uint, C.c_uint, C.c_uint]),
     "nbp_colreduce_workspace_bytes": (_sz, [_ll, _i]),
@@ -105,6 +109,7 @@ SIGNATURES["nbp_amax_f32"] = (_i, [_vp, _ll, _vp, _vp])
 SIGNATURES["nbp_pack_upconv_weight_split"] = (_i, [_vp, _i, _i, _vp, _vp, _vp])
 SIGNATURES["nbp_upconv3x3_split_f32"] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp])
 SIGNATURES["nbp_conv_split_workspace_bytes"] = SIGNATURES["nbp_conv_igemm_workspace_bytes"]
+SIGNATURES["nbp_conv_split_planned_workspace_bytes"] = (_sz, [_i, _i, _i, _i, _i, _i, _vp])
 SIGNATURES["nbp_conv3x3_split_f32"] = (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp,
                                             _sz, _vp])
 SIGNATURES["nbp_conv_igemm_bf16"] = SIGNATURES["nbp_conv_igemm_f32"]

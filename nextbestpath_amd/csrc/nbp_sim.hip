@@ -627,6 +627,81 @@ __global__ __launch_bounds__(256) void points_in_fov_kernel(const float* __restr
     if (any && __ballot(in) && (threadIdx.x & 63) == 0) any[c] = 1;      // plain store: every writer writes 1
 }
 
+// ------------------------------------------------------------------ view-state vectors of the proxy points
+// compute_view_state (macarons/utility/scone_utils.py:799-862): the direction from a proxy point to a camera, in spherical
+// coordinates (get_spherical_coords, macarons/utility/CustomGeometry.py:27-45), rounded to the nearest of n_elev x n_azim
+// directions; the point's vector [n_elev * n_azim] gets a 1 there.  fp32 with the reference's operation order (floor_divide =
+// (x - x % d) / d, macarons/utility/utils.py:113-117, `%` = remainder with the divisor's sign); asin / acos / cos are this
+// platform's, so a ray within a few ulp of a bin boundary may fall on the other side than under torch's.
+__device__ __forceinline__ float pymodf(float x, float d) {
+    float m = fmodf(x, d);
+    if (m != 0.f && ((d < 0.f) != (m < 0.f))) m += d;
+    return m;
+}
+__device__ __forceinline__ int view_bin(const float* p, const float* xc, int n_elev, int n_azim, float elev_step, float azim_step,
+                                        float half_e, float half_a) {
+    const float rx = xc[0] - p[0], ry = xc[1] - p[1], rz = xc[2] - p[2];
+    const float r = sqrtf((rx * rx + ry * ry) + rz * rz);
+    const float s = ry / r;
+    float elev = asinf(s);
+    if (s <= -1.f) elev = -1.57079632679489661923f;
+    if (s >= 1.f) elev = 1.57079632679489661923f;
+    const float c = rz / (r * cosf(elev));
+    float azim = acosf(c);
+    if (c <= -1.f) azim = 3.14159265358979323846f;
+    if (c >= 1.f) azim = 0.f;
+    if (rx < 0.f) azim *= -1.f;
+    const float me = pymodf(elev, elev_step), ma = pymodf(azim, azim_step);
+    float ie = (elev - me) / elev_step, ia = (azim - ma) / azim_step;
+    if (me > half_e) ie += 1.f;
+    if (ma > half_a) ia += 1.f;
+    // floor division of the NEGATED counts, as Python's `-n_elev // 2` parses: (-n) // 2
+    const int lo_e = -((n_elev + 1) / 2), lo_a = -((n_azim + 1) / 2);
+    if (ie >= (float)n_elev) ie = (float)(n_elev - 1);
+    if (ie < (float)lo_e) ie = (float)lo_e;
+    if (ia > (float)(n_azim / 2)) ia = (float)lo_a;
+    ie += (float)(n_elev / 2);
+    if (ia < 0.f) ia += (float)n_azim;
+    const long long ind = (long long)ie * n_azim + (long long)ia;
+    const int nc = n_elev * n_azim;
+    return (int)(((ind % nc) + nc) % nc);
+}
+struct ViewArgs { float x[3 * MAX_CAMS]; int n_view, n_elev, n_azim; float elev_step, azim_step, half_e, half_a; };
+
+// one thread per (proxy point, camera); mask (or null) / sd < dist (sd or null) select the points, as
+// Scene.update_proxy_view_states does (macarons_utils.py:3284-3306)
+__global__ __launch_bounds__(256) void view_state_kernel(const float* __restrict__ pts, int P, const unsigned char* __restrict__ mask,
+                                                         const float* __restrict__ sd, float dist, ViewArgs va,
+                                                         float* __restrict__ view_states) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P || (mask && !mask[i]) || (sd && !(sd[i] < dist))) return;
+    const float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    const int nc = va.n_elev * va.n_azim;
+    for (int v = 0; v < va.n_view; ++v)
+        view_states[(size_t)i * nc + view_bin(p, va.x + 3 * v, va.n_elev, va.n_azim, va.elev_step, va.azim_step, va.half_e, va.half_a)] = 1.f;
+}
+
+// Geometric stand-in for the coverage gain of a candidate pose (the reference predicts it with the unreleased SCONE network,
+// macarons/testers/scene.py:640-670): the number of proxy points that lie in the candidate's field of view, are still
+// believed occupied (supervision occupancy 1) and have NOT been observed from the candidate's direction yet (their view-state
+// bit for that direction is 0).  One thread per (proxy point, candidate), wave-reduced, one integer atomic per wave.
+__global__ __launch_bounds__(256) void view_gain_kernel(const float* __restrict__ pts, int P, const float* __restrict__ occ,
+                                                        const float* __restrict__ view_states, CamSet cams, ViewArgs va, int H,
+                                                        int W, float tanh_fov, float fov_range, int* __restrict__ gains) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+    int hit = 0;
+    if (i < P) {
+        const float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+        float v[3], nx, ny;
+        if (occ[i] > 0.5f && point_in_fov(p, cams.c[c], H, W, tanh_fov, fov_range, v, &nx, &ny)) {
+            const int b = view_bin(p, va.x + 3 * c, va.n_elev, va.n_azim, va.elev_step, va.azim_step, va.half_e, va.half_a);
+            hit = view_states[(size_t)i * (va.n_elev * va.n_azim) + b] == 0.f ? 1 : 0;
+        }
+    }
+    const unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(gains + c, __popcll(m));
+}
+
 // ------------------------------------------------------------------ depth-map space carving (A20)
 // One thread per proxy point: frustum + range test, bilinear depth lookup (torch grid_sample
 // semantics: align_corners = False, border padding; invalid pixels read as 1.1 zfar), counters.
@@ -635,13 +710,16 @@ __global__ __launch_bounds__(256) void carve_update_kernel(const float* __restri
                                                            float tanh_fov, float zfar, float fov_range, float tol,
                                                            float score_thr, float* __restrict__ n_inside,
                                                            float* __restrict__ n_behind, float* __restrict__ occ,
-                                                           float* __restrict__ out_of_field) {
+                                                           float* __restrict__ out_of_field, float* __restrict__ view_states,
+                                                           float vs_dist, ViewArgs va, unsigned char* __restrict__ fov_mask,
+                                                           float* __restrict__ sd_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
     float v[3], nx, ny;
     const bool in_fov = point_in_fov(p, cam, H, W, tanh_fov, fov_range, v, &nx, &ny);
     const int s = H < W ? H : W;
+    if (fov_mask) fov_mask[i] = in_fov ? 1 : 0;
     if (!in_fov) return;
     // grid_sample coordinates (mu:2929-2944): gx = -(s/W) ndc_x, gy = -(s/H) ndc_y
     const float gx = (-(float)s / (float)W) * nx, gy = (-(float)s / (float)H) * ny;
@@ -664,6 +742,13 @@ __global__ __launch_bounds__(256) void carve_update_kernel(const float* __restri
     n_inside[i] = ni; n_behind[i] = nb;
     occ[i] = (nb / ni >= score_thr) ? 1.f : 0.f;
     out_of_field[i] = 0.f;
+    if (sd_out) sd_out[i] = sd;
+    // Scene.update_proxy_view_states as the NBV driver calls it BEFORE the occupancy update (macarons/testers/scene.py:598-607;
+    // the two touch different state, so the order is immaterial): points in the field of view whose signed distance is below
+    // vs_dist gain the direction towards the camera
+    if (view_states && sd < vs_dist)
+        view_states[(size_t)i * (va.n_elev * va.n_azim) +
+                    view_bin(p, va.x, va.n_elev, va.n_azim, va.elev_step, va.azim_step, va.half_e, va.half_a)] = 1.f;
 }
 
 }  // namespace
@@ -931,7 +1016,72 @@ extern "C" int nbp_carve_update_f32(const float* proxy_pts3, int P, const float*
     for (int k = 0; k < 3; ++k) cam.T[k] = cam12_host[9 + k];
     carve_update_kernel<<<(unsigned)nbp_cdiv(P, 256), 256, 0, (hipStream_t)stream>>>(
         proxy_pts3, P, depth, mask_or_null, cam, H, W, tan_half_fov, zfar, fov_range, tol, score_threshold, n_inside,
-        n_behind, occ, out_of_field);
+        n_behind, occ, out_of_field, nullptr, 0.f, ViewArgs{}, nullptr, nullptr);
+    return nbp_launch_status();
+}
+
+static int view_args_from_host(const float* x_view_host, int n_view, int n_elev, int n_azim, ViewArgs* va) {
+    NBP_RETURN_IF(!x_view_host || n_view < 1 || n_view > MAX_CAMS || n_elev < 1 || n_azim < 1 || (long long)n_elev * n_azim > 4096, NBP_E_ARG);
+    for (int k = 0; k < 3 * MAX_CAMS; ++k) va->x[k] = k < 3 * n_view ? x_view_host[k] : 0.f;
+    va->n_view = n_view; va->n_elev = n_elev; va->n_azim = n_azim;
+    const double es = 3.14159265358979323846 / (n_elev + 1), as = 2.0 * 3.14159265358979323846 / n_azim;   // np.pi / (n_elev + 1), 2 np.pi / n_azim
+    va->elev_step = (float)es; va->azim_step = (float)as; va->half_e = (float)(es / 2.0); va->half_a = (float)(as / 2.0);
+    return 0;
+}
+
+extern "C" int nbp_view_state_update_f32(const float* pts3, int P, const unsigned char* mask_or_null, const float* sd_or_null,
+                                         float distance_to_surface, const float* x_view_host, int n_view, int n_elev, int n_azim,
+                                         float* view_states, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!pts3 || !view_states || P < 1, NBP_E_ARG);
+    ViewArgs va;
+    const int rc = view_args_from_host(x_view_host, n_view, n_elev, n_azim, &va);
+    if (rc) return rc;
+    view_state_kernel<<<(unsigned)nbp_cdiv(P, 256), 256, 0, (hipStream_t)stream>>>(pts3, P, mask_or_null, sd_or_null, distance_to_surface,
+                                                                                 va, view_states);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_view_gain_i32(const float* pts3, int P, const float* occ, const float* view_states, const float* cams12_host,
+                                 const float* x_cams_host, int n_cams, int n_elev, int n_azim, int H, int W, float tan_half_fov,
+                                 float fov_range, int* gains, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!pts3 || !occ || !view_states || !cams12_host || !x_cams_host || !gains || P < 1 || n_cams < 1 || H < 2 || W < 2, NBP_E_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(gains, 0, (size_t)n_cams * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    for (int c0 = 0; c0 < n_cams; c0 += MAX_CAMS) {                      // candidates travel in the kernel arguments, 8 at a time
+        const int nc = n_cams - c0 < MAX_CAMS ? n_cams - c0 : MAX_CAMS;
+        ViewArgs va;
+        const int rc = view_args_from_host(x_cams_host + 3 * (size_t)c0, nc, n_elev, n_azim, &va);
+        if (rc) return rc;
+        dim3 g((unsigned)nbp_cdiv(P, 256), (unsigned)nc);
+        view_gain_kernel<<<g, 256, 0, st>>>(pts3, P, occ, view_states, camset_from_host(cams12_host + 12 * (size_t)c0, nc), va, H, W,
+                                            tan_half_fov, fov_range, gains + c0);
+        const int rc2 = nbp_launch_status();
+        if (rc2) return rc2;
+    }
+    return 0;
+}
+
+extern "C" int nbp_carve_view_update_f32(const float* proxy_pts3, int P, const float* depth, const unsigned char* mask_or_null,
+                                         const float* cam12_host, int H, int W, float tan_half_fov, float zfar, float fov_range,
+                                         float tol, float score_threshold, float* n_inside, float* n_behind, float* occ,
+                                         float* out_of_field, const float* x_cam_host, int n_elev, int n_azim,
+                                         float distance_to_surface, float* view_states, unsigned char* fov_mask_or_null,
+                                         float* sd_or_null, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!proxy_pts3 || !depth || !cam12_host || !n_inside || !n_behind || !occ || !out_of_field || !view_states, NBP_E_ARG);
+    NBP_RETURN_IF(P < 1 || H < 2 || W < 2, NBP_E_ARG);
+    Cam cam;
+    for (int k = 0; k < 9; ++k) cam.R[k] = cam12_host[k];
+    for (int k = 0; k < 3; ++k) cam.T[k] = cam12_host[9 + k];
+    ViewArgs va;
+    const int rc = view_args_from_host(x_cam_host, 1, n_elev, n_azim, &va);
+    if (rc) return rc;
+    carve_update_kernel<<<(unsigned)nbp_cdiv(P, 256), 256, 0, (hipStream_t)stream>>>(
+        proxy_pts3, P, depth, mask_or_null, cam, H, W, tan_half_fov, zfar, fov_range, tol, score_threshold, n_inside,
+        n_behind, occ, out_of_field, view_states, distance_to_surface, va, fov_mask_or_null, sd_or_null);
     return nbp_launch_status();
 }
 

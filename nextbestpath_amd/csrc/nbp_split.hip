@@ -55,7 +55,8 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsi
 // atomics run at ~0.3 G/s on this part (16 k waves finishing together = 55 us), so writers spread over the words by
 // workgroup id and readers take the max of all of them with one 256-B load per wave.
 constexpr int AMAX_WORDS = 64;
-#define NBP_SPLIT_MAX_K_DEFAULT 0
+#define NBP_SPLIT_MAX_K_DEFAULT 2304
+#define NBP_SPLIT_MAX_K_SMALL_DEFAULT 576
 __device__ __forceinline__ void wave_amax(float mx, unsigned* out) {
 #pragma unroll
     for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -942,13 +943,20 @@ int launch_h2(const SplitArgs& a, hipStream_t st) {
 }  // namespace
 
 // Accuracy-driven split-K: one fp32 accumulator sees 3 roundings per 16 k (three MFMAs), and the distance of a chain's result to
-// the exact sum grows like K_chain / sqrt(steps per k) (measured, tools/diag/chain_error.py: a K = 9216 chain sits 4.5x further from
-// fp64 than stock torch CPU fp32 -- whose GEMM accumulates in blocks -- a K = 576 one 1.5x).  Chains are therefore bounded to
-// NBP_SPLIT_MAX_K products (taps x channels) whatever the occupancy says: slices beyond the occupancy-driven count exist for accuracy.
-static int chain_bounded_split(int sk, int cc, int taps) {
+// the exact sum grows like K_chain / sqrt(k per rounding) (measured, tools/diag/chain_error.py, profiles/r03/chain_error.txt: a
+// K = 9216 chain sits 4.5x further from fp64 than stock torch CPU fp32 -- whose GEMM accumulates in blocks -- a K = 576 one 1.5x).
+// Chains are therefore bounded whatever the occupancy says: slices beyond the occupancy-driven count exist for accuracy.  The
+// bound has two tiers because the price is the partial sums' traffic (slices x M x N x 8 bytes): NBP_SPLIT_MAX_K_SMALL products
+// (taps x channels) per chain where one slice of all groups is at most NBP_SPLIT_SMALL_MB (the 16 / 32-pixel levels: the extra
+// slices are free there -- more workgroups -- or cost a few us), NBP_SPLIT_MAX_K on the larger outputs.
+static int chain_bounded_split(int sk, int cc, int taps, long long M, int N, int groups) {
     static const int max_k = [] { const char* e = getenv("NBP_SPLIT_MAX_K"); return e ? atoi(e) : NBP_SPLIT_MAX_K_DEFAULT; }();
-    if (max_k <= 0) return sk;
-    const int max_chunks = max_k / (16 * taps) > 1 ? max_k / (16 * taps) : 1;
+    static const int max_k_small = [] { const char* e = getenv("NBP_SPLIT_MAX_K_SMALL"); return e ? atoi(e) : NBP_SPLIT_MAX_K_SMALL_DEFAULT; }();
+    static const int small_mb = [] { const char* e = getenv("NBP_SPLIT_SMALL_MB"); return e ? atoi(e) : 64; }();
+    const bool small = (double)M * N * groups * 4.0 <= (double)small_mb * 1048576.0;
+    const int mk = small && max_k_small > 0 ? max_k_small : max_k;
+    if (mk <= 0) return sk;
+    const int max_chunks = mk / (16 * taps) > 1 ? mk / (16 * taps) : 1;
     const int need = (int)nbp_cdiv(cc, max_chunks);
     return need > sk ? need : sk;
 }
@@ -971,7 +979,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
                 sk = 1;
                 while (blocks * sk < min_blocks_up && cc / (sk * 2) >= 4 && sk < 16) sk *= 2;
             }
-            if (split_k <= 0) sk = chain_bounded_split(sk, cc, 4);
+            if (split_k <= 0) sk = chain_bounded_split(sk, cc, 4, M, N, groups);
             if (sk > cc) sk = cc;
             const int per = (int)nbp_cdiv(cc, sk);
             p.tile = NBP_TILE_SPLIT_UP; p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
@@ -994,7 +1002,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
         // B = 12: 5.07 -> 5.02 ms, B = 8 / 1 unchanged, B = 4 +0.6 %; with 8 chunks B = 4 loses 2.5 %)
         static const int deep = [] { const char* e = getenv("NBP_SPLIT_DEEP"); return e ? atoi(e) : 16; }();
         if (deep > 0 && blocks * sk < 2 * min_blocks && cc / (sk * 2) >= deep && sk < 16) sk *= 2;
-        sk = chain_bounded_split(sk, cc, 9);
+        sk = chain_bounded_split(sk, cc, 9, M, N, groups);
     }
     if (sk > cc) sk = cc;
     const int per = (int)nbp_cdiv(cc, sk);
@@ -1229,6 +1237,16 @@ extern "C" int nbp_amax_f32(const float* x, long long n, void* amax_inout, void*
 
 extern "C" size_t nbp_conv_split_workspace_bytes(int B, int H, int W, int N, int split_k) {
     const int sk = split_k == 1 ? 0 : (split_k <= 0 ? 16 : split_k);
+    return 256 + (size_t)sk * B * H * W * N * sizeof(float);
+}
+
+// Workspace of ONE layer as the planner will run it (split_k = 0): 256 B for the max-|x| slot + the split-K slices it plans.
+// C = C0 + C1; ups = the layer reads its input through the x2 upsample (parity kernels when the low-resolution image tiles).
+extern "C" size_t nbp_conv_split_planned_workspace_bytes(int B, int H, int W, int C, int N, int ups, int* split_k_out) {
+    if (B < 1 || H < 1 || W < 1 || C < 32 || N < 1) return 0;
+    const ConvPlan p = nbp_plan_conv_split((long long)B * H * W, N, C / 32 * 9, 0, 1, H, W, 3, ups ? 1 : 0);
+    if (split_k_out) *split_k_out = p.tile ? p.split_k : 0;
+    const int sk = (p.tile && p.split_k > 1) ? p.split_k : 0;
     return 256 + (size_t)sk * B * H * W * N * sizeof(float);
 }
 

@@ -132,7 +132,7 @@ def _conv_split(src0, src1, ups, packed, N, scale, shift, relu, amax=None):
     H, W = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     C1 = 0 if src1 is None else src1.shape[3]
     out = torch.empty(B, H, W, N, dtype=torch.float32, device=src0.device)
-    ws = _ws(L.nbp_conv_split_workspace_bytes(B, H, W, N, 0), src0.device)
+    ws = _ws(L.nbp_conv_split_planned_workspace_bytes(B, H, W, C0 + C1, N, int(ups), None), src0.device)     # the slices the planner will use
     # max |x| of the inputs: the caller's slot, else taken inside the call (autograd hands tensors over without their history)
     _chk(L.nbp_conv3x3_split_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, _lib.ptr(planes), _lib.ptr(wamax), N,
                                  _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), _lib.ptr(amax), None, 0, _lib.ptr(ws),
@@ -158,7 +158,7 @@ def _upconv_split(src, w_oihw, n_pad, scale, shift, amax=None):
     _chk(L.nbp_pack_upconv_weight_split(_lib.ptr(w_oihw), n_pad, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_upconv")
     H, W = 2 * Hs, 2 * Ws
     out = torch.empty(B, H, W, n_pad, dtype=torch.float32, device=src.device)
-    ws = _ws(L.nbp_conv_split_workspace_bytes(B, H, W, n_pad, 0), src.device)
+    ws = _ws(L.nbp_conv_split_planned_workspace_bytes(B, H, W, C0, n_pad, 1, None), src.device)
     _chk(L.nbp_upconv3x3_split_f32(_lib.ptr(src), C0, B, H, W, _lib.ptr(planes), _lib.ptr(wamax), n_pad, _lib.ptr(scale),
                                    _lib.ptr(shift), 0, _lib.ptr(out), _lib.ptr(amax), None, 0, _lib.ptr(ws), ws.numel(), _st()), "upconv3x3_split")
     return out

@@ -137,7 +137,7 @@ class Scene:
     point state of the depth-map carving (mu:3239-3249, 3329-3363).  Point features (colours) are not stored."""
 
     def __init__(self, x_min, x_max, grid_l, grid_w, grid_h, cell_capacity, cell_resolution, n_proxy_points, device,
-                 score_threshold=1.0, seed=0):
+                 score_threshold=1.0, seed=0, view_state_n_elev=7, view_state_n_azim=2 * 7):
         self.x_min, self.x_max = np.asarray(x_min, f32).copy(), np.asarray(x_max, f32).copy()
         self.grid_l, self.grid_w, self.grid_h = int(grid_l), int(grid_w), int(grid_h)
         self.device, self.seed, self.n_fills = device, int(seed), 0
@@ -158,7 +158,9 @@ class Scene:
         self.cell_pts = torch.zeros(self.n_cells, self.cell_capacity, 3, dtype=torch.float32, device=device)
         self.cell_count = torch.zeros(self.n_cells, dtype=torch.int32, device=device)
         self.n_proxy_points, self.score_threshold = int(n_proxy_points), float(score_threshold)
-        self.proxy_points = None
+        self.view_state_n_elev, self.view_state_n_azim = int(view_state_n_elev), int(view_state_n_azim)      # mu:3042, 3106-3109
+        self.n_view_state_cameras = self.view_state_n_elev * self.view_state_n_azim
+        self.proxy_points = self.view_states = None
         n_per_cell = self.n_proxy_points / self.n_cells
         vol = float(self.l * self.w * self.h) / max(n_per_cell, 1e-30)
         self.distance_between_proxy_points = 2 * np.power(3 * vol / (4 * np.pi), 1.0 / 3.0)
@@ -218,14 +220,37 @@ class Scene:
         self.out_of_field = torch.ones(n, 1, device=dev)
         self.proxy_n_inside_fov = torch.zeros(n, 1, device=dev)
         self.proxy_n_behind_depth = torch.zeros(n, 1, device=dev)
+        self.view_states = torch.zeros(n, self.n_view_state_cameras, device=dev)          # mu:3245
 
-    def carve(self, depth, cam12_host, zfar, fov_range, tol):
+    def carve(self, depth, cam12_host, zfar, fov_range, tol, X_cam=None):
         """One depth frame: Camera.get_points_in_fov + get_signed_distance_to_depth_maps (mu:2849-2949) +
-        update_proxy_supervision_occ + update_proxy_out_of_field (mu:3329-3363), one fused launch."""
+        update_proxy_supervision_occ + update_proxy_out_of_field (mu:3329-3363), one fused launch.  With the camera position
+        X_cam [3] the same launch also updates the view-state vectors (update_proxy_view_states, mu:3268-3327, as the drivers
+        call it: points in the field of view whose signed distance is below 3 x distance_between_proxy_points)."""
         from ..utility import hipops
-        hipops.carve_update(self.proxy_points, depth, None, cam12_host, zfar, fov_range, tol, self.score_threshold,
-                            self.proxy_n_inside_fov, self.proxy_n_behind_depth, self.proxy_supervision_occ,
-                            self.out_of_field)
+        if X_cam is None:
+            hipops.carve_update(self.proxy_points, depth, None, cam12_host, zfar, fov_range, tol, self.score_threshold,
+                                self.proxy_n_inside_fov, self.proxy_n_behind_depth, self.proxy_supervision_occ,
+                                self.out_of_field)
+            return
+        hipops.carve_view_update(self.proxy_points, depth, None, cam12_host, zfar, fov_range, tol, self.score_threshold,
+                                 self.proxy_n_inside_fov, self.proxy_n_behind_depth, self.proxy_supervision_occ,
+                                 self.out_of_field, X_cam, self.view_state_n_elev, self.view_state_n_azim,
+                                 3.0 * self.distance_between_proxy_points, self.view_states)
+
+    def update_proxy_view_states(self, camera, proxy_mask, signed_distances=None, distance_to_surface=None, X_cam=None):
+        """mu:3268-3327 with the reference's arguments; proxy_mask [P] bool / uint8, signed_distances [P] fp32 over ALL proxy
+        points (entries outside the mask are ignored), X_cam [3] or [1, 3] (default: the camera's position)."""
+        from ..utility import hipops
+        if X_cam is None:
+            X_cam = camera.X_cam
+        xc = X_cam.detach().cpu().numpy() if torch.is_tensor(X_cam) else np.asarray(X_cam)
+        if signed_distances is not None and distance_to_surface is None:
+            distance_to_surface = 3 * self.distance_between_proxy_points
+        hipops.view_state_update(self.proxy_points, xc.reshape(-1, 3)[:1], self.view_state_n_elev, self.view_state_n_azim,
+                                 self.view_states, mask=proxy_mask.to(torch.uint8).contiguous(),
+                                 sd=None if signed_distances is None else signed_distances.reshape(-1).contiguous(),
+                                 distance_to_surface=distance_to_surface or 0.0)
 
 
 def fill_surface_scene(surface_scene, full_pc, n_dev=None, random_sampling_max_size=200000, min_n_points_per_cell_fill=3,

@@ -4,9 +4,10 @@ compute_random_walk_trajectory (macarons/testers/random_walk_planning.py:25-400)
 What the reference's loop does per pose, and what runs here:
   * covered_scene.fill_cells(current frame) + gt_scene.scene_coverage(covered_scene)  (:64-92)   -> nbp_scene.hip
   * surface_scene.fill_cells(current frame), full_pc append                            (:118-136) -> nbp_scene.hip
-  * proxy points in the field of view, signed distance to the depth map, supervision occupancy and out-of-field flags
+  * proxy points in the field of view, signed distance to the depth map, view-state vectors (compute_view_state,
+    macarons/utility/scone_utils.py:799-862), supervision occupancy and out-of-field flags
     (:140-166, 305-385; Camera.get_points_in_fov / get_signed_distance_to_depth_maps, Scene.update_proxy_*)
-                                                                                                   -> nbp_carve_update_f32
+                                                                                                   -> nbp_carve_view_update_f32
   * valid neighbours of the pose lattice (non-empty field of view, :181-182)                      -> nbp_points_in_fov_u8
   * the move (4 interpolated poses, one raster launch) and the 4 supervision frames (:258-360)     -> nbp_sim.hip
   * every recompute_surface_every_n_loop poses the surface scene is rebuilt progressively (:52-59)  -> fill_surface_scene
@@ -14,7 +15,8 @@ The occupancy field and the coverage-gain prediction of the reference need the M
 (compute_scene_occupancy_probability_field, predict_coverage_gain_for_single_camera, :169-215), which are not
 released (out of scope): `coverage_gain_fn(camera, neighbour_idx) -> float` may supply a gain
 model; without one every step takes a uniformly random valid neighbour (the reference's own 20 % exploration branch,
-:250-251).  The proxy cells and view-state vectors only feed those networks and are not maintained.  Random draws are
+:250-251); testers/scene.py holds the next-best-view loop that consumes such a model.  The proxy cells (which only index
+the proxy points for those networks) are not maintained; the view-state vectors are.  Random draws are
 seeded (sub-sampling bijection, random.Random) like the NBP driver."""
 from __future__ import annotations
 
@@ -58,6 +60,13 @@ class RandomWalkRollout:
         self.full_pc[c:c + n] = self.part[:n]
         self.full_count += n
 
+    def choose(self, valid):
+        """the random walk's rule (:250-251 plus the optional gain model); testers/scene.py::NBVRollout overrides it"""
+        if self.gain_fn is not None and self.rng.random() >= 0.2:
+            gains = [self.gain_fn(self.camera, n) for n in valid]
+            return valid[int(np.argmax(gains))]
+        return self.rng.choice(valid)
+
     def step(self):
         p, cam, pose_i = self.params, self.camera, self.pose_i
         if pose_i > 0 and pose_i % p.recompute_surface_every_n_loop == 0:
@@ -75,21 +84,17 @@ class RandomWalkRollout:
         self.surface_scene.fill_cells(self.part, n_dev=self.part_count)
         self._append_full()
         # proxy points against the current depth map (:140-166)
-        self.proxy_scene.carve(depth[0], cams[0], p.zfar, p.sensor_range, p.carving_tolerance)
+        self.proxy_scene.carve(depth[0], cams[0], p.zfar, p.sensor_range, p.carving_tolerance, X_cam=cam.X_cam)     # + view states
         # next pose among the valid neighbours (:181-251)
         valid = cam.get_valid_neighbors(cam.get_neighboring_poses_2d(), self.mesh)
-        if self.gain_fn is not None and self.rng.random() >= 0.2:
-            gains = [self.gain_fn(cam, n) for n in valid]
-            next_idx = valid[int(np.argmax(gains))]
-        else:
-            next_idx = self.rng.choice(valid)
+        next_idx = self.choose(valid)
         cam.move_and_capture(self.mesh, next_idx)
         # the 4 supervision frames: surface points, carving per frame (:305-385)
         depth, cams = self._partial([-5, -4, -3, -2], self.seed + 11 * pose_i + 5)
         self.surface_scene.fill_cells(self.part, n_dev=self.part_count)
         self._append_full()
         for i in range(depth.shape[0]):
-            self.proxy_scene.carve(depth[i], cams[i], p.zfar, p.sensor_range, p.carving_tolerance)
+            self.proxy_scene.carve(depth[i], cams[i], p.zfar, p.sensor_range, p.carving_tolerance, X_cam=hipops.camera_center(cams[i]))
         self.pose_i += 1
 
 

@@ -281,6 +281,54 @@ def carve_update(proxy_pts, depth, mask, cam12_host, zfar, fov_range, tol, score
     _lib.check(rc, "nbp_carve_update_f32")
 
 
+def camera_center(cam12_host):
+    """World position of the camera of a [12] host camera (R row-major, T): C = -T R^T in fp32 (get_camera_center)."""
+    import numpy as np
+    c = np.asarray(cam12_host, np.float32)
+    R, T = c[:9].reshape(3, 3), c[9:]
+    return np.array([-((T[0] * R[j, 0] + T[1] * R[j, 1]) + T[2] * R[j, 2]) for j in range(3)], np.float32)
+
+
+def view_state_update(pts, x_view_host, n_elev, n_azim, view_states, mask=None, sd=None, distance_to_surface=0.0):
+    """compute_view_state (scone_utils.py:799-862) OR-ed into view_states [P, n_elev * n_azim] (fp32 0 / 1) for the selected
+    points: mask [P] uint8 (None = all) and sd [P] < distance_to_surface (None = no test); x_view_host [n_view <= 8, 3]."""
+    import numpy as np
+    xv = np.ascontiguousarray(x_view_host, np.float32).reshape(-1, 3)
+    rc = _lib.lib().nbp_view_state_update_f32(_lib.ptr(pts), pts.shape[0], _lib.ptr(mask), _lib.ptr(sd), float(distance_to_surface),
+                                              xv.ctypes.data_as(C.POINTER(C.c_float)), len(xv), int(n_elev), int(n_azim),
+                                              _lib.ptr(view_states), _st())
+    _lib.check(rc, "nbp_view_state_update_f32")
+
+
+def view_gain(proxy_pts, occ, view_states, cams12_host, x_cams_host, n_elev, n_azim, H, W, fov_range, tan_half_fov=TAN_HALF_FOV):
+    """gains [n_cams] int32 (device): occupied proxy points in each candidate's field of view not yet seen from its direction."""
+    import numpy as np
+    cams = np.ascontiguousarray(cams12_host, np.float32).reshape(-1, 12)
+    xs = np.ascontiguousarray(x_cams_host, np.float32).reshape(-1, 3)
+    gains = torch.empty(len(cams), dtype=torch.int32, device=proxy_pts.device)
+    fp = C.POINTER(C.c_float)
+    rc = _lib.lib().nbp_view_gain_i32(_lib.ptr(proxy_pts), proxy_pts.shape[0], _lib.ptr(occ), _lib.ptr(view_states),
+                                      cams.ctypes.data_as(fp), xs.ctypes.data_as(fp), len(cams), int(n_elev), int(n_azim), int(H), int(W),
+                                      tan_half_fov, float(fov_range), _lib.ptr(gains), _st())
+    _lib.check(rc, "nbp_view_gain_i32")
+    return gains
+
+
+def carve_view_update(proxy_pts, depth, mask, cam12_host, zfar, fov_range, tol, score_threshold, n_inside, n_behind, occ,
+                      out_of_field, x_cam_host, n_elev, n_azim, distance_to_surface, view_states, fov_mask=None, sd=None,
+                      tan_half_fov=TAN_HALF_FOV):
+    """carve_update + Scene.update_proxy_view_states (macarons_utils.py:3268-3327) for the frame's camera in ONE launch."""
+    H, W = depth.shape[-2:]
+    cam = (C.c_float * 12)(*[float(x) for x in cam12_host])
+    xc = (C.c_float * 3)(*[float(x) for x in x_cam_host])
+    rc = _lib.lib().nbp_carve_view_update_f32(_lib.ptr(proxy_pts), proxy_pts.shape[0], _lib.ptr(depth), _lib.ptr(mask), cam, H, W,
+                                              tan_half_fov, float(zfar), float(fov_range), float(tol), float(score_threshold),
+                                              _lib.ptr(n_inside), _lib.ptr(n_behind), _lib.ptr(occ), _lib.ptr(out_of_field), xc,
+                                              int(n_elev), int(n_azim), float(distance_to_surface), _lib.ptr(view_states),
+                                              _lib.ptr(fov_mask), _lib.ptr(sd), _st())
+    _lib.check(rc, "nbp_carve_view_update_f32")
+
+
 def _scene_geom(scene):
     import numpy as np
     box = np.ascontiguousarray(scene.box6(), np.float32)

@@ -111,6 +111,12 @@ def pose_lattice(x_min, pose_l, pose_w, pose_h, n_elev, n_azim):
     return idx, poses
 
 
+def camera_center(R, T):
+    """World position of a camera given (R, T) of X_view = X_world R + T: C = -T R^T (fp32, the op order of points_in_fov)."""
+    R, T = np.asarray(R, f32), np.asarray(T, f32)
+    return np.array([-((T[0] * R[j, 0] + T[1] * R[j, 1]) + T[2] * R[j, 2]) for j in range(3)], f32)
+
+
 def points_in_fov(pts, R, T, H, W, fov_range):
     """Camera.get_points_in_fov (mu:2849-2884): boolean mask (fp32, kernel op order; same test as carve_update)."""
     s = min(H, W)

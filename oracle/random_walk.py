@@ -10,6 +10,7 @@ import numpy as np
 from . import camera as ocam
 from . import sampling
 from . import scene_store as oss
+from . import view_state as ovs
 from .rollout import OracleCamera
 
 f32 = np.float32
@@ -37,6 +38,13 @@ class OracleRandomWalk:
         P = len(self.proxy)
         self.n_inside, self.n_behind = np.zeros(P, f32), np.zeros(P, f32)
         self.occ, self.oof = np.ones(P, f32), np.ones(P, f32)
+        self.n_elev, self.n_azim = params.get("view_state_n_elev", 7), params.get("view_state_n_azim", 14)
+        self.view_states = np.zeros((P, self.n_elev * self.n_azim), f32)
+        # Scene.__init__ (mu:3110-3124): proxy_radius from the cell volume per proxy point
+        n_cells = grid[0] * grid[1] * grid[2]
+        d = (np.asarray(x_max, f32) - np.asarray(x_min, f32)) / np.asarray(grid, f32)
+        vol = float(d[0] * d[1] * d[2]) / max(P / n_cells, 1e-30)
+        self.dist_between = 2 * np.power(3 * vol / (4 * np.pi), 1.0 / 3.0)
         self.full_pc = np.zeros((0, 3), f32)
         self.rng = random.Random(seed)
         self.seed = seed * 1_000_003
@@ -59,10 +67,14 @@ class OracleRandomWalk:
             out.append(pts)
         return np.concatenate(out, 0)
 
-    def _carve(self, w):
+    def _carve(self, w, X_cam=None):
+        """carving + update_proxy_view_states (random_walk_planning.py:140-166 with X_cam = the camera's pose position,
+        :375-385 with the frame's camera centre)"""
         z, R, T = self.cam.frames[w][:3]
-        ocam.carve_update(self.proxy, z, None, R, T, self.p["zfar"], self.p["sensor_range"], self.p["carving_tolerance"],
-                          self.p["score_threshold"], self.n_inside, self.n_behind, self.occ, self.oof)
+        inf, sd = ocam.carve_update(self.proxy, z, None, R, T, self.p["zfar"], self.p["sensor_range"], self.p["carving_tolerance"],
+                                    self.p["score_threshold"], self.n_inside, self.n_behind, self.occ, self.oof)
+        xc = ocam.camera_center(R, T) if X_cam is None else np.asarray(X_cam, f32)
+        ovs.update_proxy_view_states(self.view_states, self.proxy, inf, sd, xc, self.n_elev, self.n_azim, 3 * self.dist_between)
 
     def _valid_neighbors(self):
         nbrs = self.cam.neighbors(self.cam.cam_idx)
@@ -97,7 +109,7 @@ class OracleRandomWalk:
         part = self._partial([-1], self.seed + 11 * pose_i + 3)
         self._fill("surface", self.surface, part)
         self.full_pc = np.concatenate([self.full_pc, part], 0)
-        self._carve(-1)
+        self._carve(-1, X_cam=self.cam.X)
         valid = self._valid_neighbors()
         next_idx = self.rng.choice(valid)
         self.cam.move_and_capture(self.verts, self.faces, next_idx)

@@ -382,8 +382,58 @@ def gen_scene(mu):
         torch.Tensor.get_device = orig_get_device
 
 
+def gen_viewstate(mu):
+    """View-state vectors of the proxy points: compute_view_state (macarons/utility/scone_utils.py:799-862)
+    on random points / camera positions incl. the degenerate directions (straight up / down, x = 0, azimuth +-pi), and
+    Scene.update_proxy_view_states (macarons_utils.py:3268-3327) called as the NBV driver calls it
+    (macarons/testers/scene.py:598-601: signed distances given, distance_to_surface=None, X_cam=None) on a reference Scene.
+    Same shim as gen_scene: Tensor.get_device() -> 'cpu'."""
+    import macarons.utility.scone_utils as su
+    orig_get_device = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda self: "cpu"
+    try:
+        g = torch.Generator().manual_seed(31)
+        pts = (torch.rand(4000, 3, generator=g) * 2 - 1) * torch.tensor([40.0, 6.0, 40.0])
+        views = (torch.rand(6, 3, generator=g) * 2 - 1) * torch.tensor([30.0, 10.0, 30.0])
+        # degenerate rays from the first camera: straight up / down, in the x = 0 plane on both sides, along +-x, equal points
+        pts[0] = views[0] + torch.tensor([0.0, -5.0, 0.0]); pts[1] = views[0] + torch.tensor([0.0, 5.0, 0.0])
+        pts[2] = views[0] + torch.tensor([0.0, 0.0, -7.0]); pts[3] = views[0] + torch.tensor([0.0, 0.0, 7.0])
+        pts[4] = views[0] + torch.tensor([3.0, 0.0, 0.0]); pts[5] = views[0] + torch.tensor([-3.0, 0.0, 0.0])
+        pts[6] = views[0] + torch.tensor([0.0, 1.0, 1.0]); pts[7] = views[0] + torch.tensor([-1e-3, 0.0, -9.0])
+        vs = su.compute_view_state(pts.view(1, -1, 3), views, 7, 14).view(-1, 98)
+        vs1 = su.compute_view_state(pts.view(1, -1, 3), views[:1], 7, 14).view(-1, 98)
+        vs_small = su.compute_view_state(pts[:500].view(1, -1, 3), views[:2], 4, 6).view(-1, 24)
+        # --- Scene.update_proxy_view_states, twice (the vectors accumulate: heaviside of the sum)
+        sc = mu.Scene(x_min=torch.tensor([-20.0, 0.0, -20.0]), x_max=torch.tensor([20.0, 8.0, 20.0]), grid_l=2, grid_w=1, grid_h=2,
+                      cell_capacity=100, cell_resolution=0.5, n_proxy_points=3000, device="cpu", feature_dim=0)
+        torch.manual_seed(32)
+        sc.initialize_proxy_points()
+        proxy = sc.proxy_points.clone()
+        states, masks, sds, cams = [], [], [], []
+        for k in range(2):
+            cam = types.SimpleNamespace(X_cam=views[k:k + 1].clone())
+            mask = torch.rand(3000, generator=g) < 0.6
+            sd = (torch.rand(int(mask.sum()), 1, generator=g) * 2 - 1) * 4 * sc.distance_between_proxy_points
+            sc.update_proxy_view_states(cam, mask, signed_distances=sd, distance_to_surface=None, X_cam=None)
+            states.append(sc.view_states.clone()); masks.append(mask.clone()); sds.append(sd.view(-1).clone()); cams.append(cam.X_cam[0].clone())
+        sd_full = [torch.zeros(3000).masked_scatter(m, s) for m, s in zip(masks, sds)]
+        np.savez_compressed(os.path.join(HERE, "viewstate.npz"), pts=pts.numpy(), views=views.numpy(), vs=vs.numpy().astype(np.uint8),
+                            vs1=vs1.numpy().astype(np.uint8), vs_small=vs_small.numpy().astype(np.uint8), proxy=proxy.numpy(),
+                            dist_between=np.float64(sc.distance_between_proxy_points),
+                            upd_mask=np.stack([m.numpy() for m in masks]), upd_sd=np.stack([s.numpy() for s in sd_full]),
+                            upd_cam=np.stack([c.numpy() for c in cams]),
+                            upd_state=np.stack([s.numpy().astype(np.uint8) for s in states]))
+        print("viewstate: set bits", int(vs.sum()), int(vs1.sum()), int(vs_small.sum()), "after updates", [int(s.sum()) for s in states],
+              "dist", float(sc.distance_between_proxy_points))
+    finally:
+        torch.Tensor.get_device = orig_get_device
+
+
 if __name__ == "__main__":
     model, utils, ltu, mu = import_reference()
+    if "--only-viewstate" in sys.argv:
+        gen_viewstate(mu)
+        sys.exit(0)
     if "--only-scene" in sys.argv:
         gen_scene(mu)
         sys.exit(0)
@@ -394,6 +444,7 @@ if __name__ == "__main__":
     gen_planner(ltu, mu)
     gen_replan(utils, ltu, mu)
     gen_scene(mu)
+    gen_viewstate(mu)
     gen_network(model)
     gen_training(model)
     gen_training(model, B=4, S=128, K=40, tag="S128B4")

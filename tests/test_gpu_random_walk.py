@@ -93,5 +93,72 @@ def test_random_walk_rollout_equals_oracle(hip, tmp_path):
     for got, want in ((proxy.proxy_n_inside_fov, ora.n_inside), (proxy.proxy_n_behind_depth, ora.n_behind),
                       (proxy.proxy_supervision_occ, ora.occ), (proxy.out_of_field, ora.oof)):
         assert np.array_equal(got.cpu().numpy().reshape(-1), want)
+    # view-state vectors (compute_view_state through nbp_carve_view_update_f32): identical except for rays within 1e-5 rad of a
+    # bin's rounding boundary (asin / acos of two maths libraries)
+    from oracle import view_state as ovs
+    got_vs, want_vs = proxy.view_states.cpu().numpy(), ora.view_states
+    diff = np.nonzero((got_vs != want_vs).any(1))[0]
+    assert want_vs.sum() > 1000 and want_vs.sum(1).max() >= 3 and len(diff) <= 3, (len(diff), want_vs.sum())
     assert 0 < float(proxy.out_of_field.sum()) < params.n_proxy_points            # some points seen, some never
     assert float(proxy.proxy_supervision_occ.min()) == 0.0                         # free space was carved
+
+
+def test_nbv_rollout_consumes_view_states(hip, tmp_path):
+    """testers/scene.py (the reference's compute_trajectory, macarons/testers/scene.py:491-826, with the geometric gain model in
+    place of the unreleased SCONE predictor): every step's candidate gains equal the CPU restatement evaluated on the same proxy
+    state (oracle/view_state.py::view_gain), the move goes to the first neighbour with the largest gain, a user-supplied
+    coverage_gain_fn takes over when given, and coverage grows."""
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.simulator.mesh import make_maze_scene
+    from nextbestpath_amd.testers import nbp_planning as tp
+    from nextbestpath_amd.testers.scene import NBVRollout, compute_trajectory
+    from oracle import camera as ocam
+    from oracle import view_state as ovs
+    make_maze_scene(str(tmp_path / "m"), seed=5, cells=5, size=3.0, height=1.2, tess=0.3)
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    params.image_height, params.image_width = 128, 228
+    params.n_proxy_points, params.n_gt_surface_points = 5000, 6000
+    dev = torch.device(D)
+    ds = sc.SceneDataset(str(tmp_path), ["m"])
+    settings = sc.Settings(ds[0]["settings"], params.scene_scale_factor)
+    mesh = sc.load_scene(os.path.join(str(tmp_path), "m", ds[0]["obj_name"]), params.scene_scale_factor, dev)
+
+    def fresh(seed):
+        gt_scene, covered, surface, proxy = sc.setup_test_scenes(params, settings, mesh, dev, 0.05, seed=seed)
+        cam = tp.setup_test_camera(params, mesh, settings.camera.start_positions[0], settings, dev, seed=seed)
+        return gt_scene, covered, surface, proxy, cam
+    gt_scene, covered, surface, proxy, cam = fresh(6)
+    ro = NBVRollout(params, cam, gt_scene, surface, proxy, covered, mesh, dev, 0.05, seed=6)
+    for s in range(6):
+        seen = {}
+        orig = ro.choose
+
+        def spy(valid, _orig=orig, _seen=seen):
+            # the proxy state the gains are computed from, captured at the moment of the decision
+            _seen["valid"] = list(valid)
+            _seen["occ"] = proxy.proxy_supervision_occ.cpu().numpy().copy()
+            _seen["vs"] = proxy.view_states.cpu().numpy().copy()
+            return _orig(valid)
+        ro.choose = spy
+        ro.step()
+        ro.choose = orig
+        poses = [cam.pose_from_idx(n) for n in seen["valid"]]
+        RT = [ocam.camera_RT(q[:3], q[3:]) for q in poses]
+        want = ovs.view_gain(proxy.proxy_points.cpu().numpy(), seen["occ"], seen["vs"], RT, [q[:3] for q in poses], 7, 14, 128, 228,
+                             params.sensor_range)
+        # (a point whose ray to a candidate sits within 1e-5 rad of a bin boundary may count differently: at most a few)
+        assert max(abs(a - b) for a, b in zip(ro.last_gains, want)) <= 2, (s, ro.last_gains, want)
+        assert max(want) > 0
+        first_best = seen["valid"][int(np.argmax(ro.last_gains))]            # argmax returns the FIRST maximum, as the reference's rule
+        assert tuple(cam.cam_idx_history[-1]) == tuple(first_best), s
+    assert ro.coverage_evolution[-1] > ro.coverage_evolution[0] >= 0.0 and float(proxy.view_states.sum()) > 500
+    # a user model overrides the geometric one; the reference's signature and return tuple
+    gt_scene, covered, surface, proxy, cam = fresh(7)
+    calls = []
+
+    def prefer_low_azimuth(rollout, idx):
+        calls.append(tuple(idx))
+        return -float(idx[4])
+    cov, X, V = compute_trajectory(params, None, cam, gt_scene, surface, proxy, covered, mesh, dev, coverage_gain_fn=prefer_low_azimuth,
+                                   seed=7, n_poses=3)
+    assert len(cov) == 3 and len(calls) >= 3 and X.shape[1] == 3 and V.shape[1] == 2

@@ -121,24 +121,30 @@ def _step_both_and_compare(hip_ro, ora, n_steps):
         assert np.array_equal(net_in, ora.net_inputs[-1]), f"step {s}: network input differs"
         # network on the rollout's own input (counts of 10^2..10^4 per wall cell, value head range 10^2..10^3.5, where one
         # fp32 ulp already exceeds north_star's absolute 1e-4): the bound is relative to the output range and anchored
-        # on an fp64 evaluation -- HIP must sit as close to it as fp32 arithmetic allows (stock torch CPU fp32 ops, i.e.
-        # the reference's own arithmetic, measure 1e-6..5e-5 of the range on these inputs, HIP 1e-6..2.4e-4)
+        # on an fp64 evaluation -- HIP must sit as close to it as fp32 arithmetic allows: within 3x of what stock torch CPU
+        # fp32 ops (the reference's own arithmetic) measure on the same input, or within 1e-4 of the range for the maximum.
+        # Accumulation chains are bounded (NBP_SPLIT_MAX_K / _SMALL, nbp_split.hip) so that this holds at every batch size:
+        # every fourth step the same input is also forwarded as a batch of 5 and of 12 (the bench's group batch).
         o1, o2 = ora.net_outputs[-1]
         h1, h2 = out1[0].cpu().numpy().astype(np.float64), out2[0, 0].cpu().numpy().astype(np.float64)
         with torch.no_grad():
             d1, d2 = nbp_net.nbp_forward(sd64, torch.from_numpy(net_in).double())
         d1, d2 = d1[0].numpy(), d2[0, 0].numpy()
         rng1 = max(1.0, float(np.abs(d1).max()))
-        e_hip, e_cpu = np.abs(h1 - d1), np.abs(o1 - d1)
-        # (an input on which fp32 itself is ill conditioned -- seen at step 20 of another scene: stock torch fp32 2.6 off on a
-        # range of 3968, 100x its usual error, the fp32 MFMA pipe 11, the split path 9 -- is judged against torch's error there)
-        assert e_hip.max() <= max(5e-4 * rng1, 8.0 * e_cpu.max()) and e_hip.mean() <= max(2e-6 * rng1, 8.0 * e_cpu.mean()), \
-            (s, e_hip.max(), e_hip.mean(), e_cpu.max(), e_cpu.mean(), rng1)
-        # (one accumulation chain per output on the matrix pipe; the CPU library accumulates in blocks: 3-7x its mean error)
-        assert e_hip.mean() <= 8.0 * e_cpu.mean() + 1e-7 * rng1, (s, e_hip.mean(), e_cpu.mean())
+        e_cpu = np.abs(o1 - d1)
+        variants = [(1, h1)]
+        if s % 4 == 3:
+            for Bv in (5, 12):
+                with torch.no_grad():
+                    b1, _ = hip_ro.nbp(torch.from_numpy(net_in).to(D).expand(Bv, -1, -1, -1).contiguous())
+                variants.append((Bv, b1[Bv - 1].cpu().numpy().astype(np.float64)))
+        for Bv, hv in variants:
+            e_hip = np.abs(hv - d1)
+            assert e_hip.max() <= max(1e-4 * rng1, 3.0 * e_cpu.max()), (s, Bv, e_hip.max(), e_cpu.max(), rng1)
+            assert e_hip.mean() <= 3.0 * e_cpu.mean(), (s, Bv, e_hip.mean(), e_cpu.mean(), rng1)
+            worst[0] = max(worst[0], e_hip.max() / rng1)
         assert np.abs(h2 - d2).max() < 1e-4
         assert np.array_equal(h2 >= 0.13, o2 >= np.float32(0.13))
-        worst[0] = max(worst[0], e_hip.max() / rng1)
         assert need == (ora.n_replans > (sizes[-1][1] if sizes else 0)), f"step {s}: replan decision differs"
         sizes.append((int(hip_ro.st.cloud_count.item()), ora.n_replans))
         assert hip_ro.camera.cam_idx_history == ora.cam.cam_idx_history, f"step {s}: lattice path differs"

@@ -105,3 +105,28 @@ def test_gt_surface_pipeline_keeps_every_sample(hip, tmp_path):
     ora.fill_cells(pts, seed=2 + 7919)
     assert np.array_equal(_rows(gt.cpu().numpy()), _rows(ora.return_entire_pt_cloud()))
     assert len(gt) > 0.95 * params.n_gt_surface_points                   # ~50 k, not a 0.5-voxel thinned ~35 k
+
+
+def test_view_state_kernel_vs_reference_golden(hip, golden_dir):
+    """nbp_view_state_update_f32 against the reference's own compute_view_state / update_proxy_view_states outputs
+    (tests/golden/viewstate.npz).  The bins come from asin / acos of this platform; a ray within 1e-5 rad of a bin's rounding
+    boundary may land on the other side than under torch's libm -- such rays are excluded by name, everything else is exact."""
+    import os
+    from nextbestpath_amd.utility import hipops as ho
+    from oracle import view_state as ovs
+    g = np.load(os.path.join(golden_dir, "viewstate.npz"))
+    for key, views, ne, na, pts in (("vs", g["views"], 7, 14, g["pts"]), ("vs1", g["views"][:1], 7, 14, g["pts"]),
+                                    ("vs_small", g["views"][:2], 4, 6, g["pts"][:500])):
+        vs = torch.zeros(len(pts), ne * na, device=D)
+        ho.view_state_update(torch.from_numpy(pts).to(D), views, ne, na, vs)
+        got = vs.cpu().numpy().astype(np.uint8)
+        safe = ovs.boundary_distance(pts, views, ne, na).min(1) > 1e-5
+        assert safe.mean() > 0.995 and np.array_equal(got[safe], g[key][safe]), key
+        assert (got[~safe].sum(1) >= 1).all()
+    vs = torch.zeros(len(g["proxy"]), 98, device=D)
+    proxy = torch.from_numpy(g["proxy"]).to(D)
+    for k in range(2):
+        ho.view_state_update(proxy, g["upd_cam"][k], 7, 14, vs, mask=torch.from_numpy(g["upd_mask"][k].astype(np.uint8)).to(D),
+                             sd=torch.from_numpy(g["upd_sd"][k]).to(D), distance_to_surface=3 * float(g["dist_between"]))
+        safe = ovs.boundary_distance(g["proxy"], g["upd_cam"][:k + 1], 7, 14).min(1) > 1e-5
+        assert np.array_equal(vs.cpu().numpy().astype(np.uint8)[safe], g["upd_state"][k][safe]), k

@@ -288,3 +288,67 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
         assert float((o2 - q2).abs().max()) <= 2e-5, k
         r1, r2 = outs["nohead"][k]                            # Final2 in the last convolution's epilogue: out1 untouched
         assert torch.equal(o1, r1) and float((o2 - r2).abs().max()) <= 2e-6, k
+
+
+# ---- in-tensor dynamic range (the per-tensor scale's floor)
+# The scale 2^(12 - floor(log2 max|x|)) is per TENSOR: an element 2^r below the tensor's max keeps the full two-piece precision
+# (2^-23) while r <= 14 -- its lo piece is then still a normal fp16 -- and 2^(r - 37) beyond (lo falls into fp16's subnormal
+# spacing 2^-24 of the scaled value): 2^-17 at a 10^6 spike, 2^-13 at 2^24.  The fp32 pipe has no such floor.
+@pytest.mark.parametrize("r", [14, 20, 24])
+def test_split_in_tensor_dynamic_range_floor(hip, r):
+    """One tensor holding O(1) values AND a few spikes of 2^r: outputs whose 3x3 window contains a spike are dominated by fp32's
+    own ulp of the spike terms on both pipes; outputs that do not see a spike carry the split scheme's floor 2^(r - 37) of
+    sum |w x| -- nothing at r <= 14 (the range rollout tensors have: counts up to 1e4 beside 1), measurable beyond."""
+    dev = "cuda"
+    B, H, W, C, N = 1, 32, 64, 64, 64
+    x = _rand(B, C, H, W, seed=1)
+    spikes = [(5, 7), (16, 40), (30, 63)]
+    for (yy, xx) in spikes:
+        x[0, :, yy, xx] = float(2 ** r) * (1.0 + 0.25 * _rand(C, seed=yy))
+    w = _rand(N, C, 3, 3, seed=3, scale=(6.0 / (C * 9)) ** 0.5)
+    one, zero = torch.ones(N), torch.zeros(N)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    mag = F.conv2d(x.double().abs(), w.double().abs(), None, padding=1)          # sum |w x| per output
+    near = torch.zeros(H, W, dtype=torch.bool)
+    for (yy, xx) in spikes:
+        near[max(0, yy - 1):yy + 2, max(0, xx - 1):xx + 2] = True
+    xd, wd = nhwc(x).to(dev), w.to(dev).contiguous()
+    got = nchw(conv3x3_split(xd, None, 0, pack_conv_split(wd), N, one.to(dev), zero.to(dev), False, 1)).cpu().double()
+    f32 = nchw(conv_igemm(xd, None, 0, pack_conv(wd), N, 3, one.to(dev), zero.to(dev), False, 1, 0)).cpu().double()
+    rel_s, rel_f = (got - ref).abs() / mag, (f32 - ref).abs() / mag
+    far_s, far_f = rel_s[0, :, ~near], rel_f[0, :, ~near]
+    near_s, near_f = rel_s[0, :, near], rel_f[0, :, near]
+    print(f"\n[dynamic range 2^{r}] far outputs: split max {far_s.max():.2e} rms {far_s.pow(2).mean().sqrt():.2e} | fp32 pipe max "
+          f"{far_f.max():.2e} rms {far_f.pow(2).mean().sqrt():.2e} | near: split {near_s.max():.2e} fp32 pipe {near_f.max():.2e}")
+    # with a spike in the window both pipes sit at fp32's own rounding of the spike terms
+    assert near_s.max().item() <= 3.0 * near_f.max().item() + 2.0 ** -24
+    floor = 2.0 ** (r - 37) if r > 14 else 2.0 ** -23
+    assert far_s.max().item() <= 2.0 * floor, (far_s.max().item(), floor)          # the documented floor holds ...
+    if r <= 14:
+        assert far_s.pow(2).mean().sqrt().item() <= 1.5 * far_f.pow(2).mean().sqrt().item() + 1e-9      # ... no loss in range
+    else:
+        assert far_s.pow(2).mean().sqrt().item() >= 2.0 ** (r - 43)                 # ... and is real (documented, not hidden)
+
+
+def test_split_network_with_a_spike_in_the_input(hip, nets, nbp_weights):
+    """Whole network on a count map with 10^6-count cells beside unit counts (2^20 of range inside the first activation tensors;
+    rollouts reach 10^4): the split path against fp64 with the fp32 pipe and stock torch CPU fp32 beside it."""
+    from nextbestpath_amd.utility.synthetic import make_count_maps
+    x = make_count_maps(1, 128, seed=5)
+    for (c, yy, xx) in ((0, 40, 41), (2, 64, 64), (3, 90, 30)):
+        x[0, c, yy, xx] = 1.0e6
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in nbp_weights.items()}
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    with torch.no_grad():
+        o1, o2 = nets[0](x.cuda())
+        f1, f2 = nets[1](x.cuda())
+        c1, c2 = nbp_net.nbp_forward(nbp_weights, x)
+        d1, d2 = nbp_net.nbp_forward(sd64, x.double())
+    rng = float(d1.abs().max())
+    es, ef, ec = ((t.cpu().double() - d1).abs() for t in (o1, f1, c1))
+    print(f"\n[network, 1e6 spike] out1 range {rng:.3g}: split max {es.max()/rng:.2e} mean {es.mean()/rng:.2e} | fp32 pipe max "
+          f"{ef.max()/rng:.2e} mean {ef.mean()/rng:.2e} | torch fp32 max {ec.max()/rng:.2e} mean {ec.mean()/rng:.2e}; out2: split "
+          f"{(o2.cpu().double()-d2).abs().max():.2e} fp32 pipe {(f2.cpu().double()-d2).abs().max():.2e} torch {(c2.double()-d2).abs().max():.2e}")
+    assert torch.isfinite(o1).all() and torch.isfinite(o2).all()
+    assert es.max().item() <= max(1e-4 * rng, 3.0 * ef.max().item()) and es.mean().item() <= max(1e-6 * rng, 3.0 * ef.mean().item())
+    assert torch.equal(o1.cpu().amax(1).flatten(1).argmax(1), d1.float().amax(1).flatten(1).argmax(1))

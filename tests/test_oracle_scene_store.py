@@ -87,3 +87,24 @@ def test_cartesian_coords_vs_reference(golden_dir):
     for e, a, want in zip(g["cart_elev"], g["cart_azim"], g["cart_rays"]):
         assert np.allclose(-ocam.cartesian(1.0, -float(e), 180.0 + float(a)), want, atol=3e-7)
         assert np.allclose(-_cartesian(-float(e), 180.0 + float(a)), want, atol=3e-7)
+
+
+def test_view_state_restatement_vs_reference_golden(golden_dir):
+    """compute_view_state (scone_utils.py:799-862) and Scene.update_proxy_view_states (macarons_utils.py:3268-3327): the numpy
+    restatement reproduces the reference's own outputs -- 4000 points x 6 cameras incl. the degenerate directions, two grid
+    sizes, two accumulating updates with signed-distance selection."""
+    import os
+    from oracle import view_state as ovs
+    g = np.load(os.path.join(golden_dir, "viewstate.npz"))
+    for key, views, ne, na, pts in (("vs", g["views"], 7, 14, g["pts"]), ("vs1", g["views"][:1], 7, 14, g["pts"]),
+                                    ("vs_small", g["views"][:2], 4, 6, g["pts"][:500])):
+        got = ovs.compute_view_state(pts, views, ne, na).astype(np.uint8)
+        assert np.array_equal(got, g[key]), key
+        assert got.sum(1).min() >= 1 and got.sum(1).max() <= len(views)
+    vs = np.zeros((len(g["proxy"]), 98), np.float32)
+    for k in range(2):
+        upd = ovs.update_proxy_view_states(vs, g["proxy"], g["upd_mask"][k], g["upd_sd"][k], g["upd_cam"][k], 7, 14,
+                                           3 * float(g["dist_between"]))
+        assert np.array_equal(vs.astype(np.uint8), g["upd_state"][k]), k
+        assert 0 < upd.sum() < g["upd_mask"][k].sum()                  # the signed-distance test removed some points
+    assert (g["upd_state"][1].sum(1) == 2).sum() > 100                  # vectors accumulate over the two cameras

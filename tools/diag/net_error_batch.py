@@ -23,9 +23,9 @@ for s in range(N_STEPS):
         rng = d1.abs().max().item()
         e_cpu = (c1.double() - d1).abs()
         line = f"step {s:2d} range {rng:8.1f} torch32 mean {e_cpu.mean().item()/rng:.2e} max {e_cpu.max().item()/rng:.2e}"
-        for prec in ("fp32_split", "fp32"):
+        for prec in os.environ.get("NET_ERR_PATHS", "fp32_split,fp32").split(","):
             hip_ro.nbp.conv_precision = prec
-            for B in (1, 12):
+            for B in [int(b) for b in os.environ.get("NET_ERR_BATCHES", "1,12").split(",")]:
                 with torch.no_grad():
                     h1, _ = hip_ro.nbp(hip_ro.st.net_in.expand(B, -1, -1, -1).contiguous())
                 e = (h1[B - 1:B].cpu().double() - d1).abs()
