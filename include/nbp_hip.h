@@ -135,7 +135,7 @@ int nbp_forward_timed_split_f32(const nbp_weights* handle, const float* x, int B
                                 int max_entries, int* n_entries_host);
 /* One 3x3 layer of that path (stride 1, zero padding 1; src1 / ups as nbp_conv_igemm_f32).
  * nbp_pack_conv_weight_split: planes [chunk of 16 channels][tap][hi|lo][k half][N][8] fp16 (4 bytes per weight; zero the
- * buffer first when C < c_total) scaled by 2^(12 - floor(log2 max|w|)); wamax_out = device word that receives max |w * scale|
+ * buffer first when C < c_total) scaled by 2^(14 - floor(log2 max|w|)); wamax_out = device word that receives max |w * scale|
  * (float bits).  c_off must be 0 (one scale per layer).
  * nbp_conv3x3_split_f32: images of 16 x 32 pixel tiles with N % 64 == 0, or of 16 x 16 pixel tiles with N % 128 == 0; channel
  * counts multiples of 32; NBP_E_SHAPE otherwise.  amax_in = 64 device words (256 B) whose maximum is max |x| over src0 and
@@ -259,6 +259,17 @@ int nbp_step_maps_f32(const float* points, long long N, const long long* N_dev_o
                       float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi, int S,
                       float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
                       int n_traj_fresh, float* out6, float* net_in5, void* stream);
+/* The same for the n <= 16 rollouts of a lock-step group in ONE kernel launch (two memsets, one kernel, one strided copy
+ * instead of n times that): the step's kernels are latency-bound -- one workgroup per CU, a chain of dependent round trips --
+ * so a group costs one such chain.  Rollout r writes out6_all[r] of [n][6][S][S] and net_in_all[r] of [n][5][S][S]; the other
+ * arrays are HOST arrays of n entries (points / N_dev / traj_pts: device pointers; N_cap: an upper bound of the cloud size,
+ * it sizes the grid; poses_xyz [n][3]; bounds [n][8]; band_lo_hi [n][2]; traj_fresh [n][24]).  Results are identical to n
+ * calls of nbp_step_maps_f32. */
+int nbp_step_maps_batch_f32(int n, const float* const* points, const long long* N_cap, const long long* const* N_dev,
+                            const float* poses_xyz_host, const float* bounds_host, const int* n_bounds,
+                            const float* band_lo_hi_host, int S, float lo, float hi, float* const* traj_pts,
+                            const int* n_traj_old, const float* traj_fresh_host, const int* n_traj_fresh,
+                            float* out6_all, float* net_in_all, void* stream);
 
 /* ================================================================ A14-A17: simulator
  * PyTorch3D / trimesh conventions restated (third-party; parity with the libraries unpinned):

@@ -380,6 +380,7 @@ struct AmaxBook {
         return nullptr;
     }
     void bind(const void* p, unsigned* v) { if (n < 128) { key[n] = p; val[n] = v; ++n; } }
+    unsigned* unbound() { return next < 128 ? slots + 64 * next++ : nullptr; }      // a zeroed slot, not yet attached to a tensor
     unsigned* fresh(const void* p) { unsigned* v = next < 128 ? slots + 64 * next++ : nullptr; if (v) bind(p, v); return v; }
     void alias(const void* p, const void* of) { if (unsigned* v = find(of)) bind(p, v); }
     // the decoder offers the gated tensors before it launches a gate's 1x1 GEMM; a launch that runs the psi tail in its
@@ -437,11 +438,18 @@ struct PathSplit : PathF32 {
                 const int l = li[(g && o2) ? 1 : 0] + 2;                      // the gate's psi layer follows W_g, W_x
                 psi.wpsi[g] = (const float*)h->w[l]; psi.st[g] = h->scale[l]; psi.gated[g] = ctx.gated[(g && o2) ? 1 : 0];
             }
+            // max |x psi| is measured by the fused epilogue (psi << 1 makes the inherited bound max |x| loose, and a loose bound
+            // costs the small elements of the consumer's other source their low bits); the slots are bound only if it ran
+            unsigned* gslot[2] = {nullptr, nullptr};
+            if (ctx.gated[0]) for (int g = 0; g < (o2 ? 2 : 1); ++g) psi.gated_amax[g] = gslot[g] = ctx.unbound();
             int fused = 0;
             const int rc = nbp_gate1x1_split_launch_g(s[0], o2 ? &s[1] : nullptr, C0, M, N, 1, st, ctx.gated[0] ? &psi : nullptr, &fused);
             if (fused) {
                 ctx.gated_taken = true;
-                for (int g = 0; g < (o2 ? 2 : 1); ++g) ctx.alias(ctx.gated[g], (g ? *o2 : o).src1);      // |x psi| <= |x|
+                for (int g = 0; g < (o2 ? 2 : 1); ++g) {
+                    if (gslot[g]) ctx.bind(ctx.gated[g], gslot[g]);
+                    else ctx.alias(ctx.gated[g], (g ? *o2 : o).src1);      // |x psi| <= |x|
+                }
             }
             return rc;
         }

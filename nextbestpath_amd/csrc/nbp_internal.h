@@ -86,7 +86,7 @@ int nbp_pack_gate_weight_split_launch(const float* wg, const float* scale_g, con
 // psi != null offers the gate's tail (per group: psi weights [N], {scale, shift}, gated output [M,C] = src1 * psi); *fused tells
 // whether the launch took it (a workgroup must hold all N columns of its pixels) -- if not, q is written and the caller runs
 // nbp_psi_gate_f32 as before
-struct GatePsi { const float* wpsi[2]; const float* st[2]; float* gated[2]; };
+struct GatePsi { const float* wpsi[2]; const float* st[2]; float* gated[2]; unsigned* gated_amax[2] = {nullptr, nullptr}; };   // gated_amax: zeroed 64-word slots for max |gated| (or null)
 int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C, long long M, int N, int relu,
                                hipStream_t st, const GatePsi* psi = nullptr, int* fused = nullptr);
 int nbp_conv_first_amax_launch(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale, const float* shift,

@@ -98,15 +98,20 @@ __device__ __forceinline__ void accumulate_point(float x, float y, float z, floa
 // valid), fresh = up to 8 new positions riding in the kernel arguments (appended to pts here), out = [S,S] zeroed.
 struct TrajArgs { float* pts; float* out; int n_old, n_fresh; float fresh[24]; };
 
+// One rollout's arguments of the accumulation (the batched launch carries up to MAP_BATCH of them in the kernel arguments)
+struct MapItem {
+    const float* p; long long N; const long long* n_dev; float cx, cz; Bounds bd; float band_lo, band_hi; float* out; TrajArgs tr;
+};
+
 template <int AGG_POINTS, int SLOT_BITS, int THREADS>
-__global__ __launch_bounds__(THREADS) void map_accumulate_kernel(const float* __restrict__ p, long long N,
-                                                             const long long* __restrict__ n_dev, float cx, float cz,
-                                                             Bounds bd, float band_lo, float band_hi, int S, float lo,
-                                                             float sc, float* __restrict__ out, TrajArgs tr) {
+__device__ __forceinline__ void map_accumulate_body(const MapItem& a, unsigned wg, unsigned n_wg, int S, float lo, float sc, int* keys,
+                                                    int* cnts) {
     constexpr int AGG_SLOTS = 1 << SLOT_BITS;
-    __shared__ int keys[AGG_SLOTS];
-    __shared__ int cnts[AGG_SLOTS];
-    if (tr.out && blockIdx.x == gridDim.x - 1) {                    // the trajectory workgroup (appended to the grid)
+    const float* __restrict__ p = a.p;
+    float* __restrict__ out = a.out;
+    const TrajArgs& tr = a.tr;
+    const float cx = a.cx, cz = a.cz;
+    if (tr.out && wg == n_wg - 1) {                    // the trajectory workgroup (appended to the grid)
         for (int i = threadIdx.x; i < tr.n_old + tr.n_fresh; i += THREADS) {
             float x, z;
             if (i < tr.n_old) {
@@ -124,8 +129,9 @@ __global__ __launch_bounds__(THREADS) void map_accumulate_kernel(const float* __
         }
         return;
     }
-    if (n_dev) N = *n_dev;                       // cloud size lives on the device (no host sync per step)
-    const long long first = (long long)blockIdx.x * AGG_POINTS;
+    long long N = a.N;
+    if (a.n_dev) N = *a.n_dev;                   // cloud size lives on the device (no host sync per step)
+    const long long first = (long long)wg * AGG_POINTS;
     if (first >= N) return;
     const long long last = first + AGG_POINTS < N ? first + AGG_POINTS : N;
     for (int i = threadIdx.x; i < AGG_SLOTS; i += THREADS) { keys[i] = AGG_EMPTY; cnts[i] = 0; }
@@ -145,10 +151,32 @@ __global__ __launch_bounds__(THREADS) void map_accumulate_kernel(const float* __
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k)
-        accumulate_point<SLOT_BITS>(px[k], py[k], pz[k], cx, cz, bd, band_lo, band_hi, S, lo, sc, keys, cnts, out);
+        accumulate_point<SLOT_BITS>(px[k], py[k], pz[k], cx, cz, a.bd, a.band_lo, a.band_hi, S, lo, sc, keys, cnts, out);
     __syncthreads();
     for (int i = threadIdx.x; i < AGG_SLOTS; i += THREADS)
         if (keys[i] != AGG_EMPTY) atomicAdd(out + keys[i], (float)cnts[i]);
+}
+
+template <int AGG_POINTS, int SLOT_BITS, int THREADS>
+__global__ __launch_bounds__(THREADS) void map_accumulate_kernel(MapItem a, int S, float lo, float sc) {
+    __shared__ int keys[1 << SLOT_BITS];
+    __shared__ int cnts[1 << SLOT_BITS];
+    map_accumulate_body<AGG_POINTS, SLOT_BITS, THREADS>(a, blockIdx.x, gridDim.x, S, lo, sc, keys, cnts);
+}
+
+// The same for several rollouts in ONE launch (blockIdx.y = rollout): the step's kernels are latency-bound (one workgroup
+// per CU, a chain of dependent round trips), so the rollouts of a lock-step group cost one such chain instead of one each.
+// The grid's x extent is the largest rollout's; a rollout's trajectory workgroup is its own last one (n_wg[r] - 1).
+constexpr int MAP_BATCH = 16;
+struct MapBatch { MapItem it[MAP_BATCH]; unsigned n_wg[MAP_BATCH]; };
+
+template <int AGG_POINTS, int SLOT_BITS, int THREADS>
+__global__ __launch_bounds__(THREADS) void map_accumulate_batch_kernel(MapBatch b, int S, float lo, float sc) {
+    __shared__ int keys[1 << SLOT_BITS];
+    __shared__ int cnts[1 << SLOT_BITS];
+    const unsigned r = blockIdx.y;
+    if (blockIdx.x >= b.n_wg[r]) return;
+    map_accumulate_body<AGG_POINTS, SLOT_BITS, THREADS>(b.it[r], blockIdx.x, b.n_wg[r], S, lo, sc, keys, cnts);
 }
 
 inline float grid_scale(int S, float lo, float hi) { return (float)((double)S / ((double)hi - (double)lo)); }
@@ -211,7 +239,7 @@ extern "C" int nbp_map_accumulate_f32(const float* points, long long N, const lo
     // table is shared by 16 waves in flight (26 us for 1.3 M points; 256-thread workgroups: 37 us; smaller
     // point batches flush more distinct keys to L2 and lose)
     map_accumulate_kernel<8192, 13, 1024><<<(unsigned)nbp_cdiv(N, 8192), 1024, 0, st>>>(
-        points, N, N_dev_or_null, cx, cz, bd, band_lo, band_hi, S, lo, grid_scale(S, lo, hi), out6, TrajArgs{});
+        MapItem{points, N, N_dev_or_null, cx, cz, bd, band_lo, band_hi, out6, TrajArgs{}}, S, lo, grid_scale(S, lo, hi));
     return nbp_launch_status();
 }
 
@@ -239,9 +267,54 @@ extern "C" int nbp_step_maps_f32(const float* points, long long N, const long lo
     tr.pts = traj_pts; tr.out = net_in5 + 4 * SS; tr.n_old = n_traj_old; tr.n_fresh = n_traj_fresh;
     for (int i = 0; i < 24; ++i) tr.fresh[i] = i < 3 * n_traj_fresh ? traj_fresh_host[i] : 0.f;
     map_accumulate_kernel<8192, 13, 1024><<<(unsigned)nbp_cdiv(N, 8192) + 1, 1024, 0, st>>>(
-        points, N, N_dev_or_null, cx, cz, bd, band_lo, band_hi, S, lo, grid_scale(S, lo, hi), out6, tr);
+        MapItem{points, N, N_dev_or_null, cx, cz, bd, band_lo, band_hi, out6, tr}, S, lo, grid_scale(S, lo, hi));
     int rc = nbp_launch_status();
     if (rc) return rc;
     e = hipMemcpyAsync(net_in5, out6, 4 * SS * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// nbp_step_maps_f32 for n <= 16 rollouts of a lock-step group in ONE kernel launch, two memsets and one strided copy.
+// The rollouts' map stacks are slices of one tensor out6_all [n][6][S][S] and their network inputs of net_in_all [n][5][S][S];
+// everything else is per rollout (arrays of n entries, HOST memory; device pointers inside).
+extern "C" int nbp_step_maps_batch_f32(int n, const float* const* points, const long long* N_cap, const long long* const* N_dev,
+                                       const float* poses_xyz_host, const float* bounds_host, const int* n_bounds,
+                                       const float* band_lo_hi_host, int S, float lo, float hi, float* const* traj_pts,
+                                       const int* n_traj_old, const float* traj_fresh_host, const int* n_traj_fresh,
+                                       float* out6_all, float* net_in_all, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(n < 1 || n > MAP_BATCH || !points || !N_cap || !N_dev || !poses_xyz_host || !bounds_host || !n_bounds ||
+                  !band_lo_hi_host || !traj_pts || !n_traj_old || !traj_fresh_host || !n_traj_fresh || !out6_all || !net_in_all, NBP_E_ARG);
+    NBP_RETURN_IF(S < 1 || !(hi > lo) || (long long)6 * S * S >= (1ll << 31), NBP_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t SS = (size_t)S * S;
+    MapBatch b;
+    unsigned max_wg = 1;
+    for (int r = 0; r < MAP_BATCH; ++r) {
+        const int q = r < n ? r : 0;
+        NBP_RETURN_IF(r < n && (N_cap[q] < 0 || (N_cap[q] > 0 && (!points[q] || ((uintptr_t)points[q] & 3) != 0)) || !traj_pts[q] ||
+                                n_bounds[q] < 0 || n_bounds[q] > 8 || n_traj_old[q] < 0 || n_traj_fresh[q] < 0 || n_traj_fresh[q] > 8), NBP_E_ARG);
+        MapItem& it = b.it[r];
+        it.p = points[q]; it.N = N_cap[q]; it.n_dev = N_dev[q];
+        it.cx = poses_xyz_host[3 * q]; it.cz = poses_xyz_host[3 * q + 2];
+        for (int k = 0; k < 8; ++k) it.bd.b[k] = k < n_bounds[q] ? bounds_host[8 * q + k] : 0.f;
+        it.bd.n = n_bounds[q];
+        it.band_lo = band_lo_hi_host[2 * q]; it.band_hi = band_lo_hi_host[2 * q + 1];
+        it.out = out6_all + (size_t)q * 6 * SS;
+        it.tr.pts = traj_pts[q]; it.tr.out = net_in_all + (size_t)q * 5 * SS + 4 * SS;
+        it.tr.n_old = n_traj_old[q]; it.tr.n_fresh = n_traj_fresh[q];
+        for (int i = 0; i < 24; ++i) it.tr.fresh[i] = i < 3 * n_traj_fresh[q] ? traj_fresh_host[24 * q + i] : 0.f;
+        b.n_wg[r] = r < n ? (unsigned)nbp_cdiv(N_cap[q], 8192) + 1 : 0;
+        if (b.n_wg[r] > max_wg) max_wg = b.n_wg[r];
+    }
+    hipError_t e = hipMemsetAsync(out6_all, 0, (size_t)n * 6 * SS * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset2DAsync(net_in_all + 4 * SS, 5 * SS * sizeof(float), 0, SS * sizeof(float), (size_t)n, st);       // the trajectory channels
+    if (e != hipSuccess) return (int)e;
+    map_accumulate_batch_kernel<8192, 13, 1024><<<dim3(max_wg, (unsigned)n), 1024, 0, st>>>(b, S, lo, grid_scale(S, lo, hi));
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    e = hipMemcpy2DAsync(net_in_all, 5 * SS * sizeof(float), out6_all, 6 * SS * sizeof(float), 4 * SS * sizeof(float), (size_t)n,
+                         hipMemcpyDeviceToDevice, st);
     return e == hipSuccess ? 0 : (int)e;
 }

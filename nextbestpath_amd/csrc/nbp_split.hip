@@ -8,8 +8,8 @@
 //   so s x = hi + lo up to 2^-23 |s x| (unbiased), every fp16 x fp16 product is exact in the fp32 accumulator, and
 //       x w = [hi hi + (hi lo + lo hi)] / (s_x s_w)  +  [lo lo <= 2^-22 |x w|, dropped]
 //   is THREE MFMAs of 32 cycles (96 cycles per 16 k against 512: 5.3 x the fp32 pipe's rate).
-//   s is per TENSOR: 2^(12 - floor(log2 max|x|)), which puts max|x| in [2^12, 2^13) -- no overflow (fp16 max 65504), full
-//   hi precision down to 2^-27 max|x|, an absolute representation floor of 2^-38 max|x| below that.  max|x| of every
+//   s is per TENSOR: 2^(14 - floor(log2 max|x|)), which puts max|x| in [2^14, 2^15) -- no overflow (fp16 max 65504), the full
+//   two-piece precision down to 2^-17 max|x|, an absolute representation floor of 2^-40 max|x| below that (SPLIT_EXP below).  max|x| of every
 //   activation tensor is produced by the kernel that writes it (one atomicMax per wave in the epilogue) or, for tensors
 //   that come from elsewhere, by amax_kernel; max|w| is taken at pack time.  Scales being powers of two, scaling and
 //   the final 1 / (s_x s_w) are exact.
@@ -31,9 +31,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// floor(log2 m) of a positive float given by its bits; 12 for zero (scale 1); clamped so that 2^(12 - e) is a normal float
+// Operands are scaled so that max |.| lands in [2^SPLIT_EXP, 2^(SPLIT_EXP + 1)): 14 is the largest exponent that keeps the
+// tensor's maximum below fp16's 65504.  The headroom is what the SMALL elements of a tensor are worth: an element 2^r below
+// the maximum has a normal-fp16 hi piece while r <= SPLIT_EXP + 14 and a normal lo piece (the full two-piece representation,
+// 2^-23) while r <= SPLIT_EXP + 2; beyond, lo sits on fp16's subnormal grid (spacing 2^-24 of the scaled value) and the element
+// keeps 2^(r - SPLIT_EXP - 25) relative precision (with 12, the first version: rollout tensors span 2^17 between a wall cell and
+// the median cell, whose values then carried 2^-20 instead of 2^-23; tests/test_gpu_split.py::test_split_in_tensor_dynamic_range_floor).  The bounds handed in are
+// always >= the true maximum (atomicMax of the values written, or an inherited upper bound), so nothing overflows.
+constexpr int SPLIT_EXP = 14;
+// floor(log2 m) of a positive float given by its bits; SPLIT_EXP for zero (scale 1); clamped so that 2^(SPLIT_EXP - e) is a normal float
 __host__ __device__ inline int amax_exponent(unsigned bits) {
-    if (!bits) return 12;
+    if (!bits) return SPLIT_EXP;
     int e = (int)((bits >> 23) & 255u) - 127;
     return e < -100 ? -100 : (e > 100 ? 100 : e);
 }
@@ -186,8 +194,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // operand scales (exact powers of two) from the tensors' max |.|
     const unsigned ma0 = read_amax(o.amax0), ma1 = o.amax1 ? read_amax(o.amax1) : 0u;
     const int ea = amax_exponent(ma0 > ma1 ? ma0 : ma1), ew = amax_exponent(*o.wamax);
-    const float sa = pow2f(12 - ea);
-    const int einv = ea + ew - 24;                             // 1 / (s_x s_w) = 2^einv, applied with v_ldexp_f32 (any exponent)
+    const float sa = pow2f(SPLIT_EXP - ea);
+    const int einv = ea + ew - 2 * SPLIT_EXP;                  // 1 / (s_x s_w) = 2^einv, applied with v_ldexp_f32 (any exponent)
 
     // halo staging: piece f = tid + 256 k is channels 4 (f & 3) .. + 3 of halo pixel f >> 2
     // (the LDS destination of piece k is ((f & 3) >> 1) RS + (f >> 2) 16 + (f & 1) 8: recomputed at the store, not kept)
@@ -454,6 +462,7 @@ struct GateArgs {
     const float* wpsi[2];
     const float* st[2];
     float* gated[2];
+    unsigned* gated_amax[2];    // 64-word slots (or null) that receive max |gated|: psi can be << 1, the bound max |x| is loose
 };
 
 template <int TN, bool PSI>
@@ -468,8 +477,8 @@ __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
     const int n0 = blockIdx.y * BN, khalf = lane >> 5;
     const unsigned ma0 = read_amax(o.amax0), ma1 = read_amax(o.amax1);
     const int ea = amax_exponent(ma0 > ma1 ? ma0 : ma1), ew = amax_exponent(*o.wamax);
-    const float sa = pow2f(12 - ea);
-    const int einv = ea + ew - 24;
+    const float sa = pow2f(SPLIT_EXP - ea);
+    const int einv = ea + ew - 2 * SPLIT_EXP;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.src0), 0, a.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.src1), 0, a.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(o.planes), 0, a.bytesw, 0x00020000);
@@ -602,6 +611,7 @@ __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
         const f32x4* x4 = reinterpret_cast<const f32x4*>(o.src1) + mw * C4;
         f32x4* g4 = reinterpret_cast<f32x4*>(a.gated[blockIdx.z]) + mw * C4;
         const long long lim = (a.M - mw) * C4;                            // float4s of this wave that exist
+        float gmx = 0.f;
 #pragma unroll 1
         for (int i0 = lane; i0 < total; i0 += 256) {
             f32x4 v[4];
@@ -610,9 +620,15 @@ __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + 64 * u;
-                if (i < total && i < lim) { const float ps = psil[i / C4]; g4[i] = v[u] * ps; }
+                if (i < total && i < lim) {
+                    const float ps = psil[i / C4];
+                    const f32x4 g = v[u] * ps;
+                    g4[i] = g;
+                    gmx = fmaxf(fmaxf(gmx, fmaxf(fabsf(g[0]), fabsf(g[1]))), fmaxf(fabsf(g[2]), fabsf(g[3])));
+                }
             }
         }
+        if (a.gated_amax[blockIdx.z]) wave_amax(gmx, a.gated_amax[blockIdx.z]);
     } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -642,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
 // 16-channel group 8 banks further: conflict-free.
 // Workgroup = 64 (ci) x 64 (co) block of dW for all nine taps (wave = 32 x 32, nine accumulator tiles), walking 2 x 32-pixel
 // tiles like wgrad_halo_kernel (nbp_train.hip); per tile the 4 x 34 halo of X and the 64 pixels of dY go global -> registers ->
-// scale by 2^(12 - e), split -> LDS; a 16-pixel K step is 2 + 2 transpose reads per operand and three exact MFMAs.
+// scale by 2^(14 - e), split -> LDS; a 16-pixel K step is 2 + 2 transpose reads per operand and three exact MFMAs.
 struct WgradSplitArgs {
     const float* src0; const float* src1;
     int C0, C1, ups, H, W, Hs, Ws;
@@ -684,8 +700,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
     constexpr unsigned OOB = 0x80000000u;
     const int tiles_x = a.W / TW, tiles_y = a.H / TR;
     const int ex = amax_exponent(read_amax(first ? a.amax0 : a.amax1)), ey = amax_exponent(read_amax(a.amaxy));
-    const float sx = pow2f(12 - ex), sy = pow2f(12 - ey);
-    const int einv = ex + ey - 24;
+    const float sx = pow2f(SPLIT_EXP - ex), sy = pow2f(SPLIT_EXP - ey);
+    const int einv = ex + ey - 2 * SPLIT_EXP;
 
     f32x16 acc[9];
 #pragma unroll
@@ -854,10 +870,10 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     block_amax(mx, out, words);
 }
 
-// planes [chunk of 16 channels][tap][hi|lo][k half][N][8 fp16] of w[n][c][tap] * (scale ? scale[n] : 1) * 2^(12 - e_w)
+// planes [chunk of 16 channels][tap][hi|lo][k half][N][8 fp16] of w[n][c][tap] * (scale ? scale[n] : 1) * 2^(14 - e_w)
 __global__ void pack_conv_weight_h2_kernel(const float* __restrict__ w, int N, int C, int taps, const float* __restrict__ scale,
                                            int c_off, const unsigned* __restrict__ wamax, unsigned short* __restrict__ dst) {
-    const float sw = pow2f(12 - amax_exponent(*wamax));
+    const float sw = pow2f(SPLIT_EXP - amax_exponent(*wamax));
     const long long total = (long long)N * C * taps;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int tap = (int)(i % taps);
@@ -891,7 +907,7 @@ __device__ __forceinline__ double upconv_combined(const double* v, int ph, int r
 __global__ __launch_bounds__(256) void pack_upconv_h2_kernel(const float* __restrict__ w, int N, int C, unsigned* __restrict__ wamax,
                                                              unsigned short* __restrict__ dst) {
     const long long NC = (long long)N * C;
-    const double sw = dst ? (double)pow2f(12 - amax_exponent(*wamax)) : 1.0;
+    const double sw = dst ? (double)pow2f(SPLIT_EXP - amax_exponent(*wamax)) : 1.0;
     float mx = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < NC; i += (long long)gridDim.x * blockDim.x) {
         double v[9];
@@ -1103,7 +1119,7 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     return rc;
 }
 
-// wamax_out: device word that receives max |w * scale| (float bits); the planes are scaled by 2^(12 - floor(log2 max))
+// wamax_out: device word that receives max |w * scale| (float bits); the planes are scaled by 2^(14 - floor(log2 max))
 int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
                                       int c_total, void* dst, unsigned* wamax_out, hipStream_t st) {
     NBP_RETURN_IF(!w_oihw || !dst || !wamax_out, NBP_E_ARG);
@@ -1161,6 +1177,7 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
         a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, s.amax1, s.wamax, nullptr, nullptr, nullptr, {nullptr, nullptr}, nullptr};
         const int gi = g < groups ? g : 0;
         a.wpsi[g] = psi ? psi->wpsi[gi] : nullptr; a.st[g] = psi ? psi->st[gi] : nullptr; a.gated[g] = psi ? psi->gated[gi] : nullptr;
+        a.gated_amax[g] = psi ? psi->gated_amax[gi] : nullptr;
     }
     a.C = C; a.N = N; a.relu = relu; a.M = M; a.bytes0 = (unsigned)b0; a.bytesw = (unsigned)bw; a.groups = groups;
     // 128-channel blocks only when they alone fill the chip twice; otherwise more, narrower workgroups

@@ -95,9 +95,26 @@ class Rollout:
     # rollouts and share one stream synchronisation per step; step() is the single-rollout composition.
     def pre(self, net_in=None):
         """S2-S8: coverage, un-projection of the current frame, maps, replan decision.  No host sync."""
-        st, camera, params, pose_i = self.st, self.camera, self.params, self.pose_i
-        S, grid_range = self.S, self.grid_range
+        self.pre_observe()
+        st, S = self.st, self.S
         net_in = st.net_in if net_in is None else net_in
+        # S5-S7 in one call: six maps, trajectory channel, network input (was seven launches: accumulate_step_maps,
+        # transform_points_to_n_pieces, map_points_to_n_imgs and two copies)
+        if os.environ.get("NBP_STEP_MAPS", "1") == "1":
+            full_pc, _, n_dev, pose, y_bins, traj_dev, n_old, fresh = self.maps_item()
+            hu.step_maps(full_pc, pose, y_bins, S, self.grid_range, traj_dev, n_old, fresh, st.maps6, net_in[0], n_dev=n_dev)
+            self.traj_img = net_in[0, 4]               # stays valid until this rollout's next pre()
+        else:
+            hu.accumulate_step_maps(st.cloud, self.pose, self.y_bins, S, self.grid_range, n_dev=st.cloud_count, out=st.maps6)
+            traj2d = hu.transform_points_to_n_pieces(self.camera.trajectory_points(), self.pose)
+            self.traj_img = hu.map_points_to_n_imgs(traj2d, (S, S), self.grid_range)
+            net_in[0, :4] = st.maps6[:4]
+            net_in[0, 4] = self.traj_img[0]
+        self.pre_decide()
+
+    def pre_observe(self):
+        """S2-S4: coverage of the cloud so far, un-projection of the current frame into it."""
+        st, camera, params, pose_i = self.st, self.camera, self.params, self.pose_i
         self.cov_plan.count(st.cloud, st.coverage_counts[pose_i % N_POSES], n_dev=st.cloud_count, n=st.cloud.shape[0],
                             seed=self.step_seed + 7 * pose_i, out_is_zero=pose_i < N_POSES)
         depth, cams = camera.frames_batch([-1])
@@ -106,19 +123,18 @@ class Rollout:
                                 params.sensor_range, seed=self.step_seed + 11 * pose_i,
                                 cloud_rgb=st.cloud_rgb if colour else None, **colour)
         self.pose, _ = camera.get_pose_from_idx(camera.cam_idx)
-        # S5-S7 in one call: six maps, trajectory channel, network input (was seven launches: accumulate_step_maps,
-        # transform_points_to_n_pieces, map_points_to_n_imgs and two copies)
-        if os.environ.get("NBP_STEP_MAPS", "1") == "1":
-            traj_dev, n_old, fresh = camera.trajectory_pending()
-            hu.step_maps(st.cloud, self.pose, self.y_bins, S, grid_range, traj_dev, n_old, fresh, st.maps6, net_in[0],
-                         n_dev=st.cloud_count)
-            self.traj_img = net_in[0, 4]               # stays valid until this rollout's next pre()
-        else:
-            hu.accumulate_step_maps(st.cloud, self.pose, self.y_bins, S, grid_range, n_dev=st.cloud_count, out=st.maps6)
-            traj2d = hu.transform_points_to_n_pieces(camera.trajectory_points(), self.pose)
-            self.traj_img = hu.map_points_to_n_imgs(traj2d, (S, S), grid_range)
-            net_in[0, :4] = st.maps6[:4]
-            net_in[0, 4] = self.traj_img[0]
+
+    def maps_item(self):
+        """The map stage's arguments (utils.step_maps / step_maps_batch): (cloud, host upper bound of its size, device size,
+        pose, y_bins, trajectory history, n_old, fresh positions).  A step appends at most 5 frames' kept pixels."""
+        traj_dev, n_old, fresh = self.camera.trajectory_pending()
+        per_frame = int(self.params.image_height * self.params.image_width * self.params.gathering_factor) + 1
+        n_upper = (5 * (self.pose_i + 1) + 8) * per_frame
+        return self.st.cloud, n_upper, self.st.cloud_count, self.pose, self.y_bins, traj_dev, n_old, fresh
+
+    def pre_decide(self):
+        """S8: does this step replan?  Host only."""
+        camera, pose_i = self.camera, self.pose_i
         path = self.path
         if pose_i == 0 or not path or self.path_record + 1 > len(path):
             self.need_replan = True
@@ -199,6 +215,13 @@ class MultiRollout:
         per = (R + n_groups - 1) // n_groups
         self.groups = [self.rollouts[i:i + per] for i in range(0, R, per)]
         self.net_in = [torch.zeros(len(g), 5, grid, grid, dtype=torch.float32, device=device) for g in self.groups]
+        # the rollouts' map stacks as slices of one tensor per group: the group's map stage is ONE batched launch
+        # (NBP_STEP_BATCH=0: one launch per rollout, the A/B switch)
+        self.batched = os.environ.get("NBP_STEP_BATCH", "1") == "1" and os.environ.get("NBP_STEP_MAPS", "1") == "1"
+        self.maps6 = [torch.zeros(len(g), 6, grid, grid, dtype=torch.float32, device=device) for g in self.groups]
+        for g, m6 in zip(self.groups, self.maps6):
+            for i, r in enumerate(g):
+                r.st.maps6 = m6[i]
         self.inflight = [False] * len(self.groups)
         # Streams.  One HIP stream per group carries the group's small kernels and its batched forward.
         # NBP_ROLLOUT_STREAMS = k > 0 (A/B switch) adds k side streams per group for the rollouts' ~20 small kernels per step
@@ -228,8 +251,11 @@ class MultiRollout:
         if not side:
             # one stream per group: a single stream guard around the whole group (a guard per rollout is ~10 us of host time)
             with torch.cuda.stream(fwd):
-                for i, r in enumerate(grp):
-                    r.pre(net_in[i:i + 1])
+                if self.batched and len(grp) <= 16:
+                    self._pre_group(gi)
+                else:
+                    for i, r in enumerate(grp):
+                        r.pre(net_in[i:i + 1])
                 with torch.no_grad():
                     out1, out2 = self._forward(net_in)
                 for i, r in enumerate(grp):
@@ -257,6 +283,16 @@ class MultiRollout:
                     grp[i].plan_enqueue(out1[i], out2[i])
                 self.ev_plan[gi][si].record()
         self.inflight[gi] = True
+
+    def _pre_group(self, gi):
+        """Rollout.pre for every rollout of the group with the map stage as ONE launch (identical results)."""
+        grp, net_in = self.groups[gi], self.net_in[gi]
+        for r in grp:
+            r.pre_observe()
+        hu.step_maps_batch([r.maps_item() for r in grp], grp[0].S, grp[0].grid_range, self.maps6[gi], net_in)
+        for i, r in enumerate(grp):
+            r.traj_img = net_in[i, 4]
+            r.pre_decide()
 
     def _forward(self, net_in):
         """The rollouts evaluate a frozen network: its packed weights are looked up (and their staleness checked: 327 tensor

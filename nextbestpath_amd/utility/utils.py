@@ -125,3 +125,39 @@ def step_maps(full_pc, camera_pose, y_bins, grid_size, grid_range, traj_dev, n_t
                                       float(grid_range[1]), traj_dev.data_ptr(), int(n_traj_old), fresh.ctypes.data,
                                       len(fresh), out6.data_ptr(), net_in5.data_ptr(), _lib.current_stream())
     _lib.check(rc, "nbp_step_maps_f32")
+
+
+def step_maps_batch(items, grid_size, grid_range, out6_all, net_in_all, band=0.1):
+    """step_maps for the rollouts of a lock-step group in ONE kernel launch (nbp_step_maps_batch_f32): `items` = one tuple per
+    rollout (full_pc, n_upper, n_dev, camera_pose, y_bins, traj_dev, n_traj_old, traj_fresh); rollout i writes out6_all[i]
+    ([n,6,S,S]) and net_in_all[i] ([n,5,S,S]); n_upper = a host-side upper bound of the cloud size (sizes the grid)."""
+    n, S = len(items), int(grid_size)
+    if not 1 <= n <= 16:
+        raise ValueError("step_maps_batch: 1..16 rollouts per call")
+    if tuple(out6_all.shape) != (n, 6, S, S) or tuple(net_in_all.shape) != (n, 5, S, S) or not out6_all.is_contiguous() \
+            or not net_in_all.is_contiguous():
+        raise ValueError("step_maps_batch: contiguous out6_all [n,6,S,S] and net_in_all [n,5,S,S] expected")
+    _need_cuda(out6_all, "step_maps_batch")
+    VP, LL = C.c_void_p, C.c_longlong
+    pts, ncap, ndev, traj = (VP * n)(), (LL * n)(), (VP * n)(), (VP * n)()
+    poses, bounds, nb = np.zeros((n, 3), np.float32), np.zeros((n, 8), np.float32), (C.c_int * n)()
+    bands, fresh, n_old, n_fresh = np.zeros((n, 2), np.float32), np.zeros((n, 24), np.float32), (C.c_int * n)(), (C.c_int * n)()
+    for i, (full_pc, n_upper, n_dev, pose, y_bins, traj_dev, n_traj_old, traj_fresh) in enumerate(items):
+        cx, cy, cz = _pose_xyz(pose)
+        b = [float(v) for v in (y_bins.tolist() if isinstance(y_bins, torch.Tensor) else y_bins)][:-1]
+        if len(b) > 8:
+            raise ValueError("at most 8 slab boundaries")
+        f = np.asarray(traj_fresh, np.float32).reshape(-1)
+        if n_traj_old + len(f) // 3 > traj_dev.shape[0]:
+            raise ValueError("step_maps_batch: the trajectory buffer is too small")
+        pts[i], ncap[i], ndev[i], traj[i] = full_pc.data_ptr(), min(int(n_upper), full_pc.shape[0]), n_dev.data_ptr(), traj_dev.data_ptr()
+        poses[i] = (cx, cy, cz)
+        bounds[i, :len(b)] = b
+        nb[i] = len(b)
+        bands[i] = (np.float32(cy - band), np.float32(cy + band))       # as the reference forms them: python double +-0.1, then fp32
+        fresh[i, :len(f)] = f
+        n_old[i], n_fresh[i] = int(n_traj_old), len(f) // 3
+    rc = _lib.lib().nbp_step_maps_batch_f32(n, pts, ncap, ndev, poses.ctypes.data, bounds.ctypes.data, nb, bands.ctypes.data, S,
+                                            float(grid_range[0]), float(grid_range[1]), traj, n_old, fresh.ctypes.data, n_fresh,
+                                            out6_all.data_ptr(), net_in_all.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "nbp_step_maps_batch_f32")

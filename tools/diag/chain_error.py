@@ -16,7 +16,10 @@ from nextbestpath_amd.networks.packing import fold_affine
 
 N_STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 tmp = tempfile.mkdtemp()
-hip_ro, ora, mesh = _both_rollouts(tmp, cells=8, size=4.8, tess=0.3, scene_seed=0, seed=5)
+if len(sys.argv) > 2 and sys.argv[2] == "hard":          # the 29 k-face scene of test_hip_rollout_equals_oracle_rollout_hard_scene
+    hip_ro, ora, mesh = _both_rollouts(tmp, cells=12, size=7.2, tess=0.15, scene_seed=101, seed=9)
+else:
+    hip_ro, ora, mesh = _both_rollouts(tmp, cells=8, size=4.8, tess=0.3, scene_seed=0, seed=5)
 for s in range(N_STEPS):
     hip_ro.pre()
     with torch.no_grad():
@@ -56,7 +59,21 @@ with torch.no_grad():
             a = att(f"Att{L}_{d}", dd, skips[L])
             cur = block(f"Up_conv{L}_{d}", [a, dd])
 
-print(f"input max {x_in.max().item():.0f}; columns: mean|err| / max|out64| (max|err| / max|out64|)")
+from oracle import nbp_net
+with torch.no_grad():
+    d1, _ = nbp_net.nbp_forward(sd64, x_in.double())
+    c1, _ = nbp_net.nbp_forward(sd, x_in)
+    rngo = d1.abs().max().item()
+    line = f"whole network, out1 range {rngo:.1f}: torch32 mean {(c1.double()-d1).abs().mean().item()/rngo:.2e}"
+    for prec in ("fp32_split", "fp32"):
+        hip_ro.nbp.conv_precision = prec
+        h1, _ = hip_ro.nbp(x_in.cuda())
+        line += f" | {prec} mean {(h1.cpu().double()-d1).abs().mean().item()/rngo:.2e} max {(h1.cpu().double()-d1).abs().max().item()/rngo:.2e}"
+    hip_ro.nbp.conv_precision = "fp32_split"
+print(line, flush=True)
+if os.environ.get("CHAIN_ERROR_NET_ONLY"):
+    sys.exit(0)
+print(f"input max {x_in.max().item():.0f}; columns: mean|err| / max|out64| (max|err| / max|out64|); last column: in-tensor range of the layer's input = max / median of the non-zero |x|")
 print(f"{'layer':22s} {'K':>5s} {'range':>9s} | {'torch32':>19s} | {'split sk=1':>19s} | {'split auto':>19s} | {'split sk=4':>19s} | {'fp32 pipe sk=1':>19s}")
 dev = "cuda"
 tot = {}
@@ -89,7 +106,9 @@ for p, q, srcs, ups, y64 in layers:
             res[nm] = err(nchw(conv3x3_split(x0d, x1d, 0, pk, N, scd, shd, True, sk)).cpu().double())
     res["fp32 pipe sk=1"] = err(nchw(conv_igemm(x0d, x1d, int(ups), pack_conv(wd), N, 3, scd, shd, True, 1, 0)).cpu().double())
     cols = " | ".join(f"{res[k][0]:.2e} ({res[k][1]:.2e})" for k in ("torch32", "split sk=1", "split auto", "split sk=4", "fp32 pipe sk=1"))
-    print(f"{p:22s} {9 * C:5d} {rng:9.3g} | {cols}", flush=True)
+    xa = xin.abs()
+    dyn = float(xa.max() / xa[xa > 0].median())
+    print(f"{p:22s} {9 * C:5d} {rng:9.3g} | {cols} | 2^{np.log2(dyn):.1f}", flush=True)
     for k, v in res.items():
         tot.setdefault(k, []).append(v[0])
 print("geometric mean of mean-error ratios to torch32:",
