@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void points_scatter4_kernel(const float* __res
 }
 
 template <int LANES, int UNROLL>
-__global__ __launch_bounds__(256) void coverage_mark_kernel(const float* __restrict__ pc, const long long* __restrict__ n_dev,
+__device__ __forceinline__ void coverage_mark_body(unsigned bx, unsigned by, unsigned gx, unsigned gy, const float* __restrict__ pc, const long long* __restrict__ n_dev,
                                                             long long n_host, long long k, unsigned seed, Grid g, float d2max,
                                                             const float4* __restrict__ gt_sorted, const int* __restrict__ gt_start,
                                                             unsigned* __restrict__ stamp, unsigned epoch,
@@ -209,11 +209,11 @@ __global__ __launch_bounds__(256) void coverage_mark_kernel(const float* __restr
     // instructions of a correctly rounded square root per point pair -- the kernel is bound by those pair tests
     const long long N = n_dev ? *n_dev : n_host;
     const long long M = N > k ? k : N;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *m_out = (int)M;
+    if (bx == 0 && threadIdx.x == 0) *m_out = (int)M;
     const unsigned bits = perm_bits((unsigned)N);
     const int sub = threadIdx.x % LANES;
-    for (long long j = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / LANES; j < M;
-         j += ((long long)gridDim.x * blockDim.x) / LANES) {
+    for (long long j = ((long long)bx * blockDim.x + threadIdx.x) / LANES; j < M;
+         j += ((long long)gx * blockDim.x) / LANES) {
         const long long src = N > k ? (long long)perm_index((unsigned)j, (unsigned)N, bits, seed) : j;
         const float x = pc[3 * src], y = pc[3 * src + 1], z = pc[3 * src + 2];
         // unclamped cell: a cloud point outside the grid (= the GT box grown by thr) is farther than thr from every GT point
@@ -251,12 +251,42 @@ __global__ __launch_bounds__(256) void coverage_mark_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void coverage_tally_kernel(const unsigned* __restrict__ stamp, int G, unsigned epoch,
+__device__ __forceinline__ void coverage_tally_body(unsigned bx, unsigned by, unsigned gx, unsigned gy, const unsigned* __restrict__ stamp, int G, unsigned epoch,
                                                              int* __restrict__ count) {
     int mine = 0;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < G; q += gridDim.x * blockDim.x) mine += stamp[q] == epoch ? 1 : 0;
+    for (int q = bx * blockDim.x + threadIdx.x; q < G; q += gx * blockDim.x) mine += stamp[q] == epoch ? 1 : 0;
     for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+}
+
+// ---- launch forms of the planned coverage: one rollout, or the rollouts of a lock-step group in one launch (blockIdx.y)
+template <int LANES, int UNROLL>
+__global__ __launch_bounds__(256) void coverage_mark_kernel(const float* __restrict__ pc, const long long* __restrict__ n_dev,
+                                                            long long n_host, long long k, unsigned seed, Grid g, float d2max,
+                                                            const float4* __restrict__ gt_sorted, const int* __restrict__ gt_start,
+                                                            unsigned* __restrict__ stamp, unsigned epoch, int* __restrict__ m_out) {
+    coverage_mark_body<LANES, UNROLL>(blockIdx.x, 0, gridDim.x, 1, pc, n_dev, n_host, k, seed, g, d2max, gt_sorted, gt_start, stamp, epoch, m_out);
+}
+__global__ __launch_bounds__(256) void coverage_tally_kernel(const unsigned* __restrict__ stamp, int G, unsigned epoch, int* __restrict__ count) {
+    coverage_tally_body(blockIdx.x, 0, gridDim.x, 1, stamp, G, epoch, count);
+}
+constexpr int COV_BATCH = 16;
+struct CovItem {
+    const float* pc; const long long* n_dev; long long n_host, k; const float4* gt_sorted; const int* gt_start; unsigned* stamp;
+    int* count; int* m_out; Grid g; float d2max; unsigned seed, epoch; int G; unsigned gx_mark, gx_tally;
+};
+struct CovBatch { CovItem it[COV_BATCH]; };
+template <int LANES, int UNROLL>
+__global__ __launch_bounds__(256) void coverage_mark_batch_kernel(CovBatch b) {
+    const CovItem& a = b.it[blockIdx.y];
+    if (blockIdx.x >= a.gx_mark) return;
+    coverage_mark_body<LANES, UNROLL>(blockIdx.x, 0, a.gx_mark, 1, a.pc, a.n_dev, a.n_host, a.k, a.seed, a.g, a.d2max, a.gt_sorted, a.gt_start,
+                                      a.stamp, a.epoch, a.m_out);
+}
+__global__ __launch_bounds__(256) void coverage_tally_batch_kernel(CovBatch b) {
+    const CovItem& a = b.it[blockIdx.y];
+    if (blockIdx.x >= a.gx_tally) return;
+    coverage_tally_body(blockIdx.x, 0, a.gx_tally, 1, a.stamp, a.G, a.epoch, a.count);
 }
 
 }  // namespace
@@ -433,5 +463,42 @@ extern "C" int nbp_coverage_count_planned_f32(void* plan, int G, float threshold
         pc3, N_dev_or_null, N, sample_k, seed, g, sq_below(threshold), sorted, start, stamp, epoch, m_out);
     if ((rc = nbp_launch_status())) return rc;
     coverage_tally_kernel<<<(unsigned)(G < 16384 ? 1 : 16), 256, 0, (hipStream_t)stream>>>(stamp, G, epoch, count_accum);
+    return nbp_launch_status();
+}
+
+// nbp_coverage_count_planned_f32 for n <= 16 rollouts in TWO launches (mark, tally) instead of 2 n: arrays of n entries, HOST
+// memory (plans / pc3 / N_dev / count_accum / m_out: device pointers; bbox_lo / bbox_hi [n][3]).  Identical results.
+extern "C" int nbp_coverage_count_planned_batch_f32(int n, void* const* plans, const int* G, float threshold, const float* bbox_lo_host,
+                                                    const float* bbox_hi_host, const float* const* pc3, const long long* N,
+                                                    const long long* const* N_dev, const long long* sample_k, const unsigned* seed,
+                                                    const unsigned* epoch, int* const* count_accum, int* const* m_out, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(n < 1 || n > COV_BATCH || !plans || !G || !bbox_lo_host || !bbox_hi_host || !pc3 || !N || !N_dev || !sample_k ||
+                  !seed || !epoch || !count_accum || !m_out || !(threshold > 0), NBP_E_ARG);
+    CovBatch b;
+    unsigned gmark = 1, gtally = 1;
+    const float d2max = sq_below(threshold);
+    for (int r = 0; r < COV_BATCH; ++r) {
+        const int q = r < n ? r : 0;
+        NBP_RETURN_IF(!plans[q] || !pc3[q] || !count_accum[q] || !m_out[q] || G[q] < 1 || N[q] < 0 || sample_k[q] < 1 ||
+                      N[q] > 0xffffffffll || epoch[q] == 0, NBP_E_ARG);
+        CovItem& a = b.it[r];
+        size_t ncell;
+        const int rc = coverage_grid(bbox_lo_host + 3 * q, bbox_hi_host + 3 * q, threshold, &a.g, &ncell);
+        if (rc) return rc;
+        int* start; float4* sorted; unsigned* stamp;
+        plan_carve(plans[q], ncell, G[q], &start, &sorted, &stamp);
+        a.pc = pc3[q]; a.n_dev = N_dev[q]; a.n_host = N[q]; a.k = sample_k[q]; a.gt_sorted = sorted; a.gt_start = start; a.stamp = stamp;
+        a.count = count_accum[q]; a.m_out = m_out[q]; a.d2max = d2max; a.seed = seed[q]; a.epoch = epoch[q]; a.G = G[q];
+        const long long work = N_dev[q] ? sample_k[q] : (N[q] < sample_k[q] ? N[q] : sample_k[q]);
+        a.gx_mark = r < n ? (unsigned)nbp_ew_grid((work > 0 ? work : 1) * 4, 256) : 0;
+        a.gx_tally = r < n ? (unsigned)(G[q] < 16384 ? 1 : 16) : 0;
+        if (a.gx_mark > gmark) gmark = a.gx_mark;
+        if (a.gx_tally > gtally) gtally = a.gx_tally;
+    }
+    coverage_mark_batch_kernel<4, 4><<<dim3(gmark, (unsigned)n), 256, 0, (hipStream_t)stream>>>(b);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    coverage_tally_batch_kernel<<<dim3(gtally, (unsigned)n), 256, 0, (hipStream_t)stream>>>(b);
     return nbp_launch_status();
 }

@@ -167,12 +167,12 @@ __device__ __forceinline__ unsigned quad_flags(const float4* __restrict__ d4, co
            (z.z > -1.f && z.z < fov_range ? 4u : 0u) | (z.w > -1.f && z.w < fov_range ? 8u : 0u);
 }
 
-__global__ __launch_bounds__(256) void unproject_count4_kernel(const float* __restrict__ depth,
+__device__ __forceinline__ void unproject_count4_body(unsigned bx, unsigned by, unsigned gx, unsigned gy, const float* __restrict__ depth,
                                                                const unsigned char* __restrict__ mask, int HW, int nblk,
                                                                float fov_range, int* __restrict__ blk_count,
                                                                int* __restrict__ done_ticket) {
     __shared__ int wt[4];
-    const int f = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+    const int f = by, b = bx, t = threadIdx.x;
     const float4* d4 = reinterpret_cast<const float4*>(depth + (size_t)f * HW);
     const uchar4* m4 = mask ? reinterpret_cast<const uchar4*>(mask + (size_t)f * HW) : nullptr;
     if (f == 0 && b == 0 && t == 0) *done_ticket = 0;      // ticket of the append kernel's "last block updates the size"
@@ -185,14 +185,14 @@ __global__ __launch_bounds__(256) void unproject_count4_kernel(const float* __re
     if (t == 0) blk_count[f * nblk + b] = wt[0] + wt[1] + wt[2] + wt[3];
 }
 
-__global__ __launch_bounds__(256) void unproject_compact4_kernel(const float* __restrict__ depth,
+__device__ __forceinline__ void unproject_compact4_body(unsigned bx, unsigned by, unsigned gx, unsigned gy, const float* __restrict__ depth,
                                                                  const unsigned char* __restrict__ mask, int HW, int nblk,
                                                                  float fov_range, double gather,
                                                                  const int* __restrict__ blk_count, unsigned* __restrict__ list,
                                                                  int* __restrict__ counts) {
     __shared__ int tot[17];
     __shared__ int base_s;
-    const int f = blockIdx.y, b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int f = by, b = bx, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float4* d4 = reinterpret_cast<const float4*>(depth + (size_t)f * HW);
     const uchar4* m4 = mask ? reinterpret_cast<const uchar4*>(mask + (size_t)f * HW) : nullptr;
     unsigned* out = list + (size_t)f * HW;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void unproject_compact4_kernel(const float* __
 }
 
 // K2: gather the sub-sample and append it to the cloud at *cloud_count + sum of earlier frames.
-__global__ __launch_bounds__(256) void unproject_append_kernel(const float* __restrict__ depth, CamSet cams,
+__device__ __forceinline__ void unproject_append_body(unsigned bx, unsigned by, unsigned gx, unsigned gy, const float* __restrict__ depth, const Cam* cams,
                                                                int H, int W, float tanh_fov, unsigned seed,
                                                                const unsigned* __restrict__ list,
                                                                const int* __restrict__ counts, float* __restrict__ cloud,
@@ -244,15 +244,15 @@ __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __re
                                                                const unsigned long long* __restrict__ zface,
                                                                const float* __restrict__ verts, const int* __restrict__ faces,
                                                                const float* __restrict__ vcolors, float ambient) {
-    const int f = blockIdx.y;
+    const int f = by;
     const int HW = H * W;
     const int nvalid = counts[2 * f], nkeep = counts[2 * f + 1];
     long long base = *cloud_count;
     for (int g = 0; g < f; ++g) base += counts[2 * g + 1];
     const unsigned bits = perm_bits((unsigned)nvalid);
     const unsigned sd = seed + 0x632BE5ABu * (unsigned)(f + 1);
-    const Cam cam = cams.c[f];
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nkeep; j += gridDim.x * blockDim.x) {
+    const Cam cam = cams[f];
+    for (int j = bx * blockDim.x + threadIdx.x; j < nkeep; j += gx * blockDim.x) {
         if (base + j >= capacity) break;
         const unsigned pix = list[(size_t)f * HW + perm_index((unsigned)j, (unsigned)nvalid, bits, sd)];
         const int row = (int)(pix / (unsigned)W), col = (int)(pix - (unsigned)row * W);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __re
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        last = atomicAdd(done_ticket, 1) == (int)(gridDim.x * gridDim.y) - 1;
+        last = atomicAdd(done_ticket, 1) == (int)(gx * gy) - 1;
     }
     __syncthreads();
     if (last && threadIdx.x == 0) {
@@ -288,6 +288,54 @@ __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __re
         *cloud_count = n < capacity ? n : capacity;
         *done_ticket = 0;
     }
+}
+
+// ---- launch forms of the three un-projection kernels: one call (the arguments as they were), or the rollouts of a lock-step
+// group in one launch (blockIdx.z = rollout; up to STEP_BATCH items ride in the kernel arguments).  The step's kernels are
+// latency-bound chains of a few workgroups: n of them side by side cost one chain, not n.
+constexpr int STEP_BATCH = 12;
+struct UnprojItem {
+    const float* depth; const unsigned char* mask; int* blk_count; int* ticket; unsigned* list; int* counts; float* cloud;
+    long long* cloud_count; long long capacity; float* cloud_rgb; const unsigned long long* zface; const float* verts; const int* faces;
+    const float* vcolors; unsigned seed; Cam cam[4];
+};
+struct UnprojBatch { UnprojItem it[STEP_BATCH]; };
+
+__global__ __launch_bounds__(256) void unproject_count4_kernel(const float* __restrict__ depth, const unsigned char* __restrict__ mask,
+                                                               int HW, int nblk, float fov_range, int* __restrict__ blk_count,
+                                                               int* __restrict__ done_ticket) {
+    unproject_count4_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, depth, mask, HW, nblk, fov_range, blk_count, done_ticket);
+}
+__global__ __launch_bounds__(256) void unproject_count4_batch_kernel(UnprojBatch b, int HW, int nblk, float fov_range) {
+    const UnprojItem& a = b.it[blockIdx.z];
+    unproject_count4_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth, a.mask, HW, nblk, fov_range, a.blk_count, a.ticket);
+}
+__global__ __launch_bounds__(256) void unproject_compact4_kernel(const float* __restrict__ depth, const unsigned char* __restrict__ mask,
+                                                                 int HW, int nblk, float fov_range, double gather,
+                                                                 const int* __restrict__ blk_count, unsigned* __restrict__ list,
+                                                                 int* __restrict__ counts) {
+    unproject_compact4_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, depth, mask, HW, nblk, fov_range, gather, blk_count, list, counts);
+}
+__global__ __launch_bounds__(256) void unproject_compact4_batch_kernel(UnprojBatch b, int HW, int nblk, float fov_range, double gather) {
+    const UnprojItem& a = b.it[blockIdx.z];
+    unproject_compact4_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth, a.mask, HW, nblk, fov_range, gather, a.blk_count, a.list,
+                            a.counts);
+}
+__global__ __launch_bounds__(256) void unproject_append_kernel(const float* __restrict__ depth, CamSet cams, int H, int W, float tanh_fov,
+                                                               unsigned seed, const unsigned* __restrict__ list,
+                                                               const int* __restrict__ counts, float* __restrict__ cloud,
+                                                               long long* __restrict__ cloud_count, long long capacity, int n_frames,
+                                                               int* __restrict__ done_ticket, const float* __restrict__ rgb,
+                                                               float* __restrict__ cloud_rgb, const unsigned long long* __restrict__ zface,
+                                                               const float* __restrict__ verts, const int* __restrict__ faces,
+                                                               const float* __restrict__ vcolors, float ambient) {
+    unproject_append_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, depth, cams.c, H, W, tanh_fov, seed, list, counts, cloud, cloud_count,
+                          capacity, n_frames, done_ticket, rgb, cloud_rgb, zface, verts, faces, vcolors, ambient);
+}
+__global__ __launch_bounds__(256) void unproject_append_batch_kernel(UnprojBatch b, int H, int W, float tanh_fov, int n_frames, float ambient) {
+    const UnprojItem& a = b.it[blockIdx.z];
+    unproject_append_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth, a.cam, H, W, tanh_fov, a.seed, a.list, a.counts, a.cloud,
+                          a.cloud_count, a.capacity, n_frames, a.ticket, nullptr, a.cloud_rgb, a.zface, a.verts, a.faces, a.vcolors, ambient);
 }
 
 __global__ void cloud_count_update_kernel(const int* __restrict__ counts, int F, long long* __restrict__ cloud_count,
@@ -320,21 +368,21 @@ constexpr unsigned ZBUF_EMPTY = 0x7F7F7F7Fu;   // memset pattern, 3.39e38 as a f
 
 struct BinEntry { int face; unsigned box; };   // box = tx0 | tx1 << 8 | ty0 << 16 | ty1 << 24 (fine-tile coordinates)
 
-__global__ __launch_bounds__(256) void raster_setup_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
-                                                           int n_faces, CamSet cams, int H, int W,
+__device__ __forceinline__ void raster_setup_body(unsigned bx, unsigned by, unsigned gx, unsigned gy, const float* __restrict__ verts, const int* __restrict__ faces,
+                                                           int n_faces, const Cam* cams, int H, int W,
                                                            float tanh_fov, float zclip, FaceRec* __restrict__ recs,
                                                            int ctiles_x, int ctiles_y, int* __restrict__ ccount,
                                                            BinEntry* __restrict__ clist, unsigned* __restrict__ zbuf_bits,
                                                            unsigned long long* __restrict__ zface) {
-    const int fr = blockIdx.y;
-    const int fi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int fr = by;
+    const int fi = bx * blockDim.x + threadIdx.x;
     // z-buffer (or the (z, face) buffer of the colour path) of this frame = "empty": the tile kernel merges with atomicMin
-    if (zface) for (int p = fi; p < H * W; p += gridDim.x * blockDim.x) zface[(size_t)fr * H * W + p] = ~0ull;
-    else for (int p = fi; p < H * W; p += gridDim.x * blockDim.x) zbuf_bits[(size_t)fr * H * W + p] = ZBUF_EMPTY;
+    if (zface) for (int p = fi; p < H * W; p += gx * blockDim.x) zface[(size_t)fr * H * W + p] = ~0ull;
+    else for (int p = fi; p < H * W; p += gx * blockDim.x) zbuf_bits[(size_t)fr * H * W + p] = ZBUF_EMPTY;
     bool have = false;
     int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
     if (fi < n_faces) {
-        const Cam cam = cams.c[fr];
+        const Cam cam = cams[fr];
         float v[3][3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) to_view(verts + 3 * (size_t)faces[3 * (size_t)fi + k], cam.R, cam.T, v[k]);
@@ -410,16 +458,16 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restrict__ recs, int n_faces, int H, int W,
+__device__ __forceinline__ void raster_tile_body(unsigned bx, unsigned by, unsigned gx, unsigned gy, const FaceRec* __restrict__ recs, int n_faces, int H, int W,
                                                          float tanh_fov, float zclip, int tiles_x, int tiles_y, int ctiles_x,
                                                          int ctiles_y, const int* __restrict__ ccount,
                                                          const BinEntry* __restrict__ clist, unsigned* __restrict__ zbuf_bits,
                                                          unsigned long long* __restrict__ zface, int SEG) {
     __shared__ int hits[HITS];
     __shared__ __attribute__((aligned(16))) FaceRec sh[64];
-    const int fr = blockIdx.y;
+    const int fr = by;
     const int ntiles = tiles_x * tiles_y;
-    const int tile = blockIdx.x % ntiles, seg = blockIdx.x / ntiles;
+    const int tile = bx % ntiles, seg = bx / ntiles;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int nct = ctiles_x * ctiles_y, ct = (ty / COARSE) * ctiles_x + tx / COARSE;
     const int n = ccount[fr * nct + ct];
@@ -504,13 +552,13 @@ __global__ __launch_bounds__(256) void raster_finalize_kernel(float* __restrict_
 // the barycentric interpolation of the winning face's vertex colours (TexturesVertex; perspective-correct barycentrics =
 // those of the view-space ray cast), white background; then the z-buffer value.  One thread per pixel recomputes the
 // barycentrics of its winning face from the face record.  gray_sum[frame] accumulates the luminance for adjust_contrast.
-__global__ __launch_bounds__(256) void raster_shade_kernel(const unsigned long long* __restrict__ zface,
+__device__ __forceinline__ void raster_shade_body(unsigned bx, unsigned by, unsigned gx, unsigned gy, const unsigned long long* __restrict__ zface,
                                                            const float* __restrict__ verts, const int* __restrict__ faces,
-                                                           const float* __restrict__ vcolors, CamSet cams, int H, int W,
+                                                           const float* __restrict__ vcolors, const Cam* cams, int H, int W,
                                                            float tanh_fov, float ambient, float* __restrict__ zbuf_or_null,
                                                            float* __restrict__ rgb_or_null, double* __restrict__ gray_sum) {
-    const int fr = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int fr = by;
+    const int p = bx * blockDim.x + threadIdx.x;
     float gray = 0.f;
     if (p < H * W) {
         const size_t pix = (size_t)fr * H * W + p;
@@ -518,7 +566,7 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(const unsigned long l
         float c[3] = {1.f, 1.f, 1.f};
         if (zbuf_or_null) zbuf_or_null[pix] = zf != ~0ull ? __uint_as_float((unsigned)(zf >> 32)) : -1.f;
         if (rgb_or_null) {
-            if (zf != ~0ull) shade_pixel(verts, faces, vcolors, cams.c[fr], (int)(unsigned)zf, p / W, p % W, H, W, tanh_fov, ambient, c);
+            if (zf != ~0ull) shade_pixel(verts, faces, vcolors, cams[fr], (int)(unsigned)zf, p / W, p % W, H, W, tanh_fov, ambient, c);
             rgb_or_null[3 * pix] = c[0]; rgb_or_null[3 * pix + 1] = c[1]; rgb_or_null[3 * pix + 2] = c[2];
             gray = (0.299f * c[0] + 0.587f * c[1]) + 0.114f * c[2];
         }
@@ -527,6 +575,62 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(const unsigned long l
     double gs = (double)gray;
     for (int o = 32; o; o >>= 1) gs += __shfl_xor(gs, o);
     if ((threadIdx.x & 63) == 0) atomicAdd(&gray_sum[fr], gs);
+}
+
+// ---- launch forms of the rasteriser's kernels (see the un-projection's above)
+struct RasterItem {
+    const float* verts; const int* faces; const float* vcolors; FaceRec* recs; int* ccount; BinEntry* clist; float* zbuf;
+    unsigned long long* zface; int n_faces; unsigned gx_setup, gx_tile; Cam cam[4];
+};
+struct RasterBatch { RasterItem it[STEP_BATCH]; };
+
+__global__ __launch_bounds__(256) void raster_setup_kernel(const float* __restrict__ verts, const int* __restrict__ faces, int n_faces,
+                                                           CamSet cams, int H, int W, float tanh_fov, float zclip,
+                                                           FaceRec* __restrict__ recs, int ctiles_x, int ctiles_y, int* __restrict__ ccount,
+                                                           BinEntry* __restrict__ clist, unsigned* __restrict__ zbuf_bits,
+                                                           unsigned long long* __restrict__ zface) {
+    raster_setup_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, verts, faces, n_faces, cams.c, H, W, tanh_fov, zclip, recs, ctiles_x,
+                      ctiles_y, ccount, clist, zbuf_bits, zface);
+}
+// (the batch's first launch also clears the coarse-tile counters of every item: blockIdx.y == gridDim.y - 1 is that pass, the
+// counters are consumed by the NEXT launch's atomics, so no race)
+__global__ __launch_bounds__(256) void raster_clear_batch_kernel(RasterBatch b, int n_counters) {
+    int* c = b.it[blockIdx.y].ccount;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_counters; i += gridDim.x * blockDim.x) c[i] = 0;
+}
+__global__ __launch_bounds__(256) void raster_setup_batch_kernel(RasterBatch b, int H, int W, float tanh_fov, float zclip, int ctiles_x,
+                                                                 int ctiles_y) {
+    const RasterItem& a = b.it[blockIdx.z];
+    if (blockIdx.x >= a.gx_setup) return;
+    raster_setup_body(blockIdx.x, blockIdx.y, a.gx_setup, gridDim.y, a.verts, a.faces, a.n_faces, a.cam, H, W, tanh_fov, zclip, a.recs,
+                      ctiles_x, ctiles_y, a.ccount, a.clist, nullptr, a.zface);
+}
+__global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restrict__ recs, int n_faces, int H, int W, float tanh_fov,
+                                                         float zclip, int tiles_x, int tiles_y, int ctiles_x, int ctiles_y,
+                                                         const int* __restrict__ ccount, const BinEntry* __restrict__ clist,
+                                                         unsigned* __restrict__ zbuf_bits, unsigned long long* __restrict__ zface, int SEG) {
+    raster_tile_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, recs, n_faces, H, W, tanh_fov, zclip, tiles_x, tiles_y, ctiles_x, ctiles_y,
+                     ccount, clist, zbuf_bits, zface, SEG);
+}
+__global__ __launch_bounds__(64) void raster_tile_batch_kernel(RasterBatch b, int H, int W, float tanh_fov, float zclip, int tiles_x,
+                                                               int tiles_y, int ctiles_x, int ctiles_y, int SEG) {
+    const RasterItem& a = b.it[blockIdx.z];
+    if (blockIdx.x >= a.gx_tile) return;
+    raster_tile_body(blockIdx.x, blockIdx.y, a.gx_tile, gridDim.y, a.recs, a.n_faces, H, W, tanh_fov, zclip, tiles_x, tiles_y, ctiles_x,
+                     ctiles_y, a.ccount, a.clist, nullptr, a.zface, SEG);
+}
+__global__ __launch_bounds__(256) void raster_shade_kernel(const unsigned long long* __restrict__ zface, const float* __restrict__ verts,
+                                                           const int* __restrict__ faces, const float* __restrict__ vcolors, CamSet cams,
+                                                           int H, int W, float tanh_fov, float ambient, float* __restrict__ zbuf_or_null,
+                                                           float* __restrict__ rgb_or_null, double* __restrict__ gray_sum) {
+    raster_shade_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, zface, verts, faces, vcolors, cams.c, H, W, tanh_fov, ambient, zbuf_or_null,
+                      rgb_or_null, gray_sum);
+}
+// depth image out of the (depth, face) image: the zface path's last pass (no colours are evaluated here)
+__global__ __launch_bounds__(256) void raster_depth_batch_kernel(RasterBatch b, int H, int W, float tanh_fov) {
+    const RasterItem& a = b.it[blockIdx.z];
+    raster_shade_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.zface, a.verts, a.faces, a.vcolors, a.cam, H, W, tanh_fov, 0.f, a.zbuf,
+                      nullptr, nullptr);
 }
 
 // torchvision adjust_contrast (mu:2760): out = clamp(factor * img + (1 - factor) * mean(gray), 0, 1)
@@ -964,6 +1068,113 @@ extern "C" int nbp_raster_zface_f32(const float* verts, int n_verts, const int* 
     NBP_RETURN_IF(!zface, NBP_E_ARG);
     return raster_launch(verts, n_verts, faces, n_faces, cams12_host, n_frames, H, W, tan_half_fov, z_clip, zbuf, nullptr, 0.f,
                          1.f, nullptr, ws, ws_bytes, stream, (unsigned long long*)zface);
+}
+
+// ---- the step's simulator stages for the n <= 12 rollouts of a lock-step group, one launch per kernel instead of n.
+// Every array argument is a HOST array of n entries (device pointers inside).  Results are identical to n single calls.
+//
+// nbp_unproject_append_shaded_batch_f32: item r un-projects its n_frames (<= 4) depth frames depth[r] [n_frames][H][W] (with the
+// (depth, face) images zface[r] for the colours; zface / verts / faces / vcolors / cloud_rgb entries may all be NULL: depth only)
+// and appends the sub-sample to cloud[r] at *cloud_count[r]; ws[r] >= nbp_unproject_workspace_bytes(n_frames, H, W) + 256 each
+// (counts2[r] = 2 n_frames ints of scratch that receive (valid, kept) per frame).
+extern "C" int nbp_unproject_append_shaded_batch_f32(int n, const float* const* depth, const void* const* zface, const float* const* verts,
+                                                     const int* const* faces, const float* const* vcolors, const float* cams12_host,
+                                                     int n_frames, int H, int W, float tan_half_fov, float fov_range,
+                                                     double gathering_factor, const unsigned* seeds, float ambient, int* const* counts2,
+                                                     float* const* cloud, float* const* cloud_rgb, long long* const* cloud_count,
+                                                     const long long* capacity, void* const* ws, size_t ws_bytes_each, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(n < 1 || n > STEP_BATCH || !depth || !cams12_host || !seeds || !counts2 || !cloud || !cloud_count || !capacity || !ws, NBP_E_ARG);
+    NBP_RETURN_IF(n_frames < 1 || n_frames > 4 || H < 2 || W < 2 || !(gathering_factor >= 0.0 && gathering_factor <= 1.0), NBP_E_ARG);
+    NBP_RETURN_IF(ws_bytes_each < nbp_unproject_workspace_bytes(n_frames, H, W), NBP_E_WS);
+    const int HW = H * W;
+    NBP_RETURN_IF((HW & 3) != 0, NBP_E_SHAPE);                       // the batched form is the 4-pixels-per-lane path
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (int)nbp_cdiv(HW, COMPACT_CHUNK), nb4 = (int)nbp_cdiv(HW, FAST_CHUNK);
+    NBP_RETURN_IF(nblk > 4096, NBP_E_SHAPE);
+    UnprojBatch b;
+    for (int r = 0; r < STEP_BATCH; ++r) {
+        const int q = r < n ? r : 0;
+        NBP_RETURN_IF(!depth[q] || ((uintptr_t)depth[q] & 15) != 0 || !counts2[q] || !cloud[q] || !cloud_count[q] || capacity[q] < 1 || !ws[q],
+                      NBP_E_ARG);
+        UnprojItem& a = b.it[r];
+        int* blk_count = (int*)(((uintptr_t)ws[q] + 255) / 256 * 256);
+        a.depth = depth[q]; a.mask = nullptr; a.blk_count = blk_count; a.ticket = blk_count + (size_t)n_frames * nb4;
+        a.list = (unsigned*)((char*)blk_count + ((size_t)n_frames * nblk * sizeof(int) + 255) / 256 * 256);
+        a.counts = counts2[q]; a.cloud = cloud[q]; a.cloud_count = cloud_count[q]; a.capacity = capacity[q];
+        const bool col = zface && zface[q] && cloud_rgb && cloud_rgb[q] && verts && faces && vcolors;
+        a.cloud_rgb = col ? cloud_rgb[q] : nullptr;
+        a.zface = col ? (const unsigned long long*)zface[q] : nullptr;
+        a.verts = col ? verts[q] : nullptr; a.faces = col ? faces[q] : nullptr; a.vcolors = col ? vcolors[q] : nullptr;
+        a.seed = seeds[q];
+        for (int f = 0; f < 4; ++f)
+            for (int k = 0; k < 12; ++k) {
+                const float v = f < n_frames ? cams12_host[((size_t)q * n_frames + f) * 12 + k] : 0.f;
+                if (k < 9) a.cam[f].R[k] = v; else a.cam[f].T[k - 9] = v;
+            }
+    }
+    dim3 g4((unsigned)nb4, (unsigned)n_frames, (unsigned)n);
+    unproject_count4_batch_kernel<<<g4, 256, 0, st>>>(b, HW, nb4, fov_range);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    unproject_compact4_batch_kernel<<<g4, 256, 0, st>>>(b, HW, nb4, fov_range, gathering_factor);
+    if ((rc = nbp_launch_status())) return rc;
+    const int max_keep = (int)((double)H * W * gathering_factor) + 1;
+    dim3 grid((unsigned)nbp_cdiv(max_keep, 256), (unsigned)n_frames, (unsigned)n);
+    unproject_append_batch_kernel<<<grid, 256, 0, st>>>(b, H, W, tan_half_fov, n_frames, ambient);
+    return nbp_launch_status();
+}
+
+// nbp_raster_zface_batch_f32: item r renders n_frames (<= 4) views of ITS mesh (verts[r], faces[r], n_faces[r]) into zbuf[r]
+// [n_frames][H][W] and zface[r] (the (depth, face) images); ws[r] >= nbp_raster_workspace_bytes(n_faces[r], n_frames, H, W, 0).
+// Four launches for the group (counter clear, setup, tiles, depth images) instead of 4 n.
+extern "C" int nbp_raster_zface_batch_f32(int n, const float* const* verts, const int* n_verts, const int* const* faces, const int* n_faces,
+                                          const float* cams12_host, int n_frames, int H, int W, float tan_half_fov, float z_clip,
+                                          float* const* zbuf, void* const* zface, void* const* ws, const size_t* ws_bytes, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(n < 1 || n > STEP_BATCH || !verts || !n_verts || !faces || !n_faces || !cams12_host || !zbuf || !zface || !ws || !ws_bytes,
+                  NBP_E_ARG);
+    NBP_RETURN_IF(n_frames < 1 || n_frames > 4 || H < 1 || W < 1, NBP_E_ARG);
+    const int tiles_x = (int)nbp_cdiv(W, TILE), tiles_y = (int)nbp_cdiv(H, TILE);
+    NBP_RETURN_IF(tiles_x > 256 || tiles_y > 256, NBP_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const int ctiles_x = (int)nbp_cdiv(tiles_x, COARSE), ctiles_y = (int)nbp_cdiv(tiles_y, COARSE);
+    const size_t nct = (size_t)ctiles_x * ctiles_y * n_frames;
+    static const int SEG = [] { const char* v = getenv("NBP_RASTER_SEG"); return v && atoi(v) >= 1024 ? atoi(v) / 1024 * 1024 : SEG_DEFAULT; }();
+    RasterBatch b;
+    unsigned g_setup = 1, g_tile = 1;
+    for (int r = 0; r < STEP_BATCH; ++r) {
+        const int q = r < n ? r : 0;
+        NBP_RETURN_IF(!verts[q] || !faces[q] || n_verts[q] < 3 || n_faces[q] < 1 || !zbuf[q] || !zface[q] || !ws[q], NBP_E_ARG);
+        NBP_RETURN_IF(ws_bytes[q] < raster_ws_bytes(n_faces[q], n_frames, H, W, false), NBP_E_WS);
+        RasterItem& a = b.it[r];
+        char* p = (char*)(((uintptr_t)ws[q] + 255) / 256 * 256);
+        a.recs = (FaceRec*)p; p += ((size_t)n_frames * n_faces[q] * sizeof(FaceRec) + 255) / 256 * 256;
+        a.ccount = (int*)p; p += (nct * sizeof(int) + 255) / 256 * 256;
+        a.clist = (BinEntry*)p;
+        a.verts = verts[q]; a.faces = faces[q]; a.vcolors = nullptr; a.zbuf = zbuf[q]; a.zface = (unsigned long long*)zface[q];
+        a.n_faces = n_faces[q];
+        a.gx_setup = r < n ? (unsigned)nbp_cdiv(n_faces[q], 256) : 0;
+        a.gx_tile = r < n ? (unsigned)(tiles_x * tiles_y * (int)nbp_cdiv(n_faces[q], SEG)) : 0;
+        if (a.gx_setup > g_setup) g_setup = a.gx_setup;
+        if (a.gx_tile > g_tile) g_tile = a.gx_tile;
+        for (int f = 0; f < 4; ++f)
+            for (int k = 0; k < 12; ++k) {
+                const float v = f < n_frames ? cams12_host[((size_t)q * n_frames + f) * 12 + k] : 0.f;
+                if (k < 9) a.cam[f].R[k] = v; else a.cam[f].T[k - 9] = v;
+            }
+    }
+    raster_clear_batch_kernel<<<dim3(1, (unsigned)n), 256, 0, st>>>(b, (int)nct);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    raster_setup_batch_kernel<<<dim3(g_setup, (unsigned)n_frames, (unsigned)n), 256, 0, st>>>(b, H, W, tan_half_fov, z_clip, ctiles_x, ctiles_y);
+    if ((rc = nbp_launch_status())) return rc;
+    raster_tile_batch_kernel<<<dim3(g_tile, (unsigned)n_frames, (unsigned)n), 64, 0, st>>>(b, H, W, tan_half_fov, z_clip, tiles_x, tiles_y,
+                                                                                          ctiles_x, ctiles_y, SEG);
+    if ((rc = nbp_launch_status())) return rc;
+    raster_depth_batch_kernel<<<dim3((unsigned)nbp_cdiv((long long)H * W, 256), (unsigned)n_frames, (unsigned)n), 256, 0, st>>>(b, H, W,
+                                                                                                                          tan_half_fov);
+    return nbp_launch_status();
 }
 
 extern "C" int nbp_shade_image_f32(const void* zface, const float* verts, const int* faces, const float* vcolors3,
