@@ -270,6 +270,28 @@ int nbp_step_maps_batch_f32(int n, const float* const* points, const long long* 
                             const float* band_lo_hi_host, int S, float lo, float hi, float* const* traj_pts,
                             const int* n_traj_old, const float* traj_fresh_host, const int* n_traj_fresh,
                             float* out6_all, float* net_in_all, void* stream);
+/* ---- The other latency-bound stages of an exploration step for the rollouts of a lock-step group (n <= 12; coverage: n <= 16),
+ * one launch per kernel instead of n.  Every array argument is a HOST array of n entries holding device pointers / scalars;
+ * results are identical to n single calls (tests/test_gpu_rollout.py).
+ * nbp_coverage_count_planned_batch_f32: nbp_coverage_count_planned_f32 per item (bbox_lo / bbox_hi: [n][3]).
+ * nbp_unproject_append_shaded_batch_f32: nbp_unproject_append_shaded_f32 per item for n_frames <= 4 frames each (H W % 4 == 0);
+ *   cams12_host [n][n_frames][12]; zface / verts / faces / vcolors / cloud_rgb may be NULL (or hold NULLs): depth only;
+ *   counts2[r]: 2 n_frames ints (valid, kept per frame); ws[r] >= nbp_unproject_workspace_bytes(n_frames, H, W) each.
+ * nbp_raster_zface_batch_f32: nbp_raster_zface_f32 per item (each its own mesh) for n_frames <= 4 views each;
+ *   ws[r] >= nbp_raster_workspace_bytes(n_faces[r], n_frames, H, W, 0). */
+int nbp_coverage_count_planned_batch_f32(int n, void* const* plans, const int* G, float threshold, const float* bbox_lo_host,
+                                         const float* bbox_hi_host, const float* const* pc3, const long long* N,
+                                         const long long* const* N_dev, const long long* sample_k, const unsigned* seed,
+                                         const unsigned* epoch, int* const* count_accum, int* const* m_out, void* stream);
+int nbp_unproject_append_shaded_batch_f32(int n, const float* const* depth, const void* const* zface, const float* const* verts,
+                                          const int* const* faces, const float* const* vcolors, const float* cams12_host,
+                                          int n_frames, int H, int W, float tan_half_fov, float fov_range,
+                                          double gathering_factor, const unsigned* seeds, float ambient, int* const* counts2,
+                                          float* const* cloud, float* const* cloud_rgb, long long* const* cloud_count,
+                                          const long long* capacity, void* const* ws, size_t ws_bytes_each, void* stream);
+int nbp_raster_zface_batch_f32(int n, const float* const* verts, const int* n_verts, const int* const* faces, const int* n_faces,
+                               const float* cams12_host, int n_frames, int H, int W, float tan_half_fov, float z_clip,
+                               float* const* zbuf, void* const* zface, void* const* ws, const size_t* ws_bytes, void* stream);
 
 /* ================================================================ A14-A17: simulator
  * PyTorch3D / trimesh conventions restated (third-party; parity with the libraries unpinned):

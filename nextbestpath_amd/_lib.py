@@ -39,6 +39,10 @@ SIGNATURES = {
     "nbp_map_points_to_imgs_f32": (_i, [_vp, _i, _ll, _i, _i, _f, _f, _vp, _vp]),
     "nbp_point_position_i64": (_i, [_vp, _ll, _i, _i, _f, _f, _vp, _vp]),
     "nbp_map_accumulate_f32": (_i, [_vp, _ll, _vp, _f, _f, _f, C.POINTER(_f), _i, _f, _f, _i, _f, _f, _vp, _vp]),
+    "nbp_coverage_count_planned_batch_f32": (_i, [_i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nbp_unproject_append_shaded_batch_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _d, _vp, _f, _vp, _vp, _vp, _vp,
+                                                   _vp, _vp, _sz, _vp]),
+    "nbp_raster_zface_batch_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "nbp_step_maps_batch_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nbp_step_maps_f32": (_i, [_vp, _ll, _vp, _f, _f, _f, C.POINTER(_f), _i, _f, _f, _i, _f, _f, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "nbp_unproject_workspace_bytes": (_sz, [_i, _i, _i]),

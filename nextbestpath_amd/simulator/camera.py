@@ -238,17 +238,45 @@ class Camera:
                                           device=self.device)
         return self._zbuf_ring
 
-    def capture_images(self, mesh, cams_host):
-        """Rasterises len(cams_host) frames in one launch; cams_host [n,12] fp32 (R row-major, T)."""
-        n = len(cams_host)
+    def _reserve(self, n):
         ring = self._ring()
         if self._cursor + n > 16:                       # explicit cursor: the 8 newest frames stay intact
             self._cursor = 0
         slot = self._cursor
         self._cursor += n
-        out = ring[slot:slot + n]
+        return ring[slot:slot + n], slot
+
+    def _commit(self, out, cams_host, slot):
+        n = len(cams_host)
+        for i in range(n):
+            self.frames.append((out[i], cams_host[i].copy(), slot + i))
+        self.frames = self.frames[-8:]
+        self.n_frames_captured += n
+
+    def deferred_colours(self, mesh):
+        """True when this camera renders depth + nearest face and evaluates colours where they are consumed (the default for a
+        mesh with vertex colours and contrast factor 1)."""
+        return self.render_rgb and getattr(mesh, "colors", None) is not None and self.contrast_factor == 1.0
+
+    def capture_begin(self, mesh, cams_host):
+        """First half of capture_images for a batched render of several cameras (hipops.raster_zface_batch): reserves the ring
+        slots and returns (out_z, out_zface, slot); capture_commit registers the frames once the launch is enqueued."""
+        assert self.deferred_colours(mesh)
+        out, slot = self._reserve(len(cams_host))
         self._mesh = mesh
-        if self.render_rgb and getattr(mesh, "colors", None) is not None and self.contrast_factor == 1.0:
+        if self._zface_ring is None:
+            self._zface_ring = torch.empty(16, self.image_height, self.image_width, dtype=torch.int64, device=self.device)
+        return out, self._zface_ring[slot:slot + len(cams_host)], slot
+
+    def capture_commit(self, out, cams_host, slot):
+        self._commit(out, cams_host, slot)
+
+    def capture_images(self, mesh, cams_host):
+        """Rasterises len(cams_host) frames in one launch; cams_host [n,12] fp32 (R row-major, T)."""
+        n = len(cams_host)
+        out, slot = self._reserve(n)
+        self._mesh = mesh
+        if self.deferred_colours(mesh):
             # depth AND the nearest face per pixel: the colours of the reference's renderer (mu:2743-2763) are a pure
             # function of (face, pixel, camera, mesh), so they are evaluated where they are consumed -- for the ~5 % of
             # pixels the un-projection keeps (colour_source), or as whole images on request (frames_rgb)
@@ -265,23 +293,24 @@ class Camera:
         else:
             hipops.raster_zbuf(mesh.verts, mesh.faces, cams_host, self.image_height, self.image_width, bin_cap=mesh.bin_cap,
                                out=out, overflow=self._overflow)
-        for i in range(n):
-            self.frames.append((out[i], cams_host[i].copy(), slot + i))
-        self.frames = self.frames[-8:]
-        self.n_frames_captured += n
+        self._commit(out, cams_host, slot)
         return out
 
     def capture_image(self, mesh):
         cam = np.concatenate([self.R_cam.reshape(-1), self.T_cam.reshape(-1)]).astype(f32)
         return self.capture_images(mesh, cam[None])
 
-    def move_and_capture(self, mesh, next_idx):
-        """The 4 interpolated updates + captures of nbp_planning.py:269-274 with ONE raster launch."""
+    def move_poses(self, next_idx):
+        """The 4 interpolated camera updates of a move (nbp_planning.py:269-274) -> cams host [4,12] to render."""
         cams = []
         for step in range(1, self.n_interpolation_steps + 1):
             self.update_camera(next_idx, interpolation_step=step)
             cams.append(np.concatenate([self.R_cam.reshape(-1), self.T_cam.reshape(-1)]))
-        return self.capture_images(mesh, np.asarray(cams, f32))
+        return np.asarray(cams, f32)
+
+    def move_and_capture(self, mesh, next_idx):
+        """The 4 interpolated updates + captures of nbp_planning.py:269-274 with ONE raster launch."""
+        return self.capture_images(mesh, self.move_poses(next_idx))
 
     def frames_batch(self, which):
         """Stacks frames by negative offsets (e.g. [-1] = current, [-5,-4,-3,-2] = supervision batch):

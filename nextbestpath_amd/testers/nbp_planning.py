@@ -112,11 +112,23 @@ class Rollout:
             net_in[0, 4] = self.traj_img[0]
         self.pre_decide()
 
+    def coverage_item(self):
+        st, pose_i = self.st, self.pose_i
+        return (self.cov_plan, st.cloud, st.coverage_counts[pose_i % N_POSES], st.cloud_count, st.cloud.shape[0],
+                self.step_seed + 7 * pose_i, pose_i < N_POSES)
+
     def pre_observe(self):
         """S2-S4: coverage of the cloud so far, un-projection of the current frame into it."""
-        st, camera, params, pose_i = self.st, self.camera, self.params, self.pose_i
+        self.pre_coverage()
+        self.pre_unproject()
+
+    def pre_coverage(self):
+        st, pose_i = self.st, self.pose_i
         self.cov_plan.count(st.cloud, st.coverage_counts[pose_i % N_POSES], n_dev=st.cloud_count, n=st.cloud.shape[0],
                             seed=self.step_seed + 7 * pose_i, out_is_zero=pose_i < N_POSES)
+
+    def pre_unproject(self):
+        st, camera, params, pose_i = self.st, self.camera, self.params, self.pose_i
         depth, cams = camera.frames_batch([-1])
         colour = camera.colour_source([-1])
         hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
@@ -160,7 +172,19 @@ class Rollout:
 
     def post(self):
         """S10-S14: next pose, move (4 poses, one raster launch), un-project the supervision frames."""
-        st, camera, params, pose_i, path = self.st, self.camera, self.params, self.pose_i, self.path
+        st, camera, params = self.st, self.camera, self.params
+        next_idx = self.post_choose()
+        camera.move_and_capture(self.mesh, next_idx)
+        depth, cams = camera.frames_batch([-5, -4, -3, -2])
+        colour = camera.colour_source([-5, -4, -3, -2])
+        hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
+                                params.sensor_range, seed=self.step_seed + 11 * self.pose_i + 5,
+                                cloud_rgb=st.cloud_rgb if colour else None, **colour)
+        self.post_finish()
+
+    def post_choose(self):
+        """S10: the next lattice pose (host only)."""
+        camera, path = self.camera, self.path
         if not path or self.path_record >= len(path):
             next_idx = list(camera.cam_idx)
             next_idx[4] = self.rng.randrange(8)
@@ -171,14 +195,26 @@ class Rollout:
                 next_idx[4] = self.rng.randrange(8)
         self.path = path
         self.idx_history.append(tuple(camera.cam_idx))
-        camera.move_and_capture(self.mesh, next_idx)
-        depth, cams = camera.frames_batch([-5, -4, -3, -2])
-        colour = camera.colour_source([-5, -4, -3, -2])
-        hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
-                                params.sensor_range, seed=self.step_seed + 11 * pose_i + 5,
-                                cloud_rgb=st.cloud_rgb if colour else None, **colour)
+        return next_idx
+
+    def post_finish(self):
         self.path_record += 1
         self.pose_i += 1
+
+    def unproject_item(self, which, seed):
+        """Arguments of hipops.unproject_append_batch for frames `which` of this rollout (None: the frames are not one contiguous
+        run of the ring, or the camera renders eager colours -- the caller falls back to the single call)."""
+        camera, st = self.camera, self.st
+        slots = [camera.frames[w][2] for w in which]
+        if not all(b == a + 1 for a, b in zip(slots, slots[1:])) or camera._rgb_ring is not None:
+            return None
+        depth = camera._zbuf_ring[slots[0]:slots[0] + len(slots)]
+        cams = np.stack([camera.frames[w][1] for w in which]).astype(np.float32)
+        shade = None
+        if camera._zface_ring is not None:
+            m = camera._mesh
+            shade = (camera._zface_ring[slots[0]:slots[0] + len(slots)], m.verts, m.faces, m.colors, camera.ambient)
+        return (id(self), depth, cams, st.cloud, st.cloud_count, seed, st.cloud_rgb if shade else None, shade)
 
     def step(self):
         self.pre()
@@ -218,6 +254,8 @@ class MultiRollout:
         # the rollouts' map stacks as slices of one tensor per group: the group's map stage is ONE batched launch
         # (NBP_STEP_BATCH=0: one launch per rollout, the A/B switch)
         self.batched = os.environ.get("NBP_STEP_BATCH", "1") == "1" and os.environ.get("NBP_STEP_MAPS", "1") == "1"
+        # which stages of the group's step go as one launch each (A/B: NBP_STEP_BATCH_STAGES=maps,coverage,...)
+        self.batch_stages = set(os.environ.get("NBP_STEP_BATCH_STAGES", "maps,coverage,unproject,raster").split(","))
         self.maps6 = [torch.zeros(len(g), 6, grid, grid, dtype=torch.float32, device=device) for g in self.groups]
         for g, m6 in zip(self.groups, self.maps6):
             for i, r in enumerate(g):
@@ -285,14 +323,64 @@ class MultiRollout:
         self.inflight[gi] = True
 
     def _pre_group(self, gi):
-        """Rollout.pre for every rollout of the group with the map stage as ONE launch (identical results)."""
+        """Rollout.pre for every rollout of the group, each latency-bound stage as ONE batched launch (identical results)."""
         grp, net_in = self.groups[gi], self.net_in[gi]
-        for r in grp:
-            r.pre_observe()
-        hu.step_maps_batch([r.maps_item() for r in grp], grp[0].S, grp[0].grid_range, self.maps6[gi], net_in)
+        p0, stages = grp[0].params, self.batch_stages
+        if "coverage" in stages and len(grp) <= 16:
+            hipops.coverage_count_batch([r.coverage_item() for r in grp])
+        else:
+            for r in grp:
+                r.pre_coverage()
+        items = [r.unproject_item([-1], r.step_seed + 11 * r.pose_i) for r in grp] if "unproject" in stages and len(grp) <= 12 else [None]
+        if all(it is not None for it in items):
+            hipops.unproject_append_batch(items, p0.image_height, p0.image_width, 1, p0.gathering_factor, p0.sensor_range)
+            for r in grp:
+                r.pose, _ = r.camera.get_pose_from_idx(r.camera.cam_idx)
+        else:
+            for r in grp:
+                r.pre_unproject()
+        if "maps" in stages:
+            hu.step_maps_batch([r.maps_item() for r in grp], grp[0].S, grp[0].grid_range, self.maps6[gi], net_in)
         for i, r in enumerate(grp):
+            if "maps" not in stages:
+                full_pc, _, n_dev, pose, y_bins, traj_dev, n_old, fresh = r.maps_item()
+                hu.step_maps(full_pc, pose, y_bins, r.S, r.grid_range, traj_dev, n_old, fresh, r.st.maps6, net_in[i], n_dev=n_dev)
             r.traj_img = net_in[i, 4]
             r.pre_decide()
+
+    def _post_group(self, grp):
+        """Rollout.post for the rollouts of a group: their moves are rendered in ONE batched rasteriser call and their
+        supervision frames un-projected in one (identical results)."""
+        p0 = grp[0].params
+        H, W = p0.image_height, p0.image_width
+        stages = self.batch_stages
+        can_raster = "raster" in stages and len(grp) <= 12 and all(r.camera.deferred_colours(r.mesh) for r in grp)
+        pend = []
+        for r in grp:
+            cams = r.camera.move_poses(r.post_choose())
+            if can_raster:
+                out, zf, slot = r.camera.capture_begin(r.mesh, cams)
+                pend.append((r, cams, out, zf, slot))
+            else:
+                r.camera.capture_images(r.mesh, cams)
+        if can_raster:
+            hipops.raster_zface_batch([(id(r), r.mesh.verts, r.mesh.faces, cams, out, zf) for r, cams, out, zf, _ in pend], H, W,
+                                      len(pend[0][1]))
+            for r, cams, out, _, slot in pend:
+                r.camera.capture_commit(out, cams, slot)
+        which = [-5, -4, -3, -2]
+        items = [r.unproject_item(which, r.step_seed + 11 * r.pose_i + 5) for r in grp] if "unproject" in stages and len(grp) <= 12 else [None]
+        if all(it is not None for it in items):
+            hipops.unproject_append_batch(items, H, W, 4, p0.gathering_factor, p0.sensor_range)
+        else:
+            for r in grp:
+                st, camera = r.st, r.camera
+                depth, cams = camera.frames_batch(which)
+                colour = camera.colour_source(which)
+                hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, p0.gathering_factor, p0.sensor_range,
+                                        seed=r.step_seed + 11 * r.pose_i + 5, cloud_rgb=st.cloud_rgb if colour else None, **colour)
+        for r in grp:
+            r.post_finish()
 
     def _forward(self, net_in):
         """The rollouts evaluate a frozen network: its packed weights are looked up (and their staleness checked: 327 tensor
@@ -311,7 +399,11 @@ class MultiRollout:
             with torch.cuda.stream(self.fwd_streams[gi]):
                 for r in grp:
                     r.plan_finish()
-                    r.post()
+                if self.batched:
+                    self._post_group(grp)
+                else:
+                    for r in grp:
+                        r.post()
             self.inflight[gi] = False
             return
         k = len(side)

@@ -269,6 +269,91 @@ class CoveragePlan:
         return out
 
 
+def coverage_count_batch(items):
+    """CoveragePlan.count for several rollouts in two launches: items = [(plan, pc, out[2] int32, n_dev, n, seed, out_is_zero)]
+    (<= 16); the plans share the threshold."""
+    import numpy as np
+    n = len(items)
+    VP, LL, U, I = C.c_void_p, C.c_longlong, C.c_uint, C.c_int
+    plans, G, pc, N, ndev, k, seed, epoch, cnt, mout = (VP * n)(), (I * n)(), (VP * n)(), (LL * n)(), (VP * n)(), (LL * n)(), (U * n)(), \
+        (U * n)(), (VP * n)(), (VP * n)()
+    lo, hi = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    for i, (plan, cloud, out, n_dev, nn, sd, out_is_zero) in enumerate(items):
+        if not out_is_zero:
+            out[0:1].zero_()
+        plan.epoch += 1
+        plans[i], G[i], pc[i], N[i] = plan.plan.data_ptr(), plan.G, cloud.data_ptr(), cloud.shape[0] if nn is None else int(nn)
+        ndev[i], k[i], seed[i], epoch[i] = _lib.ptr(n_dev), plan.k, int(sd) & 0xFFFFFFFF, plan.epoch
+        cnt[i], mout[i] = out[0:1].data_ptr(), out[1:2].data_ptr()
+        lo[i], hi[i] = list(plan.lo), list(plan.hi)
+    rc = _lib.lib().nbp_coverage_count_planned_batch_f32(n, plans, G, items[0][0].thr, lo.ctypes.data, hi.ctypes.data, pc, N, ndev, k, seed,
+                                                         epoch, cnt, mout, _st())
+    _lib.check(rc, "nbp_coverage_count_planned_batch_f32")
+
+
+_batch_ws = {}
+
+
+def _item_ws(tag, key, nbytes, device):
+    """Per-item scratch of the batched stages (items run concurrently: no sharing between rollouts)."""
+    w = _batch_ws.get((tag, key))
+    if w is None or w.numel() < nbytes:
+        w = _batch_ws[(tag, key)] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return w
+
+
+def unproject_append_batch(items, H, W, n_frames, gathering_factor=0.05, fov_range=70.0, tan_half_fov=TAN_HALF_FOV):
+    """unproject_append for several rollouts (<= 12) in three launches.  items = [(key, depth [F,H,W] contiguous, cams host [F,12],
+    cloud, cloud_count, seed, cloud_rgb | None, shade | None)] with shade = (zface [F,H,W] int64 contiguous, verts, faces, vcolors,
+    ambient); `key` identifies the rollout (its scratch is kept between calls)."""
+    import numpy as np
+    n = len(items)
+    L = _lib.lib()
+    VP, LL, U = C.c_void_p, C.c_longlong, C.c_uint
+    wsb = int(L.nbp_unproject_workspace_bytes(n_frames, H, W)) + 512
+    dep, zf, ve, fa, vc, cnts, cl, crgb, ccount, cap, wsp, seeds = (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)(), \
+        (VP * n)(), (VP * n)(), (VP * n)(), (LL * n)(), (VP * n)(), (U * n)()
+    cams = np.zeros((n, n_frames, 12), np.float32)
+    ambient = 0.85
+    for i, (key, depth, cam, cloud, cloud_count, seed, cloud_rgb, shade) in enumerate(items):
+        assert depth.is_contiguous() and tuple(depth.shape) == (n_frames, H, W)
+        ws = _item_ws("unproject", (key, n_frames, H, W), wsb, depth.device)
+        dep[i], cl[i], ccount[i], cap[i], wsp[i], seeds[i] = depth.data_ptr(), cloud.data_ptr(), cloud_count.data_ptr(), cloud.shape[0], \
+            ws.data_ptr(), int(seed) & 0xFFFFFFFF
+        cnts[i] = ws.data_ptr() + wsb - 256               # 2 n_frames ints in the tail of the item's scratch
+        cams[i] = np.asarray(cam, np.float32).reshape(n_frames, 12)
+        if shade is not None and cloud_rgb is not None:
+            zface, verts, faces, vcolors, ambient = shade
+            assert zface.is_contiguous()
+            zf[i], ve[i], fa[i], vc[i], crgb[i] = zface.data_ptr(), verts.data_ptr(), faces.data_ptr(), vcolors.data_ptr(), cloud_rgb.data_ptr()
+    rc = L.nbp_unproject_append_shaded_batch_f32(n, dep, zf, ve, fa, vc, cams.ctypes.data, n_frames, H, W, tan_half_fov, float(fov_range),
+                                                 float(gathering_factor), seeds, float(ambient), cnts, cl, crgb, ccount, cap, wsp,
+                                                 wsb - 256, _st())
+    _lib.check(rc, "nbp_unproject_append_shaded_batch_f32")
+
+
+def raster_zface_batch(items, H, W, n_frames, tan_half_fov=TAN_HALF_FOV, z_clip=Z_CLIP):
+    """raster_zface for several rollouts (<= 12), each its own mesh, in four launches.  items = [(key, verts, faces, cams host [F,12],
+    out_z [F,H,W], out_zface [F,H,W] int64)]."""
+    import numpy as np
+    n = len(items)
+    L = _lib.lib()
+    VP, I, SZ = C.c_void_p, C.c_int, C.c_size_t
+    ve, nv, fa, nf, zb, zf, wsp, wsn = (VP * n)(), (I * n)(), (VP * n)(), (I * n)(), (VP * n)(), (VP * n)(), (VP * n)(), (SZ * n)()
+    cams = np.zeros((n, n_frames, 12), np.float32)
+    for i, (key, verts, faces, cam, out_z, out_zface) in enumerate(items):
+        F_ = faces.shape[0]
+        nb = _ws_sizes.get(("raster", (F_, n_frames, H, W)))
+        if nb is None:
+            nb = _ws_sizes[("raster", (F_, n_frames, H, W))] = int(L.nbp_raster_workspace_bytes(F_, n_frames, H, W, 0))
+        ws = _item_ws("raster", (key, F_, n_frames, H, W), nb, verts.device)
+        ve[i], nv[i], fa[i], nf[i], zb[i], zf[i], wsp[i], wsn[i] = verts.data_ptr(), verts.shape[0], faces.data_ptr(), F_, out_z.data_ptr(), \
+            out_zface.data_ptr(), ws.data_ptr(), ws.numel()
+        cams[i] = np.asarray(cam, np.float32).reshape(n_frames, 12)
+    rc = L.nbp_raster_zface_batch_f32(n, ve, nv, fa, nf, cams.ctypes.data, n_frames, H, W, tan_half_fov, z_clip, zb, zf, wsp, wsn, _st())
+    _lib.check(rc, "nbp_raster_zface_batch_f32")
+
+
 def carve_update(proxy_pts, depth, mask, cam12_host, zfar, fov_range, tol, score_threshold, n_inside, n_behind, occ,
                  out_of_field, tan_half_fov=TAN_HALF_FOV):
     """A20 (macarons_utils.py:2849-2949, 3329-3363): in-place update of the per-proxy-point carving state."""
