@@ -470,6 +470,15 @@ int nbp_score_candidates_f32(const float* pos3, int P, float cx, float cz, const
 int nbp_edges_blocked_u8(const float* obst, int S, float lo, float hi, float cx, float cz,
                          const float* pos3, const int* edges2, int E, unsigned char* blocked,
                          void* stream);
+/* The three of them for the n <= 16 replanning rollouts of a lock-step group in two launches (fusion; scoring + edge mask):
+ * HOST arrays of n entries (device pointers / scalars), poses_xz_host [n][2] = (cx, cz), skip entries may be NULL.
+ * Identical results to the single calls. */
+int nbp_replan_batch_f32(int n, const float* const* out2, const float* const* maps6, const float* const* traj, float threshold,
+                         int S, float* const* obst, float* const* fullproj, const float* const* pos3, const int* P,
+                         const float* poses_xz_host, const float* const* out1, int V, float lo, float hi,
+                         const unsigned char* const* skip, unsigned char* const* valid, int* const* cell2,
+                         double* const* score, const int* const* edges2, const int* E, unsigned char* const* blocked,
+                         void* stream);
 /* HOST function (no kernel, no stream): the candidate loop of nbp_planning.py:233-249 around
  * generate_Dijkstra_path (long_term_utils.py:334-418) on the position lattice, after the three kernels above
  * and their device->host copies.  Nodes 0..P-1 in lexicographic (i,j,k) order (idx3 [P,3], pos3 [P,3] world

@@ -43,6 +43,7 @@ SIGNATURES = {
     "nbp_unproject_append_shaded_batch_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _d, _vp, _f, _vp, _vp, _vp, _vp,
                                                    _vp, _vp, _sz, _vp]),
     "nbp_raster_zface_batch_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "nbp_replan_batch_f32": (_i, [_i, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nbp_step_maps_batch_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nbp_step_maps_f32": (_i, [_vp, _ll, _vp, _f, _f, _f, C.POINTER(_f), _i, _f, _f, _i, _f, _f, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "nbp_unproject_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -20,10 +20,10 @@ inline float grid_scale(int S, float lo, float hi) { return (float)((double)S / 
 
 // obst = (out2 >= thr); where the full projection is non empty take the height-band projection > 0;
 // zero along the trajectory.  fullproj = min(sum of the 5 cloud channels, 1).
-__global__ __launch_bounds__(256) void fuse_obstacle_kernel(const float* __restrict__ out2, const float* __restrict__ maps6,
+__device__ __forceinline__ void fuse_obstacle_body(unsigned bx, unsigned gx, const float* __restrict__ out2, const float* __restrict__ maps6,
                                                             const float* __restrict__ traj, float thr, int SS,
                                                             float* __restrict__ obst, float* __restrict__ fullproj) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < SS; i += gridDim.x * blockDim.x) {
+    for (int i = bx * blockDim.x + threadIdx.x; i < SS; i += gx * blockDim.x) {
         const float full = (((maps6[i] + maps6[SS + i]) + maps6[2 * SS + i]) + maps6[3 * SS + i]) + maps6[4 * SS + i];
         float o = out2[i] >= thr ? 1.f : 0.f;
         if (full > 0.f) o = maps6[5 * SS + i] > 0.f ? 1.f : 0.f;
@@ -35,13 +35,13 @@ __global__ __launch_bounds__(256) void fuse_obstacle_kernel(const float* __restr
 
 // One wave per candidate: the 21 x 21 window test (check_pixel_values) is a ballot over 64 pixels at a time
 // instead of up to 441 dependent loads in one lane.
-__global__ __launch_bounds__(256) void score_candidates_kernel(const float* __restrict__ pos, int P, float cx, float cz,
+__device__ __forceinline__ void score_candidates_body(unsigned bx, unsigned gx, const float* __restrict__ pos, int P, float cx, float cz,
                                                                const float* __restrict__ out1, int V,
                                                                const float* __restrict__ fullproj, int S, float lo,
                                                                float scV, float scS, const unsigned char* __restrict__ skip,
                                                                unsigned char* __restrict__ valid, int* __restrict__ cell,
                                                                double* __restrict__ score) {
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int i = (bx * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (i >= P) return;
     if (lane == 0) { valid[i] = 0; cell[2 * i] = 0; cell[2 * i + 1] = 0; score[i] = 0.0; }
@@ -71,11 +71,11 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(const float* __re
     score[i] = (double)best - 10.0 * (double)dens;
 }
 
-__global__ __launch_bounds__(256) void edges_blocked_kernel(const float* __restrict__ obst, int S, float lo, float sc,
+__device__ __forceinline__ void edges_blocked_body(unsigned bx, unsigned gx, const float* __restrict__ obst, int S, float lo, float sc,
                                                             float cx, float cz, const float* __restrict__ pos,
                                                             const int* __restrict__ edges, int E,
                                                             unsigned char* __restrict__ blocked) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = bx * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const float* a = pos + 3 * (size_t)edges[2 * e];
     const float* b = pos + 3 * (size_t)edges[2 * e + 1];
@@ -257,6 +257,45 @@ __device__ __forceinline__ void coverage_tally_body(unsigned bx, unsigned by, un
     for (int q = bx * blockDim.x + threadIdx.x; q < G; q += gx * blockDim.x) mine += stamp[q] == epoch ? 1 : 0;
     for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+}
+
+// ---- launch forms of the replanning kernels: one rollout, or every replanning rollout of a lock-step group (blockIdx.y)
+__global__ __launch_bounds__(256) void fuse_obstacle_kernel(const float* __restrict__ out2, const float* __restrict__ maps6,
+                                                            const float* __restrict__ traj, float thr, int SS, float* __restrict__ obst,
+                                                            float* __restrict__ fullproj) {
+    fuse_obstacle_body(blockIdx.x, gridDim.x, out2, maps6, traj, thr, SS, obst, fullproj);
+}
+__global__ __launch_bounds__(256) void score_candidates_kernel(const float* __restrict__ pos, int P, float cx, float cz,
+                                                               const float* __restrict__ out1, int V, const float* __restrict__ fullproj,
+                                                               int S, float lo, float scV, float scS, const unsigned char* __restrict__ skip,
+                                                               unsigned char* __restrict__ valid, int* __restrict__ cell,
+                                                               double* __restrict__ score) {
+    score_candidates_body(blockIdx.x, gridDim.x, pos, P, cx, cz, out1, V, fullproj, S, lo, scV, scS, skip, valid, cell, score);
+}
+__global__ __launch_bounds__(256) void edges_blocked_kernel(const float* __restrict__ obst, int S, float lo, float sc, float cx, float cz,
+                                                            const float* __restrict__ pos, const int* __restrict__ edges, int E,
+                                                            unsigned char* __restrict__ blocked) {
+    edges_blocked_body(blockIdx.x, gridDim.x, obst, S, lo, sc, cx, cz, pos, edges, E, blocked);
+}
+constexpr int PLAN_BATCH = 16;
+struct PlanItem {
+    const float* out2; const float* maps6; const float* traj; float* obst; float* fullproj; const float* pos; const float* out1;
+    const unsigned char* skip; unsigned char* valid; int* cell; double* score; const int* edges; unsigned char* blocked;
+    int P, E; float cx, cz; unsigned g_score, g_edges;
+};
+struct PlanBatch { PlanItem it[PLAN_BATCH]; };
+__global__ __launch_bounds__(256) void fuse_obstacle_batch_kernel(PlanBatch b, float thr, int SS) {
+    const PlanItem& a = b.it[blockIdx.y];
+    fuse_obstacle_body(blockIdx.x, gridDim.x, a.out2, a.maps6, a.traj, thr, SS, a.obst, a.fullproj);
+}
+// candidate scoring (the first g_score workgroups of an item) and the all-edges mask (the next g_edges) in one launch
+__global__ __launch_bounds__(256) void score_edges_batch_kernel(PlanBatch b, int V, int S, float lo, float scV, float scS) {
+    const PlanItem& a = b.it[blockIdx.y];
+    if (blockIdx.x < a.g_score)
+        score_candidates_body(blockIdx.x, a.g_score, a.pos, a.P, a.cx, a.cz, a.out1, V, a.fullproj, S, lo, scV, scS, a.skip, a.valid, a.cell,
+                              a.score);
+    else if (blockIdx.x < a.g_score + a.g_edges)
+        edges_blocked_body(blockIdx.x - a.g_score, a.g_edges, a.obst, S, lo, scS, a.cx, a.cz, a.pos, a.edges, a.E, a.blocked);
 }
 
 // ---- launch forms of the planned coverage: one rollout, or the rollouts of a lock-step group in one launch (blockIdx.y)
@@ -500,5 +539,39 @@ extern "C" int nbp_coverage_count_planned_batch_f32(int n, void* const* plans, c
     int rc = nbp_launch_status();
     if (rc) return rc;
     coverage_tally_batch_kernel<<<dim3(gtally, (unsigned)n), 256, 0, (hipStream_t)stream>>>(b);
+    return nbp_launch_status();
+}
+
+// The GPU half of a replan (nbp_fuse_obstacle_f32 + nbp_score_candidates_f32 + nbp_edges_blocked_u8, nbp_planning.py:166-233,
+// long_term_utils.py:277-331) for the n <= 16 replanning rollouts of a lock-step group in TWO launches.  HOST arrays of n
+// entries; poses_xz_host [n][2] = (cx, cz); skip entries may be NULL.  Identical results to the three single calls.
+extern "C" int nbp_replan_batch_f32(int n, const float* const* out2, const float* const* maps6, const float* const* traj, float threshold,
+                                    int S, float* const* obst, float* const* fullproj, const float* const* pos3, const int* P,
+                                    const float* poses_xz_host, const float* const* out1, int V, float lo, float hi,
+                                    const unsigned char* const* skip, unsigned char* const* valid, int* const* cell2,
+                                    double* const* score, const int* const* edges2, const int* E, unsigned char* const* blocked,
+                                    void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(n < 1 || n > PLAN_BATCH || !out2 || !maps6 || !traj || !obst || !fullproj || !pos3 || !P || !poses_xz_host || !out1 ||
+                  !skip || !valid || !cell2 || !score || !edges2 || !E || !blocked || S < 1 || V < 1 || !(hi > lo), NBP_E_ARG);
+    PlanBatch b;
+    unsigned gmax = 1;
+    for (int r = 0; r < PLAN_BATCH; ++r) {
+        const int q = r < n ? r : 0;
+        NBP_RETURN_IF(!out2[q] || !maps6[q] || !traj[q] || !obst[q] || !fullproj[q] || !pos3[q] || !out1[q] || !valid[q] || !cell2[q] ||
+                      !score[q] || !edges2[q] || !blocked[q] || P[q] < 1 || E[q] < 1, NBP_E_ARG);
+        PlanItem& a = b.it[r];
+        a.out2 = out2[q]; a.maps6 = maps6[q]; a.traj = traj[q]; a.obst = obst[q]; a.fullproj = fullproj[q]; a.pos = pos3[q];
+        a.out1 = out1[q]; a.skip = skip[q]; a.valid = valid[q]; a.cell = cell2[q]; a.score = score[q]; a.edges = edges2[q];
+        a.blocked = blocked[q]; a.P = P[q]; a.E = E[q]; a.cx = poses_xz_host[2 * q]; a.cz = poses_xz_host[2 * q + 1];
+        a.g_score = r < n ? (unsigned)nbp_cdiv((long long)P[q] * 64, 256) : 0;
+        a.g_edges = r < n ? (unsigned)nbp_cdiv(E[q], 256) : 0;
+        if (a.g_score + a.g_edges > gmax) gmax = a.g_score + a.g_edges;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    fuse_obstacle_batch_kernel<<<dim3((unsigned)nbp_ew_grid((long long)S * S, 256), (unsigned)n), 256, 0, st>>>(b, threshold, S * S);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    score_edges_batch_kernel<<<dim3(gmax, (unsigned)n), 256, 0, st>>>(b, V, S, lo, grid_scale(V, lo, hi), grid_scale(S, lo, hi));
     return nbp_launch_status();
 }

@@ -255,8 +255,10 @@ class MultiRollout:
         # (NBP_STEP_BATCH=0: one launch per rollout, the A/B switch)
         self.batched = os.environ.get("NBP_STEP_BATCH", "1") == "1" and os.environ.get("NBP_STEP_MAPS", "1") == "1"
         # which stages of the group's step go as one launch each (A/B: NBP_STEP_BATCH_STAGES=maps,coverage,...)
-        self.batch_stages = set(os.environ.get("NBP_STEP_BATCH_STAGES", "maps,coverage,unproject,raster").split(","))
+        self.batch_stages = set(os.environ.get("NBP_STEP_BATCH_STAGES", "maps,coverage,unproject,raster,replan").split(","))
         self.maps6 = [torch.zeros(len(g), 6, grid, grid, dtype=torch.float32, device=device) for g in self.groups]
+        self._out1_pin = [torch.empty(len(g), 8, grid // 4, grid // 4, dtype=torch.float32).pin_memory() for g in self.groups]
+        self._plan_event = [None] * len(self.groups)
         for g, m6 in zip(self.groups, self.maps6):
             for i, r in enumerate(g):
                 r.st.maps6 = m6[i]
@@ -296,9 +298,12 @@ class MultiRollout:
                         r.pre(net_in[i:i + 1])
                 with torch.no_grad():
                     out1, out2 = self._forward(net_in)
-                for i, r in enumerate(grp):
-                    r.plan_enqueue(out1[i], out2[i])
-                    self.ev_plan[gi][i].record()
+                if self.batched and "replan" in self.batch_stages and len(grp) <= 16:
+                    self._plan_group(gi, out1, out2)
+                else:
+                    for i, r in enumerate(grp):
+                        r.plan_enqueue(out1[i], out2[i])
+                        self.ev_plan[gi][i].record()
             self.inflight[gi] = True
             return
         k = len(side)
@@ -348,6 +353,28 @@ class MultiRollout:
             r.traj_img = net_in[i, 4]
             r.pre_decide()
 
+    def _plan_group(self, gi, out1, out2):
+        """Rollout.plan_enqueue for the group: the replanning rollouts' GPU half in two launches, their results in one copy each
+        plus ONE copy of the group's value maps; one event for all of them."""
+        grp = self.groups[gi]
+        need = [(i, r) for i, r in enumerate(grp) if r.need_replan]
+        if need:
+            r0 = grp[0]
+            pin = self._out1_pin[gi]
+            items = []
+            for i, r in need:
+                r.n_replans += 1
+                r.path_record = 0
+                items.append(r.planner.replan_item(r.pose, out1[i].reshape(8, r.V, r.V), out2[i].reshape(r.S, r.S), r.st.maps6,
+                                                   r.traj_img.reshape(r.S, r.S), r.collision_list))
+            hipops.replan_batch(items, r0.S, r0.V, r0.grid_range)
+            pin.copy_(out1, non_blocking=True)
+            for i, r in need:
+                r.planner.replan_copy_back(r.pose, pin[i].reshape(8, r.V, r.V))
+        ev = self.ev_plan[gi][0]
+        ev.record()
+        self._plan_event[gi] = ev
+
     def _post_group(self, grp):
         """Rollout.post for the rollouts of a group: their moves are rendered in ONE batched rasteriser call and their
         supervision frames un-projected in one (identical results)."""
@@ -393,9 +420,14 @@ class MultiRollout:
     def _complete(self, gi):
         grp, side = self.groups[gi], self.side[gi]
         if not side:
-            for i, r in enumerate(grp):
-                if r.need_replan:
-                    self.ev_plan[gi][i].synchronize()      # the GPU keeps running whatever was queued after the event
+            if self._plan_event[gi] is not None:
+                if any(r.need_replan for r in grp):
+                    self._plan_event[gi].synchronize()     # one event for the group's batched replan results
+                self._plan_event[gi] = None
+            else:
+                for i, r in enumerate(grp):
+                    if r.need_replan:
+                        self.ev_plan[gi][i].synchronize()      # the GPU keeps running whatever was queued after the event
             with torch.cuda.stream(self.fwd_streams[gi]):
                 for r in grp:
                     r.plan_finish()

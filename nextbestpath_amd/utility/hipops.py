@@ -269,6 +269,26 @@ class CoveragePlan:
         return out
 
 
+def replan_batch(items, S, V, grid_range=(-40, 40), threshold=0.13):
+    """fuse_obstacle + score_candidates + edges_blocked for several rollouts (<= 16) in two launches; items = one tuple per
+    rollout from LatticePlanner.replan_item."""
+    import numpy as np
+    n = len(items)
+    VP, I = C.c_void_p, C.c_int
+    a = [(VP * n)() for _ in range(13)]
+    P, E = (I * n)(), (I * n)()
+    xz = np.zeros((n, 2), np.float32)
+    for i, (out2, maps6, traj, obst, fullproj, pos, cxz, out1, skip, valid, cell, score, edges, blocked) in enumerate(items):
+        for arr, t in zip(a, (out2, maps6, traj, obst, fullproj, pos, out1, skip, valid, cell, score, edges, blocked)):
+            arr[i] = None if t is None else t.data_ptr()
+        P[i], E[i] = pos.shape[0], edges.shape[0]
+        xz[i] = cxz
+    o2, m6, tr, ob, fp, ps, o1, sk, va, ce, sc, ed, bl = a
+    rc = _lib.lib().nbp_replan_batch_f32(n, o2, m6, tr, float(threshold), int(S), ob, fp, ps, P, xz.ctypes.data, o1, int(V),
+                                         float(grid_range[0]), float(grid_range[1]), sk, va, ce, sc, ed, E, bl, _st())
+    _lib.check(rc, "nbp_replan_batch_f32")
+
+
 def coverage_count_batch(items):
     """CoveragePlan.count for several rollouts in two launches: items = [(plan, pc, out[2] int32, n_dev, n, seed, out_is_zero)]
     (<= 16); the plans share the threshold."""

@@ -121,6 +121,41 @@ class LatticePlanner:
         self._new_coll = np.zeros(2 * (P + 1), np.int32)        # at most one failed first edge per candidate
         self.native_search = os.environ.get("NBP_PLAN_SEARCH", "native") != "python"
 
+    # ---- the GPU half of a replan for several rollouts at once (MultiRollout): persistent result buffers, ONE device->host copy
+    def _batch_buffers(self):
+        if getattr(self, "_res_dev", None) is None:
+            P, E, dev = len(self.idx3), len(self.edges), self.device
+            o_valid = 8 * P
+            o_blocked = (o_valid + P + 7) // 8 * 8
+            total = o_blocked + E
+            self._res_dev = torch.empty(total, dtype=torch.uint8, device=dev)
+            self._res_pin = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+            cut = lambda t: (t[:8 * P].view(torch.float64), t[o_valid:o_valid + P], t[o_blocked:o_blocked + E])
+            self._res_views_dev, self._res_views_pin = cut(self._res_dev), cut(self._res_pin)
+            self._obst = torch.empty(self.S, self.S, dtype=torch.float32, device=dev)
+            self._fullproj = torch.empty(self.S, self.S, dtype=torch.float32, device=dev)
+            self._cell = torch.empty(P, 2, dtype=torch.int32, device=dev)
+            self._skip_dev = torch.zeros(P, dtype=torch.uint8, device=dev)
+        return self._res_views_dev
+
+    def replan_item(self, pose, out1, out2, maps6, traj_img, collision_list):
+        """Arguments of hipops.replan_batch for this rollout (the skip mask goes to the device here when it is in use)."""
+        score, valid, blocked = self._batch_buffers()
+        self._sync_collisions(collision_list)
+        skip = None
+        if self._skip_any:
+            self._skip_dev.copy_(self._skip_pin, non_blocking=True)
+            skip = self._skip_dev
+        return (out2, maps6, traj_img, self._obst, self._fullproj, self.pos_dev, (float(pose[0]), float(pose[2])), out1, skip, valid,
+                self._cell, score, self.edges_dev, blocked)
+
+    def replan_copy_back(self, pose, out1_pinned):
+        """After the batched launch: this rollout's (score, valid, blocked) in ONE copy; out1_pinned = its [8,V,V] slice of the
+        group's pinned copy of the value maps."""
+        self._res_pin.copy_(self._res_dev, non_blocking=True)
+        score, valid, blocked = self._res_views_pin
+        self._pending = (pose, [valid, score, blocked, out1_pinned])
+
     def _staging(self, *tensors):
         if getattr(self, "_stg", None) is None:
             self._stg = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]

@@ -28,18 +28,20 @@ orig = torch.cuda.Event.synchronize
 def timed_sync(self):
     t = time.perf_counter(); orig(self); blocked[0] += time.perf_counter() - t
 torch.cuda.Event.synchronize = timed_sync
-parts = {"pre": 0.0, "fwd_launch": 0.0, "plan_enqueue": 0.0, "plan_finish": 0.0, "post": 0.0}
-for name in ("pre", "plan_enqueue", "plan_finish", "post"):
-    f = getattr(tp.Rollout, name)
+parts = {"pre": 0.0, "fwd_launch": 0.0, "plan_enqueue": 0.0, "plan_finish": 0.0, "post": 0.0, "_pre_group": 0.0, "_post_group": 0.0}
+for cls, name in ((tp.Rollout, "pre"), (tp.Rollout, "plan_enqueue"), (tp.Rollout, "plan_finish"), (tp.Rollout, "post"),
+                  (tp.MultiRollout, "_pre_group"), (tp.MultiRollout, "_post_group")):
+    f = getattr(cls, name)
     def wrap(f=f, name=name):
         def g(self, *a, **k):
             t = time.perf_counter(); r = f(self, *a, **k); parts[name] += time.perf_counter() - t; return r
         return g
-    setattr(tp.Rollout, name, wrap())
+    setattr(cls, name, wrap())
 fwd = net.forward
-def fwd_t(x):
-    t = time.perf_counter(); r = fwd(x); parts["fwd_launch"] += time.perf_counter() - t; return r
-net.forward = fwd_t
+mf = tp.MultiRollout._forward
+def fwd_t(self, x):
+    t = time.perf_counter(); r = mf(self, x); parts["fwd_launch"] += time.perf_counter() - t; return r
+tp.MultiRollout._forward = fwd_t
 n = 20
 t0 = time.perf_counter()
 for _ in range(n):
@@ -48,6 +50,8 @@ multi.flush(); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"R={R}: {n*R/dt:.1f} steps/s, lock-step {dt/n*1e3:.2f} ms; blocked on events {blocked[0]/n*1e3:.2f} ms/lock-step; "
       f"host parts per lock-step (ms): " + ", ".join(f"{k} {v/n*1e3:.2f}" for k, v in parts.items()))
+if os.environ.get('HOST_TIME_NO_FWD'):
+    sys.exit(0)
 x4 = multi.net_in[0]
 for B in (1, 2, 4, 8):
     x = torch.cat(multi.net_in)[:B].contiguous() if B <= R else None
