@@ -275,6 +275,7 @@ int nbp_step_maps_batch_f32(int n, const float* const* points, const long long* 
  * results are identical to n single calls (tests/test_gpu_rollout.py).
  * nbp_coverage_count_planned_batch_f32: nbp_coverage_count_planned_f32 per item (bbox_lo / bbox_hi: [n][3]).
  * nbp_unproject_append_shaded_batch_f32: nbp_unproject_append_shaded_f32 per item for n_frames <= 4 frames each (H W % 4 == 0);
+ *   depth / zface: [n][n_frames] pointers, one per FRAME ([H][W] each; a ring's frames need not be adjacent);
  *   cams12_host [n][n_frames][12]; zface / verts / faces / vcolors / cloud_rgb may be NULL (or hold NULLs): depth only;
  *   counts2[r]: 2 n_frames ints (valid, kept per frame); ws[r] >= nbp_unproject_workspace_bytes(n_frames, H, W) each.
  * nbp_raster_zface_batch_f32: nbp_raster_zface_f32 per item (each its own mesh) for n_frames <= 4 views each;

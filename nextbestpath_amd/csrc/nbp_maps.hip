@@ -103,7 +103,7 @@ struct MapItem {
     const float* p; long long N; const long long* n_dev; float cx, cz; Bounds bd; float band_lo, band_hi; float* out; TrajArgs tr;
 };
 
-template <int AGG_POINTS, int SLOT_BITS, int THREADS>
+template <int AGG_POINTS, int SLOT_BITS, int THREADS, int ROUNDS>
 __device__ __forceinline__ void map_accumulate_body(const MapItem& a, unsigned wg, unsigned n_wg, int S, float lo, float sc, int* keys,
                                                     int* cnts) {
     constexpr int AGG_SLOTS = 1 << SLOT_BITS;
@@ -137,21 +137,29 @@ __device__ __forceinline__ void map_accumulate_body(const MapItem& a, unsigned w
     for (int i = threadIdx.x; i < AGG_SLOTS; i += THREADS) { keys[i] = AGG_EMPTY; cnts[i] = 0; }
     __syncthreads();
     // 12 B per point: three consecutive dword loads per lane (768 contiguous bytes per wave instruction).  All of a
-    // thread's points are fetched BEFORE the first table insert: the probe loop's LDS atomics would otherwise fence
+    // thread's points of a round are fetched BEFORE the first table insert: the probe loop's LDS atomics would otherwise fence
     // every iteration's loads behind the previous iteration (one HBM round trip per point instead of one per thread).
-    constexpr int PER = AGG_POINTS / THREADS;
-    float px[PER], py[PER], pz[PER];
+    // ROUNDS > 1 (the batched launch: many workgroups in flight anyway): the same table takes several rounds of points before
+    // it is flushed -- consecutive points fall on few distinct cells (walls are vertical), so the flush, one device-scope atomic
+    // per distinct key and the kernel's bound (~5 G atomics/s), shrinks per point.
+    constexpr int PER = AGG_POINTS / THREADS / ROUNDS;
+#pragma unroll 1
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const long long r0 = first + (long long)rd * (AGG_POINTS / ROUNDS);
+        if (r0 >= last) break;
+        float px[PER], py[PER], pz[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const long long i = first + threadIdx.x + (long long)k * THREADS;
-        const bool in = i < last;
-        px[k] = in ? p[3 * i] : __builtin_nanf("");        // NaN fails cell_of: the slot is skipped
-        py[k] = in ? p[3 * i + 1] : 0.f;
-        pz[k] = in ? p[3 * i + 2] : 0.f;
+        for (int k = 0; k < PER; ++k) {
+            const long long i = r0 + threadIdx.x + (long long)k * THREADS;
+            const bool in = i < last;
+            px[k] = in ? p[3 * i] : __builtin_nanf("");        // NaN fails cell_of: the slot is skipped
+            py[k] = in ? p[3 * i + 1] : 0.f;
+            pz[k] = in ? p[3 * i + 2] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            accumulate_point<SLOT_BITS>(px[k], py[k], pz[k], cx, cz, a.bd, a.band_lo, a.band_hi, S, lo, sc, keys, cnts, out);
     }
-#pragma unroll
-    for (int k = 0; k < PER; ++k)
-        accumulate_point<SLOT_BITS>(px[k], py[k], pz[k], cx, cz, a.bd, a.band_lo, a.band_hi, S, lo, sc, keys, cnts, out);
     __syncthreads();
     for (int i = threadIdx.x; i < AGG_SLOTS; i += THREADS)
         if (keys[i] != AGG_EMPTY) atomicAdd(out + keys[i], (float)cnts[i]);
@@ -161,7 +169,7 @@ template <int AGG_POINTS, int SLOT_BITS, int THREADS>
 __global__ __launch_bounds__(THREADS) void map_accumulate_kernel(MapItem a, int S, float lo, float sc) {
     __shared__ int keys[1 << SLOT_BITS];
     __shared__ int cnts[1 << SLOT_BITS];
-    map_accumulate_body<AGG_POINTS, SLOT_BITS, THREADS>(a, blockIdx.x, gridDim.x, S, lo, sc, keys, cnts);
+    map_accumulate_body<AGG_POINTS, SLOT_BITS, THREADS, 1>(a, blockIdx.x, gridDim.x, S, lo, sc, keys, cnts);
 }
 
 // The same for several rollouts in ONE launch (blockIdx.y = rollout): the step's kernels are latency-bound (one workgroup
@@ -170,13 +178,13 @@ __global__ __launch_bounds__(THREADS) void map_accumulate_kernel(MapItem a, int 
 constexpr int MAP_BATCH = 16;
 struct MapBatch { MapItem it[MAP_BATCH]; unsigned n_wg[MAP_BATCH]; };
 
-template <int AGG_POINTS, int SLOT_BITS, int THREADS>
+template <int AGG_POINTS, int SLOT_BITS, int THREADS, int ROUNDS>
 __global__ __launch_bounds__(THREADS) void map_accumulate_batch_kernel(MapBatch b, int S, float lo, float sc) {
     __shared__ int keys[1 << SLOT_BITS];
     __shared__ int cnts[1 << SLOT_BITS];
     const unsigned r = blockIdx.y;
     if (blockIdx.x >= b.n_wg[r]) return;
-    map_accumulate_body<AGG_POINTS, SLOT_BITS, THREADS>(b.it[r], blockIdx.x, b.n_wg[r], S, lo, sc, keys, cnts);
+    map_accumulate_body<AGG_POINTS, SLOT_BITS, THREADS, ROUNDS>(b.it[r], blockIdx.x, b.n_wg[r], S, lo, sc, keys, cnts);
 }
 
 inline float grid_scale(int S, float lo, float hi) { return (float)((double)S / ((double)hi - (double)lo)); }
@@ -288,6 +296,9 @@ extern "C" int nbp_step_maps_batch_f32(int n, const float* const* points, const 
     NBP_RETURN_IF(S < 1 || !(hi > lo) || (long long)6 * S * S >= (1ll << 31), NBP_E_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     const size_t SS = (size_t)S * S;
+    // points per workgroup = 8192 x rounds (NBP_MAP_ROUNDS = 1 | 2 | 4): with a group's workgroups side by side the chip is full
+    // anyway, and a table that sees more consecutive points flushes fewer keys per point
+    static const int rounds = [] { const char* e = getenv("NBP_MAP_ROUNDS"); const int v = e ? atoi(e) : 4; return v == 1 || v == 2 ? v : 4; }();
     MapBatch b;
     unsigned max_wg = 1;
     for (int r = 0; r < MAP_BATCH; ++r) {
@@ -304,14 +315,16 @@ extern "C" int nbp_step_maps_batch_f32(int n, const float* const* points, const 
         it.tr.pts = traj_pts[q]; it.tr.out = net_in_all + (size_t)q * 5 * SS + 4 * SS;
         it.tr.n_old = n_traj_old[q]; it.tr.n_fresh = n_traj_fresh[q];
         for (int i = 0; i < 24; ++i) it.tr.fresh[i] = i < 3 * n_traj_fresh[q] ? traj_fresh_host[24 * q + i] : 0.f;
-        b.n_wg[r] = r < n ? (unsigned)nbp_cdiv(N_cap[q], 8192) + 1 : 0;
+        b.n_wg[r] = r < n ? (unsigned)nbp_cdiv(N_cap[q], 8192 * rounds) + 1 : 0;
         if (b.n_wg[r] > max_wg) max_wg = b.n_wg[r];
     }
     hipError_t e = hipMemsetAsync(out6_all, 0, (size_t)n * 6 * SS * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     e = hipMemset2DAsync(net_in_all + 4 * SS, 5 * SS * sizeof(float), 0, SS * sizeof(float), (size_t)n, st);       // the trajectory channels
     if (e != hipSuccess) return (int)e;
-    map_accumulate_batch_kernel<8192, 13, 1024><<<dim3(max_wg, (unsigned)n), 1024, 0, st>>>(b, S, lo, grid_scale(S, lo, hi));
+    if (rounds == 4) map_accumulate_batch_kernel<32768, 13, 1024, 4><<<dim3(max_wg, (unsigned)n), 1024, 0, st>>>(b, S, lo, grid_scale(S, lo, hi));
+    else if (rounds == 2) map_accumulate_batch_kernel<16384, 13, 1024, 2><<<dim3(max_wg, (unsigned)n), 1024, 0, st>>>(b, S, lo, grid_scale(S, lo, hi));
+    else map_accumulate_batch_kernel<8192, 13, 1024, 1><<<dim3(max_wg, (unsigned)n), 1024, 0, st>>>(b, S, lo, grid_scale(S, lo, hi));
     int rc = nbp_launch_status();
     if (rc) return rc;
     e = hipMemcpy2DAsync(net_in_all, 5 * SS * sizeof(float), out6_all, 6 * SS * sizeof(float), 4 * SS * sizeof(float), (size_t)n,

@@ -294,9 +294,9 @@ __device__ __forceinline__ void unproject_append_body(unsigned bx, unsigned by, 
 // group in one launch (blockIdx.z = rollout; up to STEP_BATCH items ride in the kernel arguments).  The step's kernels are
 // latency-bound chains of a few workgroups: n of them side by side cost one chain, not n.
 constexpr int STEP_BATCH = 12;
-struct UnprojItem {
-    const float* depth; const unsigned char* mask; int* blk_count; int* ticket; unsigned* list; int* counts; float* cloud;
-    long long* cloud_count; long long capacity; float* cloud_rgb; const unsigned long long* zface; const float* verts; const int* faces;
+struct UnprojItem {   // the frames of an item need not be adjacent in memory (a camera's ring of frames wraps): one pointer each
+    const float* depth[4]; const unsigned long long* zface[4]; int* blk_count; int* ticket; unsigned* list; int* counts; float* cloud;
+    long long* cloud_count; long long capacity; float* cloud_rgb; const float* verts; const int* faces;
     const float* vcolors; unsigned seed; Cam cam[4];
 };
 struct UnprojBatch { UnprojItem it[STEP_BATCH]; };
@@ -308,7 +308,9 @@ __global__ __launch_bounds__(256) void unproject_count4_kernel(const float* __re
 }
 __global__ __launch_bounds__(256) void unproject_count4_batch_kernel(UnprojBatch b, int HW, int nblk, float fov_range) {
     const UnprojItem& a = b.it[blockIdx.z];
-    unproject_count4_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth, a.mask, HW, nblk, fov_range, a.blk_count, a.ticket);
+    // (the bodies address frame f as base + f HW: the base is shifted so that this lands on the frame's own pointer)
+    unproject_count4_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth[blockIdx.y] - (size_t)blockIdx.y * HW, nullptr, HW, nblk,
+                          fov_range, a.blk_count, a.ticket);
 }
 __global__ __launch_bounds__(256) void unproject_compact4_kernel(const float* __restrict__ depth, const unsigned char* __restrict__ mask,
                                                                  int HW, int nblk, float fov_range, double gather,
@@ -318,8 +320,8 @@ __global__ __launch_bounds__(256) void unproject_compact4_kernel(const float* __
 }
 __global__ __launch_bounds__(256) void unproject_compact4_batch_kernel(UnprojBatch b, int HW, int nblk, float fov_range, double gather) {
     const UnprojItem& a = b.it[blockIdx.z];
-    unproject_compact4_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth, a.mask, HW, nblk, fov_range, gather, a.blk_count, a.list,
-                            a.counts);
+    unproject_compact4_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth[blockIdx.y] - (size_t)blockIdx.y * HW, nullptr, HW, nblk,
+                            fov_range, gather, a.blk_count, a.list, a.counts);
 }
 __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __restrict__ depth, CamSet cams, int H, int W, float tanh_fov,
                                                                unsigned seed, const unsigned* __restrict__ list,
@@ -334,8 +336,10 @@ __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __re
 }
 __global__ __launch_bounds__(256) void unproject_append_batch_kernel(UnprojBatch b, int H, int W, float tanh_fov, int n_frames, float ambient) {
     const UnprojItem& a = b.it[blockIdx.z];
-    unproject_append_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth, a.cam, H, W, tanh_fov, a.seed, a.list, a.counts, a.cloud,
-                          a.cloud_count, a.capacity, n_frames, a.ticket, nullptr, a.cloud_rgb, a.zface, a.verts, a.faces, a.vcolors, ambient);
+    const size_t shift = (size_t)blockIdx.y * H * W;
+    unproject_append_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth[blockIdx.y] - shift, a.cam, H, W, tanh_fov, a.seed, a.list,
+                          a.counts, a.cloud, a.cloud_count, a.capacity, n_frames, a.ticket, nullptr, a.cloud_rgb,
+                          a.zface[blockIdx.y] ? a.zface[blockIdx.y] - shift : nullptr, a.verts, a.faces, a.vcolors, ambient);
 }
 
 __global__ void cloud_count_update_kernel(const int* __restrict__ counts, int F, long long* __restrict__ cloud_count,
@@ -1073,8 +1077,9 @@ extern "C" int nbp_raster_zface_f32(const float* verts, int n_verts, const int* 
 // ---- the step's simulator stages for the n <= 12 rollouts of a lock-step group, one launch per kernel instead of n.
 // Every array argument is a HOST array of n entries (device pointers inside).  Results are identical to n single calls.
 //
-// nbp_unproject_append_shaded_batch_f32: item r un-projects its n_frames (<= 4) depth frames depth[r] [n_frames][H][W] (with the
-// (depth, face) images zface[r] for the colours; zface / verts / faces / vcolors / cloud_rgb entries may all be NULL: depth only)
+// nbp_unproject_append_shaded_batch_f32: item r un-projects its n_frames (<= 4) depth frames depth[r n_frames + f] ([H][W] each: one
+// pointer per frame, the frames of a ring need not be adjacent; with the (depth, face) images zface[r n_frames + f] for the
+// colours; zface / verts / faces / vcolors / cloud_rgb entries may all be NULL: depth only)
 // and appends the sub-sample to cloud[r] at *cloud_count[r]; ws[r] >= nbp_unproject_workspace_bytes(n_frames, H, W) + 256 each
 // (counts2[r] = 2 n_frames ints of scratch that receive (valid, kept) per frame).
 extern "C" int nbp_unproject_append_shaded_batch_f32(int n, const float* const* depth, const void* const* zface, const float* const* verts,
@@ -1095,16 +1100,20 @@ extern "C" int nbp_unproject_append_shaded_batch_f32(int n, const float* const* 
     UnprojBatch b;
     for (int r = 0; r < STEP_BATCH; ++r) {
         const int q = r < n ? r : 0;
-        NBP_RETURN_IF(!depth[q] || ((uintptr_t)depth[q] & 15) != 0 || !counts2[q] || !cloud[q] || !cloud_count[q] || capacity[q] < 1 || !ws[q],
-                      NBP_E_ARG);
+        NBP_RETURN_IF(!counts2[q] || !cloud[q] || !cloud_count[q] || capacity[q] < 1 || !ws[q], NBP_E_ARG);
         UnprojItem& a = b.it[r];
         int* blk_count = (int*)(((uintptr_t)ws[q] + 255) / 256 * 256);
-        a.depth = depth[q]; a.mask = nullptr; a.blk_count = blk_count; a.ticket = blk_count + (size_t)n_frames * nb4;
+        a.blk_count = blk_count; a.ticket = blk_count + (size_t)n_frames * nb4;
         a.list = (unsigned*)((char*)blk_count + ((size_t)n_frames * nblk * sizeof(int) + 255) / 256 * 256);
         a.counts = counts2[q]; a.cloud = cloud[q]; a.cloud_count = cloud_count[q]; a.capacity = capacity[q];
-        const bool col = zface && zface[q] && cloud_rgb && cloud_rgb[q] && verts && faces && vcolors;
+        const bool col = zface && zface[(size_t)q * n_frames] && cloud_rgb && cloud_rgb[q] && verts && faces && vcolors;
         a.cloud_rgb = col ? cloud_rgb[q] : nullptr;
-        a.zface = col ? (const unsigned long long*)zface[q] : nullptr;
+        for (int f = 0; f < 4; ++f) {
+            const int g = f < n_frames ? f : 0;
+            a.depth[f] = depth[(size_t)q * n_frames + g];
+            NBP_RETURN_IF(!a.depth[f] || ((uintptr_t)a.depth[f] & 15) != 0, NBP_E_ARG);
+            a.zface[f] = col ? (const unsigned long long*)zface[(size_t)q * n_frames + g] : nullptr;
+        }
         a.verts = col ? verts[q] : nullptr; a.faces = col ? faces[q] : nullptr; a.vcolors = col ? vcolors[q] : nullptr;
         a.seed = seeds[q];
         for (int f = 0; f < 4; ++f)

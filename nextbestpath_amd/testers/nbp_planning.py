@@ -202,18 +202,21 @@ class Rollout:
         self.pose_i += 1
 
     def unproject_item(self, which, seed):
-        """Arguments of hipops.unproject_append_batch for frames `which` of this rollout (None: the frames are not one contiguous
-        run of the ring, or the camera renders eager colours -- the caller falls back to the single call)."""
+        """Arguments of hipops.unproject_append_batch for frames `which` of this rollout (None: the camera renders eager colours --
+        the caller falls back to the single call)."""
         camera, st = self.camera, self.st
-        slots = [camera.frames[w][2] for w in which]
-        if not all(b == a + 1 for a, b in zip(slots, slots[1:])) or camera._rgb_ring is not None:
+        if camera._rgb_ring is not None:
             return None
-        depth = camera._zbuf_ring[slots[0]:slots[0] + len(slots)]
+        slots = [camera.frames[w][2] for w in which]
+        hw4 = camera.image_height * camera.image_width * 4
+        z0 = camera._zbuf_ring.data_ptr()
+        depth = [z0 + k * hw4 for k in slots]                  # frame pointers (the ring's frames are [H,W] fp32, 16-byte aligned)
         cams = np.stack([camera.frames[w][1] for w in which]).astype(np.float32)
         shade = None
         if camera._zface_ring is not None:
             m = camera._mesh
-            shade = (camera._zface_ring[slots[0]:slots[0] + len(slots)], m.verts, m.faces, m.colors, camera.ambient)
+            f0 = camera._zface_ring.data_ptr()
+            shade = ([f0 + 2 * k * hw4 for k in slots], m.verts, m.faces, m.colors, camera.ambient)
         return (id(self), depth, cams, st.cloud, st.cloud_count, seed, st.cloud_rgb if shade else None, shade)
 
     def step(self):

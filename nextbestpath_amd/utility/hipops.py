@@ -323,29 +323,32 @@ def _item_ws(tag, key, nbytes, device):
 
 
 def unproject_append_batch(items, H, W, n_frames, gathering_factor=0.05, fov_range=70.0, tan_half_fov=TAN_HALF_FOV):
-    """unproject_append for several rollouts (<= 12) in three launches.  items = [(key, depth [F,H,W] contiguous, cams host [F,12],
-    cloud, cloud_count, seed, cloud_rgb | None, shade | None)] with shade = (zface [F,H,W] int64 contiguous, verts, faces, vcolors,
-    ambient); `key` identifies the rollout (its scratch is kept between calls)."""
+    """unproject_append for several rollouts (<= 12) in three launches.  items = [(key, depth frames [F tensors [H,W]], cams host
+    [F,12], cloud, cloud_count, seed, cloud_rgb | None, shade | None)] with shade = (zface frames [F tensors [H,W] int64], verts,
+    faces, vcolors, ambient); the frames need not be adjacent in memory; `key` identifies the rollout (its scratch is kept)."""
     import numpy as np
     n = len(items)
     L = _lib.lib()
     VP, LL, U = C.c_void_p, C.c_longlong, C.c_uint
     wsb = int(L.nbp_unproject_workspace_bytes(n_frames, H, W)) + 512
-    dep, zf, ve, fa, vc, cnts, cl, crgb, ccount, cap, wsp, seeds = (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)(), \
-        (VP * n)(), (VP * n)(), (VP * n)(), (LL * n)(), (VP * n)(), (U * n)()
+    dep, zf = (VP * (n * n_frames))(), (VP * (n * n_frames))()
+    ve, fa, vc, cnts, cl, crgb, ccount, cap, wsp, seeds = (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)(), \
+        (LL * n)(), (VP * n)(), (U * n)()
     cams = np.zeros((n, n_frames, 12), np.float32)
     ambient = 0.85
     for i, (key, depth, cam, cloud, cloud_count, seed, cloud_rgb, shade) in enumerate(items):
-        assert depth.is_contiguous() and tuple(depth.shape) == (n_frames, H, W)
-        ws = _item_ws("unproject", (key, n_frames, H, W), wsb, depth.device)
-        dep[i], cl[i], ccount[i], cap[i], wsp[i], seeds[i] = depth.data_ptr(), cloud.data_ptr(), cloud_count.data_ptr(), cloud.shape[0], \
-            ws.data_ptr(), int(seed) & 0xFFFFFFFF
+        ws = _item_ws("unproject", (key, n_frames, H, W), wsb, cloud.device)
+        cl[i], ccount[i], cap[i], wsp[i], seeds[i] = cloud.data_ptr(), cloud_count.data_ptr(), cloud.shape[0], ws.data_ptr(), \
+            int(seed) & 0xFFFFFFFF
         cnts[i] = ws.data_ptr() + wsb - 256               # 2 n_frames ints in the tail of the item's scratch
         cams[i] = np.asarray(cam, np.float32).reshape(n_frames, 12)
+        for f in range(n_frames):
+            dep[i * n_frames + f] = depth[f] if isinstance(depth[f], int) else depth[f].data_ptr()
         if shade is not None and cloud_rgb is not None:
             zface, verts, faces, vcolors, ambient = shade
-            assert zface.is_contiguous()
-            zf[i], ve[i], fa[i], vc[i], crgb[i] = zface.data_ptr(), verts.data_ptr(), faces.data_ptr(), vcolors.data_ptr(), cloud_rgb.data_ptr()
+            for f in range(n_frames):
+                zf[i * n_frames + f] = zface[f] if isinstance(zface[f], int) else zface[f].data_ptr()
+            ve[i], fa[i], vc[i], crgb[i] = verts.data_ptr(), faces.data_ptr(), vcolors.data_ptr(), cloud_rgb.data_ptr()
     rc = L.nbp_unproject_append_shaded_batch_f32(n, dep, zf, ve, fa, vc, cams.ctypes.data, n_frames, H, W, tan_half_fov, float(fov_range),
                                                  float(gathering_factor), seeds, float(ambient), cnts, cl, crgb, ccount, cap, wsp,
                                                  wsb - 256, _st())
