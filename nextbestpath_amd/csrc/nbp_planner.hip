@@ -203,7 +203,7 @@ __device__ __forceinline__ void coverage_mark_body(unsigned bx, unsigned by, uns
                                                             long long n_host, long long k, unsigned seed, Grid g, float d2max,
                                                             const float4* __restrict__ gt_sorted, const int* __restrict__ gt_start,
                                                             unsigned* __restrict__ stamp, unsigned epoch,
-                                                            int* __restrict__ m_out, unsigned* __restrict__ full) {
+                                                            int* __restrict__ m_out) {
     // d2max = the largest float whose square root is below the threshold (sq_below, host): d2 <= d2max is the reference's
     // cdist(...) < threshold decision exactly (sqrtf is monotone and correctly rounded on both sides) without the ~12
     // instructions of a correctly rounded square root per point pair -- the kernel is bound by those pair tests
@@ -226,14 +226,6 @@ __device__ __forceinline__ void coverage_mark_body(unsigned bx, unsigned by, uns
             const int a = ci + col / 3 - 1, b = cj + col % 3 - 1;
             if (a < 0 || a >= g.n[0] || b < 0 || b >= g.n[1]) continue;
             const int base = (a * g.n[1] + b) * g.n[2];
-            // saturation: full[cell] == epoch says every GT point of the cell carries this call's stamp already -- a run whose
-            // (<= 3) cells are all full has nothing left to give and its ~10^2 point loads are skipped.  A dense cloud hits the
-            // same walls over and over, so most runs saturate after their first few visitors.  Whoever walks a run and sees
-            // every point stamped (before or by itself) sets the flags; the result cannot change: only finished cells are skipped.
-            bool sat = true;
-            for (int d = d0; d <= d1; ++d) sat = sat && full[base + d] == epoch;
-            if (sat) continue;
-            bool all_ok = true;
             const int hi = gt_start[base + d1 + 1];
             int q = gt_start[base + d0];
             // the run of a column is walked UNROLL points at a time: their stamps and positions are independent loads in
@@ -246,10 +238,7 @@ __device__ __forceinline__ void coverage_mark_body(unsigned bx, unsigned by, uns
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     const float ex = t[u].x - x, ey = t[u].y - y, ez = t[u].z - z;
-                    if (sp[u] != epoch) {
-                        if ((ex * ex + ey * ey) + ez * ez <= d2max) stamp[q + u] = epoch;
-                        else all_ok = false;
-                    }
+                    if (sp[u] != epoch && (ex * ex + ey * ey) + ez * ez <= d2max) stamp[q + u] = epoch;
                 }
             }
             for (; q < hi; ++q) {
@@ -257,11 +246,8 @@ __device__ __forceinline__ void coverage_mark_body(unsigned bx, unsigned by, uns
                 const float4 t = gt_sorted[q];
                 const float ex = t.x - x, ey = t.y - y, ez = t.z - z;
                 if ((ex * ex + ey * ey) + ez * ez <= d2max) stamp[q] = epoch;          // plain store: every writer writes the
-                else all_ok = false;                                                   // same value (device-scope atomics run
-            }                                                                          // at ~5 G/s on this part: 30x slower)
-            if (all_ok)
-                for (int d = d0; d <= d1; ++d) full[base + d] = epoch;
-        }
+            }                                                                          // same value (device-scope atomics run
+        }                                                                              // at ~5 G/s on this part: 30x slower)
     }
 }
 
@@ -317,10 +303,8 @@ template <int LANES, int UNROLL>
 __global__ __launch_bounds__(256) void coverage_mark_kernel(const float* __restrict__ pc, const long long* __restrict__ n_dev,
                                                             long long n_host, long long k, unsigned seed, Grid g, float d2max,
                                                             const float4* __restrict__ gt_sorted, const int* __restrict__ gt_start,
-                                                            unsigned* __restrict__ stamp, unsigned epoch, int* __restrict__ m_out,
-                                                            unsigned* __restrict__ full) {
-    coverage_mark_body<LANES, UNROLL>(blockIdx.x, 0, gridDim.x, 1, pc, n_dev, n_host, k, seed, g, d2max, gt_sorted, gt_start, stamp, epoch, m_out,
-                                      full);
+                                                            unsigned* __restrict__ stamp, unsigned epoch, int* __restrict__ m_out) {
+    coverage_mark_body<LANES, UNROLL>(blockIdx.x, 0, gridDim.x, 1, pc, n_dev, n_host, k, seed, g, d2max, gt_sorted, gt_start, stamp, epoch, m_out);
 }
 __global__ __launch_bounds__(256) void coverage_tally_kernel(const unsigned* __restrict__ stamp, int G, unsigned epoch, int* __restrict__ count) {
     coverage_tally_body(blockIdx.x, 0, gridDim.x, 1, stamp, G, epoch, count);
@@ -328,7 +312,7 @@ __global__ __launch_bounds__(256) void coverage_tally_kernel(const unsigned* __r
 constexpr int COV_BATCH = 16;
 struct CovItem {
     const float* pc; const long long* n_dev; long long n_host, k; const float4* gt_sorted; const int* gt_start; unsigned* stamp;
-    unsigned* full; int* count; int* m_out; Grid g; float d2max; unsigned seed, epoch; int G; unsigned gx_mark, gx_tally;
+    int* count; int* m_out; Grid g; float d2max; unsigned seed, epoch; int G; unsigned gx_mark, gx_tally;
 };
 struct CovBatch { CovItem it[COV_BATCH]; };
 template <int LANES, int UNROLL>
@@ -336,7 +320,7 @@ __global__ __launch_bounds__(256) void coverage_mark_batch_kernel(CovBatch b) {
     const CovItem& a = b.it[blockIdx.y];
     if (blockIdx.x >= a.gx_mark) return;
     coverage_mark_body<LANES, UNROLL>(blockIdx.x, 0, a.gx_mark, 1, a.pc, a.n_dev, a.n_host, a.k, a.seed, a.g, a.d2max, a.gt_sorted, a.gt_start,
-                                      a.stamp, a.epoch, a.m_out, a.full);
+                                      a.stamp, a.epoch, a.m_out);
 }
 __global__ __launch_bounds__(256) void coverage_tally_batch_kernel(CovBatch b) {
     const CovItem& a = b.it[blockIdx.y];
@@ -448,19 +432,18 @@ static float sq_below(float thr) {
     return x;
 }
 
-static void plan_carve(void* plan, size_t ncell, int G, int** start, float4** sorted, unsigned** stamp, unsigned** full = nullptr) {
+static void plan_carve(void* plan, size_t ncell, int G, int** start, float4** sorted, unsigned** stamp) {
     char* p = (char*)(((uintptr_t)plan + 255) / 256 * 256);
     *start = (int*)p; p += al256((ncell + 1) * 4);
     *sorted = (float4*)p; p += al256((size_t)G * 16);
-    *stamp = (unsigned*)p; p += al256((size_t)G * 4);
-    if (full) *full = (unsigned*)p;                          // per-cell saturation flags [ncell] (coverage_mark_body)
+    *stamp = (unsigned*)p;
 }
 
 extern "C" size_t nbp_coverage_plan_bytes(const float* bbox_lo_host, const float* bbox_hi_host, float threshold, int G) {
     Grid g; size_t ncell;
     if (!bbox_lo_host || !bbox_hi_host || !(threshold > 0) || G < 1) return 0;
     if (coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell)) return 0;
-    return 256 + al256((ncell + 1) * 4) + al256((size_t)G * 16) + al256((size_t)G * 4) + al256(ncell * 4);
+    return 256 + al256((ncell + 1) * 4) + al256((size_t)G * 16) + al256((size_t)G * 4);
 }
 
 extern "C" size_t nbp_coverage_plan_workspace_bytes(const float* bbox_lo_host, const float* bbox_hi_host, float threshold,
@@ -482,10 +465,8 @@ extern "C" int nbp_coverage_plan_build_f32(const float* gt3, int G, float thresh
     NBP_RETURN_IF(plan_bytes < nbp_coverage_plan_bytes(bbox_lo_host, bbox_hi_host, threshold, G), NBP_E_WS);
     NBP_RETURN_IF(ws_bytes < nbp_coverage_plan_workspace_bytes(bbox_lo_host, bbox_hi_host, threshold, G), NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;
-    int* start; float4* sorted; unsigned* stamp; unsigned* full;
-    plan_carve(plan, ncell, G, &start, &sorted, &stamp, &full);
-    hipError_t ef = hipMemsetAsync(full, 0, ncell * sizeof(unsigned), st);
-    if (ef != hipSuccess) return (int)ef;
+    int* start; float4* sorted; unsigned* stamp;
+    plan_carve(plan, ncell, G, &start, &sorted, &stamp);
     char* p = (char*)(((uintptr_t)ws + 255) / 256 * 256);
     int* count = (int*)p; p += al256(ncell * 4);
     int* tsum = (int*)p; p += al256((ncell / SCAN_TILE + 1) * 4);
@@ -511,14 +492,14 @@ extern "C" int nbp_coverage_count_planned_f32(void* plan, int G, float threshold
     Grid g; size_t ncell;
     int rc = coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell);
     if (rc) return rc;
-    int* start; float4* sorted; unsigned* stamp; unsigned* full;
-    plan_carve(plan, ncell, G, &start, &sorted, &stamp, &full);
+    int* start; float4* sorted; unsigned* stamp;
+    plan_carve(plan, ncell, G, &start, &sorted, &stamp);
     const long long work = N_dev_or_null ? sample_k : (N < sample_k ? N : sample_k);
     // 4 lanes per point, runs walked 4 GT points at a time: 34 us with the tally against 39 for one point per iteration;
     // 8 or 16 lanes per point or 8 points per iteration measure the same (the kernel is then bound by the ~50 M
     // point-pair tests, not by the chains)
     coverage_mark_kernel<4, 4><<<nbp_ew_grid((work > 0 ? work : 1) * 4, 256), 256, 0, (hipStream_t)stream>>>(
-        pc3, N_dev_or_null, N, sample_k, seed, g, sq_below(threshold), sorted, start, stamp, epoch, m_out, full);
+        pc3, N_dev_or_null, N, sample_k, seed, g, sq_below(threshold), sorted, start, stamp, epoch, m_out);
     if ((rc = nbp_launch_status())) return rc;
     coverage_tally_kernel<<<(unsigned)(G < 16384 ? 1 : 16), 256, 0, (hipStream_t)stream>>>(stamp, G, epoch, count_accum);
     return nbp_launch_status();
@@ -544,9 +525,8 @@ extern "C" int nbp_coverage_count_planned_batch_f32(int n, void* const* plans, c
         size_t ncell;
         const int rc = coverage_grid(bbox_lo_host + 3 * q, bbox_hi_host + 3 * q, threshold, &a.g, &ncell);
         if (rc) return rc;
-        int* start; float4* sorted; unsigned* stamp; unsigned* full;
-        plan_carve(plans[q], ncell, G[q], &start, &sorted, &stamp, &full);
-        a.full = full;
+        int* start; float4* sorted; unsigned* stamp;
+        plan_carve(plans[q], ncell, G[q], &start, &sorted, &stamp);
         a.pc = pc3[q]; a.n_dev = N_dev[q]; a.n_host = N[q]; a.k = sample_k[q]; a.gt_sorted = sorted; a.gt_start = start; a.stamp = stamp;
         a.count = count_accum[q]; a.m_out = m_out[q]; a.d2max = d2max; a.seed = seed[q]; a.epoch = epoch[q]; a.G = G[q];
         const long long work = N_dev[q] ? sample_k[q] : (N[q] < sample_k[q] ? N[q] : sample_k[q]);
