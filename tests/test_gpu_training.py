@@ -587,3 +587,81 @@ def test_wgrad_entry_point_fuzz(hip, entry):
         assert err < 5e-6, (trial, B, H, W, C0, C1, N, k, ups, c_real, n_real, err)
         ok += 1
     assert ok >= 20, (ok, refused)
+
+
+def _recorded_forward_fp64(sd, x):
+    """The train-mode network in float64 torch ops with every intermediate recorded under the names networks/training.py uses."""
+    rec = {}
+    r = lambda name, t: rec.setdefault(name, t)
+
+    def bn(p, t):
+        return F.batch_norm(t, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.1, 1e-5)
+
+    def conv(p, t, pad):
+        return F.conv2d(t, sd[p + ".weight"], sd[p + ".bias"], padding=pad)
+
+    def block(name, t):
+        t = r(name + ".conv.1", F.relu(bn(name + ".conv.1", r(name + ".conv.0", conv(name + ".conv.0", t, 1)))))
+        return r(name + ".conv.4", F.relu(bn(name + ".conv.4", r(name + ".conv.3", conv(name + ".conv.3", t, 1)))))
+
+    def gate(name, g, xx):
+        g1 = r(name + ".W_g.1", bn(name + ".W_g.1", r(name + ".W_g.0", conv(name + ".W_g.0", g, 0))))
+        x1 = r(name + ".W_x.1", bn(name + ".W_x.1", r(name + ".W_x.0", conv(name + ".W_x.0", xx, 0))))
+        q = r(name + ".q", F.relu(g1 + x1))
+        psi = r(name + ".psi", torch.sigmoid(r(name + ".psi.1", bn(name + ".psi.1", r(name + ".psi.0", conv(name + ".psi.0", q, 0))))))
+        return r(name + ".out", xx * psi)
+    x1 = block("Conv1", x)
+    x2 = block("Conv2", r("pool1", F.max_pool2d(x1, 2, 2)))
+    x3 = block("Conv3", r("pool2", F.max_pool2d(x2, 2, 2)))
+    x4 = block("Conv4", r("pool3", F.max_pool2d(x3, 2, 2)))
+    x5 = block("Conv5", r("pool4", F.max_pool2d(x4, 2, 2)))
+    skips, outs = {5: x4, 4: x3, 3: x2, 2: x1}, {}
+    for d, levels in ((1, (5, 4)), (2, (5, 4, 3, 2))):
+        cur = x5
+        for L in levels:
+            u = f"Up{L}_{d}"
+            dd = r(u + ".up.2", F.relu(bn(u + ".up.2", r(u + ".up.1", conv(u + ".up.1", F.interpolate(cur, scale_factor=2), 1)))))
+            cur = block(f"Up_conv{L}_{d}", torch.cat((gate(f"Att{L}_{d}", dd, skips[L]), dd), 1))
+        outs[d] = cur
+    out1 = F.conv2d(outs[1], sd["Final1.weight"], sd["Final1.bias"])
+    out2 = torch.sigmoid(F.conv2d(outs[2], sd["Final2.0.weight"], sd["Final2.0.bias"]))
+    return out1, out2, rec
+
+
+def test_composed_backward_at_the_oracle_point(hip, nbp_weights):
+    """The chaos removed: fp32 training on this network flips ReLU masks against an exact evaluation (see the tests above), which
+    is why the composed gradients can only be bounded at the 1e-2 level there.  Here the HIP forward is teacher-forced
+    (networks/training.py::TEACHER): every intermediate is overwritten by a float64 evaluation's value (rounded to fp32) as soon
+    as it is computed, so the saved tensors -- masks, pooling arg-maxes, the inputs of the batch statistics -- are the exact
+    ones, and the backward is the HIP kernels' arithmetic (data gradients, weight gradients, BatchNorm backward, gates, pooling,
+    loss) composed over all 48 layers at THAT point: all 327 parameter gradients within 1e-4 (relative L2) of float64 autograd."""
+    from nextbestpath_amd.networks.nbp_model import NBP
+    x, coords, gains, gt2, sd = _inputs(64, nbp_weights)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    sd64 = {k: (v.double().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k and "num_batches" not in k
+                else v.clone()) for k, v in sd.items()}
+    o1, o2, rec = _recorded_forward_fp64(sd64, x.double())
+    pred = o1[coords[:, 0], coords[:, 1], coords[:, 2], coords[:, 3]]
+    nbp_net.nbp_loss(sd64["log_vars"], pred, gains.double(), o2, gt2.double()).backward()
+    net = NBP()
+    net.load_state_dict(sd)
+    net = net.to(D).train()
+    tr.TEACHER = {k: v.detach().permute(0, 2, 3, 1).contiguous().float().to(D) for k, v in rec.items()}
+    try:
+        h1, h2 = net(x.to(D))
+        predh = tr.gather_values(h1, coords[:, 0].to(D), coords[:, 1:].to(D))
+        net.loss(predh, gains.to(D), h2, gt2.to(D)).backward()
+    finally:
+        tr.TEACHER = None
+    norms = {n: float(sd64[n].grad.norm()) for n, _ in net.named_parameters()}
+    big = max(norms.values())
+    worst, checked = [], 0
+    for name, p in net.named_parameters():
+        g64 = sd64[name].grad
+        if norms[name] < 1e-9 * big:
+            continue                    # conv biases in front of a train-mode BatchNorm: the true gradient is zero
+        rel = float((p.grad.cpu().double() - g64).norm()) / norms[name]
+        checked += 1
+        if rel > 1e-4:
+            worst.append((name, rel, norms[name]))
+    assert checked >= 200 and not worst, (checked, sorted(worst, key=lambda t: -t[1])[:10])
