@@ -634,7 +634,8 @@ def test_composed_backward_at_the_oracle_point(hip, nbp_weights):
     (networks/training.py::TEACHER): every intermediate is overwritten by a float64 evaluation's value (rounded to fp32) as soon
     as it is computed, so the saved tensors -- masks, pooling arg-maxes, the inputs of the batch statistics -- are the exact
     ones, and the backward is the HIP kernels' arithmetic (data gradients, weight gradients, BatchNorm backward, gates, pooling,
-    loss) composed over all 48 layers at THAT point: all 327 parameter gradients within 1e-4 (relative L2) of float64 autograd."""
+    loss) composed over all 48 layers at THAT point: every parameter gradient (of the 327 state entries: the ~143 parameter tensors
+    whose true gradient is not identically zero) within 1e-4 (relative L2) of float64 autograd."""
     from nextbestpath_amd.networks.nbp_model import NBP
     x, coords, gains, gt2, sd = _inputs(64, nbp_weights)
     torch.set_num_threads(min(32, os.cpu_count() or 8))
@@ -664,4 +665,5 @@ def test_composed_backward_at_the_oracle_point(hip, nbp_weights):
         checked += 1
         if rel > 1e-4:
             worst.append((name, rel, norms[name]))
-    assert checked >= 200 and not worst, (checked, sorted(worst, key=lambda t: -t[1])[:10])
+    # (the ~45 skipped tensors are the conv biases in front of a train-mode BatchNorm, whose true gradient is zero)
+    assert checked >= 140 and not worst, (checked, sorted(worst, key=lambda t: -t[1])[:10])
