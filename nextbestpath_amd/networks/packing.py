@@ -139,9 +139,9 @@ def forward_packed(packed: PackedWeights, x: torch.Tensor, precision: str = None
     x = x.contiguous().float()
     out1 = torch.empty(B, 8, S // 4, S // 4, dtype=torch.float32, device=x.device)
     out2 = torch.empty(B, 1, S, S, dtype=torch.float32, device=x.device)
-    ws = _workspace(B, S, x.device, precision)
     fn = getattr(_lib.lib(), _FWD[precision][0])
     if torch.cuda.current_device() == x.device.index:       # the common case: no device-guard objects in the step loop
+        ws = _workspace(B, S, x.device, precision)          # (keyed by the current stream: looked up under the right device)
         rc = fn(packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(), ws.data_ptr(), ws.numel(),
                 _lib.current_stream())
     else:

@@ -58,9 +58,12 @@ def _cam_arg(cams):
 
 def unproject_append(depth, mask, cams, cloud, cloud_count, gathering_factor=0.05, fov_range=70.0, seed=0,
                      tan_half_fov=TAN_HALF_FOV, rgb=None, cloud_rgb=None, shade=None):
-    """depth [F,H,W] fp32, mask [F,H,W] uint8|None, cams host [F,12]; appends to cloud [cap,3] at the
-    device counter cloud_count (int64[1]).  Returns counts [F,2] int32 (device)."""
+    """depth [F,H,W] fp32 (F <= 8), mask [F,H,W] uint8|None, cams host [F,12]; appends to cloud [cap,3] at the
+    device counter cloud_count (int64[1]).  Returns counts [F,2] int32 (device): a VIEW into this stream's scratch, valid
+    until the next unproject_append on the same stream -- clone it to keep it."""
     F_, H, W = depth.shape
+    if F_ > 8:
+        raise ValueError("unproject_append: at most 8 frames per call")
     L = _lib.lib()
     keep, cam_ptr, _ = _cam_arg(cams)
     ws = _workspace_for("unproject", (F_, H, W), lambda: L.nbp_unproject_workspace_bytes(F_, H, W) + 256, depth.device)
