@@ -544,6 +544,20 @@ int nbp_bn_train_backward_f32(const float* dy, const float* x, const float* y_or
                               const float* mean, const float* invstd, const float* gamma, int relu,
                               float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                               void* stream);
+/* The same two with their consumers' passes folded in (C % 4 == 0; nbp_bn_backward_fuses(C) tells): the forward also writes
+ * max |y| into amax_out (64 zeroed words, float bits by atomicMax: the operand scale of the split convolution that reads y); the
+ * backward also writes dx_colsum[c] = sum_m dx[m][c] (the bias gradient of the convolution in front of this BatchNorm) and
+ * max |dx| into amax_out (the scale of that convolution's data / weight gradients) -- in the pass that writes dx, instead of
+ * two more reads of it.  NULL outputs are skipped. */
+int nbp_bn_train_forward_amax_f32(const float* x, long long M, int C, const float* gamma, const float* beta,
+                                  float eps, float momentum, float* running_mean, float* running_var,
+                                  int relu, float* mean, float* invstd, float* y, void* amax_out, void* ws,
+                                  size_t ws_bytes, void* stream);
+int nbp_bn_backward_fuses(int C);
+int nbp_bn_train_backward_fused_f32(const float* dy, const float* x, const float* y_or_null, long long M, int C,
+                                    const float* mean, const float* invstd, const float* gamma, int relu,
+                                    float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* amax_out,
+                                    void* ws, size_t ws_bytes, void* stream);
 /* out[c] = sum_m rows[m]*x[m][c] (rows NULL = 1): conv bias gradients, psi weight gradient. */
 int nbp_colsum_f32(const float* x, const float* rows_or_null, long long M, int C, float* out, void* ws,
                    size_t ws_bytes, void* stream);

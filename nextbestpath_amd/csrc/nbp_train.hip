@@ -221,14 +221,22 @@ __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __r
     }
 }
 
+// max |.| of a tensor for the split convolutions' operand scale (nbp_split.hip): float bits, atomicMax spread over 64 words
+__device__ __forceinline__ void train_wave_amax(float mx, unsigned* out) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u), __float_as_uint(mx));
+}
+
 __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict__ x, long long total4, int C4,
                                                         const double* __restrict__ stat_d,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        int relu, float* __restrict__ y) {
+                                                        int relu, float* __restrict__ y, unsigned* __restrict__ amax_out) {
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
     f32x4* y4 = reinterpret_cast<f32x4*>(y);
     const f64x4* mu4 = reinterpret_cast<const f64x4*>(stat_d);
     const f64x4* is4 = reinterpret_cast<const f64x4*>(stat_d + 4 * (size_t)C4);
+    float mx = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
         const f64x4 g = to_d4(reinterpret_cast<const f32x4*>(gamma)[c]), bt = to_d4(reinterpret_cast<const f32x4*>(beta)[c]);
@@ -239,7 +247,9 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict_
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         y4[i] = v;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
+    if (amax_out) train_wave_amax(mx, amax_out);
 }
 
 __global__ __launch_bounds__(256) void bn_backward_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -270,6 +280,65 @@ __global__ __launch_bounds__(256) void bn_backward_apply4_kernel(const float* __
         const f64x4 r = g * is * (to_d4(dz) - invM * (db4[c] + xhat * dg4[c]));
         dx4[i] = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
     }
+}
+
+// The same with the consumers' passes folded in: the convolution in front of this BatchNorm needs sum_m dx[m][c] (its bias
+// gradient) and max |dx| (the split scheme's scale of its data / weight gradients) -- two more reads of dx as separate kernels.
+// Thread layout of colreduce4_kernel (a thread owns one float4 column and the rows rsub + k rpb of its block), the column
+// sums of the ROUNDED dx in double, per-block partials [block][2][C] for colsum_finalize_kernel.
+__global__ __launch_bounds__(256) void bn_backward_apply4_sum_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                     const float* __restrict__ y, long long M, int C4,
+                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                     const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                                     int relu, long long rows_per_block, float* __restrict__ dx,
+                                                                     double* __restrict__ part, unsigned* __restrict__ amax_out) {
+    const int CT = C4 < 256 ? C4 : 256;
+    const int rpb = 256 / CT;
+    const int c_local = threadIdx.x % CT, rsub = threadIdx.x / CT;
+    __shared__ f64x4 sh0[256];
+    const double invM = 1.0 / (double)M;
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+    f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
+    const f64x4* db4 = reinterpret_cast<const f64x4*>(sums);
+    const f64x4* dg4 = reinterpret_cast<const f64x4*>(sums + 4 * (size_t)C4);
+    const long long r_begin = (long long)blockIdx.x * rows_per_block;
+    const long long r_end = r_begin + rows_per_block < M ? r_begin + rows_per_block : M;
+    float mx = 0.f;
+    for (int c0 = 0; c0 < C4; c0 += CT) {
+        const int c = c0 + c_local;
+        f64x4 s0 = {0.0, 0.0, 0.0, 0.0};
+        if (rsub < rpb && c < C4) {
+            const f64x4 mu = to_d4(reinterpret_cast<const f32x4*>(mean)[c]), is = to_d4(reinterpret_cast<const f32x4*>(invstd)[c]);
+            const f64x4 g = to_d4(reinterpret_cast<const f32x4*>(gamma)[c]);
+            const f64x4 kb = db4[c], kg = dg4[c];
+            for (long long r = r_begin + rsub; r < r_end; r += rpb) {
+                const long long i = r * C4 + c;
+                f32x4 dz = dy4[i];
+                if (relu) {
+                    const f32x4 yy = y4[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
+                }
+                const f64x4 xhat = (to_d4(x4[i]) - mu) * is;
+                const f64x4 rr = g * is * (to_d4(dz) - invM * (kb + xhat * kg));
+                const f32x4 o = f32x4{(float)rr[0], (float)rr[1], (float)rr[2], (float)rr[3]};
+                dx4[i] = o;
+                s0 += to_d4(o);
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+            }
+        }
+        sh0[threadIdx.x] = s0;
+        __syncthreads();
+        if (rsub == 0 && c < C4) {
+            for (int k = 1; k < rpb; ++k) s0 += sh0[k * CT + c_local];
+            reinterpret_cast<f64x4*>(part + ((long long)blockIdx.x * 2 + 0) * C4 * 4)[c] = s0;
+            reinterpret_cast<f64x4*>(part + ((long long)blockIdx.x * 2 + 1) * C4 * 4)[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+        }
+        __syncthreads();
+    }
+    if (amax_out) train_wave_amax(mx, amax_out);
 }
 
 // ------------------------------------------------------------------ small elementwise pieces
@@ -837,10 +906,12 @@ extern "C" size_t nbp_colreduce_workspace_bytes(long long M, int C) {
     return (size_t)nblk * 2 * C * sizeof(double) + (size_t)2 * C * sizeof(double) + 512;
 }
 
-extern "C" int nbp_bn_train_forward_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
-                                        float momentum, float* running_mean, float* running_var, int relu, float* mean,
-                                        float* invstd, float* y, void* ws, size_t ws_bytes, void* stream) {
+// amax_out (or null): 64 zeroed words that receive max |y| (float bits; only for C % 4 == 0, else left untouched)
+extern "C" int nbp_bn_train_forward_amax_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
+                                             float momentum, float* running_mean, float* running_var, int relu, float* mean,
+                                             float* invstd, float* y, void* amax_out_v, void* ws, size_t ws_bytes, void* stream) {
     NBP_ENTER();
+    unsigned* amax_out = (unsigned*)amax_out_v;
     NBP_RETURN_IF(!x || !gamma || !beta || !mean || !invstd || !y || !ws || M < 1 || C < 1, NBP_E_ARG);
     NBP_RETURN_IF(ws_bytes < nbp_colreduce_workspace_bytes(M, C), NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;
@@ -855,15 +926,34 @@ extern "C" int nbp_bn_train_forward_f32(const float* x, long long M, int C, cons
     bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(x, part, nblk, C, M, eps, momentum, mean, invstd, running_mean,
                                                                   running_var, stat_d);
     if ((rc = nbp_launch_status())) return rc;
-    if (C % 4 == 0) bn_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(x, M * C / 4, C / 4, stat_d, gamma, beta, relu, y);
+    if (C % 4 == 0) bn_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(x, M * C / 4, C / 4, stat_d, gamma, beta, relu, y, amax_out);
     else bn_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(x, M * C, C, stat_d, gamma, beta, relu, y);
     return nbp_launch_status();
+}
+
+extern "C" int nbp_bn_train_forward_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
+                                        float momentum, float* running_mean, float* running_var, int relu, float* mean,
+                                        float* invstd, float* y, void* ws, size_t ws_bytes, void* stream) {
+    return nbp_bn_train_forward_amax_f32(x, M, C, gamma, beta, eps, momentum, running_mean, running_var, relu, mean, invstd, y, nullptr,
+                                         ws, ws_bytes, stream);
 }
 
 extern "C" int nbp_bn_train_backward_f32(const float* dy, const float* x, const float* y_or_null, long long M, int C,
                                          const float* mean, const float* invstd, const float* gamma, int relu, float* dx,
                                          float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    return nbp_bn_train_backward_fused_f32(dy, x, y_or_null, M, C, mean, invstd, gamma, relu, dx, dgamma, dbeta, nullptr, nullptr, ws,
+                                           ws_bytes, stream);
+}
+
+// dx_colsum (or null; C floats) receives sum_m dx[m][c], amax_out (or null; 64 zeroed words) max |dx| -- both only for
+// C % 4 == 0 (the caller checks nbp_bn_backward_fuses(C)); folded into the pass that writes dx.
+extern "C" int nbp_bn_backward_fuses(int C) { return C % 4 == 0; }
+extern "C" int nbp_bn_train_backward_fused_f32(const float* dy, const float* x, const float* y_or_null, long long M, int C,
+                                               const float* mean, const float* invstd, const float* gamma, int relu, float* dx,
+                                               float* dgamma, float* dbeta, float* dx_colsum, void* amax_out_v, void* ws,
+                                               size_t ws_bytes, void* stream) {
     NBP_ENTER();
+    unsigned* amax_out = (unsigned*)amax_out_v;
     NBP_RETURN_IF(!dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !ws || M < 1 || C < 1, NBP_E_ARG);
     NBP_RETURN_IF(relu && !y_or_null, NBP_E_ARG);
     NBP_RETURN_IF(ws_bytes < nbp_colreduce_workspace_bytes(M, C), NBP_E_WS);
@@ -878,6 +968,17 @@ extern "C" int nbp_bn_train_backward_f32(const float* dy, const float* x, const 
     double* sums = part + (((size_t)nblk * 2 * C + 31) / 32 * 32);          // [2][C] unrounded dbeta, dgamma (32-B aligned)
     colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, dbeta, dgamma, sums);
     if ((rc = nbp_launch_status())) return rc;
+    if (C % 4 == 0 && (dx_colsum || amax_out)) {
+        // dx, its column sums and its max |.| in ONE pass (the partials reuse `part`: the finalizer above has consumed it)
+        bn_backward_apply4_sum_kernel<<<nblk, 256, 0, st>>>(dy, x, y_or_null, M, C / 4, mean, invstd, gamma, sums, relu, rpb, dx, part,
+                                                            amax_out);
+        if ((rc = nbp_launch_status())) return rc;
+        if (dx_colsum) {
+            colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, dx_colsum, nullptr);
+            rc = nbp_launch_status();
+        }
+        return rc;
+    }
     if (C % 4 == 0)
         bn_backward_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(dy, x, y_or_null, M * C / 4, C / 4, M, mean, invstd,
                                                                               gamma, sums, relu, dx);

@@ -115,13 +115,52 @@ def _const(value, n, device):
     return t
 
 
+# ---- hand-off of what a producer already knows about its output to the convolution that consumes it (keyed by storage address,
+# valid within one forward / backward pass; NBP_TRAIN_FUSE=0 switches the hand-off off: every consumer takes its own pass)
+_FUSE = os.environ.get("NBP_TRAIN_FUSE", "1") == "1"
+_Y_AMAX = {}          # forward: y.data_ptr() -> 64-word max-|y| slot written by the BatchNorm apply pass
+_DX_INFO = {}         # backward: dx.data_ptr() -> (max-|dx| slot, column sums of dx) written by the BatchNorm backward apply pass
+_ARENA = {}
+
+
+def _fresh_slots(device, n=1):
+    """n zeroed 64-word slots out of a per-device arena that is cleared ONCE per training forward (forward_train) instead of a
+    torch.zeros per slot; falls back to an allocation when the arena is used up."""
+    a = _ARENA.get(device)
+    if a is None or a["next"] + n > a["cap"]:
+        return torch.zeros(n * 64, dtype=torch.int32, device=device)
+    k = a["next"]
+    a["next"] += n
+    return a["buf"][k * 64:(k + n) * 64]
+
+
+def _reset_arena(device, cap=1024):
+    a = _ARENA.get(device)
+    if a is None:
+        a = _ARENA[device] = {"buf": torch.zeros(cap * 64, dtype=torch.int32, device=device), "cap": cap, "next": 0}
+    else:
+        a["buf"].zero_()
+        a["next"] = 0
+    _Y_AMAX.clear()
+    _DX_INFO.clear()
+
+
 def _amax_slot(*tensors):
     """64-word max-|.| slot (csrc/nbp_split.hip) over the given tensors: one streaming pass each, shared by every kernel that
     scales them (forward + weight gradient for a layer's inputs; data + weight gradient for its output gradient)."""
-    slot = torch.zeros(64, dtype=torch.int32, device=tensors[0].device)
-    for t in tensors:
-        if t is not None and t.numel():
-            _chk(_lib.lib().nbp_amax_f32(_lib.ptr(t), t.numel(), _lib.ptr(slot), _st()), "amax")
+    live = [t for t in tensors if t is not None and t.numel()]
+    if _FUSE and len(live) == 1:
+        known = _Y_AMAX.get(live[0].data_ptr())
+        if known is not None:
+            return known                       # the producer (BatchNorm apply) measured it while writing the tensor
+    slot = _fresh_slots(tensors[0].device)
+    for t in live:
+        known = _Y_AMAX.get(t.data_ptr()) if _FUSE else None
+        if known is not None and len(live) > 1:
+            # two sources share one slot: fold the known maximum in (element-wise max of the 64 words, non-negative float bits)
+            torch.maximum(slot, known, out=slot)
+            continue
+        _chk(_lib.lib().nbp_amax_f32(_lib.ptr(t), t.numel(), _lib.ptr(slot), _st()), "amax")
     return slot
 
 
@@ -204,16 +243,23 @@ class ConvFn(torch.autograd.Function):
         N, c_real, k, C0, C1, Np, ups, has1 = ctx.meta
         x1 = x1 if has1 else None
         dev = dy.device
-        dy = _pad_channels(dy.contiguous(), Np)
+        dy = dy.contiguous()
+        info = _DX_INFO.pop(dy.data_ptr(), None) if _FUSE else None
+        if info is not None and tuple(info[2]) != tuple(dy.shape):
+            info = None                                    # (an address reused by another tensor)
+        dy = _pad_channels(dy, Np)
         B, H, W, _ = dy.shape
         M = B * H * W
-        db = _colsum(dy.view(M, Np))[:N].clone()
+        # the bias gradient: the BatchNorm behind this convolution summed dx's columns while writing it
+        db = info[1][:N].clone() if info is not None else _colsum(dy.view(M, Np))[:N].clone()
         dw = torch.empty(N, c_real, k, k, dtype=torch.float32, device=dev)
         ws = _ws(L.nbp_conv_wgrad_workspace_bytes(B, H, W, C0, C1, Np, k), dev)
         # the 3x3 weight gradients take the split scheme too (the entry point falls through to the fp32 pipe for the rest)
         dymax = None
         if _SPLIT and _WGRAD_SPLIT:
-            dymax = _amax_slot(dy) if k == 3 else None        # shared with the data gradient below
+            # max |dy|: shared with the data gradient below; measured by the BatchNorm backward when dy came from one (padding
+            # channels are zeros: same maximum)
+            dymax = (info[0] if info is not None else _amax_slot(dy)) if k == 3 else None
             _chk(L.nbp_conv_wgrad_split_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, int(ups), B, H, W, k, _lib.ptr(dy), Np, c_real, N,
                                             _lib.ptr(dw), _lib.ptr(ctx.xmax), _lib.ptr(ctx.xmax), _lib.ptr(dymax), _lib.ptr(ws),
                                             ws.numel(), _st()), "conv_wgrad_split")
@@ -259,9 +305,12 @@ class BNFn(torch.autograd.Function):
         y = torch.empty_like(x)
         ws = _ws(L.nbp_colreduce_workspace_bytes(M, C), dev)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        _chk(L.nbp_bn_train_forward_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
-                                        _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
-                                        _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(ws), ws.numel(), _st()), "bn_fwd")
+        slot = _fresh_slots(dev) if _FUSE and C % 4 == 0 else None
+        _chk(L.nbp_bn_train_forward_amax_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
+                                             _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
+                                             _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(slot), _lib.ptr(ws), ws.numel(), _st()), "bn_fwd")
+        if slot is not None:
+            _Y_AMAX[y.data_ptr()] = slot
         ctx.save_for_backward(x, y, mean, invstd, g)
         ctx.relu = bool(relu)
         return y
@@ -278,9 +327,14 @@ class BNFn(torch.autograd.Function):
         dg = torch.empty(C, dtype=torch.float32, device=dev)
         db = torch.empty(C, dtype=torch.float32, device=dev)
         ws = _ws(L.nbp_colreduce_workspace_bytes(M, C), dev)
-        _chk(L.nbp_bn_train_backward_f32(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), M, C, _lib.ptr(mean), _lib.ptr(invstd),
-                                         _lib.ptr(g), int(ctx.relu), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(ws),
-                                         ws.numel(), _st()), "bn_bwd")
+        fuse = _FUSE and C % 4 == 0
+        slot = _fresh_slots(dev) if fuse else None
+        csum = torch.empty(C, dtype=torch.float32, device=dev) if fuse else None
+        _chk(L.nbp_bn_train_backward_fused_f32(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), M, C, _lib.ptr(mean), _lib.ptr(invstd),
+                                               _lib.ptr(g), int(ctx.relu), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(csum),
+                                               _lib.ptr(slot), _lib.ptr(ws), ws.numel(), _st()), "bn_bwd")
+        if fuse:
+            _DX_INFO[dx.data_ptr()] = (slot, csum, dx.shape)
         return dx, dg, db, None, None, None, None, None
 
 
@@ -292,6 +346,9 @@ class MaxPoolFn(torch.autograd.Function):
         y = torch.empty(B, H // 2, W // 2, C, dtype=torch.float32, device=x.device)
         _chk(_lib.lib().nbp_maxpool2_nhwc_f32(_lib.ptr(x), B, H, W, C, _lib.ptr(y), _st()), "maxpool")
         ctx.save_for_backward(x)
+        known = _Y_AMAX.get(x.data_ptr()) if _FUSE else None
+        if known is not None:
+            _Y_AMAX[y.data_ptr()] = known          # a max-pool keeps the maximum
         return y
 
     @staticmethod
@@ -513,6 +570,7 @@ def forward_train(net, x):
     L = _lib.lib()
     B, _, S, _ = x.shape
     dev = x.device
+    _reset_arena(dev)
     xh = torch.empty(B, S, S, 5, dtype=torch.float32, device=dev)
     _chk(L.nbp_nchw_to_nhwc_f32(_lib.ptr(x.contiguous().float()), B, 5, S, S, _lib.ptr(xh), _st()), "to_nhwc")
     x0 = _pad_channels(xh, 64)
