@@ -8,12 +8,12 @@ REPO=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # the bench's own live PMC passes and extra stages are switched off here: rocprofv3 does not nest
-BENCH="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic --no-extra-stages"
+BENCH="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic --no-extra-stages --no-strong"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/stats" -o trace -- $BENCH > "$REPO/$OUT/bench_under_rocprof.json" 2> "$REPO/$OUT/stats.err"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --pmc $pass --output-format csv -d "$REPO/$OUT/pmc_$name" -o pmc -- python $REPO/bench.py --steps 6 --warmup 2 --advance 10 --no-cpu-baseline --no-live-traffic --no-extra-stages > "$REPO/$OUT/pmc_$name.json" 2> "$REPO/$OUT/pmc_$name.err"
+  rocprofv3 --pmc $pass --output-format csv -d "$REPO/$OUT/pmc_$name" -o pmc -- python $REPO/bench.py --steps 6 --warmup 2 --advance 10 --no-cpu-baseline --no-live-traffic --no-extra-stages --no-strong > "$REPO/$OUT/pmc_$name.json" 2> "$REPO/$OUT/pmc_$name.err"
 done
 # the roofline workload alone (tools/pmc_workload.py: 12 maps of 256x256 (one pipeline group of the default 24 rollouts per GPU) through the forward + the map accumulation;
 # 8 of 512x512 through the bf16 forward; fwd_split = the default fp32_split path, fwd_f32 = the fp32 MFMA pipe): every launch of a kernel in these runs belongs to the same forward, so the
