@@ -447,7 +447,9 @@ def main():
                     # tools/probes/mfma_f16_probe.hip, profiles/r02/mfma_f16_probe.txt): 2444 with all-ones operands
                     "frac_of_sustained_mfma_stream": (round(achieved * 3 / 1709.0, 4) if dom in SPLIT_TILES else None),
                     "traffic": None if traffic is None else round(traffic),
-                    "traffic_unit": "HBM-side bytes per launch: 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide)",
+                    "traffic_unit": "HBM-side bytes per launch: 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide; calibrated on "
+                                    "known byte counts, profiles/r03/fetch_calibration.txt: bytes / FETCH_SIZE = 2.000 for 4-B, "
+                                    "12-B-strided and 16-B loads per lane, bytes / WRITE_SIZE = 1.000 for 4-B and 16-B stores)",
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(alg_bytes / d["launches"]),
                     "launches_per_forward": d["launches"],
@@ -500,7 +502,10 @@ def main():
                    "traffic": None if sc_traffic is None else round(sc_traffic), "traffic_source": sc_src,
                    "points": n_pts, "algorithmic_bytes": alg, "ms": round(ms_sc, 4),
                    "note": "ms includes the 1.5 MB clear of the six channels; at this size the launch floor (~3 us) is "
-                           "already 2x the HBM time of the bytes"}
+                           "already 2x the HBM time of the bytes.  traffic (same 2*FETCH_SIZE + WRITE_SIZE, calibrated for this "
+                           "kernel's 12-B-strided loads: factor 2.000) exceeds the algorithmic bytes by the flush: one device-scope "
+                           "float atomic per distinct (channel, cell) key and workgroup resolves at the memory side as a "
+                           "line-granular read-modify-write"}
         # the same kernel on a full-length cloud (3 M points, the end of a 101-step trajectory)
         big = ro.st.cloud[:n_pts].repeat((3_000_000 + n_pts - 1) // max(n_pts, 1), 1)[:3_000_000].contiguous()
         maps_big = torch.empty_like(ro.st.maps6)
