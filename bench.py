@@ -232,7 +232,8 @@ def main():
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()
 
-    def make_rollout(k, hard=(args.faces == "hard"), scene_seed=None, name=None):
+    def make_rollout(k, hard=(args.faces == "hard"), scene_seed=None, name=None, fixed_seed=None):
+        """fixed_seed: every seed of the rollout independent of the rank (the strong-scaling set is the same 40 runs at any N)"""
         name = name or f"maze{k}"
         scene_seed = 100 + 16 * rank + k if scene_seed is None else scene_seed
         if hard:
@@ -243,9 +244,10 @@ def main():
         settings = sc.Settings(ds[0]["settings"], params.scene_scale_factor)
         mesh = sc.load_scene(os.path.join(tmp, name, ds[0]["obj_name"]), params.scene_scale_factor, dev)
         y_bins = sc.y_bins_for(mesh.verts_host, 4)
-        _, gt = sc.setup_gt_scene(params, settings, mesh, dev, 0.05, seed=rank)
-        cam = tp.setup_test_camera(params, mesh, settings.camera.start_positions[0], settings, dev, seed=rank)
-        return tp.Rollout(params, net, cam, gt, mesh, mesh, y_bins, dev, seed=8 + 16 * rank + k)
+        s0 = rank if fixed_seed is None else fixed_seed
+        _, gt = sc.setup_gt_scene(params, settings, mesh, dev, 0.05, seed=s0)
+        cam = tp.setup_test_camera(params, mesh, settings.camera.start_positions[0], settings, dev, seed=s0)
+        return tp.Rollout(params, net, cam, gt, mesh, mesh, y_bins, dev, seed=(8 + 16 * rank + k) if fixed_seed is None else 8 + fixed_seed)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -343,7 +345,7 @@ def main():
     if not args.no_strong:
         n_scenes = args.strong_scenes
         mine_ids = list(range(rank, n_scenes, world))
-        s_rollouts = [make_rollout(i, hard=True, scene_seed=5000 + i, name=f"hard{i}") for i in mine_ids]
+        s_rollouts = [make_rollout(i, hard=True, scene_seed=5000 + i, name=f"hard{i}", fixed_seed=100 + i) for i in mine_ids]
         faces_mine = [int(r.mesh.faces.shape[0]) for r in s_rollouts]
         s_multi = tp.MultiRollout(s_rollouts, net, dev) if s_rollouts else None
 
