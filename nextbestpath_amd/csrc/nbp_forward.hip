@@ -495,21 +495,39 @@ struct PathSplit : PathF32 {
         return nbp_psi_gate_f32(q, F, w, s2, x, Cn, M, out, st);
     }
 };
+// bf16 path: the max-pool / sigmoid-head offers of the driver, taken by the 64-channel kernel's epilogue (nbp_bf16.hip)
+struct Bf16Ctx : NoCtx {
+    bf16_t* pool = nullptr;
+    bool pool_taken = false;
+    void offer_pool(void* p) { pool = (bf16_t*)p; pool_taken = false; }
+    bool took_pool() { const bool t = pool_taken; pool = nullptr; pool_taken = false; return t; }
+    ConvHead head = {nullptr, nullptr, nullptr, nullptr};
+    bool head_taken = false;
+    void offer_head(const float* w, const float* sc, const float* sh, float* out) { head = ConvHead{w, sc, sh, out}; head_taken = false; }
+    bool took_head() { const bool t = head_taken; head = ConvHead{nullptr, nullptr, nullptr, nullptr}; head_taken = false; return t; }
+};
 struct PathBF16 {
     typedef bf16_t T;
     typedef ConvOperandsH Ops;
-    typedef NoCtx Ctx;
+    typedef Bf16Ctx Ctx;
     static constexpr int CHUNK = 64;
     static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0, int ups = 0) {
         return nbp_plan_conv_bf16(M, N, chunks, 0, 0, groups, H, H, ksize, ups);
     }
     static constexpr int MODE = 1;
-    static int conv(Ctx&, const nbp_weights* h, const int* li, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H,
+    static int conv(Ctx& ctx, const nbp_weights* h, const int* li, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B, int H,
                     int ks, int N, void* ws, size_t wsb, hipStream_t st) {
         Ops a = o, b = o2 ? *o2 : o;
         a.wpk_up = (const bf16_t*)h->wup16[li[0]];
         if (o2) b.wpk_up = (const bf16_t*)h->wup16[li[1]];
-        return nbp_conv_igemm_bf16_launch_g(a, o2 ? &b : nullptr, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st);
+        bf16_t* pools[2] = {ctx.pool, nullptr};
+        int pooled = 0, headed = 0;
+        const int rc = nbp_conv_igemm_bf16_launch_g(a, o2 ? &b : nullptr, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st,
+                                                    (ctx.pool && !o2) ? pools : nullptr, &pooled,
+                                                    (ctx.head.out && !o2) ? &ctx.head : nullptr, &headed);
+        if (pooled) ctx.pool_taken = true;
+        if (headed) ctx.head_taken = true;
+        return rc;
     }
     static int first(Ctx&, const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {
         return nbp_conv_first_bf16_launch(x, B, s, s, (const float*)h->w[0], h->scale[0], h->shift[0], out, st);

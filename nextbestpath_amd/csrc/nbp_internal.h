@@ -9,7 +9,8 @@ enum { NBP_TILE_AUTO = 0, NBP_TILE_128x128 = 1, NBP_TILE_256x64 = 2, NBP_TILE_25
        NBP_TILE_HALO_128 = 6, NBP_TILE_HALO_64 = 7,
        NBP_TILE_HALO4_128 = 8, NBP_TILE_HALO4_64 = 9,
        NBP_TILE_SPLIT_HALO_64 = 10, NBP_TILE_SPLIT_UP = 11,
-       NBP_TILE_HALO_UP_128 = 12, NBP_TILE_HALO_UP_64 = 13 };   // bf16: up_conv as four parity convolutions   // nbp_split.hip: 16x32 / 16x16-pixel halo tiles on the fp16 matrix pipe   // fp32 only: 4x32-pixel tiles   // 8x32-pixel halo-tile kernels (3x3 only), BN = 128 / 64
+       NBP_TILE_HALO_UP_128 = 12, NBP_TILE_HALO_UP_64 = 13,
+       NBP_TILE_ROWS_64 = 14 };   // bf16: 16 x 32-pixel tiles x 64 channels, weights in registers (nbp_bf16.hip)     // bf16: up_conv as four parity convolutions   // nbp_split.hip: 16x32 / 16x16-pixel halo tiles on the fp16 matrix pipe   // fp32 only: 4x32-pixel tiles   // 8x32-pixel halo-tile kernels (3x3 only), BN = 128 / 64
 struct TileInfo { int bm, bn; };
 struct ConvPlan { int tile; int split_k; int chunks_per_split; };
 
@@ -98,9 +99,11 @@ struct ConvOperandsH { const bf16_t* src0; const bf16_t* src1; const bf16_t* wpk
 ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int split_k, int groups, int H = 0, int W = 0,
                             int ksize = 0, int ups = 0);
 int nbp_pack_upconv_weight_bf16_launch(const float* w_oihw, int N, int C, bf16_t* dst, hipStream_t st);
+// pool_out / head: as for nbp_conv_split_launch_g (taken only by the NBP_TILE_ROWS_64 kernel; *pooled / *headed tell)
 int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2, int C0, int C1, int ups, int B, int H,
                                  int W, int ksize, int N, int relu, int split_k, int tile, void* ws, size_t ws_bytes,
-                                 hipStream_t st);
+                                 hipStream_t st, bf16_t* const* pool_out = nullptr, int* pooled = nullptr,
+                                 const struct ConvHead* head = nullptr, int* headed = nullptr);
 int nbp_conv_first_bf16_launch(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale,
                                const float* shift, bf16_t* out_nhwc, hipStream_t st);
 int nbp_maxpool2_bf16_launch(const bf16_t* in, int B, int H, int W, int C, bf16_t* out, hipStream_t st);

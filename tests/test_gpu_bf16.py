@@ -49,6 +49,11 @@ CASES = [
     (3, 24, 96, 64, 0, 64, 3, 0, 1, 7),      # halo, 3 x 3 tiles per image: interior tile has no padding at all
     (1, 8, 32, 512, 0, 128, 3, 0, 4, 6),     # halo + split-K over whole chunks (8 chunks / 4)
     (1, 16, 32, 192, 128, 64, 3, 0, 2, 7),   # halo + ragged split (5 chunks / 2) across the concat seam
+    (2, 16, 32, 64, 0, 64, 3, 0, 1, 14),     # weights-in-registers kernel: one tile per image, image borders on every side
+    (1, 48, 96, 64, 64, 64, 3, 0, 1, 14),    # ... 3 x 3 tiles (an interior tile without padding), fused concat
+    (1, 32, 64, 128, 0, 128, 3, 0, 1, 14),   # ... two channel blocks
+    (1, 8, 16, 64, 0, 64, 3, 1, 1, 14),      # ... fused x2 upsample (16 x 32 output)
+    (1, 16, 32, 192, 128, 64, 3, 0, 0, 14),  # ... 20 sixteen-channel chunks across the concat seam
 ]
 
 
@@ -144,6 +149,12 @@ def test_halo_kernel_shape_errors(hip):
     one = torch.ones(64, device=dev)
     with pytest.raises(_lib.NbpHipError):
         conv_igemm_bf16(x, None, 0, wpk, 64, 3, one, one, True, 1, 7)
+    x = torch.zeros(1, 24, 32, 64, device=dev, dtype=torch.bfloat16)     # the 16-row kernel: H % 16 != 0
+    with pytest.raises(_lib.NbpHipError):
+        conv_igemm_bf16(x, None, 0, wpk, 64, 3, one, one, True, 1, 14)
+    x = torch.zeros(1, 16, 32, 64, device=dev, dtype=torch.bfloat16)     # ... and it has no split-K form
+    with pytest.raises(_lib.NbpHipError):
+        conv_igemm_bf16(x, None, 0, wpk, 64, 3, one, one, True, 2, 14)
 
 
 def test_conversions(hip):
@@ -211,6 +222,47 @@ def test_forward_bf16_256_decisions(hip, net_bf16, nbp_weights):
     assert torch.equal(b1, c1) and torch.equal(b2, c2)
     # a different batch size may pick other tiles / split-K (another summation order): same tolerance as above
     assert (d1 - b1[1:2]).abs().max().item() / s1 < 2e-2 and (d2 - b2[1:2]).abs().max().item() < 2e-2
+
+
+_ROWS64_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from nextbestpath_amd.networks import packing
+from nextbestpath_amd.utility.synthetic import make_count_maps, make_explorer_state_dict
+dev = torch.device("cuda")
+packed = packing.pack_state_dict(make_explorer_state_dict(9), dev, precision="bf16")
+for B, S in ((2, 256), (1, 512)):
+    o1, o2 = packing.forward_packed(packed, make_count_maps(B, S, seed=B).to(dev))
+    torch.save((o1.cpu(), o2.cpu()), f"{sys.argv[2]}_{B}_{S}.pt")
+"""
+
+
+def test_epilogue_fusions_and_the_rows64_kernel_in_the_network(hip, tmp_path):
+    """The halo kernels carry the encoder's max-pools and the sigmoid head in their epilogue (NBP_BF16_FUSE = 0: the separate
+    kernels; read once per process, hence the subprocesses).  Pooling the same bf16 values: bit-identical.  The fused head sums
+    the same 64 products in another order (fp32).  NBP_BF16_ROWS64 = 1 gives the 64-channel layers to the weights-in-registers
+    kernel, which accumulates the taps of a chunk in another order: one-ulp flips of bf16 activations, the tolerance of the
+    network tests."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fwd.py"
+    script.write_text(_ROWS64_SCRIPT)
+    outs = {}
+    keys = ((2, 256), (1, 512))
+    for tag, env in (("fused", {}), ("nofuse", {"NBP_BF16_FUSE": "0"}), ("rows64", {"NBP_BF16_ROWS64": "1"})):
+        subprocess.run([sys.executable, str(script), root, str(tmp_path / tag)], check=True, env={**os.environ, **env}, timeout=600)
+        outs[tag] = {k: torch.load(tmp_path / f"{tag}_{k[0]}_{k[1]}.pt") for k in keys}
+    for k in keys:
+        o1, o2 = outs["fused"][k]
+        p1, p2 = outs["nofuse"][k]
+        assert torch.equal(o1, p1), k                                 # the value head never sees the fused head; the pools are exact
+        assert float((o2 - p2).abs().max()) <= 2e-6, k
+        q1, q2 = outs["rows64"][k]
+        s1 = max(float(q1.abs().max()), 1e-6)
+        assert float((o1 - q1).abs().max()) / s1 < 2e-2 and float((o2 - q2).abs().max()) < 2e-2, k
+        assert float((o1 - q1).abs().mean()) / s1 < 3e-3 and float((o2 - q2).abs().mean()) < 3e-3, k
 
 
 def test_bf16_handle_mismatch_is_an_error(hip, net_bf16):

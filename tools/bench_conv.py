@@ -103,7 +103,8 @@ def bf16(a):
         best = sorted((min(v), c) for c, v in res.items())
         txt = "  ".join(f"t{c[0]}/s{c[1]}:{t*1e3:.1f}" for t, c in best[:5]) if a.sweep else ""
         print(f"{name:8s} M={B*H*H:7d} N={N:4d} K={(C0+C1)*k*k:5d}  {first*1e3:8.1f} us  {fl/first/1e9:7.1f} TF  {txt}")
-    print(f"TOTAL {tot_t*1e3:.1f} us  {tot_f/tot_t/1e9:.2f} TF")
+    if tot_t:
+        print(f"TOTAL {tot_t*1e3:.1f} us  {tot_f/tot_t/1e9:.2f} TF")
 
 
 def main():
@@ -161,7 +162,8 @@ def main():
         fl = 2.0 * B * H * H * N * (C0 + C1) * k * k
         tot_t += ms; tot_f += fl
         print(f"{name:8s} M={B*H*H:6d} N={N:4d} K={(C0+C1)*k*k:5d}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.2f} TF")
-    print(f"TOTAL {tot_t*1e3:.1f} us  {tot_f/tot_t/1e9:.2f} TF")
+    if tot_t:
+        print(f"TOTAL {tot_t*1e3:.1f} us  {tot_f/tot_t/1e9:.2f} TF")
 
 
 if __name__ == "__main__":
