@@ -15,6 +15,8 @@ __device__ __forceinline__ void conv_first_mfma_body(const float* __restrict__ x
     constexpr int HW_ = 34, PLANE = 10 * HW_;            // 340 halo pixels per input channel
     __shared__ __attribute__((aligned(16))) float hal[5 * PLANE];
     __shared__ __attribute__((aligned(16))) float wl[46 * 64];   // [k][co], row 45 = 0
+    constexpr int TRB = 144;                             // bytes per pixel row of the epilogue's transpose image
+    __shared__ __attribute__((aligned(16))) char tr[4 * 64 * TRB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = W >> 5, tiles_y = H >> 3;
     const int n_tiles = B * tiles_y * tiles_x;
@@ -61,22 +63,38 @@ __device__ __forceinline__ void conv_first_mfma_body(const float* __restrict__ x
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, p1, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, p1, acc[1][1], 0, 0, 0);
     }
-    // D[n][m]: lane = pixel ln of row 2 wave + i; registers 4 rq .. 4 rq + 3 = channels j*32 + 8 rq + 4 kh + (0..3)
+    // D[n][m]: lane = pixel ln of row 2 wave + i; registers 4 rq .. 4 rq + 3 = channels j*32 + 8 rq + 4 kh + (0..3).
+    // A lane holds 16-byte (8-byte for bf16) pieces of one pixel, the 32 lanes of a half wave 32 different pixels: stored directly,
+    // every store instruction touches 32 lines with 32 (16) bytes each and the L2 takes one request per piece.  The wave transposes
+    // 128 bytes per pixel through LDS instead (fp32: the 32 channels of block j, two passes; bf16: all 64 channels; pixel rows
+    // padded to 144 bytes: conflict-free) and stores 16 bytes per lane, 8 lanes per pixel: whole 128-byte lines.
+    constexpr int PASSES = sizeof(OutT) == 4 ? 2 : 1;
+    char* const trw = tr + wave * (64 * TRB);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const long long m = ((long long)b * H + y0 + 2 * wave + i) * W + x0 + ln;
+    for (int pass = 0; pass < PASSES; ++pass) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int n = j * 32 + 8 * rq + 4 * kh;
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + n);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + n);
-                f32x4 v;
+            for (int j = 0; j < 2; ++j) {
+                if (PASSES == 2 && j != pass) continue;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = fmaxf(acc[i][j][4 * rq + e] * sc[e] + sh[e], 0.f); mx = fmaxf(mx, v[e]); }
-                store4(out + m * 64 + n, v);
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int n = j * 32 + 8 * rq + 4 * kh;
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + n);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + n);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = fmaxf(acc[i][j][4 * rq + e] * sc[e] + sh[e], 0.f); mx = fmaxf(mx, v[e]); }
+                    store4(reinterpret_cast<OutT*>(trw + (i * 32 + ln) * TRB) + (PASSES == 2 ? n - 32 * pass : n), v);
+                }
             }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 64 + lane, p = idx >> 3, slot = idx & 7;          // pixel p = row p / 32, column p % 32
+            const f32x4 v = *reinterpret_cast<const f32x4*>(trw + p * TRB + slot * 16);
+            const long long m = ((long long)b * H + y0 + 2 * wave + (p >> 5)) * W + x0 + (p & 31);
+            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(out + m * 64) + pass * 128 + slot * 16) = v;
+        }
     }
   }
     if (amax_out) {     // one atomic per wave, spread over the 64 words of the tensor's slot (nbp_split.hip)
