@@ -55,8 +55,9 @@ struct IgemmArgsH {
 };
 
 template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmArgsH a) {
+__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmArgsH a, GatePsiH ps) {
     int zs = blockIdx.z;
+    const int grp = zs >= a.split_k ? 1 : 0;
     if (zs >= a.split_k) {
         zs -= a.split_k;
         a.src0 = a.g_src0; a.src1 = a.g_src1; a.wpk = a.g_wpk; a.scale = a.g_scale; a.shift = a.g_shift; a.out = a.g_out;
@@ -178,6 +179,60 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmArgsH a) {
 
     // ---- epilogue.  D[n][m] of the 32x32 MFMA: col (pixel) = lane&31, row (channel) = (r&3)+8*(r>>2)+4*(lane>>5)
     const bool final_out = (a.split_k == 1);
+    if constexpr (WN == 1) {
+        if (ps.wpsi[0]) {
+            // attention gate tail (nbp_model.py:55-61): psi = sigmoid(BN(q . w_psi)), gated = x * psi, with q = this wave's BN = N
+            // columns of its TM x 32 pixels -- rounded to bf16 as the separate kernel would have read it; q itself is not written
+            const float* wp = ps.wpsi[grp];
+            float d[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) d[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int n = j * 32 + 8 * rq + 4 * khalf;
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + n);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = fmaf(acc[i][j][4 * rq + e], sc[e], sh[e]);
+                            if (a.relu) t = fmaxf(t, 0.f);
+                            d[i] = fmaf(bf2f(f2bf(t)), w4[e], d[i]);
+                        }
+                }
+            float* psil = reinterpret_cast<float*>(lds) + wave * (TM * 32);     // the stages are free: the loop ended on a barrier
+            const float s0 = ps.st[grp][0], t0 = ps.st[grp][1];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float dot = d[i] + __shfl_xor(d[i], 32);
+                if (!khalf) psil[i * 32 + (lane & 31)] = 1.f / (1.f + expf(-(dot * s0 + t0)));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the wave reads back only what it wrote itself
+            // gated = x * psi over the wave's TM x 32 pixels x C channels, 16 bytes per lane, consecutive lanes consecutive pieces;
+            // x = source 1, read a moment ago as the second half of K (L2 hits)
+            const int C8 = a.C1 >> 3;
+            const long long mw = m0 + (long long)wm * TM * 32;
+            const u16x8* x8 = reinterpret_cast<const u16x8*>(a.src1) + mw * C8;
+            u16x8* g8 = reinterpret_cast<u16x8*>(ps.gated[grp]) + mw * C8;
+            const long long lim = (a.M - mw) * C8;
+            const int total = TM * 32 * C8;
+#pragma unroll 4
+            for (int idx = lane; idx < total; idx += 64) {
+                if (idx >= lim) break;
+                const u16x8 v = x8[idx];
+                const float psi = psil[idx / C8];
+                u16x8 r;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = f2bf(bf2f(v[e]) * psi);
+                g8[idx] = r;
+            }
+            return;
+        }
+    }
     float* part = final_out ? nullptr : a.partial + (long long)blockIdx.z * a.M * a.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -846,7 +901,7 @@ static int launch_rows64(const IgemmArgsH& a, const RowsFuse& f, hipStream_t st)
 }
 
 template <int WM, int WN, int TM, int TN>
-static int launch_igemm_h(const IgemmArgsH& a, hipStream_t st) {
+static int launch_igemm_h(const IgemmArgsH& a, hipStream_t st, const GatePsiH& ps = GatePsiH{{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}}) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr size_t smem = 2 * (size_t)(BM + BN) * 128;
     static bool attr_set = false;
@@ -857,16 +912,18 @@ static int launch_igemm_h(const IgemmArgsH& a, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid((unsigned)nbp_cdiv(a.M, BM), (unsigned)(a.N / BN), (unsigned)(a.split_k * a.groups));
-    igemm_bf16_kernel<WM, WN, TM, TN><<<grid, 256, smem, st>>>(a);
+    igemm_bf16_kernel<WM, WN, TM, TN><<<grid, 256, smem, st>>>(a, ps);
     return nbp_launch_status();
 }
 
 int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2, int C0, int C1, int ups, int B, int H,
                                  int W, int ksize, int N, int relu, int split_k, int tile, void* ws, size_t ws_bytes,
-                                 hipStream_t st, bf16_t* const* pool_out, int* pooled, const ConvHead* head, int* headed) {
+                                 hipStream_t st, bf16_t* const* pool_out, int* pooled, const ConvHead* head, int* headed,
+                                 const GatePsiH* psi, int* psi_fused) {
     const int groups = o2 ? 2 : 1;
     if (pooled) *pooled = 0;
     if (headed) *headed = 0;
+    if (psi_fused) *psi_fused = 0;
     NBP_RETURN_IF(!o.src0 || !o.wpk || !o.scale || !o.shift || !o.out, NBP_E_ARG);
     NBP_RETURN_IF(o2 && (!o2->src0 || !o2->wpk || !o2->scale || !o2->shift || !o2->out), NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 1 || W < 1, NBP_E_ARG);
@@ -932,11 +989,22 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
             if (headed) *headed = 1;
         }
     }
+    // the attention gate's tail rides in the 1x1 GEMM over [g | x] when a wave holds all N columns of its pixels
+    GatePsiH gp{{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    {
+        static const int allow_psi = [] { const char* e = getenv("NBP_BF16_PSI"); return e ? atoi(e) : 1; }();
+        const bool whole_n = (p.tile == NBP_TILE_256x64 && N == 64) || (p.tile == NBP_TILE_256x32 && N == 32);
+        if (allow_psi && psi && whole_n && ksize == 1 && C1 == C0 && p.split_k == 1 && relu && psi->wpsi[0] && psi->st[0] && psi->gated[0] &&
+            (groups == 1 || (psi->wpsi[1] && psi->st[1] && psi->gated[1]))) {
+            gp = *psi;
+            if (psi_fused) *psi_fused = 1;
+        }
+    }
     int rc;
     switch (p.tile) {
         case NBP_TILE_128x128: rc = launch_igemm_h<2, 2, 2, 2>(a, st); break;
-        case NBP_TILE_256x64: rc = launch_igemm_h<4, 1, 2, 2>(a, st); break;
-        case NBP_TILE_256x32: rc = launch_igemm_h<4, 1, 2, 1>(a, st); break;
+        case NBP_TILE_256x64: rc = launch_igemm_h<4, 1, 2, 2>(a, st, gp); break;
+        case NBP_TILE_256x32: rc = launch_igemm_h<4, 1, 2, 1>(a, st, gp); break;
         case NBP_TILE_128x64: rc = launch_igemm_h<2, 2, 2, 1>(a, st); break;
         case NBP_TILE_64x128: rc = launch_igemm_h<1, 4, 2, 1>(a, st); break;
         case NBP_TILE_ROWS_64: {

@@ -497,6 +497,10 @@ struct PathSplit : PathF32 {
 };
 // bf16 path: the max-pool / sigmoid-head offers of the driver, taken by the 64-channel kernel's epilogue (nbp_bf16.hip)
 struct Bf16Ctx : NoCtx {
+    bf16_t* gated[2] = {nullptr, nullptr};
+    bool gated_taken = false;
+    void offer_gated(void* g0, void* g1) { gated[0] = (bf16_t*)g0; gated[1] = (bf16_t*)g1; gated_taken = false; }
+    bool took_gated() { const bool t = gated_taken; gated[0] = gated[1] = nullptr; gated_taken = false; return t; }
     bf16_t* pool = nullptr;
     bool pool_taken = false;
     void offer_pool(void* p) { pool = (bf16_t*)p; pool_taken = false; }
@@ -521,12 +525,20 @@ struct PathBF16 {
         a.wpk_up = (const bf16_t*)h->wup16[li[0]];
         if (o2) b.wpk_up = (const bf16_t*)h->wup16[li[1]];
         bf16_t* pools[2] = {ctx.pool, nullptr};
-        int pooled = 0, headed = 0;
+        int pooled = 0, headed = 0, psi_fused = 0;
+        GatePsiH psi{{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+        const bool gate = ks == 1 && C1 == C0 && ctx.gated[0] && (!o2 || ctx.gated[1]);
+        if (gate)
+            for (int g = 0; g < (o2 ? 2 : 1); ++g) {
+                const int l = li[g] + 2;                                      // the gate's psi layer follows W_g, W_x
+                psi.wpsi[g] = (const float*)h->w[l]; psi.st[g] = h->scale[l]; psi.gated[g] = ctx.gated[g];
+            }
         const int rc = nbp_conv_igemm_bf16_launch_g(a, o2 ? &b : nullptr, C0, C1, ups, B, H, H, ks, N, 1, 0, 0, ws, wsb, st,
                                                     (ctx.pool && !o2) ? pools : nullptr, &pooled,
-                                                    (ctx.head.out && !o2) ? &ctx.head : nullptr, &headed);
+                                                    (ctx.head.out && !o2) ? &ctx.head : nullptr, &headed, gate ? &psi : nullptr, &psi_fused);
         if (pooled) ctx.pool_taken = true;
         if (headed) ctx.head_taken = true;
+        if (psi_fused) ctx.gated_taken = true;
         return rc;
     }
     static int first(Ctx&, const float* x, int B, int s, const nbp_weights* h, T* out, hipStream_t st) {

@@ -99,11 +99,15 @@ struct ConvOperandsH { const bf16_t* src0; const bf16_t* src1; const bf16_t* wpk
 ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int split_k, int groups, int H = 0, int W = 0,
                             int ksize = 0, int ups = 0);
 int nbp_pack_upconv_weight_bf16_launch(const float* w_oihw, int N, int C, bf16_t* dst, hipStream_t st);
-// pool_out / head: as for nbp_conv_split_launch_g (taken only by the NBP_TILE_ROWS_64 kernel; *pooled / *headed tell)
+// pool_out / head: as for nbp_conv_split_launch_g (taken by the halo kernels; *pooled / *headed tell).  psi: the attention gate's tail
+// for a 1x1 launch over [g | x] whose workgroups hold all N columns (per group: psi weights [N], {scale, shift}, gated output
+// [M, C] = x * psi); *psi_fused tells whether the launch took it -- if not, q is written and the caller runs nbp_psi_gate_bf16_launch
+struct GatePsiH { const float* wpsi[2]; const float* st[2]; bf16_t* gated[2]; };
 int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2, int C0, int C1, int ups, int B, int H,
                                  int W, int ksize, int N, int relu, int split_k, int tile, void* ws, size_t ws_bytes,
                                  hipStream_t st, bf16_t* const* pool_out = nullptr, int* pooled = nullptr,
-                                 const struct ConvHead* head = nullptr, int* headed = nullptr);
+                                 const struct ConvHead* head = nullptr, int* headed = nullptr, const GatePsiH* psi = nullptr,
+                                 int* psi_fused = nullptr);
 int nbp_conv_first_bf16_launch(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale,
                                const float* shift, bf16_t* out_nhwc, hipStream_t st);
 int nbp_maxpool2_bf16_launch(const bf16_t* in, int B, int H, int W, int C, bf16_t* out, hipStream_t st);

@@ -240,7 +240,8 @@ for B, S in ((2, 256), (1, 512)):
 def test_epilogue_fusions_and_the_rows64_kernel_in_the_network(hip, tmp_path):
     """The halo kernels carry the encoder's max-pools and the sigmoid head in their epilogue (NBP_BF16_FUSE = 0: the separate
     kernels; read once per process, hence the subprocesses).  Pooling the same bf16 values: bit-identical.  The fused head sums
-    the same 64 products in another order (fp32).  NBP_BF16_ROWS64 = 1 gives the 64-channel layers to the weights-in-registers
+    the same 64 products in another order (fp32).  The attention gates' psi tail rides in the 1x1 GEMM where a wave holds all of
+    q's columns (levels 2 and 3; NBP_BF16_PSI = 0: the separate kernel).  NBP_BF16_ROWS64 = 1 gives the 64-channel layers to the weights-in-registers
     kernel, which accumulates the taps of a chunk in another order: one-ulp flips of bf16 activations, the tolerance of the
     network tests."""
     import os
@@ -251,7 +252,7 @@ def test_epilogue_fusions_and_the_rows64_kernel_in_the_network(hip, tmp_path):
     script.write_text(_ROWS64_SCRIPT)
     outs = {}
     keys = ((2, 256), (1, 512))
-    for tag, env in (("fused", {}), ("nofuse", {"NBP_BF16_FUSE": "0"}), ("rows64", {"NBP_BF16_ROWS64": "1"})):
+    for tag, env in (("fused", {}), ("nofuse", {"NBP_BF16_FUSE": "0"}), ("rows64", {"NBP_BF16_ROWS64": "1"}), ("nopsi", {"NBP_BF16_PSI": "0"})):
         subprocess.run([sys.executable, str(script), root, str(tmp_path / tag)], check=True, env={**os.environ, **env}, timeout=600)
         outs[tag] = {k: torch.load(tmp_path / f"{tag}_{k[0]}_{k[1]}.pt") for k in keys}
     for k in keys:
@@ -259,10 +260,13 @@ def test_epilogue_fusions_and_the_rows64_kernel_in_the_network(hip, tmp_path):
         p1, p2 = outs["nofuse"][k]
         assert torch.equal(o1, p1), k                                 # the value head never sees the fused head; the pools are exact
         assert float((o2 - p2).abs().max()) <= 2e-6, k
-        q1, q2 = outs["rows64"][k]
-        s1 = max(float(q1.abs().max()), 1e-6)
-        assert float((o1 - q1).abs().max()) / s1 < 2e-2 and float((o2 - q2).abs().max()) < 2e-2, k
-        assert float((o1 - q1).abs().mean()) / s1 < 3e-3 and float((o2 - q2).abs().mean()) < 3e-3, k
+        # rows64: another accumulation order; nopsi: the gates' psi tail as its own kernel (q . w_psi summed in another order: psi
+        # moves by an fp32 rounding, a gated bf16 value by one ulp now and then)
+        for tag in ("rows64", "nopsi"):
+            q1, q2 = outs[tag][k]
+            s1 = max(float(q1.abs().max()), 1e-6)
+            assert float((o1 - q1).abs().max()) / s1 < 2e-2 and float((o2 - q2).abs().max()) < 2e-2, (tag, k)
+            assert float((o1 - q1).abs().mean()) / s1 < 3e-3 and float((o2 - q2).abs().mean()) < 3e-3, (tag, k)
 
 
 def test_bf16_handle_mismatch_is_an_error(hip, net_bf16):
