@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr int WI = TPR * 4 * NB;                           // weight DMA instructions (64 rows x 16 B) per stage
     constexpr int WB = WI * 1024;
     constexpr int NF = (HPIX * 4 + 255) / 256;                 // float4 pieces of the halo tile per thread
-    static_assert(BN % 64 == 0 && TH == 16, "tile shape");
+    static_assert(BN % 64 == 0 && (TH == 16 || TH == 8), "tile shape");
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* const halo = ldsb;
     char* const wbuf = ldsb + HALO_BYTES;
@@ -941,7 +941,8 @@ int split_tile_width(int H, int W, int N, int ksize) {
 
 template <int TW, int TM, int TN, bool PH>
 int launch_h2(const SplitArgs& a, hipStream_t st) {
-    constexpr int HPIX = 18 * (TW + 2), RS = (HPIX + 7) / 8 * 8 * 16 + 64, NB = TN / 2;
+    constexpr int TH = 4 * TM * (32 / TW);
+    constexpr int HPIX = (TH + 2) * (TW + 2), RS = (HPIX + 7) / 8 * 8 * 16 + 64, NB = TN / 2;
     constexpr size_t smem = 4 * (size_t)RS + 2 * (size_t)(PH ? 8 : 12) * NB * 1024;
     static bool attr_set = false;
     if (!attr_set) {
@@ -951,7 +952,7 @@ int launch_h2(const SplitArgs& a, hipStream_t st) {
         attr_set = true;
     }
     // PH: tiles of the low-resolution image, four parities in blockIdx.z (fastest)
-    dim3 grid((unsigned)(a.M / (PH ? 4 : 1) / (16 * TW)), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups * (PH ? 4 : 1)));
+    dim3 grid((unsigned)(a.M / (PH ? 4 : 1) / (TH * TW)), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups * (PH ? 4 : 1)));
     conv3x3_halo_h2_kernel<TW, TM, TN, PH><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
@@ -985,6 +986,15 @@ static int chain_bounded_split(int sk, int cc, int taps, long long M, int N, int
 // tile == 0: the layer does not fit the split kernel (the caller runs the fp32 MFMA kernels on the fp32 pack)
 // ups: the layer reads its input through the x2 nearest upsample; when the LOW-resolution image tiles, the parity kernels run
 // (tile id NBP_TILE_SPLIT_UP), otherwise the plain kernel with the upsample folded into its gather.
+// 16 x 32-pixel tiles leave CUs idle when a launch has fewer of them than CUs (a single rollout: 128 tiles at full resolution), and
+// a workgroup's serial chain -- K / 16 chunks x 3 stages of 72 MFMAs per wave -- is what such a launch takes.  Below this many
+// workgroups (before split-K) the launch uses 8 x 32-pixel tiles: twice the workgroups, half the MFMAs per stage, the same sums in the
+// same order (NBP_SPLIT_R8_BLOCKS, 0 = never)
+static long long half_rows_below() {
+    static const int v = [] { const char* e = getenv("NBP_SPLIT_R8_BLOCKS"); return e ? atoi(e) : 256; }();
+    return v;
+}
+
 ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize, int ups) {
     ConvPlan p{0, 1, chunks_total};
     static const int allow = [] { const char* e = getenv("NBP_SPLIT_HALO"); return e ? atoi(e) : 1; }();
@@ -994,7 +1004,9 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
         if (twu) {
             static const int min_blocks_up = [] { const char* e = getenv("NBP_SPLIT_MIN_BLOCKS"); return e ? atoi(e) : 256; }();
             const int cc = chunks_total / 9 * 2;
-            const long long blocks = (M / 4 / (16 * twu)) * (N / (twu == 32 ? 64 : 128)) * groups * 4;
+            long long blocks = (M / 4 / (16 * twu)) * (N / (twu == 32 ? 64 : 128)) * groups * 4;
+            const bool r8 = twu == 32 && blocks < half_rows_below();      // 8-row tiles: twice the workgroups, half the chain each
+            if (r8) blocks *= 2;
             int sk = split_k;
             if (sk <= 0) {
                 sk = 1;
@@ -1003,7 +1015,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
             if (split_k <= 0) sk = chain_bounded_split(sk, cc, 4, M, N, groups);
             if (sk > cc) sk = cc;
             const int per = (int)nbp_cdiv(cc, sk);
-            p.tile = NBP_TILE_SPLIT_UP; p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
+            p.tile = r8 ? NBP_TILE_SPLIT_UP_R8 : NBP_TILE_SPLIT_UP; p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
             return p;
         }
     }
@@ -1013,7 +1025,9 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
     const int tw = allow ? split_tile_width(H, W, N, ksize) : 0;
     if (!tw) return p;
     const int cc = chunks_total / 9 * 2;      // the kernel's K chunks are 16 channels (chunks_total counts (32 channels, tap))
-    const long long blocks = (M / (16 * tw)) * (N / (tw == 32 ? 64 : 128)) * groups;
+    long long blocks = (M / (16 * tw)) * (N / (tw == 32 ? 64 : 128)) * groups;
+    const bool r8 = tw == 32 && blocks < half_rows_below();
+    if (r8) blocks *= 2;
     int sk = split_k;
     if (sk <= 0) {      // split-K over whole chunks until one workgroup per CU exists (each slice keeps >= 64 channels)
         sk = 1;
@@ -1027,7 +1041,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
     }
     if (sk > cc) sk = cc;
     const int per = (int)nbp_cdiv(cc, sk);
-    p.tile = NBP_TILE_SPLIT_HALO_64; p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
+    p.tile = r8 ? NBP_TILE_SPLIT_HALO_R8 : NBP_TILE_SPLIT_HALO_64; p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
     return p;
 }
 
@@ -1063,8 +1077,11 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0; a.bytesw = (unsigned)bw;
     const bool have_up = ups && o.planes_up && o.wamax_up && (!o2 || (o2->planes_up && o2->wamax_up));
     const ConvPlan p = nbp_plan_conv_split(a.M, N, (C0 + C1) / 32 * 9, split_k, groups, H, W, ksize, have_up ? 1 : 0);
-    NBP_RETURN_IF(p.tile != NBP_TILE_SPLIT_HALO_64 && p.tile != NBP_TILE_SPLIT_UP, NBP_E_SHAPE);
-    const bool ph = p.tile == NBP_TILE_SPLIT_UP;
+    NBP_RETURN_IF(p.tile != NBP_TILE_SPLIT_HALO_64 && p.tile != NBP_TILE_SPLIT_UP && p.tile != NBP_TILE_SPLIT_HALO_R8 &&
+                  p.tile != NBP_TILE_SPLIT_UP_R8, NBP_E_SHAPE);
+    const bool ph = p.tile == NBP_TILE_SPLIT_UP || p.tile == NBP_TILE_SPLIT_UP_R8;
+    const bool r8 = p.tile == NBP_TILE_SPLIT_HALO_R8 || p.tile == NBP_TILE_SPLIT_UP_R8;
+    const int th = r8 ? 8 : 16;
     a.split_k = p.split_k; a.chunks_per_split = p.chunks_per_split;
     a.chunks_total = (C0 + C1) / 16;
     const int tw = ph ? split_tile_width(H / 2, W / 2, N, ksize) : split_tile_width(H, W, N, ksize);
@@ -1080,7 +1097,7 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     }
     {
         static const int forced = [] { const char* e = getenv("NBP_XCD_REMAP"); return e ? atoi(e) : -1; }();
-        const long long ptiles = a.M / (ph ? 4 : 1) / (16 * tw), nbk = N / (tw == 32 ? 64 : 128);
+        const long long ptiles = a.M / (ph ? 4 : 1) / (th * tw), nbk = N / (tw == 32 ? 64 : 128);
         const long long tiles = ptiles * nbk;
         // bytes that cross the fabric: mode 1 = 8 x weights + activations, mode 2 = weights + min(nbk, 8) x activations
         const double wb = (double)(C0 + C1) * (ph ? 16 : 9) * N * 4, ab = (double)a.M / (ups ? 4 : 1) * (C0 + C1) * 4;
@@ -1111,7 +1128,9 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
                            !ph && tw == 32 && N == 64 && relu;
     if (headed) *headed = with_head;
     if (with_head) { a.g[0].head_w = head->w; a.g[0].head_ss[0] = head->scale; a.g[0].head_ss[1] = head->shift; a.g[0].head_out = head->out; }
-    int rc = ph ? (tw == 32 ? launch_h2<32, 4, 2, true>(a, st) : launch_h2<16, 2, 4, true>(a, st))
+    NBP_RETURN_IF(r8 && tw != 32, NBP_E_SHAPE);
+    int rc = r8 ? (ph ? launch_h2<32, 2, 2, true>(a, st) : launch_h2<32, 2, 2, false>(a, st))
+           : ph ? (tw == 32 ? launch_h2<32, 4, 2, true>(a, st) : launch_h2<16, 2, 4, true>(a, st))
                 : (tw == 32 ? launch_h2<32, 4, 2, false>(a, st) : launch_h2<16, 2, 4, false>(a, st));
     if (rc) return rc;
     if (p.split_k > 1) {
@@ -1318,7 +1337,10 @@ extern "C" int nbp_upconv3x3_split_f32(const float* src, int C, int B, int H, in
         amax = slot;
     }
     // the plain planes are not needed when the parity kernels take the layer; NBP_E_SHAPE otherwise
-    NBP_RETURN_IF(nbp_plan_conv_split((long long)B * H * W, N, C / 32 * 9, split_k, 1, H, W, 3, 1).tile != NBP_TILE_SPLIT_UP, NBP_E_SHAPE);
+    {
+        const int t = nbp_plan_conv_split((long long)B * H * W, N, C / 32 * 9, split_k, 1, H, W, 3, 1).tile;
+        NBP_RETURN_IF(t != NBP_TILE_SPLIT_UP && t != NBP_TILE_SPLIT_UP_R8, NBP_E_SHAPE);
+    }
     ConvOperandsSplit o{src, nullptr, planes_up, scale, shift, out, amax, amax, (const unsigned*)wamax_up, (unsigned*)amax_out_or_null,
                         planes_up, (const unsigned*)wamax_up};
     return nbp_conv_split_launch_g(o, nullptr, C, 0, 1, B, H, W, 3, N, relu, split_k, (char*)ws + 256, ws_bytes - 256, st);

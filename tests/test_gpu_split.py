@@ -267,7 +267,8 @@ for B, S in ((8, 256), (3, 128), (1, 64)):
 
 def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
     """The encoder's max-pools and the one-channel sigmoid head ride in the producing convolution's epilogue and the attention
-    gates' psi tail in the gate GEMM's (NBP_CONV_POOL / NBP_CONV_HEAD / NBP_GATE_PSI = 0 switch back to the separate kernels; the switches are read once per process, hence
+    gates' psi tail in the gate GEMM's (NBP_CONV_POOL / NBP_CONV_HEAD / NBP_GATE_PSI = 0 switch back to the separate kernels; NBP_SPLIT_R8_BLOCKS = 0
+    keeps every launch on 16-row tiles; the switches are read once per process, hence
     the subprocesses).  The pooled tensor is the max of the same four values: bit-identical outputs.  The fused psi sums
     q . w_psi in another order: equal to fp32 rounding of a 32..128-term dot product."""
     import subprocess
@@ -276,7 +277,8 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
     script = tmp_path / "fwd.py"
     script.write_text(_FUSION_SCRIPT)
     outs = {}
-    for tag, env in (("both", {}), ("nopool", {"NBP_CONV_POOL": "0"}), ("nopsi", {"NBP_GATE_PSI": "0"}), ("nohead", {"NBP_CONV_HEAD": "0"})):
+    for tag, env in (("both", {}), ("nopool", {"NBP_CONV_POOL": "0"}), ("nopsi", {"NBP_GATE_PSI": "0"}), ("nohead", {"NBP_CONV_HEAD": "0"}),
+                     ("nor8", {"NBP_SPLIT_R8_BLOCKS": "0"})):
         subprocess.run([sys.executable, str(script), root, str(tmp_path / tag)], check=True, env={**os.environ, **env},
                        timeout=600)
         outs[tag] = {k: torch.load(tmp_path / f"{tag}_{k[0]}_{k[1]}.pt") for k in ((8, 256), (3, 128), (1, 64))}
@@ -288,6 +290,11 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
         assert float((o2 - q2).abs().max()) <= 2e-5, k
         r1, r2 = outs["nohead"][k]                            # Final2 in the last convolution's epilogue: out1 untouched
         assert torch.equal(o1, r1) and float((o2 - r2).abs().max()) <= 2e-6, k
+        # 8 x 32-pixel tiles (launches with fewer 16-row tiles than CUs) give the same sums per output; what differs is the split-K
+        # the planner then picks (fewer slices for twice the workgroups): fp32 re-association only
+        t1, t2 = outs["nor8"][k]
+        assert float((o1 - t1).abs().max()) <= 2e-5 * max(1.0, float(t1.abs().max())), k
+        assert float((o2 - t2).abs().max()) <= 2e-5, k
 
 
 # ---- in-tensor dynamic range (the per-tensor scale's floor)
