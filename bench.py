@@ -51,9 +51,12 @@ TILE_NAMES = {1: "igemm_conv_kernel<2,2,2,2>(128x128)", 2: "igemm_conv_kernel<4,
               7: "conv3x3_halo_f32_kernel<2,2>(8x32 px x 64 ch)", 8: "conv3x3_halo_f32_kernel<4,1>(4x32 px x 128 ch)",
               9: "conv3x3_halo_f32_kernel<2,1>(4x32 px x 64 ch)",
               10: "conv3x3_halo_h2_kernel<32, 4, 2, false>(16x32 px x 64 ch; fp32 operands as 2 scaled fp16 pieces, 3 fp16 MFMAs per product)",
-              11: "conv3x3_halo_h2_kernel<32, 4, 2, true>(up_conv as four 2x2 parity convolutions of the low-resolution input; same kernel body)"}
+              11: "conv3x3_halo_h2_kernel<32, 4, 2, true>(up_conv as four 2x2 parity convolutions of the low-resolution input; same kernel body)",
+              15: "conv3x3_halo_h2_kernel<32, 2, 2, false>(8x32 px x 64 ch: launches with fewer 16-row tiles than CUs; same kernel body)",
+              16: "conv3x3_halo_h2_kernel<32, 2, 2, true>(up_conv parity form on 8x32 low-resolution tiles)"}
 SPLIT_TILE = 10
-SPLIT_TILES = (10, 11)
+SPLIT_TILES = (10, 11, 15, 16)
+PARITY_TILES = (11, 16)          # execute 4/9 of the reference formulation's products
 TIMED = {"fp32": "nbp_forward_timed_f32", "fp32_split": "nbp_forward_timed_split_f32", "bf16": "nbp_forward_timed_bf16"}
 
 
@@ -410,7 +413,7 @@ def main():
         # FLOP accounting: `flops` of a row is the REFERENCE FORMULATION's (2 M N K of the layer as nbp_model.py states it); the
         # up_conv layers run as four 2x2 parity convolutions of the low-resolution input and EXECUTE 4/9 of that
         def executed(r):
-            return r["flops"] * (4.0 / 9.0 if r["tile"] == 11 else 1.0)
+            return r["flops"] * (4.0 / 9.0 if r["tile"] in PARITY_TILES else 1.0)
         cf = sum(r["flops"] for r in layer_rows if r["tile"] > 0)
         cfx = sum(executed(r) for r in layer_rows if r["tile"] > 0)
         cm = sum(r["ms"] for r in layer_rows if r["tile"] > 0)
@@ -428,7 +431,7 @@ def main():
         live, live_src = (None, "disabled (--no-live-traffic)")
         if world == 1 and not args.no_live_traffic:
             live, live_src = live_traffic(n_pts, packed.precision, Bf)
-        dom_prefix = TILE_NAMES[dom].split("(")[0].replace(" ", "")
+        dom_prefix = TILE_NAMES.get(dom, f"tile {dom}").split("(")[0].replace(" ", "")
         traffic = pick_traffic(live, dom_prefix) if S == 256 else None
         traffic_src = live_src
         if traffic is None and (Bf, S) == (12, 256):           # the committed profiles are taken at the default group batch
@@ -437,7 +440,7 @@ def main():
             traffic_src = f"{src2}; live pass: {live_src}" if src2 else live_src
         # the split kernel issues three fp16 MFMAs per fp32 product: its ceiling is the dense fp16 peak / 3 of ALGORITHMIC flops
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if dom in SPLIT_TILES else PEAK_F32_MFMA_TFLOPS
-        roofline = {"bound": "mfma", "kernel": TILE_NAMES[dom], "achieved": round(achieved, 3),
+        roofline = {"bound": "mfma", "kernel": TILE_NAMES.get(dom, f"tile {dom}"), "achieved": round(achieved, 3),
                     "peak": round(peak, 2), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "peak_basis": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product (algorithmic fp32 flops)"
                                    if dom in SPLIT_TILES else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
@@ -462,8 +465,8 @@ def main():
                     "all_conv_tflops_reference_formulation": round(cf / (cm * 1e-3) / 1e12, 3),
                     "by_kernel": {TILE_NAMES.get(k, str(k)).split("(")[0]: {
                         "launches": v["launches"], "ms": round(v["ms"], 4),
-                        "tflops_executed": round(v["flops"] * (4.0 / 9.0 if k == 11 else 1.0) / (v["ms"] * 1e-3) / 1e12, 2),
-                        "frac_executed": round(v["flops"] * (4.0 / 9.0 if k == 11 else 1.0) / (v["ms"] * 1e-3) / 1e12 / peak, 4),
+                        "tflops_executed": round(v["flops"] * (4.0 / 9.0 if k in PARITY_TILES else 1.0) / (v["ms"] * 1e-3) / 1e12, 2),
+                        "frac_executed": round(v["flops"] * (4.0 / 9.0 if k in PARITY_TILES else 1.0) / (v["ms"] * 1e-3) / 1e12 / peak, 4),
                         "tflops_reference_formulation": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                         for k, v in sorted(by_tile.items())}}
         if args.layers:
