@@ -189,7 +189,10 @@ int nbp_bf16_to_f32(const unsigned short* in, long long n, float* out, void* str
  *   split_k >= 1 splits the K loop over blockIdx.z (ws must hold split_k*B*H*W*N floats);
  *   split_k == 0 lets the library choose.  tile: 0 = auto; 1..5 = implicit-GEMM workgroup tiles (pixels x
  *   channels) 128x128, 256x64, 256x32, 128x64, 64x128; 6 / 7 = the halo-tile kernel (3x3 only, H % 8 == 0,
- *   W % 32 == 0) with 128 / 64 output channels per workgroup, whose split-K slices are whole channel chunks. */
+ *   W % 32 == 0) with 128 / 64 output channels per workgroup, whose split-K slices are whole channel chunks.
+ *   Ids reported by the timing twins for the other paths: 10 / 11 = split-path 16-row tiles (plain / up_conv parity form), 15 / 16 = the
+ *   same on 8 x 32-pixel tiles (launches with fewer 16-row tiles than CUs); nbp_conv_igemm_bf16 also takes 12 / 13 (parity form) and
+ *   14 (3x3, H % 16 == 0, W % 32 == 0, N % 64 == 0, no split-K: 16 x 32 pixels x 64 channels, weights in registers). */
 int nbp_conv_igemm_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H,
                        int W, int ksize, const float* w_packed, int N, const float* scale,
                        const float* shift, int relu, float* out, int split_k, int tile, void* ws,
