@@ -890,7 +890,8 @@ __global__ void sum_doubles_kernel(const double* __restrict__ part, int n, doubl
 }
 
 inline int blocks_for_rows(long long M, long long* rows_per_block) {
-    long long nblk = M / 256;
+    // >= 32 rows per block (the deep levels have few rows and many columns: M = 8192 x C = 1024 at batch 32 was 32 workgroups)
+    long long nblk = M / 32;
     if (nblk < 1) nblk = 1;
     if (nblk > 1024) nblk = 1024;       // 4 workgroups per CU: the reductions are HBM streams
     *rows_per_block = nbp_cdiv(M, nblk);
