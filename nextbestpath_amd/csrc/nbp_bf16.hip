@@ -542,10 +542,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a,
 //     lands on that halo row -- 18 + 18 fragment reads for 72 MFMAs (0.5 per MFMA; 1.0 above);
 //   * both operands arrive by LDS DMA in the fragment layout ([k half][pixel or channel][8 bf16]: every 8 lanes of a ds_read_b128 read
 //     128 contiguous bytes), double buffered per chunk: ONE barrier per 72 MFMAs per wave, two workgroups per CU (76 KB each).
-// Same products in the same order per output as the other bf16 kernels' (chunk, tap, k) order?  No: here the order is (chunk, halo
-// row, ...), i.e. the taps of a chunk are visited in a different order; accumulation is fp32 either way and the tests hold this
-// kernel to the same <= 1 ulp (of bf16) bound against the exact result.
-// Epilogue fusions (as the split path has them): the encoder's 2 x 2 max-pool and the one-channel sigmoid head.
+// The taps of a chunk are visited in halo-row order, not in the (chunk, tap, k) order of the other bf16 kernels: the fp32 sums differ
+// by re-association and the tests hold this kernel to the same <= 1 ulp (of bf16) bound against the exact result, not to bit equality.
+// MEASURED SLOWER than conv3x3_halo_bf16_kernel<2,2> once that kernel stored whole lines (profiles/r03/
+// bf16_epilogue_rows64.txt: a 64-channel tile is bound by its workgroup's fixed costs, stores and DMA, which add up, not by fragment
+// reads; 16-channel chunks also fetch every pixel line four times).  Kept selectable (tile 14, NBP_BF16_ROWS64=1) with its knock-out
+// switches (NBP_ROWS64_KO, diagnosis only) as the evidence for that statement.
 
 __global__ __launch_bounds__(256, 2) void conv3x3_rows64_bf16_kernel(IgemmArgsH a, RowsFuse f) {
     if (blockIdx.z) {
