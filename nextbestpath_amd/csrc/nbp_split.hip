@@ -1005,7 +1005,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
             static const int min_blocks_up = [] { const char* e = getenv("NBP_SPLIT_MIN_BLOCKS"); return e ? atoi(e) : 256; }();
             const int cc = chunks_total / 9 * 2;
             long long blocks = (M / 4 / (16 * twu)) * (N / (twu == 32 ? 64 : 128)) * groups * 4;
-            const bool r8 = twu == 32 && blocks < half_rows_below();      // 8-row tiles: twice the workgroups, half the chain each
+            const bool r8 = blocks < half_rows_below();      // 8-row tiles: twice the workgroups, half the chain each
             if (r8) blocks *= 2;
             int sk = split_k;
             if (sk <= 0) {
@@ -1026,7 +1026,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
     if (!tw) return p;
     const int cc = chunks_total / 9 * 2;      // the kernel's K chunks are 16 channels (chunks_total counts (32 channels, tap))
     long long blocks = (M / (16 * tw)) * (N / (tw == 32 ? 64 : 128)) * groups;
-    const bool r8 = tw == 32 && blocks < half_rows_below();
+    const bool r8 = blocks < half_rows_below();
     if (r8) blocks *= 2;
     int sk = split_k;
     if (sk <= 0) {      // split-K over whole chunks until one workgroup per CU exists (each slice keeps >= 64 channels)
@@ -1128,8 +1128,8 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
                            !ph && tw == 32 && N == 64 && relu;
     if (headed) *headed = with_head;
     if (with_head) { a.g[0].head_w = head->w; a.g[0].head_ss[0] = head->scale; a.g[0].head_ss[1] = head->shift; a.g[0].head_out = head->out; }
-    NBP_RETURN_IF(r8 && tw != 32, NBP_E_SHAPE);
-    int rc = r8 ? (ph ? launch_h2<32, 2, 2, true>(a, st) : launch_h2<32, 2, 2, false>(a, st))
+    int rc = r8 ? (ph ? (tw == 32 ? launch_h2<32, 2, 2, true>(a, st) : launch_h2<16, 1, 4, true>(a, st))
+                      : (tw == 32 ? launch_h2<32, 2, 2, false>(a, st) : launch_h2<16, 1, 4, false>(a, st)))
            : ph ? (tw == 32 ? launch_h2<32, 4, 2, true>(a, st) : launch_h2<16, 2, 4, true>(a, st))
                 : (tw == 32 ? launch_h2<32, 4, 2, false>(a, st) : launch_h2<16, 2, 4, false>(a, st));
     if (rc) return rc;
