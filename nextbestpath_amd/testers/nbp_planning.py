@@ -294,14 +294,14 @@ class MultiRollout:
         if not side:
             # one stream per group: a single stream guard around the whole group (a guard per rollout is ~10 us of host time)
             with torch.cuda.stream(fwd):
-                if self.batched and len(grp) <= 16:
+                if self.batched:
                     self._pre_group(gi)
                 else:
                     for i, r in enumerate(grp):
                         r.pre(net_in[i:i + 1])
                 with torch.no_grad():
                     out1, out2 = self._forward(net_in)
-                if self.batched and "replan" in self.batch_stages and len(grp) <= 16:
+                if self.batched and "replan" in self.batch_stages:
                     self._plan_group(gi, out1, out2)
                 else:
                     for i, r in enumerate(grp):
@@ -334,12 +334,12 @@ class MultiRollout:
         """Rollout.pre for every rollout of the group, each latency-bound stage as ONE batched launch (identical results)."""
         grp, net_in = self.groups[gi], self.net_in[gi]
         p0, stages = grp[0].params, self.batch_stages
-        if "coverage" in stages and len(grp) <= 16:
+        if "coverage" in stages:
             hipops.coverage_count_batch([r.coverage_item() for r in grp])
         else:
             for r in grp:
                 r.pre_coverage()
-        items = [r.unproject_item([-1], r.step_seed + 11 * r.pose_i) for r in grp] if "unproject" in stages and len(grp) <= 12 else [None]
+        items = [r.unproject_item([-1], r.step_seed + 11 * r.pose_i) for r in grp] if "unproject" in stages else [None]
         if all(it is not None for it in items):
             hipops.unproject_append_batch(items, p0.image_height, p0.image_width, 1, p0.gathering_factor, p0.sensor_range)
             for r in grp:
@@ -384,7 +384,7 @@ class MultiRollout:
         p0 = grp[0].params
         H, W = p0.image_height, p0.image_width
         stages = self.batch_stages
-        can_raster = "raster" in stages and len(grp) <= 12 and all(r.camera.deferred_colours(r.mesh) for r in grp)
+        can_raster = "raster" in stages and all(r.camera.deferred_colours(r.mesh) for r in grp)
         pend = []
         for r in grp:
             cams = r.camera.move_poses(r.post_choose())
@@ -399,7 +399,7 @@ class MultiRollout:
             for r, cams, out, _, slot in pend:
                 r.camera.capture_commit(out, cams, slot)
         which = [-5, -4, -3, -2]
-        items = [r.unproject_item(which, r.step_seed + 11 * r.pose_i + 5) for r in grp] if "unproject" in stages and len(grp) <= 12 else [None]
+        items = [r.unproject_item(which, r.step_seed + 11 * r.pose_i + 5) for r in grp] if "unproject" in stages else [None]
         if all(it is not None for it in items):
             hipops.unproject_append_batch(items, H, W, 4, p0.gathering_factor, p0.sensor_range)
         else:

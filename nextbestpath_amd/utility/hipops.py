@@ -273,9 +273,13 @@ class CoveragePlan:
 
 
 def replan_batch(items, S, V, grid_range=(-40, 40), threshold=0.13):
-    """fuse_obstacle + score_candidates + edges_blocked for several rollouts (<= 16) in two launches; items = one tuple per
-    rollout from LatticePlanner.replan_item."""
+    """fuse_obstacle + score_candidates + edges_blocked for several rollouts in two launches; items = one tuple per
+    rollout from LatticePlanner.replan_item.  More than 16 items go in chunks of 16."""
     import numpy as np
+    if len(items) > 16:
+        for i in range(0, len(items), 16):
+            replan_batch(items[i:i + 16], S, V, grid_range, threshold)
+        return
     n = len(items)
     VP, I = C.c_void_p, C.c_int
     a = [(VP * n)() for _ in range(13)]
@@ -294,8 +298,12 @@ def replan_batch(items, S, V, grid_range=(-40, 40), threshold=0.13):
 
 def coverage_count_batch(items):
     """CoveragePlan.count for several rollouts in two launches: items = [(plan, pc, out[2] int32, n_dev, n, seed, out_is_zero)]
-    (<= 16); the plans share the threshold."""
+    (more than 16 go in chunks of 16); the plans share the threshold."""
     import numpy as np
+    if len(items) > 16:
+        for i in range(0, len(items), 16):
+            coverage_count_batch(items[i:i + 16])
+        return
     n = len(items)
     VP, LL, U, I = C.c_void_p, C.c_longlong, C.c_uint, C.c_int
     plans, G, pc, N, ndev, k, seed, epoch, cnt, mout = (VP * n)(), (I * n)(), (VP * n)(), (LL * n)(), (VP * n)(), (LL * n)(), (U * n)(), \
@@ -326,10 +334,15 @@ def _item_ws(tag, key, nbytes, device):
 
 
 def unproject_append_batch(items, H, W, n_frames, gathering_factor=0.05, fov_range=70.0, tan_half_fov=TAN_HALF_FOV):
-    """unproject_append for several rollouts (<= 12) in three launches.  items = [(key, depth frames [F tensors [H,W]], cams host
+    """unproject_append for several rollouts in three launches.  items = [(key, depth frames [F tensors [H,W]], cams host
     [F,12], cloud, cloud_count, seed, cloud_rgb | None, shade | None)] with shade = (zface frames [F tensors [H,W] int64], verts,
-    faces, vcolors, ambient); the frames need not be adjacent in memory; `key` identifies the rollout (its scratch is kept)."""
+    faces, vcolors, ambient); the frames need not be adjacent in memory; `key` identifies the rollout (its scratch is kept).
+    More than 12 items go in chunks of 12."""
     import numpy as np
+    if len(items) > 12:
+        for i in range(0, len(items), 12):
+            unproject_append_batch(items[i:i + 12], H, W, n_frames, gathering_factor, fov_range, tan_half_fov)
+        return
     n = len(items)
     L = _lib.lib()
     VP, LL, U = C.c_void_p, C.c_longlong, C.c_uint
@@ -359,9 +372,13 @@ def unproject_append_batch(items, H, W, n_frames, gathering_factor=0.05, fov_ran
 
 
 def raster_zface_batch(items, H, W, n_frames, tan_half_fov=TAN_HALF_FOV, z_clip=Z_CLIP):
-    """raster_zface for several rollouts (<= 12), each its own mesh, in four launches.  items = [(key, verts, faces, cams host [F,12],
-    out_z [F,H,W], out_zface [F,H,W] int64)]."""
+    """raster_zface for several rollouts, each its own mesh, in four launches.  items = [(key, verts, faces, cams host [F,12],
+    out_z [F,H,W], out_zface [F,H,W] int64)].  More than 12 items go in chunks of 12."""
     import numpy as np
+    if len(items) > 12:
+        for i in range(0, len(items), 12):
+            raster_zface_batch(items[i:i + 12], H, W, n_frames, tan_half_fov, z_clip)
+        return
     n = len(items)
     L = _lib.lib()
     VP, I, SZ = C.c_void_p, C.c_int, C.c_size_t

@@ -132,8 +132,12 @@ def step_maps_batch(items, grid_size, grid_range, out6_all, net_in_all, band=0.1
     rollout (full_pc, n_upper, n_dev, camera_pose, y_bins, traj_dev, n_traj_old, traj_fresh); rollout i writes out6_all[i]
     ([n,6,S,S]) and net_in_all[i] ([n,5,S,S]); n_upper = a host-side upper bound of the cloud size (sizes the grid)."""
     n, S = len(items), int(grid_size)
-    if not 1 <= n <= 16:
-        raise ValueError("step_maps_batch: 1..16 rollouts per call")
+    if n > 16:                                   # the kernel arguments hold 16 rollouts: larger groups go in chunks
+        for i in range(0, n, 16):
+            step_maps_batch(items[i:i + 16], grid_size, grid_range, out6_all[i:i + 16], net_in_all[i:i + 16], band)
+        return
+    if n < 1:
+        raise ValueError("step_maps_batch: at least one rollout")
     if tuple(out6_all.shape) != (n, 6, S, S) or tuple(net_in_all.shape) != (n, 5, S, S) or not out6_all.is_contiguous() \
             or not net_in_all.is_contiguous():
         raise ValueError("step_maps_batch: contiguous out6_all [n,6,S,S] and net_in_all [n,5,S,S] expected")

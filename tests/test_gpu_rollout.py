@@ -136,6 +136,35 @@ def test_four_streams_match_single_rollouts(hip, dataset, nbp_weights):
         assert torch.equal(a.st.cloud[:k], b.st.cloud[:k])
 
 
+def test_group_larger_than_the_batched_kernels_hold(hip, dataset, nbp_weights):
+    """A lock-step group of 18 rollouts (the strong-scaling stage on one GPU has groups of 20): the batched stages take 12 / 16
+    rollouts per launch, larger groups go in chunks -- same trajectories, clouds and coverage as one launch per rollout."""
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.testers import nbp_planning as tp
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    ds = sc.SceneDataset(dataset)
+    net = _net(nbp_weights)
+    dev = torch.device("cuda")
+    n, R = 5, 18
+    runs = []
+    for batched in (True, False):
+        ros = [tp.build_rollout(params, net, ds, (i % 2, 0), dev, seed=70 + i) for i in range(R)]
+        m = tp.MultiRollout(ros, net, dev, n_groups=1)
+        assert len(m.groups) == 1 and len(m.groups[0]) == R
+        m.batched = batched
+        for _ in range(n):
+            m.step()
+        m.flush()
+        torch.cuda.synchronize()
+        runs.append(ros)
+    for a, b in zip(*runs):
+        assert a.camera.cam_idx_history == b.camera.cam_idx_history
+        assert a.coverage_evolution(n) == b.coverage_evolution(n)
+        k = int(a.st.cloud_count.item())
+        assert k == int(b.st.cloud_count.item()) and torch.equal(a.st.cloud[:k], b.st.cloud[:k])
+        assert torch.equal(a.st.maps6, b.st.maps6)
+
+
 def test_rollout_on_512_grid(hip, dataset, nbp_weights):
     """BASELINE configs[4] geometry: 512x512 grid, +-80 window (same 0.3125 units / pixel), value map 128x128."""
     from nextbestpath_amd.simulator import scene as sc
