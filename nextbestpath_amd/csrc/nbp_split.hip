@@ -667,6 +667,7 @@ struct WgradSplitArgs {
     int co_tiles, n_tiles, splits;
     const unsigned* amax0; const unsigned* amax1; const unsigned* amaxy;
     float* part;           // [split][tap][Ctot][N]
+    int prefetch;          // 1: the next tile's loads are issued before the current tile's MFMAs (NBP_WGRAD_PREFETCH)
 };
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
@@ -719,13 +720,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
     const char* const yb_hi = wl + XB + (0 * 2 + wj) * YPL + loff;
     const char* const yb_lo = wl + XB + (1 * 2 + wj) * YPL + loff;
 
-    for (int tile = blockIdx.y; tile < a.n_tiles; tile += a.splits) {
+    // The next tile's pixels are fetched while the current tile is multiplied (a tile is 108 MFMAs per wave, ~1.6 us: less than one
+    // HBM round trip, so loads issued at the top of an iteration were exposed every time)
+    u32x4 xr[NX], yr[4];
+    auto fetch = [&](int tile) {
         int t = tile;
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
         const int b = t / tiles_y;
         const int y0 = ty * TR, x0 = tx * TW;
-        u32x4 xr[NX], yr[4];
 #pragma unroll
         for (int k = 0; k < NX; ++k) {         // X halo: HP pixels x 16 float4
             const int f = tid + 256 * k;
@@ -742,6 +745,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
             const long long m = ((long long)b * a.H + y0 + pz / TW) * a.W + x0 + pz % TW;
             yr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (unsigned)((m * a.N + co0 + c4 * 4) * 4), 0, 0);
         }
+    };
+    if (a.prefetch && (int)blockIdx.y < a.n_tiles) fetch(blockIdx.y);
+    for (int tile = blockIdx.y; tile < a.n_tiles; tile += a.splits) {
+        if (!a.prefetch) fetch(tile);
         __syncthreads();                       // every wave is done with the previous tile's planes
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
@@ -767,6 +774,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
             *reinterpret_cast<u32x2*>(d + 2 * YPL) = u32x2{l0, l1};
         }
         __syncthreads();
+        if (a.prefetch && tile + a.splits < a.n_tiles) fetch(tile + a.splits);
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
             // the row offset is made opaque to the compiler: left visible, it keeps the fragments of the halo rows that tile rows r
@@ -1243,6 +1251,7 @@ int nbp_wgrad_split_launch(const float* src0, int C0, const float* src1, int C1,
     a.src0 = src0; a.src1 = src1 ? src1 : src0; a.C0 = C0; a.C1 = C1; a.ups = ups ? 1 : 0; a.H = H; a.W = W; a.Hs = Hs; a.Ws = Ws;
     a.dy = dy; a.N = N; a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0; a.bytesy = (unsigned)by;
     a.co_tiles = N / 64; a.n_tiles = n_tiles; a.splits = splits;
+    { static const int pf = [] { const char* e = getenv("NBP_WGRAD_PREFETCH"); return e ? atoi(e) : 1; }(); a.prefetch = pf; }
     a.amax0 = amax0_in ? amax0_in : amax3; a.amax1 = amax1_in ? amax1_in : amax3 + AMAX_WORDS;
     a.amaxy = amaxy_in ? amaxy_in : amax3 + 2 * AMAX_WORDS; a.part = part;
     const bool wide = W % 32 == 0 && H % 2 == 0;              // 2 x 32 tiles, else 4 x 16 (nbp_wgrad_split_ok)
