@@ -92,7 +92,7 @@ def _pack_split(w_oihw, n_pad, c_total):
     # the pack kernel writes every plane entry of the channels it is given: only padded channels need the zero fill
     alloc = torch.zeros if C != c_total else torch.empty
     planes = alloc(c_total // 16 * 9 * 4 * n_pad * 8, dtype=torch.int16, device=w_oihw.device)
-    wamax = torch.zeros(1, dtype=torch.int32, device=w_oihw.device)
+    wamax = torch.empty(1, dtype=torch.int32, device=w_oihw.device)          # zeroed by the pack launch itself
     # the pack kernel indexes rows by the padded count: give it a zero-padded weight when N < n_pad
     if N != n_pad:
         wp = torch.zeros(n_pad, C, k, k, dtype=torch.float32, device=w_oihw.device)
@@ -193,7 +193,7 @@ def _upconv_split(src, w_oihw, n_pad, scale, shift, amax=None):
         wp[:N, :C] = w_oihw
         w_oihw = wp
     planes = torch.empty(4 * (C0 // 16) * 4 * 4 * n_pad * 8, dtype=torch.int16, device=src.device)
-    wamax = torch.zeros(1, dtype=torch.int32, device=src.device)
+    wamax = torch.empty(1, dtype=torch.int32, device=src.device)             # zeroed by the pack launch itself
     _chk(L.nbp_pack_upconv_weight_split(_lib.ptr(w_oihw), n_pad, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_upconv")
     H, W = 2 * Hs, 2 * Ws
     out = torch.empty(B, H, W, n_pad, dtype=torch.float32, device=src.device)
@@ -217,8 +217,11 @@ class ConvFn(torch.autograd.Function):
         dev = x0.device
         w = weight.detach().contiguous()
         scale = _const(1.0, Np, dev)
-        shift = torch.zeros(Np, dtype=torch.float32, device=dev)
-        shift[:N] = bias.detach()
+        if N == Np:                        # (every 3x3 layer: the bias is the epilogue's shift as it stands)
+            shift = bias.detach().contiguous()
+        else:
+            shift = torch.zeros(Np, dtype=torch.float32, device=dev)
+            shift[:N] = bias.detach()
         H, W = (x0.shape[1] * 2, x0.shape[2] * 2) if ups else (x0.shape[1], x0.shape[2])
         xmax = None                      # joint max-|.| slot of the inputs: taken once, reused by the weight gradient
         if ups and k == 3 and x1 is None and _upconv_ok(x0.shape[1], x0.shape[2], Np):
