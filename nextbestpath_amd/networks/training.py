@@ -593,7 +593,9 @@ def forward_train(net, x):
         outs[d] = cur
     o1 = ConvFn.apply(outs[1], None, net.Final1.weight, net.Final1.bias, False)          # [B,S/4,S/4,8]
     out1 = ToNCHWFn.apply(o1)
-    o2 = ConvFn.apply(outs[2], None, net.Final2[0].weight, net.Final2[0].bias, False)    # [B,S,S,1]
+    # Final2 is a 64 -> 1 convolution at full resolution: a row dot product (as the gates' psi layer), not a GEMM padded to 64
+    # output channels whose 63 zero columns are written, sliced away and padded back in for the backward
+    o2 = PsiConvFn.apply(outs[2], net.Final2[0].weight, net.Final2[0].bias)              # [B,S,S,1]
     out2 = SigmoidFn.apply(o2).reshape(B, 1, S, S)                                       # C == 1: NHWC == NCHW
     return out1, out2
 
