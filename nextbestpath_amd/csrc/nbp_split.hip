@@ -1003,6 +1003,14 @@ static long long half_rows_below() {
     return v;
 }
 
+// Whether the doubled workgroup count of 8-row tiles may buy fewer split-K slices (NBP_SPLIT_R8_SK = 1) or the slices stay those of
+// the 16-row plan (0): fewer slices are longer accumulation chains -- inside the chain bound, but the rollout-input error statistics of
+// tests/test_gpu_rollout_parity.py sit at the bound's edge then
+static bool r8_counts_double() {
+    static const int v = [] { const char* e = getenv("NBP_SPLIT_R8_SK"); return e ? atoi(e) : 0; }();
+    return v != 0;
+}
+
 ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize, int ups) {
     ConvPlan p{0, 1, chunks_total};
     static const int allow = [] { const char* e = getenv("NBP_SPLIT_HALO"); return e ? atoi(e) : 1; }();
@@ -1014,7 +1022,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
             const int cc = chunks_total / 9 * 2;
             long long blocks = (M / 4 / (16 * twu)) * (N / (twu == 32 ? 64 : 128)) * groups * 4;
             const bool r8 = blocks < half_rows_below();      // 8-row tiles: twice the workgroups, half the chain each
-            if (r8) blocks *= 2;
+            if (r8 && r8_counts_double()) blocks *= 2;
             int sk = split_k;
             if (sk <= 0) {
                 sk = 1;
@@ -1035,7 +1043,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
     const int cc = chunks_total / 9 * 2;      // the kernel's K chunks are 16 channels (chunks_total counts (32 channels, tap))
     long long blocks = (M / (16 * tw)) * (N / (tw == 32 ? 64 : 128)) * groups;
     const bool r8 = blocks < half_rows_below();
-    if (r8) blocks *= 2;
+    if (r8 && r8_counts_double()) blocks *= 2;
     int sk = split_k;
     if (sk <= 0) {      // split-K over whole chunks until one workgroup per CU exists (each slice keeps >= 64 channels)
         sk = 1;
