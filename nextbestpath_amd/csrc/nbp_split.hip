@@ -1011,6 +1011,18 @@ static bool r8_counts_double() {
     return v != 0;
 }
 
+// ... and for launches whose last round of workgroups is a thin tail: with S = 512 resident workgroups (two per CU) a launch of 640
+// 16-row workgroups is one full round plus a quarter-full one, 1280 half-size ones are 2.5 half rounds.  Measured (B = 5, whose
+// full-resolution layers are 640 workgroups): -2.8 % of the forward.  A HALF-full last round (768, 1280 workgroups: B = 12, 20) does not
+// gain -- its workgroups run alone on their CUs, 1.7 x faster -- and pays the 8-row tiles' doubled weight traffic (+0.3 .. +0.9 %), so
+// the rule takes tails of up to 160 workgroups only (NBP_SPLIT_R8_TAIL = that bound, 0 = off).
+static bool half_rows_for_tail(long long workgroups) {
+    static const int bound = [] { const char* e = getenv("NBP_SPLIT_R8_TAIL"); return e ? atoi(e) : 160; }();
+    if (bound <= 0 || workgroups <= 512) return false;
+    const long long rem = workgroups % 512;
+    return rem > 0 && rem <= bound;
+}
+
 ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize, int ups) {
     ConvPlan p{0, 1, chunks_total};
     static const int allow = [] { const char* e = getenv("NBP_SPLIT_HALO"); return e ? atoi(e) : 1; }();
@@ -1031,7 +1043,9 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
             if (split_k <= 0) sk = chain_bounded_split(sk, cc, 4, M, N, groups);
             if (sk > cc) sk = cc;
             const int per = (int)nbp_cdiv(cc, sk);
-            p.tile = r8 ? NBP_TILE_SPLIT_UP_R8 : NBP_TILE_SPLIT_UP; p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
+            p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
+            const bool r8t = r8 || half_rows_for_tail((M / 4 / (16 * twu)) * (N / (twu == 32 ? 64 : 128)) * groups * 4 * p.split_k);
+            p.tile = r8t ? NBP_TILE_SPLIT_UP_R8 : NBP_TILE_SPLIT_UP;
             return p;
         }
     }
@@ -1057,7 +1071,9 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
     }
     if (sk > cc) sk = cc;
     const int per = (int)nbp_cdiv(cc, sk);
-    p.tile = r8 ? NBP_TILE_SPLIT_HALO_R8 : NBP_TILE_SPLIT_HALO_64; p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
+    p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
+    const bool r8t = r8 || half_rows_for_tail((M / (16 * tw)) * (N / (tw == 32 ? 64 : 128)) * groups * p.split_k);
+    p.tile = r8t ? NBP_TILE_SPLIT_HALO_R8 : NBP_TILE_SPLIT_HALO_64;
     return p;
 }
 
