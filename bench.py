@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--strong-advance", type=int, default=10, help="un-timed steps before the strong-scaling window")
     ap.add_argument("--layers", action="store_true", help="per-layer timing table to stderr")
     ap.add_argument("--faces", choices=["simple", "hard"], default="simple")
-    ap.add_argument("--rollouts-per-gpu", type=int, default=24,
+    ap.add_argument("--rollouts-per-gpu", type=int, default=48,
                     help="independent rollouts stepped in lock-step per GPU (their NBP forwards are one batched launch)")
     return ap.parse_args()
 
@@ -434,7 +434,7 @@ def main():
         dom_prefix = TILE_NAMES.get(dom, f"tile {dom}").split("(")[0].replace(" ", "")
         traffic = pick_traffic(live, dom_prefix) if S == 256 else None
         traffic_src = live_src
-        if traffic is None and (Bf, S) == (12, 256):           # the committed profiles are taken at the default group batch
+        if traffic is None and (Bf, S) == (24, 256):           # the committed profiles are taken at the default group batch
             traffic, src2 = committed_traffic(dom_prefix, "forward_split_pmc_summary.csv" if dom in SPLIT_TILES
                                               else "forward_f32_pmc_summary.csv")
             traffic_src = f"{src2}; live pass: {live_src}" if src2 else live_src

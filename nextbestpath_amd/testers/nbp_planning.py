@@ -555,7 +555,7 @@ def run_one(params, nbp, dataset, run, device, test_resolution=0.05, state=None,
     return _result(ro, n_poses)
 
 
-def run_many(params, nbp, dataset, runs, device, seeds, test_resolution=0.05, n_poses=N_POSES, rollouts_per_gpu=24,
+def run_many(params, nbp, dataset, runs, device, seeds, test_resolution=0.05, n_poses=N_POSES, rollouts_per_gpu=48,
              grid=256):
     """Runs `runs` in lock-step groups of `rollouts_per_gpu` (MultiRollout); same results as run_one each."""
     out = []
@@ -577,7 +577,7 @@ def run_many(params, nbp, dataset, runs, device, seeds, test_resolution=0.05, n_
 def test_nbp_planning(params_file, model_file, results_json_file, numGPU, test_scenes, test_resolution=0.05,
                       use_perfect_depth_map=False, compute_collision=False, load_json=False, dataset_path=None,
                       nbp_weights=None, configs_dir=None, results_dir=None, n_poses=N_POSES, seed=8, torch_seed=9,
-                      rollouts_per_gpu=24, grid_size=256, nbp_precision=None):
+                      rollouts_per_gpu=48, grid_size=256, nbp_precision=None):
     """Same arguments as the reference (nbp_planning.py:364-374); `grid_size` / `nbp_precision` select
     BASELINE.json configs[4] (512 grid at the same 0.3125 units per pixel, bf16 convolutions).  Under torchrun the flattened
     (scene, start pose) runs are sharded round-robin over the ranks and the coverage curves are

@@ -15,12 +15,12 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_
   name=$(echo $pass | cut -d' ' -f1)
   rocprofv3 --pmc $pass --output-format csv -d "$REPO/$OUT/pmc_$name" -o pmc -- python $REPO/bench.py --steps 6 --warmup 2 --advance 10 --no-cpu-baseline --no-live-traffic --no-extra-stages --no-strong > "$REPO/$OUT/pmc_$name.json" 2> "$REPO/$OUT/pmc_$name.err"
 done
-# the roofline workload alone (tools/pmc_workload.py: 12 maps of 256x256 (one pipeline group of the default 24 rollouts per GPU) through the forward + the map accumulation;
+# the roofline workload alone (tools/pmc_workload.py: 24 maps of 256x256 (one pipeline group of the default 48 rollouts per GPU) through the forward + the map accumulation;
 # 8 of 512x512 through the bf16 forward; fwd_split = the default fp32_split path, fwd_f32 = the fp32 MFMA pipe): every launch of a kernel in these runs belongs to the same forward, so the
 # per-kernel means are per-launch figures on exactly the basis of bench.py's roofline.achieved
 for kind in split f32 bf16; do
-  if [ $kind = split ]; then FW="python $REPO/tools/pmc_workload.py --precision fp32_split --batch 12 --size 256 --points 1900000";
-  elif [ $kind = f32 ]; then FW="python $REPO/tools/pmc_workload.py --precision fp32 --batch 12 --size 256 --points 0";
+  if [ $kind = split ]; then FW="python $REPO/tools/pmc_workload.py --precision fp32_split --batch 24 --size 256 --points 1900000";
+  elif [ $kind = f32 ]; then FW="python $REPO/tools/pmc_workload.py --precision fp32 --batch 24 --size 256 --points 0";
   else FW="python $REPO/tools/pmc_workload.py --bf16 --batch 8 --size 512 --points 0"; fi
   for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     name=$(echo $pass | cut -d' ' -f1)
