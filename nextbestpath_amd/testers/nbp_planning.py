@@ -249,7 +249,9 @@ class MultiRollout:
         self.device, self._packed = device, None
         grid = grid or self.rollouts[0].S
         R = len(self.rollouts)
-        n_groups = n_groups or int(os.environ.get("NBP_ROLLOUT_GROUPS", "2"))
+        # two pipeline groups, and more once a group would exceed 24 rollouts (measured: 48 = 2 x 24 is the best split of one
+        # GPU; groups of 30+ lose 15 % in bench.py's configuration, 3 x 24 is level with 2 x 24)
+        n_groups = n_groups or int(os.environ.get("NBP_ROLLOUT_GROUPS", "0")) or max(2, (R + 23) // 24)
         n_groups = max(1, min(n_groups, R))
         per = (R + n_groups - 1) // n_groups
         self.groups = [self.rollouts[i:i + per] for i in range(0, R, per)]
