@@ -238,7 +238,7 @@ def main():
     def make_rollout(k, hard=(args.faces == "hard"), scene_seed=None, name=None, fixed_seed=None):
         """fixed_seed: every seed of the rollout independent of the rank (the strong-scaling set is the same 40 runs at any N)"""
         name = name or f"maze{k}"
-        scene_seed = 100 + 16 * rank + k if scene_seed is None else scene_seed
+        scene_seed = 100 + 128 * rank + k if scene_seed is None else scene_seed     # (distinct scenes per rank up to 128 rollouts per GPU)
         if hard:
             make_maze_scene(os.path.join(tmp, name), seed=scene_seed, cells=12, size=7.2, height=1.2, tess=0.15)
         else:
@@ -250,7 +250,7 @@ def main():
         s0 = rank if fixed_seed is None else fixed_seed
         _, gt = sc.setup_gt_scene(params, settings, mesh, dev, 0.05, seed=s0)
         cam = tp.setup_test_camera(params, mesh, settings.camera.start_positions[0], settings, dev, seed=s0)
-        return tp.Rollout(params, net, cam, gt, mesh, mesh, y_bins, dev, seed=(8 + 16 * rank + k) if fixed_seed is None else 8 + fixed_seed)
+        return tp.Rollout(params, net, cam, gt, mesh, mesh, y_bins, dev, seed=(8 + 128 * rank + k) if fixed_seed is None else 8 + fixed_seed)
 
     def sync_all():
         torch.cuda.synchronize()
