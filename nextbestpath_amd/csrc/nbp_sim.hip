@@ -50,11 +50,11 @@ __device__ __forceinline__ void shade_pixel(const float* __restrict__ verts, con
     const int s = H < W ? H : W;
     const float dx = (((float)W - (2.f * col + 1.f)) / (float)s) * tanh_fov;
     const float dy = (((float)H - (2.f * row + 1.f)) / (float)s) * tanh_fov;
-    const float p0 = dy * e2[2] - e2[1];
-    const float p1 = e2[0] - dx * e2[2];
-    const float p2 = dx * e2[1] - dy * e2[0];
-    const float inv = 1.f / ((e1[0] * p0 + e1[1] * p1) + e1[2] * p2);
-    const float u = -((v[0][0] * p0 + v[0][1] * p1) + v[0][2] * p2) * inv;
+    // plane forms of the face (raster_setup_body's arithmetic, oracle/raster.py::plane_forms)
+    const float a0 = e1[2] * e2[1] - e1[1] * e2[2], a1 = e1[0] * e2[2] - e1[2] * e2[0], a2 = e1[1] * e2[0] - e1[0] * e2[1];
+    const float u0 = v[0][1] * e2[2] - v[0][2] * e2[1], u1 = v[0][2] * e2[0] - v[0][0] * e2[2], u2 = v[0][0] * e2[1] - v[0][1] * e2[0];
+    const float inv = 1.f / ((a0 * dx + a1 * dy) + a2);
+    const float u = ((u0 * dx + u1 * dy) + u2) * inv;
     const float vv = ((dx * q[0] + dy * q[1]) + q[2]) * inv;
     const float w0 = (1.f - u) - vv;
     const float* c0 = vcolors + 3 * (size_t)i0;
@@ -353,7 +353,9 @@ __global__ void cloud_count_update_kernel(const int* __restrict__ counts, int F,
 
 // ------------------------------------------------------------------ rasteriser
 constexpr int TILE = 8;            // 8x8 pixel tiles, one wave per tile
-struct FaceRec { float e1[3], e2[3], v0[3], q[3], tnum, pad[3]; };   // 64 bytes
+// a face of one frame as the three linear forms of the hit test in the pixel's ray (dx, dy, 1): det = a . d, u det = un . d, v det = q . d;
+// z det = tnum (oracle/raster.py::plane_forms)
+struct FaceRec { float a[3], un[3], q[3], tnum, pad[2]; };   // 48 bytes
 
 // Two-level binning without capacity limits: fine tiles of 8x8 pixels (one wave), coarse tiles of 8x8 fine tiles.
 // raster_setup_kernel (one thread per face and frame) transforms the face, clips its screen box against the near plane and
@@ -392,14 +394,18 @@ __device__ __forceinline__ void raster_setup_body(unsigned bx, unsigned by, unsi
         for (int k = 0; k < 3; ++k) to_view(verts + 3 * (size_t)faces[3 * (size_t)fi + k], cam.R, cam.T, v[k]);
         if (!(v[0][2] <= zclip && v[1][2] <= zclip && v[2][2] <= zclip)) {          // not entirely behind the clip plane
             FaceRec r;
+            float e1[3], e2[3];
+            const float* v0 = v[0];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { r.e1[c] = v[1][c] - v[0][c]; r.e2[c] = v[2][c] - v[0][c]; r.v0[c] = v[0][c]; }
-            // q = e1 x v0  (= (-v0) x e1),  tnum = e2 . q
-            r.q[0] = r.e1[1] * r.v0[2] - r.e1[2] * r.v0[1];
-            r.q[1] = r.e1[2] * r.v0[0] - r.e1[0] * r.v0[2];
-            r.q[2] = r.e1[0] * r.v0[1] - r.e1[1] * r.v0[0];
-            r.tnum = (r.e2[0] * r.q[0] + r.e2[1] * r.q[1]) + r.e2[2] * r.q[2];
-            r.pad[0] = r.pad[1] = r.pad[2] = 0.f;
+            for (int c = 0; c < 3; ++c) { e1[c] = v[1][c] - v[0][c]; e2[c] = v[2][c] - v[0][c]; }
+            // q = e1 x v0  (= (-v0) x e1),  tnum = e2 . q;  a = -(e1 x e2),  un = v0 x e2: the hit test's numerators are linear in the ray
+            r.q[0] = e1[1] * v0[2] - e1[2] * v0[1];
+            r.q[1] = e1[2] * v0[0] - e1[0] * v0[2];
+            r.q[2] = e1[0] * v0[1] - e1[1] * v0[0];
+            r.tnum = (e2[0] * r.q[0] + e2[1] * r.q[1]) + e2[2] * r.q[2];
+            r.a[0] = e1[2] * e2[1] - e1[1] * e2[2]; r.a[1] = e1[0] * e2[2] - e1[2] * e2[0]; r.a[2] = e1[1] * e2[0] - e1[0] * e2[1];
+            r.un[0] = v0[1] * e2[2] - v0[2] * e2[1]; r.un[1] = v0[2] * e2[0] - v0[0] * e2[2]; r.un[2] = v0[0] * e2[1] - v0[1] * e2[0];
+            r.pad[0] = r.pad[1] = 0.f;
             // screen bbox of the part with z >= zclip (Sutherland-Hodgman against one plane)
             const int s = H < W ? H : W;
             float cmin = 1e30f, cmax = -1e30f, rmin = 1e30f, rmax = -1e30f;
@@ -521,14 +527,11 @@ __device__ __forceinline__ void raster_tile_body(unsigned bx, unsigned by, unsig
             __syncthreads();
             for (int k = 0; k < m; ++k) {
                 const FaceRec& f = sh[k];
-                // p = d x e2 ; det = e1 . p ; u = (-v0 . p)/det ; v = (d . q)/det ; z = tnum/det
-                const float p0 = dy * f.e2[2] - f.e2[1];
-                const float p1 = f.e2[0] - dx * f.e2[2];
-                const float p2 = dx * f.e2[1] - dy * f.e2[0];
-                const float det = (f.e1[0] * p0 + f.e1[1] * p1) + f.e1[2] * p2;
+                // det = a . d ; u = (un . d)/det ; v = (q . d)/det ; z = tnum/det with d = (dx, dy, 1): three linear forms and a reciprocal
+                const float det = (f.a[0] * dx + f.a[1] * dy) + f.a[2];
                 if (fabsf(det) < 1e-12f) continue;
                 const float inv = 1.f / det;
-                const float u = -((f.v0[0] * p0 + f.v0[1] * p1) + f.v0[2] * p2) * inv;
+                const float u = ((f.un[0] * dx + f.un[1] * dy) + f.un[2]) * inv;
                 const float vv = ((dx * f.q[0] + dy * f.q[1]) + f.q[2]) * inv;
                 const float z = f.tnum * inv;
                 // equal depths (shared edges): the lowest face id wins, whatever the order of the lists (for the colours)

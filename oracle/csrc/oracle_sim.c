@@ -63,18 +63,18 @@ static void raster_rows(const float* verts, const int* faces, int n_faces, const
         q[1] = e1[2] * v0[0] - e1[0] * v0[2];
         q[2] = e1[0] * v0[1] - e1[1] * v0[0];
         const float tnum = (e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2];
+        /* plane forms (oracle/raster.py::plane_forms): det and the u numerator are linear in the pixel's ray (dx, dy, 1) */
+        const float a[3] = {e1[2] * e2[1] - e1[1] * e2[2], e1[0] * e2[2] - e1[2] * e2[0], e1[1] * e2[0] - e1[0] * e2[1]};
+        const float un[3] = {v0[1] * e2[2] - v0[2] * e2[1], v0[2] * e2[0] - v0[0] * e2[2], v0[0] * e2[1] - v0[1] * e2[0]};
         for (int r = r0; r <= r1; ++r) {
             const float dy = dys[r];
             float* zrow = zbuf + (size_t)r * W;
             for (int c = c0; c <= c1; ++c) {
                 const float dx = dxs[c];
-                const float p0 = dy * e2[2] - e2[1];
-                const float p1 = e2[0] - dx * e2[2];
-                const float p2 = dx * e2[1] - dy * e2[0];
-                const float det = (e1[0] * p0 + e1[1] * p1) + e1[2] * p2;
+                const float det = (a[0] * dx + a[1] * dy) + a[2];
                 if (!(fabsf(det) >= 1e-12f)) continue;
                 const float inv = 1.f / det;
-                const float u = -((v0[0] * p0 + v0[1] * p1) + v0[2] * p2) * inv;
+                const float u = ((un[0] * dx + un[1] * dy) + un[2]) * inv;
                 const float vv = ((dx * q[0] + dy * q[1]) + q[2]) * inv;
                 const float z = tnum * inv;
                 if (u >= -eps && vv >= -eps && u + vv <= 1.f + eps && z > z_clip && z < zrow[c]) {

@@ -4,7 +4,7 @@ documented semantics at the reference's call site (macarons/utility/macarons_uti
 2743-2786: image_size=(256,456), blur_radius=0, faces_per_pixel=1, perspective-correct z,
 z_clip = znear/2 = 0.5): zbuf = view-space z of the nearest face through the pixel centre,
 -1 for background; pixel centres at ndc_x = (W-(2c+1))/s, ndc_y = (H-(2r+1))/s, s = min(H,W).
-Same ray/triangle algebra as nextbestpath_amd/csrc/nbp_sim.hip (fp32)."""
+Same ray/triangle algebra as nextbestpath_amd/csrc/nbp_sim.hip (fp32): per-face plane forms (plane_forms), bit for bit."""
 import numpy as np
 
 f32 = np.float32
@@ -17,6 +17,16 @@ def to_view(verts, R, T):
     for j in range(3):
         out[:, j] = ((v[:, 0] * R[0, j] + v[:, 1] * R[1, j]) + v[:, 2] * R[2, j]) + f32(T[j])
     return out
+
+
+def plane_forms(v0, e1, e2):
+    """The ray (dx, dy, 1) through a pixel centre hits the triangle (v0, v0 + e1, v0 + e2) where det = e1 . (d x e2), u = -(v0 . (d x e2)) /
+    det, v = (d . (e1 x v0)) / det: all three numerators are LINEAR in (dx, dy), so a face is three coefficient triples (fp32 cross
+    products, rounded once per face) and a pixel costs three linear forms and one reciprocal.  -> (det coefficients a, u-numerator
+    coefficients un); the v numerator's are q = e1 x v0 as before."""
+    a = np.array([e1[2] * e2[1] - e1[1] * e2[2], e1[0] * e2[2] - e1[2] * e2[0], e1[1] * e2[0] - e1[0] * e2[1]], f32)
+    un = np.array([v0[1] * e2[2] - v0[2] * e2[1], v0[2] * e2[0] - v0[0] * e2[2], v0[0] * e2[1] - v0[1] * e2[0]], f32)
+    return a, un
 
 
 def raster_zbuf(verts, faces, R, T, H, W, tan_half_fov, z_clip=0.5, eps=1e-6):
@@ -35,14 +45,12 @@ def raster_zbuf(verts, faces, R, T, H, W, tan_half_fov, z_clip=0.5, eps=1e-6):
         e1, e2 = v1 - v0, v2 - v0
         q = np.array([e1[1] * v0[2] - e1[2] * v0[1], e1[2] * v0[0] - e1[0] * v0[2], e1[0] * v0[1] - e1[1] * v0[0]], f32)
         tnum = (e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]
-        p0 = dy * e2[2] - e2[1]
-        p1 = e2[0] - dx * e2[2]
-        p2 = dx * e2[1] - dy * e2[0]
-        det = (e1[0] * p0 + e1[1] * p1) + e1[2] * p2
+        a, un = plane_forms(v0, e1, e2)
+        det = (a[0] * dx + a[1] * dy) + a[2]
         ok = np.abs(det) >= f32(1e-12)
         with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
             inv = f32(1) / det
-            u = -((v0[0] * p0 + v0[1] * p1) + v0[2] * p2) * inv
+            u = ((un[0] * dx + un[1] * dy) + un[2]) * inv
             v = ((dx * q[0] + dy * q[1]) + q[2]) * inv
             z = tnum * inv
             hit = ok & (u >= -f32(eps)) & (v >= -f32(eps)) & (u + v <= f32(1) + f32(eps)) & (z > zc) & (z < zb)
@@ -73,14 +81,12 @@ def raster_rgbz(verts, faces, colors, R, T, H, W, tan_half_fov, ambient=0.85, co
         e1, e2 = v1 - v0, v2 - v0
         q = np.array([e1[1] * v0[2] - e1[2] * v0[1], e1[2] * v0[0] - e1[0] * v0[2], e1[0] * v0[1] - e1[1] * v0[0]], f32)
         tnum = (e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]
-        p0 = dy * e2[2] - e2[1]
-        p1 = e2[0] - dx * e2[2]
-        p2 = dx * e2[1] - dy * e2[0]
-        det = (e1[0] * p0 + e1[1] * p1) + e1[2] * p2
+        a, un = plane_forms(v0, e1, e2)
+        det = (a[0] * dx + a[1] * dy) + a[2]
         ok = np.abs(det) >= f32(1e-12)
         with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
             inv = f32(1) / det
-            u = -((v0[0] * p0 + v0[1] * p1) + v0[2] * p2) * inv
+            u = ((un[0] * dx + un[1] * dy) + un[2]) * inv
             v = ((dx * q[0] + dy * q[1]) + q[2]) * inv
             z = tnum * inv
             hit = ok & (u >= -f32(eps)) & (v >= -f32(eps)) & (u + v <= f32(1) + f32(eps)) & (z > zc) & (z < zb)
