@@ -35,6 +35,12 @@ extern "C" {
 int nbp_abi_version(void);
 /* Writes gcnArchName / CU count of the current device (host strings/ints). */
 int nbp_device_info(char* arch_host, int arch_len, int* cu_count_host);
+/* The library's launch plans (tile choice, split-K bounds, fusions) are compile-time constants.  Their A/B switches (NBP_*
+ * environment variables) are honoured ONLY when the process sets NBP_TUNING=1; an inherited environment
+ * never changes results.  nbp_tuning_active: 1 when the opt-in is set.  nbp_tuning_report: writes "NAME=value,..." of the
+ * switches read so far whose value differs from the default into buf_host (truncated to len - 1) and returns their number. */
+int nbp_tuning_active(void);
+int nbp_tuning_report(char* buf_host, int len);
 
 /* ================================================================ A1: NBP network
  * Replaces NBP.forward, next_best_path/networks/nbp_model.py:110-160 (and the layer

@@ -19,6 +19,8 @@ _vp, _i, _ll, _f, _sz, _d = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_si
 SIGNATURES = {
     "nbp_abi_version": (_i, []),
     "nbp_device_info": (_i, [C.c_char_p, _i, C.POINTER(_i)]),
+    "nbp_tuning_active": (_i, []),
+    "nbp_tuning_report": (_i, [C.c_char_p, _i]),
     "nbp_packed_weights_bytes": (_sz, []),
     "nbp_pack_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, _sz, _vp, C.POINTER(_vp)]),
     "nbp_free_weights": (None, [_vp]),
@@ -201,6 +203,46 @@ def ptr(t) -> int:
     if not t.is_contiguous():
         raise ValueError("tensor passed to the HIP path must be contiguous")
     return t.data_ptr()
+
+
+# ---- A/B switches of the host side: the same gate as the library's (csrc/nbp_tuning.cpp).  A switch keeps its default unless
+# the process opted in with NBP_TUNING=1 AND sets the variable, so an inherited environment never changes results.
+_knobs = {}
+# switches that change the ARITHMETIC (results differ beyond reordering): a benchmark line measured with one of them set is
+# not the headline configuration (bench.py refuses to call it `value`)
+NUMERICS_KNOBS = {"NBP_CONV_PRECISION", "NBP_TRAIN_SPLIT", "NBP_TRAIN_WGRAD_SPLIT", "NBP_SPLIT_MAX_K", "NBP_SPLIT_MAX_K_SMALL",
+                  "NBP_SPLIT_SMALL_MB", "NBP_SPLIT_R8_SK", "NBP_SPLIT_HALO", "NBP_SPLIT_UP", "NBP_SPLIT_GATE", "NBP_GATE_PSI",
+                  "NBP_SPLIT_MIN_BLOCKS", "NBP_SPLIT_DEEP", "NBP_CONV_HEAD", "NBP_F32_HALO", "NBP_F32_HALO4", "NBP_F32_HALO_MIN",
+                  "NBP_BF16_UP", "NBP_BF16_HALO", "NBP_BF16_PSI", "NBP_BF16_FUSE", "NBP_FIRST_MFMA", "NBP_WGRAD_HALO",
+                  "NBP_WGRAD_BLOCKS", "NBP_TRAIN_FUSE"}
+
+
+def tuning_active() -> bool:
+    return os.environ.get("NBP_TUNING") == "1"
+
+
+def tune(name: str, default: str) -> str:
+    """String-valued A/B switch `name`: `default` unless NBP_TUNING=1 and the variable is set.  Recorded for effective_knobs()."""
+    v = default
+    if tuning_active():
+        e = os.environ.get(name)
+        if e is not None and e != "":
+            v = e
+    _knobs[name] = (default, v)
+    return v
+
+
+def effective_knobs() -> dict:
+    """{name: value} of every switch (host side and library) read so far whose value differs from its default."""
+    out = {k: v for k, (d, v) in _knobs.items() if v != d}
+    if _lib is not None:
+        buf = C.create_string_buffer(4096)
+        if _lib.nbp_tuning_report(buf, 4096) > 0:
+            for item in buf.value.decode().split(","):
+                if "=" in item:
+                    k, v = item.split("=", 1)
+                    out[k] = v
+    return out
 
 
 _raw_stream = None

@@ -23,6 +23,10 @@ static inline int nbp_launch_status() {
         if (cond) return (code);  \
     } while (0)
 
+// A/B switch of a launch plan: `dflt` unless the process opted in with NBP_TUNING=1 AND sets the variable (nbp_tuning.cpp: the
+// one place the library reads the environment; read once, recorded for nbp_tuning_report).  `name` must be a string literal.
+int nbp_tune_int(const char* name, int dflt);
+
 static inline long long nbp_cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
 // grid size for grid-stride elementwise kernels: enough blocks to fill 256 CUs x 8.

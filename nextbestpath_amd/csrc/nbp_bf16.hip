@@ -283,7 +283,6 @@ struct RowsFuse {
     const float* head_scale;
     const float* head_shift;
     float* head_out;            // [M]
-    int ko;                     // diagnosis only (NBP_ROWS64_KO): knock-out bits
 };
 
 template <int TN, int TPS, bool PH>
@@ -532,214 +531,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(IgemmArgsH a,
     }
 }
 
-// ------------------------------------------------------------------ 3x3 convolution, 64 output channels per workgroup, weights in registers
-// The 64-channel layers (full resolution: the largest pixel counts of the network) sit at the HBM / MFMA ridge, and with ONE MFMA per
-// product the kernel above is bound by its LDS fragment reads there: a wave tile of 2 x 2 (32 x 32) blocks reads 2 + 2 fragments for
-// 4 MFMAs per tap, i.e. the LDS is as busy as the matrix pipe.  This kernel cuts the reads per MFMA in half:
-//   * a workgroup owns 16 rows x 32 pixels x 64 channels, a wave 4 CONSECUTIVE image rows x 64 channels (4 x 2 blocks, 128 accumulators);
-//   * per 16-channel chunk (one MFMA k-step) a wave loads the 9 taps x 2 weight fragments ONCE into registers (72 VGPRs), then walks the
-//     6 halo rows it needs: 3 activation fragments per halo row (the column shifts) serve every (filter row, image row) pair that
-//     lands on that halo row -- 18 + 18 fragment reads for 72 MFMAs (0.5 per MFMA; 1.0 above);
-//   * both operands arrive by LDS DMA in the fragment layout ([k half][pixel or channel][8 bf16]: every 8 lanes of a ds_read_b128 read
-//     128 contiguous bytes), double buffered per chunk: ONE barrier per 72 MFMAs per wave, two workgroups per CU (76 KB each).
-// The taps of a chunk are visited in halo-row order, not in the (chunk, tap, k) order of the other bf16 kernels: the fp32 sums differ
-// by re-association and the tests hold this kernel to the same <= 1 ulp (of bf16) bound against the exact result, not to bit equality.
-// MEASURED SLOWER than conv3x3_halo_bf16_kernel<2,2> once that kernel stored whole lines (profiles/r03/
-// bf16_epilogue_rows64.txt: a 64-channel tile is bound by its workgroup's fixed costs, stores and DMA, which add up, not by fragment
-// reads; 16-channel chunks also fetch every pixel line four times).  Kept selectable (tile 14, NBP_BF16_ROWS64=1) with its knock-out
-// switches (NBP_ROWS64_KO, diagnosis only) as the evidence for that statement.
-
-__global__ __launch_bounds__(256, 2) void conv3x3_rows64_bf16_kernel(IgemmArgsH a, RowsFuse f) {
-    if (blockIdx.z) {
-        a.src0 = a.g_src0; a.src1 = a.g_src1; a.wpk = a.g_wpk; a.scale = a.g_scale; a.shift = a.g_shift; a.out = a.g_out;
-    }
-    constexpr int HW_ = 34, HROWS = 18, HPIX = HROWS * HW_;       // 612 halo pixels
-    constexpr int HINSTR = (HPIX + 63) / 64;                      // 10 DMA instructions of 64 pixels per k-half plane
-    constexpr int RS = HINSTR * 1024;                             // one k-half plane of the halo tile
-    constexpr int HALO_BYTES = 2 * RS;                            // 20 KB
-    constexpr int W_BYTES = 9 * 2 * 64 * 16;                      // [tap][k half][n][8 bf16]: 18 KB
-    constexpr int BUF = HALO_BYTES + W_BYTES;                     // 38 KB; two buffers
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = a.W >> 5, tiles_y = a.H >> 4;
-    unsigned tile = blockIdx.x, nt = blockIdx.y;
-    if (a.xcd_remap) {      // XCD-contiguous runs of (pixel tile, channel block), channel block fastest
-        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, T = gridDim.x * gridDim.y;
-        const unsigned xcd = L & 7u, idx = L >> 3, q = T >> 3, r = T & 7u;
-        const unsigned v = xcd * q + min(xcd, r) + idx;
-        nt = v % gridDim.y;
-        tile = v / gridDim.y;
-    }
-    const int tx = tile % tiles_x; tile /= tiles_x;
-    const int ty = tile % tiles_y;
-    const int b = tile / tiles_y;
-    const int y0 = ty * 16, x0 = tx * 32;
-    const int n0 = nt * 64;
-
-    // halo DMA: instruction q = wave + 4 i (q < 20) = (k half q / 10, pixels 64 (q % 10) ..+63); lane = pixel
-    int hpix[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int q = wave + 4 * i;
-        const int hp = (q % HINSTR) * 64 + lane;
-        const int hy = hp / HW_, hx = hp - hy * HW_;
-        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-        const bool ok = hp < HPIX && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-        hpix[i] = ok ? (b * a.Hs + (yy >> a.ups)) * a.Ws + (xx >> a.ups) : -1;
-    }
-    const __amdgpu_buffer_rsrc_t rs0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.src0), 0, a.bytes0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.src1 ? a.src1 : a.src0), 0, a.bytes1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wpk), 0, a.bytesw, 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
-    const int c16_0 = a.C0 >> 4;
-
-    auto issue = [&](int c, char* buf) {       // 16-channel chunk c of the concatenated input -> buf
-        const bool first = c < c16_0;
-        const bool ko_h = (f.ko & 1) && c > 0, ko_w = (f.ko & 2) && c > 0;
-        const int Cs = first ? a.C0 : a.C1;
-        const int cbase = (first ? c : c - c16_0) * 16;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int q = wave + 4 * i;
-            const int kh = q / HINSTR;
-            const unsigned off = hpix[i] >= 0 ? (unsigned)(hpix[i] * Cs + cbase + kh * 8) * 2u : OOB;
-            if (ko_h) continue;
-            if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(buf + q * 1024), 16, off, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(buf + q * 1024), 16, off, 0, 0, 0);
-        }
-        // weights: packed [c / 64][tap][N][64]; instruction u = wave + 4 i (u < 18) = (tap u / 2, k half u % 2); lane = channel
-        const int c64 = c >> 2, sub = c & 3;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int u = wave + 4 * i;
-            if (u < 18 && !ko_w) {
-                const int tap = u >> 1, kh = u & 1;
-                const unsigned woff = (unsigned)((((c64 * 9 + tap) * a.N + n0 + lane) * 64) + (sub * 2 + kh) * 8) * 2u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(buf + HALO_BYTES + u * 1024), 16, woff, 0, 0, 0);
-            }
-        }
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int khalf = lane >> 5;
-    const int aoff = khalf * RS + ((4 * wave) * HW_ + (lane & 31)) * 16;          // + (halo row * 34 + column shift) * 16
-    const int woff_l = HALO_BYTES + (khalf * 64 + (lane & 31)) * 16;               // + (tap * 2 * 64 + j * 32) * 16
-
-    const int c_end = (a.C0 + a.C1) >> 4;
-    issue(0, lds);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int c = 0; c < c_end; ++c) {
-        const char* cur = lds + (c & 1) * BUF;
-        if (c + 1 < c_end) issue(c + 1, lds + ((c + 1) & 1) * BUF);
-        if (f.ko & 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); continue; }
-        bf16x8 wf[9][2];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) wf[tap][j] = *reinterpret_cast<const bf16x8*>(cur + woff_l + (tap * 128 + j * 32) * 16);
-#pragma unroll
-        for (int h = 0; h < 6; ++h) {
-            bf16x8 xf[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(cur + aoff + (h * HW_ + t) * 16);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int i = h - r;
-                if (i < 0 || i > 3) continue;
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[r * 3 + t][j], xf[t], acc[i][j], 0, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane = pixel (lane & 31) of image row y0 + 4 wave + i; registers 4 rq .. 4 rq + 3 = channels 8 rq + 4 khalf ..+3 of block j.
-    // A lane holds 8-byte pieces of 32 different pixels' rows: stored directly, every store instruction would touch 32 lines with 16
-    // bytes each (the L2 takes a request per piece: measured 4 x the time of the whole tile's MFMAs).  The wave transposes its 4 rows x
-    // 32 pixels x 64 channels through LDS instead (the staging buffers are idle now; 144-byte pixel rows: 2-way conflicts at most)
-    // and stores 16 bytes per lane, 8 lanes per pixel: whole 128-byte lines.
-    const bool head = f.head_w != nullptr;
-    float hdot[4] = {0.f, 0.f, 0.f, 0.f};
-    constexpr int TR = 144;                                        // bytes per pixel row of the transpose image
-    char* const tr = lds + wave * (128 * TR);                     // this wave's 128 pixels
-    static_assert(4 * 128 * TR <= 2 * BUF, "transpose image fits the staging buffers");
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int nl = j * 32 + 8 * rq + 4 * khalf;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n0 + nl);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n0 + nl);
-            f32x4 hw = {0.f, 0.f, 0.f, 0.f};
-            if (head) hw = *reinterpret_cast<const f32x4*>(f.head_w + n0 + nl);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                u16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = fmaf(acc[i][j][4 * rq + e], sc[e], sh[e]);
-                    if (a.relu) t = fmaxf(t, 0.f);
-                    o[e] = f2bf(t);
-                    // the head reads what the next layer would have read: the bf16-rounded activations
-                    if (head) hdot[i] = fmaf(bf2f(o[e]), hw[e], hdot[i]);
-                }
-                if (!head) *reinterpret_cast<u16x4*>(tr + (i * 32 + (lane & 31)) * TR + nl * 2) = o;
-            }
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave reads back only what it wrote itself
-    if (!head) {
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int idx = it * 64 + lane, p = idx >> 3, slot = idx & 7;         // pixel p = row p / 32, column p % 32
-            const u16x8 o = *reinterpret_cast<const u16x8*>(tr + p * TR + slot * 16);
-            const long long m = ((long long)b * a.H + y0 + 4 * wave + (p >> 5)) * a.W + x0 + (p & 31);
-            if (f.ko & 8) { if (o[0] == 0x7fc1) a.out[0] = 1; continue; }
-            *reinterpret_cast<u16x8*>(a.out + m * a.N + n0 + slot * 8) = o;
-        }
-    }
-    if (f.pool_out) {       // 2 x 2 max-pool from the same image (post-ReLU bf16: the bit patterns order like the values)
-        const int Hp = a.H >> 1, Wp = a.W >> 1;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = it * 64 + lane, p = idx >> 3, slot = idx & 7;         // pooled pixel p = row p / 16, column p % 16
-            const char* src = tr + ((p >> 4) * 64 + (p & 15) * 2) * TR + slot * 16;
-            const u16x8 v00 = *reinterpret_cast<const u16x8*>(src), v01 = *reinterpret_cast<const u16x8*>(src + TR);
-            const u16x8 v10 = *reinterpret_cast<const u16x8*>(src + 32 * TR), v11 = *reinterpret_cast<const u16x8*>(src + 33 * TR);
-            u16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = max(max(v00[e], v01[e]), max(v10[e], v11[e]));
-            const long long mp = ((long long)b * Hp + ((y0 + 4 * wave) >> 1) + (p >> 4)) * Wp + (x0 >> 1) + (p & 15);
-            *reinterpret_cast<u16x8*>(f.pool_out + mp * a.N + n0 + slot * 8) = o;
-        }
-    }
-    if (head) {
-        const float hs = f.head_scale[0], ht = f.head_shift[0];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float d = hdot[i] + __shfl_xor(hdot[i], 32);
-            const long long m = ((long long)b * a.H + y0 + 4 * wave + i) * a.W + x0 + (lane & 31);
-            if (!khalf) f.head_out[m] = 1.f / (1.f + expf(-(d * hs + ht)));
-        }
-    }
-}
-
 struct ReduceGroupH { const float* scale; const float* shift; bf16_t* out; };
 __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ partial_all, int split_k,
                                                                  long long MN, int N, ReduceGroupH g0, ReduceGroupH g1,
@@ -772,7 +563,6 @@ static TileInfo tile_info_h(int tile) {
         case NBP_TILE_HALO_64: return {256, 64};
         case NBP_TILE_HALO_UP_128: return {256, 128};
         case NBP_TILE_HALO_UP_64: return {256, 64};
-        case NBP_TILE_ROWS_64: return {512, 64};
         case NBP_TILE_128x128: return {128, 128};
         case NBP_TILE_256x64: return {256, 64};
         case NBP_TILE_256x32: return {256, 32};
@@ -782,10 +572,6 @@ static TileInfo tile_info_h(int tile) {
     }
 }
 
-static bool rows64_ok(int H, int W, int N, int ksize) {
-    return ksize == 3 && H >= 16 && W >= 32 && (H & 15) == 0 && (W & 31) == 0 && N % 64 == 0;
-}
-
 static bool halo_ok(int H, int W, int N, int ksize, int bn) {
     return ksize == 3 && H >= 8 && W >= 32 && (H & 7) == 0 && (W & 31) == 0 && N % bn == 0;
 }
@@ -793,13 +579,13 @@ static bool halo_ok(int H, int W, int N, int ksize, int bn) {
 ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int split_k, int groups, int H, int W,
                             int ksize, int ups) {
     ConvPlan p;
-    static const int allow_up = [] { const char* e = getenv("NBP_BF16_UP"); return e ? atoi(e) : 1; }();
+    static const int allow_up = nbp_tune_int("NBP_BF16_UP", 1);
     if ((tile == NBP_TILE_AUTO && allow_up && ups && ksize == 3 && split_k <= 0) || tile == NBP_TILE_HALO_UP_128 ||
         tile == NBP_TILE_HALO_UP_64) {
         // up_conv as four parity convolutions of the low-resolution image (8 x 32 low-resolution tiles)
         const int bn = tile == NBP_TILE_HALO_UP_128 ? 128 : tile == NBP_TILE_HALO_UP_64 ? 64 : (N % 128 == 0 ? 128 : 64);
         if (!((H | W) & 1) && halo_ok(H / 2, W / 2, N, 3, bn)) {
-            static const int min_blocks_up = [] { const char* e = getenv("NBP_BF16_HALO_MIN"); return e ? atoi(e) : 128; }();
+            static const int min_blocks_up = nbp_tune_int("NBP_BF16_HALO_MIN", 128);
             const long long blocks = (M / 4 / 256) * (N / bn) * groups * 4;
             const int cc = chunks_total / 9;
             int sk = split_k <= 0 ? 1 : split_k;
@@ -813,22 +599,12 @@ ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int 
         }
         if (tile != NBP_TILE_AUTO) { p.tile = -1; p.split_k = 1; p.chunks_per_split = chunks_total; return p; }
     }
-    if (tile == NBP_TILE_ROWS_64 || (tile == NBP_TILE_AUTO && ksize == 3 && split_k <= 0 && N == 64)) {
-        // 64-channel layers: the weights-in-registers kernel once its 512-pixel tiles fill the chip (no split-K form)
-        static const int allow_rows = [] { const char* e = getenv("NBP_BF16_ROWS64"); return e ? atoi(e) : 0; }();
-        static const int min_rows = [] { const char* e = getenv("NBP_BF16_ROWS64_MIN"); return e ? atoi(e) : 256; }();
-        const bool ok = rows64_ok(H, W, N, ksize) && split_k <= 1;
-        if (tile == NBP_TILE_ROWS_64 || (allow_rows && ok && (M / 512) * (N / 64) * groups >= min_rows)) {
-            p.tile = ok ? NBP_TILE_ROWS_64 : -1; p.split_k = 1; p.chunks_per_split = chunks_total;
-            return p;
-        }
-    }
     if (tile == NBP_TILE_AUTO && ksize == 3 && split_k <= 0) {
         // halo-tile kernel once tiles (x split-K over whole chunks) give >= ~128 workgroups
         // (threshold from tools/bench_forward.py sweeps at B = 1..8, S = 256 / 512)
-        static const int allow = [] { const char* e = getenv("NBP_BF16_HALO"); return e ? atoi(e) : 1; }();
+        static const int allow = nbp_tune_int("NBP_BF16_HALO", 1);
         const int bn = N % 128 == 0 ? 128 : 64;
-        static const int min_blocks = [] { const char* e = getenv("NBP_BF16_HALO_MIN"); return e ? atoi(e) : 128; }();
+        static const int min_blocks = nbp_tune_int("NBP_BF16_HALO_MIN", 128);
         const long long blocks = (M / 256) * (N / bn) * groups;
         const int cc = chunks_total / 9;
         int sk = 1;
@@ -885,20 +661,6 @@ static int launch_halo(const IgemmArgsH& a, const RowsFuse& f, hipStream_t st) {
     }
     dim3 grid((unsigned)(a.M / (PH ? 4 : 1) / 256), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups * (PH ? 4 : 1)));
     conv3x3_halo_bf16_kernel<TN, TPS, PH><<<grid, 256, smem, st>>>(a, f);
-    return nbp_launch_status();
-}
-
-static int launch_rows64(const IgemmArgsH& a, const RowsFuse& f, hipStream_t st) {
-    constexpr size_t smem = 2 * (2 * 10 * 1024 + 9 * 2 * 64 * 16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rows64_bf16_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    dim3 grid((unsigned)(a.M / 512), (unsigned)(a.N / 64), (unsigned)a.groups);
-    conv3x3_rows64_bf16_kernel<<<grid, 256, smem, st>>>(a, f);
     return nbp_launch_status();
 }
 
@@ -965,10 +727,9 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
     }
     if (p.tile == NBP_TILE_HALO_128 || p.tile == NBP_TILE_HALO_64)
         NBP_RETURN_IF(!halo_ok(H, W, N, ksize, ti.bn), NBP_E_SHAPE);
-    if (p.tile == NBP_TILE_ROWS_64) NBP_RETURN_IF(!rows64_ok(H, W, N, ksize) || p.split_k != 1, NBP_E_SHAPE);
     a.split_k = p.split_k; a.chunks_per_split = p.chunks_per_split;
     {
-        static const int forced = [] { const char* e = getenv("NBP_XCD_REMAP"); return e ? atoi(e) : -1; }();
+        static const int forced = nbp_tune_int("NBP_XCD_REMAP", -1);
         a.xcd_remap = forced >= 0 ? forced : ((a.M / 256) * (N / ti.bn) >= 512 ? 1 : 0);
     }
     a.partial = nullptr;
@@ -977,15 +738,15 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
         a.partial = (float*)ws;
     }
     // epilogue fusions of the halo kernels: only a launch that writes final values of one group can take them
-    RowsFuse f{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    RowsFuse f{nullptr, nullptr, nullptr, nullptr, nullptr};
     {
-        static const int allow_fuse = [] { const char* e = getenv("NBP_BF16_FUSE"); return e ? atoi(e) : 1; }();
-        const bool halo = p.tile == NBP_TILE_HALO_128 || p.tile == NBP_TILE_HALO_64 || p.tile == NBP_TILE_ROWS_64;
+        static const int allow_fuse = nbp_tune_int("NBP_BF16_FUSE", 1);
+        const bool halo = p.tile == NBP_TILE_HALO_128 || p.tile == NBP_TILE_HALO_64;
         if (allow_fuse && halo && groups == 1 && p.split_k == 1 && !ups && relu && !((H | W) & 1) && pool_out && pool_out[0]) {
             f.pool_out = pool_out[0];
             if (pooled) *pooled = 1;
         }
-        if (allow_fuse && !f.pool_out && (p.tile == NBP_TILE_HALO_64 || p.tile == NBP_TILE_ROWS_64) && groups == 1 && p.split_k == 1 &&
+        if (allow_fuse && !f.pool_out && p.tile == NBP_TILE_HALO_64 && groups == 1 && p.split_k == 1 &&
             N == 64 && relu && head && head->w && head->scale && head->shift && head->out) {
             f.head_w = head->w; f.head_scale = head->scale; f.head_shift = head->shift; f.head_out = head->out;
             if (headed) *headed = 1;
@@ -994,7 +755,7 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
     // the attention gate's tail rides in the 1x1 GEMM over [g | x] when a wave holds all N columns of its pixels
     GatePsiH gp{{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     {
-        static const int allow_psi = [] { const char* e = getenv("NBP_BF16_PSI"); return e ? atoi(e) : 1; }();
+        static const int allow_psi = nbp_tune_int("NBP_BF16_PSI", 1);
         const bool whole_n = (p.tile == NBP_TILE_256x64 && N == 64) || (p.tile == NBP_TILE_256x32 && N == 32);
         if (allow_psi && psi && whole_n && ksize == 1 && C1 == C0 && p.split_k == 1 && relu && psi->wpsi[0] && psi->st[0] && psi->gated[0] &&
             (groups == 1 || (psi->wpsi[1] && psi->st[1] && psi->gated[1]))) {
@@ -1009,17 +770,11 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
         case NBP_TILE_256x32: rc = launch_igemm_h<4, 1, 2, 1>(a, st, gp); break;
         case NBP_TILE_128x64: rc = launch_igemm_h<2, 2, 2, 1>(a, st); break;
         case NBP_TILE_64x128: rc = launch_igemm_h<1, 4, 2, 1>(a, st); break;
-        case NBP_TILE_ROWS_64: {
-            static const int ko = [] { const char* e = getenv("NBP_ROWS64_KO"); return e ? atoi(e) : 0; }();
-            f.ko = ko;
-            rc = launch_rows64(a, f, st);
-            break;
-        }
         case NBP_TILE_HALO_128: rc = launch_halo<4, 1>(a, f, st); break;
         case NBP_TILE_HALO_UP_128: rc = launch_halo<4, 1, true>(a, f, st); break;
         case NBP_TILE_HALO_UP_64: rc = launch_halo<2, 2, true>(a, f, st); break;
         case NBP_TILE_HALO_64: {
-            static const int tps = [] { const char* e = getenv("NBP_BF16_TPS"); return e ? atoi(e) : 2; }();
+            static const int tps = nbp_tune_int("NBP_BF16_TPS", 2);
             rc = tps == 2 ? launch_halo<2, 2>(a, f, st) : launch_halo<2, 1>(a, f, st);
             break;
         }
@@ -1207,7 +962,7 @@ int nbp_conv_first_bf16_launch(const float* x_nchw, int B, int H, int W, const f
     NBP_RETURN_IF(!x_nchw || !w_oihw || !scale || !shift || !out_nhwc, NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 1 || W < 1, NBP_E_ARG);
     long long M = (long long)B * H * W;
-    static const int use_mfma = [] { const char* e = getenv("NBP_FIRST_MFMA"); return e ? atoi(e) : 1; }();
+    static const int use_mfma = nbp_tune_int("NBP_FIRST_MFMA", 1);
     if (use_mfma && (H & 7) == 0 && (W & 31) == 0) {
         conv_first_mfma_bf16_kernel<<<(unsigned)(M / 256 < 2048 ? M / 256 : 2048), 256, 0, st>>>(x_nchw, B, H, W, w_oihw, scale, shift, out_nhwc);
         return nbp_launch_status();

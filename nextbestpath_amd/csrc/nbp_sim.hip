@@ -1027,7 +1027,7 @@ static int raster_launch(const float* verts, int n_verts, const int* faces, int 
         e = hipMemsetAsync(gray, 0, (size_t)n_frames * sizeof(double), st);
         if (e != hipSuccess) return (int)e;
     }
-    static const int SEG = [] { const char* v = getenv("NBP_RASTER_SEG"); return v && atoi(v) >= 1024 ? atoi(v) / 1024 * 1024 : SEG_DEFAULT; }();
+    static const int SEG = [] { const int v = nbp_tune_int("NBP_RASTER_SEG", SEG_DEFAULT); return v >= 1024 ? v / 1024 * 1024 : SEG_DEFAULT; }();
     const int nseg = (int)nbp_cdiv(n_faces, SEG);
     dim3 g2((unsigned)(tiles_x * tiles_y * nseg), (unsigned)n_frames);
     raster_tile_kernel<<<g2, 64, 0, st>>>(recs, n_faces, H, W, tan_half_fov, z_clip, tiles_x, tiles_y, ctiles_x, ctiles_y,
@@ -1152,7 +1152,7 @@ extern "C" int nbp_raster_zface_batch_f32(int n, const float* const* verts, cons
     hipStream_t st = (hipStream_t)stream;
     const int ctiles_x = (int)nbp_cdiv(tiles_x, COARSE), ctiles_y = (int)nbp_cdiv(tiles_y, COARSE);
     const size_t nct = (size_t)ctiles_x * ctiles_y * n_frames;
-    static const int SEG = [] { const char* v = getenv("NBP_RASTER_SEG"); return v && atoi(v) >= 1024 ? atoi(v) / 1024 * 1024 : SEG_DEFAULT; }();
+    static const int SEG = [] { const int v = nbp_tune_int("NBP_RASTER_SEG", SEG_DEFAULT); return v >= 1024 ? v / 1024 * 1024 : SEG_DEFAULT; }();
     RasterBatch b;
     unsigned g_setup = 1, g_tile = 1;
     for (int r = 0; r < STEP_BATCH; ++r) {

@@ -980,9 +980,9 @@ int launch_h2(const SplitArgs& a, hipStream_t st) {
 // amplification of ANY rounding difference (profiles/r03/layer_substitution_hard.txt: ONE inexact layer at 1e-9 of its range
 // moves out1 by 1e-8 .. 9e-8 of its range, whichever arithmetic computes it).
 static int chain_bounded_split(int sk, int cc, int taps, long long M, int N, int groups) {
-    static const int max_k = [] { const char* e = getenv("NBP_SPLIT_MAX_K"); return e ? atoi(e) : NBP_SPLIT_MAX_K_DEFAULT; }();
-    static const int max_k_small = [] { const char* e = getenv("NBP_SPLIT_MAX_K_SMALL"); return e ? atoi(e) : NBP_SPLIT_MAX_K_SMALL_DEFAULT; }();
-    static const int small_mb = [] { const char* e = getenv("NBP_SPLIT_SMALL_MB"); return e ? atoi(e) : 64; }();
+    static const int max_k = nbp_tune_int("NBP_SPLIT_MAX_K", NBP_SPLIT_MAX_K_DEFAULT);
+    static const int max_k_small = nbp_tune_int("NBP_SPLIT_MAX_K_SMALL", NBP_SPLIT_MAX_K_SMALL_DEFAULT);
+    static const int small_mb = nbp_tune_int("NBP_SPLIT_SMALL_MB", 64);
     const bool small = (double)M * N * groups * 4.0 <= (double)small_mb * 1048576.0;
     const int mk = small && max_k_small > 0 ? max_k_small : max_k;
     if (mk <= 0) return sk;
@@ -999,7 +999,7 @@ static int chain_bounded_split(int sk, int cc, int taps, long long M, int N, int
 // workgroups (before split-K) the launch uses 8 x 32-pixel tiles: twice the workgroups, half the MFMAs per stage, the same sums in the
 // same order (NBP_SPLIT_R8_BLOCKS, 0 = never)
 static long long half_rows_below() {
-    static const int v = [] { const char* e = getenv("NBP_SPLIT_R8_BLOCKS"); return e ? atoi(e) : 256; }();
+    static const int v = nbp_tune_int("NBP_SPLIT_R8_BLOCKS", 256);
     return v;
 }
 
@@ -1007,7 +1007,7 @@ static long long half_rows_below() {
 // the 16-row plan (0): fewer slices are longer accumulation chains -- inside the chain bound, but the rollout-input error statistics of
 // tests/test_gpu_rollout_parity.py sit at the bound's edge then
 static bool r8_counts_double() {
-    static const int v = [] { const char* e = getenv("NBP_SPLIT_R8_SK"); return e ? atoi(e) : 0; }();
+    static const int v = nbp_tune_int("NBP_SPLIT_R8_SK", 0);
     return v != 0;
 }
 
@@ -1017,7 +1017,7 @@ static bool r8_counts_double() {
 // gain -- its workgroups run alone on their CUs, 1.7 x faster -- and pays the 8-row tiles' doubled weight traffic (+0.3 .. +0.9 %), so
 // the rule takes tails of up to 160 workgroups only (NBP_SPLIT_R8_TAIL = that bound, 0 = off).
 static bool half_rows_for_tail(long long workgroups) {
-    static const int bound = [] { const char* e = getenv("NBP_SPLIT_R8_TAIL"); return e ? atoi(e) : 160; }();
+    static const int bound = nbp_tune_int("NBP_SPLIT_R8_TAIL", 160);
     if (bound <= 0 || workgroups <= 512) return false;
     const long long rem = workgroups % 512;
     return rem > 0 && rem <= bound;
@@ -1025,12 +1025,12 @@ static bool half_rows_for_tail(long long workgroups) {
 
 ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize, int ups) {
     ConvPlan p{0, 1, chunks_total};
-    static const int allow = [] { const char* e = getenv("NBP_SPLIT_HALO"); return e ? atoi(e) : 1; }();
-    static const int allow_up = [] { const char* e = getenv("NBP_SPLIT_UP"); return e ? atoi(e) : 1; }();
+    static const int allow = nbp_tune_int("NBP_SPLIT_HALO", 1);
+    static const int allow_up = nbp_tune_int("NBP_SPLIT_UP", 1);
     if (allow && allow_up && ups && !((H | W) & 1)) {
         const int twu = split_tile_width(H / 2, W / 2, N, ksize);
         if (twu) {
-            static const int min_blocks_up = [] { const char* e = getenv("NBP_SPLIT_MIN_BLOCKS"); return e ? atoi(e) : 256; }();
+            static const int min_blocks_up = nbp_tune_int("NBP_SPLIT_MIN_BLOCKS", 256);
             const int cc = chunks_total / 9 * 2;
             long long blocks = (M / 4 / (16 * twu)) * (N / (twu == 32 ? 64 : 128)) * groups * 4;
             const bool r8 = blocks < half_rows_below();      // 8-row tiles: twice the workgroups, half the chain each
@@ -1051,7 +1051,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
     }
     // one workgroup per CU without split-K beats two with it: the partial sums cost more than the idle barrier slots
     // (B = 4 forward 2.65 ms at 256, 2.85 at 512, 2.89 at 128)
-    static const int min_blocks = [] { const char* e = getenv("NBP_SPLIT_MIN_BLOCKS"); return e ? atoi(e) : 256; }();
+    static const int min_blocks = nbp_tune_int("NBP_SPLIT_MIN_BLOCKS", 256);
     const int tw = allow ? split_tile_width(H, W, N, ksize) : 0;
     if (!tw) return p;
     const int cc = chunks_total / 9 * 2;      // the kernel's K chunks are 16 channels (chunks_total counts (32 channels, tap))
@@ -1065,7 +1065,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
         // one more halving of K towards two workgroups per CU, but only while a slice keeps >= deep_chunks 16-channel chunks: the
         // fixed cost of a workgroup (first halo, epilogue, its share of the reduce) is ~1.5 chunks (NBP_SPLIT_DEEP, 0 = off; measured
         // B = 12: 5.07 -> 5.02 ms, B = 8 / 1 unchanged, B = 4 +0.6 %; with 8 chunks B = 4 loses 2.5 %)
-        static const int deep = [] { const char* e = getenv("NBP_SPLIT_DEEP"); return e ? atoi(e) : 16; }();
+        static const int deep = nbp_tune_int("NBP_SPLIT_DEEP", 16);
         if (deep > 0 && blocks * sk < 2 * min_blocks && cc / (sk * 2) >= deep && sk < 16) sk *= 2;
         sk = chain_bounded_split(sk, cc, 9, M, N, groups);
     }
@@ -1128,7 +1128,7 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
         a.bytesw = (unsigned)bwu;
     }
     {
-        static const int forced = [] { const char* e = getenv("NBP_XCD_REMAP"); return e ? atoi(e) : -1; }();
+        static const int forced = nbp_tune_int("NBP_XCD_REMAP", -1);
         const long long ptiles = a.M / (ph ? 4 : 1) / (th * tw), nbk = N / (tw == 32 ? 64 : 128);
         const long long tiles = ptiles * nbk;
         // bytes that cross the fabric: mode 1 = 8 x weights + activations, mode 2 = weights + min(nbk, 8) x activations
@@ -1148,14 +1148,14 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
         a.partial = (float*)ws;
     }
     // the max-pool that follows an encoder block rides in the epilogue when the launch writes final values (no split-K)
-    static const int allow_pool = [] { const char* e = getenv("NBP_CONV_POOL"); return e ? atoi(e) : 1; }();
+    static const int allow_pool = nbp_tune_int("NBP_CONV_POOL", 1);
     const bool with_pool = allow_pool && pool_out && pool_out[0] && (groups == 1 || pool_out[1]) && p.split_k == 1 && !ph && !ups &&
                            !((H | W) & 1);
     if (pooled) *pooled = with_pool;
     if (with_pool)
         for (int g = 0; g < groups; ++g) a.g[g].pool_out = pool_out[g];
     // the one-channel sigmoid head that consumes this layer alone (Final2) rides in the epilogue instead of the layer's own store
-    static const int allow_head = [] { const char* e = getenv("NBP_CONV_HEAD"); return e ? atoi(e) : 1; }();
+    static const int allow_head = nbp_tune_int("NBP_CONV_HEAD", 1);
     const bool with_head = allow_head && head && head->w && head->scale && head->shift && head->out && groups == 1 && p.split_k == 1 &&
                            !ph && tw == 32 && N == 64 && relu;
     if (headed) *headed = with_head;
@@ -1240,7 +1240,7 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
     int bn = N % 128 == 0 ? 128 : (N % 64 == 0 ? 64 : 32);
     if (bn == 128 && nbp_cdiv(M, 128) * (N / 128) * groups < 512) bn = 64;
     // the gate's tail (psi, x * psi) runs in the epilogue when a workgroup holds every column of its pixels
-    static const int allow_psi = [] { const char* e = getenv("NBP_GATE_PSI"); return e ? atoi(e) : 1; }();
+    static const int allow_psi = nbp_tune_int("NBP_GATE_PSI", 1);
     const bool with_psi = allow_psi && psi && bn == N && psi->wpsi[0] && psi->st[0] && psi->gated[0] &&
                           (groups == 1 || (psi->wpsi[1] && psi->st[1] && psi->gated[1]));
     if (fused) *fused = with_psi;
@@ -1275,7 +1275,7 @@ int nbp_wgrad_split_launch(const float* src0, int C0, const float* src1, int C1,
     a.src0 = src0; a.src1 = src1 ? src1 : src0; a.C0 = C0; a.C1 = C1; a.ups = ups ? 1 : 0; a.H = H; a.W = W; a.Hs = Hs; a.Ws = Ws;
     a.dy = dy; a.N = N; a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0; a.bytesy = (unsigned)by;
     a.co_tiles = N / 64; a.n_tiles = n_tiles; a.splits = splits;
-    { static const int pf = [] { const char* e = getenv("NBP_WGRAD_PREFETCH"); return e ? atoi(e) : 1; }(); a.prefetch = pf; }
+    { static const int pf = nbp_tune_int("NBP_WGRAD_PREFETCH", 1); a.prefetch = pf; }
     a.amax0 = amax0_in ? amax0_in : amax3; a.amax1 = amax1_in ? amax1_in : amax3 + AMAX_WORDS;
     a.amaxy = amaxy_in ? amaxy_in : amax3 + 2 * AMAX_WORDS; a.part = part;
     const bool wide = W % 32 == 0 && H % 2 == 0;              // 2 x 32 tiles, else 4 x 16 (nbp_wgrad_split_ok)

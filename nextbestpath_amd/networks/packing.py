@@ -130,27 +130,73 @@ def _workspace(B, S, device, precision="fp32"):
     return ws
 
 
-def forward_packed(packed: PackedWeights, x: torch.Tensor, precision: str = None):
-    """precision overrides the handle's own only where the handle allows it ("fp32" on a "fp32_split" handle)."""
+def forward_packed(packed: PackedWeights, x: torch.Tensor, precision: str = None, out=None, ws=None):
+    """precision overrides the handle's own only where the handle allows it ("fp32" on a "fp32_split" handle).
+    out = (out1, out2) / ws: caller-owned result tensors and workspace (ForwardGraph: everything a captured launch touches
+    must outlive the graph)."""
     precision = precision or packed.precision
     if precision != packed.precision and not (precision == "fp32" and packed.precision == "fp32_split"):
         raise ValueError(f"weights packed for {packed.precision!r} cannot run the {precision!r} forward")
     B, _, S, _ = x.shape
     x = x.contiguous().float()
-    out1 = torch.empty(B, 8, S // 4, S // 4, dtype=torch.float32, device=x.device)
-    out2 = torch.empty(B, 1, S, S, dtype=torch.float32, device=x.device)
+    if out is None:
+        out1 = torch.empty(B, 8, S // 4, S // 4, dtype=torch.float32, device=x.device)
+        out2 = torch.empty(B, 1, S, S, dtype=torch.float32, device=x.device)
+    else:
+        out1, out2 = out
     fn = getattr(_lib.lib(), _FWD[precision][0])
     if torch.cuda.current_device() == x.device.index:       # the common case: no device-guard objects in the step loop
-        ws = _workspace(B, S, x.device, precision)          # (keyed by the current stream: looked up under the right device)
+        if ws is None:
+            ws = _workspace(B, S, x.device, precision)      # (keyed by the current stream: looked up under the right device)
         rc = fn(packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(), ws.data_ptr(), ws.numel(),
                 _lib.current_stream())
     else:
         with torch.cuda.device(x.device):
-            ws = _workspace(B, S, x.device, precision)
+            if ws is None:
+                ws = _workspace(B, S, x.device, precision)
             rc = fn(packed.handle, x.data_ptr(), B, S, out1.data_ptr(), out2.data_ptr(), ws.data_ptr(), ws.numel(),
                     _lib.current_stream())
     _lib.check(rc, _FWD[precision][0])
     return out1, out2
+
+
+class ForwardGraph:
+    """The eval forward on FIXED buffers, captured once into a hipGraph and replayed.
+
+    The reference's own usage is one forward per exploration step on one map (nbp_planning.py:166): ~60 kernel launches of a
+    few microseconds each, where the launch-to-launch gaps are a fifth of the time.  A rollout's network input is a persistent
+    tensor (RolloutState.net_in), so the whole launch sequence is replayable: same kernels, same arguments, same order -- the
+    outputs are bit-identical to the eager call's (tests/test_gpu_network.py::test_forward_graph_is_bit_identical).
+    `x` must stay alive and keep its address; `out1` / `out2` are overwritten by every replay (consume them on the replaying
+    stream before the next one)."""
+
+    def __init__(self, packed: PackedWeights, x: torch.Tensor, precision: str = None):
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+        precision = precision or packed.precision
+        B, _, S, _ = x.shape
+        L = _lib.lib()
+        self.packed, self.x, self.precision = packed, x, precision
+        with torch.cuda.device(x.device):
+            n = getattr(L, _FWD[precision][1])(B, S)
+            if n == 0:
+                raise _lib.NbpHipError(f"unsupported NBP input size B={B} S={S}")
+            self.ws = torch.empty(n, dtype=torch.uint8, device=x.device)
+            self.out1 = torch.empty(B, 8, S // 4, S // 4, dtype=torch.float32, device=x.device)
+            self.out2 = torch.empty(B, 1, S, S, dtype=torch.float32, device=x.device)
+            cur = torch.cuda.current_stream(x.device)
+            side = torch.cuda.Stream(x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):           # warm-up outside the capture: one-time function attributes, lazy module loads
+                forward_packed(packed, x, precision, (self.out1, self.out2), self.ws)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(x.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                forward_packed(packed, x, precision, (self.out1, self.out2), self.ws)
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out1, self.out2
 
 
 def forward_eval(module, x: torch.Tensor):

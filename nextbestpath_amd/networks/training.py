@@ -78,8 +78,8 @@ def _igemm(src0, src1, ups, wpk, N, ksize, scale, shift, relu):
 
 # 3x3 convolutions of the forward and of the data gradient on the fp16 matrix pipe through two-piece operand splitting
 # (csrc/nbp_split.hip: the fp32 pipe's accuracy at 5.3x its matrix rate); NBP_TRAIN_SPLIT=0 keeps the fp32 MFMA pipe.
-_SPLIT = os.environ.get("NBP_TRAIN_SPLIT", "1") != "0"
-_WGRAD_SPLIT = os.environ.get("NBP_TRAIN_WGRAD_SPLIT", "1") == "1"      # A/B: weight gradients on the fp32 pipe
+_SPLIT = _lib.tune("NBP_TRAIN_SPLIT", "1") != "0"
+_WGRAD_SPLIT = _lib.tune("NBP_TRAIN_WGRAD_SPLIT", "1") == "1"      # A/B: weight gradients on the fp32 pipe
 
 
 def _split_ok(H, W, N, ksize):
@@ -117,7 +117,7 @@ def _const(value, n, device):
 
 # ---- hand-off of what a producer already knows about its output to the convolution that consumes it (keyed by storage address,
 # valid within one forward / backward pass; NBP_TRAIN_FUSE=0 switches the hand-off off: every consumer takes its own pass)
-_FUSE = os.environ.get("NBP_TRAIN_FUSE", "1") == "1"
+_FUSE = _lib.tune("NBP_TRAIN_FUSE", "1") == "1"
 _Y_AMAX = {}          # forward: y.data_ptr() -> 64-word max-|y| slot written by the BatchNorm apply pass
 _DX_INFO = {}         # backward: dx.data_ptr() -> (max-|dx| slot, column sums of dx) written by the BatchNorm backward apply pass
 _ARENA = {}
@@ -521,19 +521,23 @@ class MeanLossFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------- network
-# Test hook (tests/test_gpu_training.py::test_composed_backward_at_the_oracle_point): when TEACHER is a dict {name: NHWC fp32
-# device tensor}, every intermediate of the forward is overwritten with the given values right after it is computed, so that
-# the saved tensors -- ReLU masks, pooling arg-maxes, batch statistics' inputs -- are an exact evaluation's and the backward is
-# the HIP kernels' arithmetic at THAT linearisation point (fp32 on this network is chaotic: a pre-activation inside the rounding
-# band flips its mask).  None (always, outside that test): no effect.
-TEACHER = None
+# Forward observer: a callable (name, tensor) invoked on every named intermediate (NHWC fp32) right after it is computed -- the
+# train-mode counterpart of a module forward hook (the layers here are autograd Functions, not modules).  None by default; what
+# an observer does with the tensor is its own business (tests/hip_helpers.py::teacher_forcing overwrites it with an exact
+# evaluation's value so that a backward can be checked at that linearisation point).
+_observer = None
+
+
+def set_forward_observer(fn):
+    """Installs (or, with None, removes) the observer; returns the previous one."""
+    global _observer
+    prev, _observer = _observer, fn
+    return prev
 
 
 def _t(name, y):
-    if TEACHER is not None:
-        ref = TEACHER.get(name)
-        if ref is not None:
-            y.data.copy_(ref.reshape(y.shape))
+    if _observer is not None and name is not None:
+        _observer(name, y)
     return y
 
 

@@ -18,6 +18,7 @@ import os
 import numpy as np
 import torch
 
+from .. import _lib
 from ..utility import hipops
 
 f32 = np.float32
@@ -80,7 +81,7 @@ class Camera:
         self.gathering_factor, self.sensor_range = gathering_factor, sensor_range
         self.seed = int(seed)
         self.ambient, self.contrast_factor = float(ambient_light_intensity), float(contrast_factor)
-        self.render_rgb = render_rgb and os.environ.get("NBP_RENDER_RGB", "1") != "0"      # A/B switch
+        self.render_rgb = render_rgb and _lib.tune("NBP_RENDER_RGB", "1") != "0"      # A/B switch
         self._rgb_ring = None
         self._zface_ring = None
         self._mesh = None

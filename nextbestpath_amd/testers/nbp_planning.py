@@ -23,6 +23,7 @@ import time
 import numpy as np
 import torch
 
+from .. import _lib
 from ..networks.nbp_model import NBP
 from ..simulator import scene as sim_scene
 from ..simulator.camera import Camera
@@ -31,6 +32,10 @@ from ..utility import utils as hu
 from ..utility.long_term_utils import LatticePlanner, compute_auc
 
 N_POSES = 101            # range(101) at nbp_planning.py:60
+_STEP_MAPS = _lib.tune("NBP_STEP_MAPS", "1") == "1"      # A/B: 0 = the step's map stage as separate reference-API calls
+# the eval forward as a replayed hipGraph (packing.ForwardGraph): 0 = never, 1 = a single rollout's B = 1 forward, 2 = also the
+# lock-step groups' batched forwards
+_FWD_GRAPH = int(_lib.tune("NBP_FWD_GRAPH", "1"))
 
 
 class RolloutState:
@@ -100,7 +105,7 @@ class Rollout:
         net_in = st.net_in if net_in is None else net_in
         # S5-S7 in one call: six maps, trajectory channel, network input (was seven launches: accumulate_step_maps,
         # transform_points_to_n_pieces, map_points_to_n_imgs and two copies)
-        if os.environ.get("NBP_STEP_MAPS", "1") == "1":
+        if _STEP_MAPS:
             full_pc, _, n_dev, pose, y_bins, traj_dev, n_old, fresh = self.maps_item()
             hu.step_maps(full_pc, pose, y_bins, S, self.grid_range, traj_dev, n_old, fresh, st.maps6, net_in[0], n_dev=n_dev)
             self.traj_img = net_in[0, 4]               # stays valid until this rollout's next pre()
@@ -217,12 +222,14 @@ class Rollout:
             m = camera._mesh
             f0 = camera._zface_ring.data_ptr()
             shade = ([f0 + 2 * k * hw4 for k in slots], m.verts, m.faces, m.colors, camera.ambient)
-        return (id(self), depth, cams, st.cloud, st.cloud_count, seed, st.cloud_rgb if shade else None, shade)
+        return (self, depth, cams, st.cloud, st.cloud_count, seed, st.cloud_rgb if shade else None, shade)
 
     def step(self):
         self.pre()
         with torch.no_grad():          # S9: one NBP forward per step (the reference also runs it without replanning, :252)
-            out1, out2 = self.nbp(self.st.net_in)
+            static = getattr(self.nbp, "forward_static", None) if _FWD_GRAPH >= 1 else None
+            # net_in is a persistent tensor: the ~60 launches of a B = 1 forward replay as one hipGraph (bit-identical outputs)
+            out1, out2 = static(self.st.net_in) if static is not None else self.nbp(self.st.net_in)
         self.plan_enqueue(out1, out2)
         if self.need_replan:
             torch.cuda.current_stream().synchronize()
@@ -251,16 +258,16 @@ class MultiRollout:
         R = len(self.rollouts)
         # two pipeline groups, and more once a group would exceed 24 rollouts (measured: 48 = 2 x 24 is the best split of one
         # GPU; groups of 30+ lose 15 % in bench.py's configuration, 3 x 24 is level with 2 x 24)
-        n_groups = n_groups or int(os.environ.get("NBP_ROLLOUT_GROUPS", "0")) or max(2, (R + 23) // 24)
+        n_groups = n_groups or int(_lib.tune("NBP_ROLLOUT_GROUPS", "0")) or max(2, (R + 23) // 24)
         n_groups = max(1, min(n_groups, R))
         per = (R + n_groups - 1) // n_groups
         self.groups = [self.rollouts[i:i + per] for i in range(0, R, per)]
         self.net_in = [torch.zeros(len(g), 5, grid, grid, dtype=torch.float32, device=device) for g in self.groups]
         # the rollouts' map stacks as slices of one tensor per group: the group's map stage is ONE batched launch
         # (NBP_STEP_BATCH=0: one launch per rollout, the A/B switch)
-        self.batched = os.environ.get("NBP_STEP_BATCH", "1") == "1" and os.environ.get("NBP_STEP_MAPS", "1") == "1"
+        self.batched = _lib.tune("NBP_STEP_BATCH", "1") == "1" and _STEP_MAPS
         # which stages of the group's step go as one launch each (A/B: NBP_STEP_BATCH_STAGES=maps,coverage,...)
-        self.batch_stages = set(os.environ.get("NBP_STEP_BATCH_STAGES", "maps,coverage,unproject,raster,replan").split(","))
+        self.batch_stages = set(_lib.tune("NBP_STEP_BATCH_STAGES", "maps,coverage,unproject,raster,replan").split(","))
         self.maps6 = [torch.zeros(len(g), 6, grid, grid, dtype=torch.float32, device=device) for g in self.groups]
         self._out1_pin = [torch.empty(len(g), 8, grid // 4, grid // 4, dtype=torch.float32).pin_memory() for g in self.groups]
         self._plan_event = [None] * len(self.groups)
@@ -277,7 +284,7 @@ class MultiRollout:
         # every CU's registers and LDS, so a small kernel that "overlaps" takes CUs away from them anyway.
         main = torch.cuda.current_stream(device)
         multi = streams and len(self.groups) >= 2
-        k = int(os.environ.get("NBP_ROLLOUT_STREAMS", "0")) if multi else 0
+        k = int(_lib.tune("NBP_ROLLOUT_STREAMS", "0")) if multi else 0
         if multi:
             self.fwd_streams = [torch.cuda.Stream(device) for _ in self.groups]
             self.side = [[torch.cuda.Stream(device) for _ in range(min(k, len(g)))] for g in self.groups]
@@ -396,7 +403,7 @@ class MultiRollout:
             else:
                 r.camera.capture_images(r.mesh, cams)
         if can_raster:
-            hipops.raster_zface_batch([(id(r), r.mesh.verts, r.mesh.faces, cams, out, zf) for r, cams, out, zf, _ in pend], H, W,
+            hipops.raster_zface_batch([(r, r.mesh.verts, r.mesh.faces, cams, out, zf) for r, cams, out, zf, _ in pend], H, W,
                                       len(pend[0][1]))
             for r, cams, out, _, slot in pend:
                 r.camera.capture_commit(out, cams, slot)
@@ -419,6 +426,8 @@ class MultiRollout:
         versions) once per lock-step, not once per forward."""
         if self._packed is None:
             return self.nbp(net_in)
+        if _FWD_GRAPH >= 2:
+            return self.nbp.forward_static(net_in)
         from ..networks import packing
         return packing.forward_packed(self._packed, net_in)
 

@@ -322,21 +322,21 @@ def coverage_count_batch(items):
     _lib.check(rc, "nbp_coverage_count_planned_batch_f32")
 
 
-_batch_ws = {}
-
-
-def _item_ws(tag, key, nbytes, device):
-    """Per-item scratch of the batched stages (items run concurrently: no sharing between rollouts)."""
-    w = _batch_ws.get((tag, key))
+def _item_ws(tag, owner, key, nbytes, device):
+    """Per-item scratch of the batched stages (items run concurrently: no sharing between rollouts).  The scratch belongs to
+    `owner` (the rollout: any object with a __dict__) and is released with it -- a module-level cache keyed by id(rollout) kept
+    ~1.2 KB per face per rollout alive for the life of the process."""
+    store = owner.__dict__.setdefault("_hip_scratch", {})
+    w = store.get((tag, key))
     if w is None or w.numel() < nbytes:
-        w = _batch_ws[(tag, key)] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        w = store[(tag, key)] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     return w
 
 
 def unproject_append_batch(items, H, W, n_frames, gathering_factor=0.05, fov_range=70.0, tan_half_fov=TAN_HALF_FOV):
     """unproject_append for several rollouts in three launches.  items = [(key, depth frames [F tensors [H,W]], cams host
     [F,12], cloud, cloud_count, seed, cloud_rgb | None, shade | None)] with shade = (zface frames [F tensors [H,W] int64], verts,
-    faces, vcolors, ambient); the frames need not be adjacent in memory; `key` identifies the rollout (its scratch is kept).
+    faces, vcolors, ambient); the frames need not be adjacent in memory; `key` is the rollout OBJECT: it owns its scratch.
     More than 12 items go in chunks of 12."""
     import numpy as np
     if len(items) > 12:
@@ -353,7 +353,7 @@ def unproject_append_batch(items, H, W, n_frames, gathering_factor=0.05, fov_ran
     cams = np.zeros((n, n_frames, 12), np.float32)
     ambient = 0.85
     for i, (key, depth, cam, cloud, cloud_count, seed, cloud_rgb, shade) in enumerate(items):
-        ws = _item_ws("unproject", (key, n_frames, H, W), wsb, cloud.device)
+        ws = _item_ws("unproject", key, (n_frames, H, W), wsb, cloud.device)
         cl[i], ccount[i], cap[i], wsp[i], seeds[i] = cloud.data_ptr(), cloud_count.data_ptr(), cloud.shape[0], ws.data_ptr(), \
             int(seed) & 0xFFFFFFFF
         cnts[i] = ws.data_ptr() + wsb - 256               # 2 n_frames ints in the tail of the item's scratch
@@ -372,8 +372,8 @@ def unproject_append_batch(items, H, W, n_frames, gathering_factor=0.05, fov_ran
 
 
 def raster_zface_batch(items, H, W, n_frames, tan_half_fov=TAN_HALF_FOV, z_clip=Z_CLIP):
-    """raster_zface for several rollouts, each its own mesh, in four launches.  items = [(key, verts, faces, cams host [F,12],
-    out_z [F,H,W], out_zface [F,H,W] int64)].  More than 12 items go in chunks of 12."""
+    """raster_zface for several rollouts, each its own mesh, in four launches.  items = [(key = the rollout object, which owns the
+    scratch, verts, faces, cams host [F,12], out_z [F,H,W], out_zface [F,H,W] int64)].  More than 12 items go in chunks of 12."""
     import numpy as np
     if len(items) > 12:
         for i in range(0, len(items), 12):
@@ -389,7 +389,7 @@ def raster_zface_batch(items, H, W, n_frames, tan_half_fov=TAN_HALF_FOV, z_clip=
         nb = _ws_sizes.get(("raster", (F_, n_frames, H, W)))
         if nb is None:
             nb = _ws_sizes[("raster", (F_, n_frames, H, W))] = int(L.nbp_raster_workspace_bytes(F_, n_frames, H, W, 0))
-        ws = _item_ws("raster", (key, F_, n_frames, H, W), nb, verts.device)
+        ws = _item_ws("raster", key, (F_, n_frames, H, W), nb, verts.device)
         ve[i], nv[i], fa[i], nf[i], zb[i], zf[i], wsp[i], wsn[i] = verts.data_ptr(), verts.shape[0], faces.data_ptr(), F_, out_z.data_ptr(), \
             out_zface.data_ptr(), ws.data_ptr(), ws.numel()
         cams[i] = np.asarray(cam, np.float32).reshape(n_frames, 12)

@@ -119,7 +119,7 @@ class LatticePlanner:
         self._hist_n = 0
         self._path_nodes, self._path_heads = np.zeros(P + 1, np.int32), np.zeros(P + 1, np.int32)
         self._new_coll = np.zeros(2 * (P + 1), np.int32)        # at most one failed first edge per candidate
-        self.native_search = os.environ.get("NBP_PLAN_SEARCH", "native") != "python"
+        self.native_search = _lib.tune("NBP_PLAN_SEARCH", "native") != "python"
 
     # ---- the GPU half of a replan for several rollouts at once (MultiRollout): persistent result buffers, ONE device->host copy
     def _batch_buffers(self):

@@ -58,6 +58,68 @@ def test_shard_and_gather_world2():
             assert abs(auc - compute_auc(cov)) < 1e-5
 
 
+def _check_gather(n_runs, n_poses, world, starts_per_scene=1):
+    """`world` gloo ranks shard an n_runs list (run i = scene i // starts, start i % starts) as test_nbp_planning does and gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_n, args=(r, world, port, n_runs, n_poses, starts_per_scene, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    from nextbestpath_amd.utility.long_term_utils import compute_auc
+    runs = [(i // starts_per_scene, i % starts_per_scene) for i in range(n_runs)]
+    shards = {r: m for r, _, m in got}
+    assert sorted(sum((shards[r] for r in range(world)), [])) == runs                     # disjoint cover of the run list
+    for r in range(world):
+        assert shards[r] == runs[r::world]                                                # rank r takes runs r, r + W, ...
+        assert len(shards[r]) == len(range(r, n_runs, world))
+    for _, rows, _ in got:                                                               # every rank sees all runs, in run order
+        assert [x[0] for x in rows] == list(range(n_runs))
+        for rid, final, auc, c1 in rows:
+            cov = np.linspace(0, 0.01 * (rid + 1), n_poses).astype(np.float32)
+            assert abs(final - cov[-1]) < 1e-6 and abs(c1 - cov[1]) < 1e-6 and abs(auc - compute_auc(cov)) < 1e-5
+
+
+def _worker_n(rank, world, port, n_runs, n_poses, starts, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from nextbestpath_amd import parallel_rollout as pr
+    r, w, _ = pr.init_distributed()
+    runs = [(i // starts, i % starts) for i in range(n_runs)]
+    mine = pr.shard(runs, r, w)
+    results = []
+    for run in reversed(mine):                  # local completion order must not matter: rows carry their run id
+        rid = runs.index(run)
+        cov = np.linspace(0, 0.01 * (rid + 1), n_poses).astype(np.float32)
+        results.append({"run_id": rid, "coverage": cov.tolist()})
+    out = pr.gather_results(results, runs, r, w, torch.device("cpu"), n_poses)
+    q.put((r, [(o["run_id"], o["final"], o["auc"], o["coverage"][1]) for o in out], [m for m in mine]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world8_configs3_forty_scenes_five_per_rank():
+    """BASELINE configs[3]: 40 AiMDoom_hard scenes over the 8 GPUs of a node, 5 per rank, no padded rows (the rank-indexing logic of
+    the first 8-GPU run, on gloo: no 8-GPU node has been available to this build)."""
+    _check_gather(40, 101, 8)
+
+
+def test_world8_uneven_list_has_padded_rows():
+    """37 runs over 8 ranks: ranks 0-4 hold 5 runs, ranks 5-7 hold 4 and one padded (-1) row each; two start poses per scene."""
+    _check_gather(37, 21, 8, starts_per_scene=2)
+
+
+def test_world8_fewer_runs_than_ranks():
+    """3 runs over 8 ranks: five ranks have nothing but padding and still take part in the collective."""
+    _check_gather(3, 5, 8)
+
+
 def test_single_process_path():
     from nextbestpath_amd import parallel_rollout as pr
     runs = [(0, 0), (1, 0)]

@@ -277,9 +277,15 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
     script = tmp_path / "fwd.py"
     script.write_text(_FUSION_SCRIPT)
     outs = {}
-    for tag, env in (("both", {}), ("nopool", {"NBP_CONV_POOL": "0"}), ("nopsi", {"NBP_GATE_PSI": "0"}), ("nohead", {"NBP_CONV_HEAD": "0"}),
-                     ("nor8", {"NBP_SPLIT_R8_BLOCKS": "0"})):
-        subprocess.run([sys.executable, str(script), root, str(tmp_path / tag)], check=True, env={**os.environ, **env},
+    T = {"NBP_TUNING": "1"}          # the switches are honoured only under the explicit opt-in
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("NBP_")}
+    for tag, env in (("both", {}), ("nopool", {**T, "NBP_CONV_POOL": "0"}), ("nopsi", {**T, "NBP_GATE_PSI": "0"}),
+                     ("nohead", {**T, "NBP_CONV_HEAD": "0"}), ("nor8", {**T, "NBP_SPLIT_R8_BLOCKS": "0"}),
+                     # a polluted environment WITHOUT the opt-in must change nothing
+                     ("polluted", {"NBP_CONV_POOL": "0", "NBP_GATE_PSI": "0", "NBP_CONV_HEAD": "0", "NBP_SPLIT_MAX_K": "576",
+                                   "NBP_SPLIT_MAX_K_SMALL": "288", "NBP_SPLIT_R8_SK": "1", "NBP_SPLIT_HALO": "0", "NBP_SPLIT_UP": "0",
+                                   "NBP_SPLIT_GATE": "0", "NBP_CONV_PRECISION": "fp32", "NBP_XCD_REMAP": "0"})):
+        subprocess.run([sys.executable, str(script), root, str(tmp_path / tag)], check=True, env={**clean, **env},
                        timeout=600)
         outs[tag] = {k: torch.load(tmp_path / f"{tag}_{k[0]}_{k[1]}.pt") for k in ((8, 256), (3, 128), (1, 64))}
     for k, (o1, o2) in outs["both"].items():
@@ -294,6 +300,8 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
         # same split-K slices: bit-identical
         t1, t2 = outs["nor8"][k]
         assert torch.equal(o1, t1) and torch.equal(o2, t2), k
+        u1, u2 = outs["polluted"][k]                          # no NBP_TUNING=1: the environment is not read
+        assert torch.equal(o1, u1) and torch.equal(o2, u2), k
 
 
 # ---- in-tensor dynamic range (the per-tensor scale's floor)
