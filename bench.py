@@ -108,18 +108,35 @@ def timed_layers(packed, x, out1, out2, ws):
 
 
 # ---------------------------------------------------------------------------------------------- HBM-side traffic
-def _pmc_means(csv_dir):
-    """{kernel name -> {counter -> mean per dispatch}} from rocprofv3 counter_collection csv files under csv_dir."""
+def _pmc_means(csv_dir, last=None):
+    """{kernel name -> {counter -> mean per dispatch}} from rocprofv3 counter_collection csv files under csv_dir.
+    last = {kernel prefix: k}: for kernels whose name starts with the prefix only the LAST k dispatches count (a workload whose first
+    launches of that kernel are set-up, not the measured case)."""
     import csv
     import glob
     acc = {}
     for path in glob.glob(os.path.join(csv_dir, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as fh:
             for row in csv.DictReader(fh):
-                cell = acc.setdefault(row["Kernel_Name"].replace("void ", ""), {}).setdefault(row["Counter_Name"], [0, 0.0])
-                cell[0] += 1
-                cell[1] += float(row["Counter_Value"])
-    return {k: {c: s / n for c, (n, s) in v.items()} for k, v in acc.items()}
+                name = row["Kernel_Name"].replace("void ", "")
+                acc.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(
+                    (int(row.get("Dispatch_Id") or 0), float(row["Counter_Value"])))
+    out = {}
+    for k, v in acc.items():
+        keep = next((n for p, n in (last or {}).items() if k.replace(" ", "").replace("(anonymousnamespace)::", "").startswith(p)), None)
+        out[k] = {}
+        for c, rows in v.items():
+            # a dispatch may be reported once per XCD / dimension: sum per dispatch first
+            per = {}
+            for did, val in rows:
+                per[did] = per.get(did, 0.0) + val
+            vals = [per[d] for d in sorted(per)]
+            n_rows_per_dispatch = len(rows) / max(len(per), 1)
+            vals = [x / n_rows_per_dispatch for x in vals]          # (the mean over a dispatch's rows, as before)
+            if keep:
+                vals = vals[-keep:]
+            out[k][c] = sum(vals) / len(vals)
+    return out
 
 
 def live_traffic(n_points, precision="fp32", batch=12):
@@ -143,7 +160,7 @@ def live_traffic(n_points, precision="fp32", batch=12):
             return None, f"rocprofv3 --pmc {counter} timed out"
         if r.returncode != 0:
             return None, f"rocprofv3 --pmc {counter} failed: {r.stderr[-300:]}"
-        for k, v in _pmc_means(d).items():
+        for k, v in _pmc_means(d, last={"map_binned_kernel": 3}).items():      # (tools/pmc_workload.py: the first binned build only files)
             means.setdefault(k, {}).update(v)
     shutil.rmtree(out, ignore_errors=True)
     res = {}
@@ -177,6 +194,68 @@ def pick_traffic(live, prefix):
         if k.replace("(anonymousnamespace)::", "").startswith(prefix):
             return v
     return None
+
+
+class PowerSampler:
+    """Board power (hwmon power1_input / power1_average) and core clock (freq1_input) of the GPU this process runs on, sampled
+    every 20 ms from a thread: the forward runs the board at its power cap (profiles/r04/power_trace_b24.txt), so watts and MHz
+    belong next to every throughput figure."""
+
+    def __init__(self, device_index=0):
+        import glob
+        import threading
+        import torch
+        self.files, self.rows, self._stop = {}, [], False
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            want = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}."
+            for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+                if want in os.path.realpath(os.path.dirname(os.path.dirname(d))):
+                    for name in ("power1_average", "power1_input", "freq1_input", "power1_cap"):
+                        if os.path.exists(os.path.join(d, name)):
+                            self.files.setdefault(name, os.path.join(d, name))
+        except Exception:
+            pass
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        pw = self.files.get("power1_average") or self.files.get("power1_input")
+        fq = self.files.get("freq1_input")
+        while not self._stop:
+            self.rows.append((self._read(pw) if pw else None, self._read(fq) if fq else None))
+            time.sleep(0.02)
+
+    def __enter__(self):
+        if self.files:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self.files:
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        pw = [r[0] / 1e6 for r in self.rows if r[0]]
+        fq = [r[1] / 1e6 for r in self.rows if r[1]]
+        if not pw:
+            return None
+        cap = self._read(self.files["power1_cap"]) if "power1_cap" in self.files else None
+        out = {"board_power_w_mean": round(sum(pw) / len(pw), 1), "board_power_w_max": round(max(pw), 1), "samples": len(pw),
+               "power_cap_w": None if not cap else round(cap / 1e6, 1)}
+        if cap:
+            out["frac_of_power_cap"] = round(out["board_power_w_mean"] / (cap / 1e6), 4)
+        if fq:
+            out["sclk_mhz_mean"] = round(sum(fq) / len(fq), 1)
+        return out
 
 
 def ev_time(fn, reps=20):
@@ -214,6 +293,19 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # one rank per GPU: every rank keeps to its own slice of the host cores (the replanning search, the launch loop and the
+    # runtime's helper threads of 8 ranks otherwise migrate over all 256 cores and each other's caches).  NBP_BENCH_AFFINITY=0: off.
+    affinity = None
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world > 1 and hasattr(os, "sched_setaffinity") and os.environ.get("NBP_BENCH_AFFINITY", "1") != "0":
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // max(local_world, 1)
+        if per >= 4:
+            lr = int(os.environ.get("LOCAL_RANK", "0")) % local_world
+            mine = cores[lr * per:(lr + 1) * per]
+            os.sched_setaffinity(0, mine)
+            torch.set_num_threads(min(per, 16))
+            affinity = [mine[0], mine[-1]]
 
     from nextbestpath_amd import _lib
     from nextbestpath_amd.networks import packing
@@ -317,7 +409,9 @@ def main():
         return d, mine
 
     replans0 = sum(r.n_replans for r in rollouts)
-    dt, _ = timed_steps(args.steps)
+    with PowerSampler(local_rank) as ps_timed:
+        dt, _ = timed_steps(args.steps)
+    power_timed = ps_timed.summary()
     n1 = cloud_points()
     replans_timed = sum(r.n_replans for r in rollouts) - replans0
     last_step = first_step + args.steps
@@ -474,51 +568,110 @@ def main():
                 tf = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0
                 print(f'{r["name"]:24s} M={r["M"]:7d} N={r["N"]:5d} K={r["K"]:5d} tile={r["tile"]:2d} '
                       f'sk={r["split_k"]:2d} {r["ms"]*1e3:9.1f} us {tf:7.2f} TF', file=sys.stderr)
-        ms_fwd = ev_time(lambda: net(x))
+        with PowerSampler(local_rank) as ps_fwd:
+            ms_fwd = ev_time(lambda: net(x), reps=60)
         fl = L.nbp_forward_flops(Bf, S)
         x1 = x[:1].contiguous()
-        ms_fwd1 = ev_time(lambda: net(x1))
+        ms_fwd1_eager = ev_time(lambda: net(x1), reps=100)
+        net.forward_static(x1)                                   # capture (outside the timing)
+        ms_fwd1 = ev_time(lambda: net.forward_static(x1), reps=100)     # what Rollout.step runs: the B = 1 forward as a replayed hipGraph
         def fwd_stage(ms, B_, flops_ref, factor, pk):
             tf_ref = flops_ref / (ms * 1e-3) / 1e12
             return {"ms": round(ms, 4), "batch": B_, "maps_per_s": round(B_ * 1e3 / ms, 2),
                     "tflops_reference_formulation": round(tf_ref, 3), "tflops_executed": round(tf_ref * factor, 3),
                     "frac_executed_of_conv_ceiling": round(tf_ref * factor / pk, 4), "conv_ceiling_tflops": round(pk, 2),
                     "executed_over_reference_flops": round(factor, 4)}
-        stage["nbp_forward_b1"] = fwd_stage(ms_fwd1, 1, L.nbp_forward_flops(1, S), exec_factor, peak)
-        stage["nbp_forward"] = dict(fwd_stage(ms_fwd, Bf, fl, exec_factor, peak), conv_precision=net.conv_precision)
+        stage["nbp_forward_b1"] = dict(fwd_stage(ms_fwd1, 1, L.nbp_forward_flops(1, S), exec_factor, peak),
+                                       launch="replayed hipGraph (packing.ForwardGraph, bit-identical to the eager launches)",
+                                       ms_eager_launches=round(ms_fwd1_eager, 4))
+        stage["nbp_forward"] = dict(fwd_stage(ms_fwd, Bf, fl, exec_factor, peak), conv_precision=net.conv_precision,
+                                    power=ps_fwd.summary())
         if net.conv_precision != "fp32" and not args.no_extra_stages:
             # the same forward on the fp32 MFMA pipe (NBP_CONV_PRECISION=fp32 makes it the rollouts' path)
             pk32 = packing.pack_state_dict(sd, dev, precision="fp32")
             ms32 = ev_time(lambda: packing.forward_packed(pk32, x))
             stage["nbp_forward_fp32_pipe"] = fwd_stage(ms32, Bf, fl, 1.0, PEAK_F32_MFMA_TFLOPS)   # no parity form on this pipe
             pk32.free()
-        # map accumulation: the HBM-bound scatter.  Event pair on the launch stream around `reps` launches; bytes =
-        # 12 N (every point read once) + 24 S^2 (six channels written once)
-        ms_sc = ev_time(lambda: hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=ro.st.cloud_count,
-                                                        out=ro.st.maps6))
+        # map accumulation: the HBM-bound scatter.  The step loop builds its maps from the tile-binned shadow copy of the cloud
+        # (utils.CloudBins, map_binned_kernel: one launch + the clear); bytes = 12 N (every point read once) + 24 S^2 (six channels
+        # written once).  Three timings on the rollout's own cloud, event pairs on the launch stream:
+        #   ms          a build that meets one step's new points (the last five frames' ~29 k points are counted directly and filed,
+        #               the rest comes from the pages): what a step pays -- the roofline figure
+        #   ms_steady   builds with nothing new (everything already filed)
+        #   append_order_kernel  the round-3 kernel (LDS hash per 8192 consecutive points) on the same cloud
         alg = 12 * n_pts + 6 * S * S * 4
-        sc_traffic = pick_traffic(live, "map_accumulate_kernel")
+        vh = np.asarray(mesh.verts_host, np.float32)
+        ext_lo, ext_hi = (float(vh[:, 0].min()), float(vh[:, 2].min())), (float(vh[:, 0].max()), float(vh[:, 2].max()))
+        bins_b = hu.CloudBins(ext_lo, ext_hi, ro.st.cloud.shape[0], dev)
+        n_new = min(5 * 5836, n_pts // 2)
+        nd_b = torch.tensor([n_pts - n_new], dtype=torch.int64, device=dev)
+        maps_b = torch.empty_like(ro.st.maps6)
+        t_new = []
+        for _ in range(5):
+            bins_b.reset()
+            nd_b.fill_(n_pts - n_new)
+            hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=nd_b, out=maps_b, bins=bins_b)      # files all but the last step
+            hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=nd_b, out=maps_b, bins=bins_b)
+            nd_b.fill_(n_pts)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=nd_b, out=maps_b, bins=bins_b)
+            e1.record()
+            torch.cuda.synchronize()
+            t_new.append(e0.elapsed_time(e1))
+        ms_sc = sorted(t_new)[len(t_new) // 2]
+        ms_steady = ev_time(lambda: hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=nd_b, out=maps_b, bins=bins_b), reps=50)
+        ms_old = ev_time(lambda: hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=ro.st.cloud_count,
+                                                         out=ro.st.maps6))
+        maps_equal = bool(torch.equal(maps_b, ro.st.maps6))
+        hb = bins_b.header()
+        # the group form the lock-step really launches: the first pipeline group's rollouts in one call
+        grp0 = multi.groups[0]
+        o6g, nig = torch.empty_like(multi.maps6[0]), torch.empty_like(multi.net_in[0])
+
+        def grp_items():
+            return [(r.st.cloud, r.st.cloud.shape[0] if r.st.bins is None else min(r.st.cloud.shape[0], r.st.frames_appended * 5837),
+                     r.st.cloud_count, r.pose, r.y_bins, torch.zeros(256, 3, device=dev), 0, np.zeros((0, 3), np.float32), r.st.bins)
+                    for r in grp0]
+        gi_items = grp_items()
+        ms_grp = ev_time(lambda: hu.step_maps_batch(gi_items, S, (-40, 40), o6g, nig), reps=20)
+        pts_grp = int(sum(int(r.st.cloud_count.item()) for r in grp0))
+        alg_grp = 12 * pts_grp + len(grp0) * 6 * S * S * 4
+        sc_traffic = pick_traffic(live, "map_binned_kernel")
         sc_src = live_src
         if sc_traffic is None:
-            sc_traffic, src2 = committed_traffic("map_accumulate_kernel", "pmc_summary.csv")
+            sc_traffic, src2 = committed_traffic("map_binned_kernel", "pmc_summary.csv")
             sc_src = f"{src2}; live pass: {live_src}" if src2 else live_src
-        scatter = {"bound": "hbm", "kernel": "map_accumulate_kernel", "achieved": round(alg / (ms_sc * 1e-3) / 1e9, 1),
+        scatter = {"bound": "hbm", "kernel": "map_binned_kernel (tile-binned shadow copy of the cloud: one workgroup per 2048-point page of a "
+                                             "2.5-unit tile on a dense LDS histogram; new points counted directly and filed by the same launch)",
+                   "achieved": round(alg / (ms_sc * 1e-3) / 1e9, 1),
                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(alg / (ms_sc * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                    "traffic": None if sc_traffic is None else round(sc_traffic), "traffic_source": sc_src,
-                   "points": n_pts, "algorithmic_bytes": alg, "ms": round(ms_sc, 4),
-                   "note": "ms includes the 1.5 MB clear of the six channels; at this size the launch floor (~3 us) is "
-                           "already 2x the HBM time of the bytes.  traffic (same 2*FETCH_SIZE + WRITE_SIZE, calibrated for this "
-                           "kernel's 12-B-strided loads: factor 2.000) exceeds the algorithmic bytes by the flush: one device-scope "
-                           "float atomic per distinct (channel, cell) key and workgroup resolves at the memory side as a "
-                           "line-granular read-modify-write"}
-        # the same kernel on a full-length cloud (3 M points, the end of a 101-step trajectory)
+                   "traffic_note": "per launch of map_binned_kernel over tools/pmc_workload.py's synthetic wall cloud of the same size (two "
+                                   "steady builds and one that meets 29 k new points): 2 * FETCH_SIZE + WRITE_SIZE",
+                   "points": n_pts, "new_points_in_timed_build": n_new, "algorithmic_bytes": alg, "ms": round(ms_sc, 4),
+                   "ms_steady": round(ms_steady, 4), "frac_steady": round(alg / (ms_steady * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                   "pages": hb["n_pages"], "side_list": hb["n_overflow"], "maps_equal_append_order_kernel": maps_equal,
+                   "append_order_kernel": {"kernel": "map_accumulate_kernel (round 3)", "ms": round(ms_old, 4),
+                                           "frac": round(alg / (ms_old * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+                   "group_form": {"rollouts": len(grp0), "points": pts_grp, "ms": round(ms_grp, 4),
+                                  "us_per_rollout": round(ms_grp * 1e3 / len(grp0), 2),
+                                  "achieved": round(alg_grp / (ms_grp * 1e-3) / 1e9, 1),
+                                  "frac": round(alg_grp / (ms_grp * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                  "note": "nbp_step_maps_binned_batch_f32 over the first pipeline group's rollouts (steady state), as "
+                                          "the lock-step launches it"},
+                   "note": "ms includes the 1.5 MB clear of the six channels; at this size two launches' fixed cost (~8 us) is "
+                           "several times the HBM time of the bytes (3.6 us at 8 TB/s)"}
+        # the same build on a full-length cloud (3 M points, the end of a 101-step trajectory)
         big = ro.st.cloud[:n_pts].repeat((3_000_000 + n_pts - 1) // max(n_pts, 1), 1)[:3_000_000].contiguous()
+        bins_big = hu.CloudBins(ext_lo, ext_hi, big.shape[0], dev)
         maps_big = torch.empty_like(ro.st.maps6)
-        ms_big = ev_time(lambda: hu.accumulate_step_maps(big, pose, y_bins, S, (-40, 40), out=maps_big))
+        hu.accumulate_step_maps(big, pose, y_bins, S, (-40, 40), out=maps_big, bins=bins_big)
+        ms_big = ev_time(lambda: hu.accumulate_step_maps(big, pose, y_bins, S, (-40, 40), out=maps_big, bins=bins_big), reps=50)
         alg_big = 12 * big.shape[0] + 6 * S * S * 4
-        scatter["at_3M_points"] = {"ms": round(ms_big, 4), "achieved": round(alg_big / (ms_big * 1e-3) / 1e9, 1),
-                                   "frac": round(alg_big / (ms_big * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-        del big, maps_big
+        scatter["at_3M_points"] = {"ms_steady": round(ms_big, 4), "achieved": round(alg_big / (ms_big * 1e-3) / 1e9, 1),
+                                   "frac_steady": round(alg_big / (ms_big * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        del big, maps_big, bins_big, bins_b
         cams4 = np.stack([f[1] for f in cam.frames[-4:]])
         H_, W_ = params.image_height, params.image_width
         zb = torch.empty(4, H_, W_, device=dev)
@@ -560,13 +713,33 @@ def main():
             sd16 = {k: v.detach().clone() for k, v in net.state_dict().items()}
             pk16 = packing.pack_state_dict(sd16, dev, bf16=True)
             x5 = torch.zeros(8, 5, 512, 512, device=dev)
-            x5[:, :, 128:384, 128:384] = x[:1].expand(8, -1, -1, -1) if S == 256 else 0.0
+            x5[:, :, 128:384, 128:384] = (x[:8] if Bf >= 8 else x[:1].expand(8, -1, -1, -1)) if S == 256 else 0.0     # eight rollouts' maps
             ms16 = ev_time(lambda: packing.forward_packed(pk16, x5), reps=10)
+            # decision metric of the bf16 path: does it pick the same goal cell as the fp32 path?
+            def goal_cells(o1):
+                v = o1.amax(1).flatten(1)
+                return v.argmax(1), v
+            with torch.no_grad():
+                b1, _ = packing.forward_packed(pk16, x5)
+                f1, _ = packing.forward_packed(packed, x5)
+                gb, vb = goal_cells(b1)
+                gf, vf = goal_cells(f1)
+                b1s, _ = packing.forward_packed(pk16, x[:8].contiguous() if Bf >= 8 else x)
+                f1s, _ = packing.forward_packed(packed, x[:8].contiguous() if Bf >= 8 else x)
+                gbs, _ = goal_cells(b1s)
+                gfs, vfs = goal_cells(f1s)
+                # how much value the bf16 choice gives up, measured on the fp32 map, relative to that map's range
+                regret = ((vf.gather(1, gf[:, None]) - vf.gather(1, gb[:, None]))[:, 0] / (vf.amax(1) - vf.amin(1)).clamp_min(1e-12))
+            bf16_goal = {"maps": int(gb.numel()), "goal_cell_agreement_512": round(float((gb == gf).float().mean()), 4),
+                         "goal_cell_agreement_256": round(float((gbs == gfs).float().mean()), 4),
+                         "max_value_regret_of_range_512": round(float(regret.max()), 6),
+                         "note": "goal cell = argmax over cells of out1.amax(heading); fp32 path = the default fp32_split forward on the "
+                                 "same maps (eight rollouts' network inputs); regret = fp32 value at the fp32 goal minus at the bf16 goal"}
             fl16 = L.nbp_forward_flops(8, 512)
             # executed / reference FLOPs of the bf16 forward: its six up_conv layers take the parity form (4/9 of 4.832 GMAC each
             # of the 91.206 GMAC per 256^2 map; the ratio is size independent)
-            f16 = 1.0 - (6 * 4.832 * 5.0 / 9.0) / 91.206 if os.environ.get("NBP_BF16_UP", "1") != "0" else 1.0
-            stage["config5_forward_bf16_512_b8"] = dict(fwd_stage(ms16, 8, fl16, f16, PEAK_BF16_MFMA_TFLOPS),
+            f16 = 1.0 - (6 * 4.832 * 5.0 / 9.0) / 91.206 if _lib.tune("NBP_BF16_UP", "1") != "0" else 1.0
+            stage["config5_forward_bf16_512_b8"] = dict(fwd_stage(ms16, 8, fl16, f16, PEAK_BF16_MFMA_TFLOPS), vs_fp32_path=bf16_goal,
                                                         # 16-bit MFMA stream on random operands: 1709 TFLOP/s (mfma_f16_probe)
                                                         frac_executed_of_sustained_mfma_stream=round(fl16 * f16 / (ms16 * 1e-3) / 1e12 / 1709.0, 4))
             pk16.free()
@@ -639,8 +812,21 @@ def main():
             "nbp_maps_per_s": round(world * stage["nbp_forward"]["maps_per_s"], 2),
             "stages": stage, "roofline": roofline, "roofline_scatter": scatter, "cpu_baseline": cpu,
             "strong_scaling": strong,
-            "distributed": None if dist is None else {"backend": dist.get_backend(), "world": world},
+            "distributed": None if dist is None else {"backend": dist.get_backend(), "world": world, "rank0_core_range": affinity,
+                                                       "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES")},
+            "power": {"timed_region": power_timed,
+                      "note": "hwmon power1 / freq1 of this GPU, 20 ms samples over the K timed steps; the batched forward alone holds the "
+                              "board at its cap (stages.nbp_forward.power; profiles/r04/power_trace_b24.txt)"},
         }
+        # A/B switches (NBP_TUNING=1 ...): state every non-default one; a line measured with a switch that changes the
+        # arithmetic is not the headline configuration and does not get to call itself `value`
+        knobs = _lib.effective_knobs()
+        numerics = sorted(k for k in knobs if k in _lib.NUMERICS_KNOBS)
+        out["tuning"] = {"active": _lib.tuning_active(), "non_default_knobs": knobs, "numerics_affecting": numerics}
+        if numerics:
+            out["value_with_numerics_knobs"] = out["value"]
+            out["value"] = None
+            out["note"] += f"; NOT a headline: numerics-affecting switches set ({', '.join(numerics)})"
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()                  # keep every rank alive until rank 0 has printed

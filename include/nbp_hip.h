@@ -279,6 +279,40 @@ int nbp_step_maps_batch_f32(int n, const float* const* points, const long long* 
                             const float* band_lo_hi_host, int S, float lo, float hi, float* const* traj_pts,
                             const int* n_traj_old, const float* traj_fresh_host, const int* n_traj_fresh,
                             float* out6_all, float* net_in_all, void* stream);
+/* ---- Tile-binned shadow copy of a rollout's cloud (round 4).  The six maps are a translated window of the world, so the map build
+ * can run on points grouped by (x, z) tile: one workgroup per 2048-point PAGE of a tile on a dense 16 x 16-cell x 6-channel
+ * histogram in LDS, tiles outside the +-40 window never read.  The canonical cloud (append order) is untouched; the store holds a
+ * second copy of every point, filed when a map build first sees it.  Maps are bit-identical to nbp_step_maps_f32's (integer counts).
+ *   nbp_cloud_bins_bytes      bytes of the store for a scene whose (x, z) extent is [lo_xz, hi_xz] and a cloud of `capacity` points
+ *                             (2.5-unit tiles with one tile of margin; 0 = bad arguments)
+ *   nbp_cloud_bins_geometry   the same plan as numbers: {nx, nz, max_pages}, {x0, z0, tile}
+ *   nbp_cloud_bins_init       empties the store (256-byte aligned): call it whenever the cloud is reset to zero points
+ *   nbp_step_maps_binned_f32  nbp_step_maps_f32 on the store, ONE kernel launch: page workgroups build the maps from the pages filed
+ *                             by earlier builds, tail workgroups count points [n_binned, N) of `points` directly and file them for
+ *                             the builds to come.  parity = (number of builds on this store since its init) & 1: the page side
+ *                             reads the snapshot of that parity, the tail side publishes the other one (the caller alternates).
+ *                             page_bound = host upper bound of the pages in use (max_pages is always safe; a bound that is too low
+ *                             only costs time).  traj_pts and net_in5 may both be NULL: only out6 is produced.  Points that cannot
+ *                             be filed (outside the tile grid, more than 64 pages in one tile, pool exhausted) are kept in an index
+ *                             list and counted with direct atomics: nothing is dropped; header word 2 (error) becomes non-zero only
+ *                             if that list overflows too (65536 entries).
+ *   nbp_step_maps_binned_batch_f32  the same for the n <= 16 rollouts of a lock-step group (stores[n], page_bound[n], parity[n]: HOST
+ *                             arrays).
+ * Store header (device, int32 words): 0 n_pages, 1 n_overflow, 2 error, 3 ticket, 4-5 n_binned (int64). */
+size_t nbp_cloud_bins_bytes(const float* lo_xz_host, const float* hi_xz_host, long long capacity);
+int nbp_cloud_bins_geometry(const float* lo_xz_host, const float* hi_xz_host, long long capacity, int* nx_nz_maxpages_host,
+                            float* x0_z0_tile_host);
+int nbp_cloud_bins_init(void* store, size_t store_bytes, const float* lo_xz_host, const float* hi_xz_host, long long capacity,
+                        void* stream);
+int nbp_step_maps_binned_f32(void* store, int page_bound, int parity, const float* points, long long N, const long long* N_dev_or_null,
+                             float cx, float cy, float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi,
+                             int S, float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
+                             int n_traj_fresh, float* out6, float* net_in5, void* stream);
+int nbp_step_maps_binned_batch_f32(int n, void* const* stores, const int* page_bound, const int* parity, const float* const* points,
+                                   const long long* N_cap, const long long* const* N_dev, const float* poses_xyz_host,
+                                   const float* bounds_host, const int* n_bounds, const float* band_lo_hi_host, int S, float lo,
+                                   float hi, float* const* traj_pts, const int* n_traj_old, const float* traj_fresh_host,
+                                   const int* n_traj_fresh, float* out6_all, float* net_in_all, void* stream);
 /* ---- The other latency-bound stages of an exploration step for the rollouts of a lock-step group (n <= 12; coverage: n <= 16),
  * one launch per kernel instead of n.  Every array argument is a HOST array of n entries holding device pointers / scalars;
  * results are identical to n single calls (tests/test_gpu_rollout.py).

@@ -8,6 +8,7 @@
 // even), bounds test -- so the integer cell of every point is bit-identical.
 #include "common.h"
 #include <cstdlib>
+#include <cstring>
 #pragma clang fp contract(off)
 
 namespace {
@@ -189,6 +190,298 @@ __global__ __launch_bounds__(THREADS) void map_accumulate_batch_kernel(MapBatch 
     map_accumulate_body<AGG_POINTS, SLOT_BITS, THREADS, ROUNDS>(b.it[r], blockIdx.x, b.n_wg[r], S, lo, sc, keys, cnts);
 }
 
+// ------------------------------------------------------------------ tile-binned shadow copy of the cloud (round 4)
+// The six maps are a TRANSLATED window of the world (no rotation: cell = rint((-(v - c) + 40) * S / 80)), so a world-space tile of
+// T x T units always lands on a (T S / 80 + 1)^2 block of cells.  The canonical cloud stays in append order (coverage sampling,
+// parity); beside it every point is copied ONCE, by the first map build that sees it, into a page of its (x, z) tile:
+//   store = [BinDesc | tile_count[nt] | count_snap[2][nt] | page_table[nt][BIN_MAXP] | page_info[max_pages] | overflow[BIN_OVF] |
+//            pages[max_pages][2048][3]]
+// A map build is ONE launch whose workgroups take three roles:
+//   page workgroups   one per page: a DENSE 16 x 16-cell x 6-channel histogram in LDS (plain LDS adds, no CAS probing), flushed with
+//                     one global atomic per non-zero counter; tiles outside the +-40 window are never read;
+//   tail workgroups   the points the store has not seen yet ([n_binned, N): one step's ~29 k) are counted directly (global atomics)
+//                     AND filed into their tiles' pages for the builds to come;
+//   side list / trajectory channel.
+// Page workgroups and tail workgroups of one launch must not meet: the page side reads a SNAPSHOT of the tile counts / page count /
+// side-list length (slot `parity` of the double-buffered snapshots), the tail side updates the live counters, and the tail workgroup
+// that finishes last copies live -> snapshot[1 - parity] for the next build (the host alternates the parity per build).
+// Counts are integers, so the maps are bit-identical to map_accumulate_kernel's whatever the order (tests/test_gpu_maps.py, every
+// rollout parity test).
+// Slot reservation: one atomicAdd per (wave, tile), all of a wave's in flight together; the lane whose slot is the first of a page
+// allocates it and publishes its id in the page table (release), lanes of other waves spin on the entry (bounded) -- within a wave
+// every allocation is issued before any lane waits, so a waiter never blocks its own allocator.  What cannot be filed (outside the
+// tile grid, a tile beyond BIN_MAXP pages, the page pool exhausted, a spin that timed out) goes to an index list that every build
+// walks with direct atomics: nothing is ever dropped.
+constexpr int BIN_PAGE_BITS = 11, BIN_PAGE = 1 << BIN_PAGE_BITS;      // 2048 points = 24 KB per page
+constexpr int BIN_MAXP = 64;                                          // pages per tile: 131072 points, beyond -> side list
+constexpr unsigned BIN_OVF = 1u << 16;
+constexpr int BIN_R = 16;                                             // LDS histogram: 16 x 16 cells (a 2.5-unit tile is 9 x 9 + slack)
+constexpr int BIN_TAIL_WGS = 64, BIN_OVF_WGS = 2;
+struct BinDesc {                // head of the store (device memory, 256 B reserved)
+    unsigned n_pages, n_overflow, error, ticket;          // live counters (tail side)
+    long long n_binned;                                   // points of the cloud already filed
+    unsigned n_pages_snap[2], n_overflow_snap[2];         // what the page side of a build with that parity may read
+    int nx, nz, nt, max_pages;
+    float x0, z0, inv_t, tile;
+    unsigned long long off_count, off_snap, off_table, off_info, off_ovf, off_pages, total_bytes;
+};
+static_assert(sizeof(BinDesc) <= 256, "BinDesc header");
+
+struct BinView { BinDesc* d; unsigned* count; unsigned* snap; int* table; unsigned* info; unsigned* ovf; float* pages; };
+__device__ __forceinline__ BinView bin_view(char* store) {
+    BinDesc* d = reinterpret_cast<BinDesc*>(store);
+    return BinView{d, reinterpret_cast<unsigned*>(store + d->off_count), reinterpret_cast<unsigned*>(store + d->off_snap),
+                   reinterpret_cast<int*>(store + d->off_table), reinterpret_cast<unsigned*>(store + d->off_info),
+                   reinterpret_cast<unsigned*>(store + d->off_ovf), reinterpret_cast<float*>(store + d->off_pages)};
+}
+
+__device__ __forceinline__ int channel_of(float y, const Bounds& bd) {
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cnt += (k < bd.n && bd.b[k] < y) ? 1 : 0;
+    const int bin = cnt - 1;
+    return (bin >= 0 && bin < 4) ? bin : 4;
+}
+
+__device__ __forceinline__ void count_direct(float x, float y, float z, const MapItem& a, int S, float lo, float sc) {
+    int i0, i1;
+    if (!cell_of(-(z - a.cz), -(x - a.cx), lo, sc, sc, S, S, i0, i1)) return;
+    atomicAdd(a.out + channel_of(y, a.bd) * S * S + i0 * S + i1, 1.0f);
+    if (a.band_lo < y && y < a.band_hi) atomicAdd(a.out + 5 * S * S + i0 * S + i1, 1.0f);
+}
+
+// tail workgroup `wg` of `n_wg`: points [n_binned, N) of the cloud are counted into the maps and filed into pages; the tail
+// workgroup that finishes last publishes the snapshot for the next build and advances n_binned
+__device__ __forceinline__ void bin_tail_body(const MapItem& a, const BinView& v, long long N, unsigned wg, unsigned n_wg, int parity, int S,
+                                              float lo, float sc) {
+    const float* __restrict__ cloud = a.p;
+    const long long first = v.d->n_binned;
+    const int nx = v.d->nx, nz = v.d->nz, max_pages = v.d->max_pages;
+    const float x0 = v.d->x0, z0 = v.d->z0, inv_t = v.d->inv_t;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (long long i0 = first + (long long)wg * 256; i0 < N; i0 += (long long)n_wg * 256) {      // uniform per workgroup
+        const long long i = i0 + threadIdx.x;
+        const bool active = i < N;
+        f32x3 p = {__builtin_nanf(""), 0.f, 0.f};
+        if (active) p = *reinterpret_cast<const f32x3*>(cloud + 3 * i);
+        if (active) count_direct(p[0], p[1], p[2], a, S, lo, sc);
+        const float fx = (p[0] - x0) * inv_t, fz = (p[2] - z0) * inv_t;
+        const int tx = (int)floorf(fx), tz = (int)floorf(fz);
+        const bool inside = active && fx >= 0.f && fz >= 0.f && tx < nx && tz < nz;       // NaN fails
+        const int t = inside ? tz * nx + tx : -1;
+        // groups of lanes with the same tile (ballots only), then ONE reserving atomic per group, all in flight together
+        int leader = lane;
+        unsigned rank = 0, gsize = 0;
+        unsigned long long todo = __ballot(inside);
+        while (todo) {
+            const int l0 = __ffsll((long long)todo) - 1;
+            const int t0 = __shfl(t, l0);
+            const unsigned long long m = __ballot(inside && t == t0);
+            if (inside && t == t0) { leader = l0; rank = (unsigned)__popcll(m & lt); gsize = (unsigned)__popcll(m); }
+            todo &= ~m;
+        }
+        unsigned b = 0;
+        if (inside && lane == leader) b = atomicAdd(&v.count[t], gsize);
+        b = __shfl(b, leader);
+        const unsigned slot = b + rank;
+        const unsigned k = slot >> BIN_PAGE_BITS;
+        const bool paged = inside && k < (unsigned)BIN_MAXP;
+        int* entry = paged ? v.table + (size_t)t * BIN_MAXP + k : nullptr;
+        if (paged && (slot & (BIN_PAGE - 1)) == 0) {          // first slot of a page: allocate it and publish its id
+            const unsigned pid = atomicAdd(&v.d->n_pages, 1u);
+            int pub = -2;                                     // -2: the pool is exhausted (waiters go to the side list)
+            if (pid < (unsigned)max_pages) { v.info[pid] = (unsigned)t | (k << 16); pub = (int)pid; }
+            __hip_atomic_store(entry, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int pid = -1;
+        if (paged) {
+            int budget = 1 << 20;
+            pid = __hip_atomic_load(entry, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            while (pid == -1 && --budget > 0) {
+                __builtin_amdgcn_s_sleep(2);
+                pid = __hip_atomic_load(entry, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (pid >= 0) {
+            float* dst = v.pages + ((size_t)pid * BIN_PAGE + (slot & (BIN_PAGE - 1))) * 3;
+            dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+        } else if (active) {
+            const unsigned q = atomicAdd(&v.d->n_overflow, 1u);
+            if (q < BIN_OVF) v.ovf[q] = (unsigned)i;
+            else v.d->error = 1u;                             // (checked by the host: tests, end of a rollout)
+        }
+    }
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(&v.d->ticket, 1u) == n_wg - 1;
+    }
+    __syncthreads();
+    if (last) {             // every tail workgroup has filed its points: live -> the snapshot the NEXT build's page side reads
+        __threadfence();
+        unsigned* dst = v.snap + (size_t)(1 - parity) * v.d->nt;
+        for (int q = threadIdx.x; q < v.d->nt; q += 256) dst[q] = __hip_atomic_load(&v.count[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            v.d->n_pages_snap[1 - parity] = __hip_atomic_load(&v.d->n_pages, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.d->n_overflow_snap[1 - parity] = __hip_atomic_load(&v.d->n_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.d->n_binned = N > first ? N : first;
+            v.d->ticket = 0;
+        }
+    }
+}
+
+// One workgroup of 256 threads.  Roles by index: [0, n_page_wg) pages, then BIN_TAIL_WGS tail, BIN_OVF_WGS side list, 1 trajectory.
+__device__ __forceinline__ void map_binned_body(const MapItem& a, char* store, unsigned wg, unsigned n_page_wg, int parity, int S, float lo,
+                                                float sc, int* hist) {
+    float* __restrict__ out = a.out;
+    const float cx = a.cx, cz = a.cz;
+    const int SS = S * S;
+    if (wg == n_page_wg + BIN_TAIL_WGS + BIN_OVF_WGS) {     // trajectory workgroup (as in map_accumulate_body)
+        const TrajArgs& tr = a.tr;
+        if (!tr.out) return;
+        for (int i = threadIdx.x; i < tr.n_old + tr.n_fresh; i += 256) {
+            float x, z;
+            if (i < tr.n_old) {
+                x = tr.pts[3 * i]; z = tr.pts[3 * i + 2];
+            } else {
+                float y = 0.f;
+                x = z = 0.f;
+#pragma unroll
+                for (int f = 0; f < 8; ++f)
+                    if (i - tr.n_old == f) { x = tr.fresh[3 * f]; y = tr.fresh[3 * f + 1]; z = tr.fresh[3 * f + 2]; }
+                tr.pts[3 * i] = x; tr.pts[3 * i + 1] = y; tr.pts[3 * i + 2] = z;
+            }
+            int i0, i1;
+            if (cell_of(-(z - cz), -(x - cx), lo, sc, sc, S, S, i0, i1)) atomicAdd(tr.out + i0 * S + i1, 1.0f);
+        }
+        return;
+    }
+    const BinView v = bin_view(store);
+    if (wg >= n_page_wg + BIN_TAIL_WGS) {                  // the side list as of the previous build: direct atomics
+        const unsigned n = min(v.d->n_overflow_snap[parity], BIN_OVF);
+        for (unsigned i = (wg - n_page_wg - BIN_TAIL_WGS) * 256 + threadIdx.x; i < n; i += BIN_OVF_WGS * 256) {
+            const f32x3 p = *reinterpret_cast<const f32x3*>(a.p + 3 * (size_t)v.ovf[i]);
+            count_direct(p[0], p[1], p[2], a, S, lo, sc);
+        }
+        return;
+    }
+    if (wg >= n_page_wg) {
+        long long N = a.N;
+        if (a.n_dev) N = *a.n_dev;
+        bin_tail_body(a, v, N, wg - n_page_wg, BIN_TAIL_WGS, parity, S, lo, sc);
+        return;
+    }
+    const unsigned n_pages = min(v.d->n_pages_snap[parity], (unsigned)v.d->max_pages);
+    const unsigned* __restrict__ tcount = v.snap + (size_t)parity * v.d->nt;
+    // (one page per workgroup when the host's bound n_page_wg covers the pages that exist; a bound that is too low only costs time)
+    for (unsigned page = wg; page < n_pages; page += n_page_wg) {
+        const unsigned info = v.info[page];
+        const int t = (int)(info & 0xffffu), k = (int)(info >> 16);
+        const unsigned tc = tcount[t];
+        if (tc <= (unsigned)k * BIN_PAGE) continue;        // (cannot happen: a page exists once its first slot is reserved)
+        const int cnt = (int)min((unsigned)BIN_PAGE, tc - (unsigned)k * BIN_PAGE);
+        // the block of cells the tile can reach (one cell of slack each way: a point outside it, or outside the LDS block, goes direct)
+        const int tx = t % v.d->nx, tz = t / v.d->nx;
+        const float T = v.d->tile;
+        const float xa = v.d->x0 + tx * T, xb = v.d->x0 + (tx + 1) * T, za = v.d->z0 + tz * T, zb = v.d->z0 + (tz + 1) * T;
+        const float r_hi = rintf((-(za - cz) - lo) * sc) + 1.f, r_lo = rintf((-(zb - cz) - lo) * sc) - 1.f;
+        const float c_hi = rintf((-(xa - cx) - lo) * sc) + 1.f, c_lo = rintf((-(xb - cx) - lo) * sc) - 1.f;
+        if (r_hi < 0.f || r_lo >= (float)S || c_hi < 0.f || c_lo >= (float)S) continue;      // the tile is outside the window
+        const int r0 = (int)r_lo, c0 = (int)c_lo;
+        __syncthreads();                                   // (the previous page's flush has read the histogram)
+        for (int i = threadIdx.x; i < 6 * BIN_R * BIN_R; i += 256) hist[i] = 0;
+        __syncthreads();
+        const float* __restrict__ pg = v.pages + (size_t)page * BIN_PAGE * 3;
+        constexpr int PER = BIN_PAGE / 256;
+        float px[PER], py[PER], pz[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = threadIdx.x + q * 256;
+            f32x3 p = {__builtin_nanf(""), 0.f, 0.f};
+            if (i < cnt) p = *reinterpret_cast<const f32x3*>(pg + 3 * i);
+            px[q] = p[0]; py[q] = p[1]; pz[q] = p[2];
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            int i0, i1;
+            if (!cell_of(-(pz[q] - cz), -(px[q] - cx), lo, sc, sc, S, S, i0, i1)) continue;  // NaN (a slot never written) fails
+            const int ch = channel_of(py[q], a.bd);
+            const bool band = a.band_lo < py[q] && py[q] < a.band_hi;
+            const int li = i0 - r0, lj = i1 - c0;
+            if ((unsigned)li < (unsigned)BIN_R && (unsigned)lj < (unsigned)BIN_R) {
+                atomicAdd(&hist[(ch * BIN_R + li) * BIN_R + lj], 1);
+                if (band) atomicAdd(&hist[(5 * BIN_R + li) * BIN_R + lj], 1);
+            } else {
+                atomicAdd(out + ch * SS + i0 * S + i1, 1.0f);
+                if (band) atomicAdd(out + 5 * SS + i0 * S + i1, 1.0f);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 6 * BIN_R * BIN_R; i += 256) {
+            const int c = hist[i];
+            if (c) {
+                const int ch = i / (BIN_R * BIN_R), li = (i / BIN_R) % BIN_R, lj = i % BIN_R;
+                atomicAdd(out + ch * SS + (r0 + li) * S + (c0 + lj), (float)c);               // (in the window: the point passed cell_of)
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void map_binned_kernel(MapItem a, char* store, unsigned n_page_wg, int parity, int S, float lo, float sc) {
+    __shared__ int hist[6 * BIN_R * BIN_R];
+    map_binned_body(a, store, blockIdx.x, n_page_wg, parity, S, lo, sc, hist);
+}
+struct BinBatch { char* store[MAP_BATCH]; unsigned n_page_wg[MAP_BATCH]; unsigned parity_bits; };
+__global__ __launch_bounds__(256) void map_binned_batch_kernel(MapBatch b, BinBatch s, int S, float lo, float sc) {
+    __shared__ int hist[6 * BIN_R * BIN_R];
+    const unsigned r = blockIdx.y;
+    if (blockIdx.x >= s.n_page_wg[r] + BIN_TAIL_WGS + BIN_OVF_WGS + 1) return;
+    map_binned_body(b.it[r], s.store[r], blockIdx.x, s.n_page_wg[r], (int)((s.parity_bits >> r) & 1u), S, lo, sc, hist);
+}
+
+__global__ __launch_bounds__(256) void bin_init_kernel(char* store, BinDesc d) {
+    BinDesc* dd = reinterpret_cast<BinDesc*>(store);
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    if (gid == 0) *dd = d;
+    unsigned* count = reinterpret_cast<unsigned*>(store + d.off_count);       // live counts, then the two snapshots (contiguous)
+    int* table = reinterpret_cast<int*>(store + d.off_table);
+    float* pages = reinterpret_cast<float*>(store + d.off_pages);
+    for (size_t i = gid; i < (size_t)d.nt * 3; i += stride) count[i] = 0u;
+    for (size_t i = gid; i < (size_t)d.nt * BIN_MAXP; i += stride) table[i] = -1;
+    const float nanv = __builtin_nanf("");
+    for (size_t i = gid; i < (size_t)d.max_pages * BIN_PAGE * 3; i += stride) pages[i] = nanv;     // empty slots fail cell_of
+}
+
+// host: geometry of the store for a scene whose (x, z) extent is [lo, hi] and a cloud of `capacity` points
+static BinDesc bin_desc(const float* lo_xz, const float* hi_xz, long long capacity) {
+    BinDesc d;
+    memset(&d, 0, sizeof d);
+    float T = 2.5f;                                        // 8 cells of the 0.3125-unit grid
+    const float ex = hi_xz[0] - lo_xz[0], ez = hi_xz[1] - lo_xz[1];
+    while (((double)ex / T + 3.0) * ((double)ez / T + 3.0) > 16384.0) T *= 2.f;      // (tile ids are 16 bits)
+    d.tile = T; d.inv_t = 1.0f / T;
+    d.x0 = lo_xz[0] - T; d.z0 = lo_xz[1] - T;              // one tile of margin
+    d.nx = (int)(ex / T) + 3; d.nz = (int)(ez / T) + 3;
+    d.nt = d.nx * d.nz;
+    d.max_pages = (int)(capacity / BIN_PAGE) + d.nt + 64;
+    unsigned long long off = 256;
+    auto take = [&](unsigned long long bytes) { const unsigned long long o = off; off += (bytes + 255) / 256 * 256; return o; };
+    d.off_count = take((unsigned long long)d.nt * 4 * 3);  // live + 2 snapshots
+    d.off_snap = d.off_count + (unsigned long long)d.nt * 4;
+    d.off_table = take((unsigned long long)d.nt * BIN_MAXP * 4);
+    d.off_info = take((unsigned long long)d.max_pages * 4);
+    d.off_ovf = take((unsigned long long)BIN_OVF * 4);
+    d.off_pages = take((unsigned long long)d.max_pages * BIN_PAGE * 12);
+    d.total_bytes = off;
+    return d;
+}
+static bool bin_geometry_ok(const float* lo_xz, const float* hi_xz, long long capacity) {
+    return lo_xz && hi_xz && capacity > 0 && capacity < (1ll << 32) && hi_xz[0] >= lo_xz[0] && hi_xz[1] >= lo_xz[1] &&
+           hi_xz[0] - lo_xz[0] < 1e6f && hi_xz[1] - lo_xz[1] < 1e6f;
+}
+
 inline float grid_scale(int S, float lo, float hi) { return (float)((double)S / ((double)hi - (double)lo)); }
 
 }  // namespace
@@ -327,6 +620,125 @@ extern "C" int nbp_step_maps_batch_f32(int n, const float* const* points, const 
     if (rounds == 4) map_accumulate_batch_kernel<32768, 13, 1024, 4><<<dim3(max_wg, (unsigned)n), 1024, 0, st>>>(b, S, lo, grid_scale(S, lo, hi));
     else if (rounds == 2) map_accumulate_batch_kernel<16384, 13, 1024, 2><<<dim3(max_wg, (unsigned)n), 1024, 0, st>>>(b, S, lo, grid_scale(S, lo, hi));
     else map_accumulate_batch_kernel<8192, 13, 1024, 1><<<dim3(max_wg, (unsigned)n), 1024, 0, st>>>(b, S, lo, grid_scale(S, lo, hi));
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    e = hipMemcpy2DAsync(net_in_all, 5 * SS * sizeof(float), out6_all, 6 * SS * sizeof(float), 4 * SS * sizeof(float), (size_t)n,
+                         hipMemcpyDeviceToDevice, st);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// ---- tile-binned shadow copy of the cloud (kernels above): sizing, initialisation, and the step's map stage on it
+extern "C" size_t nbp_cloud_bins_bytes(const float* lo_xz_host, const float* hi_xz_host, long long capacity) {
+    if (!bin_geometry_ok(lo_xz_host, hi_xz_host, capacity)) return 0;
+    return (size_t)bin_desc(lo_xz_host, hi_xz_host, capacity).total_bytes;
+}
+
+extern "C" int nbp_cloud_bins_geometry(const float* lo_xz_host, const float* hi_xz_host, long long capacity, int* nx_nz_maxpages_host,
+                                       float* x0_z0_tile_host) {
+    NBP_RETURN_IF(!bin_geometry_ok(lo_xz_host, hi_xz_host, capacity) || !nx_nz_maxpages_host || !x0_z0_tile_host, NBP_E_ARG);
+    const BinDesc d = bin_desc(lo_xz_host, hi_xz_host, capacity);
+    nx_nz_maxpages_host[0] = d.nx; nx_nz_maxpages_host[1] = d.nz; nx_nz_maxpages_host[2] = d.max_pages;
+    x0_z0_tile_host[0] = d.x0; x0_z0_tile_host[1] = d.z0; x0_z0_tile_host[2] = d.tile;
+    return 0;
+}
+
+// (Re-)initialises the store: empty tiles, no pages, every page slot NaN.  Call it whenever the cloud is reset to zero points.
+extern "C" int nbp_cloud_bins_init(void* store, size_t store_bytes, const float* lo_xz_host, const float* hi_xz_host, long long capacity,
+                                   void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!store || ((uintptr_t)store & 255) || !bin_geometry_ok(lo_xz_host, hi_xz_host, capacity), NBP_E_ARG);
+    const BinDesc d = bin_desc(lo_xz_host, hi_xz_host, capacity);
+    NBP_RETURN_IF(store_bytes < d.total_bytes, NBP_E_WS);
+    bin_init_kernel<<<1024, 256, 0, (hipStream_t)stream>>>((char*)store, d);
+    return nbp_launch_status();
+}
+
+// The step's map stage (nbp_step_maps_f32) on the binned copy, one launch (map_binned_kernel): points of the cloud that no build has
+// seen yet are counted directly and filed into their tiles' pages, everything else is counted from the pages.  page_bound: the
+// host's upper bound on the pages in use (the store's max_pages is always safe; a tighter bound launches fewer idle workgroups).
+// traj_pts / net_in5 may both be null: only out6 is produced (the reference-API form accumulate_step_maps).
+extern "C" int nbp_step_maps_binned_f32(void* store, int page_bound, int parity, const float* points, long long N, const long long* N_dev_or_null,
+                                        float cx, float cy, float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi,
+                                        int S, float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
+                                        int n_traj_fresh, float* out6, float* net_in5, void* stream) {
+    NBP_ENTER();
+    (void)cy;
+    NBP_RETURN_IF(!store || page_bound < 1 || !out6 || N < 0 || S < 1 || !(hi > lo), NBP_E_ARG);
+    NBP_RETURN_IF((net_in5 == nullptr) != (traj_pts == nullptr), NBP_E_ARG);
+    NBP_RETURN_IF(n_bounds < 0 || n_bounds > 8 || (n_bounds > 0 && !bounds_host), NBP_E_ARG);
+    NBP_RETURN_IF(n_traj_old < 0 || n_traj_fresh < 0 || n_traj_fresh > 8 || (n_traj_fresh > 0 && !traj_fresh_host), NBP_E_ARG);
+    NBP_RETURN_IF(N > 0 && (!points || ((uintptr_t)points & 3) != 0), NBP_E_ARG);
+    NBP_RETURN_IF((long long)6 * S * S >= (1ll << 31), NBP_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t SS = (size_t)S * S;
+    hipError_t e = hipMemsetAsync(out6, 0, 6 * SS * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (net_in5) {
+        e = hipMemsetAsync(net_in5 + 4 * SS, 0, SS * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    Bounds bd;
+    for (int k = 0; k < 8; ++k) bd.b[k] = k < n_bounds ? bounds_host[k] : 0.f;
+    bd.n = n_bounds;
+    TrajArgs tr;
+    memset(&tr, 0, sizeof tr);
+    if (net_in5) {
+        tr.pts = traj_pts; tr.out = net_in5 + 4 * SS; tr.n_old = n_traj_old; tr.n_fresh = n_traj_fresh;
+        for (int i = 0; i < 24; ++i) tr.fresh[i] = i < 3 * n_traj_fresh ? traj_fresh_host[i] : 0.f;
+    }
+    NBP_RETURN_IF(parity != 0 && parity != 1, NBP_E_ARG);
+    map_binned_kernel<<<(unsigned)page_bound + BIN_TAIL_WGS + BIN_OVF_WGS + 1, 256, 0, st>>>(
+        MapItem{points, N, N_dev_or_null, cx, cz, bd, band_lo, band_hi, out6, tr}, (char*)store, (unsigned)page_bound, parity, S, lo,
+        grid_scale(S, lo, hi));
+    int rc = nbp_launch_status();
+    if (rc || !net_in5) return rc;
+    e = hipMemcpyAsync(net_in5, out6, 4 * SS * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// nbp_step_maps_batch_f32 on the rollouts' binned copies (stores[n], page_bound[n]: HOST arrays)
+extern "C" int nbp_step_maps_binned_batch_f32(int n, void* const* stores, const int* page_bound, const int* parity,
+                                              const float* const* points,
+                                              const long long* N_cap, const long long* const* N_dev, const float* poses_xyz_host,
+                                              const float* bounds_host, const int* n_bounds, const float* band_lo_hi_host, int S, float lo,
+                                              float hi, float* const* traj_pts, const int* n_traj_old, const float* traj_fresh_host,
+                                              const int* n_traj_fresh, float* out6_all, float* net_in_all, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(n < 1 || n > MAP_BATCH || !stores || !page_bound || !parity || !points || !N_cap || !N_dev || !poses_xyz_host || !bounds_host ||
+                  !n_bounds || !band_lo_hi_host || !traj_pts || !n_traj_old || !traj_fresh_host || !n_traj_fresh || !out6_all || !net_in_all,
+                  NBP_E_ARG);
+    NBP_RETURN_IF(S < 1 || !(hi > lo) || (long long)6 * S * S >= (1ll << 31), NBP_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t SS = (size_t)S * S;
+    MapBatch b;
+    BinBatch s;
+    s.parity_bits = 0u;
+    unsigned max_wg = 1;
+    for (int r = 0; r < MAP_BATCH; ++r) {
+        const int q = r < n ? r : 0;
+        NBP_RETURN_IF(r < n && (!stores[q] || page_bound[q] < 1 || N_cap[q] < 0 || (N_cap[q] > 0 && (!points[q] || ((uintptr_t)points[q] & 3) != 0)) ||
+                                !traj_pts[q] || n_bounds[q] < 0 || n_bounds[q] > 8 || n_traj_old[q] < 0 || n_traj_fresh[q] < 0 ||
+                                n_traj_fresh[q] > 8), NBP_E_ARG);
+        MapItem& it = b.it[r];
+        it.p = points[q]; it.N = N_cap[q]; it.n_dev = N_dev[q];
+        it.cx = poses_xyz_host[3 * q]; it.cz = poses_xyz_host[3 * q + 2];
+        for (int k = 0; k < 8; ++k) it.bd.b[k] = k < n_bounds[q] ? bounds_host[8 * q + k] : 0.f;
+        it.bd.n = n_bounds[q];
+        it.band_lo = band_lo_hi_host[2 * q]; it.band_hi = band_lo_hi_host[2 * q + 1];
+        it.out = out6_all + (size_t)q * 6 * SS;
+        it.tr.pts = traj_pts[q]; it.tr.out = net_in_all + (size_t)q * 5 * SS + 4 * SS;
+        it.tr.n_old = n_traj_old[q]; it.tr.n_fresh = n_traj_fresh[q];
+        for (int i = 0; i < 24; ++i) it.tr.fresh[i] = i < 3 * n_traj_fresh[q] ? traj_fresh_host[24 * q + i] : 0.f;
+        b.n_wg[r] = 0;
+        s.store[r] = (char*)stores[q]; s.n_page_wg[r] = r < n ? (unsigned)page_bound[q] : 0u;
+        if (r < n && (parity[q] & 1)) s.parity_bits |= 1u << r;
+        if (r < n && s.n_page_wg[r] + BIN_TAIL_WGS + BIN_OVF_WGS + 1 > max_wg) max_wg = s.n_page_wg[r] + BIN_TAIL_WGS + BIN_OVF_WGS + 1;
+    }
+    hipError_t e = hipMemsetAsync(out6_all, 0, (size_t)n * 6 * SS * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset2DAsync(net_in_all + 4 * SS, 5 * SS * sizeof(float), 0, SS * sizeof(float), (size_t)n, st);       // the trajectory channels
+    if (e != hipSuccess) return (int)e;
+    map_binned_batch_kernel<<<dim3(max_wg, (unsigned)n), 256, 0, st>>>(b, s, S, lo, grid_scale(S, lo, hi));
     int rc = nbp_launch_status();
     if (rc) return rc;
     e = hipMemcpy2DAsync(net_in_all, 5 * SS * sizeof(float), out6_all, 6 * SS * sizeof(float), 4 * SS * sizeof(float), (size_t)n,

@@ -36,6 +36,8 @@ _STEP_MAPS = _lib.tune("NBP_STEP_MAPS", "1") == "1"      # A/B: 0 = the step's m
 # the eval forward as a replayed hipGraph (packing.ForwardGraph): 0 = never, 1 = a single rollout's B = 1 forward, 2 = also the
 # lock-step groups' batched forwards
 _FWD_GRAPH = int(_lib.tune("NBP_FWD_GRAPH", "1"))
+# the step's maps from the tile-binned shadow copy of the cloud (utils.CloudBins; bit-identical maps): 0 = the append-order kernel
+_MAP_BINS = _lib.tune("NBP_MAP_BINS", "1") == "1"
 
 
 class RolloutState:
@@ -49,6 +51,8 @@ class RolloutState:
         self.coverage_counts = torch.zeros(N_POSES, 2, dtype=torch.int32, device=device)
         self.maps6 = torch.zeros(6, grid, grid, dtype=torch.float32, device=device)
         self.net_in = torch.zeros(1, 5, grid, grid, dtype=torch.float32, device=device)
+        self.bins = None             # utils.CloudBins of `cloud` (made by the rollout: the tile grid needs the scene's extent)
+        self.frames_appended = 0     # frames un-projected into the cloud so far (host bound of its size: <= that many x per-frame keep)
 
 
 def setup_test_camera(params, mesh, start_cam_idx, settings, device, seed=0):
@@ -85,6 +89,17 @@ class Rollout:
         self.st = state or RolloutState(device, grid=grid)
         self.st.cloud_count.zero_()
         self.st.coverage_counts.zero_()
+        self.st.frames_appended = 0
+        if _MAP_BINS:
+            vh = np.asarray(mesh.verts_host, np.float32)
+            lo, hi = (float(vh[:, 0].min()), float(vh[:, 2].min())), (float(vh[:, 0].max()), float(vh[:, 2].max()))
+            b = self.st.bins
+            if b is None or (tuple(b.lo), tuple(b.hi), b.capacity) != (lo, hi, self.st.cloud.shape[0]):
+                self.st.bins = hu.CloudBins(lo, hi, self.st.cloud.shape[0], device)
+            else:
+                b.reset()                     # the cloud starts from zero points again
+        else:
+            self.st.bins = None
         self.rng = random.Random(seed)
         self.planner = LatticePlanner(camera, mesh_for_check, device, self.V, self.S, self.grid_range, rng=self.rng)
         self.gt = gt_scene_pc.contiguous()
@@ -106,8 +121,9 @@ class Rollout:
         # S5-S7 in one call: six maps, trajectory channel, network input (was seven launches: accumulate_step_maps,
         # transform_points_to_n_pieces, map_points_to_n_imgs and two copies)
         if _STEP_MAPS:
-            full_pc, _, n_dev, pose, y_bins, traj_dev, n_old, fresh = self.maps_item()
-            hu.step_maps(full_pc, pose, y_bins, S, self.grid_range, traj_dev, n_old, fresh, st.maps6, net_in[0], n_dev=n_dev)
+            full_pc, n_upper, n_dev, pose, y_bins, traj_dev, n_old, fresh, bins = self.maps_item()
+            hu.step_maps(full_pc, pose, y_bins, S, self.grid_range, traj_dev, n_old, fresh, st.maps6, net_in[0], n_dev=n_dev,
+                         bins=bins, n_upper=n_upper)
             self.traj_img = net_in[0, 4]               # stays valid until this rollout's next pre()
         else:
             hu.accumulate_step_maps(st.cloud, self.pose, self.y_bins, S, self.grid_range, n_dev=st.cloud_count, out=st.maps6)
@@ -139,15 +155,18 @@ class Rollout:
         hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
                                 params.sensor_range, seed=self.step_seed + 11 * pose_i,
                                 cloud_rgb=st.cloud_rgb if colour else None, **colour)
+        st.frames_appended += 1
         self.pose, _ = camera.get_pose_from_idx(camera.cam_idx)
 
     def maps_item(self):
         """The map stage's arguments (utils.step_maps / step_maps_batch): (cloud, host upper bound of its size, device size,
-        pose, y_bins, trajectory history, n_old, fresh positions).  A step appends at most 5 frames' kept pixels."""
+        pose, y_bins, trajectory history, n_old, fresh positions, bins).  The bound counts the frames actually un-projected into
+        the cloud (a frame keeps at most int(H W gathering_factor) pixels); it only sizes grids -- the kernels read the device
+        count, and the binned build walks every page whatever the bound (a guessed bound must not drop points)."""
         traj_dev, n_old, fresh = self.camera.trajectory_pending()
         per_frame = int(self.params.image_height * self.params.image_width * self.params.gathering_factor) + 1
-        n_upper = (5 * (self.pose_i + 1) + 8) * per_frame
-        return self.st.cloud, n_upper, self.st.cloud_count, self.pose, self.y_bins, traj_dev, n_old, fresh
+        n_upper = self.st.cloud.shape[0] if self.st.bins is None else min(self.st.cloud.shape[0], self.st.frames_appended * per_frame)
+        return self.st.cloud, n_upper, self.st.cloud_count, self.pose, self.y_bins, traj_dev, n_old, fresh, self.st.bins
 
     def pre_decide(self):
         """S8: does this step replan?  Host only."""
@@ -185,6 +204,7 @@ class Rollout:
         hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
                                 params.sensor_range, seed=self.step_seed + 11 * self.pose_i + 5,
                                 cloud_rgb=st.cloud_rgb if colour else None, **colour)
+        st.frames_appended += 4
         self.post_finish()
 
     def post_choose(self):
@@ -352,6 +372,7 @@ class MultiRollout:
         if all(it is not None for it in items):
             hipops.unproject_append_batch(items, p0.image_height, p0.image_width, 1, p0.gathering_factor, p0.sensor_range)
             for r in grp:
+                r.st.frames_appended += 1
                 r.pose, _ = r.camera.get_pose_from_idx(r.camera.cam_idx)
         else:
             for r in grp:
@@ -360,8 +381,9 @@ class MultiRollout:
             hu.step_maps_batch([r.maps_item() for r in grp], grp[0].S, grp[0].grid_range, self.maps6[gi], net_in)
         for i, r in enumerate(grp):
             if "maps" not in stages:
-                full_pc, _, n_dev, pose, y_bins, traj_dev, n_old, fresh = r.maps_item()
-                hu.step_maps(full_pc, pose, y_bins, r.S, r.grid_range, traj_dev, n_old, fresh, r.st.maps6, net_in[i], n_dev=n_dev)
+                full_pc, n_upper, n_dev, pose, y_bins, traj_dev, n_old, fresh, bins = r.maps_item()
+                hu.step_maps(full_pc, pose, y_bins, r.S, r.grid_range, traj_dev, n_old, fresh, r.st.maps6, net_in[i], n_dev=n_dev,
+                             bins=bins, n_upper=n_upper)
             r.traj_img = net_in[i, 4]
             r.pre_decide()
 
@@ -411,6 +433,8 @@ class MultiRollout:
         items = [r.unproject_item(which, r.step_seed + 11 * r.pose_i + 5) for r in grp] if "unproject" in stages else [None]
         if all(it is not None for it in items):
             hipops.unproject_append_batch(items, H, W, 4, p0.gathering_factor, p0.sensor_range)
+            for r in grp:
+                r.st.frames_appended += 4
         else:
             for r in grp:
                 st, camera = r.st, r.camera
@@ -418,6 +442,7 @@ class MultiRollout:
                 colour = camera.colour_source(which)
                 hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, p0.gathering_factor, p0.sensor_range,
                                         seed=r.step_seed + 11 * r.pose_i + 5, cloud_rgb=st.cloud_rgb if colour else None, **colour)
+                st.frames_appended += 4
         for r in grp:
             r.post_finish()
 

@@ -70,8 +70,54 @@ def map_points_to_n_imgs(points_2d_batch, grid_size, grid_range, device=None):
     return out
 
 
+class CloudBins:
+    """Tile-binned shadow copy of ONE cloud tensor (include/nbp_hip.h "Tile-binned shadow copy"): a map build counts the points it
+    has not seen yet directly and files them into 2048-point pages of their 2.5-unit (x, z) tile, and builds the rest of the six
+    maps from the pages -- one workgroup per page on a dense LDS histogram, tiles outside the window never read; one launch.  The maps are bit-identical to the
+    unbinned kernel's.  `lo_xz` / `hi_xz`: the scene's horizontal extent (points outside it are still counted, through a slower
+    side list).  The store follows the cloud from zero points: call reset() whenever the cloud is emptied."""
+
+    def __init__(self, lo_xz, hi_xz, capacity, device):
+        L = _lib.lib()
+        self.lo = (C.c_float * 2)(float(lo_xz[0]), float(lo_xz[1]))
+        self.hi = (C.c_float * 2)(float(hi_xz[0]), float(hi_xz[1]))
+        self.capacity = int(capacity)
+        nbytes = int(L.nbp_cloud_bins_bytes(self.lo, self.hi, self.capacity))
+        if nbytes == 0:
+            raise ValueError(f"CloudBins: bad extent {tuple(lo_xz)} .. {tuple(hi_xz)} / capacity {capacity}")
+        g, t = (C.c_int * 3)(), (C.c_float * 3)()
+        _lib.check(L.nbp_cloud_bins_geometry(self.lo, self.hi, self.capacity, g, t), "nbp_cloud_bins_geometry")
+        self.nx, self.nz, self.max_pages = int(g[0]), int(g[1]), int(g[2])
+        self.x0, self.z0, self.tile = float(t[0]), float(t[1]), float(t[2])
+        self.store = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.reset()
+
+    def next_parity(self):
+        """Parity of the build about to be enqueued (its page side reads that snapshot; its tail side publishes the other one)."""
+        p = self.builds & 1
+        self.builds += 1
+        return p
+
+    def reset(self):
+        self.builds = 0
+        with torch.cuda.device(self.store.device):
+            rc = _lib.lib().nbp_cloud_bins_init(self.store.data_ptr(), self.store.numel(), self.lo, self.hi, self.capacity,
+                                                _lib.current_stream())
+        _lib.check(rc, "nbp_cloud_bins_init")
+
+    def page_bound(self, n_upper):
+        """Upper bound of the pages in use for a cloud of at most n_upper points (every tile may hold one partial page)."""
+        return max(1, min(self.max_pages, int(n_upper) // 2048 + self.nx * self.nz + 1))
+
+    def header(self):
+        """{n_pages, n_overflow, error, n_binned} (synchronises: tests and end-of-rollout checks only)."""
+        h = self.store[:24].cpu()
+        w = h.view(torch.int32)
+        return {"n_pages": int(w[0]), "n_overflow": int(w[1]), "error": int(w[2]), "n_binned": int(h[16:24].view(torch.int64)[0])}
+
+
 def accumulate_step_maps(full_pc, camera_pose, y_bins, grid_size=256, grid_range=(-40, 40), band=0.1, n_dev=None,
-                         out=None):
+                         out=None, bins=None):
     """One fused pass replacing nbp_planning.py:114-127 + :172-183.
 
     Returns [6,S,S]: four height slabs (torch.bucketize(p_y, y_bins[:-1]) - 1 semantics),
@@ -93,6 +139,14 @@ def accumulate_step_maps(full_pc, camera_pose, y_bins, grid_size=256, grid_range
     band_hi = torch.tensor(cy + band, dtype=torch.float32).item()
     band_lo = torch.tensor(cy - band, dtype=torch.float32).item()
     with torch.cuda.device(p.device):
+        if bins is not None:          # on the tile-binned shadow copy of THIS cloud tensor (CloudBins): same maps, bit for bit
+            if p.data_ptr() != full_pc.data_ptr():
+                raise ValueError("accumulate_step_maps(bins=...): the cloud must be the contiguous fp32 tensor the bins follow")
+            rc = _lib.lib().nbp_step_maps_binned_f32(bins.store.data_ptr(), bins.page_bound(p.shape[0]), bins.next_parity(), p.data_ptr(), p.shape[0], n_dev,
+                                                     cx, cy, cz, arr, len(bounds), band_lo, band_hi, S, float(grid_range[0]),
+                                                     float(grid_range[1]), None, 0, None, 0, out.data_ptr(), None, _lib.current_stream())
+            _lib.check(rc, "nbp_step_maps_binned_f32")
+            return out
         rc = _lib.lib().nbp_map_accumulate_f32(p.data_ptr(), p.shape[0], n_dev, cx, cy, cz, arr, len(bounds), band_lo,
                                                band_hi, S, float(grid_range[0]), float(grid_range[1]),
                                                out.data_ptr(), _lib.current_stream())
@@ -101,7 +155,7 @@ def accumulate_step_maps(full_pc, camera_pose, y_bins, grid_size=256, grid_range
 
 
 def step_maps(full_pc, camera_pose, y_bins, grid_size, grid_range, traj_dev, n_traj_old, traj_fresh, out6, net_in5,
-              band=0.1, n_dev=None):
+              band=0.1, n_dev=None, bins=None, n_upper=None):
     """accumulate_step_maps + the trajectory channel + the copy of the four slabs into the network input, in one call
     (nbp_step_maps_f32: two memsets, one kernel, one copy instead of seven launches).  traj_dev: device [cap,3] history
     of camera positions, n_traj_old of them valid; traj_fresh: host [k<=8,3] new positions, appended by the kernel.
@@ -120,6 +174,15 @@ def step_maps(full_pc, camera_pose, y_bins, grid_size, grid_range, traj_dev, n_t
         raise ValueError("step_maps: the trajectory buffer is too small")
     # thresholds exactly as the reference forms them: python double +-0.1, then fp32 compare
     band_hi, band_lo = float(np.float32(cy + band)), float(np.float32(cy - band))
+    if bins is not None:              # the tile-binned shadow copy of this cloud (CloudBins): same maps, bit for bit
+        nu = full_pc.shape[0] if n_upper is None else min(int(n_upper), full_pc.shape[0])
+        rc = _lib.lib().nbp_step_maps_binned_f32(bins.store.data_ptr(), bins.page_bound(nu), bins.next_parity(), full_pc.data_ptr(), full_pc.shape[0],
+                                                 None if n_dev is None else n_dev.data_ptr(), cx, cy, cz, arr, len(bounds), band_lo,
+                                                 band_hi, S, float(grid_range[0]), float(grid_range[1]), traj_dev.data_ptr(),
+                                                 int(n_traj_old), fresh.ctypes.data, len(fresh), out6.data_ptr(), net_in5.data_ptr(),
+                                                 _lib.current_stream())
+        _lib.check(rc, "nbp_step_maps_binned_f32")
+        return
     rc = _lib.lib().nbp_step_maps_f32(full_pc.data_ptr(), full_pc.shape[0], None if n_dev is None else n_dev.data_ptr(),
                                       cx, cy, cz, arr, len(bounds), band_lo, band_hi, S, float(grid_range[0]),
                                       float(grid_range[1]), traj_dev.data_ptr(), int(n_traj_old), fresh.ctypes.data,
@@ -129,8 +192,9 @@ def step_maps(full_pc, camera_pose, y_bins, grid_size, grid_range, traj_dev, n_t
 
 def step_maps_batch(items, grid_size, grid_range, out6_all, net_in_all, band=0.1):
     """step_maps for the rollouts of a lock-step group in ONE kernel launch (nbp_step_maps_batch_f32): `items` = one tuple per
-    rollout (full_pc, n_upper, n_dev, camera_pose, y_bins, traj_dev, n_traj_old, traj_fresh); rollout i writes out6_all[i]
-    ([n,6,S,S]) and net_in_all[i] ([n,5,S,S]); n_upper = a host-side upper bound of the cloud size (sizes the grid)."""
+    rollout (full_pc, n_upper, n_dev, camera_pose, y_bins, traj_dev, n_traj_old, traj_fresh[, bins]); rollout i writes out6_all[i]
+    ([n,6,S,S]) and net_in_all[i] ([n,5,S,S]); n_upper = a host-side upper bound of the cloud size (sizes the grid).  With a
+    ninth entry (CloudBins) in EVERY item the group runs on the binned shadow copies (nbp_step_maps_binned_batch_f32)."""
     n, S = len(items), int(grid_size)
     if n > 16:                                   # the kernel arguments hold 16 rollouts: larger groups go in chunks
         for i in range(0, n, 16):
@@ -146,7 +210,12 @@ def step_maps_batch(items, grid_size, grid_range, out6_all, net_in_all, band=0.1
     pts, ncap, ndev, traj = (VP * n)(), (LL * n)(), (VP * n)(), (VP * n)()
     poses, bounds, nb = np.zeros((n, 3), np.float32), np.zeros((n, 8), np.float32), (C.c_int * n)()
     bands, fresh, n_old, n_fresh = np.zeros((n, 2), np.float32), np.zeros((n, 24), np.float32), (C.c_int * n)(), (C.c_int * n)()
-    for i, (full_pc, n_upper, n_dev, pose, y_bins, traj_dev, n_traj_old, traj_fresh) in enumerate(items):
+    binned = all(len(it) > 8 and it[8] is not None for it in items)
+    stores, pbound, parity = (VP * n)(), (C.c_int * n)(), (C.c_int * n)()
+    for i, it in enumerate(items):
+        full_pc, n_upper, n_dev, pose, y_bins, traj_dev, n_traj_old, traj_fresh = it[:8]
+        if binned:
+            stores[i], pbound[i], parity[i] = it[8].store.data_ptr(), it[8].page_bound(min(int(n_upper), full_pc.shape[0])), it[8].next_parity()
         cx, cy, cz = _pose_xyz(pose)
         b = [float(v) for v in (y_bins.tolist() if isinstance(y_bins, torch.Tensor) else y_bins)][:-1]
         if len(b) > 8:
@@ -161,6 +230,13 @@ def step_maps_batch(items, grid_size, grid_range, out6_all, net_in_all, band=0.1
         bands[i] = (np.float32(cy - band), np.float32(cy + band))       # as the reference forms them: python double +-0.1, then fp32
         fresh[i, :len(f)] = f
         n_old[i], n_fresh[i] = int(n_traj_old), len(f) // 3
+    if binned:
+        rc = _lib.lib().nbp_step_maps_binned_batch_f32(n, stores, pbound, parity, pts, ncap, ndev, poses.ctypes.data, bounds.ctypes.data, nb,
+                                                       bands.ctypes.data, S, float(grid_range[0]), float(grid_range[1]), traj, n_old,
+                                                       fresh.ctypes.data, n_fresh, out6_all.data_ptr(), net_in_all.data_ptr(),
+                                                       _lib.current_stream())
+        _lib.check(rc, "nbp_step_maps_binned_batch_f32")
+        return
     rc = _lib.lib().nbp_step_maps_batch_f32(n, pts, ncap, ndev, poses.ctypes.data, bounds.ctypes.data, nb, bands.ctypes.data, S,
                                             float(grid_range[0]), float(grid_range[1]), traj, n_old, fresh.ctypes.data, n_fresh,
                                             out6_all.data_ptr(), net_in_all.data_ptr(), _lib.current_stream())

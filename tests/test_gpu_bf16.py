@@ -219,6 +219,31 @@ def test_forward_bf16_256_decisions(hip, net_bf16, nbp_weights):
     assert (d1 - b1[1:2]).abs().max().item() / s1 < 2e-2 and (d2 - b2[1:2]).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("S,B", [(256, 16), (512, 4)])
+def test_forward_bf16_goal_cell_agreement(hip, S, B):
+    """The decision the value head feeds (nbp_planning.py:203-233 scores candidates by out1 at their cell and heading): the goal
+    cell -- argmax over cells of out1.amax(heading) -- of the bf16 path against the fp32 path's on the same maps, with the
+    explorer weights the rollouts use.  Reported as an agreement rate; asserted through the REGRET: the
+    fp32 value the bf16 choice gives up, relative to the map's range, stays inside the bf16 tolerance of the value head, and where
+    the two goals differ the fp32 map itself is flat between them (a near-tie, not a different decision)."""
+    from nextbestpath_amd.networks import packing
+    from nextbestpath_amd.utility.synthetic import make_count_maps, make_explorer_state_dict
+    sd = make_explorer_state_dict(9)
+    p32 = packing.pack_state_dict(sd, "cuda", precision="fp32_split")
+    p16 = packing.pack_state_dict(sd, "cuda", precision="bf16")
+    x = make_count_maps(B, S, seed=31).cuda()
+    f1, _ = packing.forward_packed(p32, x)
+    b1, _ = packing.forward_packed(p16, x)
+    vf, vb = f1.amax(1).flatten(1), b1.amax(1).flatten(1)
+    gf, gb = vf.argmax(1), vb.argmax(1)
+    rng = (vf.amax(1) - vf.amin(1)).clamp_min(1e-12)
+    regret = (vf.gather(1, gf[:, None]) - vf.gather(1, gb[:, None]))[:, 0] / rng
+    agree = float((gf == gb).float().mean())
+    print(f"bf16 vs fp32 goal cell at {S}^2: agreement {agree:.3f} over {B} maps, max regret {float(regret.max()):.2e} of range")
+    assert float(regret.max()) < 2e-2, (agree, regret.tolist())
+    assert agree >= 0.5, (agree, regret.tolist())
+
+
 _FUSE_SCRIPT = r"""
 import sys, torch
 sys.path.insert(0, sys.argv[1])

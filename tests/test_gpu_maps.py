@@ -113,3 +113,111 @@ def test_step_maps_is_the_separate_calls(hip, golden_dir, N, n_old, n_fresh, S):
         hu.step_maps(pc, pose, ybins, S, gr, traj_dev[:1], 1, traj[:1], out6, net_in)
     with pytest.raises(Exception):
         hu.step_maps(pc, pose, ybins, S, gr, traj_dev, 0, np.zeros((9, 3), np.float32), out6, net_in)
+
+
+# ---- the tile-binned shadow copy of the cloud (round 4): same maps, bit for bit, whatever the append pattern
+def _wall_cloud(n, seed, extent=30.0, y_range=(0.0, 12.0)):
+    """Points on a few vertical walls (what a rollout's cloud looks like: thousands of points per top-down cell)."""
+    rng = np.random.default_rng(seed)
+    k = 12
+    a = rng.uniform(-extent, extent, (k, 2)).astype(np.float32)
+    d = rng.uniform(-1, 1, (k, 2)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    w = rng.integers(0, k, n)
+    s = rng.uniform(0, 25, n).astype(np.float32)
+    xz = a[w] + d[w] * s[:, None] + rng.normal(0, 0.02, (n, 2)).astype(np.float32)
+    y = rng.uniform(*y_range, n).astype(np.float32)
+    return torch.from_numpy(np.stack([xz[:, 0], y, xz[:, 1]], 1).astype(np.float32))
+
+
+@pytest.mark.parametrize("S", [256, 512])
+def test_binned_maps_equal_the_append_order_kernel(hip, S):
+    """A cloud that grows in ragged chunks (as a rollout's does), maps built after every chunk from a moving pose: the binned build
+    (CloudBins: pages per 2.5-unit tile, dense LDS histograms) equals map_accumulate_kernel bit for bit; every point is filed once."""
+    gr = (-40 * S // 256, 40 * S // 256)
+    cap = 400_000
+    pts = _wall_cloud(cap, seed=S, extent=35.0)
+    cloud = torch.zeros(cap, 3, device="cuda")
+    n_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
+    bins = hu.CloudBins((-62.0, -62.0), (62.0, 62.0), cap, "cuda")
+    ybins = torch.arange(0.5, 11.5 + 2.75, 2.75)
+    n = 0
+    rng = np.random.default_rng(5)
+    for step, add in enumerate([1, 63, 64, 0, 5836, 29_180, 130_000, 17, 120_000, 60_000]):
+        cloud[n:n + add] = pts[n:n + add].cuda()
+        n += add
+        n_dev.fill_(n)
+        pose = np.array([rng.uniform(-20, 20), 6.0 + 0.01 * step, rng.uniform(-20, 20), 0, 0], np.float32)
+        want = hu.accumulate_step_maps(cloud, torch.from_numpy(pose), ybins, S, gr, n_dev=n_dev)
+        got = hu.accumulate_step_maps(cloud, torch.from_numpy(pose), ybins, S, gr, n_dev=n_dev, bins=bins)
+        assert torch.equal(got, want), (step, n)
+        h = bins.header()
+        assert h["n_binned"] == n and h["error"] == 0 and h["n_overflow"] == 0, (step, h)
+    # a second build from the same state files nothing and gives the same maps (idempotent)
+    again = hu.accumulate_step_maps(cloud, torch.from_numpy(pose), ybins, S, gr, n_dev=n_dev, bins=bins)
+    assert torch.equal(again, want) and bins.header()["n_binned"] == n
+    # after reset() the store follows a new cloud from zero points
+    bins.reset()
+    n_dev.fill_(1000)
+    got = hu.accumulate_step_maps(cloud, torch.from_numpy(pose), ybins, S, gr, n_dev=n_dev, bins=bins)
+    assert torch.equal(got, hu.accumulate_step_maps(cloud[:1000], torch.from_numpy(pose), ybins, S, gr))
+    assert bins.header()["n_binned"] == 1000
+
+
+def test_binned_maps_points_that_cannot_be_filed_are_still_counted(hip):
+    """Points outside the tile grid, NaN points, and a tile that outgrows its 64 pages (a 150 k-point blob on one spot) go to the
+    side list and are counted with direct atomics: the maps still equal the append-order kernel's."""
+    S, gr = 256, (-40, 40)
+    rng = np.random.default_rng(11)
+    inside = _wall_cloud(60_000, seed=2, extent=10.0)
+    blob = torch.from_numpy(np.concatenate([rng.normal(3.0, 0.3, (150_000, 1)), rng.uniform(0, 12, (150_000, 1)),
+                                            rng.normal(-2.0, 0.3, (150_000, 1))], 1).astype(np.float32))
+    far = torch.from_numpy(rng.uniform(-39, 39, (5_000, 3)).astype(np.float32) * np.array([1, 0.1, 1], np.float32) + np.array([0, 5, 0], np.float32))
+    nan = torch.full((7, 3), float("nan"))
+    pc = torch.cat([inside, far, blob, nan, inside[:100]]).cuda().contiguous()
+    bins = hu.CloudBins((-12.0, -12.0), (12.0, 12.0), pc.shape[0], "cuda")          # `far` mostly lies outside this grid
+    ybins = torch.arange(0.5, 11.5 + 2.75, 2.75)
+    pose = torch.tensor([1.0, 5.05, -1.0, 0, 0])
+    want = hu.accumulate_step_maps(pc, pose, ybins, S, gr)
+    got = hu.accumulate_step_maps(pc, pose, ybins, S, gr, bins=bins)
+    assert torch.equal(got, want)
+    h = bins.header()
+    assert h["error"] == 0 and h["n_binned"] == pc.shape[0]
+    assert h["n_overflow"] > 1000                       # outside points + the blob's tail beyond 64 pages of its tiles
+    # ... and again from another pose (the side list is walked on every build)
+    pose2 = torch.tensor([-8.0, 5.05, 9.0, 0, 0])
+    assert torch.equal(hu.accumulate_step_maps(pc, pose2, ybins, S, gr, bins=bins), hu.accumulate_step_maps(pc, pose2, ybins, S, gr))
+
+
+def test_binned_step_maps_and_batch_equal_the_unbinned_calls(hip):
+    """nbp_step_maps_binned_f32 / _batch_f32 (trajectory channel, network input, group form with a low page bound) == nbp_step_maps_f32."""
+    S, gr = 256, (-40, 40)
+    ybins = torch.arange(0.5, 11.5 + 2.75, 2.75)
+    R = 5
+    clouds = [_wall_cloud(40_000 + 7_000 * r, seed=20 + r, extent=25.0).cuda().contiguous() for r in range(R)]
+    n_devs = [torch.tensor([c.shape[0] - 11 * r], dtype=torch.int64, device="cuda") for r, c in enumerate(clouds)]
+    binss = [hu.CloudBins((-52.0, -52.0), (52.0, 52.0), c.shape[0], "cuda") for c in clouds]
+    rng = np.random.default_rng(3)
+    for rnd in range(2):                       # second round: everything already filed
+        poses = [np.array([rng.uniform(-10, 10), 5.0, rng.uniform(-10, 10), 0, 0], np.float32) for _ in range(R)]
+        trajs = [(rng.standard_normal((3 + r, 3)) * 10).astype(np.float32) for r in range(R)]
+        items_a, items_b = [], []
+        for r in range(R):
+            ta, tb = torch.zeros(64, 3, device="cuda"), torch.zeros(64, 3, device="cuda")
+            ta[:2] = tb[:2] = torch.from_numpy(trajs[r][:2]).cuda()
+            items_a.append((clouds[r], clouds[r].shape[0], n_devs[r], poses[r], ybins, ta, 2, trajs[r][2:]))
+            items_b.append((clouds[r], 100, n_devs[r], poses[r], ybins, tb, 2, trajs[r][2:], binss[r]))      # n_upper far too low on purpose
+        o6a, nia = torch.zeros(R, 6, S, S, device="cuda"), torch.zeros(R, 5, S, S, device="cuda")
+        o6b, nib = torch.full((R, 6, S, S), 3.0, device="cuda"), torch.full((R, 5, S, S), 4.0, device="cuda")
+        hu.step_maps_batch(items_a, S, gr, o6a, nia)
+        hu.step_maps_batch(items_b, S, gr, o6b, nib)
+        assert torch.equal(o6a, o6b) and torch.equal(nia, nib), rnd
+        for r in range(R):
+            assert torch.equal(items_a[r][5], items_b[r][5])                    # trajectory history appended alike
+            assert binss[r].header()["n_binned"] == int(n_devs[r].item())
+        # single-call form
+        o6c, nic = torch.zeros(6, S, S, device="cuda"), torch.zeros(5, S, S, device="cuda")
+        tc = torch.zeros(64, 3, device="cuda")
+        tc[:2] = torch.from_numpy(trajs[0][:2]).cuda()
+        hu.step_maps(clouds[0], poses[0], ybins, S, gr, tc, 2, trajs[0][2:], o6c, nic, n_dev=n_devs[0], bins=binss[0])
+        assert torch.equal(o6c, o6a[0]) and torch.equal(nic, nia[0])

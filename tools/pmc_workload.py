@@ -48,6 +48,16 @@ def main():
         out = torch.empty(6, 256, 256, device=dev)
         for _ in range(2):
             hu.accumulate_step_maps(pc, pose, ybins, 256, (-40, 40), out=out)
+        # the step loop's build: the tile-binned shadow copy (utils.CloudBins).  The first call files every point (a tail-only
+        # launch, not what a step does); the two launches that follow are steady-state builds from the pages, and a last one meets
+        # one step's worth of new points: bench.py reads the launches by kernel name and takes the LAST three
+        n_new = min(29_180, a.points // 4)
+        n_dev = torch.tensor([a.points - n_new], dtype=torch.int64, device=dev)
+        bins = hu.CloudBins((-58.0, -58.0), (58.0, 58.0), pc.shape[0], dev)
+        for k in range(4):
+            if k == 3:
+                n_dev.fill_(a.points)
+            hu.accumulate_step_maps(pc, pose, ybins, 256, (-40, 40), n_dev=n_dev, out=out, bins=bins)
     torch.cuda.synchronize()
 
 
