@@ -287,28 +287,26 @@ int nbp_step_maps_batch_f32(int n, const float* const* points, const long long* 
  *                             (2.5-unit tiles with one tile of margin; 0 = bad arguments)
  *   nbp_cloud_bins_geometry   the same plan as numbers: {nx, nz, max_pages}, {x0, z0, tile}
  *   nbp_cloud_bins_init       empties the store (256-byte aligned): call it whenever the cloud is reset to zero points
- *   nbp_step_maps_binned_f32  nbp_step_maps_f32 on the store, ONE kernel launch: page workgroups build the maps from the pages filed
- *                             by earlier builds, tail workgroups count points [n_binned, N) of `points` directly and file them for
- *                             the builds to come.  parity = (number of builds on this store since its init) & 1: the page side
- *                             reads the snapshot of that parity, the tail side publishes the other one (the caller alternates).
- *                             page_bound = host upper bound of the pages in use (max_pages is always safe; a bound that is too low
- *                             only costs time).  traj_pts and net_in5 may both be NULL: only out6 is produced.  Points that cannot
- *                             be filed (outside the tile grid, more than 64 pages in one tile, pool exhausted) are kept in an index
- *                             list and counted with direct atomics: nothing is dropped; header word 2 (error) becomes non-zero only
- *                             if that list overflows too (65536 entries).
- *   nbp_step_maps_binned_batch_f32  the same for the n <= 16 rollouts of a lock-step group (stores[n], page_bound[n], parity[n]: HOST
- *                             arrays).
+ *   nbp_step_maps_binned_f32  nbp_step_maps_f32 on the store, two launches: points [n_binned, N) of `points` are filed into their
+ *                             tiles' pages, then the maps are built from the pages (every point is counted pre-aggregated per tile:
+ *                             a fused form that counted the new points with one global atomic each cost the lock-step 5 %).
+ *                             page_bound = page workgroups to launch (max_pages is always enough; fewer only cost time: they
+ *                             stride over every page that exists).  traj_pts and net_in5 may both be NULL: only out6 is produced.
+ *                             Points that cannot be filed (outside the tile grid, page pool exhausted) are kept in an index list
+ *                             and counted with direct atomics; if that list overflows too (65536 entries) header word 2 (error)
+ *                             becomes non-zero and every later build counts the whole cloud directly: slower, never wrong.
+ *   nbp_step_maps_binned_batch_f32  the same for the n <= 16 rollouts of a lock-step group (stores[n], page_bound[n]: HOST arrays).
  * Store header (device, int32 words): 0 n_pages, 1 n_overflow, 2 error, 3 ticket, 4-5 n_binned (int64). */
 size_t nbp_cloud_bins_bytes(const float* lo_xz_host, const float* hi_xz_host, long long capacity);
 int nbp_cloud_bins_geometry(const float* lo_xz_host, const float* hi_xz_host, long long capacity, int* nx_nz_maxpages_host,
                             float* x0_z0_tile_host);
 int nbp_cloud_bins_init(void* store, size_t store_bytes, const float* lo_xz_host, const float* hi_xz_host, long long capacity,
                         void* stream);
-int nbp_step_maps_binned_f32(void* store, int page_bound, int parity, const float* points, long long N, const long long* N_dev_or_null,
+int nbp_step_maps_binned_f32(void* store, int page_bound, const float* points, long long N, const long long* N_dev_or_null,
                              float cx, float cy, float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi,
                              int S, float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
                              int n_traj_fresh, float* out6, float* net_in5, void* stream);
-int nbp_step_maps_binned_batch_f32(int n, void* const* stores, const int* page_bound, const int* parity, const float* const* points,
+int nbp_step_maps_binned_batch_f32(int n, void* const* stores, const int* page_bound, const float* const* points,
                                    const long long* N_cap, const long long* const* N_dev, const float* poses_xyz_host,
                                    const float* bounds_host, const int* n_bounds, const float* band_lo_hi_host, int S, float lo,
                                    float hi, float* const* traj_pts, const int* n_traj_old, const float* traj_fresh_host,

@@ -51,10 +51,9 @@ SIGNATURES = {
     "nbp_cloud_bins_bytes": (_sz, [C.POINTER(_f), C.POINTER(_f), _ll]),
     "nbp_cloud_bins_geometry": (_i, [C.POINTER(_f), C.POINTER(_f), _ll, C.POINTER(_i), C.POINTER(_f)]),
     "nbp_cloud_bins_init": (_i, [_vp, _sz, C.POINTER(_f), C.POINTER(_f), _ll, _vp]),
-    "nbp_step_maps_binned_f32": (_i, [_vp, _i, _i, _vp, _ll, _vp, _f, _f, _f, C.POINTER(_f), _i, _f, _f, _i, _f, _f, _vp, _i, _vp, _i, _vp,
-                                      _vp, _vp]),
-    "nbp_step_maps_binned_batch_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp,
-                                            _vp]),
+    "nbp_step_maps_binned_f32": (_i, [_vp, _i, _vp, _ll, _vp, _f, _f, _f, C.POINTER(_f), _i, _f, _f, _i, _f, _f, _vp, _i, _vp, _i, _vp, _vp,
+                                      _vp]),
+    "nbp_step_maps_binned_batch_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nbp_unproject_workspace_bytes": (_sz, [_i, _i, _i]),
     "nbp_unproject_append_f32": (_i, [_vp, _vp, C.POINTER(_f), _i, _i, _i, _f, _f, _d, C.c_uint, _vp, _vp, _vp, _ll, _vp, _sz,
                                       _vp]),

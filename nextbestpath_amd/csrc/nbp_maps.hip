@@ -193,46 +193,49 @@ __global__ __launch_bounds__(THREADS) void map_accumulate_batch_kernel(MapBatch 
 // ------------------------------------------------------------------ tile-binned shadow copy of the cloud (round 4)
 // The six maps are a TRANSLATED window of the world (no rotation: cell = rint((-(v - c) + 40) * S / 80)), so a world-space tile of
 // T x T units always lands on a (T S / 80 + 1)^2 block of cells.  The canonical cloud stays in append order (coverage sampling,
-// parity); beside it every point is copied ONCE, by the first map build that sees it, into a page of its (x, z) tile:
-//   store = [BinDesc | tile_count[nt] | count_snap[2][nt] | page_table[nt][BIN_MAXP] | page_info[max_pages] | overflow[BIN_OVF] |
-//            pages[max_pages][2048][3]]
-// A map build is ONE launch whose workgroups take three roles:
-//   page workgroups   one per page: a DENSE 16 x 16-cell x 6-channel histogram in LDS (plain LDS adds, no CAS probing), flushed with
-//                     one global atomic per non-zero counter; tiles outside the +-40 window are never read;
-//   tail workgroups   the points the store has not seen yet ([n_binned, N): one step's ~29 k) are counted directly (global atomics)
-//                     AND filed into their tiles' pages for the builds to come;
-//   side list / trajectory channel.
-// Page workgroups and tail workgroups of one launch must not meet: the page side reads a SNAPSHOT of the tile counts / page count /
-// side-list length (slot `parity` of the double-buffered snapshots), the tail side updates the live counters, and the tail workgroup
-// that finishes last copies live -> snapshot[1 - parity] for the next build (the host alternates the parity per build).
+// parity); beside it every point is copied ONCE, before the first map build that sees it, into a page of its (x, z) tile:
+//   store = [BinDesc | tile_count[nt] | page_hash[H] | page_info[max_pages] | side_list[BIN_OVF] | pages[max_pages][2048][3]]
+// A map build is two launches:
+//   bin_append_kernel  files the points the store has not seen yet ([n_binned, N): one step's ~29 k) into their tiles' pages;
+//   map_binned_kernel  one workgroup per page: a DENSE 16 x 16-cell x 6-channel histogram in LDS (plain LDS adds, no CAS probing),
+//                      flushed with one global atomic per non-zero counter; tiles outside the +-40 window are never read; plus a
+//                      few workgroups for the side list and the trajectory channel.
+// Every point is counted from a page, i.e. pre-aggregated per tile.  A fused single-launch form that counted the new points with one
+// global atomic each was measured (profiles/r04/map_bins_in_situ.txt): 2 us faster alone, and 5 % of the lock-step's steps/s lost --
+// a frame's points fall on a handful of cells, and thousands of same-address device-scope atomics stall the memory channels the
+// concurrent convolutions stream through (the page side alone is free there).
 // Counts are integers, so the maps are bit-identical to map_accumulate_kernel's whatever the order (tests/test_gpu_maps.py, every
 // rollout parity test).
 // Slot reservation: one atomicAdd per (wave, tile), all of a wave's in flight together; the lane whose slot is the first of a page
-// allocates it and publishes its id in the page table (release), lanes of other waves spin on the entry (bounded) -- within a wave
-// every allocation is issued before any lane waits, so a waiter never blocks its own allocator.  What cannot be filed (outside the
-// tile grid, a tile beyond BIN_MAXP pages, the page pool exhausted, a spin that timed out) goes to an index list that every build
-// walks with direct atomics: nothing is ever dropped.
+// allocates it and publishes (tile, page ordinal) -> page id in an open-addressing hash (one 64-bit CAS: key and id appear together;
+// entries are never removed), lanes of other waves probe for the key and wait at the first empty slot of its probe sequence
+// (bounded) -- within a wave every allocation is issued before any lane waits, so a waiter never blocks its own allocator.  A tile
+// may own any number of pages (a wall the agent lingers at collects > 10^5 points).  What cannot be filed (outside the tile grid,
+// the page pool exhausted, a wait that timed out) goes to an index list that every build walks with direct atomics; if that list
+// fills up too the store marks itself broken (header word 2) and every later build counts the whole cloud directly:
+// slow, never wrong.
 constexpr int BIN_PAGE_BITS = 11, BIN_PAGE = 1 << BIN_PAGE_BITS;      // 2048 points = 24 KB per page
-constexpr int BIN_MAXP = 64;                                          // pages per tile: 131072 points, beyond -> side list
 constexpr unsigned BIN_OVF = 1u << 16;
 constexpr int BIN_R = 16;                                             // LDS histogram: 16 x 16 cells (a 2.5-unit tile is 9 x 9 + slack)
-constexpr int BIN_TAIL_WGS = 64, BIN_OVF_WGS = 2;
+constexpr int BIN_APPEND_WGS = 64, BIN_OVF_WGS = 4;
 struct BinDesc {                // head of the store (device memory, 256 B reserved)
-    unsigned n_pages, n_overflow, error, ticket;          // live counters (tail side)
+    unsigned n_pages, n_overflow, error, ticket;
     long long n_binned;                                   // points of the cloud already filed
-    unsigned n_pages_snap[2], n_overflow_snap[2];         // what the page side of a build with that parity may read
     int nx, nz, nt, max_pages;
     float x0, z0, inv_t, tile;
-    unsigned long long off_count, off_snap, off_table, off_info, off_ovf, off_pages, total_bytes;
+    unsigned hash_mask, pad0;                             // page hash: hash_mask + 1 entries (a power of two >= 2 max_pages)
+    unsigned long long off_count, off_table, off_info, off_ovf, off_pages, total_bytes;
 };
 static_assert(sizeof(BinDesc) <= 256, "BinDesc header");
 
-struct BinView { BinDesc* d; unsigned* count; unsigned* snap; int* table; unsigned* info; unsigned* ovf; float* pages; };
+struct BinView { BinDesc* d; unsigned* count; unsigned long long* table; unsigned* info; unsigned* ovf; float* pages; };
+constexpr unsigned long long BIN_EMPTY = ~0ull;           // hash entry: (key << 32) | page id; key = tile | page ordinal << 16
+constexpr unsigned BIN_POOL_EXHAUSTED = 0xFFFFFFFEu;      // page id published when the pool has no page left
 __device__ __forceinline__ BinView bin_view(char* store) {
     BinDesc* d = reinterpret_cast<BinDesc*>(store);
-    return BinView{d, reinterpret_cast<unsigned*>(store + d->off_count), reinterpret_cast<unsigned*>(store + d->off_snap),
-                   reinterpret_cast<int*>(store + d->off_table), reinterpret_cast<unsigned*>(store + d->off_info),
-                   reinterpret_cast<unsigned*>(store + d->off_ovf), reinterpret_cast<float*>(store + d->off_pages)};
+    return BinView{d, reinterpret_cast<unsigned*>(store + d->off_count), reinterpret_cast<unsigned long long*>(store + d->off_table),
+                   reinterpret_cast<unsigned*>(store + d->off_info), reinterpret_cast<unsigned*>(store + d->off_ovf),
+                   reinterpret_cast<float*>(store + d->off_pages)};
 }
 
 __device__ __forceinline__ int channel_of(float y, const Bounds& bd) {
@@ -250,95 +253,91 @@ __device__ __forceinline__ void count_direct(float x, float y, float z, const Ma
     if (a.band_lo < y && y < a.band_hi) atomicAdd(a.out + 5 * S * S + i0 * S + i1, 1.0f);
 }
 
-// tail workgroup `wg` of `n_wg`: points [n_binned, N) of the cloud are counted into the maps and filed into pages; the tail
-// workgroup that finishes last publishes the snapshot for the next build and advances n_binned
-__device__ __forceinline__ void bin_tail_body(const MapItem& a, const BinView& v, long long N, unsigned wg, unsigned n_wg, int parity, int S,
-                                              float lo, float sc) {
-    const float* __restrict__ cloud = a.p;
+// workgroup `wg` of `n_wg`: points [n_binned, N) of the cloud are filed into pages; the workgroup that finishes last advances n_binned
+__device__ __forceinline__ void bin_append_body(char* store, const float* __restrict__ cloud, long long N, unsigned wg, unsigned n_wg) {
+    const BinView v = bin_view(store);
     const long long first = v.d->n_binned;
-    const int nx = v.d->nx, nz = v.d->nz, max_pages = v.d->max_pages;
-    const float x0 = v.d->x0, z0 = v.d->z0, inv_t = v.d->inv_t;
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (long long i0 = first + (long long)wg * 256; i0 < N; i0 += (long long)n_wg * 256) {      // uniform per workgroup
-        const long long i = i0 + threadIdx.x;
-        const bool active = i < N;
-        f32x3 p = {__builtin_nanf(""), 0.f, 0.f};
-        if (active) p = *reinterpret_cast<const f32x3*>(cloud + 3 * i);
-        if (active) count_direct(p[0], p[1], p[2], a, S, lo, sc);
-        const float fx = (p[0] - x0) * inv_t, fz = (p[2] - z0) * inv_t;
-        const int tx = (int)floorf(fx), tz = (int)floorf(fz);
-        const bool inside = active && fx >= 0.f && fz >= 0.f && tx < nx && tz < nz;       // NaN fails
-        const int t = inside ? tz * nx + tx : -1;
-        // groups of lanes with the same tile (ballots only), then ONE reserving atomic per group, all in flight together
-        int leader = lane;
-        unsigned rank = 0, gsize = 0;
-        unsigned long long todo = __ballot(inside);
-        while (todo) {
-            const int l0 = __ffsll((long long)todo) - 1;
-            const int t0 = __shfl(t, l0);
-            const unsigned long long m = __ballot(inside && t == t0);
-            if (inside && t == t0) { leader = l0; rank = (unsigned)__popcll(m & lt); gsize = (unsigned)__popcll(m); }
-            todo &= ~m;
-        }
-        unsigned b = 0;
-        if (inside && lane == leader) b = atomicAdd(&v.count[t], gsize);
-        b = __shfl(b, leader);
-        const unsigned slot = b + rank;
-        const unsigned k = slot >> BIN_PAGE_BITS;
-        const bool paged = inside && k < (unsigned)BIN_MAXP;
-        int* entry = paged ? v.table + (size_t)t * BIN_MAXP + k : nullptr;
-        if (paged && (slot & (BIN_PAGE - 1)) == 0) {          // first slot of a page: allocate it and publish its id
-            const unsigned pid = atomicAdd(&v.d->n_pages, 1u);
-            int pub = -2;                                     // -2: the pool is exhausted (waiters go to the side list)
-            if (pid < (unsigned)max_pages) { v.info[pid] = (unsigned)t | (k << 16); pub = (int)pid; }
-            __hip_atomic_store(entry, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        int pid = -1;
-        if (paged) {
-            int budget = 1 << 20;
-            pid = __hip_atomic_load(entry, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            while (pid == -1 && --budget > 0) {
-                __builtin_amdgcn_s_sleep(2);
-                pid = __hip_atomic_load(entry, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (v.d->error == 0u) {                               // (a broken store files nothing more: its builds scan the cloud)
+        const int nx = v.d->nx, nz = v.d->nz, max_pages = v.d->max_pages;
+        const float x0 = v.d->x0, z0 = v.d->z0, inv_t = v.d->inv_t;
+        const unsigned mask = v.d->hash_mask;
+        const int lane = threadIdx.x & 63;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (long long i0 = first + (long long)wg * 256; i0 < N; i0 += (long long)n_wg * 256) {      // uniform per workgroup
+            const long long i = i0 + threadIdx.x;
+            const bool active = i < N;
+            f32x3 p = {__builtin_nanf(""), 0.f, 0.f};
+            if (active) p = *reinterpret_cast<const f32x3*>(cloud + 3 * i);
+            const float fx = (p[0] - x0) * inv_t, fz = (p[2] - z0) * inv_t;
+            const int tx = (int)floorf(fx), tz = (int)floorf(fz);
+            const bool inside = active && fx >= 0.f && fz >= 0.f && tx < nx && tz < nz;       // NaN fails
+            const int t = inside ? tz * nx + tx : -1;
+            // groups of lanes with the same tile (ballots only), then ONE reserving atomic per group, all in flight together
+            int leader = lane;
+            unsigned rank = 0, gsize = 0;
+            unsigned long long todo = __ballot(inside);
+            while (todo) {
+                const int l0 = __ffsll((long long)todo) - 1;
+                const int t0 = __shfl(t, l0);
+                const unsigned long long m = __ballot(inside && t == t0);
+                if (inside && t == t0) { leader = l0; rank = (unsigned)__popcll(m & lt); gsize = (unsigned)__popcll(m); }
+                todo &= ~m;
             }
-        }
-        if (pid >= 0) {
-            float* dst = v.pages + ((size_t)pid * BIN_PAGE + (slot & (BIN_PAGE - 1))) * 3;
-            dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
-        } else if (active) {
-            const unsigned q = atomicAdd(&v.d->n_overflow, 1u);
-            if (q < BIN_OVF) v.ovf[q] = (unsigned)i;
-            else v.d->error = 1u;                             // (checked by the host: tests, end of a rollout)
+            unsigned b = 0;
+            if (inside && lane == leader) b = atomicAdd(&v.count[t], gsize);
+            b = __shfl(b, leader);
+            const unsigned slot = b + rank;
+            const unsigned k = slot >> BIN_PAGE_BITS;
+            const unsigned key = (unsigned)t | (k << 16);
+            unsigned pos = (key * 0x9E3779B1u) >> 7 & mask;
+            if (inside && (slot & (BIN_PAGE - 1)) == 0) {         // first slot of a page: allocate it and publish (key -> id)
+                const unsigned got = atomicAdd(&v.d->n_pages, 1u);
+                unsigned pub = BIN_POOL_EXHAUSTED;                // the pool is exhausted: waiters go to the side list
+                if (got < (unsigned)max_pages) { v.info[got] = key; pub = got; }
+                const unsigned long long e = ((unsigned long long)key << 32) | pub;
+                unsigned q = pos;
+                for (unsigned probe = 0; probe <= mask; ++probe, q = (q + 1) & mask)
+                    if (atomicCAS(&v.table[q], BIN_EMPTY, e) == BIN_EMPTY) break;         // (2 max_pages entries: a free one exists)
+            }
+            int pid = -1;
+            if (inside) {
+                int budget = 1 << 20;
+                while (budget > 0) {
+                    // (relaxed: only the entry itself is awaited -- an acquire here is an L2 invalidate per probe on gfx950)
+                    const unsigned long long e = __hip_atomic_load(&v.table[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (e == BIN_EMPTY) { --budget; __builtin_amdgcn_s_sleep(2); continue; }    // not published yet: it lands here or later
+                    if ((unsigned)(e >> 32) == key) { const unsigned id = (unsigned)e; pid = id == BIN_POOL_EXHAUSTED ? -2 : (int)id; break; }
+                    pos = (pos + 1) & mask;                       // another key's entry (permanent): move on
+                }
+            }
+            if (pid >= 0) {
+                float* dst = v.pages + ((size_t)pid * BIN_PAGE + (slot & (BIN_PAGE - 1))) * 3;
+                dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+            } else if (active) {
+                const unsigned q = atomicAdd(&v.d->n_overflow, 1u);
+                if (q < BIN_OVF) v.ovf[q] = (unsigned)i;
+                else v.d->error = 1u;                             // broken from the next build on: the whole cloud is counted directly
+            }
         }
     }
     __shared__ int last;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(&v.d->ticket, 1u) == n_wg - 1;
-    }
+    if (threadIdx.x == 0)       // (no fence: __threadfence() is an L2 write-back + invalidate here, and the last workgroup reads nothing
+        last = atomicAdd(&v.d->ticket, 1u) == n_wg - 1;      //  the others wrote: what they filed is read by later launches only)
     __syncthreads();
-    if (last) {             // every tail workgroup has filed its points: live -> the snapshot the NEXT build's page side reads
-        __threadfence();
-        unsigned* dst = v.snap + (size_t)(1 - parity) * v.d->nt;
-        for (int q = threadIdx.x; q < v.d->nt; q += 256) dst[q] = __hip_atomic_load(&v.count[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (threadIdx.x == 0) {
-            v.d->n_pages_snap[1 - parity] = __hip_atomic_load(&v.d->n_pages, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v.d->n_overflow_snap[1 - parity] = __hip_atomic_load(&v.d->n_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v.d->n_binned = N > first ? N : first;
-            v.d->ticket = 0;
-        }
+    if (last && threadIdx.x == 0) {
+        v.d->n_binned = N > first ? N : first;
+        v.d->ticket = 0;
     }
 }
 
-// One workgroup of 256 threads.  Roles by index: [0, n_page_wg) pages, then BIN_TAIL_WGS tail, BIN_OVF_WGS side list, 1 trajectory.
-__device__ __forceinline__ void map_binned_body(const MapItem& a, char* store, unsigned wg, unsigned n_page_wg, int parity, int S, float lo,
+// One workgroup of 256 threads.  Roles by index: [0, n_page_wg) pages, then BIN_OVF_WGS side list, 1 trajectory.
+__device__ __forceinline__ void map_binned_body(const MapItem& a, char* store, unsigned wg, unsigned n_page_wg, int S, float lo,
                                                 float sc, int* hist) {
     float* __restrict__ out = a.out;
     const float cx = a.cx, cz = a.cz;
     const int SS = S * S;
-    if (wg == n_page_wg + BIN_TAIL_WGS + BIN_OVF_WGS) {     // trajectory workgroup (as in map_accumulate_body)
+    if (wg == n_page_wg + BIN_OVF_WGS) {                    // trajectory workgroup (as in map_accumulate_body)
         const TrajArgs& tr = a.tr;
         if (!tr.out) return;
         for (int i = threadIdx.x; i < tr.n_old + tr.n_fresh; i += 256) {
@@ -359,27 +358,32 @@ __device__ __forceinline__ void map_binned_body(const MapItem& a, char* store, u
         return;
     }
     const BinView v = bin_view(store);
-    if (wg >= n_page_wg + BIN_TAIL_WGS) {                  // the side list as of the previous build: direct atomics
-        const unsigned n = min(v.d->n_overflow_snap[parity], BIN_OVF);
-        for (unsigned i = (wg - n_page_wg - BIN_TAIL_WGS) * 256 + threadIdx.x; i < n; i += BIN_OVF_WGS * 256) {
+    const bool broken = v.d->error != 0u;                  // (set by an append launch, never by this one)
+    if (wg >= n_page_wg) {                                 // the side list -- or, for a broken store, the whole cloud -- with direct atomics
+        const unsigned w = wg - n_page_wg;
+        if (broken) {
+            long long N = a.N;
+            if (a.n_dev) N = *a.n_dev;
+            for (long long i = (long long)w * 256 + threadIdx.x; i < N; i += (long long)BIN_OVF_WGS * 256) {
+                const f32x3 p = *reinterpret_cast<const f32x3*>(a.p + 3 * i);
+                count_direct(p[0], p[1], p[2], a, S, lo, sc);
+            }
+            return;
+        }
+        const unsigned n = min(v.d->n_overflow, BIN_OVF);
+        for (unsigned i = w * 256 + threadIdx.x; i < n; i += BIN_OVF_WGS * 256) {
             const f32x3 p = *reinterpret_cast<const f32x3*>(a.p + 3 * (size_t)v.ovf[i]);
             count_direct(p[0], p[1], p[2], a, S, lo, sc);
         }
         return;
     }
-    if (wg >= n_page_wg) {
-        long long N = a.N;
-        if (a.n_dev) N = *a.n_dev;
-        bin_tail_body(a, v, N, wg - n_page_wg, BIN_TAIL_WGS, parity, S, lo, sc);
-        return;
-    }
-    const unsigned n_pages = min(v.d->n_pages_snap[parity], (unsigned)v.d->max_pages);
-    const unsigned* __restrict__ tcount = v.snap + (size_t)parity * v.d->nt;
+    if (broken) return;
+    const unsigned n_pages = min(v.d->n_pages, (unsigned)v.d->max_pages);
     // (one page per workgroup when the host's bound n_page_wg covers the pages that exist; a bound that is too low only costs time)
     for (unsigned page = wg; page < n_pages; page += n_page_wg) {
         const unsigned info = v.info[page];
         const int t = (int)(info & 0xffffu), k = (int)(info >> 16);
-        const unsigned tc = tcount[t];
+        const unsigned tc = v.count[t];
         if (tc <= (unsigned)k * BIN_PAGE) continue;        // (cannot happen: a page exists once its first slot is reserved)
         const int cnt = (int)min((unsigned)BIN_PAGE, tc - (unsigned)k * BIN_PAGE);
         // the block of cells the tile can reach (one cell of slack each way: a point outside it, or outside the LDS block, goes direct)
@@ -429,27 +433,34 @@ __device__ __forceinline__ void map_binned_body(const MapItem& a, char* store, u
     }
 }
 
-__global__ __launch_bounds__(256) void map_binned_kernel(MapItem a, char* store, unsigned n_page_wg, int parity, int S, float lo, float sc) {
-    __shared__ int hist[6 * BIN_R * BIN_R];
-    map_binned_body(a, store, blockIdx.x, n_page_wg, parity, S, lo, sc, hist);
+__global__ __launch_bounds__(256) void bin_append_kernel(char* store, const float* __restrict__ cloud, long long N, const long long* n_dev) {
+    bin_append_body(store, cloud, n_dev ? *n_dev : N, blockIdx.x, gridDim.x);
 }
-struct BinBatch { char* store[MAP_BATCH]; unsigned n_page_wg[MAP_BATCH]; unsigned parity_bits; };
+__global__ __launch_bounds__(256) void map_binned_kernel(MapItem a, char* store, unsigned n_page_wg, int S, float lo, float sc) {
+    __shared__ int hist[6 * BIN_R * BIN_R];
+    map_binned_body(a, store, blockIdx.x, n_page_wg, S, lo, sc, hist);
+}
+struct BinBatch { char* store[MAP_BATCH]; unsigned n_page_wg[MAP_BATCH]; };
+__global__ __launch_bounds__(256) void bin_append_batch_kernel(MapBatch b, BinBatch s) {
+    const MapItem& a = b.it[blockIdx.y];
+    bin_append_body(s.store[blockIdx.y], a.p, a.n_dev ? *a.n_dev : a.N, blockIdx.x, gridDim.x);
+}
 __global__ __launch_bounds__(256) void map_binned_batch_kernel(MapBatch b, BinBatch s, int S, float lo, float sc) {
     __shared__ int hist[6 * BIN_R * BIN_R];
     const unsigned r = blockIdx.y;
-    if (blockIdx.x >= s.n_page_wg[r] + BIN_TAIL_WGS + BIN_OVF_WGS + 1) return;
-    map_binned_body(b.it[r], s.store[r], blockIdx.x, s.n_page_wg[r], (int)((s.parity_bits >> r) & 1u), S, lo, sc, hist);
+    if (blockIdx.x >= s.n_page_wg[r] + BIN_OVF_WGS + 1) return;
+    map_binned_body(b.it[r], s.store[r], blockIdx.x, s.n_page_wg[r], S, lo, sc, hist);
 }
 
 __global__ __launch_bounds__(256) void bin_init_kernel(char* store, BinDesc d) {
     BinDesc* dd = reinterpret_cast<BinDesc*>(store);
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
     if (gid == 0) *dd = d;
-    unsigned* count = reinterpret_cast<unsigned*>(store + d.off_count);       // live counts, then the two snapshots (contiguous)
-    int* table = reinterpret_cast<int*>(store + d.off_table);
+    unsigned* count = reinterpret_cast<unsigned*>(store + d.off_count);
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(store + d.off_table);
     float* pages = reinterpret_cast<float*>(store + d.off_pages);
-    for (size_t i = gid; i < (size_t)d.nt * 3; i += stride) count[i] = 0u;
-    for (size_t i = gid; i < (size_t)d.nt * BIN_MAXP; i += stride) table[i] = -1;
+    for (size_t i = gid; i < (size_t)d.nt; i += stride) count[i] = 0u;
+    for (size_t i = gid; i <= (size_t)d.hash_mask; i += stride) table[i] = BIN_EMPTY;
     const float nanv = __builtin_nanf("");
     for (size_t i = gid; i < (size_t)d.max_pages * BIN_PAGE * 3; i += stride) pages[i] = nanv;     // empty slots fail cell_of
 }
@@ -460,17 +471,22 @@ static BinDesc bin_desc(const float* lo_xz, const float* hi_xz, long long capaci
     memset(&d, 0, sizeof d);
     float T = 2.5f;                                        // 8 cells of the 0.3125-unit grid
     const float ex = hi_xz[0] - lo_xz[0], ez = hi_xz[1] - lo_xz[1];
-    while (((double)ex / T + 3.0) * ((double)ez / T + 3.0) > 16384.0) T *= 2.f;      // (tile ids are 16 bits)
+    while (((double)ex / T + 3.0) * ((double)ez / T + 3.0) > 65535.0) T *= 2.f;      // tile ids are 16 bits (2.5-unit tiles up to ~630 x 630 units;
+                                                                                        // larger tiles still work: cells beyond the 16 x 16 LDS block go direct)
     d.tile = T; d.inv_t = 1.0f / T;
     d.x0 = lo_xz[0] - T; d.z0 = lo_xz[1] - T;              // one tile of margin
     d.nx = (int)(ex / T) + 3; d.nz = (int)(ez / T) + 3;
     d.nt = d.nx * d.nz;
-    d.max_pages = (int)(capacity / BIN_PAGE) + d.nt + 64;
+    // every occupied tile ends in a partial page; scenes are mostly empty space, so the pool holds 4096 of those (a rollout's cloud
+    // touches a few hundred tiles) -- beyond, the side list takes over
+    d.max_pages = (int)(capacity / BIN_PAGE) + (d.nt < 4096 ? d.nt : 4096) + 64;
+    unsigned hsize = 1024;
+    while (hsize < 2u * (unsigned)d.max_pages) hsize *= 2;
+    d.hash_mask = hsize - 1;
     unsigned long long off = 256;
     auto take = [&](unsigned long long bytes) { const unsigned long long o = off; off += (bytes + 255) / 256 * 256; return o; };
-    d.off_count = take((unsigned long long)d.nt * 4 * 3);  // live + 2 snapshots
-    d.off_snap = d.off_count + (unsigned long long)d.nt * 4;
-    d.off_table = take((unsigned long long)d.nt * BIN_MAXP * 4);
+    d.off_count = take((unsigned long long)d.nt * 4);
+    d.off_table = take((unsigned long long)hsize * 8);
     d.off_info = take((unsigned long long)d.max_pages * 4);
     d.off_ovf = take((unsigned long long)BIN_OVF * 4);
     d.off_pages = take((unsigned long long)d.max_pages * BIN_PAGE * 12);
@@ -478,7 +494,7 @@ static BinDesc bin_desc(const float* lo_xz, const float* hi_xz, long long capaci
     return d;
 }
 static bool bin_geometry_ok(const float* lo_xz, const float* hi_xz, long long capacity) {
-    return lo_xz && hi_xz && capacity > 0 && capacity < (1ll << 32) && hi_xz[0] >= lo_xz[0] && hi_xz[1] >= lo_xz[1] &&
+    return lo_xz && hi_xz && capacity > 0 && capacity < 65535ll * BIN_PAGE && hi_xz[0] >= lo_xz[0] && hi_xz[1] >= lo_xz[1] &&
            hi_xz[0] - lo_xz[0] < 1e6f && hi_xz[1] - lo_xz[1] < 1e6f;
 }
 
@@ -653,11 +669,12 @@ extern "C" int nbp_cloud_bins_init(void* store, size_t store_bytes, const float*
     return nbp_launch_status();
 }
 
-// The step's map stage (nbp_step_maps_f32) on the binned copy, one launch (map_binned_kernel): points of the cloud that no build has
-// seen yet are counted directly and filed into their tiles' pages, everything else is counted from the pages.  page_bound: the
-// host's upper bound on the pages in use (the store's max_pages is always safe; a tighter bound launches fewer idle workgroups).
+// The step's map stage (nbp_step_maps_f32) on the binned copy: points of the cloud that no build has seen yet are filed into their
+// tiles' pages (bin_append_kernel), then the six maps are built from the pages (map_binned_kernel).  page_bound: the host's bound on
+// the pages in use (the store's max_pages is always safe; a tighter bound launches fewer idle workgroups; one that is too low only
+// costs time: page workgroups stride over every page that exists).
 // traj_pts / net_in5 may both be null: only out6 is produced (the reference-API form accumulate_step_maps).
-extern "C" int nbp_step_maps_binned_f32(void* store, int page_bound, int parity, const float* points, long long N, const long long* N_dev_or_null,
+extern "C" int nbp_step_maps_binned_f32(void* store, int page_bound, const float* points, long long N, const long long* N_dev_or_null,
                                         float cx, float cy, float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi,
                                         int S, float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
                                         int n_traj_fresh, float* out6, float* net_in5, void* stream) {
@@ -686,9 +703,13 @@ extern "C" int nbp_step_maps_binned_f32(void* store, int page_bound, int parity,
         tr.pts = traj_pts; tr.out = net_in5 + 4 * SS; tr.n_old = n_traj_old; tr.n_fresh = n_traj_fresh;
         for (int i = 0; i < 24; ++i) tr.fresh[i] = i < 3 * n_traj_fresh ? traj_fresh_host[i] : 0.f;
     }
-    NBP_RETURN_IF(parity != 0 && parity != 1, NBP_E_ARG);
-    map_binned_kernel<<<(unsigned)page_bound + BIN_TAIL_WGS + BIN_OVF_WGS + 1, 256, 0, st>>>(
-        MapItem{points, N, N_dev_or_null, cx, cz, bd, band_lo, band_hi, out6, tr}, (char*)store, (unsigned)page_bound, parity, S, lo,
+    if (N > 0) {
+        bin_append_kernel<<<BIN_APPEND_WGS, 256, 0, st>>>((char*)store, points, N, N_dev_or_null);
+        const int rc0 = nbp_launch_status();
+        if (rc0) return rc0;
+    }
+    map_binned_kernel<<<(unsigned)page_bound + BIN_OVF_WGS + 1, 256, 0, st>>>(
+        MapItem{points, N, N_dev_or_null, cx, cz, bd, band_lo, band_hi, out6, tr}, (char*)store, (unsigned)page_bound, S, lo,
         grid_scale(S, lo, hi));
     int rc = nbp_launch_status();
     if (rc || !net_in5) return rc;
@@ -697,14 +718,13 @@ extern "C" int nbp_step_maps_binned_f32(void* store, int page_bound, int parity,
 }
 
 // nbp_step_maps_batch_f32 on the rollouts' binned copies (stores[n], page_bound[n]: HOST arrays)
-extern "C" int nbp_step_maps_binned_batch_f32(int n, void* const* stores, const int* page_bound, const int* parity,
-                                              const float* const* points,
+extern "C" int nbp_step_maps_binned_batch_f32(int n, void* const* stores, const int* page_bound, const float* const* points,
                                               const long long* N_cap, const long long* const* N_dev, const float* poses_xyz_host,
                                               const float* bounds_host, const int* n_bounds, const float* band_lo_hi_host, int S, float lo,
                                               float hi, float* const* traj_pts, const int* n_traj_old, const float* traj_fresh_host,
                                               const int* n_traj_fresh, float* out6_all, float* net_in_all, void* stream) {
     NBP_ENTER();
-    NBP_RETURN_IF(n < 1 || n > MAP_BATCH || !stores || !page_bound || !parity || !points || !N_cap || !N_dev || !poses_xyz_host || !bounds_host ||
+    NBP_RETURN_IF(n < 1 || n > MAP_BATCH || !stores || !page_bound || !points || !N_cap || !N_dev || !poses_xyz_host || !bounds_host ||
                   !n_bounds || !band_lo_hi_host || !traj_pts || !n_traj_old || !traj_fresh_host || !n_traj_fresh || !out6_all || !net_in_all,
                   NBP_E_ARG);
     NBP_RETURN_IF(S < 1 || !(hi > lo) || (long long)6 * S * S >= (1ll << 31), NBP_E_SHAPE);
@@ -712,7 +732,6 @@ extern "C" int nbp_step_maps_binned_batch_f32(int n, void* const* stores, const 
     const size_t SS = (size_t)S * S;
     MapBatch b;
     BinBatch s;
-    s.parity_bits = 0u;
     unsigned max_wg = 1;
     for (int r = 0; r < MAP_BATCH; ++r) {
         const int q = r < n ? r : 0;
@@ -731,15 +750,17 @@ extern "C" int nbp_step_maps_binned_batch_f32(int n, void* const* stores, const 
         for (int i = 0; i < 24; ++i) it.tr.fresh[i] = i < 3 * n_traj_fresh[q] ? traj_fresh_host[24 * q + i] : 0.f;
         b.n_wg[r] = 0;
         s.store[r] = (char*)stores[q]; s.n_page_wg[r] = r < n ? (unsigned)page_bound[q] : 0u;
-        if (r < n && (parity[q] & 1)) s.parity_bits |= 1u << r;
-        if (r < n && s.n_page_wg[r] + BIN_TAIL_WGS + BIN_OVF_WGS + 1 > max_wg) max_wg = s.n_page_wg[r] + BIN_TAIL_WGS + BIN_OVF_WGS + 1;
+        if (r < n && s.n_page_wg[r] + BIN_OVF_WGS + 1 > max_wg) max_wg = s.n_page_wg[r] + BIN_OVF_WGS + 1;
     }
     hipError_t e = hipMemsetAsync(out6_all, 0, (size_t)n * 6 * SS * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     e = hipMemset2DAsync(net_in_all + 4 * SS, 5 * SS * sizeof(float), 0, SS * sizeof(float), (size_t)n, st);       // the trajectory channels
     if (e != hipSuccess) return (int)e;
-    map_binned_batch_kernel<<<dim3(max_wg, (unsigned)n), 256, 0, st>>>(b, s, S, lo, grid_scale(S, lo, hi));
+    bin_append_batch_kernel<<<dim3(BIN_APPEND_WGS, (unsigned)n), 256, 0, st>>>(b, s);
     int rc = nbp_launch_status();
+    if (rc) return rc;
+    map_binned_batch_kernel<<<dim3(max_wg, (unsigned)n), 256, 0, st>>>(b, s, S, lo, grid_scale(S, lo, hi));
+    rc = nbp_launch_status();
     if (rc) return rc;
     e = hipMemcpy2DAsync(net_in_all, 5 * SS * sizeof(float), out6_all, 6 * SS * sizeof(float), 4 * SS * sizeof(float), (size_t)n,
                          hipMemcpyDeviceToDevice, st);

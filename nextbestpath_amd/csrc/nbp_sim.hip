@@ -243,7 +243,7 @@ __device__ __forceinline__ void unproject_append_body(unsigned bx, unsigned by, 
                                                                const float* __restrict__ rgb, float* __restrict__ cloud_rgb,
                                                                const unsigned long long* __restrict__ zface,
                                                                const float* __restrict__ verts, const int* __restrict__ faces,
-                                                               const float* __restrict__ vcolors, float ambient) {
+                                                               const float* __restrict__ vcolors, float ambient, int fence = 0) {
     const int f = by;
     const int HW = H * W;
     const int nvalid = counts[2 * f], nkeep = counts[2 * f + 1];
@@ -278,7 +278,11 @@ __device__ __forceinline__ void unproject_append_body(unsigned bx, unsigned by, 
     __shared__ int last;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        // No fence: on gfx950 __threadfence() is an L2 write-back + invalidate (buffer_wbl2 sc1 / buffer_inv sc1) -- thousands of
+        // them per lock-step group flush the L2 lines of the convolutions running beside this kernel.  None is needed: this block's
+        // read of *cloud_count was consumed (the stores above used it) before the barrier, what the last block reads (counts) was
+        // written by an earlier launch, and what this launch writes is read by later launches only.  (fence = 1: the round-3 form, A/B.)
+        if (fence) __threadfence();
         last = atomicAdd(done_ticket, 1) == (int)(gx * gy) - 1;
     }
     __syncthreads();
@@ -330,16 +334,17 @@ __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __re
                                                                int* __restrict__ done_ticket, const float* __restrict__ rgb,
                                                                float* __restrict__ cloud_rgb, const unsigned long long* __restrict__ zface,
                                                                const float* __restrict__ verts, const int* __restrict__ faces,
-                                                               const float* __restrict__ vcolors, float ambient) {
+                                                               const float* __restrict__ vcolors, float ambient, int fence) {
     unproject_append_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, depth, cams.c, H, W, tanh_fov, seed, list, counts, cloud, cloud_count,
-                          capacity, n_frames, done_ticket, rgb, cloud_rgb, zface, verts, faces, vcolors, ambient);
+                          capacity, n_frames, done_ticket, rgb, cloud_rgb, zface, verts, faces, vcolors, ambient, fence);
 }
-__global__ __launch_bounds__(256) void unproject_append_batch_kernel(UnprojBatch b, int H, int W, float tanh_fov, int n_frames, float ambient) {
+__global__ __launch_bounds__(256) void unproject_append_batch_kernel(UnprojBatch b, int H, int W, float tanh_fov, int n_frames, float ambient,
+                                                                     int fence) {
     const UnprojItem& a = b.it[blockIdx.z];
     const size_t shift = (size_t)blockIdx.y * H * W;
     unproject_append_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth[blockIdx.y] - shift, a.cam, H, W, tanh_fov, a.seed, a.list,
                           a.counts, a.cloud, a.cloud_count, a.capacity, n_frames, a.ticket, nullptr, a.cloud_rgb,
-                          a.zface[blockIdx.y] ? a.zface[blockIdx.y] - shift : nullptr, a.verts, a.faces, a.vcolors, ambient);
+                          a.zface[blockIdx.y] ? a.zface[blockIdx.y] - shift : nullptr, a.verts, a.faces, a.vcolors, ambient, fence);
 }
 
 __global__ void cloud_count_update_kernel(const int* __restrict__ counts, int F, long long* __restrict__ cloud_count,
@@ -881,6 +886,7 @@ static CamSet camset_from_host(const float* cams12_host, int n) {
     return cs;
 }
 
+static int ticket_fence() { static const int v = nbp_tune_int("NBP_TICKET_FENCE", 0); return v; }
 struct ShadeSrc { const unsigned long long* zface; const float* verts; const int* faces; const float* vcolors; float ambient; };
 static int unproject_launch(const float* depth, const unsigned char* mask_or_null, const float* cams12_host, int n_frames, int H,
                             int W, float tan_half_fov, float fov_range, double gathering_factor, unsigned seed, int* counts2,
@@ -952,7 +958,7 @@ static int unproject_launch(const float* depth, const unsigned char* mask_or_nul
         if ((rc = nbp_launch_status())) return rc;
         unproject_append_kernel<<<grid, 256, 0, st>>>(depth, cams, H, W, tan_half_fov, seed, list, counts2, cloud, cloud_count,
                                                       capacity, n_frames, ticket, rgb_or_null, cloud_rgb_or_null, sh.zface, sh.verts, sh.faces,
-                                                      sh.vcolors, sh.ambient);
+                                                      sh.vcolors, sh.ambient, ticket_fence());
         return nbp_launch_status();
     }
     dim3 gc((unsigned)nblk, (unsigned)n_frames);
@@ -963,7 +969,7 @@ static int unproject_launch(const float* depth, const unsigned char* mask_or_nul
     if ((rc = nbp_launch_status())) return rc;
     unproject_append_kernel<<<grid, 256, 0, st>>>(depth, cams, H, W, tan_half_fov, seed, list, counts2, cloud, cloud_count,
                                                   capacity, n_frames, nullptr, rgb_or_null, cloud_rgb_or_null, sh.zface, sh.verts, sh.faces,
-                                                  sh.vcolors, sh.ambient);
+                                                  sh.vcolors, sh.ambient, 0);
     if ((rc = nbp_launch_status())) return rc;
     cloud_count_update_kernel<<<1, 64, 0, st>>>(counts2, n_frames, cloud_count, capacity);
     return nbp_launch_status();
@@ -1133,7 +1139,7 @@ extern "C" int nbp_unproject_append_shaded_batch_f32(int n, const float* const* 
     if ((rc = nbp_launch_status())) return rc;
     const int max_keep = (int)((double)H * W * gathering_factor) + 1;
     dim3 grid((unsigned)nbp_cdiv(max_keep, 256), (unsigned)n_frames, (unsigned)n);
-    unproject_append_batch_kernel<<<grid, 256, 0, st>>>(b, H, W, tan_half_fov, n_frames, ambient);
+    unproject_append_batch_kernel<<<grid, 256, 0, st>>>(b, H, W, tan_half_fov, n_frames, ambient, ticket_fence());
     return nbp_launch_status();
 }
 

@@ -71,9 +71,9 @@ def map_points_to_n_imgs(points_2d_batch, grid_size, grid_range, device=None):
 
 
 class CloudBins:
-    """Tile-binned shadow copy of ONE cloud tensor (include/nbp_hip.h "Tile-binned shadow copy"): a map build counts the points it
-    has not seen yet directly and files them into 2048-point pages of their 2.5-unit (x, z) tile, and builds the rest of the six
-    maps from the pages -- one workgroup per page on a dense LDS histogram, tiles outside the window never read; one launch.  The maps are bit-identical to the
+    """Tile-binned shadow copy of ONE cloud tensor (include/nbp_hip.h "Tile-binned shadow copy"): a map build files the points it
+    has not seen yet into 2048-point pages of their 2.5-unit (x, z) tile and builds the six maps from the pages -- one workgroup
+    per page on a dense LDS histogram, tiles outside the window never read.  The maps are bit-identical to the
     unbinned kernel's.  `lo_xz` / `hi_xz`: the scene's horizontal extent (points outside it are still counted, through a slower
     side list).  The store follows the cloud from zero points: call reset() whenever the cloud is emptied."""
 
@@ -92,22 +92,17 @@ class CloudBins:
         self.store = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.reset()
 
-    def next_parity(self):
-        """Parity of the build about to be enqueued (its page side reads that snapshot; its tail side publishes the other one)."""
-        p = self.builds & 1
-        self.builds += 1
-        return p
-
     def reset(self):
-        self.builds = 0
         with torch.cuda.device(self.store.device):
             rc = _lib.lib().nbp_cloud_bins_init(self.store.data_ptr(), self.store.numel(), self.lo, self.hi, self.capacity,
                                                 _lib.current_stream())
         _lib.check(rc, "nbp_cloud_bins_init")
 
     def page_bound(self, n_upper):
-        """Upper bound of the pages in use for a cloud of at most n_upper points (every tile may hold one partial page)."""
-        return max(1, min(self.max_pages, int(n_upper) // 2048 + self.nx * self.nz + 1))
+        """Page workgroups to launch for a cloud of at most n_upper points: the full pages plus room for 512 tiles' partial ones (a
+        rollout's cloud sits on a few hundred tiles).  NOT a correctness bound: the kernel's page workgroups stride over every
+        page that exists, so a cloud on more tiles than that only costs time."""
+        return max(1, min(self.max_pages, int(n_upper) // 2048 + min(self.nx * self.nz, 512) + 1))
 
     def header(self):
         """{n_pages, n_overflow, error, n_binned} (synchronises: tests and end-of-rollout checks only)."""
@@ -142,7 +137,7 @@ def accumulate_step_maps(full_pc, camera_pose, y_bins, grid_size=256, grid_range
         if bins is not None:          # on the tile-binned shadow copy of THIS cloud tensor (CloudBins): same maps, bit for bit
             if p.data_ptr() != full_pc.data_ptr():
                 raise ValueError("accumulate_step_maps(bins=...): the cloud must be the contiguous fp32 tensor the bins follow")
-            rc = _lib.lib().nbp_step_maps_binned_f32(bins.store.data_ptr(), bins.page_bound(p.shape[0]), bins.next_parity(), p.data_ptr(), p.shape[0], n_dev,
+            rc = _lib.lib().nbp_step_maps_binned_f32(bins.store.data_ptr(), bins.page_bound(p.shape[0]), p.data_ptr(), p.shape[0], n_dev,
                                                      cx, cy, cz, arr, len(bounds), band_lo, band_hi, S, float(grid_range[0]),
                                                      float(grid_range[1]), None, 0, None, 0, out.data_ptr(), None, _lib.current_stream())
             _lib.check(rc, "nbp_step_maps_binned_f32")
@@ -176,7 +171,7 @@ def step_maps(full_pc, camera_pose, y_bins, grid_size, grid_range, traj_dev, n_t
     band_hi, band_lo = float(np.float32(cy + band)), float(np.float32(cy - band))
     if bins is not None:              # the tile-binned shadow copy of this cloud (CloudBins): same maps, bit for bit
         nu = full_pc.shape[0] if n_upper is None else min(int(n_upper), full_pc.shape[0])
-        rc = _lib.lib().nbp_step_maps_binned_f32(bins.store.data_ptr(), bins.page_bound(nu), bins.next_parity(), full_pc.data_ptr(), full_pc.shape[0],
+        rc = _lib.lib().nbp_step_maps_binned_f32(bins.store.data_ptr(), bins.page_bound(nu), full_pc.data_ptr(), full_pc.shape[0],
                                                  None if n_dev is None else n_dev.data_ptr(), cx, cy, cz, arr, len(bounds), band_lo,
                                                  band_hi, S, float(grid_range[0]), float(grid_range[1]), traj_dev.data_ptr(),
                                                  int(n_traj_old), fresh.ctypes.data, len(fresh), out6.data_ptr(), net_in5.data_ptr(),
@@ -211,11 +206,11 @@ def step_maps_batch(items, grid_size, grid_range, out6_all, net_in_all, band=0.1
     poses, bounds, nb = np.zeros((n, 3), np.float32), np.zeros((n, 8), np.float32), (C.c_int * n)()
     bands, fresh, n_old, n_fresh = np.zeros((n, 2), np.float32), np.zeros((n, 24), np.float32), (C.c_int * n)(), (C.c_int * n)()
     binned = all(len(it) > 8 and it[8] is not None for it in items)
-    stores, pbound, parity = (VP * n)(), (C.c_int * n)(), (C.c_int * n)()
+    stores, pbound = (VP * n)(), (C.c_int * n)()
     for i, it in enumerate(items):
         full_pc, n_upper, n_dev, pose, y_bins, traj_dev, n_traj_old, traj_fresh = it[:8]
         if binned:
-            stores[i], pbound[i], parity[i] = it[8].store.data_ptr(), it[8].page_bound(min(int(n_upper), full_pc.shape[0])), it[8].next_parity()
+            stores[i], pbound[i] = it[8].store.data_ptr(), it[8].page_bound(min(int(n_upper), full_pc.shape[0]))
         cx, cy, cz = _pose_xyz(pose)
         b = [float(v) for v in (y_bins.tolist() if isinstance(y_bins, torch.Tensor) else y_bins)][:-1]
         if len(b) > 8:
@@ -231,7 +226,7 @@ def step_maps_batch(items, grid_size, grid_range, out6_all, net_in_all, band=0.1
         fresh[i, :len(f)] = f
         n_old[i], n_fresh[i] = int(n_traj_old), len(f) // 3
     if binned:
-        rc = _lib.lib().nbp_step_maps_binned_batch_f32(n, stores, pbound, parity, pts, ncap, ndev, poses.ctypes.data, bounds.ctypes.data, nb,
+        rc = _lib.lib().nbp_step_maps_binned_batch_f32(n, stores, pbound, pts, ncap, ndev, poses.ctypes.data, bounds.ctypes.data, nb,
                                                        bands.ctypes.data, S, float(grid_range[0]), float(grid_range[1]), traj, n_old,
                                                        fresh.ctypes.data, n_fresh, out6_all.data_ptr(), net_in_all.data_ptr(),
                                                        _lib.current_stream())

@@ -30,6 +30,8 @@ def test_bench_single_gpu_line(hip):
     assert sc["bound"] == "hbm" and 0 < sc["frac"] <= 1 and sc["unit"] == "GB/s"
     assert d["strong_scaling"]["scenes_per_rank"] == [3] and d["strong_scaling"]["value"] > 0
     assert d["value_fp32_pipe"] is None         # --no-extra-stages: no fp32-pipe window
+    assert sc["maps_equal_append_order_kernel"] is True and sc["side_list"] == 0 and sc["group_form"]["frac"] > 0
+    assert d["tuning"] == {"active": False, "non_default_knobs": {}, "numerics_affecting": []}
     assert cpu["kind"] == "port" and cpu["value"] > 0 and set(cpu["legs_ms"]) == {"nbp_forward", "raster", "unproject",
                                                                                  "map_accumulate", "coverage"}
 
@@ -41,3 +43,5 @@ def test_bench_gpus_flag_launches_the_ranks(hip):
     st = d["strong_scaling"]                # 3 fixed hard scenes over 2 ranks: 2 + 1, the job's time is the slower rank's
     assert st["scaling"] == "strong" and st["scenes_per_rank"] == [2, 1] and len(st["per_rank_s"]) == 2
     assert abs(st["value"] - 3 * 3 / (st["ms_per_step"] * 3e-3)) < 1e-3 * st["value"] and st["imbalance_max_over_mean"] >= 1.0
+    assert st["ms_per_step"] * 3e-3 >= max(st["per_rank_s"]) - 1e-6            # the job's time is the slowest rank's (max over ranks)
+    assert d["distributed"]["backend"] == "gloo" and d["distributed"]["world"] == 2

@@ -165,8 +165,9 @@ def test_binned_maps_equal_the_append_order_kernel(hip, S):
 
 
 def test_binned_maps_points_that_cannot_be_filed_are_still_counted(hip):
-    """Points outside the tile grid, NaN points, and a tile that outgrows its 64 pages (a 150 k-point blob on one spot) go to the
-    side list and are counted with direct atomics: the maps still equal the append-order kernel's."""
+    """Points outside the tile grid and NaN points go to the side list and are counted with direct atomics; a tile may own any
+    number of pages (a 150 k-point blob on one spot: 70+ pages in a tile or two); a side list that overflows breaks the store,
+    which then counts the whole cloud directly: the maps equal the append-order kernel's in every case."""
     S, gr = 256, (-40, 40)
     rng = np.random.default_rng(11)
     inside = _wall_cloud(60_000, seed=2, extent=10.0)
@@ -183,10 +184,19 @@ def test_binned_maps_points_that_cannot_be_filed_are_still_counted(hip):
     assert torch.equal(got, want)
     h = bins.header()
     assert h["error"] == 0 and h["n_binned"] == pc.shape[0]
-    assert h["n_overflow"] > 1000                       # outside points + the blob's tail beyond 64 pages of its tiles
+    assert 1000 < h["n_overflow"] < 65536 and h["n_pages"] >= 150_000 // 2048     # the outside points only; the blob is paged
     # ... and again from another pose (the side list is walked on every build)
     pose2 = torch.tensor([-8.0, 5.05, 9.0, 0, 0])
     assert torch.equal(hu.accumulate_step_maps(pc, pose2, ybins, S, gr, bins=bins), hu.accumulate_step_maps(pc, pose2, ybins, S, gr))
+    # a grid that misses the scene: 215 k points on a 65536-entry side list -> the store breaks, the maps stay right
+    tiny = hu.CloudBins((500.0, 500.0), (501.0, 501.0), pc.shape[0], "cuda")
+    n_dev = torch.tensor([pc.shape[0] - 5000], dtype=torch.int64, device="cuda")
+    for k, pz in enumerate((pose, pose2, pose)):
+        if k == 2:
+            n_dev.fill_(pc.shape[0])                    # new points arrive after the break
+        got = hu.accumulate_step_maps(pc, pz, ybins, S, gr, n_dev=n_dev, bins=tiny)
+        assert torch.equal(got, hu.accumulate_step_maps(pc, pz, ybins, S, gr, n_dev=n_dev)), k
+    assert tiny.header()["error"] == 1
 
 
 def test_binned_step_maps_and_batch_equal_the_unbinned_calls(hip):

@@ -144,4 +144,5 @@ def test_bench_under_one_rank_torchrun_uses_rccl(hip):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["distributed"] == {"backend": "nccl", "world": 1}
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["distributed"]["backend"] == "nccl" and d["distributed"]["world"] == 1
+    assert d["tuning"]["numerics_affecting"] == [] and d["power"]["timed_region"] is None or d["power"]["timed_region"]["board_power_w_mean"] > 0
