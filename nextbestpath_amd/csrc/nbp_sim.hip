@@ -299,11 +299,18 @@ __device__ __forceinline__ void unproject_append_body(unsigned bx, unsigned by, 
 // latency-bound chains of a few workgroups: n of them side by side cost one chain, not n.
 constexpr int STEP_BATCH = 12;
 struct UnprojItem {   // the frames of an item need not be adjacent in memory (a camera's ring of frames wraps): one pointer each
-    const float* depth[4]; const unsigned long long* zface[4]; int* blk_count; int* ticket; unsigned* list; int* counts; float* cloud;
+    const float* depth[4]; const unsigned long long* zface[4]; int* blk_count; int* counts; float* cloud;
     long long* cloud_count; long long capacity; float* cloud_rgb; const float* verts; const int* faces;
     const float* vcolors; unsigned seed; Cam cam[4];
 };
-struct UnprojBatch { UnprojItem it[STEP_BATCH]; };
+// the ticket and the pixel list of an item sit at launch-uniform offsets behind its block counts (one scratch buffer per item)
+struct UnprojBatch {
+    UnprojItem it[STEP_BATCH]; int ticket_off; unsigned list_off_bytes;
+    __device__ int* ticket(int r) const { return it[r].blk_count + ticket_off; }
+    __device__ unsigned* list(int r) const { return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(it[r].blk_count) + list_off_bytes); }
+};
+// kernel arguments stay inside the 4 KB every HIP runtime accepts (12 x 352 B was 4224 B and ran, out of spec)
+static_assert(sizeof(UnprojBatch) + 32 <= 4096, "UnprojBatch + the scalar arguments of its kernels must fit 4 KB of kernel arguments");
 
 __global__ __launch_bounds__(256) void unproject_count4_kernel(const float* __restrict__ depth, const unsigned char* __restrict__ mask,
                                                                int HW, int nblk, float fov_range, int* __restrict__ blk_count,
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(256) void unproject_count4_batch_kernel(UnprojBatch
     const UnprojItem& a = b.it[blockIdx.z];
     // (the bodies address frame f as base + f HW: the base is shifted so that this lands on the frame's own pointer)
     unproject_count4_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth[blockIdx.y] - (size_t)blockIdx.y * HW, nullptr, HW, nblk,
-                          fov_range, a.blk_count, a.ticket);
+                          fov_range, a.blk_count, b.ticket(blockIdx.z));
 }
 __global__ __launch_bounds__(256) void unproject_compact4_kernel(const float* __restrict__ depth, const unsigned char* __restrict__ mask,
                                                                  int HW, int nblk, float fov_range, double gather,
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(256) void unproject_compact4_kernel(const float* __
 __global__ __launch_bounds__(256) void unproject_compact4_batch_kernel(UnprojBatch b, int HW, int nblk, float fov_range, double gather) {
     const UnprojItem& a = b.it[blockIdx.z];
     unproject_compact4_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth[blockIdx.y] - (size_t)blockIdx.y * HW, nullptr, HW, nblk,
-                            fov_range, gather, a.blk_count, a.list, a.counts);
+                            fov_range, gather, a.blk_count, b.list(blockIdx.z), a.counts);
 }
 __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __restrict__ depth, CamSet cams, int H, int W, float tanh_fov,
                                                                unsigned seed, const unsigned* __restrict__ list,
@@ -342,8 +349,8 @@ __global__ __launch_bounds__(256) void unproject_append_batch_kernel(UnprojBatch
                                                                      int fence) {
     const UnprojItem& a = b.it[blockIdx.z];
     const size_t shift = (size_t)blockIdx.y * H * W;
-    unproject_append_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth[blockIdx.y] - shift, a.cam, H, W, tanh_fov, a.seed, a.list,
-                          a.counts, a.cloud, a.cloud_count, a.capacity, n_frames, a.ticket, nullptr, a.cloud_rgb,
+    unproject_append_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, a.depth[blockIdx.y] - shift, a.cam, H, W, tanh_fov, a.seed,
+                          b.list(blockIdx.z), a.counts, a.cloud, a.cloud_count, a.capacity, n_frames, b.ticket(blockIdx.z), nullptr, a.cloud_rgb,
                           a.zface[blockIdx.y] ? a.zface[blockIdx.y] - shift : nullptr, a.verts, a.faces, a.vcolors, ambient, fence);
 }
 
@@ -1107,13 +1114,14 @@ extern "C" int nbp_unproject_append_shaded_batch_f32(int n, const float* const* 
     const int nblk = (int)nbp_cdiv(HW, COMPACT_CHUNK), nb4 = (int)nbp_cdiv(HW, FAST_CHUNK);
     NBP_RETURN_IF(nblk > 4096, NBP_E_SHAPE);
     UnprojBatch b;
+    b.ticket_off = n_frames * nb4;
+    b.list_off_bytes = (unsigned)(((size_t)n_frames * nblk * sizeof(int) + 255) / 256 * 256);
     for (int r = 0; r < STEP_BATCH; ++r) {
         const int q = r < n ? r : 0;
         NBP_RETURN_IF(!counts2[q] || !cloud[q] || !cloud_count[q] || capacity[q] < 1 || !ws[q], NBP_E_ARG);
         UnprojItem& a = b.it[r];
         int* blk_count = (int*)(((uintptr_t)ws[q] + 255) / 256 * 256);
-        a.blk_count = blk_count; a.ticket = blk_count + (size_t)n_frames * nb4;
-        a.list = (unsigned*)((char*)blk_count + ((size_t)n_frames * nblk * sizeof(int) + 255) / 256 * 256);
+        a.blk_count = blk_count;
         a.counts = counts2[q]; a.cloud = cloud[q]; a.cloud_count = cloud_count[q]; a.capacity = capacity[q];
         const bool col = zface && zface[(size_t)q * n_frames] && cloud_rgb && cloud_rgb[q] && verts && faces && vcolors;
         a.cloud_rgb = col ? cloud_rgb[q] : nullptr;

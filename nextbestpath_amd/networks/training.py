@@ -115,12 +115,31 @@ def _const(value, n, device):
     return t
 
 
-# ---- hand-off of what a producer already knows about its output to the convolution that consumes it (keyed by storage address,
-# valid within one forward / backward pass; NBP_TRAIN_FUSE=0 switches the hand-off off: every consumer takes its own pass)
+# ---- hand-off of what a producer already knows about its output to the convolution that consumes it.  The note rides ON the
+# tensor object (a Python attribute: it lives and dies with the tensor, and a different tensor that happens to reuse the address
+# -- a forward under no_grad, recompute, two forwards before one backward -- can never pick it up; round 3 keyed process-global
+# dicts by data_ptr()).  A consumer that gets a tensor without a note (autograd summed two gradients, a slice, a copy) takes its
+# own pass.  NBP_TRAIN_FUSE=0 switches the hand-off off altogether.
 _FUSE = _lib.tune("NBP_TRAIN_FUSE", "1") == "1"
-_Y_AMAX = {}          # forward: y.data_ptr() -> 64-word max-|y| slot written by the BatchNorm apply pass
-_DX_INFO = {}         # backward: dx.data_ptr() -> (max-|dx| slot, column sums of dx) written by the BatchNorm backward apply pass
 _ARENA = {}
+
+
+def _note(t, **kw):
+    """Attach producer knowledge to tensor t: amax = 64-word max-|t| slot; colsum = column sums of t (with its max slot)."""
+    if _FUSE:
+        t._nbp_note = kw
+    return t
+
+
+HANDOFF_STATS = {"hit": 0, "miss": 0}      # notes found / not found by consumers (tools/bench_train.py prints them)
+
+
+def _noted(t, key):
+    n = getattr(t, "_nbp_note", None) if _FUSE and t is not None else None
+    v = None if n is None else n.get(key)
+    HANDOFF_STATS["hit" if v is not None else "miss"] += 1
+    return v
+
 
 
 def _fresh_slots(device, n=1):
@@ -135,14 +154,9 @@ def _fresh_slots(device, n=1):
 
 
 def _reset_arena(device, cap=1024):
-    a = _ARENA.get(device)
-    if a is None:
-        a = _ARENA[device] = {"buf": torch.zeros(cap * 64, dtype=torch.int32, device=device), "cap": cap, "next": 0}
-    else:
-        a["buf"].zero_()
-        a["next"] = 0
-    _Y_AMAX.clear()
-    _DX_INFO.clear()
+    """A FRESH zeroed arena per training forward (one fill): the slots an earlier forward handed to its autograd contexts are
+    views into that forward's own arena, which stays alive (and untouched) for as long as they reference it."""
+    _ARENA[device] = {"buf": torch.zeros(cap * 64, dtype=torch.int32, device=device), "cap": cap, "next": 0}
 
 
 def _amax_slot(*tensors):
@@ -150,12 +164,12 @@ def _amax_slot(*tensors):
     scales them (forward + weight gradient for a layer's inputs; data + weight gradient for its output gradient)."""
     live = [t for t in tensors if t is not None and t.numel()]
     if _FUSE and len(live) == 1:
-        known = _Y_AMAX.get(live[0].data_ptr())
+        known = _noted(live[0], "amax")
         if known is not None:
             return known                       # the producer (BatchNorm apply) measured it while writing the tensor
     slot = _fresh_slots(tensors[0].device)
     for t in live:
-        known = _Y_AMAX.get(t.data_ptr()) if _FUSE else None
+        known = _noted(t, "amax")
         if known is not None and len(live) > 1:
             # two sources share one slot: fold the known maximum in (element-wise max of the 64 words, non-negative float bits)
             torch.maximum(slot, known, out=slot)
@@ -246,10 +260,8 @@ class ConvFn(torch.autograd.Function):
         N, c_real, k, C0, C1, Np, ups, has1 = ctx.meta
         x1 = x1 if has1 else None
         dev = dy.device
+        info = _noted(dy, "colsum") if dy.is_contiguous() else None       # (max-|dy| slot, column sums): this very tensor's
         dy = dy.contiguous()
-        info = _DX_INFO.pop(dy.data_ptr(), None) if _FUSE else None
-        if info is not None and tuple(info[2]) != tuple(dy.shape):
-            info = None                                    # (an address reused by another tensor)
         dy = _pad_channels(dy, Np)
         B, H, W, _ = dy.shape
         M = B * H * W
@@ -313,7 +325,7 @@ class BNFn(torch.autograd.Function):
                                              _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
                                              _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(slot), _lib.ptr(ws), ws.numel(), _st()), "bn_fwd")
         if slot is not None:
-            _Y_AMAX[y.data_ptr()] = slot
+            _note(y, amax=slot)
         ctx.save_for_backward(x, y, mean, invstd, g)
         ctx.relu = bool(relu)
         return y
@@ -337,7 +349,7 @@ class BNFn(torch.autograd.Function):
                                                _lib.ptr(g), int(ctx.relu), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(csum),
                                                _lib.ptr(slot), _lib.ptr(ws), ws.numel(), _st()), "bn_bwd")
         if fuse:
-            _DX_INFO[dx.data_ptr()] = (slot, csum, dx.shape)
+            _note(dx, colsum=(slot, csum))
         return dx, dg, db, None, None, None, None, None
 
 
@@ -349,9 +361,9 @@ class MaxPoolFn(torch.autograd.Function):
         y = torch.empty(B, H // 2, W // 2, C, dtype=torch.float32, device=x.device)
         _chk(_lib.lib().nbp_maxpool2_nhwc_f32(_lib.ptr(x), B, H, W, C, _lib.ptr(y), _st()), "maxpool")
         ctx.save_for_backward(x)
-        known = _Y_AMAX.get(x.data_ptr()) if _FUSE else None
+        known = _noted(x, "amax")
         if known is not None:
-            _Y_AMAX[y.data_ptr()] = known          # a max-pool keeps the maximum
+            _note(y, amax=known)                   # a max-pool keeps the maximum
         return y
 
     @staticmethod
@@ -538,6 +550,8 @@ def set_forward_observer(fn):
 def _t(name, y):
     if _observer is not None and name is not None:
         _observer(name, y)
+        if hasattr(y, "_nbp_note"):
+            del y._nbp_note             # an observer may have rewritten the values: what the producer measured no longer holds
     return y
 
 

@@ -239,12 +239,29 @@ class Scene:
                                  3.0 * self.distance_between_proxy_points, self.view_states)
 
     def update_proxy_view_states(self, camera, proxy_mask, signed_distances=None, distance_to_surface=None, X_cam=None):
-        """mu:3268-3327 with the reference's arguments; proxy_mask [P] bool / uint8, signed_distances [P] fp32 over ALL proxy
-        points (entries outside the mask are ignored), X_cam [3] or [1, 3] (default: the camera's position)."""
+        """mu:3268-3327 with the reference's arguments; proxy_mask [P] bool / uint8; signed_distances either as the reference
+        passes them -- one value per point INSIDE the mask (mu:3299-3302: `update_mask[proxy_mask] = sd < dist`), scattered here
+        into a [P] buffer -- or already [P] fp32 over all proxy points (entries outside the mask are ignored); any other size
+        raises.  X_cam [3] or [1, 3] (default: the camera's position)."""
         from ..utility import hipops
         if X_cam is None:
             X_cam = camera.X_cam
         xc = X_cam.detach().cpu().numpy() if torch.is_tensor(X_cam) else np.asarray(X_cam)
+        P = self.proxy_points.shape[0]
+        if proxy_mask.numel() != P:
+            raise ValueError(f"update_proxy_view_states: proxy_mask has {proxy_mask.numel()} entries, the scene {P} proxy points")
+        if signed_distances is not None:
+            sd = signed_distances.reshape(-1).to(torch.float32)
+            if sd.numel() != P:
+                mask_b = proxy_mask.reshape(-1).to(torch.bool)
+                n_in = int(mask_b.sum().item())
+                if sd.numel() != n_in:
+                    raise ValueError(f"update_proxy_view_states: signed_distances has {sd.numel()} values; expected one per masked "
+                                     f"point ({n_in}) or one per proxy point ({P})")
+                full = torch.full((P,), float("inf"), dtype=torch.float32, device=self.proxy_points.device)
+                full[mask_b] = sd.to(full.device)
+                sd = full
+            signed_distances = sd
         if signed_distances is not None and distance_to_surface is None:
             distance_to_surface = 3 * self.distance_between_proxy_points
         hipops.view_state_update(self.proxy_points, xc.reshape(-1, 3)[:1], self.view_state_n_elev, self.view_state_n_azim,

@@ -144,8 +144,11 @@ def _step_both_and_compare(hip_ro, ora, n_steps):
                 variants.append((Bv, b1[Bv - 1].cpu().numpy().astype(np.float64)))
         for Bv, hv in variants:
             e_hip = np.abs(hv - d1)
-            assert e_hip.max() <= max(1e-3 * rng1, 10.0 * e_cpu.max()) and e_hip.mean() <= max(2e-6 * rng1, 10.0 * e_cpu.mean()), \
+            # hard cap per step and batch size: north_star's 1e-4, read relative to the output range (round 4: was 1e-3; measured
+            # 1.6e-5).  The 10x-of-torch escape only exists for a step where stock torch fp32 itself is beyond 1e-5 of the range.
+            assert e_hip.max() <= 1e-4 * rng1 or (e_cpu.max() > 1e-5 * rng1 and e_hip.max() <= 10.0 * e_cpu.max()), \
                 (s, Bv, e_hip.max(), e_hip.mean(), e_cpu.max(), e_cpu.mean(), rng1)
+            assert e_hip.mean() <= max(2e-6 * rng1, 10.0 * e_cpu.mean()), (s, Bv, e_hip.mean(), e_cpu.mean(), rng1)
             ratios.append((e_hip.mean() / max(e_cpu.mean(), 1e-30), e_hip.max() / max(e_cpu.max(), 1e-30), e_hip.max() / rng1))
             worst[0] = max(worst[0], e_hip.max() / rng1)
         assert np.abs(h2 - d2).max() < 1e-4
@@ -179,6 +182,88 @@ def test_hip_rollout_equals_oracle_rollout_256(hip, tmp_path):
     counts = _step_both_and_compare(hip_ro, ora, 12)
     assert counts[0] == 0 and counts[-1] > 0
     assert int(hip_ro.camera._overflow.item()) == 0
+
+
+def test_hip_rollout_equals_oracle_rollout_24_steps(hip, tmp_path):
+    """A quarter of a trajectory (24 steps, ~0.7 M points, 18+ replans, the frame ring wrapped seven times) on a second scene and
+    seed: identical step by step (round 3 ran this from tools/diag/parity_long.py only)."""
+    hip_ro, ora, mesh = _both_rollouts(str(tmp_path), cells=8, size=4.8, tess=0.3, scene_seed=1, seed=6)
+    counts = _step_both_and_compare(hip_ro, ora, 24)
+    assert counts[-1] > counts[3] > 0 and int(hip_ro.st.cloud_count.item()) > 500_000
+    h = hip_ro.st.bins.header()
+    assert h["error"] == 0 and h["n_overflow"] == 0 and h["n_binned"] >= int(hip_ro.st.cloud_count.item()) - 4 * 5837
+
+
+def test_late_trajectory_steps_from_a_snapshot(hip, tmp_path):
+    """Late in a trajectory: the HIP rollout alone is advanced 56 steps (1.5 M+ points in the cloud, 700+ pages in the binned copy,
+    dozens of replans behind it), its state is copied into the oracle rollout (cloud, lattice histories, lists, path, the random
+    stream, the last frames' cameras), and both are stepped three more steps: network inputs bit-identical on a cloud of that size,
+    same replan decisions, same poses, same new cloud points, same coverage counts."""
+    import copy
+    hip_ro, ora, mesh = _both_rollouts(str(tmp_path), cells=8, size=4.8, tess=0.3, scene_seed=2, seed=7)
+    n_ff = 56
+    for _ in range(n_ff):
+        hip_ro.step()
+    torch.cuda.synchronize()
+    n0 = int(hip_ro.st.cloud_count.item())
+    assert n0 >= 1_500_000, n0
+    cam, oc = hip_ro.camera, ora.cam
+    # ---- snapshot -> oracle
+    ora.full_pc = hip_ro.st.cloud[:n0].cpu().numpy().copy()
+    ora.full_rgb = hip_ro.st.cloud_rgb[:n0].cpu().numpy().copy()
+    oc.cam_idx = tuple(int(v) for v in cam.cam_idx)
+    oc.cam_idx_history = [tuple(int(v) for v in h) for h in cam.cam_idx_history]
+    oc.X_hist = [np.asarray(x, np.float32).copy() for x in cam.X_cam_history]
+    oc.V_hist = [np.asarray(v, np.float32).copy() for v in cam.V_cam_history]
+    oc.X, oc.V = oc.X_hist[-1].copy(), oc.V_hist[-1].copy()
+    from oracle import camera as ocam
+    from nextbestpath_amd.utility import hipops as ho
+    oc.R, oc.T = ocam.camera_RT(oc.X, oc.V)
+    frames = []
+    for zb, cam12, _slot in cam.frames[-8:]:            # the last frame is un-projected by the next step's first stage
+        c = np.asarray(cam12, np.float32)
+        fr = [zb.cpu().numpy().copy(), c[:9].reshape(3, 3).copy(), c[9:].copy()]
+        if oc.colors is not None:                       # the oracle renders colours eagerly: rebuild them from the same frame
+            _, rgb = ho.raster_rgbz(mesh.verts, mesh.faces, mesh.colors, c[None], zb.shape[0], zb.shape[1], oc.ambient, oc.contrast)
+            fr.append(rgb[0].cpu().numpy())
+        frames.append(tuple(fr))
+    oc.frames = frames
+    ora.path = copy.deepcopy(hip_ro.path)
+    ora.path_record, ora.pose_i, ora.n_replans = hip_ro.path_record, hip_ro.pose_i, hip_ro.n_replans
+    ora.collision_list, ora.passable_list = copy.deepcopy(hip_ro.collision_list), copy.deepcopy(hip_ro.passable_list)
+    ora.idx_history = [tuple(h) for h in hip_ro.idx_history]
+    ora.rng.setstate(hip_ro.rng.getstate())
+    assert ora.step_seed == hip_ro.step_seed
+    # ---- three steps side by side
+    for s in range(3):
+        hip_ro.pre()
+        with torch.no_grad():
+            out1, out2 = hip_ro.nbp(hip_ro.st.net_in)
+        net_in = hip_ro.st.net_in.cpu().numpy()
+        need, before = hip_ro.need_replan, ora.n_replans
+        hip_ro.plan_enqueue(out1, out2)
+        torch.cuda.synchronize()
+        hip_ro.plan_finish()
+        hip_ro.post()
+        ora.step()
+        assert np.array_equal(net_in, ora.net_inputs[-1]), f"late step {s}: network input differs"
+        assert float(net_in[0, :4].max()) > 1000.0                                   # wall cells with thousands of points
+        o1, o2 = ora.net_outputs[-1]
+        rng1 = max(1.0, float(np.abs(o1).max()))
+        assert np.abs(out1[0].cpu().numpy() - o1).max() <= 1e-4 * rng1               # vs stock torch fp32 on the same input
+        assert np.array_equal(out2[0, 0].cpu().numpy() >= np.float32(0.13), o2 >= np.float32(0.13))
+        assert need == (ora.n_replans > before), f"late step {s}: replan decision differs"
+        assert hip_ro.camera.cam_idx_history == ora.cam.cam_idx_history, f"late step {s}: lattice path differs"
+        assert int(hip_ro.st.cloud_count.item()) == len(ora.full_pc), f"late step {s}: cloud size"
+    n = len(ora.full_pc)
+    assert n > n0 + 20_000
+    assert torch.equal(hip_ro.st.cloud[n0:n].cpu(), torch.from_numpy(ora.full_pc[n0:]))
+    counts = hip_ro.st.coverage_counts[n_ff:n_ff + 3, 0].cpu().numpy().tolist()
+    assert counts == ora.coverage_counts[-3:], (counts, ora.coverage_counts)
+    assert hip_ro.collision_list == ora.collision_list and hip_ro.passable_list == ora.passable_list
+    assert np.array_equal(hip_ro.camera.X_cam_history, np.stack(ora.cam.X_hist))
+    h = hip_ro.st.bins.header()
+    assert h["error"] == 0 and h["n_overflow"] == 0 and h["n_pages"] >= n0 // 2048
 
 
 def test_hip_rollout_equals_oracle_rollout_hard_scene(hip, tmp_path):

@@ -131,3 +131,30 @@ def test_view_state_kernel_vs_reference_golden(hip, golden_dir):
                              sd=torch.from_numpy(g["upd_sd"][k]).to(D), distance_to_surface=3 * float(g["dist_between"]))
         safe = ovs.boundary_distance(g["proxy"], g["upd_cam"][:k + 1], 7, 14).min(1) > 1e-5
         assert np.array_equal(vs.cpu().numpy().astype(np.uint8)[safe], g["upd_state"][k][safe]), k
+
+
+def test_update_proxy_view_states_takes_the_reference_masked_distances(hip, golden_dir):
+    """Scene.update_proxy_view_states with signed distances as the REFERENCE passes them (one per point inside the mask,
+    macarons_utils.py:3299-3302) gives what the full-size form gives; any other size raises (it used to be read out
+    of bounds)."""
+    import os
+    import types
+    from nextbestpath_amd.simulator.scene import Scene
+    g = np.load(os.path.join(golden_dir, "viewstate.npz"))
+    proxy = torch.from_numpy(g["proxy"]).to(D)
+    P = len(proxy)
+
+    def scene():
+        return types.SimpleNamespace(proxy_points=proxy, view_states=torch.zeros(P, 98, device=D), view_state_n_elev=7,
+                                     view_state_n_azim=14, distance_between_proxy_points=float(g["dist_between"]))
+    mask = torch.from_numpy(g["upd_mask"][0].astype(bool)).to(D)
+    sd_full = torch.from_numpy(g["upd_sd"][0]).to(D)
+    cam = types.SimpleNamespace(X_cam=torch.from_numpy(g["upd_cam"][0]))
+    a, b = scene(), scene()
+    Scene.update_proxy_view_states(a, cam, mask, sd_full)
+    Scene.update_proxy_view_states(b, cam, mask, sd_full[mask])                  # the reference's calling convention
+    assert torch.equal(a.view_states, b.view_states) and float(a.view_states.sum()) > 0
+    with pytest.raises(ValueError):
+        Scene.update_proxy_view_states(scene(), cam, mask, sd_full[:7])
+    with pytest.raises(ValueError):
+        Scene.update_proxy_view_states(scene(), cam, mask[:-1], sd_full)

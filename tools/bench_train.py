@@ -68,7 +68,7 @@ def main():
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3, 2), "dtype": "f32",
         "data": "synthetic", "config": {"workload": f"configs[2]: train step, batch {a.batch} x {a.size}x{a.size}"},
         "tflops_reference_formulation": round(a.batch * flop_map / dt / 1e12, 2), "frac_of_split_ceiling_reference_formulation": round(a.batch * flop_map / dt / (2500e12 / 3), 4),
-        "loss": float(loss.item()),
+        "loss": float(loss.item()), "producer_notes": dict(tr.HANDOFF_STATS),
         "cpu_baseline": {"value": round(nb / cpu_dt, 4), "unit": "maps/s", "cores": torch.get_num_threads(), "kind": "port",
                          "sample": f"one fwd+bwd of {nb} maps with torch CPU autograd ({cpu_dt:.1f} s)"}}))
 
