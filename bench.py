@@ -708,6 +708,21 @@ def main():
                 dt_l = timed_window(20)
                 windows["late"] = {"steps": [80, 100], "steps_per_s": round(20 * R / dt_l, 2),
                                    "cloud_points_end": cloud_points()}
+            # ---- reported-only: the same rollouts when the forwards whose output the reference discards are not run
+            # (MultiRollout(elide_dead_forward=True): only the replanning rollouts' maps are forwarded; identical trajectories and
+            # coverage, tests/test_gpu_rollout.py::test_dead_forward_elision_changes_nothing).  NEVER `value`: the headline does
+            # the reference's work.  Rank 0's rollouts, right after the late window.
+            multi.elide_dead_forward = True
+            run_steps(2)
+            rp0 = sum(r.n_replans for r in rollouts)
+            dte = timed_window(10)
+            multi.elide_dead_forward = False
+            run_steps(1)
+            stage["steps_per_s_dead_forward_elided"] = {
+                "value_per_gpu": round(10 * R / dte, 3), "unit": "steps/s", "steps": 10,
+                "forwarded_fraction_of_maps": round((sum(r.n_replans for r in rollouts) - rp0) / (10 * R), 4),
+                "note": "reported only, never `value`: the forwards of non-replanning steps (whose output nbp_planning.py:252 discards) "
+                        "are not run; same trajectories and coverage (tests/test_gpu_rollout.py)"}
             # ---- BASELINE configs[4] forward (reported beside the headline, not part of `value`): 8 maps of 512x512
             # through the bf16 network; fraction of the dense bf16 MFMA peak (2.5 PFLOP/s)
             sd16 = {k: v.detach().clone() for k, v in net.state_dict().items()}

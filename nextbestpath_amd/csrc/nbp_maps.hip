@@ -217,7 +217,7 @@ __global__ __launch_bounds__(THREADS) void map_accumulate_batch_kernel(MapBatch 
 constexpr int BIN_PAGE_BITS = 11, BIN_PAGE = 1 << BIN_PAGE_BITS;      // 2048 points = 24 KB per page
 constexpr unsigned BIN_OVF = 1u << 16;
 constexpr int BIN_R = 16;                                             // LDS histogram: 16 x 16 cells (a 2.5-unit tile is 9 x 9 + slack)
-constexpr int BIN_APPEND_WGS = 64, BIN_OVF_WGS = 4;
+constexpr int BIN_APPEND_WGS = 128, BIN_OVF_WGS = 4;     // 128 x 256 threads: one step's ~29 k new points in one pass
 struct BinDesc {                // head of the store (device memory, 256 B reserved)
     unsigned n_pages, n_overflow, error, ticket;
     long long n_binned;                                   // points of the cloud already filed
@@ -253,8 +253,17 @@ __device__ __forceinline__ void count_direct(float x, float y, float z, const Ma
     if (a.band_lo < y && y < a.band_hi) atomicAdd(a.out + 5 * S * S + i0 * S + i1, 1.0f);
 }
 
-// workgroup `wg` of `n_wg`: points [n_binned, N) of the cloud are filed into pages; the workgroup that finishes last advances n_binned
-__device__ __forceinline__ void bin_append_body(char* store, const float* __restrict__ cloud, long long N, unsigned wg, unsigned n_wg) {
+// workgroup `wg` of `n_wg`: points [n_binned, N) of the cloud are filed into pages; the workgroup that finishes last advances n_binned.
+// The launch also clears what the map launch behind it accumulates into (zero6: the six maps, zero1: the trajectory channel, SS floats
+// each): two memset launches less per build -- every launch boundary is an L2 write-back / invalidate under the other group's forward.
+__device__ __forceinline__ void bin_append_body(char* store, const float* __restrict__ cloud, long long N, unsigned wg, unsigned n_wg,
+                                                float* __restrict__ zero6, float* __restrict__ zero1, int SS) {
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const int n6 = zero6 ? 6 * SS / 4 : 0, n1 = zero1 ? SS / 4 : 0;          // (SS % 4 == 0: launcher)
+        for (int i = (int)(wg * 256 + threadIdx.x); i < n6 + n1; i += (int)(n_wg * 256))
+            reinterpret_cast<f32x4*>(i < n6 ? zero6 : zero1)[i < n6 ? i : i - n6] = z;
+    }
     const BinView v = bin_view(store);
     const long long first = v.d->n_binned;
     if (v.d->error == 0u) {                               // (a broken store files nothing more: its builds scan the cloud)
@@ -433,17 +442,18 @@ __device__ __forceinline__ void map_binned_body(const MapItem& a, char* store, u
     }
 }
 
-__global__ __launch_bounds__(256) void bin_append_kernel(char* store, const float* __restrict__ cloud, long long N, const long long* n_dev) {
-    bin_append_body(store, cloud, n_dev ? *n_dev : N, blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(256) void bin_append_kernel(char* store, const float* __restrict__ cloud, long long N, const long long* n_dev,
+                                                         float* zero6, float* zero1, int SS) {
+    bin_append_body(store, cloud, n_dev ? *n_dev : N, blockIdx.x, gridDim.x, zero6, zero1, SS);
 }
 __global__ __launch_bounds__(256) void map_binned_kernel(MapItem a, char* store, unsigned n_page_wg, int S, float lo, float sc) {
     __shared__ int hist[6 * BIN_R * BIN_R];
     map_binned_body(a, store, blockIdx.x, n_page_wg, S, lo, sc, hist);
 }
 struct BinBatch { char* store[MAP_BATCH]; unsigned n_page_wg[MAP_BATCH]; };
-__global__ __launch_bounds__(256) void bin_append_batch_kernel(MapBatch b, BinBatch s) {
+__global__ __launch_bounds__(256) void bin_append_batch_kernel(MapBatch b, BinBatch s, int SS) {
     const MapItem& a = b.it[blockIdx.y];
-    bin_append_body(s.store[blockIdx.y], a.p, a.n_dev ? *a.n_dev : a.N, blockIdx.x, gridDim.x);
+    bin_append_body(s.store[blockIdx.y], a.p, a.n_dev ? *a.n_dev : a.N, blockIdx.x, gridDim.x, a.out, a.tr.out, SS);
 }
 __global__ __launch_bounds__(256) void map_binned_batch_kernel(MapBatch b, BinBatch s, int S, float lo, float sc) {
     __shared__ int hist[6 * BIN_R * BIN_R];
@@ -688,12 +698,8 @@ extern "C" int nbp_step_maps_binned_f32(void* store, int page_bound, const float
     NBP_RETURN_IF((long long)6 * S * S >= (1ll << 31), NBP_E_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     const size_t SS = (size_t)S * S;
-    hipError_t e = hipMemsetAsync(out6, 0, 6 * SS * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-    if (net_in5) {
-        e = hipMemsetAsync(net_in5 + 4 * SS, 0, SS * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
-    }
+    NBP_RETURN_IF(SS % 4 != 0 || ((uintptr_t)out6 & 15) || (net_in5 && ((uintptr_t)net_in5 & 15)), NBP_E_SHAPE);
+    hipError_t e = hipSuccess;
     Bounds bd;
     for (int k = 0; k < 8; ++k) bd.b[k] = k < n_bounds ? bounds_host[k] : 0.f;
     bd.n = n_bounds;
@@ -703,8 +709,8 @@ extern "C" int nbp_step_maps_binned_f32(void* store, int page_bound, const float
         tr.pts = traj_pts; tr.out = net_in5 + 4 * SS; tr.n_old = n_traj_old; tr.n_fresh = n_traj_fresh;
         for (int i = 0; i < 24; ++i) tr.fresh[i] = i < 3 * n_traj_fresh ? traj_fresh_host[i] : 0.f;
     }
-    if (N > 0) {
-        bin_append_kernel<<<BIN_APPEND_WGS, 256, 0, st>>>((char*)store, points, N, N_dev_or_null);
+    {       // files the new points AND clears the maps / the trajectory channel (no memset launches)
+        bin_append_kernel<<<BIN_APPEND_WGS, 256, 0, st>>>((char*)store, points, N, N_dev_or_null, out6, tr.out, (int)SS);
         const int rc0 = nbp_launch_status();
         if (rc0) return rc0;
     }
@@ -752,11 +758,9 @@ extern "C" int nbp_step_maps_binned_batch_f32(int n, void* const* stores, const 
         s.store[r] = (char*)stores[q]; s.n_page_wg[r] = r < n ? (unsigned)page_bound[q] : 0u;
         if (r < n && s.n_page_wg[r] + BIN_OVF_WGS + 1 > max_wg) max_wg = s.n_page_wg[r] + BIN_OVF_WGS + 1;
     }
-    hipError_t e = hipMemsetAsync(out6_all, 0, (size_t)n * 6 * SS * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemset2DAsync(net_in_all + 4 * SS, 5 * SS * sizeof(float), 0, SS * sizeof(float), (size_t)n, st);       // the trajectory channels
-    if (e != hipSuccess) return (int)e;
-    bin_append_batch_kernel<<<dim3(BIN_APPEND_WGS, (unsigned)n), 256, 0, st>>>(b, s);
+    NBP_RETURN_IF(SS % 4 != 0 || ((uintptr_t)out6_all & 15) || ((uintptr_t)net_in_all & 15), NBP_E_SHAPE);
+    hipError_t e = hipSuccess;
+    bin_append_batch_kernel<<<dim3(BIN_APPEND_WGS, (unsigned)n), 256, 0, st>>>(b, s, (int)SS);       // (also clears maps + trajectory channels)
     int rc = nbp_launch_status();
     if (rc) return rc;
     map_binned_batch_kernel<<<dim3(max_wg, (unsigned)n), 256, 0, st>>>(b, s, S, lo, grid_scale(S, lo, hi));

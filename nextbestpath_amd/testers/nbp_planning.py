@@ -271,8 +271,14 @@ class MultiRollout:
     un-projection, map accumulation, raster, planner) run underneath the other group's convolutions instead of
     in front of them.  Each rollout's results are identical to running it alone (tests/test_gpu_rollout.py)."""
 
-    def __init__(self, rollouts, nbp, device, grid=None, streams=True, n_groups=None):
+    def __init__(self, rollouts, nbp, device, grid=None, streams=True, n_groups=None, elide_dead_forward=False):
         self.rollouts, self.nbp = list(rollouts), nbp
+        # The reference runs the network at every step and uses its output only when it replans (nbp_planning.py:166 / :252).
+        # Default (False): every rollout's map goes through the forward at every step, as there.  True (reported beside the
+        # headline, never as it): only the replanning rollouts' maps are forwarded -- same trajectories, same coverage
+        # (tests/test_gpu_rollout.py::test_dead_forward_elision_changes_nothing).
+        self.elide_dead_forward = bool(elide_dead_forward)
+        self._sub = {}
         self.device, self._packed = device, None
         grid = grid or self.rollouts[0].S
         R = len(self.rollouts)
@@ -328,10 +334,14 @@ class MultiRollout:
                 else:
                     for i, r in enumerate(grp):
                         r.pre(net_in[i:i + 1])
-                with torch.no_grad():
-                    out1, out2 = self._forward(net_in)
+                rows = None
+                if self.elide_dead_forward and self.batched and "replan" in self.batch_stages and self._packed is not None:
+                    out1, out2, rows = self._forward_replanning_only(gi)
+                else:
+                    with torch.no_grad():
+                        out1, out2 = self._forward(net_in)
                 if self.batched and "replan" in self.batch_stages:
-                    self._plan_group(gi, out1, out2)
+                    self._plan_group(gi, out1, out2, rows)
                 else:
                     for i, r in enumerate(grp):
                         r.plan_enqueue(out1[i], out2[i])
@@ -387,24 +397,58 @@ class MultiRollout:
             r.traj_img = net_in[i, 4]
             r.pre_decide()
 
-    def _plan_group(self, gi, out1, out2):
+    def _forward_replanning_only(self, gi):
+        """elide_dead_forward: the forward over the maps of the rollouts that replan this step only -> (out1, out2, {rollout
+        index in the group: row}); (None, None, {}) when none does.  The rows are gathered on the device (index list through a
+        pinned buffer: no pageable copy in the loop); the workspace is the full group's."""
+        from ..networks import packing
+        grp, net_in = self.groups[gi], self.net_in[gi]
+        need = [i for i, r in enumerate(grp) if r.need_replan]
+        if not need:
+            return None, None, {}
+        if len(need) == len(grp):
+            with torch.no_grad():
+                out1, out2 = self._forward(net_in)
+            return out1, out2, None
+        st = self._sub.get(gi)
+        if st is None:
+            n, S = net_in.shape[0], net_in.shape[-1]
+            prec = self._packed.precision
+            nbytes = max(int(getattr(_lib.lib(), packing._FWD[prec][1])(b, S)) for b in range(1, n + 1))
+            st = self._sub[gi] = {"pin": [torch.zeros(n, dtype=torch.int64).pin_memory() for _ in range(4)], "k": 0,
+                                  "idx": torch.zeros(n, dtype=torch.int64, device=self.device), "x": torch.empty_like(net_in),
+                                  "ws": torch.empty(nbytes, dtype=torch.uint8, device=self.device)}
+        k = len(need)
+        pin = st["pin"][st["k"] % 4]
+        st["k"] += 1
+        pin[:k] = torch.tensor(need, dtype=torch.int64)
+        st["idx"][:k].copy_(pin[:k], non_blocking=True)
+        x = st["x"][:k]
+        torch.index_select(net_in, 0, st["idx"][:k], out=x)
+        with torch.no_grad():
+            out1, out2 = packing.forward_packed(self._packed, x, ws=st["ws"])
+        return out1, out2, {i: row for row, i in enumerate(need)}
+
+    def _plan_group(self, gi, out1, out2, rows=None):
         """Rollout.plan_enqueue for the group: the replanning rollouts' GPU half in two launches, their results in one copy each
-        plus ONE copy of the group's value maps; one event for all of them."""
+        plus ONE copy of the group's value maps; one event for all of them.  rows: rollout index -> row of out1 / out2 (None:
+        the identity)."""
         grp = self.groups[gi]
         need = [(i, r) for i, r in enumerate(grp) if r.need_replan]
         if need:
             r0 = grp[0]
             pin = self._out1_pin[gi]
             items = []
+            row = (lambda i: i) if rows is None else rows.__getitem__
             for i, r in need:
                 r.n_replans += 1
                 r.path_record = 0
-                items.append(r.planner.replan_item(r.pose, out1[i].reshape(8, r.V, r.V), out2[i].reshape(r.S, r.S), r.st.maps6,
+                items.append(r.planner.replan_item(r.pose, out1[row(i)].reshape(8, r.V, r.V), out2[row(i)].reshape(r.S, r.S), r.st.maps6,
                                                    r.traj_img.reshape(r.S, r.S), r.collision_list))
             hipops.replan_batch(items, r0.S, r0.V, r0.grid_range)
-            pin.copy_(out1, non_blocking=True)
+            pin[:out1.shape[0]].copy_(out1, non_blocking=True)
             for i, r in need:
-                r.planner.replan_copy_back(r.pose, pin[i].reshape(8, r.V, r.V))
+                r.planner.replan_copy_back(r.pose, pin[row(i)].reshape(8, r.V, r.V))
         ev = self.ev_plan[gi][0]
         ev.record()
         self._plan_event[gi] = ev

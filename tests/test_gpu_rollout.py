@@ -107,6 +107,36 @@ def test_multi_rollout_matches_single(hip, dataset, nbp_weights):
         assert ca == cb
 
 
+def test_dead_forward_elision_changes_nothing(hip, dataset, nbp_weights):
+    """MultiRollout(elide_dead_forward=True) forwards only the maps of the rollouts that replan (the reference discards the
+    network's output on the other steps, nbp_planning.py:252): trajectories, clouds and coverage are those of the default mode,
+    which forwards every map at every step as the reference does (bench.py reports the elided rate beside the headline only)."""
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.testers import nbp_planning as tp
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    ds = sc.SceneDataset(dataset)
+    net = _net(nbp_weights)
+    dev = torch.device("cuda")
+    n = 14
+    runs = {}
+    for elide in (False, True):
+        ros = [tp.build_rollout(params, net, ds, (i % 2, 0), dev, seed=60 + i) for i in range(6)]
+        m = tp.MultiRollout(ros, net, dev, elide_dead_forward=elide)
+        seen = []
+        for _ in range(n):
+            m.step()
+            seen.append(sum(r.need_replan for r in ros))
+        m.flush()
+        runs[elide] = (ros, seen)
+    assert 0 < sum(runs[True][1]) < 6 * n                       # some steps replanned, some did not: both branches were exercised
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert a.camera.cam_idx_history == b.camera.cam_idx_history and a.n_replans == b.n_replans
+        assert np.array_equal(a.camera.X_cam_history, b.camera.X_cam_history)
+        assert a.coverage_evolution(n) == b.coverage_evolution(n)
+        na = int(a.st.cloud_count.item())
+        assert na == int(b.st.cloud_count.item()) and torch.equal(a.st.cloud[:na], b.st.cloud[:na])
+
+
 def test_four_streams_match_single_rollouts(hip, dataset, nbp_weights):
     """Four groups = four HIP streams stepping concurrently (scratch buffers are per stream): every rollout still walks
     exactly the trajectory it walks alone."""
