@@ -599,6 +599,19 @@ int nbp_bn_train_backward_fused_f32(const float* dy, const float* x, const float
                                     const float* mean, const float* invstd, const float* gamma, int relu,
                                     float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* amax_out,
                                     void* ws, size_t ws_bytes, void* stream);
+/* Round 4: the backward without reading y.  nbp_bn_train_forward_stat_f32 = nbp_bn_train_forward_amax_f32 that also hands out the
+ * UNROUNDED statistics the normalisation used (stat_out: [2 C] doubles, mean | invstd, 32-byte aligned);
+ * nbp_bn_train_backward_stat_f32 = nbp_bn_train_backward_fused_f32 whose ReLU mask (y > 0) is rebuilt from x -- which the pass
+ * reads anyway -- through the forward's own arithmetic on those statistics (C % 4 == 0): two tensor reads less per BatchNorm and
+ * step, the same mask bit for bit. */
+int nbp_bn_train_forward_stat_f32(const float* x, long long M, int C, const float* gamma, const float* beta,
+                                  float eps, float momentum, float* running_mean, float* running_var,
+                                  int relu, float* mean, float* invstd, float* y, void* amax_out, double* stat_out,
+                                  void* ws, size_t ws_bytes, void* stream);
+int nbp_bn_train_backward_stat_f32(const float* dy, const float* x, const double* stat_d, const float* beta, long long M, int C,
+                                   const float* mean, const float* invstd, const float* gamma, int relu,
+                                   float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* amax_out,
+                                   void* ws, size_t ws_bytes, void* stream);
 /* out[c] = sum_m rows[m]*x[m][c] (rows NULL = 1): conv bias gradients, psi weight gradient. */
 int nbp_colsum_f32(const float* x, const float* rows_or_null, long long M, int C, float* out, void* ws,
                    size_t ws_bytes, void* stream);

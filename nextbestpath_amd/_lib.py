@@ -71,6 +71,8 @@ SIGNATURES = {
     "nbp_colreduce_workspace_bytes": (_sz, [_ll, _i]),
     "nbp_bn_train_forward_f32": (_i, [_vp, _ll, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "nbp_bn_train_forward_amax_f32": (_i, [_vp, _ll, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nbp_bn_train_forward_stat_f32": (_i, [_vp, _ll, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nbp_bn_train_backward_stat_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "nbp_bn_backward_fuses": (_i, [_i]),
     "nbp_bn_train_backward_fused_f32": (_i, [_vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "nbp_bn_train_backward_f32": (_i, [_vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

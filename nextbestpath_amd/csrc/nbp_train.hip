@@ -70,12 +70,21 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f64x4 to_d4(f32x4 v) { return f64x4{(double)v[0], (double)v[1], (double)v[2], (double)v[3]}; }
 
+// The train-mode BatchNorm output of four channels, evaluated in double from the UNROUNDED statistics and rounded once
+// (bn_apply4_kernel).  The backward kernels call the same function on the same inputs to rebuild the ReLU mask (y > 0) from x,
+// which they read anyway, instead of reading y: two of the ten tensor passes a BatchNorm costs per step (round 4).
+__device__ __forceinline__ f32x4 bn_value4(f32x4 x, f64x4 mu, f64x4 is, f64x4 g, f64x4 bt) {
+    const f64x4 r = (to_d4(x) - mu) * is * g + bt;
+    return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+}
+struct MaskStat { const double* stat_d; const float* gamma; const float* beta; };     // stat_d = [mean | invstd] doubles, or null: mask from y
+
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          const float* __restrict__ y, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ rows,
                                                          long long M, int C4, int relu, long long rows_per_block,
-                                                         double* __restrict__ part) {
+                                                         double* __restrict__ part, MaskStat ms = MaskStat{nullptr, nullptr, nullptr}) {
     const int CT = C4 < 256 ? C4 : 256;
     const int rpb = 256 / CT;
     const int c_local = threadIdx.x % CT, rsub = threadIdx.x / CT;
@@ -92,18 +101,25 @@ __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict
             f64x4 mu = {0.0, 0.0, 0.0, 0.0}, is = {0.0, 0.0, 0.0, 0.0};
             if (MODE == 1) { mu = to_d4(reinterpret_cast<const f32x4*>(mean)[c]); is = to_d4(reinterpret_cast<const f32x4*>(invstd)[c]); }
             if (MODE == 0) mu = to_d4(a4[c]);  // shift = the first row (see colreduce_kernel)
+            f64x4 mmu = mu, mis = is, mg = mu, mbt = mu;       // MODE 1, mask from the statistics: the forward's unrounded mean / invstd
+            const bool stat_mask = MODE == 1 && relu && ms.stat_d;
+            if (stat_mask) {
+                mmu = reinterpret_cast<const f64x4*>(ms.stat_d)[c]; mis = reinterpret_cast<const f64x4*>(ms.stat_d + 4 * (size_t)C4)[c];
+                mg = to_d4(reinterpret_cast<const f32x4*>(ms.gamma)[c]); mbt = to_d4(reinterpret_cast<const f32x4*>(ms.beta)[c]);
+            }
             auto step = [&](long long r) {
                 const f32x4 v = a4[r * C4 + c];
                 if (MODE == 0) { const f64x4 d = to_d4(v) - mu; s0 += d; s1 += d * d; }
                 if (MODE == 1) {
                     f32x4 dz = v;
+                    const f32x4 xv = b4[r * C4 + c];
                     if (relu) {
-                        const f32x4 yy = y4[r * C4 + c];
+                        const f32x4 yy = stat_mask ? bn_value4(xv, mmu, mis, mg, mbt) : y4[r * C4 + c];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
                     }
                     const f64x4 dzd = to_d4(dz);
-                    s0 += dzd; s1 += dzd * ((to_d4(b4[r * C4 + c]) - mu) * is);
+                    s0 += dzd; s1 += dzd * ((to_d4(xv) - mu) * is);
                 }
                 if (MODE == 2) s0 += to_d4(v) * (double)(rows ? rows[r] : 1.f);
             };
@@ -240,8 +256,7 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict_
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
         const f64x4 g = to_d4(reinterpret_cast<const f32x4*>(gamma)[c]), bt = to_d4(reinterpret_cast<const f32x4*>(beta)[c]);
-        const f64x4 r = (to_d4(x4[i]) - mu4[c]) * is4[c] * g + bt;
-        f32x4 v = {(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+        f32x4 v = bn_value4(x4[i], mu4[c], is4[c], g, bt);
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(256) void bn_backward_apply4_kernel(const float* __
                                                                  const float* __restrict__ invstd,
                                                                  const float* __restrict__ gamma,
                                                                  const double* __restrict__ sums, int relu,
-                                                                 float* __restrict__ dx) {
+                                                                 float* __restrict__ dx, MaskStat ms) {
     const double invM = 1.0 / (double)M;
     const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
@@ -266,17 +281,21 @@ __global__ __launch_bounds__(256) void bn_backward_apply4_kernel(const float* __
     f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
     const f64x4* db4 = reinterpret_cast<const f64x4*>(sums);
     const f64x4* dg4 = reinterpret_cast<const f64x4*>(sums + 4 * (size_t)C4);
+    const bool stat_mask = relu && ms.stat_d;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
         const f64x4 mu = to_d4(reinterpret_cast<const f32x4*>(mean)[c]), is = to_d4(reinterpret_cast<const f32x4*>(invstd)[c]);
         const f64x4 g = to_d4(reinterpret_cast<const f32x4*>(gamma)[c]);
         f32x4 dz = dy4[i];
+        const f32x4 xv = x4[i];
         if (relu) {
-            const f32x4 yy = y4[i];
+            const f32x4 yy = stat_mask ? bn_value4(xv, reinterpret_cast<const f64x4*>(ms.stat_d)[c],
+                                                   reinterpret_cast<const f64x4*>(ms.stat_d + 4 * (size_t)C4)[c], g,
+                                                   to_d4(reinterpret_cast<const f32x4*>(ms.beta)[c])) : y4[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
         }
-        const f64x4 xhat = (to_d4(x4[i]) - mu) * is;
+        const f64x4 xhat = (to_d4(xv) - mu) * is;
         const f64x4 r = g * is * (to_d4(dz) - invM * (db4[c] + xhat * dg4[c]));
         dx4[i] = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
     }
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(256) void bn_backward_apply4_sum_kernel(const float
                                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                      const float* __restrict__ gamma, const double* __restrict__ sums,
                                                                      int relu, long long rows_per_block, float* __restrict__ dx,
-                                                                     double* __restrict__ part, unsigned* __restrict__ amax_out) {
+                                                                     double* __restrict__ part, unsigned* __restrict__ amax_out, MaskStat ms) {
     const int CT = C4 < 256 ? C4 : 256;
     const int rpb = 256 / CT;
     const int c_local = threadIdx.x % CT, rsub = threadIdx.x / CT;
@@ -313,15 +332,22 @@ __global__ __launch_bounds__(256) void bn_backward_apply4_sum_kernel(const float
             const f64x4 mu = to_d4(reinterpret_cast<const f32x4*>(mean)[c]), is = to_d4(reinterpret_cast<const f32x4*>(invstd)[c]);
             const f64x4 g = to_d4(reinterpret_cast<const f32x4*>(gamma)[c]);
             const f64x4 kb = db4[c], kg = dg4[c];
+            const bool stat_mask = relu && ms.stat_d;
+            f64x4 mmu = mu, mis = is, mbt = mu;
+            if (stat_mask) {
+                mmu = reinterpret_cast<const f64x4*>(ms.stat_d)[c]; mis = reinterpret_cast<const f64x4*>(ms.stat_d + 4 * (size_t)C4)[c];
+                mbt = to_d4(reinterpret_cast<const f32x4*>(ms.beta)[c]);
+            }
             for (long long r = r_begin + rsub; r < r_end; r += rpb) {
                 const long long i = r * C4 + c;
                 f32x4 dz = dy4[i];
+                const f32x4 xv = x4[i];
                 if (relu) {
-                    const f32x4 yy = y4[i];
+                    const f32x4 yy = stat_mask ? bn_value4(xv, mmu, mis, g, mbt) : y4[i];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
                 }
-                const f64x4 xhat = (to_d4(x4[i]) - mu) * is;
+                const f64x4 xhat = (to_d4(xv) - mu) * is;
                 const f64x4 rr = g * is * (to_d4(dz) - invM * (kb + xhat * kg));
                 const f32x4 o = f32x4{(float)rr[0], (float)rr[1], (float)rr[2], (float)rr[3]};
                 dx4[i] = o;
@@ -908,10 +934,30 @@ extern "C" size_t nbp_colreduce_workspace_bytes(long long M, int C) {
 }
 
 // amax_out (or null): 64 zeroed words that receive max |y| (float bits; only for C % 4 == 0, else left untouched)
+// stat_out (or null): [2 C] doubles that receive the UNROUNDED mean | invstd the normalisation used -- handed to
+// nbp_bn_train_backward_stat_f32, which rebuilds the ReLU mask from x with them instead of reading y
+static int bn_forward_impl(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, int relu, float* mean,
+                           float* invstd, float* y, void* amax_out_v, double* stat_out, void* ws, size_t ws_bytes, void* stream);
 extern "C" int nbp_bn_train_forward_amax_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
                                              float momentum, float* running_mean, float* running_var, int relu, float* mean,
                                              float* invstd, float* y, void* amax_out_v, void* ws, size_t ws_bytes, void* stream) {
     NBP_ENTER();
+    return bn_forward_impl(x, M, C, gamma, beta, eps, momentum, running_mean, running_var, relu, mean, invstd, y, amax_out_v, nullptr, ws,
+                           ws_bytes, stream);
+}
+extern "C" int nbp_bn_train_forward_stat_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
+                                             float momentum, float* running_mean, float* running_var, int relu, float* mean,
+                                             float* invstd, float* y, void* amax_out_v, double* stat_out, void* ws, size_t ws_bytes,
+                                             void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!stat_out || ((uintptr_t)stat_out & 31), NBP_E_ARG);
+    return bn_forward_impl(x, M, C, gamma, beta, eps, momentum, running_mean, running_var, relu, mean, invstd, y, amax_out_v, stat_out, ws,
+                           ws_bytes, stream);
+}
+static int bn_forward_impl(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, int relu, float* mean,
+                           float* invstd, float* y, void* amax_out_v, double* stat_out, void* ws, size_t ws_bytes, void* stream) {
     unsigned* amax_out = (unsigned*)amax_out_v;
     NBP_RETURN_IF(!x || !gamma || !beta || !mean || !invstd || !y || !ws || M < 1 || C < 1, NBP_E_ARG);
     NBP_RETURN_IF(ws_bytes < nbp_colreduce_workspace_bytes(M, C), NBP_E_WS);
@@ -923,7 +969,7 @@ extern "C" int nbp_bn_train_forward_amax_f32(const float* x, long long M, int C,
     else colreduce_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, rpb, part);
     int rc = nbp_launch_status();
     if (rc) return rc;
-    double* stat_d = part + (((size_t)nblk * 2 * C + 31) / 32 * 32);        // [2][C] unrounded mean, invstd (32-B aligned)
+    double* stat_d = stat_out ? stat_out : part + (((size_t)nblk * 2 * C + 31) / 32 * 32);        // [2][C] unrounded mean, invstd (32-B aligned)
     bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(x, part, nblk, C, M, eps, momentum, mean, invstd, running_mean,
                                                                   running_var, stat_d);
     if ((rc = nbp_launch_status())) return rc;
@@ -949,20 +995,41 @@ extern "C" int nbp_bn_train_backward_f32(const float* dy, const float* x, const 
 // dx_colsum (or null; C floats) receives sum_m dx[m][c], amax_out (or null; 64 zeroed words) max |dx| -- both only for
 // C % 4 == 0 (the caller checks nbp_bn_backward_fuses(C)); folded into the pass that writes dx.
 extern "C" int nbp_bn_backward_fuses(int C) { return C % 4 == 0; }
+static int bn_backward_impl(const float* dy, const float* x, const float* y_or_null, MaskStat ms, long long M, int C,
+                            const float* mean, const float* invstd, const float* gamma, int relu, float* dx,
+                            float* dgamma, float* dbeta, float* dx_colsum, void* amax_out_v, void* ws, size_t ws_bytes, void* stream);
 extern "C" int nbp_bn_train_backward_fused_f32(const float* dy, const float* x, const float* y_or_null, long long M, int C,
                                                const float* mean, const float* invstd, const float* gamma, int relu, float* dx,
                                                float* dgamma, float* dbeta, float* dx_colsum, void* amax_out_v, void* ws,
                                                size_t ws_bytes, void* stream) {
     NBP_ENTER();
+    return bn_backward_impl(dy, x, y_or_null, MaskStat{nullptr, nullptr, nullptr}, M, C, mean, invstd, gamma, relu, dx, dgamma, dbeta,
+                            dx_colsum, amax_out_v, ws, ws_bytes, stream);
+}
+// The same with the ReLU mask rebuilt from x (read anyway) through the forward's unrounded statistics (stat_d of
+// nbp_bn_train_forward_stat_f32) and beta, instead of reading y: C % 4 == 0 only.
+extern "C" int nbp_bn_train_backward_stat_f32(const float* dy, const float* x, const double* stat_d, const float* beta, long long M, int C,
+                                              const float* mean, const float* invstd, const float* gamma, int relu, float* dx,
+                                              float* dgamma, float* dbeta, float* dx_colsum, void* amax_out_v, void* ws,
+                                              size_t ws_bytes, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!stat_d || !beta || ((uintptr_t)stat_d & 31), NBP_E_ARG);
+    NBP_RETURN_IF(C % 4 != 0, NBP_E_SHAPE);
+    return bn_backward_impl(dy, x, nullptr, MaskStat{stat_d, gamma, beta}, M, C, mean, invstd, gamma, relu, dx, dgamma, dbeta, dx_colsum,
+                            amax_out_v, ws, ws_bytes, stream);
+}
+static int bn_backward_impl(const float* dy, const float* x, const float* y_or_null, MaskStat ms, long long M, int C,
+                            const float* mean, const float* invstd, const float* gamma, int relu, float* dx,
+                            float* dgamma, float* dbeta, float* dx_colsum, void* amax_out_v, void* ws, size_t ws_bytes, void* stream) {
     unsigned* amax_out = (unsigned*)amax_out_v;
     NBP_RETURN_IF(!dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !ws || M < 1 || C < 1, NBP_E_ARG);
-    NBP_RETURN_IF(relu && !y_or_null, NBP_E_ARG);
+    NBP_RETURN_IF(relu && !y_or_null && !ms.stat_d, NBP_E_ARG);
     NBP_RETURN_IF(ws_bytes < nbp_colreduce_workspace_bytes(M, C), NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;
     long long rpb;
     const int nblk = blocks_for_rows(M, &rpb);
     double* part = (double*)(((uintptr_t)ws + 255) / 256 * 256);
-    if (C % 4 == 0) colreduce4_kernel<1><<<nblk, 256, 0, st>>>(dy, x, y_or_null, mean, invstd, nullptr, M, C / 4, relu, rpb, part);
+    if (C % 4 == 0) colreduce4_kernel<1><<<nblk, 256, 0, st>>>(dy, x, y_or_null, mean, invstd, nullptr, M, C / 4, relu, rpb, part, ms);
     else colreduce_kernel<1><<<nblk, 256, 0, st>>>(dy, x, y_or_null, mean, invstd, nullptr, M, C, relu, rpb, part);
     int rc = nbp_launch_status();
     if (rc) return rc;
@@ -972,7 +1039,7 @@ extern "C" int nbp_bn_train_backward_fused_f32(const float* dy, const float* x, 
     if (C % 4 == 0 && (dx_colsum || amax_out)) {
         // dx, its column sums and its max |.| in ONE pass (the partials reuse `part`: the finalizer above has consumed it)
         bn_backward_apply4_sum_kernel<<<nblk, 256, 0, st>>>(dy, x, y_or_null, M, C / 4, mean, invstd, gamma, sums, relu, rpb, dx, part,
-                                                            amax_out);
+                                                            amax_out, ms);
         if ((rc = nbp_launch_status())) return rc;
         if (dx_colsum) {
             colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, dx_colsum, nullptr);
@@ -982,7 +1049,7 @@ extern "C" int nbp_bn_train_backward_fused_f32(const float* dy, const float* x, 
     }
     if (C % 4 == 0)
         bn_backward_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(dy, x, y_or_null, M * C / 4, C / 4, M, mean, invstd,
-                                                                              gamma, sums, relu, dx);
+                                                                              gamma, sums, relu, dx, ms);
     else
         bn_backward_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(dy, x, y_or_null, M * C, C, M, mean, invstd, gamma,
                                                                          sums, relu, dx);

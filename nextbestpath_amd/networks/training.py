@@ -121,6 +121,7 @@ def _const(value, n, device):
 # dicts by data_ptr()).  A consumer that gets a tensor without a note (autograd summed two gradients, a slice, a copy) takes its
 # own pass.  NBP_TRAIN_FUSE=0 switches the hand-off off altogether.
 _FUSE = _lib.tune("NBP_TRAIN_FUSE", "1") == "1"
+_MASK_FROM_X = _lib.tune("NBP_TRAIN_MASK_FROM_X", "1") == "1"      # BatchNorm backward: ReLU mask rebuilt from x (0 = read y, as round 3)
 _ARENA = {}
 
 
@@ -321,19 +322,36 @@ class BNFn(torch.autograd.Function):
         ws = _ws(L.nbp_colreduce_workspace_bytes(M, C), dev)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         slot = _fresh_slots(dev) if _FUSE and C % 4 == 0 else None
-        _chk(L.nbp_bn_train_forward_amax_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
-                                             _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
-                                             _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(slot), _lib.ptr(ws), ws.numel(), _st()), "bn_fwd")
+        # the backward rebuilds the ReLU mask from x through the unrounded statistics (two tensor reads less per BatchNorm): not
+        # when an observer may rewrite y after the fact (its mask is then y's, and y is what gets saved)
+        stat = torch.empty(2 * C, dtype=torch.float64, device=dev) if (_MASK_FROM_X and relu and C % 4 == 0 and _observer is None) else None
+        if stat is not None:
+            _chk(L.nbp_bn_train_forward_stat_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
+                                                 _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
+                                                 _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(slot), _lib.ptr(stat), _lib.ptr(ws), ws.numel(),
+                                                 _st()), "bn_fwd")
+        else:
+            _chk(L.nbp_bn_train_forward_amax_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
+                                                 _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
+                                                 _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(slot), _lib.ptr(ws), ws.numel(), _st()), "bn_fwd")
         if slot is not None:
             _note(y, amax=slot)
-        ctx.save_for_backward(x, y, mean, invstd, g)
+        if stat is not None:
+            ctx.save_for_backward(x, stat, mean, invstd, g, b)
+        else:
+            ctx.save_for_backward(x, y, mean, invstd, g)
+        ctx.mask_from_x = stat is not None
         ctx.relu = bool(relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         L = _lib.lib()
-        x, y, mean, invstd, g = ctx.saved_tensors
+        if ctx.mask_from_x:
+            x, stat, mean, invstd, g, beta = ctx.saved_tensors
+            y = None
+        else:
+            x, y, mean, invstd, g = ctx.saved_tensors
         C = x.shape[-1]
         M = x.numel() // C
         dev = x.device
@@ -345,9 +363,14 @@ class BNFn(torch.autograd.Function):
         fuse = _FUSE and C % 4 == 0
         slot = _fresh_slots(dev) if fuse else None
         csum = torch.empty(C, dtype=torch.float32, device=dev) if fuse else None
-        _chk(L.nbp_bn_train_backward_fused_f32(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), M, C, _lib.ptr(mean), _lib.ptr(invstd),
-                                               _lib.ptr(g), int(ctx.relu), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(csum),
-                                               _lib.ptr(slot), _lib.ptr(ws), ws.numel(), _st()), "bn_bwd")
+        if ctx.mask_from_x:
+            _chk(L.nbp_bn_train_backward_stat_f32(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(stat), _lib.ptr(beta), M, C, _lib.ptr(mean),
+                                                  _lib.ptr(invstd), _lib.ptr(g), int(ctx.relu), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db),
+                                                  _lib.ptr(csum), _lib.ptr(slot), _lib.ptr(ws), ws.numel(), _st()), "bn_bwd")
+        else:
+            _chk(L.nbp_bn_train_backward_fused_f32(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), M, C, _lib.ptr(mean), _lib.ptr(invstd),
+                                                   _lib.ptr(g), int(ctx.relu), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(csum),
+                                                   _lib.ptr(slot), _lib.ptr(ws), ws.numel(), _st()), "bn_bwd")
         if fuse:
             _note(dx, colsum=(slot, csum))
         return dx, dg, db, None, None, None, None, None

@@ -119,6 +119,32 @@ def test_batchnorm_statistics_when_mean_dwarfs_std(hip, C):
     assert (y.cpu().double().reshape(-1, C) - yy).abs().max() < 2e-3   # x itself carries 4e-6 / 0.01 relative noise
 
 
+def test_batchnorm_backward_mask_from_x_is_the_mask_from_y(hip, monkeypatch):
+    """Round 4: the BatchNorm backward rebuilds the ReLU mask (y > 0) from x, which it reads anyway, through the forward's unrounded
+    statistics, instead of reading y (nbp_bn_train_backward_stat_f32).  Same mask -> the same dx, dgamma, dbeta bit for bit as the
+    y-reading form, including pre-activations that round to exactly zero and values a hair on either side of it."""
+    torch.manual_seed(3)
+    B, H, W, C = 3, 16, 32, 64
+    x = torch.randn(B, H, W, C, device=D) * 2.0 + 0.3
+    gamma, beta = (torch.rand(C, device=D) + 0.5), torch.randn(C, device=D) * 0.2
+    x[0, 0, :4] = 0.0                                              # exact repeats of one value per channel ...
+    beta[5] = 0.0
+    gamma[7] = 0.0                                                 # ... a channel whose output is beta everywhere (all on one side)
+    dy = torch.randn(B, H, W, C, device=D)
+    outs = []
+    for from_x in (True, False):
+        monkeypatch.setattr(tr, "_MASK_FROM_X", from_x)
+        xx = x.clone().requires_grad_(True)
+        g, b = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=D), torch.ones(C, device=D)
+        y = tr.BNFn.apply(xx, g, b, rm, rv, 1e-5, 0.1, True)
+        y.backward(dy)
+        outs.append((y.detach().clone(), xx.grad.clone(), g.grad.clone(), b.grad.clone()))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    assert float((outs[0][0] == 0).float().mean()) > 0.2         # the mask really cuts
+
+
 def test_small_functions(hip):
     # max-pool (with ties -> first maximum), add+relu, psi conv, sigmoid, row scale, layout, gather, losses
     x = torch.floor(_rand(2, 8, 6, 64, seed=1) * 3)
