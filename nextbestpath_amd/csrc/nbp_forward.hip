@@ -373,7 +373,10 @@ struct AmaxBook {
     int init(Bump& bp, hipStream_t s, bool dry) {
         st = s; next = n = 0;
         slots = bp.take<unsigned>(128 * 64);       // 64 words per tensor (nbp_split.hip: AMAX_WORDS)
-        return dry ? 0 : (int)hipMemsetAsync(slots, 0, 128 * 64 * sizeof(unsigned), st);
+        // zeroed by a KERNEL, not hipMemsetAsync: in a captured forward (packing.ForwardGraph) the memset node of ROCm 7.2's
+        // graph replay is not ordered against the kernel nodes around it -- replays on new input kept the previous maxima or
+        // lost fresh ones (tools/diag/graph_replay_check.py; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 hid it).  Same cost when eager.
+        return dry ? 0 : fill_f32(reinterpret_cast<float*>(slots), 0.f, 128 * 64, st);
     }
     unsigned* find(const void* p) const {
         for (int i = n - 1; i >= 0; --i) if (key[i] == p) return val[i];

@@ -43,6 +43,10 @@ def _c1(ci, co):
     return nn.Conv2d(ci, co, kernel_size=1, stride=1, padding=0, bias=True)
 
 
+# rocprofv3 --pmc serialises every dispatch to read its counters and aborts the queue on a graph replay ("AQL packet is malformed",
+# observed on ROCm 7.2 / gfx950): under counter collection forward_static runs the same launches eagerly (bit-identical outputs)
+_COUNTER_COLLECTION = os.environ.get("ROCPROF_COUNTER_COLLECTION", "") not in ("", "0", "False", "false")
+
 class _Holder(nn.Module):
     """A module whose only child is an ``nn.Sequential`` registered under ``attr``.
 
@@ -128,7 +132,7 @@ class NBP(nn.Module):
     def forward_static(self, x: torch.Tensor):
         """Eval forward on a PERSISTENT input tensor (a rollout's net_in): captured once per (tensor, weights) into a hipGraph and
         replayed (packing.ForwardGraph).  Returns the graph's own out1 / out2, overwritten by the next call on the same x."""
-        if self.training or not x.is_cuda:
+        if self.training or not x.is_cuda or _COUNTER_COLLECTION:
             return self.forward(x)
         from . import packing
         packed = self._ensure_packed(x.device)

@@ -300,6 +300,20 @@ class MultiRollout:
         for g, m6 in zip(self.groups, self.maps6):
             for i, r in enumerate(g):
                 r.st.maps6 = m6[i]
+        # the replanning results of a group's rollouts as rows of ONE buffer pair per group (one device -> host copy per group and
+        # step); rollouts whose lattices differ in size keep their own buffers
+        self._res = []
+        for g in self.groups:
+            nb = {r.planner.result_bytes() for r in g}
+            if len(nb) == 1:
+                n = nb.pop()
+                devb = torch.empty(len(g), n, dtype=torch.uint8, device=device)
+                pinb = torch.empty(len(g), n, dtype=torch.uint8).pin_memory()
+                for i, r in enumerate(g):
+                    r.planner.share_result_buffers(devb[i], pinb[i])
+                self._res.append((devb, pinb))
+            else:
+                self._res.append(None)
         self.inflight = [False] * len(self.groups)
         # Streams.  One HIP stream per group carries the group's small kernels and its batched forward.
         # NBP_ROLLOUT_STREAMS = k > 0 (A/B switch) adds k side streams per group for the rollouts' ~20 small kernels per step
@@ -447,6 +461,8 @@ class MultiRollout:
                                                    r.traj_img.reshape(r.S, r.S), r.collision_list))
             hipops.replan_batch(items, r0.S, r0.V, r0.grid_range)
             pin[:out1.shape[0]].copy_(out1, non_blocking=True)
+            if self._res[gi] is not None:
+                self._res[gi][1].copy_(self._res[gi][0], non_blocking=True)        # every rollout's (scores, valid, blocked) rows at once
             for i, r in need:
                 r.planner.replan_copy_back(r.pose, pin[row(i)].reshape(8, r.V, r.V))
         ev = self.ev_plan[gi][0]

@@ -122,14 +122,27 @@ class LatticePlanner:
         self.native_search = _lib.tune("NBP_PLAN_SEARCH", "native") != "python"
 
     # ---- the GPU half of a replan for several rollouts at once (MultiRollout): persistent result buffers, ONE device->host copy
+    def result_bytes(self):
+        """Bytes of one rollout's replan results (scores f64 [P] | valid u8 [P] | blocked u8 [E])."""
+        P, E = len(self.idx3), len(self.edges)
+        return (8 * P + P + 7) // 8 * 8 + E
+
+    def share_result_buffers(self, dev_row, pin_row):
+        """MultiRollout: this planner's results live in a row of its GROUP's buffers, so that the group needs ONE device -> host
+        copy per step instead of one per replanning rollout (each such copy is a launch: ~15 per group and step)."""
+        assert dev_row.numel() == self.result_bytes() == pin_row.numel()
+        self._res_dev, self._res_pin, self._res_shared = dev_row, pin_row, True
+        self._res_views_dev = None
+
     def _batch_buffers(self):
-        if getattr(self, "_res_dev", None) is None:
+        if getattr(self, "_res_dev", None) is None or getattr(self, "_res_views_dev", None) is None:
             P, E, dev = len(self.idx3), len(self.edges), self.device
             o_valid = 8 * P
             o_blocked = (o_valid + P + 7) // 8 * 8
             total = o_blocked + E
-            self._res_dev = torch.empty(total, dtype=torch.uint8, device=dev)
-            self._res_pin = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+            if getattr(self, "_res_dev", None) is None:
+                self._res_dev = torch.empty(total, dtype=torch.uint8, device=dev)
+                self._res_pin = torch.empty(total, dtype=torch.uint8, pin_memory=True)
             cut = lambda t: (t[:8 * P].view(torch.float64), t[o_valid:o_valid + P], t[o_blocked:o_blocked + E])
             self._res_views_dev, self._res_views_pin = cut(self._res_dev), cut(self._res_pin)
             self._obst = torch.empty(self.S, self.S, dtype=torch.float32, device=dev)
@@ -152,7 +165,8 @@ class LatticePlanner:
     def replan_copy_back(self, pose, out1_pinned):
         """After the batched launch: this rollout's (score, valid, blocked) in ONE copy; out1_pinned = its [8,V,V] slice of the
         group's pinned copy of the value maps."""
-        self._res_pin.copy_(self._res_dev, non_blocking=True)
+        if not getattr(self, "_res_shared", False):          # (shared rows: the group copies all of them at once)
+            self._res_pin.copy_(self._res_dev, non_blocking=True)
         score, valid, blocked = self._res_views_pin
         self._pending = (pose, [valid, score, blocked, out1_pinned])
 

@@ -215,6 +215,39 @@ def test_repack_after_weight_update(hip, nbp_weights):
     assert (b1 - a1 - 1.0).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("precision", ["fp32_split", "fp32", "bf16"])
+def test_forward_graph_is_bit_identical(hip, nbp_weights, precision):
+    """packing.ForwardGraph / NBP.forward_static: the eval forward on fixed buffers captured once into a hipGraph and replayed -- the
+    same kernels with the same arguments in the same order, so the outputs are the eager call's bit for bit, replay after replay
+    and when the input tensor's CONTENT changes; a weight update re-packs and re-captures."""
+    from nextbestpath_amd.networks import packing
+    from nextbestpath_amd.networks.nbp_model import NBP
+    from nextbestpath_amd.utility.synthetic import make_count_maps
+    m = NBP()
+    m.load_state_dict(nbp_weights, strict=True)
+    m = m.cuda().eval()
+    m.conv_precision = precision
+    for B, S in ((1, 256), (3, 64)):
+        x = make_count_maps(B, S, seed=B).cuda()
+        with torch.no_grad():
+            e1, e2 = m(x)
+            g1, g2 = m.forward_static(x)
+            assert torch.equal(e1, g1) and torch.equal(e2, g2), (precision, B, S)
+            x.copy_(make_count_maps(B, S, seed=B + 10).cuda())           # new content, same tensor: the replay reads it
+            e1, e2 = m(x)
+            for _ in range(3):
+                g1, g2 = m.forward_static(x)
+            assert torch.equal(e1, g1) and torch.equal(e2, g2), (precision, B, S)
+    n_graphs = len(m._graphs)
+    assert n_graphs == 2
+    with torch.no_grad():
+        m.Final1.weight.mul_(1.5)                                        # a weight update: new pack, the captured graphs are dropped
+        e1, _ = m(x)
+        g1, _ = m.forward_static(x)
+    assert torch.equal(e1, g1) and len(m._graphs) == 1
+    assert isinstance(next(iter(m._graphs.values())), packing.ForwardGraph)
+
+
 def test_halo_tile_on_1x1_is_a_shape_error(hip):
     """An explicit halo tile id on a 1x1 convolution (or an image that is not a multiple of the tile) is refused with
     NBP_E_SHAPE -- regression: the plan used to divide by zero."""

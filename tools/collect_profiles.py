@@ -11,7 +11,9 @@ pairs = [("kernel_stats.csv", "kernel_stats.csv"), ("pmc_summary.csv", "pmc_summ
          ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("fwd_split/kernel_stats.csv", "forward_split_kernel_stats.csv"),
          ("fwd_split/pmc_summary.csv", "forward_split_pmc_summary.csv"), ("fwd_f32/kernel_stats.csv", "forward_f32_kernel_stats.csv"),
          ("fwd_f32/pmc_summary.csv", "forward_f32_pmc_summary.csv"), ("fwd_bf16/kernel_stats.csv", "forward_bf16_kernel_stats.csv"),
-         ("fwd_bf16/pmc_summary.csv", "forward_bf16_pmc_summary.csv"), ("train/kernel_stats.csv", "train_kernel_stats.csv")]
+         ("fwd_bf16/pmc_summary.csv", "forward_bf16_pmc_summary.csv"), ("train/kernel_stats.csv", "train_kernel_stats.csv"),
+         ("power_trace_b24.txt", "power_trace_b24.txt"), ("power_trace_bf16_512_b8.txt", "power_trace_bf16_512_b8.txt"),
+         ("fwd_graph_ab.txt", "fwd_graph_ab.txt"), ("bf16_layer_table.txt", "bf16_layer_table.txt"), ("map_bins_ab.txt", "map_bins_ab.txt")]
 for a, b in pairs:
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 0:
