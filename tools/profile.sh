@@ -42,3 +42,6 @@ timeout 200 python tools/diag/power_trace.py --batch 8 --seconds 3 --precision b
 timeout 300 python tools/diag/fwd_graph_ab.py --batches 1 2 4 24 > "$OUT/fwd_graph_ab.txt" 2>&1
 timeout 300 python tools/diag/bf16_layer_table.py > "$OUT/bf16_layer_table.txt" 2>&1
 timeout 200 python tools/diag/map_bins_ab.py > "$OUT/map_bins_ab.txt" 2>&1
+# gpurun merges at most 64 MiB back: the per-dispatch traces and counter rows are summarised above (kernel_stats.csv, pmc_summary.csv)
+find "$OUT" \( -name "*kernel_trace.csv" -o -name "*counter_collection.csv" -o -name "*agent_info.csv" \) -delete
+du -sh "$OUT" | tail -1
