@@ -618,6 +618,10 @@ int nbp_colsum_f32(const float* x, const float* rows_or_null, long long M, int C
 /* op 0: relu(a+b)  1: a*(b>0)  2: sigmoid(a)  3: a*b*(1-b)  4: a+b  5: a+b[0] */
 int nbp_elementwise_f32(int op, const float* a, const float* b, long long n, float* out, void* stream);
 int nbp_rowscale_f32(const float* x, const float* s, long long M, int C, float* out, void* stream);   /* x[m][c]*s[m] */
+/* backward of out = x * s[m] in one pass: dx[m][c] = dy[m][c] * s[m], ds[m] = sum_c dy[m][c] * x[m][c]; dy's rows are ldy >= C floats
+ * apart (a channel slice of a wider gradient is read in place); C, ldy multiples of 4, 16-byte aligned pointers (else NBP_E_SHAPE) */
+int nbp_rowscale_backward_f32(const float* dy, long long ldy, const float* x, const float* s, long long M, int C, float* dx,
+                              float* ds, void* stream);
 int nbp_rowdot_f32(const float* a, const float* b, int b_is_vector, long long M, int C, float* out,
                    void* stream);                                                                     /* sum_c a*b   */
 int nbp_outer_f32(const float* s, const float* w, long long M, int C, float* out, void* stream);      /* s[m]*w[c]   */

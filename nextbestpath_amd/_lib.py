@@ -80,6 +80,7 @@ SIGNATURES = {
     "nbp_elementwise_f32": (_i, [_i, _vp, _vp, _ll, _vp, _vp]),
     "nbp_rowscale_f32": (_i, [_vp, _vp, _ll, _i, _vp, _vp]),
     "nbp_rowdot_f32": (_i, [_vp, _vp, _i, _ll, _i, _vp, _vp]),
+    "nbp_rowscale_backward_f32": (_i, [_vp, _ll, _vp, _vp, _ll, _i, _vp, _vp, _vp]),
     "nbp_outer_f32": (_i, [_vp, _vp, _ll, _i, _vp, _vp]),
     "nbp_maxpool2_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "nbp_sum2x2_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -532,6 +532,34 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a
     }
 }
 
+// The backward of out = x * s[m] in ONE pass over dy: dx[m][c] = dy[m][c] * s[m] and ds[m] = sum_c dy[m][c] * x[m][c] (it was a
+// row-scale launch plus a row-dot launch, each reading dy).  dy's rows may be ldy >= C floats apart: the gradient of the first
+// source of a two-source convolution is a channel slice of the joint gradient, read in place instead of copied out.
+// 16 lanes per row, one float4 per lane and step.
+__global__ __launch_bounds__(256) void rowscale_bwd4_kernel(const float* __restrict__ dy, long long ldy4, const float* __restrict__ x,
+                                                            const float* __restrict__ s, long long M, int C4,
+                                                            float* __restrict__ dx, float* __restrict__ ds) {
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
+    const int sub = threadIdx.x & 15;
+    const long long rpb = blockDim.x >> 4;
+    for (long long m = (long long)blockIdx.x * rpb + (threadIdx.x >> 4); m < M; m += (long long)gridDim.x * rpb) {
+        const float sm = s[m];
+        float acc = 0.f;
+        for (int c = sub; c < C4; c += 16) {
+            const f32x4 g = dy4[m * ldy4 + c], xv = x4[m * C4 + c];
+            dx4[m * C4 + c] = g * sm;
+            acc = fmaf(g[0], xv[0], acc); acc = fmaf(g[1], xv[1], acc); acc = fmaf(g[2], xv[2], acc); acc = fmaf(g[3], xv[3], acc);
+        }
+        acc += __shfl_xor(acc, 8, 16);
+        acc += __shfl_xor(acc, 4, 16);
+        acc += __shfl_xor(acc, 2, 16);
+        acc += __shfl_xor(acc, 1, 16);
+        if (sub == 0) ds[m] = acc;
+    }
+}
+
 // out[m][c] = s[m] * w[c]
 __global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ s, const float* __restrict__ w, long long total,
                                                     int C, float* __restrict__ out) {
@@ -1117,6 +1145,15 @@ extern "C" int nbp_rowscale_f32(const float* x, const float* s, long long M, int
         rowscale4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, (hipStream_t)stream>>>(x, s, M * C / 4, C / 4, out);
     else
         rowscale_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, (hipStream_t)stream>>>(x, s, M * C, C, out);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_rowscale_backward_f32(const float* dy, long long ldy, const float* x, const float* s, long long M, int C, float* dx,
+                                         float* ds, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!dy || !x || !s || !dx || !ds || M < 1 || C < 4, NBP_E_ARG);
+    NBP_RETURN_IF((C & 3) || (ldy & 3) || ldy < C || (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15), NBP_E_SHAPE);
+    rowscale_bwd4_kernel<<<nbp_ew_grid(M * 16, 256), 256, 0, (hipStream_t)stream>>>(dy, ldy / 4, x, s, M, C / 4, dx, ds);
     return nbp_launch_status();
 }
 

@@ -121,6 +121,7 @@ def _const(value, n, device):
 # dicts by data_ptr()).  A consumer that gets a tensor without a note (autograd summed two gradients, a slice, a copy) takes its
 # own pass.  NBP_TRAIN_FUSE=0 switches the hand-off off altogether.
 _FUSE = _lib.tune("NBP_TRAIN_FUSE", "1") == "1"
+_SLICE_VIEWS = _lib.tune("NBP_TRAIN_SLICE_VIEWS", "1") == "1"      # two-source convolutions return channel-slice VIEWS of dx (0 = copies)
 _MASK_FROM_X = _lib.tune("NBP_TRAIN_MASK_FROM_X", "1") == "1"      # BatchNorm backward: ReLU mask rebuilt from x (0 = read y, as round 3)
 _ARENA = {}
 
@@ -298,7 +299,11 @@ class ConvFn(torch.autograd.Function):
                 low = torch.empty(B, H // 2, W // 2, Ctot, dtype=torch.float32, device=dev)
                 _chk(L.nbp_sum2x2_f32(_lib.ptr(dx), B, H // 2, W // 2, Ctot, _lib.ptr(low), _st()), "sum2x2")
                 dx = low
-            if has1:
+            if has1 and _SLICE_VIEWS:
+                # views of the joint gradient: the attention gate's RowScaleFn reads its slice in place, autograd's sum of dd's two
+                # gradients reads the other (the two slice copies were 2 x (C0 + C1) x M x 4 bytes per decoder level)
+                dx0, dx1 = dx[..., :C0], dx[..., C0:]
+            elif has1:
                 dx0, dx1 = _slice_channels(dx, 0, C0), _slice_channels(dx, C0, C1)
             else:
                 dx0 = dx
@@ -481,11 +486,20 @@ class RowScaleFn(torch.autograd.Function):
         x, s = ctx.saved_tensors
         B, H, W, C = x.shape
         M = B * H * W
-        dy = dy.contiguous()
         dx = torch.empty_like(x)
-        _chk(L.nbp_rowscale_f32(_lib.ptr(dy), _lib.ptr(s), M, C, _lib.ptr(dx), _st()), "rowscale")
         ds = torch.empty(M, dtype=torch.float32, device=x.device)
-        _chk(L.nbp_rowdot_f32(_lib.ptr(dy), _lib.ptr(x), 0, M, C, _lib.ptr(ds), _st()), "rowdot")
+        # one pass over dy for both gradients; a channel slice of a two-source convolution's joint gradient (ConvFn.backward
+        # returns views) is read in place through its row stride
+        ld = dy.stride(2) if dy.dim() == 4 else 0
+        if not (dy.dim() == 4 and dy.stride(3) == 1 and ld >= C and ld % 4 == 0 and dy.stride(1) == W * ld
+                and dy.stride(0) == H * W * ld and dy.data_ptr() % 16 == 0):
+            dy, ld = dy.contiguous(), C
+        if C % 4 == 0:
+            _chk(L.nbp_rowscale_backward_f32(dy.data_ptr(), ld, _lib.ptr(x), _lib.ptr(s), M, C, _lib.ptr(dx), _lib.ptr(ds), _st()), "rowscale_bwd")
+        else:
+            dy = dy.contiguous()
+            _chk(L.nbp_rowscale_f32(_lib.ptr(dy), _lib.ptr(s), M, C, _lib.ptr(dx), _st()), "rowscale")
+            _chk(L.nbp_rowdot_f32(_lib.ptr(dy), _lib.ptr(x), 0, M, C, _lib.ptr(ds), _st()), "rowdot")
         return dx, ds.view(s.shape)
 
 

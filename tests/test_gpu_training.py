@@ -198,6 +198,27 @@ def test_small_functions(hip):
     _close(p2d.grad, p2r.grad, what="bce grad")
 
 
+def test_rowscale_backward_reads_a_channel_slice_in_place(hip):
+    """RowScaleFn.backward on a channel-slice VIEW of a wider gradient (what ConvFn.backward returns for the first source of a
+    two-source convolution): one pass, row stride = the joint width -- the same dx / ds as on a contiguous copy of the slice,
+    and as torch's autograd."""
+    x, s = _rand(2, 6, 4, 64, seed=21), torch.sigmoid(_rand(2, 6, 4, 1, seed=22))
+    joint = _rand(2, 6, 4, 192, seed=23).to(D)
+    for lo in (0, 64, 128):
+        gview = joint[..., lo:lo + 64]
+        assert not gview.is_contiguous()
+        xr, sr = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        (xr * sr).backward(gview.cpu())
+        got = []
+        for g in (gview, gview.contiguous()):
+            xd, sd = x.to(D).requires_grad_(True), s.to(D).requires_grad_(True)
+            tr.RowScaleFn.apply(xd, sd).backward(g)
+            got.append((xd.grad, sd.grad))
+        assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+        _close(got[0][0], xr.grad, what="rowscale dx")
+        _close(got[0][1], sr.grad, what="rowscale ds")
+
+
 def _ref_step(sd, x, coords, gains, gt2):
     sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
           for k, v in sd.items()}
