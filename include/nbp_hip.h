@@ -173,6 +173,25 @@ int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, 
                           const void* w_planes, const void* wamax, int N, const float* scale, const float* shift, int relu,
                           float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws,
                           size_t ws_bytes, void* stream);
+/* Training: the same convolution (and its up_conv form), whose epilogue also leaves the column sums of the output and of its
+ * squares for the BatchNorm behind it (nextbestpath_amd/networks/training.py: ConvFn -> BNFn; the reference's nn.Sequential of
+ * Conv2d + BatchNorm2d, nbp_model.py:14-33): bn_part receives *bn_rows rows of [2][N] doubles -- at most
+ * nbp_conv_bn_part_rows(B, H, W) rows -- finalised by nbp_bn_train_forward_part_f32 without another pass over the tensor.
+ * *bn_rows = 0: this launch did not take them (split-K or half-height tiles); the caller's BatchNorm reads the tensor itself. */
+int nbp_conv_bn_part_rows(int B, int H, int W);
+int nbp_conv3x3_split_bn_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
+                             const void* w_planes, const void* wamax, int N, const float* scale, const float* shift, int relu,
+                             float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws,
+                             size_t ws_bytes, double* bn_part, int* bn_rows, void* stream);
+int nbp_upconv3x3_split_bn_f32(const float* src, int C, int B, int H, int W, const void* planes_up, const void* wamax_up, int N,
+                               const float* scale, const float* shift, int relu, float* out, const void* amax_in_or_null,
+                               void* amax_out_or_null, int split_k, void* ws, size_t ws_bytes, double* bn_part, int* bn_rows,
+                               void* stream);
+/* BatchNorm2d training forward from those partial sums (zero_row = C zeros): finalize + normalise, x is read once */
+int nbp_bn_train_forward_part_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
+                                  float momentum, float* running_mean, float* running_var, int relu, float* mean, float* invstd,
+                                  float* y, void* amax_out, double* stat_out, const double* part, int rows, const float* zero_row,
+                                  void* stream);
 /* Single bf16 layer: as nbp_conv_igemm_f32 with bf16 (uint16 storage) NHWC sources / output, C0, C1 multiples
  * of 64, w_packed from nbp_pack_conv_weight_bf16 ([(c_off+c)/64][tap][N][64] bf16), fp32 scale / shift. */
 int nbp_conv_igemm_bf16(const unsigned short* src0, int C0, const unsigned short* src1, int C1, int ups,

@@ -75,7 +75,7 @@ struct ConvHead { const float* w; const float* scale; const float* shift; float*
 int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C0, int C1, int ups, int B, int H, int W,
                             int ksize, int N, int relu, int split_k, void* ws, size_t ws_bytes, hipStream_t st,
                             float* const* pool_out = nullptr, int* pooled = nullptr, const struct ConvHead* head = nullptr,
-                            int* headed = nullptr);
+                            int* headed = nullptr, double* bn_part = nullptr, int* bn_rows = nullptr);
 int nbp_pack_conv_weight_split_launch(const float* w_oihw, int N, int C, int ksize, const float* scale_or_null, int c_off,
                                       int c_total, void* dst, unsigned* wamax_out, hipStream_t st);
 int nbp_amax_launch(const float* x, long long n, unsigned* amax_inout, hipStream_t st);

@@ -95,6 +95,10 @@ struct SplitOps {
     // not null (N == 64 == the tile's columns): the layer feeds only the one-channel sigmoid head (Final2, nbp_model.py:108,
     // :158-159): head_out[m] = sigmoid((out[m, :] . head_w) * head_ss[0] + head_ss[1]) is written INSTEAD of out
     const float* head_w; const float* head_ss[2]; float* head_out;
+    // not null (training, kernels instantiated with BS): every workgroup writes the column sums of the values it stores and of
+    // their squares, in double, as row (pixel tile [x 4 + parity]) of bn_part[rows][2][N] -- the BatchNorm behind the
+    // convolution finalises these instead of reading the tensor once more (nbp_train.hip: colsum_pair)
+    double* bn_part;
 };
 struct SplitArgs {
     SplitOps g[2];              // blockIdx.z >= split_k: the second problem of a grouped launch
@@ -131,7 +135,7 @@ __device__ unsigned nbp_dbg_n;
 #else
 #define NBP_TS(tag) do {} while (0)
 #endif
-template <int TW, int TM, int TN, bool PH>
+template <int TW, int TM, int TN, bool PH, bool BS = false>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_h2_kernel(SplitArgs a) {
     int zs = blockIdx.z;
     const int py = PH ? (zs >> 1) & 1 : 0, px = PH ? zs & 1 : 0;
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             tile = idx * g + xcd % g;
         }
     }
+    const unsigned tile_lin = tile;                           // (BS: the row of the workgroup's BatchNorm partials)
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y;
     const int b = tile / tiles_y;
@@ -338,6 +343,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     float mx = 0.f;
     constexpr bool HEADABLE = !PH && TN == 2;              // 64 columns = all channels of the head's input in one wave
     const bool head = HEADABLE && final_out && o.head_out;
+    const bool bn_stats = BS && final_out && o.bn_part;
+    double* const bsh = reinterpret_cast<double*>(ldsb);       // [wave][BN columns][sum | sum of squares]: the stage buffers are dead
+    if constexpr (BS) { if (bn_stats) __syncthreads(); }       // (every wave has left the last stage's LDS reads)
     float hp[HEADABLE ? TM : 1][16];
     if constexpr (HEADABLE) {
 #pragma unroll
@@ -366,6 +374,18 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 if (!head) outp[(mrow + poff) * a.N + n] = v;
                 vals[i][r] = v;
                 if constexpr (HEADABLE) hp[i][r] = fmaf(v, hw, hp[i][r]);
+            }
+        }
+        if constexpr (BS) {
+            if (bn_stats) {
+                // this lane's column over its TM x 16 pixels, the other half wave's pixels by one exchange, in double
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const double d = (double)vals[i][r]; s1 += d; s2 = fma(d, d, s2); }
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (lane < 32) { bsh[(wave * BN + j * 32 + lane) * 2] = s1; bsh[(wave * BN + j * 32 + lane) * 2 + 1] = s2; }
             }
         }
         // 2x2 max-pool of the same values: the four pixels of a window are registers of ONE lane (a wave's row blocks are
@@ -425,6 +445,19 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 const int pb = (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 const long long mrow = ((long long)b * a.H + y0 + (TM * wave + i) * RPB) * a.W + x0;
                 if (!(lane & 1)) o.head_out[mrow + (pb / TW) * a.W + (pb % TW)] = 1.f / (1.f + expf(-(dot * hs + ht)));
+            }
+        }
+    }
+    if constexpr (BS) {
+        if (bn_stats) {
+            __syncthreads();
+            if (tid < BN) {                                    // the four waves' pixel rows in a fixed order
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { s1 += bsh[(w * BN + tid) * 2]; s2 += bsh[(w * BN + tid) * 2 + 1]; }
+                const long long row = PH ? (long long)tile_lin * 4 + (py * 2 + px) : (long long)tile_lin;
+                o.bn_part[(row * 2) * a.N + n0 + tid] = s1;
+                o.bn_part[(row * 2 + 1) * a.N + n0 + tid] = s2;
             }
         }
     }
@@ -947,21 +980,21 @@ int split_tile_width(int H, int W, int N, int ksize) {
     return 0;
 }
 
-template <int TW, int TM, int TN, bool PH>
+template <int TW, int TM, int TN, bool PH, bool BS = false>
 int launch_h2(const SplitArgs& a, hipStream_t st) {
     constexpr int TH = 4 * TM * (32 / TW);
     constexpr int HPIX = (TH + 2) * (TW + 2), RS = (HPIX + 7) / 8 * 8 * 16 + 64, NB = TN / 2;
     constexpr size_t smem = 4 * (size_t)RS + 2 * (size_t)(PH ? 8 : 12) * NB * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_h2_kernel<TW, TM, TN, PH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     // PH: tiles of the low-resolution image, four parities in blockIdx.z (fastest)
     dim3 grid((unsigned)(a.M / (PH ? 4 : 1) / (TH * TW)), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups * (PH ? 4 : 1)));
-    conv3x3_halo_h2_kernel<TW, TM, TN, PH><<<grid, 256, smem, st>>>(a);
+    conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 
@@ -1086,8 +1119,9 @@ int nbp_amax_launch(const float* x, long long n, unsigned* amax_inout, hipStream
 // Returns NBP_E_SHAPE for layers the kernel does not take.
 int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C0, int C1, int ups, int B, int H, int W,
                             int ksize, int N, int relu, int split_k, void* ws, size_t ws_bytes, hipStream_t st,
-                            float* const* pool_out, int* pooled, const ConvHead* head, int* headed) {
+                            float* const* pool_out, int* pooled, const ConvHead* head, int* headed, double* bn_part, int* bn_rows) {
     const int groups = o2 ? 2 : 1;
+    if (bn_rows) *bn_rows = 0;
     NBP_RETURN_IF(!o.src0 || !o.planes || !o.scale || !o.shift || !o.out || !o.amax0 || !o.wamax, NBP_E_ARG);
     NBP_RETURN_IF(o2 && (!o2->src0 || !o2->planes || !o2->scale || !o2->shift || !o2->out || !o2->amax0 || !o2->wamax), NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 1 || W < 1 || ksize != 3, NBP_E_ARG);
@@ -1097,7 +1131,7 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     SplitArgs a;
     for (int g = 0; g < 2; ++g) {
         const ConvOperandsSplit& s = (g && o2) ? *o2 : o;
-        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, C1 ? s.amax1 : nullptr, s.wamax, s.amax_out, nullptr, nullptr, {nullptr, nullptr}, nullptr};
+        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, C1 ? s.amax1 : nullptr, s.wamax, s.amax_out, nullptr, nullptr, {nullptr, nullptr}, nullptr, nullptr};
     }
     a.C0 = C0; a.C1 = C1; a.ups = ups ? 1 : 0;
     a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W;
@@ -1160,6 +1194,13 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
                            !ph && tw == 32 && N == 64 && relu;
     if (headed) *headed = with_head;
     if (with_head) { a.g[0].head_w = head->w; a.g[0].head_ss[0] = head->scale; a.g[0].head_ss[1] = head->shift; a.g[0].head_out = head->out; }
+    // training: the BatchNorm partials ride in the epilogue of the full-height tiles when the launch writes final values
+    if (bn_part && bn_rows && p.split_k == 1 && !r8 && groups == 1) {
+        a.g[0].bn_part = bn_part;
+        *bn_rows = (int)(a.M / (16 * tw));               // pixel tiles (x 4 parities for the up_conv form: the same count)
+        return ph ? (tw == 32 ? launch_h2<32, 4, 2, true, true>(a, st) : launch_h2<16, 2, 4, true, true>(a, st))
+                  : (tw == 32 ? launch_h2<32, 4, 2, false, true>(a, st) : launch_h2<16, 2, 4, false, true>(a, st));
+    }
     int rc = r8 ? (ph ? (tw == 32 ? launch_h2<32, 2, 2, true>(a, st) : launch_h2<16, 1, 4, true>(a, st))
                       : (tw == 32 ? launch_h2<32, 2, 2, false>(a, st) : launch_h2<16, 1, 4, false>(a, st)))
            : ph ? (tw == 32 ? launch_h2<32, 4, 2, true>(a, st) : launch_h2<16, 2, 4, true>(a, st))
@@ -1324,11 +1365,10 @@ extern "C" size_t nbp_conv_split_planned_workspace_bytes(int B, int H, int W, in
     return 256 + (size_t)sk * B * H * W * N * sizeof(float);
 }
 
-extern "C" int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
-                                     const void* w_planes, const void* wamax, int N, const float* scale, const float* shift,
-                                     int relu, float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k,
-                                     void* ws, size_t ws_bytes, void* stream) {
-    NBP_ENTER();
+static int conv3x3_split_impl(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
+                              const void* w_planes, const void* wamax, int N, const float* scale, const float* shift,
+                              int relu, float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k,
+                              void* ws, size_t ws_bytes, void* stream, double* bn_part, int* bn_rows) {
     NBP_RETURN_IF(!ws || ws_bytes < 256 || !src0, NBP_E_WS);
     hipStream_t st = (hipStream_t)stream;
     const unsigned* amax = (const unsigned*)amax_in_or_null;
@@ -1344,7 +1384,29 @@ extern "C" int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src
     }
     ConvOperandsSplit o{src0, src1, w_planes, scale, shift, out, amax, amax, (const unsigned*)wamax, (unsigned*)amax_out_or_null,
                         nullptr, nullptr};
-    return nbp_conv_split_launch_g(o, nullptr, C0, C1, ups, B, H, W, 3, N, relu, split_k, (char*)ws + 256, ws_bytes - 256, st);
+    return nbp_conv_split_launch_g(o, nullptr, C0, C1, ups, B, H, W, 3, N, relu, split_k, (char*)ws + 256, ws_bytes - 256, st, nullptr,
+                                   nullptr, nullptr, nullptr, bn_part, bn_rows);
+}
+extern "C" int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
+                                     const void* w_planes, const void* wamax, int N, const float* scale, const float* shift,
+                                     int relu, float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
+    return conv3x3_split_impl(src0, C0, src1, C1, ups, B, H, W, w_planes, wamax, N, scale, shift, relu, out, amax_in_or_null,
+                              amax_out_or_null, split_k, ws, ws_bytes, stream, nullptr, nullptr);
+}
+// The same, and the column sums of the output and of its squares for the BatchNorm that follows (training): bn_part receives
+// *bn_rows rows of [2][N] doubles (at most nbp_conv_bn_part_rows(B, H, W) of them); *bn_rows = 0 when this launch did not take them
+// (split-K or half-height tiles: the caller's BatchNorm then reads the tensor itself).
+extern "C" int nbp_conv_bn_part_rows(int B, int H, int W) { return (int)((long long)B * H * W / 256); }
+extern "C" int nbp_conv3x3_split_bn_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
+                                        const void* w_planes, const void* wamax, int N, const float* scale, const float* shift,
+                                        int relu, float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k,
+                                        void* ws, size_t ws_bytes, double* bn_part, int* bn_rows, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!bn_part || !bn_rows || ((uintptr_t)bn_part & 7), NBP_E_ARG);
+    return conv3x3_split_impl(src0, C0, src1, C1, ups, B, H, W, w_planes, wamax, N, scale, shift, relu, out, amax_in_or_null,
+                              amax_out_or_null, split_k, ws, ws_bytes, stream, bn_part, bn_rows);
 }
 
 extern "C" int nbp_pack_upconv_weight_split(const float* w_oihw, int N, int C, void* dst_planes, void* wamax_out, void* stream) {
@@ -1352,11 +1414,10 @@ extern "C" int nbp_pack_upconv_weight_split(const float* w_oihw, int N, int C, v
     return nbp_pack_upconv_weight_split_launch(w_oihw, N, C, dst_planes, (unsigned*)wamax_out, (hipStream_t)stream);
 }
 
-extern "C" int nbp_upconv3x3_split_f32(const float* src, int C, int B, int H, int W, const void* planes_up, const void* wamax_up,
-                                       int N, const float* scale, const float* shift, int relu, float* out,
-                                       const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws, size_t ws_bytes,
-                                       void* stream) {
-    NBP_ENTER();
+static int upconv3x3_split_impl(const float* src, int C, int B, int H, int W, const void* planes_up, const void* wamax_up,
+                                int N, const float* scale, const float* shift, int relu, float* out,
+                                const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws, size_t ws_bytes,
+                                void* stream, double* bn_part, int* bn_rows) {
     NBP_RETURN_IF(!ws || ws_bytes < 256 || !src || !planes_up || !wamax_up, NBP_E_WS);
     NBP_RETURN_IF((H | W) & 1, NBP_E_SHAPE);
     hipStream_t st = (hipStream_t)stream;
@@ -1376,5 +1437,23 @@ extern "C" int nbp_upconv3x3_split_f32(const float* src, int C, int B, int H, in
     }
     ConvOperandsSplit o{src, nullptr, planes_up, scale, shift, out, amax, amax, (const unsigned*)wamax_up, (unsigned*)amax_out_or_null,
                         planes_up, (const unsigned*)wamax_up};
-    return nbp_conv_split_launch_g(o, nullptr, C, 0, 1, B, H, W, 3, N, relu, split_k, (char*)ws + 256, ws_bytes - 256, st);
+    return nbp_conv_split_launch_g(o, nullptr, C, 0, 1, B, H, W, 3, N, relu, split_k, (char*)ws + 256, ws_bytes - 256, st, nullptr, nullptr,
+                                   nullptr, nullptr, bn_part, bn_rows);
+}
+extern "C" int nbp_upconv3x3_split_f32(const float* src, int C, int B, int H, int W, const void* planes_up, const void* wamax_up,
+                                       int N, const float* scale, const float* shift, int relu, float* out,
+                                       const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    NBP_ENTER();
+    return upconv3x3_split_impl(src, C, B, H, W, planes_up, wamax_up, N, scale, shift, relu, out, amax_in_or_null, amax_out_or_null, split_k,
+                                ws, ws_bytes, stream, nullptr, nullptr);
+}
+extern "C" int nbp_upconv3x3_split_bn_f32(const float* src, int C, int B, int H, int W, const void* planes_up, const void* wamax_up,
+                                          int N, const float* scale, const float* shift, int relu, float* out,
+                                          const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws, size_t ws_bytes,
+                                          double* bn_part, int* bn_rows, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!bn_part || !bn_rows || ((uintptr_t)bn_part & 7), NBP_E_ARG);
+    return upconv3x3_split_impl(src, C, B, H, W, planes_up, wamax_up, N, scale, shift, relu, out, amax_in_or_null, amax_out_or_null, split_k,
+                                ws, ws_bytes, stream, bn_part, bn_rows);
 }

@@ -138,27 +138,30 @@ __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict
     }
 }
 
-// Column sums of the per-block partials part[k][2][C]: a 256-thread block owns 32 channels; thread (c, ks) adds the
-// rows k = ks, ks + 8, ... in double (fixed order), the 8 slices meet in LDS in a fixed order: deterministic, and
-// nblk / 8 dependent loads per thread instead of nblk.
-__device__ __forceinline__ void colsum_pair(const double* __restrict__ part, int nblk, int C, int c, int ks, double (*sh)[2][32],
+// Column sums of the per-block partials part[k][2][C]: a 256-thread block owns FIN_CH = 8 channels; thread (c, ks) adds the
+// rows k = ks, ks + 32, ... in double (fixed order, four loads in flight), the 32 slices meet in LDS in a fixed order:
+// deterministic, and nblk / 32 dependent loads per thread.  (Round 3 had 32 channels x 8 slices: with 64 channels that was a
+// grid of TWO workgroups walking 128-long chains -- 14 us per finalize, ~150 of them per training step.)
+constexpr int FIN_CH = 8, FIN_SL = 256 / FIN_CH;
+__device__ __forceinline__ void colsum_pair(const double* __restrict__ part, int nblk, int C, int c, int ks, double (*sh)[2][FIN_CH],
                                             double* s0_out, double* s1_out) {
     double s0 = 0, s1 = 0;
     if (c < C) {
         int k = ks;
-        for (; k + 24 < nblk; k += 32) {          // four rows in flight, added in the same order as one at a time
+        for (; k + 3 * FIN_SL < nblk; k += 4 * FIN_SL) {          // four rows in flight, added in the same order as one at a time
             double a[4], b[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = part[((long long)(k + 8 * u) * 2) * C + c]; b[u] = part[((long long)(k + 8 * u) * 2 + 1) * C + c]; }
+            for (int u = 0; u < 4; ++u) { a[u] = part[((long long)(k + FIN_SL * u) * 2) * C + c]; b[u] = part[((long long)(k + FIN_SL * u) * 2 + 1) * C + c]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { s0 += a[u]; s1 += b[u]; }
         }
-        for (; k < nblk; k += 8) { s0 += part[((long long)k * 2) * C + c]; s1 += part[((long long)k * 2 + 1) * C + c]; }
+        for (; k < nblk; k += FIN_SL) { s0 += part[((long long)k * 2) * C + c]; s1 += part[((long long)k * 2 + 1) * C + c]; }
     }
-    sh[ks][0][threadIdx.x & 31] = s0; sh[ks][1][threadIdx.x & 31] = s1;
+    sh[ks][0][threadIdx.x % FIN_CH] = s0; sh[ks][1][threadIdx.x % FIN_CH] = s1;
     __syncthreads();
     s0 = 0; s1 = 0;
-    for (int q = 0; q < 8; ++q) { s0 += sh[q][0][threadIdx.x & 31]; s1 += sh[q][1][threadIdx.x & 31]; }
+    if (ks == 0)
+        for (int q = 0; q < FIN_SL; ++q) { s0 += sh[q][0][threadIdx.x % FIN_CH]; s1 += sh[q][1][threadIdx.x % FIN_CH]; }
     *s0_out = s0; *s1_out = s1;
 }
 
@@ -170,8 +173,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
                                                           double* __restrict__ stat_d) {
-    __shared__ double sh[8][2][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), ks = threadIdx.x >> 5;
+    __shared__ double sh[FIN_SL][2][FIN_CH];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, ks = threadIdx.x / FIN_CH;
     double s0, s1;
     colsum_pair(part, nblk, C, c, ks, sh, &s0, &s1);
     if (c >= C || ks != 0) return;
@@ -193,8 +196,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ part, int nblk, int C,
                                                               float* __restrict__ out0, float* __restrict__ out1,
                                                               double* __restrict__ out_d = nullptr) {
-    __shared__ double sh[8][2][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), ks = threadIdx.x >> 5;
+    __shared__ double sh[FIN_SL][2][FIN_CH];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, ks = threadIdx.x / FIN_CH;
     double s0, s1;
     colsum_pair(part, nblk, C, c, ks, sh, &s0, &s1);
     if (c >= C || ks != 0) return;
@@ -992,7 +995,8 @@ extern "C" size_t nbp_colreduce_workspace_bytes(long long M, int C) {
 // nbp_bn_train_backward_stat_f32, which rebuilds the ReLU mask from x with them instead of reading y
 static int bn_forward_impl(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
                            float momentum, float* running_mean, float* running_var, int relu, float* mean,
-                           float* invstd, float* y, void* amax_out_v, double* stat_out, void* ws, size_t ws_bytes, void* stream);
+                           float* invstd, float* y, void* amax_out_v, double* stat_out, void* ws, size_t ws_bytes, void* stream,
+                           const double* ext_part = nullptr, int ext_rows = 0, const float* zero_row = nullptr);
 extern "C" int nbp_bn_train_forward_amax_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
                                              float momentum, float* running_mean, float* running_var, int relu, float* mean,
                                              float* invstd, float* y, void* amax_out_v, void* ws, size_t ws_bytes, void* stream) {
@@ -1011,25 +1015,44 @@ extern "C" int nbp_bn_train_forward_stat_f32(const float* x, long long M, int C,
 }
 static int bn_forward_impl(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
                            float momentum, float* running_mean, float* running_var, int relu, float* mean,
-                           float* invstd, float* y, void* amax_out_v, double* stat_out, void* ws, size_t ws_bytes, void* stream) {
+                           float* invstd, float* y, void* amax_out_v, double* stat_out, void* ws, size_t ws_bytes, void* stream,
+                           const double* ext_part, int ext_rows, const float* zero_row) {
     unsigned* amax_out = (unsigned*)amax_out_v;
-    NBP_RETURN_IF(!x || !gamma || !beta || !mean || !invstd || !y || !ws || M < 1 || C < 1, NBP_E_ARG);
-    NBP_RETURN_IF(ws_bytes < nbp_colreduce_workspace_bytes(M, C), NBP_E_WS);
+    NBP_RETURN_IF(!x || !gamma || !beta || !mean || !invstd || !y || M < 1 || C < 1, NBP_E_ARG);
     hipStream_t st = (hipStream_t)stream;
-    long long rpb;
-    const int nblk = blocks_for_rows(M, &rpb);
-    double* part = (double*)(((uintptr_t)ws + 255) / 256 * 256);
-    if (C % 4 == 0) colreduce4_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C / 4, 0, rpb, part);
-    else colreduce_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, rpb, part);
-    int rc = nbp_launch_status();
-    if (rc) return rc;
-    double* stat_d = stat_out ? stat_out : part + (((size_t)nblk * 2 * C + 31) / 32 * 32);        // [2][C] unrounded mean, invstd (32-B aligned)
-    bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(x, part, nblk, C, M, eps, momentum, mean, invstd, running_mean,
-                                                                  running_var, stat_d);
+    int rc = 0, nblk = ext_rows;
+    const double* part = ext_part;
+    double* stat_d = stat_out;
+    if (!ext_part) {
+        NBP_RETURN_IF(!ws || ws_bytes < nbp_colreduce_workspace_bytes(M, C), NBP_E_WS);
+        long long rpb;
+        nblk = blocks_for_rows(M, &rpb);
+        double* p = (double*)(((uintptr_t)ws + 255) / 256 * 256);
+        if (C % 4 == 0) colreduce4_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C / 4, 0, rpb, p);
+        else colreduce_kernel<0><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, rpb, p);
+        if ((rc = nbp_launch_status())) return rc;
+        part = p;
+        if (!stat_d) stat_d = p + (((size_t)nblk * 2 * C + 31) / 32 * 32);        // [2][C] unrounded mean, invstd (32-B aligned)
+    }
+    // (external partials -- the producing convolution's epilogue -- are sums of x and x^2 themselves: the shift row is zeros)
+    bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, FIN_CH), 256, 0, st>>>(ext_part ? zero_row : x, part, nblk, C, M, eps, momentum, mean, invstd,
+                                                                      running_mean, running_var, stat_d);
     if ((rc = nbp_launch_status())) return rc;
     if (C % 4 == 0) bn_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(x, M * C / 4, C / 4, stat_d, gamma, beta, relu, y, amax_out);
     else bn_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(x, M * C, C, stat_d, gamma, beta, relu, y);
     return nbp_launch_status();
+}
+
+// ... with the statistics' partial sums already written by the convolution that produced x (nbp_conv3x3_split_bn_f32 /
+// nbp_upconv3x3_split_bn_f32: rows x [2][C] doubles of sum x, sum x^2): finalize + apply only, x is read once.  zero_row = C zeros.
+extern "C" int nbp_bn_train_forward_part_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
+                                             float momentum, float* running_mean, float* running_var, int relu, float* mean,
+                                             float* invstd, float* y, void* amax_out_v, double* stat_out, const double* part, int rows,
+                                             const float* zero_row, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!stat_out || ((uintptr_t)stat_out & 31) || !part || rows < 1 || !zero_row, NBP_E_ARG);
+    return bn_forward_impl(x, M, C, gamma, beta, eps, momentum, running_mean, running_var, relu, mean, invstd, y, amax_out_v, stat_out,
+                           nullptr, 0, stream, part, rows, zero_row);
 }
 
 extern "C" int nbp_bn_train_forward_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
@@ -1088,7 +1111,7 @@ static int bn_backward_impl(const float* dy, const float* x, const float* y_or_n
     int rc = nbp_launch_status();
     if (rc) return rc;
     double* sums = part + (((size_t)nblk * 2 * C + 31) / 32 * 32);          // [2][C] unrounded dbeta, dgamma (32-B aligned)
-    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, dbeta, dgamma, sums);
+    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, FIN_CH), 256, 0, st>>>(part, nblk, C, dbeta, dgamma, sums);
     if ((rc = nbp_launch_status())) return rc;
     if (C % 4 == 0 && (dx_colsum || amax_out)) {
         // dx, its column sums and its max |.| in ONE pass (the partials reuse `part`: the finalizer above has consumed it)
@@ -1096,7 +1119,7 @@ static int bn_backward_impl(const float* dy, const float* x, const float* y_or_n
                                                             amax_out, ms);
         if ((rc = nbp_launch_status())) return rc;
         if (dx_colsum) {
-            colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, dx_colsum, nullptr);
+            colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, FIN_CH), 256, 0, st>>>(part, nblk, C, dx_colsum, nullptr);
             rc = nbp_launch_status();
         }
         return rc;
@@ -1124,7 +1147,7 @@ extern "C" int nbp_colsum_f32(const float* x, const float* rows_or_null, long lo
     else colreduce_kernel<2><<<nblk, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, rows_or_null, M, C, 0, rpb, part);
     int rc = nbp_launch_status();
     if (rc) return rc;
-    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, 32), 256, 0, st>>>(part, nblk, C, out, nullptr);
+    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, FIN_CH), 256, 0, st>>>(part, nblk, C, out, nullptr);
     return nbp_launch_status();
 }
 

@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import os
 
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -121,6 +123,7 @@ def _const(value, n, device):
 # dicts by data_ptr()).  A consumer that gets a tensor without a note (autograd summed two gradients, a slice, a copy) takes its
 # own pass.  NBP_TRAIN_FUSE=0 switches the hand-off off altogether.
 _FUSE = _lib.tune("NBP_TRAIN_FUSE", "1") == "1"
+_BN_EPILOGUE = _lib.tune("NBP_TRAIN_BN_EPILOGUE", "1") == "1"      # BatchNorm statistics from the producing convolution's epilogue (0 = its own pass)
 _SLICE_VIEWS = _lib.tune("NBP_TRAIN_SLICE_VIEWS", "1") == "1"      # two-source convolutions return channel-slice VIEWS of dx (0 = copies)
 _MASK_FROM_X = _lib.tune("NBP_TRAIN_MASK_FROM_X", "1") == "1"      # BatchNorm backward: ReLU mask rebuilt from x (0 = read y, as round 3)
 _ARENA = {}
@@ -180,7 +183,13 @@ def _amax_slot(*tensors):
     return slot
 
 
-def _conv_split(src0, src1, ups, packed, N, scale, shift, relu, amax=None):
+def _bn_part(out):
+    """Buffer for the BatchNorm partial sums a convolution's epilogue may leave beside its output [B, H, W, N] (rows x [2][N] doubles)."""
+    B, H, W, N = out.shape
+    return torch.empty(_lib.lib().nbp_conv_bn_part_rows(B, H, W) * 2 * N, dtype=torch.float64, device=out.device), ctypes.c_int(0)
+
+
+def _conv_split(src0, src1, ups, packed, N, scale, shift, relu, amax=None, bn=False):
     L = _lib.lib()
     planes, wamax = packed
     B, Hs, Ws, C0 = src0.shape
@@ -189,6 +198,14 @@ def _conv_split(src0, src1, ups, packed, N, scale, shift, relu, amax=None):
     out = torch.empty(B, H, W, N, dtype=torch.float32, device=src0.device)
     ws = _ws(L.nbp_conv_split_planned_workspace_bytes(B, H, W, C0 + C1, N, int(ups), None), src0.device)     # the slices the planner will use
     # max |x| of the inputs: the caller's slot, else taken inside the call (autograd hands tensors over without their history)
+    if bn:      # the BatchNorm behind this layer gets the column sums of the output from the epilogue (when the launch has them)
+        part, rows = _bn_part(out)
+        _chk(L.nbp_conv3x3_split_bn_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, _lib.ptr(planes), _lib.ptr(wamax), N,
+                                        _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), _lib.ptr(amax), None, 0, _lib.ptr(ws),
+                                        ws.numel(), _lib.ptr(part), ctypes.byref(rows), _st()), "conv3x3_split_bn")
+        if rows.value > 0:
+            _note(out, bnpart=(part, rows.value))
+        return out
     _chk(L.nbp_conv3x3_split_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, _lib.ptr(planes), _lib.ptr(wamax), N,
                                  _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), _lib.ptr(amax), None, 0, _lib.ptr(ws),
                                  ws.numel(), _st()), "conv3x3_split")
@@ -200,7 +217,7 @@ def _upconv_ok(Hs, Ws, N):
     return _SPLIT and Hs % 16 == 0 and ((Ws % 32 == 0 and N % 64 == 0) or (Ws % 16 == 0 and N % 128 == 0))
 
 
-def _upconv_split(src, w_oihw, n_pad, scale, shift, amax=None):
+def _upconv_split(src, w_oihw, n_pad, scale, shift, amax=None, bn=False):
     L = _lib.lib()
     N, C, _, _ = w_oihw.shape
     B, Hs, Ws, C0 = src.shape
@@ -214,6 +231,14 @@ def _upconv_split(src, w_oihw, n_pad, scale, shift, amax=None):
     H, W = 2 * Hs, 2 * Ws
     out = torch.empty(B, H, W, n_pad, dtype=torch.float32, device=src.device)
     ws = _ws(L.nbp_conv_split_planned_workspace_bytes(B, H, W, C0, n_pad, 1, None), src.device)
+    if bn:
+        part, rows = _bn_part(out)
+        _chk(L.nbp_upconv3x3_split_bn_f32(_lib.ptr(src), C0, B, H, W, _lib.ptr(planes), _lib.ptr(wamax), n_pad, _lib.ptr(scale),
+                                          _lib.ptr(shift), 0, _lib.ptr(out), _lib.ptr(amax), None, 0, _lib.ptr(ws), ws.numel(),
+                                          _lib.ptr(part), ctypes.byref(rows), _st()), "upconv3x3_split_bn")
+        if rows.value > 0:
+            _note(out, bnpart=(part, rows.value))
+        return out
     _chk(L.nbp_upconv3x3_split_f32(_lib.ptr(src), C0, B, H, W, _lib.ptr(planes), _lib.ptr(wamax), n_pad, _lib.ptr(scale),
                                    _lib.ptr(shift), 0, _lib.ptr(out), _lib.ptr(amax), None, 0, _lib.ptr(ws), ws.numel(), _st()), "upconv3x3_split")
     return out
@@ -224,7 +249,7 @@ class ConvFn(torch.autograd.Function):
     x0 / x1 channel counts are multiples of 64 (c_real < C0 only for the zero-padded network input)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, ups):
+    def forward(ctx, x0, x1, weight, bias, ups, bn_next=False):
         L = _lib.lib()
         N, c_real, k, _ = weight.shape
         C0 = x0.shape[3]
@@ -240,12 +265,15 @@ class ConvFn(torch.autograd.Function):
             shift[:N] = bias.detach()
         H, W = (x0.shape[1] * 2, x0.shape[2] * 2) if ups else (x0.shape[1], x0.shape[2])
         xmax = None                      # joint max-|.| slot of the inputs: taken once, reused by the weight gradient
+        # bn_next: a BatchNorm consumes this output -- its statistics' partial sums come out of the epilogue (not for padded
+        # channel counts, whose output is sliced; not under an observer, which may rewrite the output)
+        bn = bool(bn_next) and _BN_EPILOGUE and N == Np and _observer is None
         if ups and k == 3 and x1 is None and _upconv_ok(x0.shape[1], x0.shape[2], Np):
             xmax = _amax_slot(x0)
-            y = _upconv_split(x0, w, Np, scale, shift, xmax)
+            y = _upconv_split(x0, w, Np, scale, shift, xmax, bn)
         elif _split_ok(H, W, Np, k):
             xmax = _amax_slot(x0, x1)
-            y = _conv_split(x0, x1, ups, _pack_split(w, Np, Ctot), Np, scale, shift, False, xmax)
+            y = _conv_split(x0, x1, ups, _pack_split(w, Np, Ctot), Np, scale, shift, False, xmax, bn)
         else:
             wpk = torch.empty(Ctot // 32 * k * k * Np * 32, dtype=torch.float32, device=dev)
             _chk(L.nbp_pack_conv_weight_padded(_lib.ptr(w), N, c_real, k, Ctot, Np, _lib.ptr(wpk), _st()), "pack_fwd")
@@ -307,7 +335,7 @@ class ConvFn(torch.autograd.Function):
                 dx0, dx1 = _slice_channels(dx, 0, C0), _slice_channels(dx, C0, C1)
             else:
                 dx0 = dx
-        return dx0, dx1, dw, db, None
+        return dx0, dx1, dw, db, None, None
 
 
 class BNFn(torch.autograd.Function):
@@ -330,7 +358,13 @@ class BNFn(torch.autograd.Function):
         # the backward rebuilds the ReLU mask from x through the unrounded statistics (two tensor reads less per BatchNorm): not
         # when an observer may rewrite y after the fact (its mask is then y's, and y is what gets saved)
         stat = torch.empty(2 * C, dtype=torch.float64, device=dev) if (_MASK_FROM_X and relu and C % 4 == 0 and _observer is None) else None
-        if stat is not None:
+        part = _noted(x, "bnpart") if stat is not None else None
+        if part is not None:
+            _chk(L.nbp_bn_train_forward_part_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
+                                                 _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
+                                                 _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(slot), _lib.ptr(stat), _lib.ptr(part[0]), part[1],
+                                                 _lib.ptr(_const(0.0, C, dev)), _st()), "bn_fwd_part")
+        elif stat is not None:
             _chk(L.nbp_bn_train_forward_stat_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
                                                  _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
                                                  _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(slot), _lib.ptr(stat), _lib.ptr(ws), ws.numel(),
@@ -601,15 +635,15 @@ def _bn(mod, x, relu, name=None):
 
 def _block(seq, x0, x1=None, name=""):
     """conv_block (ref :8-21): (conv3x3 -> BN -> ReLU) x 2 on cat(x0, x1)."""
-    y = _t(name + ".conv.0", ConvFn.apply(x0, x1, seq[0].weight, seq[0].bias, False))
+    y = _t(name + ".conv.0", ConvFn.apply(x0, x1, seq[0].weight, seq[0].bias, False, True))
     y = _bn(seq[1], y, True, name + ".conv.1")
-    y = _t(name + ".conv.3", ConvFn.apply(y, None, seq[3].weight, seq[3].bias, False))
+    y = _t(name + ".conv.3", ConvFn.apply(y, None, seq[3].weight, seq[3].bias, False, True))
     return _bn(seq[4], y, True, name + ".conv.4")
 
 
 def _up_conv(seq, x, name=""):
     """up_conv (ref :23-34): nearest x2 -> conv3x3 -> BN -> ReLU (the upsample is fused in the conv gather)."""
-    y = _t(name + ".up.1", ConvFn.apply(x, None, seq[1].weight, seq[1].bias, True))
+    y = _t(name + ".up.1", ConvFn.apply(x, None, seq[1].weight, seq[1].bias, True, True))
     return _bn(seq[2], y, True, name + ".up.2")
 
 

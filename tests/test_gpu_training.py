@@ -119,6 +119,34 @@ def test_batchnorm_statistics_when_mean_dwarfs_std(hip, C):
     assert (y.cpu().double().reshape(-1, C) - yy).abs().max() < 2e-3   # x itself carries 4e-6 / 0.01 relative noise
 
 
+@pytest.mark.parametrize("ups,two", [(False, False), (True, False), (False, True)])
+def test_batchnorm_statistics_from_the_convolution_epilogue(hip, monkeypatch, ups, two):
+    """Conv -> BatchNorm(+ReLU) in training: the convolution's epilogue leaves per-workgroup column sums of its output and of
+    its squares (double), and the BatchNorm finalises those instead of reading the tensor for its statistics.  Same y, running
+    statistics and gradients as with the BatchNorm's own reduction pass (summation order differs: 1e-6), large mean included."""
+    B, Hs, C0, N = 2, (128 if ups else 256), 64, 64
+    x0 = _rand(B, Hs, Hs, C0, seed=1).to(D)
+    x1 = _rand(B, Hs, Hs, C0, seed=2).to(D) if two else None
+    w = (_rand(N, C0 * (2 if two else 1), 3, 3, seed=3) * 0.05).to(D)
+    bias = (_rand(N, seed=4) * 0.1 + 30.0).to(D)                       # |mean| >> std: the sums must not cancel
+    g, b = (_rand(N, seed=5) * 0.3 + 1).to(D), (_rand(N, seed=6) * 0.2).to(D)
+    gy = _rand(B, 2 * Hs if ups else Hs, 2 * Hs if ups else Hs, N, seed=7).to(D)
+    res = []
+    for epilogue in (True, False):
+        monkeypatch.setattr(tr, "_BN_EPILOGUE", epilogue)
+        tr._reset_arena(torch.device(D))
+        leaves = [t.clone().requires_grad_(True) for t in (x0, w, bias, g, b)]
+        rm, rv = torch.zeros(N, device=D), torch.ones(N, device=D)
+        yc = tr.ConvFn.apply(leaves[0], x1, leaves[1], leaves[2], ups, True)
+        took = "bnpart" in (getattr(yc, "_nbp_note", None) or {})
+        assert took == epilogue, "the epilogue form must be the one that runs (no split-K at this size)"
+        y = tr.BNFn.apply(yc, leaves[3], leaves[4], rm, rv, 1e-5, 0.1, True)
+        y.backward(gy)
+        res.append([y.detach(), rm, rv] + [t.grad for t in leaves])
+    for nm, a, c in zip(("y", "running_mean", "running_var", "dx", "dw", "dbias", "dgamma", "dbeta"), res[0], res[1]):
+        _close(a, c, rtol=2e-5, what=nm)
+
+
 def test_batchnorm_backward_mask_from_x_is_the_mask_from_y(hip, monkeypatch):
     """Round 4: the BatchNorm backward rebuilds the ReLU mask (y > 0) from x, which it reads anyway, through the forward's unrounded
     statistics, instead of reading y (nbp_bn_train_backward_stat_f32).  Same mask -> the same dx, dgamma, dbeta bit for bit as the
