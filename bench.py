@@ -792,6 +792,7 @@ def main():
             except Exception as e:                      # the headline must not depend on the training stage
                 stage["config3_train_step_b32"] = {"error": repr(e)[:200]}
         stage["replans_in_timed_region"] = replans_timed
+        stage["group_streams"] = multi.stream_check          # the lock-step's streams were verified to run side by side
         if single is not None:
             stage["single_rollout_steps_per_s"] = round(single, 2)
         stage["windows"] = windows

@@ -262,6 +262,41 @@ class Rollout:
         return [float(np.float32(c) / G) for c in counts[:, 0]]
 
 
+def _concurrent_streams(device, n, tries=24, cycles=300_000):
+    """n torch streams whose kernels the runtime really runs side by side, and how that was established.
+
+    HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) when they are first used, and two streams on one
+    queue run their kernels strictly one after the other -- the lock-step's two groups then stop overlapping.  Measured: after
+    ANY hipGraph capture in the process (the single-rollout path's ForwardGraph) the next two pool streams land on one queue and
+    the 48-rollout lock-step loses 6 % (profiles/r04/stream_queue_collision.txt).  So the streams are not taken on trust: a
+    candidate is kept only if a short spin kernel on it overlaps with one on every stream already chosen."""
+    def overlap(a, b):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        torch.cuda.synchronize(device)
+        with torch.cuda.stream(a):
+            ev[0].record()
+            torch.cuda._sleep(cycles)
+            ev[1].record()
+        with torch.cuda.stream(b):
+            torch.cuda._sleep(cycles)
+            ev[2].record()
+        torch.cuda.synchronize(device)
+        return ev[0].elapsed_time(ev[2]) < 1.5 * ev[0].elapsed_time(ev[1])
+
+    chosen, tested = [], 0
+    while len(chosen) < n and tested < tries:
+        st = torch.cuda.Stream(device)
+        tested += 1
+        with torch.cuda.stream(st):
+            torch.cuda._sleep(1)                   # first use: the stream gets its hardware queue here
+        if all(overlap(c, st) for c in chosen):
+            chosen.append(st)
+    ok = len(chosen) == n
+    while len(chosen) < n:                         # (never seen: fewer than n distinct queues among `tries` streams)
+        chosen.append(torch.cuda.Stream(device))
+    return chosen, {"streams_tested": tested, "concurrent": ok}
+
+
 class MultiRollout:
     """R independent rollouts (different scenes / start poses) on one GPU ("B_rollout
     concurrent rollouts per rank").  They are split in two groups that are software-pipelined: while the GPU
@@ -325,8 +360,9 @@ class MultiRollout:
         main = torch.cuda.current_stream(device)
         multi = streams and len(self.groups) >= 2
         k = int(_lib.tune("NBP_ROLLOUT_STREAMS", "0")) if multi else 0
+        self.stream_check = None
         if multi:
-            self.fwd_streams = [torch.cuda.Stream(device) for _ in self.groups]
+            self.fwd_streams, self.stream_check = _concurrent_streams(device, len(self.groups))
             self.side = [[torch.cuda.Stream(device) for _ in range(min(k, len(g)))] for g in self.groups]
             for st in self.fwd_streams + [x for g in self.side for x in g]:
                 st.wait_stream(main)          # the rollouts were built on the caller's stream

@@ -137,6 +137,37 @@ def test_dead_forward_elision_changes_nothing(hip, dataset, nbp_weights):
         assert na == int(b.st.cloud_count.item()) and torch.equal(a.st.cloud[:na], b.st.cloud[:na])
 
 
+def test_group_streams_run_side_by_side_even_after_a_graph_capture(hip, nbp_weights):
+    """The lock-step's groups overlap only if their streams sit on different hardware queues.  HIP assigns queues at first use;
+    after a hipGraph capture in the process (NBP.forward_static) two fresh pool streams were measured on ONE queue (6 % of the
+    48-rollout lock-step, profiles/r04/stream_queue_collision.txt).  _concurrent_streams keeps only streams that it has seen
+    overlap: checked here after a capture, for two and for three groups."""
+    from nextbestpath_amd.networks.nbp_model import NBP
+    from nextbestpath_amd.testers import nbp_planning as tp
+    from nextbestpath_amd.utility.synthetic import make_count_maps
+    dev = torch.device("cuda")
+    m = NBP()
+    m.load_state_dict(nbp_weights, strict=True)
+    m = m.cuda().eval()
+    x = make_count_maps(1, 64, seed=1).cuda()
+    with torch.no_grad():
+        m.forward_static(x)                                   # a capture: the condition under which the collision was seen
+    for n in (2, 3):
+        streams, check = tp._concurrent_streams(dev, n)
+        assert len(streams) == n and check["concurrent"] and check["streams_tested"] >= n
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        torch.cuda.synchronize()
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                if i == 0:
+                    ev[0].record()
+                torch.cuda._sleep(400_000)
+                ev[i + 1].record()
+        torch.cuda.synchronize()
+        one = ev[0].elapsed_time(ev[1])
+        assert max(ev[0].elapsed_time(e) for e in ev[1:]) < 1.6 * one, "the spin kernels ran one after the other"
+
+
 def test_four_streams_match_single_rollouts(hip, dataset, nbp_weights):
     """Four groups = four HIP streams stepping concurrently (scratch buffers are per stream): every rollout still walks
     exactly the trajectory it walks alone."""
