@@ -894,6 +894,64 @@ __global__ __launch_bounds__(256) void splitk_reduce_split_kernel(const float* _
     if (amax_out) block_amax(mx, amax_out);
 }
 
+// The same reduction for an encoder layer whose 2x2 max-pool follows (nbp_model.py:113-123): a thread owns the four pixels of a pool
+// window (four channels of each), adds their slices in slice order -- the sums above, bit for bit -- and writes the window's
+// maximum beside the four outputs.  Split-K launches (a single rollout: every encoder level below the first) lost the pool's
+// own launch this way; launches that write final values pool in the convolution's epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_pool_kernel(const float* __restrict__ partial, int split_k, unsigned MN, unsigned N,
+                                                                 int H, int W, SplitOps o, int relu) {
+    const unsigned N4 = N >> 2, Wp = (unsigned)W >> 1, Hp = (unsigned)H >> 1;
+    const unsigned total = (MN >> 4);                          // pool windows x float4 columns
+    const unsigned rowN = (unsigned)W * N;
+    float mx = 0.f;
+    for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < total; p += gridDim.x * 256u) {
+        const unsigned n4 = p % N4;
+        unsigned q = p / N4;
+        const unsigned xp = q % Wp; q /= Wp;
+        const unsigned yp = q % Hp, b = q / Hp;
+        const unsigned base = ((b * (unsigned)H + 2u * yp) * (unsigned)W + 2u * xp) * N + 4u * n4;
+        const unsigned idx[4] = {base, base + N, base + rowN, base + rowN + N};
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(partial + idx[k]);
+        for (int s0 = 1; s0 < split_k; s0 += 2) {              // two slices x four pixels in flight, added in slice order
+            f32x4 u[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bool in = s0 + t < split_k;
+                const float* ps = partial + (size_t)(s0 + t) * MN;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u[t][k] = in ? *reinterpret_cast<const f32x4*>(ps + idx[k]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (s0 + t < split_k) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[k][e] += u[t][k][e];
+                }
+        }
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(o.scale + 4u * n4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(o.shift + 4u * n4);
+        f32x4 pm;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float r = v[k][e] * sc[e] + sh[e];
+                if (relu) r = fmaxf(r, 0.f);
+                mx = fmaxf(mx, fabsf(r));
+                v[k][e] = r;
+                pm[e] = k ? fmaxf(pm[e], r) : r;
+            }
+            *reinterpret_cast<f32x4*>(o.out + idx[k]) = v[k];
+        }
+        *reinterpret_cast<f32x4*>(o.pool_out + 4u * p) = pm;
+    }
+    if (o.amax_out) block_amax(mx, o.amax_out);
+}
+
 // max |x| (float bits, atomicMax: the caller zeroes the slot); optional per-row scale for weights [N][per_row]
 // words = 64 (activation convention) or 1 (max |w| of a layer)
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long n, const float* __restrict__ row_scale,
@@ -1185,8 +1243,10 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     static const int allow_pool = nbp_tune_int("NBP_CONV_POOL", 1);
     const bool with_pool = allow_pool && pool_out && pool_out[0] && (groups == 1 || pool_out[1]) && p.split_k == 1 && !ph && !ups &&
                            !((H | W) & 1);
-    if (pooled) *pooled = with_pool;
-    if (with_pool)
+    // ... and in the split-K reduce otherwise (one problem per launch: the encoder's layers)
+    const bool pool_in_reduce = allow_pool && pool_out && pool_out[0] && groups == 1 && p.split_k > 1 && !ph && !ups && !((H | W) & 1);
+    if (pooled) *pooled = with_pool || pool_in_reduce;
+    if (with_pool || pool_in_reduce)
         for (int g = 0; g < groups; ++g) a.g[g].pool_out = pool_out[g];
     // the one-channel sigmoid head that consumes this layer alone (Final2) rides in the epilogue instead of the layer's own store
     static const int allow_head = nbp_tune_int("NBP_CONV_HEAD", 1);
@@ -1210,6 +1270,10 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
         const long long MN = a.M * N;
         NBP_RETURN_IF(MN >= (1ll << 31), NBP_E_SHAPE);
         dim3 grid((unsigned)min(nbp_cdiv(MN / 4, 256 * 4), 1024ll), (unsigned)groups);     // >= 4 float4s per thread
+        if (pool_in_reduce)
+            splitk_reduce_pool_kernel<<<(unsigned)min(nbp_cdiv(MN / 16, 256), 1024ll), 256, 0, st>>>((const float*)ws, p.split_k, (unsigned)MN,
+                                                                                                    (unsigned)N, H, W, a.g[0], relu);
+        else
         splitk_reduce_split_kernel<<<grid, 256, 0, st>>>((const float*)ws, p.split_k, (unsigned)MN, (unsigned)N, a.g[0], a.g[1], relu);
         rc = nbp_launch_status();
     }

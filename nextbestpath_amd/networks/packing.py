@@ -163,8 +163,9 @@ def forward_packed(packed: PackedWeights, x: torch.Tensor, precision: str = None
 class ForwardGraph:
     """The eval forward on FIXED buffers, captured once into a hipGraph and replayed.
 
-    The reference's own usage is one forward per exploration step on one map (nbp_planning.py:166): ~60 kernel launches of a
-    few microseconds each, where the launch-to-launch gaps are a fifth of the time.  A rollout's network input is a persistent
+    The reference's own usage is one forward per exploration step on one map (nbp_planning.py:166): ~100 kernel launches of a
+    few microseconds each, 0.8 ms of host enqueue time per forward against 0.03 ms for a replay (the GPU time is the same:
+    profiles/r04/fwd_graph_ab.txt) -- the single-rollout loop is host-bound without it.  A rollout's network input is a persistent
     tensor (RolloutState.net_in), so the whole launch sequence is replayable: same kernels, same arguments, same order -- the
     outputs are bit-identical to the eager call's (tests/test_gpu_network.py::test_forward_graph_is_bit_identical).
     `x` must stay alive and keep its address; `out1` / `out2` are overwritten by every replay (consume them on the replaying

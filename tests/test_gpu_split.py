@@ -259,7 +259,7 @@ from nextbestpath_amd.networks import packing
 from nextbestpath_amd.utility.synthetic import make_count_maps, make_explorer_state_dict
 dev = torch.device("cuda")
 packed = packing.pack_state_dict(make_explorer_state_dict(9), dev, precision="fp32_split")
-for B, S in ((8, 256), (3, 128), (1, 64)):
+for B, S in ((8, 256), (3, 128), (1, 64), (1, 256)):
     o1, o2 = packing.forward_packed(packed, make_count_maps(B, S, seed=B).to(dev))
     torch.save((o1.cpu(), o2.cpu()), f"{sys.argv[2]}_{B}_{S}.pt")
 """
@@ -269,7 +269,8 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
     """The encoder's max-pools and the one-channel sigmoid head ride in the producing convolution's epilogue and the attention
     gates' psi tail in the gate GEMM's (NBP_CONV_POOL / NBP_CONV_HEAD / NBP_GATE_PSI = 0 switch back to the separate kernels; NBP_SPLIT_R8_BLOCKS = 0
     keeps every launch on 16-row tiles; the switches are read once per process, hence
-    the subprocesses).  The pooled tensor is the max of the same four values: bit-identical outputs.  The fused psi sums
+    the subprocesses; a single map of 256 x 256 is the case whose encoder runs split-K, where the pool rides in the reduce kernel).
+    The pooled tensor is the max of the same four values: bit-identical outputs.  The fused psi sums
     q . w_psi in another order: equal to fp32 rounding of a 32..128-term dot product."""
     import subprocess
     import sys
@@ -287,7 +288,7 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
                                    "NBP_SPLIT_GATE": "0", "NBP_CONV_PRECISION": "fp32", "NBP_XCD_REMAP": "0"})):
         subprocess.run([sys.executable, str(script), root, str(tmp_path / tag)], check=True, env={**clean, **env},
                        timeout=600)
-        outs[tag] = {k: torch.load(tmp_path / f"{tag}_{k[0]}_{k[1]}.pt") for k in ((8, 256), (3, 128), (1, 64))}
+        outs[tag] = {k: torch.load(tmp_path / f"{tag}_{k[0]}_{k[1]}.pt") for k in ((8, 256), (3, 128), (1, 64), (1, 256))}
     for k, (o1, o2) in outs["both"].items():
         p1, p2 = outs["nopool"][k]
         assert torch.equal(o1, p1) and torch.equal(o2, p2), k
