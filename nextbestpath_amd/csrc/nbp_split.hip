@@ -135,11 +135,16 @@ __device__ unsigned nbp_dbg_n;
 #else
 #define NBP_TS(tag) do {} while (0)
 #endif
-template <int TW, int TM, int TN, bool PH, bool BS = false>
+// P2 (PH only): a workgroup owns BOTH column parities (px = 0, 1) of its row parity over a tile of half the height -- the same
+// accumulator count (2 x TM x TN), the same MFMAs per stage, but ONE staged halo serves two parities' tap products and the three
+// halo columns the four (px, tap) pairs touch are read from LDS three times instead of four: the staging work per MFMA of the
+// one-parity form was 2.3 x the plain kernel's (4 taps per staged chunk instead of 9), this form's is 1.25 x.
+template <int TW, int TM, int TN, bool PH, bool BS = false, bool P2 = false>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_h2_kernel(SplitArgs a) {
+    static_assert(!P2 || (PH && !BS), "two-parity form: up_conv layers, eval");
     int zs = blockIdx.z;
-    const int py = PH ? (zs >> 1) & 1 : 0, px = PH ? zs & 1 : 0;
-    if (PH) zs >>= 2;
+    const int py = PH ? (P2 ? zs & 1 : (zs >> 1) & 1) : 0, px = (PH && !P2) ? zs & 1 : 0;
+    if (PH) zs >>= (P2 ? 1 : 2);
     const int zslice = zs;                                     // partial-sum slice: group * split_k + split
     const SplitOps& o = zs >= a.split_k ? a.g[1] : a.g[0];
     if (zs >= a.split_k) zs -= a.split_k;
@@ -149,8 +154,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr int HW_ = TW + 2, HPIX = (TH + 2) * HW_;         // 18 x 34 = 612 / 18 x 18 = 324 halo pixels
     constexpr int RS = (HPIX + 7) / 8 * 8 * 16 + 64;           // bytes between (plane, k half) regions (+64: ds_write banks)
     constexpr int HALO_BYTES = 4 * RS;
-    constexpr int WI = TPR * 4 * NB;                           // weight DMA instructions (64 rows x 16 B) per stage
-    constexpr int WB = WI * 1024;
+    constexpr int WI = TPR * 4 * NB;                           // weight DMA instructions (64 rows x 16 B) per stage (and parity)
+    constexpr int NPAR = P2 ? 2 : 1;                           // column parities a workgroup computes
+    constexpr int WB1 = WI * 1024, WB = NPAR * WB1;
     constexpr int NF = (HPIX * 4 + 255) / 256;                 // float4 pieces of the halo tile per thread
     static_assert(BN % 64 == 0 && (TH == 16 || TH == 8), "tile shape");
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
@@ -253,24 +259,30 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int c = u / ROWS, row = u - ROWS * c;
         char* dst = wbuf + (u & 1) * WB;
         // PH: the four parities' planes follow each other, each [chunk][4 taps][plane][k half][N][8]
-        const long long pbase = PH ? (long long)(py * 2 + px) * a.chunks_total * TAPS * 4 * a.N : 0;
 #pragma unroll
-        for (int k = 0; k < WI / 4; ++k) {
-            const int q = wave + 4 * k;
-            const int tt = q / (4 * NB), r = q - tt * (4 * NB);
-            const int r4 = r / NB, nb = r - r4 * NB;
-            const unsigned woff = (unsigned)((pbase + (((long long)c * TAPS + row * TPR + tt) * 4 + r4) * a.N + n0 + nb * 64 + lane) * 16);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + q * 1024), 16, woff, 0, 0, 0);
+        for (int pq = 0; pq < NPAR; ++pq) {
+            const long long pbase = PH ? (long long)(py * 2 + (P2 ? pq : px)) * a.chunks_total * TAPS * 4 * a.N : 0;
+#pragma unroll
+            for (int k = 0; k < WI / 4; ++k) {
+                const int q = wave + 4 * k;
+                const int tt = q / (4 * NB), r = q - tt * (4 * NB);
+                const int r4 = r / NB, nb = r - r4 * NB;
+                const unsigned woff = (unsigned)((pbase + (((long long)c * TAPS + row * TPR + tt) * 4 + r4) * a.N + n0 + nb * 64 + lane) * 16);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + pq * WB1 + q * 1024), 16, woff, 0, 0, 0);
+            }
         }
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 accs[NPAR][TM][TN];
+    f32x16 (&acc)[TM][TN] = accs[0];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int pq = 0; pq < NPAR; ++pq)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[pq][i][j][r] = 0.f;
 
     const int khalf = lane >> 5;
     const int hbase = (TM * wave * RPB + ((lane & 31) / TW)) * HW_ + ((lane & 31) % TW);
@@ -296,6 +308,39 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             NBP_TS(1);
             if (row < ROWS - 1 || more) issue_w(u + 1);
             const char* Bt = wbuf + (u & 1) * WB + brow;
+            if constexpr (P2) {
+                // halo column 0: (px 0, tap 0); column 1: (px 0, tap 1) and (px 1, tap 0); column 2: (px 1, tap 1)
+                constexpr int PX[3] = {1, 0, 0};
+                constexpr int PW[3] = {0, 1, 0};
+#pragma unroll
+                for (int col = 0; col < 3; ++col) {
+                    u32x4 xp[TM][2];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+                            xp[i][p] = *reinterpret_cast<const u32x4*>(arow + p * (2 * RS) + ((row + py + i * RPB) * HW_ + col) * 16);
+#pragma unroll
+                    for (int pq = 0; pq < 2; ++pq) {
+                        const int tt = col - pq;
+                        if (tt < 0 || tt > 1) continue;
+                        u32x4 wp[TN][2];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int p = 0; p < 2; ++p)
+                                wp[j][p] = *reinterpret_cast<const u32x4*>(Bt + pq * WB1 + ((tt * 4 + p * 2) * NB + (j >> 1)) * 1024 + (j & 1) * 512);
+#pragma unroll
+                        for (int v = 0; v < 3; ++v)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                                for (int i = 0; i < TM; ++i)
+                                    accs[pq][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xp[i][PX[v]]),
+                                                                                            __builtin_bit_cast(f16x8, wp[j][PW[v]]), accs[pq][i][j], 0, 0, 0);
+                    }
+                }
+            } else
 #pragma unroll
             for (int tt = 0; tt < TPR; ++tt) {
                 u32x4 xp[TM][2], wp[TN][2];
@@ -354,7 +399,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int r = 0; r < 16; ++r) hp[i][r] = 0.f;
     }
 #pragma unroll
+    for (int pq = 0; pq < NPAR; ++pq)
+#pragma unroll
     for (int j = 0; j < TN; ++j) {
+        const int pxe = P2 ? pq : px;                          // the column parity these accumulators belong to
         const int n = n0 + j * 32 + (lane & 31);
         float sc = 1.f, sh = 0.f;
         if (final_out) { sc = o.scale[n]; sh = o.shift[n]; }
@@ -362,13 +410,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         float vals[TM][16];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const long long mrow = PH ? ((long long)b * a.H + 2 * (y0 + (TM * wave + i) * RPB) + py) * a.W + 2 * x0 + px
+            const long long mrow = PH ? ((long long)b * a.H + 2 * (y0 + (TM * wave + i) * RPB) + py) * a.W + 2 * x0 + pxe
                                       : ((long long)b * a.H + y0 + (TM * wave + i) * RPB) * a.W + x0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pb = (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 const int poff = PH ? 2 * ((pb / TW) * a.W + (pb % TW)) : (pb / TW) * a.W + (pb % TW);
-                float v = ldexpf(acc[i][j][r], einv) * sc + sh;
+                float v = ldexpf(accs[pq][i][j][r], einv) * sc + sh;
                 if (final_out && a.relu) v = fmaxf(v, 0.f);
                 mx = fmaxf(mx, fabsf(v));
                 if (!head) outp[(mrow + poff) * a.N + n] = v;
@@ -1038,21 +1086,21 @@ int split_tile_width(int H, int W, int N, int ksize) {
     return 0;
 }
 
-template <int TW, int TM, int TN, bool PH, bool BS = false>
+template <int TW, int TM, int TN, bool PH, bool BS = false, bool P2 = false>
 int launch_h2(const SplitArgs& a, hipStream_t st) {
     constexpr int TH = 4 * TM * (32 / TW);
     constexpr int HPIX = (TH + 2) * (TW + 2), RS = (HPIX + 7) / 8 * 8 * 16 + 64, NB = TN / 2;
-    constexpr size_t smem = 4 * (size_t)RS + 2 * (size_t)(PH ? 8 : 12) * NB * 1024;
+    constexpr size_t smem = 4 * (size_t)RS + 2 * (size_t)(PH ? 8 : 12) * NB * 1024 * (P2 ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS, P2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     // PH: tiles of the low-resolution image, four parities in blockIdx.z (fastest)
-    dim3 grid((unsigned)(a.M / (PH ? 4 : 1) / (TH * TW)), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups * (PH ? 4 : 1)));
-    conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS><<<grid, 256, smem, st>>>(a);
+    dim3 grid((unsigned)(a.M / (PH ? 4 : 1) / (TH * TW)), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups * (PH ? (P2 ? 2 : 4) : 1)));
+    conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS, P2><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 
@@ -1261,7 +1309,11 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
         return ph ? (tw == 32 ? launch_h2<32, 4, 2, true, true>(a, st) : launch_h2<16, 2, 4, true, true>(a, st))
                   : (tw == 32 ? launch_h2<32, 4, 2, false, true>(a, st) : launch_h2<16, 2, 4, false, true>(a, st));
     }
-    int rc = r8 ? (ph ? (tw == 32 ? launch_h2<32, 2, 2, true>(a, st) : launch_h2<16, 1, 4, true>(a, st))
+    // up_conv layers on full-height tiles: both column parities in one workgroup of half the height (same workgroup count, one
+    // staged halo for two parities; NBP_SPLIT_UP2 = 0: one parity per workgroup, as round 3)
+    static const int allow_p2 = nbp_tune_int("NBP_SPLIT_UP2", 1);
+    int rc = (ph && !r8 && allow_p2) ? (tw == 32 ? launch_h2<32, 2, 2, true, false, true>(a, st) : launch_h2<16, 1, 4, true, false, true>(a, st))
+           : r8 ? (ph ? (tw == 32 ? launch_h2<32, 2, 2, true>(a, st) : launch_h2<16, 1, 4, true>(a, st))
                       : (tw == 32 ? launch_h2<32, 2, 2, false>(a, st) : launch_h2<16, 1, 4, false>(a, st)))
            : ph ? (tw == 32 ? launch_h2<32, 4, 2, true>(a, st) : launch_h2<16, 2, 4, true>(a, st))
                 : (tw == 32 ? launch_h2<32, 4, 2, false>(a, st) : launch_h2<16, 2, 4, false>(a, st));

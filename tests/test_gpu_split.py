@@ -282,6 +282,7 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
     clean = {k: v for k, v in os.environ.items() if not k.startswith("NBP_")}
     for tag, env in (("both", {}), ("nopool", {**T, "NBP_CONV_POOL": "0"}), ("nopsi", {**T, "NBP_GATE_PSI": "0"}),
                      ("nohead", {**T, "NBP_CONV_HEAD": "0"}), ("nor8", {**T, "NBP_SPLIT_R8_BLOCKS": "0"}),
+                     ("noup2", {**T, "NBP_SPLIT_UP2": "0"}),
                      # a polluted environment WITHOUT the opt-in must change nothing
                      ("polluted", {"NBP_CONV_POOL": "0", "NBP_GATE_PSI": "0", "NBP_CONV_HEAD": "0", "NBP_SPLIT_MAX_K": "576",
                                    "NBP_SPLIT_MAX_K_SMALL": "288", "NBP_SPLIT_R8_SK": "1", "NBP_SPLIT_HALO": "0", "NBP_SPLIT_UP": "0",
@@ -301,6 +302,10 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
         # same split-K slices: bit-identical
         t1, t2 = outs["nor8"][k]
         assert torch.equal(o1, t1) and torch.equal(o2, t2), k
+        # up_conv layers: two column parities per workgroup on half-height tiles against one parity per workgroup -- the same
+        # products in the same order into every accumulator: bit-identical
+        w1, w2 = outs["noup2"][k]
+        assert torch.equal(o1, w1) and torch.equal(o2, w2), k
         u1, u2 = outs["polluted"][k]                          # no NBP_TUNING=1: the environment is not read
         assert torch.equal(o1, u1) and torch.equal(o2, u2), k
 
