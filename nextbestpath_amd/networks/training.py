@@ -291,12 +291,17 @@ class ConvFn(torch.autograd.Function):
         x1 = x1 if has1 else None
         dev = dy.device
         info = _noted(dy, "colsum") if dy.is_contiguous() else None       # (max-|dy| slot, column sums): this very tensor's
+        dy_note = getattr(dy, "_nbp_note", None)
         dy = dy.contiguous()
         dy = _pad_channels(dy, Np)
         B, H, W, _ = dy.shape
         M = B * H * W
         # the bias gradient: the BatchNorm behind this convolution summed dx's columns while writing it
-        db = info[1][:N].clone() if info is not None else _colsum(dy.view(M, Np))[:N].clone()
+        if info is not None and info[1].numel() == N:
+            db = info[1]                               # handed over as it is: nothing else keeps it (the note lets go of it here),
+            dy_note.pop("colsum", None)                # so autograd takes the tensor instead of cloning it
+        else:
+            db = info[1][:N].clone() if info is not None else _colsum(dy.view(M, Np))[:N].clone()
         dw = torch.empty(N, c_real, k, k, dtype=torch.float32, device=dev)
         ws = _ws(L.nbp_conv_wgrad_workspace_bytes(B, H, W, C0, C1, Np, k), dev)
         # the 3x3 weight gradients take the split scheme too (the entry point falls through to the fp32 pipe for the rest)
@@ -626,10 +631,16 @@ def _t(name, y):
     return y
 
 
+_NBT = None          # inside forward_train: the BatchNorm layers' num_batches_tracked tensors seen so far
+
+
 def _bn(mod, x, relu, name=None):
     y = BNFn.apply(x, mod.weight, mod.bias, mod.running_mean, mod.running_var, mod.eps, mod.momentum, relu)
-    with torch.no_grad():
-        mod.num_batches_tracked += 1
+    if _NBT is not None:
+        _NBT.append(mod.num_batches_tracked)       # forward_train bumps all of a forward's counters in one launch
+    else:
+        with torch.no_grad():
+            mod.num_batches_tracked += 1
     return _t(name, y)
 
 
@@ -663,6 +674,18 @@ def forward_train(net, x):
     B, _, S, _ = x.shape
     dev = x.device
     _reset_arena(dev)
+    global _NBT
+    _NBT = []
+    try:
+        return _forward_train(net, x, L, B, S, dev)
+    finally:
+        if _NBT:
+            with torch.no_grad():
+                torch._foreach_add_(_NBT, 1)       # nn.BatchNorm2d's num_batches_tracked += 1 (46 one-element kernels otherwise)
+        _NBT = None
+
+
+def _forward_train(net, x, L, B, S, dev):
     xh = torch.empty(B, S, S, 5, dtype=torch.float32, device=dev)
     _chk(L.nbp_nchw_to_nhwc_f32(_lib.ptr(x.contiguous().float()), B, 5, S, S, _lib.ptr(xh), _st()), "to_nhwc")
     x0 = _pad_channels(xh, 64)
