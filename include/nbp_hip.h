@@ -173,6 +173,10 @@ int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, 
                           const void* w_planes, const void* wamax, int N, const float* scale, const float* shift, int relu,
                           float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws,
                           size_t ws_bytes, void* stream);
+/* Training: planes of the DATA-GRADIENT convolution of a 3x3 layer (dx = conv3x3(dy, w'), w'[c][n][tap] = w[n][c][8 - tap]; autograd
+ * of nn.Conv2d, nbp_model.py:14-33) straight from the layer's weights w [N][C][3][3]: C rows, N input channels padded to c_total */
+int nbp_pack_conv_weight_split_dgrad(const float* w_oihw, int N, int C, int c_total, void* dst_planes, void* wamax_out, void* stream);
+
 /* Training: the same convolution (and its up_conv form), whose epilogue also leaves the column sums of the output and of its
  * squares for the BatchNorm behind it (nextbestpath_amd/networks/training.py: ConvFn -> BNFn; the reference's nn.Sequential of
  * Conv2d + BatchNorm2d, nbp_model.py:14-33): bn_part receives *bn_rows rows of [2][N] doubles -- at most

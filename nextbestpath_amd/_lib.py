@@ -132,6 +132,7 @@ SIGNATURES["nbp_conv_split_workspace_bytes"] = SIGNATURES["nbp_conv_igemm_worksp
 SIGNATURES["nbp_conv_split_planned_workspace_bytes"] = (_sz, [_i, _i, _i, _i, _i, _i, _vp])
 SIGNATURES["nbp_conv3x3_split_f32"] = (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp,
                                             _sz, _vp])
+SIGNATURES["nbp_pack_conv_weight_split_dgrad"] = (_i, [_vp, _i, _i, _i, _vp, _vp, _vp])
 SIGNATURES["nbp_conv_bn_part_rows"] = (_i, [_i, _i, _i])
 SIGNATURES["nbp_conv3x3_split_bn_f32"] = (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp,
                                                _sz, _vp, C.POINTER(_i), _vp])

@@ -1018,8 +1018,11 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
 }
 
 // planes [chunk of 16 channels][tap][hi|lo][k half][N][8 fp16] of w[n][c][tap] * (scale ? scale[n] : 1) * 2^(14 - e_w)
+// transposed: the planes of w'[n][c][tap] = w[c][n][taps - 1 - tap] (w is then [C][N][taps]): the data-gradient convolution's
+// weights -- input and output channels swapped, taps reversed -- straight from the layer's own tensor
 __global__ void pack_conv_weight_h2_kernel(const float* __restrict__ w, int N, int C, int taps, const float* __restrict__ scale,
-                                           int c_off, const unsigned* __restrict__ wamax, unsigned short* __restrict__ dst) {
+                                           int c_off, const unsigned* __restrict__ wamax, unsigned short* __restrict__ dst,
+                                           int transposed = 0) {
     const float sw = pow2f(SPLIT_EXP - amax_exponent(*wamax));
     const long long total = (long long)N * C * taps;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -1027,7 +1030,7 @@ __global__ void pack_conv_weight_h2_kernel(const float* __restrict__ w, int N, i
         const long long t = i / taps;
         const int c = (int)(t % C);
         const int n = (int)(t / C);
-        float v = w[i];
+        float v = transposed ? w[((long long)c * N + n) * taps + (taps - 1 - tap)] : w[i];
         if (scale) v *= scale[n];
         unsigned h, l;
         split_pair(v * sw, 0.f, h, l);
@@ -1458,6 +1461,23 @@ extern "C" int nbp_pack_conv_weight_split(const float* w_oihw, int N, int C, int
     NBP_ENTER();
     return nbp_pack_conv_weight_split_launch(w_oihw, N, C, ksize, scale_or_null, c_off, c_total, dst_planes, (unsigned*)wamax_out,
                                              (hipStream_t)stream);
+}
+
+// Planes of the data-gradient convolution of a 3x3 layer with weights w [N][C][3][3]: dx = conv3x3(dy, w') with
+// w'[c][n][tap] = w[n][c][8 - tap] -- C output rows, N input channels padded to c_total (flip + permute + pack in one launch).
+extern "C" int nbp_pack_conv_weight_split_dgrad(const float* w_oihw, int N, int C, int c_total, void* dst_planes, void* wamax_out,
+                                                void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!w_oihw || !dst_planes || !wamax_out, NBP_E_ARG);
+    NBP_RETURN_IF(N < 1 || C < 1 || N > c_total || c_total % 32, NBP_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)N * C * 9;
+    hipError_t e = hipMemsetAsync(wamax_out, 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return (int)e;
+    amax_kernel<<<min(nbp_ew_grid(total, 256), 256), 256, 0, st>>>(w_oihw, total, nullptr, 9ll * C, (unsigned*)wamax_out, 1u);
+    pack_conv_weight_h2_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(w_oihw, C, N, 9, nullptr, 0, (const unsigned*)wamax_out,
+                                                                       (unsigned short*)dst_planes, 1);
+    return nbp_launch_status();
 }
 
 extern "C" int nbp_amax_f32(const float* x, long long n, void* amax_inout, void* stream) {

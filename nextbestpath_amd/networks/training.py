@@ -322,8 +322,16 @@ class ConvFn(torch.autograd.Function):
             one, zero = _const(1.0, Ctot, dev), _const(0.0, Ctot, dev)
             if _split_ok(H, W, Ctot, k):
                 # dx = conv3x3(dy, w^T with the taps reversed): output channels = the (padded) input channels
-                wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()                # [c_real, N, 3, 3]
-                dx = _conv_split(dy, None, False, _pack_split(wt, Ctot, Np), Ctot, one, zero, False, dymax)
+                if c_real == Ctot and N == Np:
+                    # flip + permute + pack in one launch (they were an ATen flip, a strided copy and the pack)
+                    planes = torch.empty(Np // 16 * 9 * 4 * Ctot * 8, dtype=torch.int16, device=dev)
+                    wamax = torch.empty(1, dtype=torch.int32, device=dev)
+                    _chk(L.nbp_pack_conv_weight_split_dgrad(_lib.ptr(w), N, c_real, Np, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_dgrad_split")
+                    packed = (planes, wamax)
+                else:
+                    wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()            # [c_real, N, 3, 3]
+                    packed = _pack_split(wt, Ctot, Np)
+                dx = _conv_split(dy, None, False, packed, Ctot, one, zero, False, dymax)
             else:
                 wt = torch.empty(Np // 32 * k * k * Ctot * 32, dtype=torch.float32, device=dev)
                 _chk(L.nbp_pack_conv_weight_dgrad(_lib.ptr(w), N, c_real, k, Ctot, Np, _lib.ptr(wt), _st()), "pack_dgrad")
