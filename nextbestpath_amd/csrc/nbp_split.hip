@@ -1398,9 +1398,12 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
     a.C = C; a.N = N; a.relu = relu; a.M = M; a.bytes0 = (unsigned)b0; a.bytesw = (unsigned)bw; a.groups = groups;
     // 128-channel blocks only when they alone fill the chip twice; otherwise more, narrower workgroups
     int bn = N % 128 == 0 ? 128 : (N % 64 == 0 ? 64 : 32);
-    if (bn == 128 && nbp_cdiv(M, 128) * (N / 128) * groups < 512) bn = 64;
-    // the gate's tail (psi, x * psi) runs in the epilogue when a workgroup holds every column of its pixels
+    // ... unless 128 columns are the whole gate and its psi tail is on offer: the tail then rides in the epilogue (bn == N below) and
+    // its own launch goes (level 4 below B = 8: -0.8 % of the B = 1 forward, -1.1 % at B = 4)
     static const int allow_psi = nbp_tune_int("NBP_GATE_PSI", 1);
+    const bool psi_wants_128 = allow_psi && psi && N == 128 && psi->wpsi[0] && psi->st[0] && psi->gated[0];
+    if (bn == 128 && nbp_cdiv(M, 128) * (N / 128) * groups < 512 && !psi_wants_128) bn = 64;
+    // the gate's tail (psi, x * psi) runs in the epilogue when a workgroup holds every column of its pixels
     const bool with_psi = allow_psi && psi && bn == N && psi->wpsi[0] && psi->st[0] && psi->gated[0] &&
                           (groups == 1 || (psi->wpsi[1] && psi->st[1] && psi->gated[1]));
     if (fused) *fused = with_psi;
