@@ -233,8 +233,14 @@ __device__ __forceinline__ void coverage_mark_body(unsigned bx, unsigned by, uns
             for (; q + UNROLL <= hi; q += UNROLL) {
                 unsigned sp[UNROLL];
                 float4 t[UNROLL];
+                // stamps first, positions only of the points no one has stamped yet in this launch: a covered GT point is near
+                // many of the 100 k sampled cloud points and all but the first find it stamped -- a 4-byte load instead of 20 and
+                // no distance test (lock-step +1.0 %, profiles/r04/coverage_lazy_positions.txt; a stale "unstamped" read from
+                // another XCD's L2 only repeats a test)
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) { sp[u] = stamp[q + u]; t[u] = gt_sorted[q + u]; }
+                for (int u = 0; u < UNROLL; ++u) sp[u] = stamp[q + u];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) t[u] = sp[u] != epoch ? gt_sorted[q + u] : make_float4(3e38f, 3e38f, 3e38f, 0.f);
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     const float ex = t[u].x - x, ey = t[u].y - y, ez = t[u].z - z;
