@@ -1401,7 +1401,8 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
     // ... unless 128 columns are the whole gate and its psi tail is on offer: the tail then rides in the epilogue (bn == N below) and
     // its own launch goes (level 4 below B = 8: -0.8 % of the B = 1 forward, -1.1 % at B = 4)
     static const int allow_psi = nbp_tune_int("NBP_GATE_PSI", 1);
-    const bool psi_wants_128 = allow_psi && psi && N == 128 && psi->wpsi[0] && psi->st[0] && psi->gated[0];
+    static const int wide_psi = nbp_tune_int("NBP_GATE_WIDE_PSI", 1);
+    const bool psi_wants_128 = wide_psi && allow_psi && psi && N == 128 && psi->wpsi[0] && psi->st[0] && psi->gated[0];
     if (bn == 128 && nbp_cdiv(M, 128) * (N / 128) * groups < 512 && !psi_wants_128) bn = 64;
     // the gate's tail (psi, x * psi) runs in the epilogue when a workgroup holds every column of its pixels
     const bool with_psi = allow_psi && psi && bn == N && psi->wpsi[0] && psi->st[0] && psi->gated[0] &&

@@ -11,6 +11,10 @@ for k in range(first, first + seeds):
     t0 = time.time()
     tmp = tempfile.mkdtemp()
     hip_ro, ora, mesh = T._both_rollouts(tmp, cells=8, size=4.8, tess=0.3, scene_seed=k, seed=5 + k)
-    counts = T._step_both_and_compare(hip_ro, ora, steps)
+    try:
+        counts = T._step_both_and_compare(hip_ro, ora, steps)
+    except AssertionError as e:        # (step, output, max / mean |HIP - fp64|, max / mean |torch fp32 - fp64|, range) of the network check
+        print(f"scene {k}: FAILED {e}", flush=True)
+        continue
     print(f"scene {k}: {steps} steps identical (poses, replans {hip_ro.n_replans}, collision / passable lists, cloud, maps, network inputs, "
           f"coverage counts {counts[0]} -> {counts[-1]}), native search {hip_ro.planner.native_search}, {time.time() - t0:.0f} s", flush=True)
