@@ -517,7 +517,6 @@ __device__ __forceinline__ void raster_tile_body(unsigned bx, unsigned by, unsig
         // pass 1: the faces of this piece whose fine-tile box covers the tile (entry loads are independent: the compiler
         // keeps several in flight), compacted into LDS
         int nh = 0;
-#pragma unroll 4
         for (int base = c0; base < c1; base += 64) {
             bool in = false;
             int face = 0;
