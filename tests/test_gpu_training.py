@@ -226,6 +226,21 @@ def test_small_functions(hip):
     _close(p2d.grad, p2r.grad, what="bce grad")
 
 
+def test_dgrad_weight_pack_is_the_pack_of_the_flipped_transposed_weights(hip):
+    """nbp_pack_conv_weight_split_dgrad: the data-gradient convolution's fp16 planes straight from the layer's [N][C][3][3] weights --
+    bit for bit the planes (and the max |w| word) of packing w.flip(2, 3).permute(1, 0, 2, 3), which it replaces."""
+    from nextbestpath_amd import _lib
+    L = _lib.lib()
+    for N, C in ((64, 64), (128, 64), (64, 256)):
+        w = (_rand(N, C, 3, 3, seed=N + C) * 0.2).to(D)
+        planes = torch.empty(N // 16 * 9 * 4 * C * 8, dtype=torch.int16, device=D)
+        wamax = torch.empty(1, dtype=torch.int32, device=D)
+        assert L.nbp_pack_conv_weight_split_dgrad(_lib.ptr(w), N, C, N, _lib.ptr(planes), _lib.ptr(wamax), _lib.current_stream()) == 0
+        ref_planes, ref_amax = tr._pack_split(w.flip(2, 3).permute(1, 0, 2, 3).contiguous(), C, N)
+        torch.cuda.synchronize()
+        assert torch.equal(wamax, ref_amax) and torch.equal(planes, ref_planes), (N, C)
+
+
 def test_rowscale_backward_reads_a_channel_slice_in_place(hip):
     """RowScaleFn.backward on a channel-slice VIEW of a wider gradient (what ConvFn.backward returns for the first source of a
     two-source convolution): one pass, row stride = the joint width -- the same dx / ds as on a contiguous copy of the slice,
