@@ -1315,7 +1315,9 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     // up_conv layers on full-height tiles: both column parities in one workgroup of half the height (same workgroup count, one
     // staged halo for two parities; NBP_SPLIT_UP2 = 0: one parity per workgroup, as round 3)
     static const int allow_p2 = nbp_tune_int("NBP_SPLIT_UP2", 1);
-    int rc = (ph && !r8 && allow_p2) ? (tw == 32 ? launch_h2<32, 2, 2, true, false, true>(a, st) : launch_h2<16, 1, 4, true, false, true>(a, st))
+    // (NBP_SPLIT_UP2 = 2 also takes the 16-pixel-wide levels, where the form measured 7 % slower per launch: 619 against 577 us at B = 24)
+    int rc = (ph && !r8 && allow_p2 && (tw == 32 || allow_p2 >= 2))
+                 ? (tw == 32 ? launch_h2<32, 2, 2, true, false, true>(a, st) : launch_h2<16, 1, 4, true, false, true>(a, st))
            : r8 ? (ph ? (tw == 32 ? launch_h2<32, 2, 2, true>(a, st) : launch_h2<16, 1, 4, true>(a, st))
                       : (tw == 32 ? launch_h2<32, 2, 2, false>(a, st) : launch_h2<16, 1, 4, false>(a, st)))
            : ph ? (tw == 32 ? launch_h2<32, 4, 2, true>(a, st) : launch_h2<16, 2, 4, true>(a, st))
