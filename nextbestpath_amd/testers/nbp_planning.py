@@ -283,6 +283,8 @@ def _concurrent_streams(device, n, tries=24, cycles=300_000):
         torch.cuda.synchronize(device)
         return ev[0].elapsed_time(ev[2]) < 1.5 * ev[0].elapsed_time(ev[1])
 
+    if not hasattr(torch.cuda, "_sleep"):          # (a torch without the spin kernel: the streams are taken as they come)
+        return [torch.cuda.Stream(device) for _ in range(n)], {"streams_tested": 0, "concurrent": None}
     chosen, tested = [], 0
     while len(chosen) < n and tested < tries:
         st = torch.cuda.Stream(device)
