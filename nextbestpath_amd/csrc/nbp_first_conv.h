@@ -26,6 +26,27 @@ __device__ __forceinline__ void conv_first_mfma_body(const float* __restrict__ x
     }
     const int kh = lane >> 5, ln = lane & 31;
     float mx = 0.f;                                      // max |out| of this workgroup's tiles (split path: the next layer's scale)
+    // the halo of the NEXT tile is fetched into registers before this tile's MFMAs and epilogue (round 4: a tile was load ->
+    // barrier -> MFMA -> store with nothing in flight across tiles; a workgroup walks 12 tiles at B = 24)
+    constexpr int NPRE = (5 * PLANE + 255) / 256;
+    float pre[NPRE];
+    auto fetch = [&](int tile_id) {
+        int tile = tile_id;
+        const int tx = tile % tiles_x; tile /= tiles_x;
+        const int ty = tile % tiles_y;
+        const int b = tile / tiles_y;
+        const int y0 = ty * 8, x0 = tx * 32;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int i = tid + 256 * q;
+            const int ci = i / PLANE, r = i - ci * PLANE;
+            const int hy = r / HW_, hx = r - hy * HW_;
+            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            const bool ok = i < 5 * PLANE && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            pre[q] = ok ? x[((long long)(b * 5 + ci) * H + yy) * W + xx] : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
   for (int tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
     int tile = tile_id;
     const int tx = tile % tiles_x; tile /= tiles_x;
@@ -33,14 +54,13 @@ __device__ __forceinline__ void conv_first_mfma_body(const float* __restrict__ x
     const int b = tile / tiles_y;
     const int y0 = ty * 8, x0 = tx * 32;
     __syncthreads();                                     // previous tile's MFMA reads of `hal` are done
-    for (int i = tid; i < 5 * PLANE; i += 256) {
-        const int ci = i / PLANE, r = i - ci * PLANE;
-        const int hy = r / HW_, hx = r - hy * HW_;
-        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-        const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        hal[i] = ok ? x[((long long)(b * 5 + ci) * H + yy) * W + xx] : 0.f;
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+        const int i = tid + 256 * q;
+        if (i < 5 * PLANE) hal[i] = pre[q];
     }
     __syncthreads();
+    if (tile_id + (int)gridDim.x < n_tiles) fetch(tile_id + gridDim.x);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
