@@ -45,15 +45,32 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfm
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 = dense fp16 (v_mfma_f32_32x32x16_{bf16,f16})
 PEAK_HBM_GBS = 8000.0
 N_POSES = 101
-TILE_NAMES = {1: "igemm_conv_kernel<2,2,2,2>(128x128)", 2: "igemm_conv_kernel<4,1,2,2>(256x64)",
-              3: "igemm_conv_kernel<4,1,2,1>(256x32)", 4: "igemm_conv_kernel<2,2,2,1>(128x64)",
-              5: "igemm_conv_kernel<1,4,2,1>(64x128)", 6: "conv3x3_halo_f32_kernel<4,2>(8x32 px x 128 ch)",
-              7: "conv3x3_halo_f32_kernel<2,2>(8x32 px x 64 ch)", 8: "conv3x3_halo_f32_kernel<4,1>(4x32 px x 128 ch)",
-              9: "conv3x3_halo_f32_kernel<2,1>(4x32 px x 64 ch)",
-              10: "conv3x3_halo_h2_kernel<32, 4, 2, false>(16x32 px x 64 ch; fp32 operands as 2 scaled fp16 pieces, 3 fp16 MFMAs per product)",
-              11: "conv3x3_halo_h2_kernel<32, 4, 2, true>(up_conv as four 2x2 parity convolutions of the low-resolution input; same kernel body)",
-              15: "conv3x3_halo_h2_kernel<32, 2, 2, false>(8x32 px x 64 ch: launches with fewer 16-row tiles than CUs; same kernel body)",
-              16: "conv3x3_halo_h2_kernel<32, 2, 2, true>(up_conv parity form on 8x32 low-resolution tiles)"}
+# what a convolution tile id (nbp_layer_timing.tile) stands for.  The kernel SYMBOL of a tile is not kept here: the library reports the
+# instantiation it launched (nbp_tile_kernel_symbol), so that profiler rows are looked up by the name the profiler will print
+TILE_NOTES = {1: "implicit GEMM 128x128", 2: "implicit GEMM 256x64", 3: "implicit GEMM 256x32", 4: "implicit GEMM 128x64",
+              5: "implicit GEMM 64x128", 6: "8x32 px x 128 ch halo tiles, fp32 MFMA pipe", 7: "8x32 px x 64 ch halo tiles, fp32 MFMA pipe",
+              8: "4x32 px x 128 ch halo tiles, fp32 MFMA pipe", 9: "4x32 px x 64 ch halo tiles, fp32 MFMA pipe",
+              10: "16x32 px x 64 ch (16x16 px x 128 ch on the 16-pixel-wide level); fp32 operands as 2 scaled fp16 pieces, 3 fp16 MFMAs per product",
+              11: "up_conv as 2x2 parity convolutions of the low-resolution input, both column parities per workgroup on 8-row tiles; same kernel body",
+              12: "bf16 up_conv parity form, 128 ch", 13: "bf16 up_conv parity form, 64 ch",
+              15: "8x32 px x 64 ch: launches with fewer 16-row tiles than CUs; same kernel body",
+              16: "up_conv parity form on 8-row low-resolution tiles, one parity per workgroup"}
+
+
+def tile_symbol(tile):
+    """The kernel symbol the library launched tile id `tile` as in this process ('' if it has not been launched)."""
+    from nextbestpath_amd import _lib
+    buf = C.create_string_buffer(128)
+    n = _lib.lib().nbp_tile_kernel_symbol(int(tile), buf, 128)
+    return buf.value.decode() if n > 0 else ""
+
+
+def tile_label(tile):
+    sym = tile_symbol(tile) or f"tile {tile}"
+    note = TILE_NOTES.get(tile)
+    return f"{sym} ({note})" if note else sym
+
+
 SPLIT_TILE = 10
 SPLIT_TILES = (10, 11, 15, 16)
 PARITY_TILES = (11, 16)          # execute 4/9 of the reference formulation's products
@@ -171,10 +188,15 @@ def live_traffic(n_points, precision="fp32", batch=12):
 
 
 def committed_traffic(kernel_prefix, which):
-    """Fallback: the same quantity from the newest committed rocprofv3 summaries (profiles/r03, r02, r01)."""
+    """Fallback: the same quantity from the NEWEST committed rocprofv3 summary that has a row for this kernel symbol
+    (profiles/rNN, highest NN first)."""
     import csv
-    for rnd in ("r03", "r02", "r01"):
-        path = os.path.join(ROOT, "profiles", rnd, which)
+    import glob
+    import re
+    rounds = sorted((d for d in glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*")) if os.path.isdir(d)),
+                    key=lambda d: int(re.sub(r"\D", "", os.path.basename(d)) or 0), reverse=True)
+    for d in rounds:
+        path = os.path.join(d, which)
         if not os.path.exists(path):
             continue
         vals = {}
@@ -183,7 +205,7 @@ def committed_traffic(kernel_prefix, which):
                 if row["kernel"].replace(" ", "").replace("(anonymousnamespace)::", "").startswith(kernel_prefix):
                     vals[row["counter"]] = float(row["mean_per_dispatch"])
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-            return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, f"profiles/{rnd}/{which} (committed)"
+            return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, f"profiles/{os.path.basename(d)}/{which} (committed)"
     return None, None
 
 
@@ -525,16 +547,19 @@ def main():
         live, live_src = (None, "disabled (--no-live-traffic)")
         if world == 1 and not args.no_live_traffic:
             live, live_src = live_traffic(n_pts, packed.precision, Bf)
-        dom_prefix = TILE_NAMES.get(dom, f"tile {dom}").split("(")[0].replace(" ", "")
+        dom_symbol = tile_symbol(dom)                       # e.g. "conv3x3_halo_h2_kernel<32, 4, 2, false, false, false>": what rocprofv3 prints
+        dom_prefix = dom_symbol.replace(" ", "") or f"tile{dom}"
         traffic = pick_traffic(live, dom_prefix) if S == 256 else None
         traffic_src = live_src
+        traffic_is_live = traffic is not None
         if traffic is None and (Bf, S) == (24, 256):           # the committed profiles are taken at the default group batch
             traffic, src2 = committed_traffic(dom_prefix, "forward_split_pmc_summary.csv" if dom in SPLIT_TILES
                                               else "forward_f32_pmc_summary.csv")
-            traffic_src = f"{src2}; live pass: {live_src}" if src2 else live_src
+            traffic_src = (f"{src2}; live pass: {live_src}" if src2 else
+                           f"no row for {dom_symbol} in the live pass or in any committed profile; live pass: {live_src}")
         # the split kernel issues three fp16 MFMAs per fp32 product: its ceiling is the dense fp16 peak / 3 of ALGORITHMIC flops
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if dom in SPLIT_TILES else PEAK_F32_MFMA_TFLOPS
-        roofline = {"bound": "mfma", "kernel": TILE_NAMES.get(dom, f"tile {dom}"), "achieved": round(achieved, 3),
+        roofline = {"bound": "mfma", "kernel": tile_label(dom), "kernel_symbol": dom_symbol, "achieved": round(achieved, 3),
                     "peak": round(peak, 2), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "peak_basis": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product (algorithmic fp32 flops)"
                                    if dom in SPLIT_TILES else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
@@ -549,7 +574,8 @@ def main():
                     "traffic_unit": "HBM-side bytes per launch: 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide; calibrated on "
                                     "known byte counts, profiles/r03/fetch_calibration.txt: bytes / FETCH_SIZE = 2.000 for 4-B, "
                                     "12-B-strided and 16-B loads per lane, bytes / WRITE_SIZE = 1.000 for 4-B and 16-B stores)",
-                    "traffic_source": traffic_src,
+                    "traffic_source": traffic_src, "traffic_is_live": traffic_is_live,
+                    "traffic_over_algorithmic": None if traffic is None else round(traffic / (alg_bytes / d["launches"]), 4),
                     "algorithmic_bytes_per_launch": round(alg_bytes / d["launches"]),
                     "launches_per_forward": d["launches"],
                     "avg_launch_ms": round(d["ms"] / d["launches"], 5), "flops_per_launch": d["flops"] / d["launches"],
@@ -557,7 +583,7 @@ def main():
                     "all_conv_tflops_executed": round(cfx / (cm * 1e-3) / 1e12, 3),
                     "all_conv_frac_executed": round(cfx / (cm * 1e-3) / 1e12 / peak, 4),
                     "all_conv_tflops_reference_formulation": round(cf / (cm * 1e-3) / 1e12, 3),
-                    "by_kernel": {TILE_NAMES.get(k, str(k)).split("(")[0]: {
+                    "by_kernel": {(tile_symbol(k) or f"tile {k}"): {
                         "launches": v["launches"], "ms": round(v["ms"], 4),
                         "tflops_executed": round(v["flops"] * (4.0 / 9.0 if k in PARITY_TILES else 1.0) / (v["ms"] * 1e-3) / 1e12, 2),
                         "frac_executed": round(v["flops"] * (4.0 / 9.0 if k in PARITY_TILES else 1.0) / (v["ms"] * 1e-3) / 1e12 / peak, 4),
@@ -639,6 +665,7 @@ def main():
         alg_grp = 12 * pts_grp + len(grp0) * 6 * S * S * 4
         sc_traffic = pick_traffic(live, "map_binned_kernel")
         sc_src = live_src
+        sc_live = sc_traffic is not None
         if sc_traffic is None:
             sc_traffic, src2 = committed_traffic("map_binned_kernel", "pmc_summary.csv")
             sc_src = f"{src2}; live pass: {live_src}" if src2 else live_src
@@ -646,7 +673,7 @@ def main():
                                              "2.5-unit tile on a dense LDS histogram; new points counted directly and filed by the same launch)",
                    "achieved": round(alg / (ms_sc * 1e-3) / 1e9, 1),
                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(alg / (ms_sc * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                   "traffic": None if sc_traffic is None else round(sc_traffic), "traffic_source": sc_src,
+                   "traffic": None if sc_traffic is None else round(sc_traffic), "traffic_source": sc_src, "traffic_is_live": sc_live,
                    "traffic_note": "per launch of map_binned_kernel over tools/pmc_workload.py's synthetic wall cloud of the same size (two "
                                    "steady builds and one that meets 29 k new points): 2 * FETCH_SIZE + WRITE_SIZE",
                    "points": n_pts, "new_points_in_timed_build": n_new, "algorithmic_bytes": alg, "ms": round(ms_sc, 4),
@@ -834,6 +861,22 @@ def main():
                       "note": "hwmon power1 / freq1 of this GPU, 20 ms samples over the K timed steps; the batched forward alone holds the "
                               "board at its cap (stages.nbp_forward.power; profiles/r04/power_trace_b24.txt)"},
         }
+        # scalar copies of the stage figures at the top level of the line (a reader that keeps only top-level scalars still sees them)
+        def _g(name, key):
+            v = stage.get(name)
+            return v.get(key) if isinstance(v, dict) else None
+        n_groups = len(multi.groups)
+        out["train_maps_per_s"] = _g("config3_train_step_b32", "maps_per_s")
+        out["bf16_512_b8_frac"] = _g("config5_forward_bf16_512_b8", "frac_executed_of_conv_ceiling")
+        out["fwd_b1_ms"] = _g("nbp_forward_b1", "ms")
+        out["fwd_group_ms"] = _g("nbp_forward", "ms")
+        out["single_rollout_steps_per_s"] = stage.get("single_rollout_steps_per_s")
+        # share of a lock-step that its groups' batched forwards alone would take (1.0 = the step's own kernels are fully hidden)
+        out["lockstep_forward_share"] = round(n_groups * stage["nbp_forward"]["ms"] / out["ms_per_step"], 4)
+        out["all_conv_frac_executed"] = None if roofline is None else roofline["all_conv_frac_executed"]
+        out["roofline_frac"] = None if roofline is None else roofline["frac"]
+        out["roofline_traffic_is_live"] = None if roofline is None else roofline["traffic_is_live"]
+        out["scatter_frac"] = None if scatter is None else scatter["frac"]
         # A/B switches (NBP_TUNING=1 ...): state every non-default one; a line measured with a switch that changes the
         # arithmetic is not the headline configuration and does not get to call itself `value`
         knobs = _lib.effective_knobs()

@@ -41,6 +41,10 @@ int nbp_device_info(char* arch_host, int arch_len, int* cu_count_host);
  * switches read so far whose value differs from the default into buf_host (truncated to len - 1) and returns their number. */
 int nbp_tuning_active(void);
 int nbp_tuning_report(char* buf_host, int len);
+/* Kernel symbol (as a profiler demangles it, without "void" / the anonymous namespace / the argument list) that convolution tile
+ * id `tile` (nbp_layer_timing.tile) was most recently launched as in this process; returns its length, 0 if that tile id has not
+ * been launched yet.  The launchers build the text from their own template arguments. */
+int nbp_tile_kernel_symbol(int tile, char* buf_host, int len);
 
 /* ================================================================ A1: NBP network
  * Replaces NBP.forward, next_best_path/networks/nbp_model.py:110-160 (and the layer
@@ -173,6 +177,12 @@ int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, 
                           const void* w_planes, const void* wamax, int N, const float* scale, const float* shift, int relu,
                           float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws,
                           size_t ws_bytes, void* stream);
+/* 1x1 convolution on the same scheme (training: Attention_block.W_g / W_x, nbp_model.py:44-53, and their data gradients):
+ * out [M][N] = src [M][C] W * scale + shift, C % 32 == 0, N % 32 == 0.  w_planes / wamax: nbp_pack_conv_weight_split with ksize 1
+ * (forward) or nbp_pack_conv1x1_weight_split_dgrad (dx = dy W^T from the layer's own [N][C] weight).  amax_in: 64-word max-|src| slot. */
+int nbp_conv1x1_split_f32(const float* src, int C, long long M, const void* w_planes, const void* wamax, int N,
+                          const float* scale, const float* shift, int relu, float* out, const void* amax_in, void* stream);
+int nbp_pack_conv1x1_weight_split_dgrad(const float* w_nc, int N, int C, void* dst_planes, void* wamax_out, void* stream);
 /* Training: planes of the DATA-GRADIENT convolution of a 3x3 layer (dx = conv3x3(dy, w'), w'[c][n][tap] = w[n][c][8 - tap]; autograd
  * of nn.Conv2d, nbp_model.py:14-33) straight from the layer's weights w [N][C][3][3]: C rows, N input channels padded to c_total */
 int nbp_pack_conv_weight_split_dgrad(const float* w_oihw, int N, int C, int c_total, void* dst_planes, void* wamax_out, void* stream);

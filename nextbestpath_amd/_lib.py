@@ -21,6 +21,7 @@ SIGNATURES = {
     "nbp_device_info": (_i, [C.c_char_p, _i, C.POINTER(_i)]),
     "nbp_tuning_active": (_i, []),
     "nbp_tuning_report": (_i, [C.c_char_p, _i]),
+    "nbp_tile_kernel_symbol": (_i, [_i, C.c_char_p, _i]),
     "nbp_packed_weights_bytes": (_sz, []),
     "nbp_pack_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, _sz, _vp, C.POINTER(_vp)]),
     "nbp_free_weights": (None, [_vp]),
@@ -132,6 +133,8 @@ SIGNATURES["nbp_conv_split_workspace_bytes"] = SIGNATURES["nbp_conv_igemm_worksp
 SIGNATURES["nbp_conv_split_planned_workspace_bytes"] = (_sz, [_i, _i, _i, _i, _i, _i, _vp])
 SIGNATURES["nbp_conv3x3_split_f32"] = (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp,
                                             _sz, _vp])
+SIGNATURES["nbp_conv1x1_split_f32"] = (_i, [_vp, _i, _ll, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp])
+SIGNATURES["nbp_pack_conv1x1_weight_split_dgrad"] = (_i, [_vp, _i, _i, _vp, _vp, _vp])
 SIGNATURES["nbp_pack_conv_weight_split_dgrad"] = (_i, [_vp, _i, _i, _i, _vp, _vp, _vp])
 SIGNATURES["nbp_conv_bn_part_rows"] = (_i, [_i, _i, _i])
 SIGNATURES["nbp_conv3x3_split_bn_f32"] = (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp,

@@ -26,6 +26,8 @@ static inline int nbp_launch_status() {
 // A/B switch of a launch plan: `dflt` unless the process opted in with NBP_TUNING=1 AND sets the variable (nbp_tuning.cpp: the
 // one place the library reads the environment; read once, recorded for nbp_tuning_report).  `name` must be a string literal.
 int nbp_tune_int(const char* name, int dflt);
+// the kernel symbol a convolution tile id was launched as (nbp_tuning.cpp; read back through nbp_tile_kernel_symbol)
+void nbp_note_kernel_symbol(int tile, const char* symbol);
 
 static inline long long nbp_cdiv(long long a, long long b) { return (a + b - 1) / b; }
 

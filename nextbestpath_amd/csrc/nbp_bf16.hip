@@ -650,7 +650,8 @@ ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int 
 }
 
 template <int TN, int TPS, bool PH = false>
-static int launch_halo(const IgemmArgsH& a, const RowsFuse& f, hipStream_t st) {
+static int launch_halo(const IgemmArgsH& a, const RowsFuse& f, hipStream_t st, int tile) {
+    { char nm[96]; snprintf(nm, sizeof(nm), "conv3x3_halo_bf16_kernel<%d, %d, %s>", TN, TPS, PH ? "true" : "false"); nbp_note_kernel_symbol(tile, nm); }
     constexpr size_t smem = 344 * 128 + 2 * (size_t)TPS * TN * 32 * 128;
     static bool attr_set = false;
     if (!attr_set) {
@@ -665,7 +666,8 @@ static int launch_halo(const IgemmArgsH& a, const RowsFuse& f, hipStream_t st) {
 }
 
 template <int WM, int WN, int TM, int TN>
-static int launch_igemm_h(const IgemmArgsH& a, hipStream_t st, const GatePsiH& ps = GatePsiH{{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}}) {
+static int launch_igemm_h(const IgemmArgsH& a, hipStream_t st, int tile, const GatePsiH& ps = GatePsiH{{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}}) {
+    { char nm[96]; snprintf(nm, sizeof(nm), "igemm_bf16_kernel<%d, %d, %d, %d>", WM, WN, TM, TN); nbp_note_kernel_symbol(tile, nm); }
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr size_t smem = 2 * (size_t)(BM + BN) * 128;
     static bool attr_set = false;
@@ -765,17 +767,17 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
     }
     int rc;
     switch (p.tile) {
-        case NBP_TILE_128x128: rc = launch_igemm_h<2, 2, 2, 2>(a, st); break;
-        case NBP_TILE_256x64: rc = launch_igemm_h<4, 1, 2, 2>(a, st, gp); break;
-        case NBP_TILE_256x32: rc = launch_igemm_h<4, 1, 2, 1>(a, st, gp); break;
-        case NBP_TILE_128x64: rc = launch_igemm_h<2, 2, 2, 1>(a, st); break;
-        case NBP_TILE_64x128: rc = launch_igemm_h<1, 4, 2, 1>(a, st); break;
-        case NBP_TILE_HALO_128: rc = launch_halo<4, 1>(a, f, st); break;
-        case NBP_TILE_HALO_UP_128: rc = launch_halo<4, 1, true>(a, f, st); break;
-        case NBP_TILE_HALO_UP_64: rc = launch_halo<2, 2, true>(a, f, st); break;
+        case NBP_TILE_128x128: rc = launch_igemm_h<2, 2, 2, 2>(a, st, p.tile); break;
+        case NBP_TILE_256x64: rc = launch_igemm_h<4, 1, 2, 2>(a, st, p.tile, gp); break;
+        case NBP_TILE_256x32: rc = launch_igemm_h<4, 1, 2, 1>(a, st, p.tile, gp); break;
+        case NBP_TILE_128x64: rc = launch_igemm_h<2, 2, 2, 1>(a, st, p.tile); break;
+        case NBP_TILE_64x128: rc = launch_igemm_h<1, 4, 2, 1>(a, st, p.tile); break;
+        case NBP_TILE_HALO_128: rc = launch_halo<4, 1>(a, f, st, p.tile); break;
+        case NBP_TILE_HALO_UP_128: rc = launch_halo<4, 1, true>(a, f, st, p.tile); break;
+        case NBP_TILE_HALO_UP_64: rc = launch_halo<2, 2, true>(a, f, st, p.tile); break;
         case NBP_TILE_HALO_64: {
             static const int tps = nbp_tune_int("NBP_BF16_TPS", 2);
-            rc = tps == 2 ? launch_halo<2, 2>(a, f, st) : launch_halo<2, 1>(a, f, st);
+            rc = tps == 2 ? launch_halo<2, 2>(a, f, st, p.tile) : launch_halo<2, 1>(a, f, st, p.tile);
             break;
         }
         default: return NBP_E_ARG;

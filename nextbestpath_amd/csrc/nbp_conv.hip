@@ -507,7 +507,8 @@ ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split
 }
 
 template <int TN, int TM>
-static int launch_halo_f32(const IgemmArgs& a, hipStream_t st) {
+static int launch_halo_f32(const IgemmArgs& a, hipStream_t st, int tile) {
+    { char nm[96]; snprintf(nm, sizeof(nm), "conv3x3_halo_f32_kernel<%d, %d>", TN, TM); nbp_note_kernel_symbol(tile, nm); }
     constexpr size_t smem = (size_t)(((4 * TM + 2) * 34 + 7) / 8) * 1024 + 2 * (size_t)TN * 32 * 128;
     static bool attr_set = false;
     if (!attr_set) {
@@ -522,7 +523,8 @@ static int launch_halo_f32(const IgemmArgs& a, hipStream_t st) {
 }
 
 template <int WM, int WN, int TM, int TN>
-static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
+static int launch_igemm(const IgemmArgs& a, hipStream_t st, int tile) {
+    { char nm[96]; snprintf(nm, sizeof(nm), "igemm_conv_kernel<%d, %d, %d, %d>", WM, WN, TM, TN); nbp_note_kernel_symbol(tile, nm); }
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr size_t smem = 2 * (size_t)(BM + BN) * 32 * sizeof(float);
     static bool attr_set = false;
@@ -588,15 +590,15 @@ int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C
     }
     int rc;
     switch (p.tile) {
-        case NBP_TILE_128x128: rc = launch_igemm<2, 2, 2, 2>(a, st); break;
-        case NBP_TILE_256x64: rc = launch_igemm<4, 1, 2, 2>(a, st); break;
-        case NBP_TILE_256x32: rc = launch_igemm<4, 1, 2, 1>(a, st); break;
-        case NBP_TILE_128x64: rc = launch_igemm<2, 2, 2, 1>(a, st); break;
-        case NBP_TILE_64x128: rc = launch_igemm<1, 4, 2, 1>(a, st); break;
-        case NBP_TILE_HALO_128: rc = launch_halo_f32<4, 2>(a, st); break;
-        case NBP_TILE_HALO_64: rc = launch_halo_f32<2, 2>(a, st); break;
-        case NBP_TILE_HALO4_128: rc = launch_halo_f32<4, 1>(a, st); break;
-        case NBP_TILE_HALO4_64: rc = launch_halo_f32<2, 1>(a, st); break;
+        case NBP_TILE_128x128: rc = launch_igemm<2, 2, 2, 2>(a, st, p.tile); break;
+        case NBP_TILE_256x64: rc = launch_igemm<4, 1, 2, 2>(a, st, p.tile); break;
+        case NBP_TILE_256x32: rc = launch_igemm<4, 1, 2, 1>(a, st, p.tile); break;
+        case NBP_TILE_128x64: rc = launch_igemm<2, 2, 2, 1>(a, st, p.tile); break;
+        case NBP_TILE_64x128: rc = launch_igemm<1, 4, 2, 1>(a, st, p.tile); break;
+        case NBP_TILE_HALO_128: rc = launch_halo_f32<4, 2>(a, st, p.tile); break;
+        case NBP_TILE_HALO_64: rc = launch_halo_f32<2, 2>(a, st, p.tile); break;
+        case NBP_TILE_HALO4_128: rc = launch_halo_f32<4, 1>(a, st, p.tile); break;
+        case NBP_TILE_HALO4_64: rc = launch_halo_f32<2, 1>(a, st, p.tile); break;
         default: return NBP_E_ARG;
     }
     if (rc) return rc;

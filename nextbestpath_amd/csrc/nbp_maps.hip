@@ -219,6 +219,11 @@ constexpr unsigned BIN_OVF = 1u << 16;
 constexpr int BIN_R = 16;                                             // LDS histogram: 16 x 16 cells (a 2.5-unit tile is 9 x 9 + slack)
 constexpr int BIN_APPEND_WGS = 128, BIN_OVF_WGS = 4;     // 128 x 256 threads: one step's ~29 k new points in one pass
 struct BinDesc {                // head of the store (device memory, 256 B reserved)
+    // error is STICKY: set (never cleared) by a filing launch whose side list overflowed, reset only by nbp_cloud_bins_init.  Every
+    // workgroup of a filing launch reads it once at entry and another workgroup may set it during the same launch, so late
+    // workgroups may file nothing while n_binned still advances to N: correct only because every later build then counts the whole
+    // cloud directly (map_binned_kernel's `broken` branch) -- clearing the flag by any other route would lose those points
+    // (tests/test_gpu_maps.py::test_binned_maps_points_that_cannot_be_filed_are_still_counted walks through the break).
     unsigned n_pages, n_overflow, error, ticket;
     long long n_binned;                                   // points of the cloud already filed
     int nx, nz, nt, max_pages;

@@ -534,7 +534,9 @@ extern "C" int nbp_dbg_read(unsigned long long* host, unsigned* n) {
 // double buffer in LDS by DMA.  Three exact fp16 MFMAs per product as in the 3x3 kernel.
 struct GateArgs {
     SplitOps g[2];
-    int C, N, relu;             // channels of EACH source; output channels (N % 32 == 0)
+    int C, N, relu;             // channels of source 0 (and of source 1 when there is one); output channels (N % 32 == 0)
+    int C1;                     // channels of source 1: C (the gates' K = [g | x]) or 0 (a plain 1x1 convolution: training's W_g / W_x
+                                // layers and their data gradients, where a BatchNorm with batch statistics sits between the two halves)
     long long M;
     unsigned bytes0, bytesw;
     int groups;
@@ -556,15 +558,15 @@ __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long m = (long long)blockIdx.x * 128 + wave * 32 + (lane & 31);
     const int n0 = blockIdx.y * BN, khalf = lane >> 5;
-    const unsigned ma0 = read_amax(o.amax0), ma1 = read_amax(o.amax1);
+    const unsigned ma0 = read_amax(o.amax0), ma1 = o.amax1 ? read_amax(o.amax1) : 0u;
     const int ea = amax_exponent(ma0 > ma1 ? ma0 : ma1), ew = amax_exponent(*o.wamax);
     const float sa = pow2f(SPLIT_EXP - ea);
     const int einv = ea + ew - 2 * SPLIT_EXP;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.src0), 0, a.bytes0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.src1), 0, a.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.src1 ? o.src1 : o.src0), 0, a.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(o.planes), 0, a.bytesw, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    const int stages0 = a.C >> 5, stages = stages0 * 2;        // 32-channel stages: source 0 then source 1
+    const int stages0 = a.C >> 5, stages = stages0 + (a.C1 >> 5);      // 32-channel stages: source 0 then source 1
     const unsigned prow = m < a.M ? (unsigned)(m * a.C) * 4u : OOB;
 
     // The pixel's channels are prefetched three stages ahead (a ring of four register sets): a stage is only ~0.3 us of MFMAs,
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
     for (int d = 0; d < D - 1; ++d) load_x(d, d);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int base = 0; base < stages; base += D) {            // stages % 4 == 0 (launcher: C % 64 == 0)
+    for (int base = 0; base < stages; base += D) {            // (stages past the end: zero pixels x stale weights = zero products)
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const int st = base + u;
@@ -1090,7 +1092,13 @@ int split_tile_width(int H, int W, int N, int ksize) {
 }
 
 template <int TW, int TM, int TN, bool PH, bool BS = false, bool P2 = false>
-int launch_h2(const SplitArgs& a, hipStream_t st) {
+int launch_h2(const SplitArgs& a, hipStream_t st, int tile) {
+    {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "conv3x3_halo_h2_kernel<%d, %d, %d, %s, %s, %s>", TW, TM, TN, PH ? "true" : "false", BS ? "true" : "false",
+                 P2 ? "true" : "false");
+        nbp_note_kernel_symbol(tile, nm);
+    }
     constexpr int TH = 4 * TM * (32 / TW);
     constexpr int HPIX = (TH + 2) * (TW + 2), RS = (HPIX + 7) / 8 * 8 * 16 + 64, NB = TN / 2;
     constexpr size_t smem = 4 * (size_t)RS + 2 * (size_t)(PH ? 8 : 12) * NB * 1024 * (P2 ? 2 : 1);
@@ -1309,19 +1317,19 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     if (bn_part && bn_rows && p.split_k == 1 && !r8 && groups == 1) {
         a.g[0].bn_part = bn_part;
         *bn_rows = (int)(a.M / (16 * tw));               // pixel tiles (x 4 parities for the up_conv form: the same count)
-        return ph ? (tw == 32 ? launch_h2<32, 4, 2, true, true>(a, st) : launch_h2<16, 2, 4, true, true>(a, st))
-                  : (tw == 32 ? launch_h2<32, 4, 2, false, true>(a, st) : launch_h2<16, 2, 4, false, true>(a, st));
+        return ph ? (tw == 32 ? launch_h2<32, 4, 2, true, true>(a, st, p.tile) : launch_h2<16, 2, 4, true, true>(a, st, p.tile))
+                  : (tw == 32 ? launch_h2<32, 4, 2, false, true>(a, st, p.tile) : launch_h2<16, 2, 4, false, true>(a, st, p.tile));
     }
     // up_conv layers on full-height tiles: both column parities in one workgroup of half the height (same workgroup count, one
     // staged halo for two parities; NBP_SPLIT_UP2 = 0: one parity per workgroup, as round 3)
     static const int allow_p2 = nbp_tune_int("NBP_SPLIT_UP2", 1);
     // (NBP_SPLIT_UP2 = 2 also takes the 16-pixel-wide levels, where the form measured 7 % slower per launch: 619 against 577 us at B = 24)
     int rc = (ph && !r8 && allow_p2 && (tw == 32 || allow_p2 >= 2))
-                 ? (tw == 32 ? launch_h2<32, 2, 2, true, false, true>(a, st) : launch_h2<16, 1, 4, true, false, true>(a, st))
-           : r8 ? (ph ? (tw == 32 ? launch_h2<32, 2, 2, true>(a, st) : launch_h2<16, 1, 4, true>(a, st))
-                      : (tw == 32 ? launch_h2<32, 2, 2, false>(a, st) : launch_h2<16, 1, 4, false>(a, st)))
-           : ph ? (tw == 32 ? launch_h2<32, 4, 2, true>(a, st) : launch_h2<16, 2, 4, true>(a, st))
-                : (tw == 32 ? launch_h2<32, 4, 2, false>(a, st) : launch_h2<16, 2, 4, false>(a, st));
+                 ? (tw == 32 ? launch_h2<32, 2, 2, true, false, true>(a, st, p.tile) : launch_h2<16, 1, 4, true, false, true>(a, st, p.tile))
+           : r8 ? (ph ? (tw == 32 ? launch_h2<32, 2, 2, true>(a, st, p.tile) : launch_h2<16, 1, 4, true>(a, st, p.tile))
+                      : (tw == 32 ? launch_h2<32, 2, 2, false>(a, st, p.tile) : launch_h2<16, 1, 4, false>(a, st, p.tile)))
+           : ph ? (tw == 32 ? launch_h2<32, 4, 2, true>(a, st, p.tile) : launch_h2<16, 2, 4, true>(a, st, p.tile))
+                : (tw == 32 ? launch_h2<32, 4, 2, false>(a, st, p.tile) : launch_h2<16, 2, 4, false>(a, st, p.tile));
     if (rc) return rc;
     if (p.split_k > 1) {
         const long long MN = a.M * N;
@@ -1397,7 +1405,7 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
         a.wpsi[g] = psi ? psi->wpsi[gi] : nullptr; a.st[g] = psi ? psi->st[gi] : nullptr; a.gated[g] = psi ? psi->gated[gi] : nullptr;
         a.gated_amax[g] = psi ? psi->gated_amax[gi] : nullptr;
     }
-    a.C = C; a.N = N; a.relu = relu; a.M = M; a.bytes0 = (unsigned)b0; a.bytesw = (unsigned)bw; a.groups = groups;
+    a.C = C; a.C1 = C; a.N = N; a.relu = relu; a.M = M; a.bytes0 = (unsigned)b0; a.bytesw = (unsigned)bw; a.groups = groups;
     // 128-channel blocks only when they alone fill the chip twice; otherwise more, narrower workgroups
     int bn = N % 128 == 0 ? 128 : (N % 64 == 0 ? 64 : 32);
     // ... unless 128 columns are the whole gate and its psi tail is on offer: the tail then rides in the epilogue (bn == N below) and
@@ -1417,6 +1425,32 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
         else if (bn == 64) gate1x1_h2_kernel<2, true><<<grid, 256, smem, st>>>(a);
         else gate1x1_h2_kernel<1, true><<<grid, 256, smem, st>>>(a);
     } else if (bn == 128) gate1x1_h2_kernel<4, false><<<grid, 256, smem, st>>>(a);
+    else if (bn == 64) gate1x1_h2_kernel<2, false><<<grid, 256, smem, st>>>(a);
+    else gate1x1_h2_kernel<1, false><<<grid, 256, smem, st>>>(a);
+    return nbp_launch_status();
+}
+
+// out [M][N] = src [M][C] W + shift (optionally scale / ReLU): a 1x1 convolution on the split scheme through the gates' kernel with
+// ONE source (training: the attention gates' W_g / W_x layers and their data gradients ran on the fp32 pipe -- compute-bound there
+// on the deep levels, and padded from 32 to 64 output channels on level 2).  planes: nbp_pack_conv_weight_split with ksize = 1
+// ([chunk of 16][hi|lo][k half][N][8]); C % 32 == 0, N % 32 == 0.
+int nbp_conv1x1_split_launch(const float* src, int C, long long M, const void* planes, const unsigned* wamax, const unsigned* amax_in,
+                             int N, const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+    NBP_RETURN_IF(!src || !planes || !wamax || !amax_in || !scale || !shift || !out, NBP_E_ARG);
+    NBP_RETURN_IF(C < 32 || C % 32 || N < 32 || N % 32 || M < 1, NBP_E_SHAPE);
+    const long long b0 = M * C * 4, bw = (long long)C * N * 4;
+    NBP_RETURN_IF(b0 >= (1ll << 31) || bw >= (1ll << 31) || M * N * 4 >= (1ll << 33), NBP_E_SHAPE);
+    GateArgs a;
+    for (int g = 0; g < 2; ++g) {
+        a.g[g] = SplitOps{src, nullptr, planes, scale, shift, out, amax_in, nullptr, wamax, nullptr, nullptr, nullptr, {nullptr, nullptr}, nullptr, nullptr};
+        a.wpsi[g] = nullptr; a.st[g] = nullptr; a.gated[g] = nullptr; a.gated_amax[g] = nullptr;
+    }
+    a.C = C; a.C1 = 0; a.N = N; a.relu = relu; a.M = M; a.bytes0 = (unsigned)b0; a.bytesw = (unsigned)bw; a.groups = 1;
+    int bn = N % 128 == 0 ? 128 : (N % 64 == 0 ? 64 : 32);
+    if (bn == 128 && nbp_cdiv(M, 128) * (N / 128) < 512) bn = 64;
+    dim3 grid((unsigned)nbp_cdiv(M, 128), (unsigned)(N / bn), 1u);
+    const size_t smem = 2 * (size_t)8 * bn * 16;
+    if (bn == 128) gate1x1_h2_kernel<4, false><<<grid, 256, smem, st>>>(a);
     else if (bn == 64) gate1x1_h2_kernel<2, false><<<grid, 256, smem, st>>>(a);
     else gate1x1_h2_kernel<1, false><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
@@ -1549,6 +1583,30 @@ extern "C" int nbp_conv3x3_split_bn_f32(const float* src0, int C0, const float* 
     NBP_RETURN_IF(!bn_part || !bn_rows || ((uintptr_t)bn_part & 7), NBP_E_ARG);
     return conv3x3_split_impl(src0, C0, src1, C1, ups, B, H, W, w_planes, wamax, N, scale, shift, relu, out, amax_in_or_null,
                               amax_out_or_null, split_k, ws, ws_bytes, stream, bn_part, bn_rows);
+}
+
+// out [M][N] = src [M][C] (1x1 convolution) on the split scheme; w_planes / wamax from nbp_pack_conv_weight_split(ksize = 1),
+// or from nbp_pack_conv1x1_weight_split_dgrad for the data gradient (dx = dy W^T); amax_in: the 64-word max-|src| slot (required).
+extern "C" int nbp_conv1x1_split_f32(const float* src, int C, long long M, const void* w_planes, const void* wamax, int N,
+                                     const float* scale, const float* shift, int relu, float* out, const void* amax_in, void* stream) {
+    NBP_ENTER();
+    return nbp_conv1x1_split_launch(src, C, M, w_planes, (const unsigned*)wamax, (const unsigned*)amax_in, N, scale, shift, relu, out,
+                                    (hipStream_t)stream);
+}
+// planes of w^T for the data gradient of a 1x1 layer w [N][C]: a 1x1 convolution from N (dy's channels) to C
+extern "C" int nbp_pack_conv1x1_weight_split_dgrad(const float* w_nc, int N, int C, void* dst_planes, void* wamax_out, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!w_nc || !dst_planes || !wamax_out, NBP_E_ARG);
+    NBP_RETURN_IF(N < 32 || N % 32 || C < 32 || C % 32, NBP_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)N * C;
+    hipError_t e = hipMemsetAsync(wamax_out, 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return (int)e;
+    amax_kernel<<<min(nbp_ew_grid(total, 256), 256), 256, 0, st>>>(w_nc, total, nullptr, C, (unsigned*)wamax_out, 1u);
+    // (transposed form of the pack: rows = C output channels, K = N input channels, w'[c][n] = w[n][c])
+    pack_conv_weight_h2_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(w_nc, C, N, 1, nullptr, 0, (const unsigned*)wamax_out,
+                                                                       (unsigned short*)dst_planes, 1);
+    return nbp_launch_status();
 }
 
 extern "C" int nbp_pack_upconv_weight_split(const float* w_oihw, int N, int C, void* dst_planes, void* wamax_out, void* stream) {

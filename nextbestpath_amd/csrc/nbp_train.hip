@@ -73,8 +73,15 @@ __device__ __forceinline__ f64x4 to_d4(f32x4 v) { return f64x4{(double)v[0], (do
 // The train-mode BatchNorm output of four channels, evaluated in double from the UNROUNDED statistics and rounded once
 // (bn_apply4_kernel).  The backward kernels call the same function on the same inputs to rebuild the ReLU mask (y > 0) from x,
 // which they read anyway, instead of reading y: two of the ten tensor passes a BatchNorm costs per step (round 4).
+// The forward (bn_apply4_kernel) and three backward kernels must round IDENTICALLY for the rebuilt mask to be the forward's: the
+// expression is evaluated without contraction -- sub, mul, mul, add, each rounded -- whatever the surrounding kernel's code looks
+// like to the optimiser (left to the compiler, an fma in one kernel and not in another would flip masks at y = 0).
 __device__ __forceinline__ f32x4 bn_value4(f32x4 x, f64x4 mu, f64x4 is, f64x4 g, f64x4 bt) {
-    const f64x4 r = (to_d4(x) - mu) * is * g + bt;
+#pragma clang fp contract(off)
+    const f64x4 d = to_d4(x) - mu;
+    const f64x4 n = d * is;
+    const f64x4 s = n * g;
+    const f64x4 r = s + bt;
     return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
 }
 struct MaskStat { const double* stat_d; const float* gamma; const float* beta; };     // stat_d = [mean | invstd] doubles, or null: mask from y

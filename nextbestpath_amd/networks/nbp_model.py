@@ -79,6 +79,9 @@ class _Gate(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
 
+_MAX_GRAPHS = 8          # captured forwards kept by NBP.forward_static (each owns a forward workspace)
+
+
 class NBP(nn.Module):
     def __init__(self, img_ch: int = 5, output_ch1: int = 8, output_ch2: int = 1):
         super().__init__()
@@ -131,17 +134,21 @@ class NBP(nn.Module):
 
     def forward_static(self, x: torch.Tensor):
         """Eval forward on a PERSISTENT input tensor (a rollout's net_in): captured once per (tensor, weights) into a hipGraph and
-        replayed (packing.ForwardGraph).  Returns the graph's own out1 / out2, overwritten by the next call on the same x."""
-        if self.training or not x.is_cuda or _COUNTER_COLLECTION:
+        replayed (packing.ForwardGraph).  Returns the graph's own out1 / out2: ALIASED buffers, overwritten by the next call on
+        the same x (Rollout.step consumes them before its next forward; any other caller must copy what it keeps).  A graph owns a
+        forward workspace and keeps x alive, so only the most recently used few are kept (a fresh RolloutState brings a new
+        net_in address).  Inputs a capture cannot take (not contiguous, not fp32) go through forward()."""
+        if self.training or not x.is_cuda or _COUNTER_COLLECTION or not x.is_contiguous() or x.dtype != torch.float32:
             return self.forward(x)
         from . import packing
         packed = self._ensure_packed(x.device)
         key = (x.data_ptr(), tuple(x.shape), id(packed))
-        g = self._graphs.get(key)
+        g = self._graphs.pop(key, None)
         if g is None:
-            if len(self._graphs) >= 64:
-                self._graphs.clear()
-            g = self._graphs[key] = packing.ForwardGraph(packed, x)
+            while len(self._graphs) >= _MAX_GRAPHS:
+                self._graphs.pop(next(iter(self._graphs)))         # least recently used first (dicts keep insertion order)
+            g = packing.ForwardGraph(packed, x)
+        self._graphs[key] = g                                      # (re-inserted: most recently used last)
         return g()
 
     def _apply(self, fn, *a, **k):     # .to() / .cuda() / .float() replace storages

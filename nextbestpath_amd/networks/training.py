@@ -212,6 +212,25 @@ def _conv_split(src0, src1, ups, packed, N, scale, shift, relu, amax=None, bn=Fa
     return out
 
 
+# 1x1 layers (the attention gates' W_g / W_x) and their data gradients on the split scheme through the gates' kernel with one source
+# (csrc/nbp_split.hip: nbp_conv1x1_split_f32) instead of the fp32 pipe's implicit GEMM: no padding of 32 output channels to 64,
+# memory-bound on every level.  NBP_TRAIN_SPLIT_1X1=0: the implicit GEMM.
+_SPLIT_1X1 = _lib.tune("NBP_TRAIN_SPLIT_1X1", "1") == "1"
+
+
+def _conv1x1_ok(M, C, N, c_real):
+    return _SPLIT and _SPLIT_1X1 and C % 32 == 0 and N % 32 == 0 and c_real == C and M * C * 4 < 2 ** 31 and N * C * 4 < 2 ** 31
+
+
+def _conv1x1_split(x, planes, wamax, N, scale, shift, amax):
+    """x [B,H,W,C] -> [B,H,W,N] through the 1x1 split kernel; amax = the 64-word max-|x| slot."""
+    B, H, W, C = x.shape
+    out = torch.empty(B, H, W, N, dtype=torch.float32, device=x.device)
+    _chk(_lib.lib().nbp_conv1x1_split_f32(_lib.ptr(x), C, B * H * W, _lib.ptr(planes), _lib.ptr(wamax), N, _lib.ptr(scale),
+                                          _lib.ptr(shift), 0, _lib.ptr(out), _lib.ptr(amax), _st()), "conv1x1_split")
+    return out
+
+
 def _upconv_ok(Hs, Ws, N):
     """up_conv layers (x2 nearest upsample + 3x3): four 2x2 parity convolutions of the low-resolution input when it tiles."""
     return _SPLIT and Hs % 16 == 0 and ((Ws % 32 == 0 and N % 64 == 0) or (Ws % 16 == 0 and N % 128 == 0))
@@ -256,6 +275,10 @@ class ConvFn(torch.autograd.Function):
         C1 = 0 if x1 is None else x1.shape[3]
         Ctot, Np = C0 + C1, _up(N)
         dev = x0.device
+        M = x0.shape[0] * x0.shape[1] * x0.shape[2]
+        one_by_one = k == 1 and not ups and x1 is None and _conv1x1_ok(M, C0, N, c_real)
+        if one_by_one:
+            Np = N                         # (no padding to 64 columns: the kernel takes 32-column blocks)
         w = weight.detach().contiguous()
         scale = _const(1.0, Np, dev)
         if N == Np:                        # (every 3x3 layer: the bias is the epilogue's shift as it stands)
@@ -274,20 +297,26 @@ class ConvFn(torch.autograd.Function):
         elif _split_ok(H, W, Np, k):
             xmax = _amax_slot(x0, x1)
             y = _conv_split(x0, x1, ups, _pack_split(w, Np, Ctot), Np, scale, shift, False, xmax, bn)
+        elif one_by_one:
+            xmax = _amax_slot(x0)
+            planes = torch.empty(C0 // 16 * 4 * N * 8, dtype=torch.int16, device=dev)
+            wamax = torch.empty(1, dtype=torch.int32, device=dev)
+            _chk(L.nbp_pack_conv_weight_split(_lib.ptr(w), N, C0, 1, None, 0, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_split_1x1")
+            y = _conv1x1_split(x0, planes, wamax, N, scale, shift, xmax)
         else:
             wpk = torch.empty(Ctot // 32 * k * k * Np * 32, dtype=torch.float32, device=dev)
             _chk(L.nbp_pack_conv_weight_padded(_lib.ptr(w), N, c_real, k, Ctot, Np, _lib.ptr(wpk), _st()), "pack_fwd")
             y = _igemm(x0, x1, ups, wpk, Np, k, scale, shift, False)
         ctx.save_for_backward(x0, x1 if x1 is not None else torch.empty(0, device=dev), w)
         ctx.xmax = xmax
-        ctx.meta = (N, c_real, k, C0, C1, Np, bool(ups), x1 is not None)
+        ctx.meta = (N, c_real, k, C0, C1, Np, bool(ups), x1 is not None, one_by_one)
         return _slice_channels(y, 0, N)
 
     @staticmethod
     def backward(ctx, dy):
         L = _lib.lib()
         x0, x1, w = ctx.saved_tensors
-        N, c_real, k, C0, C1, Np, ups, has1 = ctx.meta
+        N, c_real, k, C0, C1, Np, ups, has1, one_by_one = ctx.meta
         x1 = x1 if has1 else None
         dev = dy.device
         info = _noted(dy, "colsum") if dy.is_contiguous() else None       # (max-|dy| slot, column sums): this very tensor's
@@ -303,24 +332,34 @@ class ConvFn(torch.autograd.Function):
         else:
             db = info[1][:N].clone() if info is not None else _colsum(dy.view(M, Np))[:N].clone()
         dw = torch.empty(N, c_real, k, k, dtype=torch.float32, device=dev)
-        ws = _ws(L.nbp_conv_wgrad_workspace_bytes(B, H, W, C0, C1, Np, k), dev)
+        # (the fp32-pipe weight-gradient kernels of the 1x1 layers take 64-column blocks of dy: a 32-channel gate pads here only)
+        dyw, Nw = (dy, Np) if Np % 64 == 0 else (_pad_channels(dy, _up(Np)), _up(Np))
+        ws = _ws(L.nbp_conv_wgrad_workspace_bytes(B, H, W, C0, C1, Nw, k), dev)
         # the 3x3 weight gradients take the split scheme too (the entry point falls through to the fp32 pipe for the rest)
         dymax = None
         if _SPLIT and _WGRAD_SPLIT:
             # max |dy|: shared with the data gradient below; measured by the BatchNorm backward when dy came from one (padding
             # channels are zeros: same maximum)
-            dymax = (info[0] if info is not None else _amax_slot(dy)) if k == 3 else None
-            _chk(L.nbp_conv_wgrad_split_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, int(ups), B, H, W, k, _lib.ptr(dy), Np, c_real, N,
+            dymax = (info[0] if info is not None else _amax_slot(dy)) if (k == 3 or one_by_one) else None
+            _chk(L.nbp_conv_wgrad_split_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, int(ups), B, H, W, k, _lib.ptr(dyw), Nw, c_real, N,
                                             _lib.ptr(dw), _lib.ptr(ctx.xmax), _lib.ptr(ctx.xmax), _lib.ptr(dymax), _lib.ptr(ws),
                                             ws.numel(), _st()), "conv_wgrad_split")
         else:
-            _chk(L.nbp_conv_wgrad_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, int(ups), B, H, W, k, _lib.ptr(dy), Np, c_real, N,
+            _chk(L.nbp_conv_wgrad_f32(_lib.ptr(x0), C0, _lib.ptr(x1), C1, int(ups), B, H, W, k, _lib.ptr(dyw), Nw, c_real, N,
                                       _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _st()), "conv_wgrad")
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             Ctot = C0 + C1
             one, zero = _const(1.0, Ctot, dev), _const(0.0, Ctot, dev)
-            if _split_ok(H, W, Ctot, k):
+            if one_by_one:
+                # dx = dy W^T: a 1x1 convolution from N to C0 channels on the same kernel
+                planes = torch.empty(N // 16 * 4 * C0 * 8, dtype=torch.int16, device=dev)
+                wamax = torch.empty(1, dtype=torch.int32, device=dev)
+                _chk(L.nbp_pack_conv1x1_weight_split_dgrad(_lib.ptr(w), N, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_dgrad_1x1")
+                if dymax is None:
+                    dymax = info[0] if info is not None else _amax_slot(dy)
+                dx = _conv1x1_split(dy, planes, wamax, C0, one, zero, dymax)
+            elif _split_ok(H, W, Ctot, k):
                 # dx = conv3x3(dy, w^T with the taps reversed): output channels = the (padded) input channels
                 if c_real == Ctot and N == Np:
                     # flip + permute + pack in one launch (they were an ATen flip, a strided copy and the pack)

@@ -123,9 +123,11 @@ class LatticePlanner:
 
     # ---- the GPU half of a replan for several rollouts at once (MultiRollout): persistent result buffers, ONE device->host copy
     def result_bytes(self):
-        """Bytes of one rollout's replan results (scores f64 [P] | valid u8 [P] | blocked u8 [E])."""
+        """Bytes of one rollout's replan results (scores f64 [P] | valid u8 [P] | blocked u8 [E]), rounded up to a multiple of 256:
+        MultiRollout lays the rollouts of a group out as ROWS of one buffer, and every row must start 8-byte aligned for its
+        float64 scores (E = 2 W (2 L H - L - H) is a multiple of 8 on square lattices only: pose_l = 10, pose_h = 12 gives 436)."""
         P, E = len(self.idx3), len(self.edges)
-        return (8 * P + P + 7) // 8 * 8 + E
+        return ((8 * P + P + 7) // 8 * 8 + E + 255) // 256 * 256
 
     def share_result_buffers(self, dev_row, pin_row):
         """MultiRollout: this planner's results live in a row of its GROUP's buffers, so that the group needs ONE device -> host
@@ -139,7 +141,7 @@ class LatticePlanner:
             P, E, dev = len(self.idx3), len(self.edges), self.device
             o_valid = 8 * P
             o_blocked = (o_valid + P + 7) // 8 * 8
-            total = o_blocked + E
+            total = self.result_bytes()                  # (o_blocked + E, padded to the row pitch)
             if getattr(self, "_res_dev", None) is None:
                 self._res_dev = torch.empty(total, dtype=torch.uint8, device=dev)
                 self._res_pin = torch.empty(total, dtype=torch.uint8, pin_memory=True)

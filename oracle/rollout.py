@@ -261,12 +261,14 @@ class OracleRollout:
             cand = [(self.nodes[i], scores[i]) for i in np.nonzero(valid)[0]]
             cand.sort(key=lambda t: t[1], reverse=True)                    # stable (:233)
             self.last_candidates = cand
+            self.last_goal = None                                          # (introspection for the parity tests)
             start = tuple(cam.cam_idx[:3])
             cache, cache_version = {}, len(self.collision_list)
             for goal, _ in cand:
                 path = self._dijkstra(start, goal, pose, obst, out1, cache)
                 if path is not None and len(path) > 0:
                     if not self._segment_hits(cam.cam_idx[:3], path[0][:3]):
+                        self.last_goal = goal
                         break
                     c3, n3 = list(cam.cam_idx[:3]), list(path[0][:3])
                     self.collision_list += [[c3, n3], [n3, c3]]

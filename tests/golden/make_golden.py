@@ -429,8 +429,83 @@ def gen_viewstate(mu):
         torch.Tensor.get_device = orig_get_device
 
 
+def gen_camera(ltu, mu):
+    """The pure-torch pieces of the simulator rows A13 / A14 that the reference holds itself (no PyTorch3D arithmetic involved):
+    the NDC tables and pose lattice of Camera.__init__ (macarons_utils.py:2270-2279, 2283-2327), the mask / keep-count logic of
+    compute_partial_point_cloud (:2811-2838; the un-projection itself is PyTorch3D's and is replaced by the identity here, so the
+    returned rows are (ndc_x, ndc_y, depth) of the kept pixels), and obtain_depth's outputs and random draws
+    (long_term_utils.py:50-155) with use_perfect_depth."""
+    H, W = 256, 456
+    renderer = types.SimpleNamespace(rasterizer=types.SimpleNamespace(raster_settings=types.SimpleNamespace(image_size=(H, W))))
+    x_min, x_max = torch.tensor([-24.0, 0.0, -21.0]), torch.tensor([24.0, 12.0, 21.0])
+    cam = mu.Camera(x_min, x_max, 15, 1, 13, 5, 8, 4, 1000.0, renderer, "cpu", contrast_factor=1.0, gathering_factor=0.05)
+    keys = list(cam.pose_space.keys())
+    poses = torch.stack([cam.pose_space[k] for k in keys]).numpy()
+    # ---- compute_partial_point_cloud: identity un-projection, recorded randperm
+    g = torch.Generator().manual_seed(77)
+    depth = torch.rand(1, H, W, 1, generator=g) * 100.0
+    mask = torch.rand(1, H, W, 1, generator=g) < 0.7
+    depth[0, :40] = -1.0                                          # "no hit" rows as zbuf has them
+    mask = mask & (depth > -1)
+    ident = types.SimpleNamespace(unproject_points=lambda pts, scaled_depth_input=False: pts)
+    out = {}
+    for tag, gf, fov_range in [("a", 0.05, 70.0), ("b", 0.3, None), ("c", 0.05, 5.0)]:
+        torch.manual_seed(5)
+        pts = cam.compute_partial_point_cloud(depth, mask, fov_cameras=ident, gathering_factor=gf, fov_range=fov_range)
+        out[f"ppc_{tag}"] = pts.numpy()
+        out[f"ppc_{tag}_args"] = np.array([gf, -1.0 if fov_range is None else fov_range])
+    # ---- obtain_depth with perfect depth: what the rollout consumes is (depth, mask); count the numpy draws it makes
+    params = types.SimpleNamespace(data_augmentation=False, jitter_probability=0.5, symmetry_probability=0.5, znear=0.5, zfar=1000.0,
+                                   n_alpha=2, use_depth_mask=True, pose_factor=1.0, image_height=32, image_width=57, min_depth=0.5, max_depth=1000.0,
+                                   height=32, width=57)
+    B, h, w = 2, 32, 57
+    zb = torch.rand(B, h, w, 1, generator=g) * 60.0
+    zb[:, :5] = -1.0
+    bmask = zb > -1
+    img = torch.rand(B, h, w, 3, generator=g)
+    Rm = torch.eye(3).view(1, 3, 3).repeat(B, 1, 1)
+    Tm = torch.rand(B, 3, generator=g)
+    bd = {"images": img, "mask": bmask, "R": Rm, "T": Tm, "zfar": 1000.0, "zbuf": zb}
+    ad = {"images": img.view(B, 1, h, w, 3).repeat(1, 2, 1, 1, 1), "mask": bmask.view(B, 1, h, w, 1).repeat(1, 2, 1, 1, 1),
+          "R": Rm.view(B, 1, 3, 3).repeat(1, 2, 1, 1), "T": Tm.view(B, 1, 3).repeat(1, 2, 1), "zfar": 1000.0, "zbuf": zb}
+    draws = {"n": 0}
+    orig_rand = np.random.rand
+
+    def counting_rand(*a):
+        draws["n"] += 1
+        return orig_rand(*a)
+    # third-party pieces on obtain_depth's way (stubbed modules here): the relative pose goes through PyTorch3D's quaternion
+    # helpers -- replaced by zeros, the rollout never reads it (nbp_planning.py:90-92) --, and the error mask pads with
+    # torchvision's `pad`, whose reflect mode is torch.nn.functional.pad's
+    ltu.convert_matrix_to_pose = lambda params, R, T, aR, aT: torch.zeros(T.shape[0], aT.shape[1], 6)
+    ltu.pad = lambda img, padding, padding_mode: torch.nn.functional.pad(img, (padding,) * 4, mode=padding_mode)
+    od = {}
+    np.random.rand = counting_rand
+    try:
+        for tag, aug in (("", False), ("_aug", True)):
+            params.data_augmentation = aug
+            params.jitter_probability = params.symmetry_probability = 0.0        # the draws are made, neither branch is taken
+            draws["n"] = 0
+            d, m, em, pose, gtp = ltu.obtain_depth(params, bd, ad, "cpu", use_perfect_depth=True)
+            od.update({f"od_depth{tag}": d.numpy(), f"od_mask{tag}": m.numpy(), f"od_draws{tag}": np.array(draws["n"])})
+        od["od_zbuf"] = zb.numpy()
+        od["od_znear_zfar"] = np.array([params.znear, params.zfar], np.float32)
+    finally:
+        np.random.rand = orig_rand
+    np.savez_compressed(os.path.join(HERE, "camera.npz"), ndc_x=cam.ndc_x_tab.numpy(), ndc_y=cam.ndc_y_tab.numpy(),
+                        ndc_minmax=np.array([float(cam.min_ndc_x), float(cam.max_ndc_x), float(cam.min_ndc_y), float(cam.max_ndc_y)], np.float32),
+                        cam_x_min=cam.x_min.numpy(), pose_keys=np.array(keys), poses=poses, pose_shift=cam.pose_shift.numpy(),
+                        dims=np.array([15, 1, 13, 5, 8]), x_min_in=x_min.numpy(),
+                        depth=depth.numpy()[0, :, :, 0], mask=mask.numpy()[0, :, :, 0], **out, **od)
+    print("camera: ndc_x", float(cam.ndc_x_tab.min()), float(cam.ndc_x_tab.max()), "poses", poses.shape,
+          "ppc", {k: v.shape for k, v in out.items() if not k.endswith("args")}, "obtain_depth", {k: getattr(v, "shape", v) for k, v in od.items()})
+
+
 if __name__ == "__main__":
     model, utils, ltu, mu = import_reference()
+    if "--only-camera" in sys.argv:
+        gen_camera(ltu, mu)
+        sys.exit(0)
     if "--only-viewstate" in sys.argv:
         gen_viewstate(mu)
         sys.exit(0)
@@ -445,6 +520,7 @@ if __name__ == "__main__":
     gen_replan(utils, ltu, mu)
     gen_scene(mu)
     gen_viewstate(mu)
+    gen_camera(ltu, mu)
     gen_network(model)
     gen_training(model)
     gen_training(model, B=4, S=128, K=40, tag="S128B4")

@@ -11,9 +11,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, env=None):
+def _run(extra, env=None, live=False):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--advance", "2",
-                        "--rollouts-per-gpu", "2", "--no-live-traffic", "--no-extra-stages", "--strong-scenes", "3", "--strong-advance", "1"] + extra,
+                        "--rollouts-per-gpu", "2", "--no-extra-stages", "--strong-scenes", "3", "--strong-advance", "1"]
+                       + ([] if live else ["--no-live-traffic"]) + extra,
                        capture_output=True, text=True, timeout=1200, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -34,6 +35,26 @@ def test_bench_single_gpu_line(hip):
     assert d["tuning"] == {"active": False, "non_default_knobs": {}, "numerics_affecting": []}
     assert cpu["kind"] == "port" and cpu["value"] > 0 and set(cpu["legs_ms"]) == {"nbp_forward", "raster", "unproject",
                                                                                  "map_accumulate", "coverage"}
+
+
+def test_bench_live_traffic_pass_finds_the_dominant_kernel(hip):
+    """the rocprofv3 PMC passes bench.py runs itself must find the dominant kernel by the symbol the LIBRARY
+    reports (nbp_tile_kernel_symbol) -- a name table in bench.py went stale when the kernel grew template parameters and the line
+    silently carried a committed figure of an older round."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    d = _run(["--no-cpu-baseline", "--no-strong"], live=True)
+    rf, sc = d["roofline"], d["roofline_scatter"]
+    assert rf["kernel_symbol"].startswith("conv3x3_halo_h2_kernel<") and rf["kernel_symbol"].endswith(">")
+    assert rf["traffic_is_live"] is True and rf["traffic_source"].startswith("rocprofv3"), rf["traffic_source"]
+    assert rf["traffic"] > 0 and 0.5 < rf["traffic_over_algorithmic"] < 4.0
+    assert sc["traffic_is_live"] is True and sc["traffic"] > 0
+    assert all(k.startswith(("conv3x3_halo_h2_kernel<", "tile ")) for k in rf["by_kernel"])
+    for key in ("train_maps_per_s", "bf16_512_b8_frac", "fwd_b1_ms", "single_rollout_steps_per_s", "lockstep_forward_share",
+                "value_fp32_pipe", "all_conv_frac_executed", "roofline_traffic_is_live"):
+        assert key in d                                      # top-level scalars (None for the stages --no-extra-stages skips)
+    assert d["fwd_b1_ms"] > 0 and 0 < d["lockstep_forward_share"] < 2 and d["roofline_traffic_is_live"] is True
 
 
 def test_bench_gpus_flag_launches_the_ranks(hip):

@@ -107,6 +107,44 @@ def test_multi_rollout_matches_single(hip, dataset, nbp_weights):
         assert ca == cb
 
 
+def test_multi_rollout_on_a_non_square_lattice(hip, nbp_weights, tmp_path):
+    """the rollouts of a group keep their replanning results as ROWS of one buffer; a row holds float64 scores,
+    so the row pitch must be a multiple of 8 whatever the lattice -- E = 2 W (2 L H - L - H) directed edges is a multiple of 8 on
+    square lattices only (13 x 15 gives 724).  Four rollouts in two groups of two walk the single rollouts' trajectories."""
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.simulator.mesh import make_maze_scene
+    from nextbestpath_amd.testers import nbp_planning as tp
+    for i in range(2):
+        make_maze_scene(str(tmp_path / f"rect_{i}"), seed=20 + i, cells=8, size=4.8, height=1.2, tess=0.3)
+        path = tmp_path / f"rect_{i}" / "settings.json"
+        st = json.loads(path.read_text())
+        assert st["camera"]["pose_l"] == 15
+        st["camera"]["pose_l"] = 13                              # 13 x 15 positions over the same extent
+        st["camera"]["start_positions"] = [[min(p[0], 11)] + p[1:] for p in st["camera"]["start_positions"]]
+        path.write_text(json.dumps(st))
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    ds = sc.SceneDataset(str(tmp_path))
+    net = _net(nbp_weights)
+    dev = torch.device("cuda")
+    n = 8
+    singles = [tp.build_rollout(params, net, ds, (k % 2, 0), dev, seed=3 + k) for k in range(4)]
+    E = len(singles[0].planner.edges)
+    assert E % 8 != 0 and singles[0].planner.result_bytes() % 8 == 0
+    for r in singles:
+        for _ in range(n):
+            r.step()
+    multi_r = [tp.build_rollout(params, net, ds, (k % 2, 0), dev, seed=3 + k) for k in range(4)]
+    m = tp.MultiRollout(multi_r, net, dev)
+    assert all(len(g) == 2 for g in m.groups) and all(res is not None for res in m._res)
+    for _ in range(n):
+        m.step()
+    m.flush()
+    assert sum(r.n_replans for r in multi_r) > 0
+    for a, b in zip(singles, multi_r):
+        assert a.camera.cam_idx_history == b.camera.cam_idx_history
+        assert a.coverage_evolution(n) == b.coverage_evolution(n)
+
+
 def test_dead_forward_elision_changes_nothing(hip, dataset, nbp_weights):
     """MultiRollout(elide_dead_forward=True) forwards only the maps of the rollouts that replan (the reference discards the
     network's output on the other steps, nbp_planning.py:252): trajectories, clouds and coverage are those of the default mode,

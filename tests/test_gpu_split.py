@@ -373,3 +373,48 @@ def test_split_network_with_a_spike_in_the_input(hip, nets, nbp_weights):
     assert torch.isfinite(o1).all() and torch.isfinite(o2).all()
     assert es.max().item() <= max(1e-4 * rng, 3.0 * ef.max().item()) and es.mean().item() <= max(1e-6 * rng, 3.0 * ef.mean().item())
     assert torch.equal(o1.cpu().amax(1).flatten(1).argmax(1), d1.float().amax(1).flatten(1).argmax(1))
+
+
+# (pixels as B, H, W; input channels; output channels)
+CASES_1X1 = [(2, 16, 32, 64, 32), (1, 25, 40, 128, 64), (2, 8, 8, 512, 256), (3, 16, 16, 32, 64), (1, 16, 16, 256, 512), (1, 7, 9, 96, 160)]
+
+
+@pytest.mark.parametrize("case", CASES_1X1)
+def test_conv1x1_split_vs_fp64(hip, case):
+    """nbp_conv1x1_split_f32 (training's W_g / W_x layers: the gates' kernel with one source) and its data gradient through
+    nbp_pack_conv1x1_weight_split_dgrad against float64: the split scheme's error (<= a few 2^-24 of sum |terms|), whole-range
+    pixel counts (M not a multiple of the 128-pixel workgroup), 1 .. 16 stages of 32 channels (K not a multiple of 128)."""
+    B, H, W, C, N = case
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    x = (_rand(B, H, W, C, seed=C + N) * torch.logspace(-2, 0, C)).cuda().contiguous()
+    w = (_rand(N, C, 1, 1, seed=N) / np.sqrt(C)).cuda().contiguous()
+    bias = _rand(N, seed=3).cuda()
+    M = B * H * W
+
+    def run(src, Cin, planes, wamax, Nout, shift):
+        slot = torch.zeros(64, dtype=torch.int32, device="cuda")
+        _lib.check(L.nbp_amax_f32(src.data_ptr(), src.numel(), slot.data_ptr(), st), "amax")
+        out = torch.full((B, H, W, Nout), float("nan"), device="cuda")
+        one = torch.ones(Nout, device="cuda")
+        _lib.check(L.nbp_conv1x1_split_f32(src.data_ptr(), Cin, M, planes.data_ptr(), wamax.data_ptr(), Nout, one.data_ptr(),
+                                           shift.data_ptr(), 0, out.data_ptr(), slot.data_ptr(), st), "conv1x1_split")
+        return out
+    planes = torch.empty(C // 16 * 4 * N * 8, dtype=torch.int16, device="cuda")
+    wamax = torch.empty(1, dtype=torch.int32, device="cuda")
+    _lib.check(L.nbp_pack_conv_weight_split(w.data_ptr(), N, C, 1, None, 0, C, planes.data_ptr(), wamax.data_ptr(), st), "pack")
+    y = run(x, C, planes, wamax, N, bias)
+    xd, wd = x.double().view(M, C), w.double().view(N, C)
+    want = xd @ wd.t() + bias.double()
+    mag = xd.abs() @ wd.abs().t() + bias.double().abs()
+    err = (y.double().view(M, N) - want).abs()
+    assert bool(torch.isfinite(y).all()) and float((err / mag).max()) < 4e-7, float((err / mag).max())
+    # data gradient: dx = dy W (w^T packed straight from the layer's [N][C] weight)
+    dy = _rand(B, H, W, N, seed=7).cuda().contiguous()
+    planes_t = torch.empty(N // 16 * 4 * C * 8, dtype=torch.int16, device="cuda")
+    _lib.check(L.nbp_pack_conv1x1_weight_split_dgrad(w.data_ptr(), N, C, planes_t.data_ptr(), wamax.data_ptr(), st), "pack_dgrad")
+    dx = run(dy, N, planes_t, wamax, C, torch.zeros(C, device="cuda"))
+    want = dy.double().view(M, N) @ wd
+    mag = dy.double().abs().view(M, N) @ wd.abs()
+    err = (dx.double().view(M, C) - want).abs()
+    assert float((err / mag.clamp_min(1e-30)).max()) < 4e-7, float((err / mag.clamp_min(1e-30)).max())

@@ -106,3 +106,48 @@ def test_training_oracle_vs_reference(nbp_weights, golden_dir, tag):
         ref = g[kk]
         err = np.abs(got[::int(stride)].numpy() - ref).max()
         assert err < 2e-3 * max(np.abs(ref).max(), 1e-6), (k, err)
+
+
+def test_camera_tables_and_sampling_logic_vs_reference(golden_dir):
+    """VERDICT r04 missing 2: the pure-torch pieces of rows A13 / A14 as the reference itself computes them
+    (tests/golden/camera.npz, generated by make_golden.py::gen_camera from the imported reference): Camera.__init__'s NDC tables
+    and pose lattice (macarons_utils.py:2270-2279, 2283-2327), compute_partial_point_cloud's mask and keep count (:2811-2838, the
+    PyTorch3D un-projection replaced by the identity), obtain_depth's depth / mask outputs and numpy draws
+    (long_term_utils.py:50-155)."""
+    from oracle import camera as ocam
+    g = _load(golden_dir, "camera.npz")
+    H, W = g["ndc_x"].shape
+    nx, ny = ocam.ndc_tables(H, W)
+    assert nx.dtype == np.float32 and np.array_equal(nx, g["ndc_x"]) and np.array_equal(ny, g["ndc_y"])      # bit for bit
+    assert np.array_equal(np.array([nx[-1, -1], nx[0, 0], ny[-1, -1], ny[0, 0]], np.float32), g["ndc_minmax"])
+    # the pose lattice: same order as the reference's dict (string keys of the index rows), same fp32 values
+    L, Wd, Hd, E, A = (int(v) for v in g["dims"])
+    idx, poses = ocam.pose_lattice(g["x_min_in"], L, Wd, Hd, E, A)
+    assert [str(list(r)) for r in idx] == [str(k) for k in g["pose_keys"]]
+    assert np.array_equal(poses, g["poses"])
+    assert np.array_equal(g["cam_x_min"], g["x_min_in"] + 3)            # (self.x_min is shifted; the poses are offset from the argument)
+    # compute_partial_point_cloud: which pixels are candidates, how many are kept
+    depth, mask = g["depth"], g["mask"]
+    for tag in "abc":
+        gf, fr = float(g[f"ppc_{tag}_args"][0]), float(g[f"ppc_{tag}_args"][1])
+        fov_range = np.inf if fr < 0 else fr
+        ref = g[f"ppc_{tag}"]                                          # rows (ndc_x, ndc_y, depth) of the kept pixels
+        pts, n_valid = ocam.partial_point_cloud(depth, mask, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), gf, fov_range, seed=1)
+        assert len(pts) == len(ref) == int(n_valid * gf)
+        valid = (mask != 0) & (depth < np.float32(fov_range))
+        assert int(valid.sum()) == n_valid
+        rows = np.stack([nx[valid], ny[valid], depth[valid]], 1)
+        have = {r.tobytes() for r in rows}
+        got = [r.tobytes() for r in np.ascontiguousarray(ref)]
+        assert len(set(got)) == len(got) and all(r in have for r in got)      # a duplicate-free subset of exactly the candidates
+    # obtain_depth with perfect depth: depth = clamp(zbuf, znear, zfar), the mask is the input mask (zbuf > -1), and the two
+    # numpy draws are made only under data augmentation (the rollout's config has none): the product derives the mask in its
+    # un-projection kernel and draws nothing
+    zb = g["od_zbuf"]
+    zn, zf = g["od_znear_zfar"]
+    for tag, n in (("", 0), ("_aug", 2)):
+        assert int(g[f"od_draws{tag}"]) == n
+        assert np.array_equal(g[f"od_mask{tag}"], zb > -1)
+        assert np.array_equal(g[f"od_depth{tag}"], np.clip(zb, zn, zf))
+    m_none = ocam.partial_point_cloud(zb[0, :, :, 0], None, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), 1.0, np.inf, seed=1)[1]
+    assert m_none == int((zb[0] > -1).sum())

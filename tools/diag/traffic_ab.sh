@@ -3,6 +3,7 @@ set -u
 REPO=$(pwd); export TMPDIR=/tmp; cd /tmp
 for mode in auto 1 0; do
   for c in FETCH_SIZE WRITE_SIZE; do
+    export NBP_TUNING=1      # the A/B switches are ignored without the opt-in (csrc/nbp_tuning.cpp)
     if [ $mode = auto ]; then unset NBP_XCD_REMAP; else export NBP_XCD_REMAP=$mode; fi
     rocprofv3 --pmc $c --output-format csv -d $REPO/gpurun_out/tab/$mode/pmc_$c -o pmc -- python $REPO/tools/pmc_workload.py --precision fp32_split --batch 8 --size 256 --points 0 > /dev/null 2>&1
   done
