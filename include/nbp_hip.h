@@ -633,7 +633,8 @@ int nbp_bn_train_backward_fused_f32(const float* dy, const float* x, const float
                                     float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* amax_out,
                                     void* ws, size_t ws_bytes, void* stream);
 /* Round 4: the backward without reading y.  nbp_bn_train_forward_stat_f32 = nbp_bn_train_forward_amax_f32 that also hands out the
- * UNROUNDED statistics the normalisation used (stat_out: [2 C] doubles, mean | invstd, 32-byte aligned);
+ * UNROUNDED statistics the normalisation used (stat_out: [4 C] doubles, 32-byte aligned: mean | invstd | lo | hi, the last two with
+ * relu only: y > 0 <=> lo <= x <= hi exactly, two floats per channel found by bisection with the forward's own arithmetic);
  * nbp_bn_train_backward_stat_f32 = nbp_bn_train_backward_fused_f32 whose ReLU mask (y > 0) is rebuilt from x -- which the pass
  * reads anyway -- through the forward's own arithmetic on those statistics (C % 4 == 0): two tensor reads less per BatchNorm and
  * step, the same mask bit for bit. */

@@ -612,13 +612,14 @@ __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
     for (int d = 0; d < D - 1; ++d) load_x(d, d);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int base = 0; base < stages; base += D) {            // (stages past the end: zero pixels x stale weights = zero products)
+    for (int base = 0; base < stages; base += D) {            // (the last round may hold stages past the end: loads return zeros, MFMAs are skipped)
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const int st = base + u;
             if (st + 1 < stages) issue_w(st + 1);
             load_x(st + D - 1, (u + D - 1) % D);               // past the end: out-of-range offsets (zeros), never used
             const char* Bt = wbuf + (st & 1) * WST + khalf * (BN * 16) + (lane & 31) * 16;
+            if (st < stages)               // (uniform; a stage past the end has no weights in LDS: never-written LDS may hold NaN patterns)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const f32x4 v0 = __builtin_bit_cast(f32x4, xr[u][ks][0]), v1 = __builtin_bit_cast(f32x4, xr[u][ks][1]);

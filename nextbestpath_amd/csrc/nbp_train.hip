@@ -84,7 +84,47 @@ __device__ __forceinline__ f32x4 bn_value4(f32x4 x, f64x4 mu, f64x4 is, f64x4 g,
     const f64x4 r = s + bt;
     return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
 }
-struct MaskStat { const double* stat_d; const float* gamma; const float* beta; };     // stat_d = [mean | invstd] doubles, or null: mask from y
+// stat_d = [mean | invstd | lo | hi] doubles (nbp_bn_train_forward_stat_f32), or null: mask from y.
+// lo / hi: bn_value is a composition of rounded monotone operations, hence monotone in x (direction = sign of gamma), so the
+// forward's ReLU mask (y > 0) is EXACTLY lo <= x <= hi for two floats found once per channel by bisection over the ordered floats
+// with the forward's own arithmetic (bn_finalize_kernel).  The backward kernels test two fp32 compares per element instead of
+// re-evaluating six double-precision operations: they were co-limited by the fp64 pipe (3.0 - 3.8 TB/s; round 5).
+struct MaskStat { const double* stat_d; const float* gamma; const float* beta; };
+__device__ __forceinline__ float bn_value1(float x, double mu, double is, double g, double bt) {      // bn_value4, one element
+#pragma clang fp contract(off)
+    const double d = (double)x - mu;
+    const double n = d * is;
+    const double s = n * g;
+    const double r = s + bt;
+    return (float)r;
+}
+// order-preserving map between non-NaN floats and signed integers (its own inverse)
+__device__ __forceinline__ int float_key(int bits) { return bits ^ ((bits >> 31) & 0x7fffffff); }
+// lo <= x <= hi  <=>  bn_value1(x) > 0, for finite x
+__device__ inline void bn_mask_bounds(double mu, double is, double g, double bt, float* lo_out, float* hi_out) {
+    const float INF = __int_as_float(0x7f800000), FMAX = __int_as_float(0x7f7fffff);
+    auto P = [&](int key) { return bn_value1(__int_as_float(float_key(key)), mu, is, g, bt) > 0.f; };
+    const int kmin = float_key(__float_as_int(-FMAX)), kmax = float_key(__float_as_int(FMAX));
+    float lo = INF, hi = -INF;                               // never
+    if (!(g > 0.0) && !(g < 0.0)) {                          // gamma == 0 (or NaN): y = beta for every finite x
+        if (P(float_key(0))) { lo = -INF; hi = INF; }
+    } else if (g > 0.0) {                                    // increasing: the smallest x with y > 0
+        if (P(kmin)) { lo = -INF; hi = INF; }
+        else if (P(kmax)) {
+            long long a = kmin, b = kmax;                    // P(a) false, P(b) true
+            while (b - a > 1) { const long long m = a + (b - a) / 2; if (P((int)m)) b = m; else a = m; }
+            lo = __int_as_float(float_key((int)b)); hi = INF;
+        }
+    } else {                                                 // decreasing: the largest x with y > 0
+        if (P(kmax)) { lo = -INF; hi = INF; }
+        else if (P(kmin)) {
+            long long a = kmin, b = kmax;                    // P(a) true, P(b) false
+            while (b - a > 1) { const long long m = a + (b - a) / 2; if (P((int)m)) a = m; else b = m; }
+            lo = -INF; hi = __int_as_float(float_key((int)a));
+        }
+    }
+    *lo_out = lo; *hi_out = hi;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -105,28 +145,35 @@ __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict
         const int c = c0 + c_local;
         f64x4 s0 = {0.0, 0.0, 0.0, 0.0}, s1 = {0.0, 0.0, 0.0, 0.0};
         if (rsub < rpb && c < C4) {
-            f64x4 mu = {0.0, 0.0, 0.0, 0.0}, is = {0.0, 0.0, 0.0, 0.0};
-            if (MODE == 1) { mu = to_d4(reinterpret_cast<const f32x4*>(mean)[c]); is = to_d4(reinterpret_cast<const f32x4*>(invstd)[c]); }
+            f64x4 mu = {0.0, 0.0, 0.0, 0.0};
             if (MODE == 0) mu = to_d4(a4[c]);  // shift = the first row (see colreduce_kernel)
-            f64x4 mmu = mu, mis = is, mg = mu, mbt = mu;       // MODE 1, mask from the statistics: the forward's unrounded mean / invstd
+            // MODE 1, mask from the statistics: two fp32 bounds per channel (MaskStat)
             const bool stat_mask = MODE == 1 && relu && ms.stat_d;
+            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
             if (stat_mask) {
-                mmu = reinterpret_cast<const f64x4*>(ms.stat_d)[c]; mis = reinterpret_cast<const f64x4*>(ms.stat_d + 4 * (size_t)C4)[c];
-                mg = to_d4(reinterpret_cast<const f32x4*>(ms.gamma)[c]); mbt = to_d4(reinterpret_cast<const f32x4*>(ms.beta)[c]);
+                const f64x4 l = reinterpret_cast<const f64x4*>(ms.stat_d + 8 * (size_t)C4)[c], h = reinterpret_cast<const f64x4*>(ms.stat_d + 12 * (size_t)C4)[c];
+                lo = f32x4{(float)l[0], (float)l[1], (float)l[2], (float)l[3]}; hi = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
             }
             auto step = [&](long long r) {
                 const f32x4 v = a4[r * C4 + c];
                 if (MODE == 0) { const f64x4 d = to_d4(v) - mu; s0 += d; s1 += d * d; }
                 if (MODE == 1) {
+                    // s1 = sum dz x (RAW: the finalizer turns it into sum dz xhat = invstd (s1 - mean s0), in double): two
+                    // double operations per element here instead of five
                     f32x4 dz = v;
                     const f32x4 xv = b4[r * C4 + c];
                     if (relu) {
-                        const f32x4 yy = stat_mask ? bn_value4(xv, mmu, mis, mg, mbt) : y4[r * C4 + c];
+                        if (stat_mask) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
+                            for (int e = 0; e < 4; ++e) if (!(xv[e] >= lo[e] && xv[e] <= hi[e])) dz[e] = 0.f;
+                        } else {
+                            const f32x4 yy = y4[r * C4 + c];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
+                        }
                     }
                     const f64x4 dzd = to_d4(dz);
-                    s0 += dzd; s1 += dzd * ((to_d4(xv) - mu) * is);
+                    s0 += dzd; s1 += dzd * to_d4(xv);
                 }
                 if (MODE == 2) s0 += to_d4(v) * (double)(rows ? rows[r] : 1.f);
             };
@@ -179,7 +226,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           const double* __restrict__ part, int nblk, int C, long long M, float eps,
                                                           float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                          double* __restrict__ stat_d) {
+                                                          double* __restrict__ stat_d, const float* __restrict__ gamma = nullptr,
+                                                          const float* __restrict__ beta = nullptr) {
     __shared__ double sh[FIN_SL][2][FIN_CH];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, ks = threadIdx.x / FIN_CH;
     double s0, s1;
@@ -192,6 +240,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     stat_d[c] = mu; stat_d[C + c] = 1.0 / sqrt(var + (double)eps);      // unrounded, for the forward normalisation
+    if (gamma) {                // the ReLU mask of this channel as two float bounds (MaskStat): [2C, 3C) lo, [3C, 4C) hi
+        float lo, hi;
+        bn_mask_bounds(mu, 1.0 / sqrt(var + (double)eps), (double)gamma[c], (double)beta[c], &lo, &hi);
+        stat_d[2 * C + c] = (double)lo; stat_d[3 * C + c] = (double)hi;
+    }
     if (run_mean) {
         const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
         run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mu);
@@ -200,14 +253,18 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 
 // finalize generic: out0[c] (+ out1[c]) = sum over blocks
+// raw_mean / raw_invstd (not null): the second sum is sum dz x (colreduce4_kernel<1>) and becomes sum dz xhat here
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ part, int nblk, int C,
                                                               float* __restrict__ out0, float* __restrict__ out1,
-                                                              double* __restrict__ out_d = nullptr) {
+                                                              double* __restrict__ out_d = nullptr,
+                                                              const float* __restrict__ raw_mean = nullptr,
+                                                              const float* __restrict__ raw_invstd = nullptr) {
     __shared__ double sh[FIN_SL][2][FIN_CH];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, ks = threadIdx.x / FIN_CH;
     double s0, s1;
     colsum_pair(part, nblk, C, c, ks, sh, &s0, &s1);
     if (c >= C || ks != 0) return;
+    if (raw_mean) s1 = (double)raw_invstd[c] * (s1 - (double)raw_mean[c] * s0);
     if (out0) out0[c] = (float)s0;
     if (out1) out1[c] = (float)s1;
     if (out_d) { out_d[c] = s0; out_d[C + c] = s1; }          // unrounded sums for the backward apply
@@ -303,6 +360,44 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict_
     if (amax_out) train_wave_amax(mx, amax_out);
 }
 
+// dx = gamma invstd (dz - (dbeta + xhat dgamma) / M) as an AFFINE form per channel, dx = A dz + (B x + D) with
+//   A = gamma invstd,  B = -A invstd dgamma / M,  D = -A (dbeta - mean invstd dgamma) / M
+// evaluated in double and rounded once: two fused multiply-adds per element instead of six double operations (the large terms
+// B x and D cancel to ~|mean| / std of their size: 1e-16 relative of that in double).  The ReLU mask comes from the two float
+// bounds of MaskStat (or from y).
+struct BnAffine { f64x4 A, B, D; f32x4 lo, hi; };
+__device__ __forceinline__ BnAffine bn_affine4(int c, int C4, const float* mean, const float* invstd, const float* gamma, const double* sums,
+                                               double invM, const MaskStat& ms, bool stat_mask) {
+    BnAffine k;
+    const f64x4 mu = to_d4(reinterpret_cast<const f32x4*>(mean)[c]), is = to_d4(reinterpret_cast<const f32x4*>(invstd)[c]);
+    const f64x4 g = to_d4(reinterpret_cast<const f32x4*>(gamma)[c]);
+    const f64x4 kb = reinterpret_cast<const f64x4*>(sums)[c], kg = reinterpret_cast<const f64x4*>(sums + 4 * (size_t)C4)[c];
+    k.A = g * is;
+    k.B = -(k.A * is * kg) * invM;
+    k.D = -(k.A * (kb - mu * is * kg)) * invM;
+    k.lo = f32x4{0.f, 0.f, 0.f, 0.f}; k.hi = k.lo;
+    if (stat_mask) {
+        const f64x4 l = reinterpret_cast<const f64x4*>(ms.stat_d + 8 * (size_t)C4)[c], h = reinterpret_cast<const f64x4*>(ms.stat_d + 12 * (size_t)C4)[c];
+        k.lo = f32x4{(float)l[0], (float)l[1], (float)l[2], (float)l[3]}; k.hi = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    }
+    return k;
+}
+__device__ __forceinline__ f32x4 bn_dx4(f32x4 dz, f32x4 xv, f32x4 yy, const BnAffine& k, int relu, bool stat_mask) {
+    if (relu) {
+        if (stat_mask) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (!(xv[e] >= k.lo[e] && xv[e] <= k.hi[e])) dz[e] = 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
+        }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (float)fma(k.A[e], (double)dz[e], fma(k.B[e], (double)xv[e], k.D[e]));
+    return o;
+}
+
 __global__ __launch_bounds__(256) void bn_backward_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                  const float* __restrict__ y, long long total4, int C4,
                                                                  long long M, const float* __restrict__ mean,
@@ -315,32 +410,19 @@ __global__ __launch_bounds__(256) void bn_backward_apply4_kernel(const float* __
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
     f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
-    const f64x4* db4 = reinterpret_cast<const f64x4*>(sums);
-    const f64x4* dg4 = reinterpret_cast<const f64x4*>(sums + 4 * (size_t)C4);
     const bool stat_mask = relu && ms.stat_d;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
-        const f64x4 mu = to_d4(reinterpret_cast<const f32x4*>(mean)[c]), is = to_d4(reinterpret_cast<const f32x4*>(invstd)[c]);
-        const f64x4 g = to_d4(reinterpret_cast<const f32x4*>(gamma)[c]);
-        f32x4 dz = dy4[i];
+        const BnAffine k = bn_affine4(c, C4, mean, invstd, gamma, sums, invM, ms, stat_mask);
         const f32x4 xv = x4[i];
-        if (relu) {
-            const f32x4 yy = stat_mask ? bn_value4(xv, reinterpret_cast<const f64x4*>(ms.stat_d)[c],
-                                                   reinterpret_cast<const f64x4*>(ms.stat_d + 4 * (size_t)C4)[c], g,
-                                                   to_d4(reinterpret_cast<const f32x4*>(ms.beta)[c])) : y4[i];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
-        }
-        const f64x4 xhat = (to_d4(xv) - mu) * is;
-        const f64x4 r = g * is * (to_d4(dz) - invM * (db4[c] + xhat * dg4[c]));
-        dx4[i] = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+        dx4[i] = bn_dx4(dy4[i], xv, (relu && !stat_mask) ? y4[i] : xv, k, relu, stat_mask);
     }
 }
 
 // The same with the consumers' passes folded in: the convolution in front of this BatchNorm needs sum_m dx[m][c] (its bias
 // gradient) and max |dx| (the split scheme's scale of its data / weight gradients) -- two more reads of dx as separate kernels.
-// Thread layout of colreduce4_kernel (a thread owns one float4 column and the rows rsub + k rpb of its block), the column
-// sums of the ROUNDED dx in double, per-block partials [block][2][C] for colsum_finalize_kernel.
+// Thread layout of colreduce4_kernel (a thread owns one float4 column and the rows rsub + k rpb of its block, four rows in flight),
+// the column sums of the ROUNDED dx in double, per-block partials [block][2][C] for colsum_finalize_kernel.
 __global__ __launch_bounds__(256) void bn_backward_apply4_sum_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                      const float* __restrict__ y, long long M, int C4,
                                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -356,39 +438,37 @@ __global__ __launch_bounds__(256) void bn_backward_apply4_sum_kernel(const float
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
     f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
-    const f64x4* db4 = reinterpret_cast<const f64x4*>(sums);
-    const f64x4* dg4 = reinterpret_cast<const f64x4*>(sums + 4 * (size_t)C4);
     const long long r_begin = (long long)blockIdx.x * rows_per_block;
     const long long r_end = r_begin + rows_per_block < M ? r_begin + rows_per_block : M;
+    const bool stat_mask = relu && ms.stat_d;
+    const bool from_y = relu && !stat_mask;
     float mx = 0.f;
     for (int c0 = 0; c0 < C4; c0 += CT) {
         const int c = c0 + c_local;
         f64x4 s0 = {0.0, 0.0, 0.0, 0.0};
         if (rsub < rpb && c < C4) {
-            const f64x4 mu = to_d4(reinterpret_cast<const f32x4*>(mean)[c]), is = to_d4(reinterpret_cast<const f32x4*>(invstd)[c]);
-            const f64x4 g = to_d4(reinterpret_cast<const f32x4*>(gamma)[c]);
-            const f64x4 kb = db4[c], kg = dg4[c];
-            const bool stat_mask = relu && ms.stat_d;
-            f64x4 mmu = mu, mis = is, mbt = mu;
-            if (stat_mask) {
-                mmu = reinterpret_cast<const f64x4*>(ms.stat_d)[c]; mis = reinterpret_cast<const f64x4*>(ms.stat_d + 4 * (size_t)C4)[c];
-                mbt = to_d4(reinterpret_cast<const f32x4*>(ms.beta)[c]);
-            }
-            for (long long r = r_begin + rsub; r < r_end; r += rpb) {
-                const long long i = r * C4 + c;
-                f32x4 dz = dy4[i];
-                const f32x4 xv = x4[i];
-                if (relu) {
-                    const f32x4 yy = stat_mask ? bn_value4(xv, mmu, mis, g, mbt) : y4[i];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (!(yy[e] > 0.f)) dz[e] = 0.f;
-                }
-                const f64x4 xhat = (to_d4(xv) - mu) * is;
-                const f64x4 rr = g * is * (to_d4(dz) - invM * (kb + xhat * kg));
-                const f32x4 o = f32x4{(float)rr[0], (float)rr[1], (float)rr[2], (float)rr[3]};
+            const BnAffine k = bn_affine4(c, C4, mean, invstd, gamma, sums, invM, ms, stat_mask);
+            auto emit = [&](long long i, f32x4 dz, f32x4 xv, f32x4 yy) {
+                const f32x4 o = bn_dx4(dz, xv, yy, k, relu, stat_mask);
                 dx4[i] = o;
                 s0 += to_d4(o);
                 mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+            };
+            long long r = r_begin + rsub;
+            for (; r + 3 * rpb < r_end; r += 4 * rpb) {          // four rows in flight (8 - 12 loads), the sums in row order
+                f32x4 dz[4], xv[4], yy[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long i = (r + u * rpb) * C4 + c;
+                    dz[u] = dy4[i]; xv[u] = x4[i]; yy[u] = from_y ? y4[i] : xv[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) emit((r + u * rpb) * C4 + c, dz[u], xv[u], yy[u]);
+            }
+            for (; r < r_end; r += rpb) {
+                const long long i = r * C4 + c;
+                const f32x4 xv = x4[i];
+                emit(i, dy4[i], xv, from_y ? y4[i] : xv);
             }
         }
         sh0[threadIdx.x] = s0;
@@ -998,7 +1078,8 @@ extern "C" size_t nbp_colreduce_workspace_bytes(long long M, int C) {
 }
 
 // amax_out (or null): 64 zeroed words that receive max |y| (float bits; only for C % 4 == 0, else left untouched)
-// stat_out (or null): [2 C] doubles that receive the UNROUNDED mean | invstd the normalisation used -- handed to
+// stat_out (or null): [4 C] doubles that receive the UNROUNDED mean | invstd the normalisation used and, with relu, the two float
+// bounds lo | hi of the channel's ReLU mask (y > 0 <=> lo <= x <= hi, MaskStat) -- handed to
 // nbp_bn_train_backward_stat_f32, which rebuilds the ReLU mask from x with them instead of reading y
 static int bn_forward_impl(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
                            float momentum, float* running_mean, float* running_var, int relu, float* mean,
@@ -1042,8 +1123,10 @@ static int bn_forward_impl(const float* x, long long M, int C, const float* gamm
         if (!stat_d) stat_d = p + (((size_t)nblk * 2 * C + 31) / 32 * 32);        // [2][C] unrounded mean, invstd (32-B aligned)
     }
     // (external partials -- the producing convolution's epilogue -- are sums of x and x^2 themselves: the shift row is zeros)
+    // (stat_out: the caller's [4 C] doubles -- the ReLU mask's two bounds per channel are found here too)
     bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, FIN_CH), 256, 0, st>>>(ext_part ? zero_row : x, part, nblk, C, M, eps, momentum, mean, invstd,
-                                                                      running_mean, running_var, stat_d);
+                                                                      running_mean, running_var, stat_d, (stat_out && relu) ? gamma : nullptr,
+                                                                      beta);
     if ((rc = nbp_launch_status())) return rc;
     if (C % 4 == 0) bn_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(x, M * C / 4, C / 4, stat_d, gamma, beta, relu, y, amax_out);
     else bn_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(x, M * C, C, stat_d, gamma, beta, relu, y);
@@ -1118,7 +1201,9 @@ static int bn_backward_impl(const float* dy, const float* x, const float* y_or_n
     int rc = nbp_launch_status();
     if (rc) return rc;
     double* sums = part + (((size_t)nblk * 2 * C + 31) / 32 * 32);          // [2][C] unrounded dbeta, dgamma (32-B aligned)
-    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, FIN_CH), 256, 0, st>>>(part, nblk, C, dbeta, dgamma, sums);
+    // (the float4 reduction leaves sum dz x: turned into sum dz xhat by the finalizer)
+    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(C, FIN_CH), 256, 0, st>>>(part, nblk, C, dbeta, dgamma, sums, C % 4 == 0 ? mean : nullptr,
+                                                                          C % 4 == 0 ? invstd : nullptr);
     if ((rc = nbp_launch_status())) return rc;
     if (C % 4 == 0 && (dx_colsum || amax_out)) {
         // dx, its column sums and its max |.| in ONE pass (the partials reuse `part`: the finalizer above has consumed it)

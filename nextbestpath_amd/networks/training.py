@@ -409,7 +409,7 @@ class BNFn(torch.autograd.Function):
         slot = _fresh_slots(dev) if _FUSE and C % 4 == 0 else None
         # the backward rebuilds the ReLU mask from x through the unrounded statistics (two tensor reads less per BatchNorm): not
         # when an observer may rewrite y after the fact (its mask is then y's, and y is what gets saved)
-        stat = torch.empty(2 * C, dtype=torch.float64, device=dev) if (_MASK_FROM_X and relu and C % 4 == 0 and _observer is None) else None
+        stat = torch.empty(4 * C, dtype=torch.float64, device=dev) if (_MASK_FROM_X and relu and C % 4 == 0 and _observer is None) else None       # mean | invstd | mask bounds lo | hi
         part = _noted(x, "bnpart") if stat is not None else None
         if part is not None:
             _chk(L.nbp_bn_train_forward_part_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),

@@ -150,7 +150,9 @@ def test_batchnorm_statistics_from_the_convolution_epilogue(hip, monkeypatch, up
 def test_batchnorm_backward_mask_from_x_is_the_mask_from_y(hip, monkeypatch):
     """Round 4: the BatchNorm backward rebuilds the ReLU mask (y > 0) from x, which it reads anyway, through the forward's unrounded
     statistics, instead of reading y (nbp_bn_train_backward_stat_f32).  Same mask -> the same dx, dgamma, dbeta bit for bit as the
-    y-reading form, including pre-activations that round to exactly zero and values a hair on either side of it."""
+    y-reading form, including pre-activations that round to exactly zero and values a hair on either side of it.  Round 5: the
+    mask is evaluated as lo <= x <= hi with two floats per channel found by bisection over the ordered floats with the forward's own
+    arithmetic (the forward is monotone in x): exact, whatever the sign of gamma."""
     torch.manual_seed(3)
     B, H, W, C = 3, 16, 32, 64
     x = torch.randn(B, H, W, C, device=D) * 2.0 + 0.3
@@ -158,6 +160,8 @@ def test_batchnorm_backward_mask_from_x_is_the_mask_from_y(hip, monkeypatch):
     x[0, 0, :4] = 0.0                                              # exact repeats of one value per channel ...
     beta[5] = 0.0
     gamma[7] = 0.0                                                 # ... a channel whose output is beta everywhere (all on one side)
+    gamma[9], gamma[10] = -0.7, -1e-3                              # decreasing channels: the mask is x <= hi (round 5: the mask is two
+    beta[11], beta[12] = 50.0, -50.0                               # float bounds per channel); always / never positive channels
     dy = torch.randn(B, H, W, C, device=D)
     outs = []
     for from_x in (True, False):

@@ -49,28 +49,32 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     flop_map = 546.9e9 * (a.size / 256) ** 2
-    # CPU baseline: torch autograd on the oracle network (bounded sample: cpu-batch maps, 1 step)
-    from oracle import nbp_net
-    sd = {k: (v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k))
-          for k, v in net.state_dict().items()}
-    nb = a.cpu_batch
-    xc, gc = xs[:nb].cpu(), gt[:nb].cpu()
-    sel = (bidx < nb).cpu()
-    cc, gn, bi = coords.cpu()[sel], gains.cpu()[sel], bidx.cpu()[sel]
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    t0 = time.perf_counter()
-    o1, o2 = nbp_net.nbp_forward(sd, xc, train=True)
-    l = nbp_net.nbp_loss(sd["log_vars"], o1[bi, cc[:, 0], cc[:, 1], cc[:, 2]], gn, o2, gc)
-    l.backward()
-    cpu_dt = time.perf_counter() - t0
+    # CPU baseline: torch autograd on the oracle network (bounded sample: cpu-batch maps, 1 step; --cpu-batch 0: none -- profiling runs,
+    # whose copy counts would otherwise include the 327 device -> host copies of the state dict)
+    cpu = None
+    if a.cpu_batch > 0:
+        from oracle import nbp_net
+        sd = {k: (v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k))
+              for k, v in net.state_dict().items()}
+        nb = a.cpu_batch
+        xc, gc = xs[:nb].cpu(), gt[:nb].cpu()
+        sel = (bidx < nb).cpu()
+        cc, gn, bi = coords.cpu()[sel], gains.cpu()[sel], bidx.cpu()[sel]
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        t0 = time.perf_counter()
+        o1, o2 = nbp_net.nbp_forward(sd, xc, train=True)
+        l = nbp_net.nbp_loss(sd["log_vars"], o1[bi, cc[:, 0], cc[:, 1], cc[:, 2]], gn, o2, gc)
+        l.backward()
+        cpu_dt = time.perf_counter() - t0
+        cpu = {"value": round(nb / cpu_dt, 4), "unit": "maps/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"one fwd+bwd of {nb} maps with torch CPU autograd ({cpu_dt:.1f} s)"}
     print(json.dumps({
         "metric": "NBP training maps/s (fwd+bwd+AdamW, fp32)", "value": round(a.batch / dt, 3), "unit": "maps/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3, 2), "dtype": "f32",
         "data": "synthetic", "config": {"workload": f"configs[2]: train step, batch {a.batch} x {a.size}x{a.size}"},
         "tflops_reference_formulation": round(a.batch * flop_map / dt / 1e12, 2), "frac_of_split_ceiling_reference_formulation": round(a.batch * flop_map / dt / (2500e12 / 3), 4),
         "loss": float(loss.item()), "producer_notes": dict(tr.HANDOFF_STATS),
-        "cpu_baseline": {"value": round(nb / cpu_dt, 4), "unit": "maps/s", "cores": torch.get_num_threads(), "kind": "port",
-                         "sample": f"one fwd+bwd of {nb} maps with torch CPU autograd ({cpu_dt:.1f} s)"}}))
+        "cpu_baseline": cpu}))
 
 
 if __name__ == "__main__":

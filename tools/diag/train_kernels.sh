@@ -1,6 +1,6 @@
 # Diagnostic (GPU box): per-kernel share of the training step (rocprofv3 --kernel-trace --stats over tools/bench_train.py)
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/tr2 -o trace -- python /root/repo/tools/bench_train.py --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/tr2 -o trace -- python /root/repo/tools/bench_train.py --steps 3 --warmup 1 --cpu-batch 0 > /dev/null 2>&1
 cd /root/repo
 python - <<'PY'
 import csv, glob
