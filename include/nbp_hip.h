@@ -173,6 +173,9 @@ size_t nbp_conv_split_workspace_bytes(int B, int H, int W, int N, int split_k);
  * the output is <= 64 MB and to NBP_SPLIT_MAX_K (2304) elsewhere, so that the result's distance to the exact sum does not
  * grow with the batch size. */
 size_t nbp_conv_split_planned_workspace_bytes(int B, int H, int W, int C, int N, int ups, int* split_k_out);
+/* ... for a split_k request: 0 = the planner with its accuracy-driven chain bound (the eval forward), < 0 = the planner by
+ * occupancy only (the training step), > 0 = as given.  The same request goes to nbp_conv3x3_split_f32 / nbp_upconv3x3_split_f32. */
+size_t nbp_conv_split_planned_workspace_bytes_k(int B, int H, int W, int C, int N, int ups, int split_k, int* split_k_out);
 int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
                           const void* w_planes, const void* wamax, int N, const float* scale, const float* shift, int relu,
                           float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws,

@@ -131,6 +131,7 @@ SIGNATURES["nbp_pack_upconv_weight_split"] = (_i, [_vp, _i, _i, _vp, _vp, _vp])
 SIGNATURES["nbp_upconv3x3_split_f32"] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp])
 SIGNATURES["nbp_conv_split_workspace_bytes"] = SIGNATURES["nbp_conv_igemm_workspace_bytes"]
 SIGNATURES["nbp_conv_split_planned_workspace_bytes"] = (_sz, [_i, _i, _i, _i, _i, _i, _vp])
+SIGNATURES["nbp_conv_split_planned_workspace_bytes_k"] = (_sz, [_i, _i, _i, _i, _i, _i, _i, _vp])
 SIGNATURES["nbp_conv3x3_split_f32"] = (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp,
                                             _sz, _vp])
 SIGNATURES["nbp_conv1x1_split_f32"] = (_i, [_vp, _i, _ll, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp])

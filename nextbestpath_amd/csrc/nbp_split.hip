@@ -863,7 +863,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
         for (int r = 0; r < TR; ++r) {
             // the row offset is made opaque to the compiler: left visible, it keeps the fragments of the halo rows that tile rows r
             // and r + 1 share ((r, dy + 1) = (r + 1, dy)) in registers across the r iterations and spills 36 dwords around the
-            // staging; re-reading them costs 48 more transpose reads per tile and is 1.5x faster (1.20 -> 0.78 ms at 256^2, 64 x 64)
+            // staging; re-reading them costs 48 more transpose reads per tile and is 1.5x faster (1.20 -> 0.78 ms at 256^2, 64 x 64).
+            // Round 5 measured the explicit form of that sharing -- column-major over the taps, the TR + 2 halo rows of a column
+            // serving all (r, dy) pairs: 28 fragment reads per 54 MFMAs instead of 40 -- at 104 B of scratch per lane and 13 % SLOWER
+            // (0.727 against 0.642 ms on the same layer, profiles/r05/rejected_experiments.txt): 144 accumulator + 52 prefetch
+            // registers leave ~40 for fragments, the shared rows need 48
             int rofs = r * HW_ * 64;
             asm volatile("" : "+v"(rofs));
 #pragma unroll
@@ -1191,7 +1195,7 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
                 sk = 1;
                 while (blocks * sk < min_blocks_up && cc / (sk * 2) >= 4 && sk < 16) sk *= 2;
             }
-            if (split_k <= 0) sk = chain_bounded_split(sk, cc, 4, M, N, groups);
+            if (split_k == 0) sk = chain_bounded_split(sk, cc, 4, M, N, groups);      // (split_k < 0: by occupancy only)
             if (sk > cc) sk = cc;
             const int per = (int)nbp_cdiv(cc, sk);
             p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
@@ -1218,7 +1222,12 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
         // B = 12: 5.07 -> 5.02 ms, B = 8 / 1 unchanged, B = 4 +0.6 %; with 8 chunks B = 4 loses 2.5 %)
         static const int deep = nbp_tune_int("NBP_SPLIT_DEEP", 16);
         if (deep > 0 && blocks * sk < 2 * min_blocks && cc / (sk * 2) >= deep && sk < 16) sk *= 2;
-        sk = chain_bounded_split(sk, cc, 9, M, N, groups);
+        // split_k < 0 (the training step): slices by occupancy only.  The accuracy-driven slices exist for the eval forward's parity bar
+        // on rollout inputs (error vs fp64 within ~2.5x of torch CPU's blocked fp32 GEMM); without them a chain is what the fp32 MFMA
+        // pipe's own chain is (rms error 1.9e-8 of sum |terms| at K = 9216 against the pipe's 3.0e-8, tools/diag/split_precision.hip),
+        // and training pays for every slice twice (partial sums + their reduce launch, and the BatchNorm statistics the epilogue
+        // can only take from a launch that writes final values)
+        if (split_k == 0) sk = chain_bounded_split(sk, cc, 9, M, N, groups);
     }
     if (sk > cc) sk = cc;
     const int per = (int)nbp_cdiv(cc, sk);
@@ -1485,6 +1494,7 @@ int nbp_wgrad_split_launch(const float* src0, int C0, const float* src1, int C1,
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 4 * (4 * 34 * 64) + 4 * (64 * 64));
+
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     4 * (6 * 18 * 64) + 4 * (64 * 64));
@@ -1534,9 +1544,14 @@ extern "C" size_t nbp_conv_split_workspace_bytes(int B, int H, int W, int N, int
 
 // Workspace of ONE layer as the planner will run it (split_k = 0): 256 B for the max-|x| slot + the split-K slices it plans.
 // C = C0 + C1; ups = the layer reads its input through the x2 upsample (parity kernels when the low-resolution image tiles).
+extern "C" size_t nbp_conv_split_planned_workspace_bytes_k(int B, int H, int W, int C, int N, int ups, int split_k, int* split_k_out);
 extern "C" size_t nbp_conv_split_planned_workspace_bytes(int B, int H, int W, int C, int N, int ups, int* split_k_out) {
+    return nbp_conv_split_planned_workspace_bytes_k(B, H, W, C, N, ups, 0, split_k_out);
+}
+// ... for a given split_k request (0: planner with the accuracy bound, < 0: planner by occupancy only, > 0: as given)
+extern "C" size_t nbp_conv_split_planned_workspace_bytes_k(int B, int H, int W, int C, int N, int ups, int split_k, int* split_k_out) {
     if (B < 1 || H < 1 || W < 1 || C < 32 || N < 1) return 0;
-    const ConvPlan p = nbp_plan_conv_split((long long)B * H * W, N, C / 32 * 9, 0, 1, H, W, 3, ups ? 1 : 0);
+    const ConvPlan p = nbp_plan_conv_split((long long)B * H * W, N, C / 32 * 9, split_k, 1, H, W, 3, ups ? 1 : 0);
     if (split_k_out) *split_k_out = p.tile ? p.split_k : 0;
     const int sk = (p.tile && p.split_k > 1) ? p.split_k : 0;
     return 256 + (size_t)sk * B * H * W * N * sizeof(float);

@@ -105,6 +105,10 @@ def _pack_split(w_oihw, n_pad, c_total):
     return planes, wamax
 
 
+# split-K request of the training convolutions: -1 = slices by occupancy only (csrc/nbp_split.hip: nbp_plan_conv_split; the
+# accuracy-driven chain bound of the eval forward costs the step partial sums, ~25 reduce launches and the BatchNorm statistics of
+# every layer it splits); NBP_TRAIN_CHAIN_BOUND=1: 0 = the eval forward's plan
+_TRAIN_SK = 0 if _lib.tune("NBP_TRAIN_CHAIN_BOUND", "0") == "1" else -1
 _CONST = {}
 
 
@@ -196,18 +200,18 @@ def _conv_split(src0, src1, ups, packed, N, scale, shift, relu, amax=None, bn=Fa
     H, W = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     C1 = 0 if src1 is None else src1.shape[3]
     out = torch.empty(B, H, W, N, dtype=torch.float32, device=src0.device)
-    ws = _ws(L.nbp_conv_split_planned_workspace_bytes(B, H, W, C0 + C1, N, int(ups), None), src0.device)     # the slices the planner will use
+    ws = _ws(L.nbp_conv_split_planned_workspace_bytes_k(B, H, W, C0 + C1, N, int(ups), _TRAIN_SK, None), src0.device)     # the slices the planner will use
     # max |x| of the inputs: the caller's slot, else taken inside the call (autograd hands tensors over without their history)
     if bn:      # the BatchNorm behind this layer gets the column sums of the output from the epilogue (when the launch has them)
         part, rows = _bn_part(out)
         _chk(L.nbp_conv3x3_split_bn_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, _lib.ptr(planes), _lib.ptr(wamax), N,
-                                        _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), _lib.ptr(amax), None, 0, _lib.ptr(ws),
+                                        _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), _lib.ptr(amax), None, _TRAIN_SK, _lib.ptr(ws),
                                         ws.numel(), _lib.ptr(part), ctypes.byref(rows), _st()), "conv3x3_split_bn")
         if rows.value > 0:
             _note(out, bnpart=(part, rows.value))
         return out
     _chk(L.nbp_conv3x3_split_f32(_lib.ptr(src0), C0, _lib.ptr(src1), C1, int(ups), B, H, W, _lib.ptr(planes), _lib.ptr(wamax), N,
-                                 _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), _lib.ptr(amax), None, 0, _lib.ptr(ws),
+                                 _lib.ptr(scale), _lib.ptr(shift), int(relu), _lib.ptr(out), _lib.ptr(amax), None, _TRAIN_SK, _lib.ptr(ws),
                                  ws.numel(), _st()), "conv3x3_split")
     return out
 
@@ -249,17 +253,17 @@ def _upconv_split(src, w_oihw, n_pad, scale, shift, amax=None, bn=False):
     _chk(L.nbp_pack_upconv_weight_split(_lib.ptr(w_oihw), n_pad, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_upconv")
     H, W = 2 * Hs, 2 * Ws
     out = torch.empty(B, H, W, n_pad, dtype=torch.float32, device=src.device)
-    ws = _ws(L.nbp_conv_split_planned_workspace_bytes(B, H, W, C0, n_pad, 1, None), src.device)
+    ws = _ws(L.nbp_conv_split_planned_workspace_bytes_k(B, H, W, C0, n_pad, 1, _TRAIN_SK, None), src.device)
     if bn:
         part, rows = _bn_part(out)
         _chk(L.nbp_upconv3x3_split_bn_f32(_lib.ptr(src), C0, B, H, W, _lib.ptr(planes), _lib.ptr(wamax), n_pad, _lib.ptr(scale),
-                                          _lib.ptr(shift), 0, _lib.ptr(out), _lib.ptr(amax), None, 0, _lib.ptr(ws), ws.numel(),
+                                          _lib.ptr(shift), 0, _lib.ptr(out), _lib.ptr(amax), None, _TRAIN_SK, _lib.ptr(ws), ws.numel(),
                                           _lib.ptr(part), ctypes.byref(rows), _st()), "upconv3x3_split_bn")
         if rows.value > 0:
             _note(out, bnpart=(part, rows.value))
         return out
     _chk(L.nbp_upconv3x3_split_f32(_lib.ptr(src), C0, B, H, W, _lib.ptr(planes), _lib.ptr(wamax), n_pad, _lib.ptr(scale),
-                                   _lib.ptr(shift), 0, _lib.ptr(out), _lib.ptr(amax), None, 0, _lib.ptr(ws), ws.numel(), _st()), "upconv3x3_split")
+                                   _lib.ptr(shift), 0, _lib.ptr(out), _lib.ptr(amax), None, _TRAIN_SK, _lib.ptr(ws), ws.numel(), _st()), "upconv3x3_split")
     return out
 
 
