@@ -180,6 +180,16 @@ int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, 
                           const void* w_planes, const void* wamax, int N, const float* scale, const float* shift, int relu,
                           float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws,
                           size_t ws_bytes, void* stream);
+/* Data gradient of an up_conv layer (nbp_model.py:25-33: x2 nearest upsample + 3x3 convolution, C -> N channels) in the parity form of
+ * nbp_upconv3x3_split_f32: dx [B,H,W,C] at the LOW resolution straight from dy [B,2H,2W,N] -- 16 tap-products per low-resolution pixel
+ * instead of the 36 of the full-resolution 3x3 data gradient followed by a 2x2 sum.  nbp_pack_upconv_weight_split_dgrad: 32 N C fp16
+ * from the layer's own OIHW weight; scale / shift: C ones / zeros; amax_in: 64-word max-|dy| slot; ws: nbp_upconv_split_dgrad_workspace_bytes.
+ * NBP_E_SHAPE when the low-resolution image does not tile (H % 16, W % 32 with C % 64, or W % 16 with C % 128). */
+int nbp_pack_upconv_weight_split_dgrad(const float* w_oihw, int N, int C, void* dst_planes, void* wamax_out, void* stream);
+size_t nbp_upconv_split_dgrad_workspace_bytes(int B, int H, int W, int N, int C);
+int nbp_upconv3x3_split_dgrad_f32(const float* dy, int N, int B, int H, int W, const void* planes, const void* wamax, int C,
+                                  const float* scale, const float* shift, float* dx, const void* amax_in, void* amax_out_or_null,
+                                  void* ws, size_t ws_bytes, void* stream);
 /* 1x1 convolution on the same scheme (training: Attention_block.W_g / W_x, nbp_model.py:44-53, and their data gradients):
  * out [M][N] = src [M][C] W * scale + shift, C % 32 == 0, N % 32 == 0.  w_planes / wamax: nbp_pack_conv_weight_split with ksize 1
  * (forward) or nbp_pack_conv1x1_weight_split_dgrad (dx = dy W^T from the layer's own [N][C] weight).  amax_in: 64-word max-|src| slot. */

@@ -11,8 +11,10 @@ enum { NBP_TILE_AUTO = 0, NBP_TILE_128x128 = 1, NBP_TILE_256x64 = 2, NBP_TILE_25
        NBP_TILE_SPLIT_HALO_64 = 10, NBP_TILE_SPLIT_UP = 11,
        NBP_TILE_HALO_UP_128 = 12, NBP_TILE_HALO_UP_64 = 13,
        NBP_TILE_RESERVED_14 = 14,   // (was the weights-in-registers bf16 kernel of round 3: measured slower, removed)
-      
-       NBP_TILE_SPLIT_HALO_R8 = 15, NBP_TILE_SPLIT_UP_R8 = 16 };   // nbp_split.hip: 8 x 32-pixel tiles (launches that would leave CUs idle)     // bf16: 16 x 32-pixel tiles x 64 channels, weights in registers (nbp_bf16.hip)     // bf16: up_conv as four parity convolutions   // nbp_split.hip: 16x32 / 16x16-pixel halo tiles on the fp16 matrix pipe   // fp32 only: 4x32-pixel tiles   // 8x32-pixel halo-tile kernels (3x3 only), BN = 128 / 64
+       // 10 / 11: nbp_split.hip, 16x32 / 16x16-pixel halo tiles on the fp16 matrix pipe (11: up_conv as parity convolutions);
+       // 15 / 16: their 8-row forms (launches that would leave CUs idle); 12 / 13: the bf16 up_conv parity kernels
+       NBP_TILE_SPLIT_HALO_R8 = 15, NBP_TILE_SPLIT_UP_R8 = 16,
+       NBP_TILE_SPLIT_UP_DGRAD = 17 };   // nbp_split.hip: data gradient of an up_conv layer in parity form (training)
 struct TileInfo { int bm, bn; };
 struct ConvPlan { int tile; int split_k; int chunks_per_split; };
 

@@ -139,12 +139,22 @@ __device__ unsigned nbp_dbg_n;
 // accumulator count (2 x TM x TN), the same MFMAs per stage, but ONE staged halo serves two parities' tap products and the three
 // halo columns the four (px, tap) pairs touch are read from LDS three times instead of four: the staging work per MFMA of the
 // one-parity form was 2.3 x the plain kernel's (4 taps per staged chunk instead of 9), this form's is 1.25 x.
-template <int TW, int TM, int TN, bool PH, bool BS = false, bool P2 = false>
+// DG (PH only; training): the DATA GRADIENT of an up_conv layer in the same parity form.  With the output gradient seen as four
+// parity planes D[py, px][v, u] = dout[2 v + py, 2 u + px] of the low-resolution grid,
+//   din[y, x, c] = sum over (py, px), (r, t), n of Wc[py, px][r][t][n][c] D[py, px][y + 1 - py - r, x + 1 - px - t, n]:
+// a convolution over K = 4 parities x N channels with 2 x 2 taps per chunk -- 16 tap-products per low-resolution pixel where the
+// full-resolution 3 x 3 convolution of dout followed by the 2 x 2 sum (round 4) does 36.  A 16-channel chunk belongs to ONE parity,
+// which sets its halo gather (the parity plane, read straight from dout: + py W + px pixels) and the origin of its 2 x 2 taps
+// (1 - py, 1 - px); the filter-row flip r' = 1 - r is baked into the packed planes (pack_upconv_dgrad_h2_kernel).  One workgroup per
+// low-resolution tile, plain output (no parity scatter, no 2 x 2 sum pass).  a.H / a.W = the low-resolution output, a.Hs / a.Ws = dout.
+template <int TW, int TM, int TN, bool PH, bool BS = false, bool P2 = false, bool DG = false>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_h2_kernel(SplitArgs a) {
     static_assert(!P2 || (PH && !BS), "two-parity form: up_conv layers, eval");
+    static_assert(!DG || (PH && !BS && !P2), "data gradient of an up_conv layer: the one-parity tap structure");
+    constexpr bool PHO = PH && !DG;                            // the launch writes one output parity of the full-resolution image
     int zs = blockIdx.z;
-    const int py = PH ? (P2 ? zs & 1 : (zs >> 1) & 1) : 0, px = (PH && !P2) ? zs & 1 : 0;
-    if (PH) zs >>= (P2 ? 1 : 2);
+    const int py = PHO ? (P2 ? zs & 1 : (zs >> 1) & 1) : 0, px = (PHO && !P2) ? zs & 1 : 0;
+    if (PHO) zs >>= (P2 ? 1 : 2);
     const int zslice = zs;                                     // partial-sum slice: group * split_k + split
     const SplitOps& o = zs >= a.split_k ? a.g[1] : a.g[0];
     if (zs >= a.split_k) zs -= a.split_k;
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     unsigned dbg_i = 0;
     NBP_WALL(100); NBP_TS(101);
 #endif
-    const int Ht = PH ? a.Hs : a.H, Wt = PH ? a.Ws : a.W;     // the tile grid: output pixels, or low-resolution pixels for PH
+    const int Ht = PHO ? a.Hs : a.H, Wt = PHO ? a.Ws : a.W;   // the tile grid: output pixels, or low-resolution pixels for PH
     const int tiles_x = Wt / TW, tiles_y = Ht / TH;
     unsigned tile = blockIdx.x, nt = blockIdx.y;
     // Workgroups go round-robin to the 8 XCDs (each with its own L2) in linear-id order.  xcd_remap 1: an XCD takes a contiguous
@@ -218,7 +228,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int hy = hr / HW_, hx = hr - hy * HW_;
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
         const bool ok = hr < HPIX && (unsigned)yy < (unsigned)Ht && (unsigned)xx < (unsigned)Wt;
-        hpix[k] = ok ? (PH ? (b * a.Hs + yy) * a.Ws + xx : (b * a.Hs + (yy >> a.ups)) * a.Ws + (xx >> a.ups)) : -1;
+        hpix[k] = ok ? (DG ? (b * a.Hs + 2 * yy) * a.Ws + 2 * xx          // (the parity's own (py, px) is added per chunk)
+                          : PH ? (b * a.Hs + yy) * a.Ws + xx : (b * a.Hs + (yy >> a.ups)) * a.Ws + (xx >> a.ups)) : -1;
     }
     const int hdst0 = ((tid & 3) >> 1) * RS + (tid >> 2) * 16 + (tid & 1) * 8;      // piece k: + k * 64 pixels * 16 B
     const __amdgpu_buffer_rsrc_t rs0 =
@@ -232,6 +243,16 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
     u32x4 hreg[NF];
     auto load_halo = [&](int c) {       // 16-channel chunk c of the concatenated input
+        if constexpr (DG) {             // chunk = (parity q, 16 channels of dout): the parity plane of the halo tile
+            const int q = c / c16_0, cbase = (c - q * c16_0) * 16 + (tid & 3) * 4;
+            const int shift = (q >> 1) * a.Ws + (q & 1);
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                const unsigned off = hpix[k] >= 0 ? (unsigned)((hpix[k] + shift) * a.C0 + cbase) * 4u : OOB;
+                hreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
+            }
+            return;
+        }
         const bool first = c < c16_0;
         const int Cs = first ? a.C0 : a.C1;
         const int cbase = (first ? c : c - c16_0) * 16 + (tid & 3) * 4;
@@ -261,7 +282,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // PH: the four parities' planes follow each other, each [chunk][4 taps][plane][k half][N][8]
 #pragma unroll
         for (int pq = 0; pq < NPAR; ++pq) {
-            const long long pbase = PH ? (long long)(py * 2 + (P2 ? pq : px)) * a.chunks_total * TAPS * 4 * a.N : 0;
+            const long long pbase = PHO ? (long long)(py * 2 + (P2 ? pq : px)) * a.chunks_total * TAPS * 4 * a.N : 0;
 #pragma unroll
             for (int k = 0; k < WI / 4; ++k) {
                 const int q = wave + 4 * k;
@@ -340,7 +361,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                                                                                             __builtin_bit_cast(f16x8, wp[j][PW[v]]), accs[pq][i][j], 0, 0, 0);
                     }
                 }
-            } else
+            } else {
+            // DG: the chunk's parity sets the origin of its 2 x 2 taps (uniform over the workgroup)
+            const int pyc = DG ? 1 - ((c / c16_0) >> 1) : py, pxc = DG ? 1 - ((c / c16_0) & 1) : px;
 #pragma unroll
             for (int tt = 0; tt < TPR; ++tt) {
                 u32x4 xp[TM][2], wp[TN][2];
@@ -348,7 +371,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
-                        xp[i][p] = *reinterpret_cast<const u32x4*>(arow + p * (2 * RS) + ((row + py + i * RPB) * HW_ + tt + px) * 16);
+                        xp[i][p] = *reinterpret_cast<const u32x4*>(arow + p * (2 * RS) + ((row + pyc + i * RPB) * HW_ + tt + pxc) * 16);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -365,6 +388,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                         for (int i = 0; i < TM; ++i)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xp[i][PX[v]]),
                                                                                __builtin_bit_cast(f16x8, wp[j][PW[v]]), acc[i][j], 0, 0, 0);
+            }
             }
             NBP_TS(2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -410,12 +434,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         float vals[TM][16];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const long long mrow = PH ? ((long long)b * a.H + 2 * (y0 + (TM * wave + i) * RPB) + py) * a.W + 2 * x0 + pxe
-                                      : ((long long)b * a.H + y0 + (TM * wave + i) * RPB) * a.W + x0;
+            const long long mrow = PHO ? ((long long)b * a.H + 2 * (y0 + (TM * wave + i) * RPB) + py) * a.W + 2 * x0 + pxe
+                                       : ((long long)b * a.H + y0 + (TM * wave + i) * RPB) * a.W + x0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pb = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                const int poff = PH ? 2 * ((pb / TW) * a.W + (pb % TW)) : (pb / TW) * a.W + (pb % TW);
+                const int poff = PHO ? 2 * ((pb / TW) * a.W + (pb % TW)) : (pb / TW) * a.W + (pb % TW);
                 float v = ldexpf(accs[pq][i][j][r], einv) * sc + sh;
                 if (final_out && a.relu) v = fmaxf(v, 0.f);
                 mx = fmaxf(mx, fabsf(v));
@@ -1088,6 +1112,37 @@ __global__ __launch_bounds__(256) void pack_upconv_h2_kernel(const float* __rest
     if (!dst) block_amax(mx, wamax, 1u);
 }
 
+// The same parity filters for the DATA GRADIENT of the layer (conv3x3_halo_h2_kernel<..., DG>): K runs over (parity q, output channel
+// n of the layer), rows over its input channels c, and the tap (r', t') of chunk q holds Wc[q][1 - r'][1 - t'][n][c] (the kernel walks
+// the parity plane with the forward's tap origin mirrored).  pass 0 (dst == nullptr): max |Wc| into wamax; pass 1: planes
+// [q (N / 16) + n / 16][4 taps][hi|lo][k half][C][8 fp16].
+__global__ __launch_bounds__(256) void pack_upconv_dgrad_h2_kernel(const float* __restrict__ w, int N, int C, unsigned* __restrict__ wamax,
+                                                                   unsigned short* __restrict__ dst) {
+    const long long NC = (long long)N * C;
+    const double sw = dst ? (double)pow2f(SPLIT_EXP - amax_exponent(*wamax)) : 1.0;
+    float mx = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < NC; i += (long long)gridDim.x * blockDim.x) {
+        double v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = (double)w[i * 9 + k];
+        const int n = (int)(i / C), c = (int)(i % C);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {
+                const double wc = upconv_combined(v, q, 1 - (tap >> 1), 1 - (tap & 1));
+                if (!dst) { mx = fmaxf(mx, fabsf((float)wc)); continue; }
+                const double ws = wc * sw;
+                const _Float16 h = (_Float16)(float)ws;
+                const _Float16 l = (_Float16)(float)(ws - (double)(float)h);
+                const long long base = (((long long)q * (N >> 4) + (n >> 4)) * 4 + tap) * 4 + ((n >> 3) & 1);
+                dst[((base + 0) * C + c) * 8 + (n & 7)] = __builtin_bit_cast(unsigned short, h);
+                dst[((base + 2) * C + c) * 8 + (n & 7)] = __builtin_bit_cast(unsigned short, l);
+            }
+    }
+    if (!dst) block_amax(mx, wamax, 1u);
+}
+
 // tile width the layer runs with: 32 (16 x 32 pixel tiles x 64 channels), 16 (16 x 16 x 128 channels) or 0 (not taken)
 int split_tile_width(int H, int W, int N, int ksize) {
     if (ksize != 3 || H < 16 || H % 16) return 0;
@@ -1096,12 +1151,12 @@ int split_tile_width(int H, int W, int N, int ksize) {
     return 0;
 }
 
-template <int TW, int TM, int TN, bool PH, bool BS = false, bool P2 = false>
+template <int TW, int TM, int TN, bool PH, bool BS = false, bool P2 = false, bool DG = false>
 int launch_h2(const SplitArgs& a, hipStream_t st, int tile) {
     {
         char nm[96];
-        snprintf(nm, sizeof(nm), "conv3x3_halo_h2_kernel<%d, %d, %d, %s, %s, %s>", TW, TM, TN, PH ? "true" : "false", BS ? "true" : "false",
-                 P2 ? "true" : "false");
+        snprintf(nm, sizeof(nm), "conv3x3_halo_h2_kernel<%d, %d, %d, %s, %s, %s, %s>", TW, TM, TN, PH ? "true" : "false", BS ? "true" : "false",
+                 P2 ? "true" : "false", DG ? "true" : "false");
         nbp_note_kernel_symbol(tile, nm);
     }
     constexpr int TH = 4 * TM * (32 / TW);
@@ -1109,14 +1164,15 @@ int launch_h2(const SplitArgs& a, hipStream_t st, int tile) {
     constexpr size_t smem = 4 * (size_t)RS + 2 * (size_t)(PH ? 8 : 12) * NB * 1024 * (P2 ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS, P2>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS, P2, DG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    // PH: tiles of the low-resolution image, four parities in blockIdx.z (fastest)
-    dim3 grid((unsigned)(a.M / (PH ? 4 : 1) / (TH * TW)), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups * (PH ? (P2 ? 2 : 4) : 1)));
-    conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS, P2><<<grid, 256, smem, st>>>(a);
+    // PH: tiles of the low-resolution image, four parities in blockIdx.z (fastest); DG: a.M counts the low-resolution output itself
+    constexpr bool PHO = PH && !DG;
+    dim3 grid((unsigned)(a.M / (PHO ? 4 : 1) / (TH * TW)), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups * (PHO ? (P2 ? 2 : 4) : 1)));
+    conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS, P2, DG><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 
@@ -1440,6 +1496,50 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
     return nbp_launch_status();
 }
 
+// Data gradient of an up_conv layer (x2 nearest upsample + 3 x 3 convolution from C to N channels) in parity form: dx [B,H,W,C] at the
+// LOW resolution from dy [B,2H,2W,N]; planes / wamax from nbp_pack_upconv_weight_split_dgrad; amax_in = the 64-word max-|dy| slot.
+// split_k <= 0: slices by occupancy.  NBP_E_SHAPE when the low-resolution image does not tile.
+int nbp_upconv_dgrad_split_launch(const float* dy, int N, int B, int H, int W, const void* planes, const unsigned* wamax,
+                                  const unsigned* amax_in, int C, const float* scale, const float* shift, float* out, unsigned* amax_out,
+                                  int split_k, void* ws, size_t ws_bytes, hipStream_t st) {
+    NBP_RETURN_IF(!dy || !planes || !wamax || !amax_in || !scale || !shift || !out, NBP_E_ARG);
+    NBP_RETURN_IF(B < 1 || N < 16 || N % 16 || C < 64 || C % 64, NBP_E_SHAPE);
+    const int tw = split_tile_width(H, W, C, 3);
+    NBP_RETURN_IF(!tw, NBP_E_SHAPE);
+    SplitArgs a;
+    for (int g = 0; g < 2; ++g)
+        a.g[g] = SplitOps{dy, nullptr, planes, scale, shift, out, amax_in, nullptr, wamax, amax_out, nullptr, nullptr, {nullptr, nullptr}, nullptr, nullptr};
+    a.C0 = N; a.C1 = 0; a.ups = 0; a.H = H; a.W = W; a.Hs = 2 * H; a.Ws = 2 * W; a.N = C; a.relu = 0; a.groups = 1;
+    a.M = (long long)B * H * W;
+    const long long b0 = (long long)B * 4 * H * W * N * 4, bw = 64ll * N * C;
+    NBP_RETURN_IF(b0 >= (1ll << 31) || bw >= (1ll << 31), NBP_E_SHAPE);
+    a.bytes0 = (unsigned)b0; a.bytes1 = (unsigned)b0; a.bytesw = (unsigned)bw;
+    a.chunks_total = 4 * (N / 16);
+    const long long blocks = (a.M / (16 * tw)) * (C / (tw == 32 ? 64 : 128));
+    int sk = split_k;
+    if (sk <= 0) { sk = 1; while (blocks * sk < 256 && a.chunks_total / (sk * 2) >= 4 && sk < 16) sk *= 2; }
+    if (sk > a.chunks_total) sk = a.chunks_total;
+    a.chunks_per_split = (int)nbp_cdiv(a.chunks_total, sk);
+    a.split_k = (int)nbp_cdiv(a.chunks_total, a.chunks_per_split);
+    a.xcd_remap = blocks >= 8 ? 1 : 0;
+    a.partial = nullptr;
+    if (a.split_k > 1) {
+        NBP_RETURN_IF(!ws || ws_bytes < (size_t)a.split_k * a.M * C * sizeof(float), NBP_E_WS);
+        a.partial = (float*)ws;
+    }
+    int rc = tw == 32 ? launch_h2<32, 4, 2, true, false, false, true>(a, st, NBP_TILE_SPLIT_UP_DGRAD)
+                      : launch_h2<16, 2, 4, true, false, false, true>(a, st, NBP_TILE_SPLIT_UP_DGRAD);
+    if (rc) return rc;
+    if (a.split_k > 1) {
+        const long long MN = a.M * C;
+        NBP_RETURN_IF(MN >= (1ll << 31), NBP_E_SHAPE);
+        dim3 grid((unsigned)min(nbp_cdiv(MN / 4, 256 * 4), 1024ll), 1u);
+        splitk_reduce_split_kernel<<<grid, 256, 0, st>>>((const float*)ws, a.split_k, (unsigned)MN, (unsigned)C, a.g[0], a.g[1], 0);
+        rc = nbp_launch_status();
+    }
+    return rc;
+}
+
 // out [M][N] = src [M][C] W + shift (optionally scale / ReLU): a 1x1 convolution on the split scheme through the gates' kernel with
 // ONE source (training: the attention gates' W_g / W_x layers and their data gradients ran on the fp32 pipe -- compute-bound there
 // on the deep levels, and padded from 32 to 64 output channels on level 2).  planes: nbp_pack_conv_weight_split with ksize = 1
@@ -1599,6 +1699,41 @@ extern "C" int nbp_conv3x3_split_bn_f32(const float* src0, int C0, const float* 
     NBP_RETURN_IF(!bn_part || !bn_rows || ((uintptr_t)bn_part & 7), NBP_E_ARG);
     return conv3x3_split_impl(src0, C0, src1, C1, ups, B, H, W, w_planes, wamax, N, scale, shift, relu, out, amax_in_or_null,
                               amax_out_or_null, split_k, ws, ws_bytes, stream, bn_part, bn_rows);
+}
+
+// ---- data gradient of an up_conv layer in parity form (training; conv3x3_halo_h2_kernel<..., DG>)
+// planes: 32 N C fp16 ([4 parities x N / 16 chunks][4 taps][hi|lo][k half][C][8]) from the layer's own weight [N][C][3][3]
+extern "C" int nbp_pack_upconv_weight_split_dgrad(const float* w_oihw, int N, int C, void* dst_planes, void* wamax_out, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!w_oihw || !dst_planes || !wamax_out, NBP_E_ARG);
+    NBP_RETURN_IF(N < 16 || N % 16 || C < 1, NBP_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(wamax_out, 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return (int)e;
+    const long long NC = (long long)N * C;
+    pack_upconv_dgrad_h2_kernel<<<min(nbp_ew_grid(NC, 256), 256), 256, 0, st>>>(w_oihw, N, C, (unsigned*)wamax_out, nullptr);
+    pack_upconv_dgrad_h2_kernel<<<nbp_ew_grid(NC, 256), 256, 0, st>>>(w_oihw, N, C, (unsigned*)wamax_out, (unsigned short*)dst_planes);
+    return nbp_launch_status();
+}
+// workspace of nbp_upconv3x3_split_dgrad_f32 (its split-K slices, by occupancy)
+extern "C" size_t nbp_upconv_split_dgrad_workspace_bytes(int B, int H, int W, int N, int C) {
+    if (B < 1 || H < 1 || W < 1 || N < 16 || C < 64) return 0;
+    const int tw = split_tile_width(H, W, C, 3);
+    if (!tw) return 0;
+    const long long M = (long long)B * H * W, blocks = (M / (16 * tw)) * (C / (tw == 32 ? 64 : 128));
+    const int chunks = 4 * (N / 16);
+    int sk = 1;
+    while (blocks * sk < 256 && chunks / (sk * 2) >= 4 && sk < 16) sk *= 2;
+    return 256 + (sk > 1 ? (size_t)sk * M * C * sizeof(float) : 0);
+}
+// dx [B,H,W,C] (the layer's LOW-resolution input gradient) from dy [B,2H,2W,N]; scale / shift: C ones / zeros (the epilogue's affine)
+extern "C" int nbp_upconv3x3_split_dgrad_f32(const float* dy, int N, int B, int H, int W, const void* planes, const void* wamax, int C,
+                                             const float* scale, const float* shift, float* dx, const void* amax_in, void* amax_out_or_null,
+                                             void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
+    return nbp_upconv_dgrad_split_launch(dy, N, B, H, W, planes, (const unsigned*)wamax, (const unsigned*)amax_in, C, scale, shift, dx,
+                                         (unsigned*)amax_out_or_null, 0, ws ? (char*)ws + 256 : nullptr, ws_bytes >= 256 ? ws_bytes - 256 : 0,
+                                         (hipStream_t)stream);
 }
 
 // out [M][N] = src [M][C] (1x1 convolution) on the split scheme; w_planes / wamax from nbp_pack_conv_weight_split(ksize = 1),

@@ -235,6 +235,11 @@ def _conv1x1_split(x, planes, wamax, N, scale, shift, amax):
     return out
 
 
+# data gradient of the up_conv layers in parity form (csrc/nbp_split.hip: conv3x3_halo_h2_kernel<..., DG>): dx at the low resolution
+# straight from dy, 16 tap-products per low-resolution pixel instead of 36 + a 2x2 sum pass.  NBP_TRAIN_UP_DGRAD=0: round 4's form.
+_UP_DGRAD = _lib.tune("NBP_TRAIN_UP_DGRAD", "1") == "1"
+
+
 def _upconv_ok(Hs, Ws, N):
     """up_conv layers (x2 nearest upsample + 3x3): four 2x2 parity convolutions of the low-resolution input when it tiles."""
     return _SPLIT and Hs % 16 == 0 and ((Ws % 32 == 0 and N % 64 == 0) or (Ws % 16 == 0 and N % 128 == 0))
@@ -355,6 +360,19 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             Ctot = C0 + C1
             one, zero = _const(1.0, Ctot, dev), _const(0.0, Ctot, dev)
+            if (ups and k == 3 and not has1 and _UP_DGRAD and N == Np and c_real == C0 and _upconv_ok(H // 2, W // 2, C0)
+                    and B * H * W * Np * 4 < 2 ** 31):
+                planes = torch.empty(32 * Np * C0, dtype=torch.int16, device=dev)
+                wamax = torch.empty(1, dtype=torch.int32, device=dev)
+                _chk(L.nbp_pack_upconv_weight_split_dgrad(_lib.ptr(w), Np, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_upconv_dgrad")
+                if dymax is None:
+                    dymax = info[0] if info is not None else _amax_slot(dy)
+                dxl = torch.empty(B, H // 2, W // 2, C0, dtype=torch.float32, device=dev)
+                wsd = _ws(L.nbp_upconv_split_dgrad_workspace_bytes(B, H // 2, W // 2, Np, C0), dev)
+                _chk(L.nbp_upconv3x3_split_dgrad_f32(_lib.ptr(dy), Np, B, H // 2, W // 2, _lib.ptr(planes), _lib.ptr(wamax), C0,
+                                                     _lib.ptr(one), _lib.ptr(zero), _lib.ptr(dxl), _lib.ptr(dymax), None, _lib.ptr(wsd),
+                                                     wsd.numel(), _st()), "upconv_dgrad_split")
+                return dxl, None, dw, db, None, None
             if one_by_one:
                 # dx = dy W^T: a 1x1 convolution from N to C0 channels on the same kernel
                 planes = torch.empty(N // 16 * 4 * C0 * 8, dtype=torch.int16, device=dev)

@@ -147,6 +147,37 @@ def test_batchnorm_statistics_from_the_convolution_epilogue(hip, monkeypatch, up
         _close(a, c, rtol=2e-5, what=nm)
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 32, 128, 64), (1, 32, 64, 64, 64), (2, 16, 16, 256, 128), (1, 16, 32, 64, 192)])
+def test_upconv_data_gradient_in_parity_form(hip, monkeypatch, shape):
+    """Round 5: the data gradient of an up_conv layer (x2 nearest upsample + 3x3) at the LOW resolution straight from dy -- four parity
+    planes x 2 x 2 taps (nbp_upconv3x3_split_dgrad_f32) -- against float64 autograd of the reference formulation and against
+    round 4's form (full-resolution 3x3 data gradient + 2x2 sum); image borders included (the tiles cover the whole image)."""
+    B, Hs, Ws, C, N = shape
+    x = _rand(B, Hs, Ws, C, seed=1)
+    w = _rand(N, C, 3, 3, seed=2) * 0.05
+    bias = _rand(N, seed=3) * 0.1
+    gy = _rand(B, 2 * Hs, 2 * Ws, N, seed=4)
+    xr = x.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), w.double(), bias.double(), padding=1)
+    yr.backward(gy.double().permute(0, 3, 1, 2))
+    want = xr.grad.permute(0, 2, 3, 1)
+    got = []
+    for parity in (True, False):
+        monkeypatch.setattr(tr, "_UP_DGRAD", parity)
+        tr._reset_arena(torch.device(D))
+        xd, wd, bd = x.to(D).requires_grad_(True), w.to(D).requires_grad_(True), bias.to(D).requires_grad_(True)
+        y = tr.ConvFn.apply(xd, None, wd, bd, True, False)
+        y.backward(gy.to(D))
+        got.append(xd.grad.cpu().double())
+    import ctypes
+    buf = ctypes.create_string_buffer(128)
+    assert _lib.lib().nbp_tile_kernel_symbol(17, buf, 128) > 0 and buf.value.decode().endswith("true, false, false, true>")    # the DG form ran
+    scale = float(want.abs().max())
+    assert float((got[0] - want).abs().max()) < 2e-6 * scale, float((got[0] - want).abs().max()) / scale
+    assert float((got[1] - want).abs().max()) < 2e-6 * scale
+    assert float((got[0] - got[1]).abs().max()) < 2e-6 * scale
+
+
 def test_batchnorm_backward_mask_from_x_is_the_mask_from_y(hip, monkeypatch):
     """Round 4: the BatchNorm backward rebuilds the ReLU mask (y > 0) from x, which it reads anyway, through the forward's unrounded
     statistics, instead of reading y (nbp_bn_train_backward_stat_f32).  Same mask -> the same dx, dgamma, dbeta bit for bit as the
