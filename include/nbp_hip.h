@@ -190,6 +190,12 @@ size_t nbp_upconv_split_dgrad_workspace_bytes(int B, int H, int W, int N, int C)
 int nbp_upconv3x3_split_dgrad_f32(const float* dy, int N, int B, int H, int W, const void* planes, const void* wamax, int C,
                                   const float* scale, const float* shift, float* dx, const void* amax_in, void* amax_out_or_null,
                                   void* ws, size_t ws_bytes, void* stream);
+/* Weight gradient of the same layer in parity form: dW [N][C][3][3] from the LOW-resolution input x [B,Hs,Ws,C] and dy [B,2Hs,2Ws,N] as
+ * 16 tap-GEMMs over M / 4 pixels (four parities x 2 x 2 taps) folded into the 3x3 filter by the reduce kernel; C % 64 == 0, N % 64 == 0,
+ * (Ws % 32 == 0 and Hs % 2 == 0) or (Ws % 16 == 0 and Hs % 4 == 0), else NBP_E_SHAPE.  amax_x / amax_y: 64-word max-|.| slots. */
+size_t nbp_upconv_wgrad_split_workspace_bytes(int B, int Hs, int Ws, int C, int N);
+int nbp_upconv_wgrad_split_f32(const float* x, int C, int B, int Hs, int Ws, const float* dy, int N, float* dw,
+                               const void* amax_x, const void* amax_y, void* ws, size_t ws_bytes, void* stream);
 /* 1x1 convolution on the same scheme (training: Attention_block.W_g / W_x, nbp_model.py:44-53, and their data gradients):
  * out [M][N] = src [M][C] W * scale + shift, C % 32 == 0, N % 32 == 0.  w_planes / wamax: nbp_pack_conv_weight_split with ksize 1
  * (forward) or nbp_pack_conv1x1_weight_split_dgrad (dx = dy W^T from the layer's own [N][C] weight).  amax_in: 64-word max-|src| slot. */

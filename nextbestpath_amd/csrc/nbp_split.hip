@@ -920,6 +920,166 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ weight gradient of an up_conv layer in parity form
+// The layer (x2 nearest upsample + 3 x 3, nbp_model.py:25-33) is four 2 x 2 convolutions of the LOW-resolution input, one per output
+// parity (conv3x3_halo_h2_kernel<..., PH>), so its weight gradient is
+//   dWc[py, px][r][t][c][n] = sum over low-resolution pixels (v, u) of X[v - 1 + py + r, u - 1 + px + t, c] dY[2 v + py, 2 u + px, n]:
+// 16 tap-GEMMs over M / 4 pixels each where the 3 x 3 form over the upsampled image does 9 over M (2.25 x fewer MFMAs), and
+//   dW[ky][kx] = sum of dWc[py, px][r][t] over the (py, r) whose pre-summed filter row contains ky (and columns alike)
+// is taken by the reduce kernel below.  A workgroup owns a 64 (c) x 64 (n) block of ONE parity (blockIdx.z) and walks 64-pixel tiles of
+// the low-resolution image like wgrad_split_kernel: the (TR + 1) x (TW + 1) halo of X it needs (rows v0 - 1 + py .., columns
+// u0 - 1 + px ..) and the tile's 64 pixels of dY's parity plane go global -> registers -> scale, split -> LDS fp16 planes
+// [32-channel half][pixel][32 channels]; transpose reads hand both MFMA operands 8 consecutive pixels of one channel per lane.
+// Four accumulator tiles per wave instead of nine: 64 + 44 registers of accumulators and prefetch, no scratch, three workgroups per CU.
+template <int TW>
+__global__ __launch_bounds__(256, 3) void wgrad_up_split_kernel(WgradSplitArgs a) {
+    constexpr int TR = 64 / TW, HW_ = TW + 2, HP = (TR + 1) * HW_;     // tile rows; halo pixels ((TR + 1) rows x (TW + 2): TW + 1 are used)
+    constexpr int NX = (HP * 16 + 255) / 256;
+    constexpr int XPL = HP * 64, YPL = 64 * 64;
+    constexpr int XB = 4 * XPL;
+    extern __shared__ __attribute__((aligned(16))) char wl[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1, kh = lane >> 5, ln = lane & 31;
+    const int ci0 = (blockIdx.x / a.co_tiles) * 64, co0 = (blockIdx.x % a.co_tiles) * 64;
+    const int py = blockIdx.z >> 1, px = blockIdx.z & 1;
+    const int C = a.C0;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.bytesy, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int tiles_x = a.Ws / TW, tiles_y = a.Hs / TR;              // tiles of the LOW-resolution image (a.H / a.W: dY's size)
+    const int ex = amax_exponent(read_amax(a.amax0)), ey = amax_exponent(read_amax(a.amaxy));
+    const float sx = pow2f(SPLIT_EXP - ex), sy = pow2f(SPLIT_EXP - ey);
+    const int einv = ex + ey - 2 * SPLIT_EXP;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int c4 = tid & 15;
+    const int sdst = c4 >> 3;
+    const int loff = (8 * kh + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const char* const xa_hi = wl + (0 * 2 + wi) * XPL + loff;
+    const char* const xa_lo = wl + (1 * 2 + wi) * XPL + loff;
+    const char* const yb_hi = wl + XB + (0 * 2 + wj) * YPL + loff;
+    const char* const yb_lo = wl + XB + (1 * 2 + wj) * YPL + loff;
+
+    u32x4 xr[NX], yr[4];
+    auto fetch = [&](int tile) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int b = t / tiles_y;
+        const int v0 = ty * TR, u0 = tx * TW;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {         // X halo: halo pixel (hy, hx) = image (v0 - 1 + py + hy, u0 - 1 + px + hx)
+            const int f = tid + 256 * k;
+            const int hr = f >> 4;
+            const int hy = hr / HW_, hx = hr - hy * HW_;
+            const int yy = v0 - 1 + py + hy, xx = u0 - 1 + px + hx;
+            const bool ok = hr < HP && (unsigned)yy < (unsigned)a.Hs && (unsigned)xx < (unsigned)a.Ws;
+            const unsigned off = ok ? (unsigned)(((b * a.Hs + yy) * a.Ws + xx) * C + ci0 + c4 * 4) * 4u : OOB;
+            xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {          // dY: the tile's 64 pixels of the parity plane
+            const int pz = (tid + 256 * k) >> 4;
+            const long long m = ((long long)b * a.H + 2 * (v0 + pz / TW) + py) * a.W + 2 * (u0 + pz % TW) + px;
+            yr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (unsigned)((m * a.N + co0 + c4 * 4) * 4), 0, 0);
+        }
+    };
+    if ((int)blockIdx.y < a.n_tiles) fetch(blockIdx.y);
+    for (int tile = blockIdx.y; tile < a.n_tiles; tile += a.splits) {
+        __syncthreads();                       // every wave is done with the previous tile's planes
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int hr = (tid + 256 * k) >> 4;
+            if (hr >= HP) continue;
+            const f32x4 v = __builtin_bit_cast(f32x4, xr[k]);
+            unsigned h0, l0, h1, l1;
+            split_pair(v[0] * sx, v[1] * sx, h0, l0);
+            split_pair(v[2] * sx, v[3] * sx, h1, l1);
+            char* d = wl + sdst * XPL + hr * 64 + (c4 & 7) * 8;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + 2 * XPL) = u32x2{l0, l1};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pz = (tid + 256 * k) >> 4;
+            const f32x4 v = __builtin_bit_cast(f32x4, yr[k]);
+            unsigned h0, l0, h1, l1;
+            split_pair(v[0] * sy, v[1] * sy, h0, l0);
+            split_pair(v[2] * sy, v[3] * sy, h1, l1);
+            char* d = wl + XB + sdst * YPL + pz * 64 + (c4 & 7) * 8;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + 2 * YPL) = u32x2{l0, l1};
+        }
+        __syncthreads();
+        if (tile + a.splits < a.n_tiles) fetch(tile + a.splits);
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            int rofs = r * HW_ * 64;           // opaque to the compiler (as in wgrad_split_kernel: no fragments carried across tile rows)
+            asm volatile("" : "+v"(rofs));
+#pragma unroll
+            for (int s = 0; s < TW / 16; ++s) {
+                const int p0 = r * TW + 16 * s;
+                const f16x8 bh = tr_frag(yb_hi + p0 * 64), bl = tr_frag(yb_lo + p0 * 64);
+#pragma unroll
+                for (int tap = 0; tap < 4; ++tap) {
+                    const int hp0 = (tap >> 1) * HW_ + 16 * s + (tap & 1);            // halo pixel of (row r + r', column 16 s + t'), less row r
+                    const f16x8 ah = tr_frag(xa_hi + rofs + hp0 * 64), al = tr_frag(xa_lo + rofs + hp0 * 64);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[tap], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // part [split][parity][tap][C][N]
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+        float* out = a.part + ((((long long)blockIdx.y * 4 + blockIdx.z) * 4 + tap) * C) * a.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            out[(long long)ci * a.N + co0 + wj * 32 + ln] = ldexpf(acc[tap][r], einv);
+        }
+    }
+}
+
+// dW OIHW [N][C][3][3] from the parity partials [split][parity][tap][C][N]: filter row ky collects the (py, r) pairs whose pre-summed
+// row contains it -- ky = 0: (0, 0), (1, 0); ky = 1: (0, 1), (1, 0); ky = 2: (0, 1), (1, 1) -- columns alike; slices in slice order,
+// the four entries in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void wgrad_up_reduce_kernel(const float* __restrict__ part, int splits, int C, int N,
+                                                              float* __restrict__ dw) {
+    const long long total = (long long)N * C * 9;
+    const long long plane = (long long)C * N, slice = 16 * plane;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % N);
+        long long t = i / N;
+        const int ci = (int)(t % C), k9 = (int)(t / C);
+        const int ky = k9 / 3, kx = k9 % 3;
+        // (parity bit, tap bit) pairs per filter index
+        const int pa[3][2] = {{0, 1}, {0, 1}, {0, 1}};
+        const int ta[3][2] = {{0, 0}, {1, 0}, {1, 1}};
+        float s = 0.f;
+        const float* p = part + (long long)ci * N + co;
+        for (int k = 0; k < splits; ++k) {
+            float v = 0.f;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const int q = pa[ky][e] * 2 + pa[kx][f], tap = ta[ky][e] * 2 + ta[kx][f];
+                    v += p[(long long)k * slice + (q * 4 + tap) * plane];
+                }
+            s += v;
+        }
+        dw[((long long)co * C + ci) * 9 + k9] = s;
+    }
+}
+
 // Grid-stride over float4s of the output, two positions per thread and iteration, the slices' loads of both issued together
 // (four slices at a time) and added in slice order -- a serial load-add chain costs one memory round trip per slice, and
 // one float4 per thread is bound by the wave launch rate (measured: 31 us serial / 56 us one-per-thread / see DESIGN.md).
@@ -1699,6 +1859,63 @@ extern "C" int nbp_conv3x3_split_bn_f32(const float* src0, int C0, const float* 
     NBP_RETURN_IF(!bn_part || !bn_rows || ((uintptr_t)bn_part & 7), NBP_E_ARG);
     return conv3x3_split_impl(src0, C0, src1, C1, ups, B, H, W, w_planes, wamax, N, scale, shift, relu, out, amax_in_or_null,
                               amax_out_or_null, split_k, ws, ws_bytes, stream, bn_part, bn_rows);
+}
+
+// ---- weight gradient of an up_conv layer in parity form (training; wgrad_up_split_kernel)
+static void wgrad_up_plan(int B, int Hs, int Ws, int C, int N, int* n_tiles, int* splits) {
+    *n_tiles = (int)((long long)B * Hs * Ws / 64);
+    const long long pairs = (long long)(C / 64) * (N / 64) * 4;       // x four parities
+    long long sp = nbp_cdiv(768, pairs);                              // three workgroups per CU
+    if (sp > *n_tiles) sp = *n_tiles;
+    if (sp > 1024) sp = 1024;
+    if (sp < 1) sp = 1;
+    *splits = (int)sp;
+}
+static bool wgrad_up_ok(int Hs, int Ws, int C, int N) {
+    return C >= 64 && C % 64 == 0 && N >= 64 && N % 64 == 0 && ((Ws % 32 == 0 && Hs % 2 == 0) || (Ws % 16 == 0 && Hs % 4 == 0));
+}
+extern "C" size_t nbp_upconv_wgrad_split_workspace_bytes(int B, int Hs, int Ws, int C, int N) {
+    if (B < 1 || !wgrad_up_ok(Hs, Ws, C, N)) return 0;
+    int nt, sp;
+    wgrad_up_plan(B, Hs, Ws, C, N, &nt, &sp);
+    return 1024 + (size_t)sp * 16 * C * N * sizeof(float);
+}
+// dW [N][C][3][3] of an up_conv layer from its low-resolution input x [B,Hs,Ws,C] and dy [B,2Hs,2Ws,N]; amax_x / amax_y: the tensors'
+// 64-word max-|.| slots (required).  NBP_E_SHAPE when the low-resolution image does not tile (the caller takes nbp_conv_wgrad_split_f32).
+extern "C" int nbp_upconv_wgrad_split_f32(const float* x, int C, int B, int Hs, int Ws, const float* dy, int N, float* dw,
+                                          const void* amax_x, const void* amax_y, void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!x || !dy || !dw || !amax_x || !amax_y || !ws || B < 1, NBP_E_ARG);
+    NBP_RETURN_IF(!wgrad_up_ok(Hs, Ws, C, N), NBP_E_SHAPE);
+    const long long b0 = (long long)B * Hs * Ws * C * 4, by = (long long)B * 4 * Hs * Ws * N * 4;
+    NBP_RETURN_IF(b0 >= (1ll << 31) || by >= (1ll << 31), NBP_E_SHAPE);
+    int n_tiles, splits;
+    wgrad_up_plan(B, Hs, Ws, C, N, &n_tiles, &splits);
+    NBP_RETURN_IF(ws_bytes < 1024 + (size_t)splits * 16 * C * N * sizeof(float), NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    WgradSplitArgs a;
+    a.src0 = x; a.src1 = x; a.C0 = C; a.C1 = 0; a.ups = 1; a.H = 2 * Hs; a.W = 2 * Ws; a.Hs = Hs; a.Ws = Ws;
+    a.dy = dy; a.N = N; a.bytes0 = (unsigned)b0; a.bytes1 = (unsigned)b0; a.bytesy = (unsigned)by;
+    a.co_tiles = N / 64; a.n_tiles = n_tiles; a.splits = splits; a.prefetch = 1;
+    a.amax0 = (const unsigned*)amax_x; a.amax1 = a.amax0; a.amaxy = (const unsigned*)amax_y;
+    a.part = (float*)((char*)(((uintptr_t)ws + 255) / 256 * 256));
+    const bool wide = Ws % 32 == 0 && Hs % 2 == 0;
+    constexpr int smem32 = 4 * (3 * 34 * 64) + 4 * (64 * 64), smem16 = 4 * (5 * 18 * 64) + 4 * (64 * 64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_up_split_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, smem32);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_up_split_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, smem16);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((C / 64) * (N / 64)), (unsigned)splits, 4u);
+    if (wide) wgrad_up_split_kernel<32><<<grid, 256, smem32, st>>>(a);
+    else wgrad_up_split_kernel<16><<<grid, 256, smem16, st>>>(a);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    wgrad_up_reduce_kernel<<<nbp_ew_grid((long long)N * C * 9, 256), 256, 0, st>>>(a.part, splits, C, N, dw);
+    return nbp_launch_status();
 }
 
 // ---- data gradient of an up_conv layer in parity form (training; conv3x3_halo_h2_kernel<..., DG>)

@@ -238,6 +238,8 @@ def _conv1x1_split(x, planes, wamax, N, scale, shift, amax):
 # data gradient of the up_conv layers in parity form (csrc/nbp_split.hip: conv3x3_halo_h2_kernel<..., DG>): dx at the low resolution
 # straight from dy, 16 tap-products per low-resolution pixel instead of 36 + a 2x2 sum pass.  NBP_TRAIN_UP_DGRAD=0: round 4's form.
 _UP_DGRAD = _lib.tune("NBP_TRAIN_UP_DGRAD", "1") == "1"
+# ... and their weight gradient (wgrad_up_split_kernel: 16 tap-GEMMs over M / 4 pixels instead of 9 over M).  NBP_TRAIN_UP_WGRAD=0: the 3x3 form.
+_UP_WGRAD = _lib.tune("NBP_TRAIN_UP_WGRAD", "1") == "1"
 
 
 def _upconv_ok(Hs, Ws, N):
@@ -346,7 +348,15 @@ class ConvFn(torch.autograd.Function):
         ws = _ws(L.nbp_conv_wgrad_workspace_bytes(B, H, W, C0, C1, Nw, k), dev)
         # the 3x3 weight gradients take the split scheme too (the entry point falls through to the fp32 pipe for the rest)
         dymax = None
-        if _SPLIT and _WGRAD_SPLIT:
+        up_parity = (ups and k == 3 and not has1 and N == Np and c_real == C0 and _SPLIT and _WGRAD_SPLIT and ctx.xmax is not None
+                     and B * H * W * Np * 4 < 2 ** 31)
+        wsu = L.nbp_upconv_wgrad_split_workspace_bytes(B, H // 2, W // 2, C0, Np) if (up_parity and _UP_WGRAD) else 0
+        if wsu:
+            dymax = info[0] if info is not None else _amax_slot(dy)
+            wsb = _ws(wsu, dev)
+            _chk(L.nbp_upconv_wgrad_split_f32(_lib.ptr(x0), C0, B, H // 2, W // 2, _lib.ptr(dy), Np, _lib.ptr(dw), _lib.ptr(ctx.xmax),
+                                              _lib.ptr(dymax), _lib.ptr(wsb), wsb.numel(), _st()), "upconv_wgrad_split")
+        elif _SPLIT and _WGRAD_SPLIT:
             # max |dy|: shared with the data gradient below; measured by the BatchNorm backward when dy came from one (padding
             # channels are zeros: same maximum)
             dymax = (info[0] if info is not None else _amax_slot(dy)) if (k == 3 or one_by_one) else None

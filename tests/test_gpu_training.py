@@ -148,7 +148,7 @@ def test_batchnorm_statistics_from_the_convolution_epilogue(hip, monkeypatch, up
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 32, 128, 64), (1, 32, 64, 64, 64), (2, 16, 16, 256, 128), (1, 16, 32, 64, 192)])
-def test_upconv_data_gradient_in_parity_form(hip, monkeypatch, shape):
+def test_upconv_gradients_in_parity_form(hip, monkeypatch, shape):
     """Round 5: the data gradient of an up_conv layer (x2 nearest upsample + 3x3) at the LOW resolution straight from dy -- four parity
     planes x 2 x 2 taps (nbp_upconv3x3_split_dgrad_f32) -- against float64 autograd of the reference formulation and against
     round 4's form (full-resolution 3x3 data gradient + 2x2 sum); image borders included (the tiles cover the whole image)."""
@@ -161,14 +161,24 @@ def test_upconv_data_gradient_in_parity_form(hip, monkeypatch, shape):
     yr = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), w.double(), bias.double(), padding=1)
     yr.backward(gy.double().permute(0, 3, 1, 2))
     want = xr.grad.permute(0, 2, 3, 1)
-    got = []
+    want_w = None
+    got, got_w = [], []
     for parity in (True, False):
         monkeypatch.setattr(tr, "_UP_DGRAD", parity)
+        monkeypatch.setattr(tr, "_UP_WGRAD", parity)
         tr._reset_arena(torch.device(D))
         xd, wd, bd = x.to(D).requires_grad_(True), w.to(D).requires_grad_(True), bias.to(D).requires_grad_(True)
         y = tr.ConvFn.apply(xd, None, wd, bd, True, False)
         y.backward(gy.to(D))
         got.append(xd.grad.cpu().double())
+        got_w.append(wd.grad.cpu().double())
+    # the weight gradient in parity form (wgrad_up_split_kernel + its fold into the 3x3 filter) against float64 and the 3x3 form
+    wr = w.double().clone().requires_grad_(True)
+    F.conv2d(F.interpolate(x.double().permute(0, 3, 1, 2), scale_factor=2, mode="nearest"), wr, None, padding=1).backward(
+        gy.double().permute(0, 3, 1, 2))
+    ws_ = float(wr.grad.abs().max())
+    assert float((got_w[0] - wr.grad).abs().max()) < 3e-6 * ws_, float((got_w[0] - wr.grad).abs().max()) / ws_
+    assert float((got_w[1] - wr.grad).abs().max()) < 3e-6 * ws_
     import ctypes
     buf = ctypes.create_string_buffer(128)
     assert _lib.lib().nbp_tile_kernel_symbol(17, buf, 128) > 0 and buf.value.decode().endswith("true, false, false, true>")    # the DG form ran
