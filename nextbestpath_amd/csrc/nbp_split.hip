@@ -1048,6 +1048,85 @@ __global__ __launch_bounds__(256, 3) void wgrad_up_split_kernel(WgradSplitArgs a
     }
 }
 
+// ------------------------------------------------------------------ weight gradient of a 1x1 layer on the split scheme
+// dW[c][n] = sum over pixels of X[m][c] dY[m][n] (training's W_g / W_x layers on the large levels, where the fp32-pipe kernel ran at a
+// quarter of the HBM rate and needed dY padded from 32 to 64 channels): wgrad_split_kernel without halo or taps.  A workgroup owns a
+// 64 (c) x 64 (n) block -- columns beyond N are zero pixels and are not written -- and walks 64-pixel runs of the [M][.] tensors; one
+// accumulator tile per wave, so four workgroups share a CU and cover each other's loads.
+__global__ __launch_bounds__(256, 4) void wgrad_1x1_split_kernel(WgradSplitArgs a) {
+    constexpr int PL = 64 * 64;                // bytes of one (plane, channel half) region: 64 pixels x 64 B
+    extern __shared__ __attribute__((aligned(16))) char wl[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1, kh = lane >> 5, ln = lane & 31;
+    const int ci0 = (blockIdx.x / a.co_tiles) * 64, co0 = (blockIdx.x % a.co_tiles) * 64;
+    const int C = a.C0;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.bytesy, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int ex = amax_exponent(read_amax(a.amax0)), ey = amax_exponent(read_amax(a.amaxy));
+    const float sx = pow2f(SPLIT_EXP - ex), sy = pow2f(SPLIT_EXP - ey);
+    const int einv = ex + ey - 2 * SPLIT_EXP;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int c4 = tid & 15, sdst = c4 >> 3;
+    const bool ycol = co0 + c4 * 4 < a.N;      // (N % 4 == 0: a float4 of dY's columns exists or not as a whole)
+    const int loff = (8 * kh + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const char* const xa_hi = wl + (0 * 2 + wi) * PL + loff;
+    const char* const xa_lo = wl + (1 * 2 + wi) * PL + loff;
+    const char* const yb_hi = wl + 4 * PL + (0 * 2 + wj) * PL + loff;
+    const char* const yb_lo = wl + 4 * PL + (1 * 2 + wj) * PL + loff;
+    u32x4 xr[4], yr[4];
+    const long long M = (long long)a.H * a.W;  // (pixels; the launcher passes H = M / W)
+    auto fetch = [&](int tile) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long m = (long long)tile * 64 + ((tid + 256 * k) >> 4);
+            const bool ok = m < M;
+            xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? (unsigned)((m * C + ci0 + c4 * 4) * 4) : OOB, 0, 0);
+            yr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (ok && ycol) ? (unsigned)((m * a.N + co0 + c4 * 4) * 4) : OOB, 0, 0);
+        }
+    };
+    if ((int)blockIdx.y < a.n_tiles) fetch(blockIdx.y);
+    for (int tile = blockIdx.y; tile < a.n_tiles; tile += a.splits) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pz = (tid + 256 * k) >> 4;
+            const f32x4 v = __builtin_bit_cast(f32x4, xr[k]), w = __builtin_bit_cast(f32x4, yr[k]);
+            unsigned h0, l0, h1, l1;
+            split_pair(v[0] * sx, v[1] * sx, h0, l0);
+            split_pair(v[2] * sx, v[3] * sx, h1, l1);
+            char* d = wl + sdst * PL + pz * 64 + (c4 & 7) * 8;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + 2 * PL) = u32x2{l0, l1};
+            split_pair(w[0] * sy, w[1] * sy, h0, l0);
+            split_pair(w[2] * sy, w[3] * sy, h1, l1);
+            d += 4 * PL;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + 2 * PL) = u32x2{l0, l1};
+        }
+        __syncthreads();
+        if (tile + a.splits < a.n_tiles) fetch(tile + a.splits);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f16x8 bh = tr_frag(yb_hi + s * 1024), bl = tr_frag(yb_lo + s * 1024);
+            const f16x8 ah = tr_frag(xa_hi + s * 1024), al = tr_frag(xa_lo + s * 1024);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        }
+    }
+    float* out = a.part + (long long)blockIdx.y * C * a.N;      // part [split][C][N]
+    const int co = co0 + wj * 32 + ln;
+    if (co < a.N)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            out[(long long)ci * a.N + co] = ldexpf(acc[r], einv);
+        }
+}
+
 // dW OIHW [N][C][3][3] from the parity partials [split][parity][tap][C][N]: filter row ky collects the (py, r) pairs whose pre-summed
 // row contains it -- ky = 0: (0, 0), (1, 0); ky = 1: (0, 1), (1, 0); ky = 2: (0, 1), (1, 1) -- columns alike; slices in slice order,
 // the four entries in a fixed order (deterministic)
@@ -1915,6 +1994,22 @@ extern "C" int nbp_upconv_wgrad_split_f32(const float* x, int C, int B, int Hs, 
     int rc = nbp_launch_status();
     if (rc) return rc;
     wgrad_up_reduce_kernel<<<nbp_ew_grid((long long)N * C * 9, 256), 256, 0, st>>>(a.part, splits, C, N, dw);
+    return nbp_launch_status();
+}
+
+// ---- weight gradient of a 1x1 layer on the split scheme (wgrad_1x1_split_kernel): partial sums [splits][C][N] into `part`;
+// the caller reduces them (nbp_train.hip).  C % 64 == 0, N % 4 == 0.
+int nbp_wgrad_1x1_split_launch(const float* x, int C, long long M, const float* dy, int N, int n_tiles, int splits, const unsigned* amax_x,
+                               const unsigned* amax_y, float* part, hipStream_t st) {
+    NBP_RETURN_IF(M * C * 4 >= (1ll << 31) || M * N * 4 >= (1ll << 31), NBP_E_SHAPE);
+    WgradSplitArgs a;
+    NBP_RETURN_IF(M % 64 != 0, NBP_E_SHAPE);                       // (every level of the network; the kernel counts pixels as H x 64)
+    a.src0 = x; a.src1 = x; a.C0 = C; a.C1 = 0; a.ups = 0; a.H = (int)(M / 64); a.W = 64; a.Hs = a.H; a.Ws = a.W;
+    a.dy = dy; a.N = N; a.bytes0 = (unsigned)(M * C * 4); a.bytes1 = a.bytes0; a.bytesy = (unsigned)(M * N * 4);
+    a.co_tiles = (N + 63) / 64; a.n_tiles = n_tiles; a.splits = splits; a.prefetch = 1;
+    a.amax0 = amax_x; a.amax1 = amax_x; a.amaxy = amax_y; a.part = part;
+    dim3 grid((unsigned)((C / 64) * a.co_tiles), (unsigned)splits);
+    wgrad_1x1_split_kernel<<<grid, 256, 8 * 64 * 64, st>>>(a);
     return nbp_launch_status();
 }
 

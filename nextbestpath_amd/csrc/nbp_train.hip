@@ -139,8 +139,11 @@ __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
     const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
-    const long long r_begin = (long long)blockIdx.x * rows_per_block;
-    const long long r_end = r_begin + rows_per_block < M ? r_begin + rows_per_block : M;
+    // Rows are dealt to the workgroups in CHUNKS of 4 rpb rows, chunk k to workgroup k mod gridDim.x (round 5): with one contiguous
+    // run of rows per workgroup all 1024 workgroups walked their runs in step, 512 KB apart on the large tensors -- the same few HBM
+    // channels at any moment (3.0 - 3.5 TB/s); interleaved 16-KB chunks spread every moment's requests over all channels.
+    (void)rows_per_block;
+    const long long R = 4ll * rpb, n_chunks = (M + R - 1) / R;
     for (int c0 = 0; c0 < C4; c0 += CT) {
         const int c = c0 + c_local;
         f64x4 s0 = {0.0, 0.0, 0.0, 0.0}, s1 = {0.0, 0.0, 0.0, 0.0};
@@ -177,9 +180,12 @@ __global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict
                 }
                 if (MODE == 2) s0 += to_d4(v) * (double)(rows ? rows[r] : 1.f);
             };
-            long long r = r_begin + rsub;
-            for (; r + 3 * rpb < r_end; r += 4 * rpb) { step(r); step(r + rpb); step(r + 2 * rpb); step(r + 3 * rpb); }
-            for (; r < r_end; r += rpb) step(r);
+            for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+                const long long r = ch * R + rsub;
+                if (r + 3 * rpb < M) { step(r); step(r + rpb); step(r + 2 * rpb); step(r + 3 * rpb); }
+                else
+                    for (long long q = r; q < M; q += rpb) step(q);
+            }
         }
         sh0[threadIdx.x] = s0; sh1[threadIdx.x] = s1;
         __syncthreads();
@@ -438,8 +444,8 @@ __global__ __launch_bounds__(256) void bn_backward_apply4_sum_kernel(const float
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
     f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
-    const long long r_begin = (long long)blockIdx.x * rows_per_block;
-    const long long r_end = r_begin + rows_per_block < M ? r_begin + rows_per_block : M;
+    (void)rows_per_block;                      // chunks of 4 rpb rows, chunk k to workgroup k mod gridDim.x (see colreduce4_kernel)
+    const long long R = 4ll * rpb, n_chunks = (M + R - 1) / R;
     const bool stat_mask = relu && ms.stat_d;
     const bool from_y = relu && !stat_mask;
     float mx = 0.f;
@@ -454,21 +460,24 @@ __global__ __launch_bounds__(256) void bn_backward_apply4_sum_kernel(const float
                 s0 += to_d4(o);
                 mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
             };
-            long long r = r_begin + rsub;
-            for (; r + 3 * rpb < r_end; r += 4 * rpb) {          // four rows in flight (8 - 12 loads), the sums in row order
-                f32x4 dz[4], xv[4], yy[4];
+            for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+                const long long r = ch * R + rsub;
+                if (r + 3 * rpb < M) {                           // four rows in flight (8 - 12 loads), the sums in row order
+                    f32x4 dz[4], xv[4], yy[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const long long i = (r + u * rpb) * C4 + c;
-                    dz[u] = dy4[i]; xv[u] = x4[i]; yy[u] = from_y ? y4[i] : xv[u];
+                    for (int u = 0; u < 4; ++u) {
+                        const long long i = (r + u * rpb) * C4 + c;
+                        dz[u] = dy4[i]; xv[u] = x4[i]; yy[u] = from_y ? y4[i] : xv[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) emit((r + u * rpb) * C4 + c, dz[u], xv[u], yy[u]);
+                } else {
+                    for (long long q = r; q < M; q += rpb) {
+                        const long long i = q * C4 + c;
+                        const f32x4 xv = x4[i];
+                        emit(i, dy4[i], xv, from_y ? y4[i] : xv);
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) emit((r + u * rpb) * C4 + c, dz[u], xv[u], yy[u]);
-            }
-            for (; r < r_end; r += rpb) {
-                const long long i = r * C4 + c;
-                const f32x4 xv = x4[i];
-                emit(i, dy4[i], xv, from_y ? y4[i] : xv);
             }
         }
         sh0[threadIdx.x] = s0;
@@ -990,6 +999,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// First stage of a long slice reduction: out[g][i] = sum over the `group` consecutive slices of group g (slice order), 16 B per lane,
+// four slices in flight.  With one 64 x 64 channel block a 256 x 256 layer leaves 512 slices of 147 KB, and one thread per output
+// element walking all of them was a launch of 144 workgroups x 128 dependent round trips (50 us for 75 MB); 16 groups of 32 run on
+// 16 x as many workgroups and the final pass reads 16 slices (round 5).
+constexpr int WGRAD_REDUCE_GROUPS = 16;
+__global__ __launch_bounds__(256) void slice_group_sum_kernel(const float* __restrict__ part, int splits, long long slice4, int group,
+                                                              float* __restrict__ out) {
+    const int g = blockIdx.y;
+    const int k0 = g * group, k1 = min(k0 + group, splits);
+    const f32x4* p = reinterpret_cast<const f32x4*>(part);
+    f32x4* o = reinterpret_cast<f32x4*>(out) + (long long)g * slice4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slice4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            const f32x4 v0 = p[(long long)k * slice4 + i], v1 = p[(long long)(k + 1) * slice4 + i], v2 = p[(long long)(k + 2) * slice4 + i],
+                        v3 = p[(long long)(k + 3) * slice4 + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < k1; ++k) s += p[(long long)k * slice4 + i];
+        o[i] = s;
+    }
+}
+// part [splits][taps][Ctot][N] -> dw OIHW; long reductions in two stages through `tmp` (WGRAD_REDUCE_GROUPS slices)
+static int wgrad_reduce_launch(const float* part, int splits, int taps, int Ctot, int N, int c_real, int n_real, float* dw, float* tmp,
+                               hipStream_t st) {
+    const long long slice = (long long)taps * Ctot * N, total = (long long)n_real * c_real * taps;
+    if (tmp && splits >= 4 * WGRAD_REDUCE_GROUPS && slice % 4 == 0) {
+        const int group = (int)nbp_cdiv(splits, WGRAD_REDUCE_GROUPS), ng = (int)nbp_cdiv(splits, group);
+        dim3 grid((unsigned)min(nbp_cdiv(slice / 4, 256), 1024ll), (unsigned)ng);
+        slice_group_sum_kernel<<<grid, 256, 0, st>>>(part, splits, slice / 4, group, tmp);
+        int rc = nbp_launch_status();
+        if (rc) return rc;
+        part = tmp; splits = ng;
+    }
+    wgrad_reduce_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(part, splits, taps, Ctot, N, c_real, n_real, dw);
+    return nbp_launch_status();
+}
+
 // flipped + transposed packing for the data gradient: dst[(co)/32][tap][ci][co%32] = w[co][ci][taps-1-tap]
 __global__ void pack_dgrad_kernel(const float* __restrict__ w, int N, int C, int taps, int Cpad, int Npad,
                                   float* __restrict__ dst) {
@@ -1364,6 +1412,12 @@ static void wgrad_plan(long long M, int Ctot, int N, int taps, int* ti, int* ci_
 
 extern "C" size_t nbp_conv_wgrad_workspace_bytes(int B, int H, int W, int C0, int C1, int N, int ksize) {
     int ti, cit, cot, sp, ct, cps;
+    if (ksize == 1 && C1 == 0 && C0 % 64 == 0 && C0 <= 128 && N % 4 == 0 && N % 64) {      // the 1x1 split form alone takes such N
+        const long long M1 = (long long)B * H * W, n_tiles = M1 / 64;
+        long long s1 = nbp_cdiv(1024, (long long)(C0 / 64) * ((N + 63) / 64));
+        if (s1 > n_tiles) s1 = n_tiles;
+        return (size_t)(s1 + WGRAD_REDUCE_GROUPS) * C0 * N * sizeof(float) + 256 + 1024;
+    }
     if ((C0 + C1) % 64 || N % 64 || C0 % 64) return 0;
     wgrad_plan((long long)B * H * W, C0 + C1, N, ksize * ksize, &ti, &cit, &cot, &sp, &ct, &cps);
     if (wgrad_halo_ok(H, W, ksize)) {
@@ -1375,7 +1429,14 @@ extern "C" size_t nbp_conv_wgrad_workspace_bytes(int B, int H, int W, int C0, in
         wgrad_halo_plan(B, H / 2, W * 2, C0 + C1, N, &nt, &hs);
         if (hs > sp) sp = hs;
     }
-    return (size_t)sp * ksize * ksize * (C0 + C1) * N * sizeof(float) + 256 + 1024;     // + max-|.| scratch of the split form
+    if (ksize == 1 && C1 == 0 && C0 <= 128) {                      // the 1x1 split form: up to 1024 slices
+        const long long M1 = (long long)B * H * W, n_tiles = M1 / 64;
+        long long s1 = nbp_cdiv(1024, (long long)(C0 / 64) * (N / 64));
+        if (s1 > n_tiles) s1 = n_tiles;
+        if (s1 > sp) sp = (int)s1;
+    }
+    // (+ max-|.| scratch of the split form, + the first-stage sums of a long slice reduction)
+    return (size_t)(sp + WGRAD_REDUCE_GROUPS) * ksize * ksize * (C0 + C1) * N * sizeof(float) + 256 + 1024;
 }
 
 // dW [n_real][c_real][k][k] (OIHW) of out = conv(cat(src0, src1) [upsampled]) given dY [B,H,W,N].
@@ -1418,9 +1479,9 @@ extern "C" int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, 
         wgrad_halo_kernel<<<grid, 256, smem, st>>>(h);
         int rc = nbp_launch_status();
         if (rc) return rc;
-        const long long total = (long long)n_real * c_real * 9;
-        wgrad_reduce_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(h.part, h.splits, 9, C0 + C1, N, c_real, n_real, dw);
-        return nbp_launch_status();
+        float* tmp = h.part + (size_t)h.splits * 9 * (C0 + C1) * N;
+        const bool room = ws_bytes >= (size_t)(h.splits + WGRAD_REDUCE_GROUPS) * 9 * (C0 + C1) * N * sizeof(float) + 256;
+        return wgrad_reduce_launch(h.part, h.splits, 9, C0 + C1, N, c_real, n_real, dw, room ? tmp : nullptr, st);
     }
     int ti, sp;
     wgrad_plan(a.M, C0 + C1, N, a.taps, &ti, &a.ci_tiles, &a.co_tiles, &sp, &a.chunks_total, &a.chunks_per_split);
@@ -1432,12 +1493,16 @@ extern "C" int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, 
     else wgrad_kernel<1, 1><<<grid, 256, 0, st>>>(a);
     int rc = nbp_launch_status();
     if (rc) return rc;
-    const long long total = (long long)n_real * c_real * a.taps;
-    wgrad_reduce_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(a.part, sp, a.taps, C0 + C1, N, c_real, n_real, dw);
-    return nbp_launch_status();
+    {
+        float* tmp = a.part + (size_t)sp * a.taps * (C0 + C1) * N;
+        const bool room = ws_bytes >= (size_t)(sp + WGRAD_REDUCE_GROUPS) * a.taps * (C0 + C1) * N * sizeof(float) + 256;
+        return wgrad_reduce_launch(a.part, sp, a.taps, C0 + C1, N, c_real, n_real, dw, room ? tmp : nullptr, st);
+    }
 }
 
 // (nbp_split.hip)
+int nbp_wgrad_1x1_split_launch(const float* x, int C, long long M, const float* dy, int N, int n_tiles, int splits, const unsigned* amax_x,
+                               const unsigned* amax_y, float* part, hipStream_t st);
 int nbp_wgrad_split_launch(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W, const float* dy, int N,
                            int n_tiles, int splits, unsigned* amax3, const unsigned* amax0_in, const unsigned* amax1_in,
                            const unsigned* amaxy_in, float* part, hipStream_t st);
@@ -1453,6 +1518,25 @@ extern "C" int nbp_conv_wgrad_split_f32(const float* src0, int C0, const float* 
     const bool take = ksize == 3 && (wide || narrow) && (long long)B * H * W * N * 4 < (1ll << 31) && src0 && dy && dw &&
                       ws && B >= 1 && C0 >= 64 && C0 % 64 == 0 && C1 >= 0 && C1 % 64 == 0 && N >= 64 && N % 64 == 0 &&
                       (C1 == 0 || src1) && !(ups && ((H | W) & 1));
+    // 1x1 layers on the large levels (few channels, many pixels: memory-bound) run the split scheme's own kernel; N need not be padded
+    const long long M1 = (long long)B * H * W;
+    if (ksize == 1 && C1 == 0 && !ups && src0 && dy && dw && ws && amax0_or_null && amaxy_or_null && C0 >= 64 && C0 % 64 == 0 && C0 <= 128 &&
+        N >= 4 && N % 4 == 0 && c_real == C0 && n_real == N && M1 % 64 == 0 && M1 * C0 * 4 < (1ll << 31) && M1 * N * 4 < (1ll << 31)) {
+        NBP_ENTER();
+        const int n_tiles = (int)(M1 / 64);
+        const long long pairs = (long long)(C0 / 64) * ((N + 63) / 64);
+        long long sp = nbp_cdiv(1024, pairs);
+        if (sp > n_tiles) sp = n_tiles;
+        const size_t slice = (size_t)C0 * N * sizeof(float);
+        if (ws_bytes >= (size_t)(sp + WGRAD_REDUCE_GROUPS) * slice + 256) {
+            float* part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
+            hipStream_t st1 = (hipStream_t)stream;
+            int rc = nbp_wgrad_1x1_split_launch(src0, C0, M1, dy, N, n_tiles, (int)sp, (const unsigned*)amax0_or_null,
+                                                (const unsigned*)amaxy_or_null, part, st1);
+            if (rc) return rc;
+            return wgrad_reduce_launch(part, (int)sp, 1, C0, N, c_real, n_real, dw, part + (size_t)sp * C0 * N, st1);
+        }
+    }
     if (!take) return nbp_conv_wgrad_f32(src0, C0, src1, C1, ups, B, H, W, ksize, dy, N, c_real, n_real, dw, ws, ws_bytes, stream);
     NBP_ENTER();
     NBP_RETURN_IF(c_real < 1 || c_real > C0 + C1 || n_real < 1 || n_real > N, NBP_E_ARG);
@@ -1465,9 +1549,9 @@ extern "C" int nbp_conv_wgrad_split_f32(const float* src0, int C0, const float* 
     int rc = nbp_wgrad_split_launch(src0, C0, src1, C1, ups, B, H, W, dy, N, n_tiles, splits, amax3, (const unsigned*)amax0_or_null,
                                     (const unsigned*)amax1_or_null, (const unsigned*)amaxy_or_null, part, st);
     if (rc) return rc;
-    const long long total = (long long)n_real * c_real * 9;
-    wgrad_reduce_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(part, splits, 9, C0 + C1, N, c_real, n_real, dw);
-    return nbp_launch_status();
+    float* tmp = part + (size_t)splits * 9 * (C0 + C1) * N;
+    const bool room = ws_bytes >= (size_t)(splits + WGRAD_REDUCE_GROUPS) * 9 * (C0 + C1) * N * sizeof(float) + 256 + 1024;
+    return wgrad_reduce_launch(part, splits, 9, C0 + C1, N, c_real, n_real, dw, room ? tmp : nullptr, st);
 }
 
 extern "C" int nbp_gather_values_f32(const float* out1_nchw, const long long* coords_bcxy, int K, int C, int H, int W, float* pred,

@@ -344,7 +344,9 @@ class ConvFn(torch.autograd.Function):
             db = info[1][:N].clone() if info is not None else _colsum(dy.view(M, Np))[:N].clone()
         dw = torch.empty(N, c_real, k, k, dtype=torch.float32, device=dev)
         # (the fp32-pipe weight-gradient kernels of the 1x1 layers take 64-column blocks of dy: a 32-channel gate pads here only)
-        dyw, Nw = (dy, Np) if Np % 64 == 0 else (_pad_channels(dy, _up(Np)), _up(Np))
+        # ... unless the 1x1 split form takes the layer (few input channels, many pixels: it masks the missing columns itself)
+        own_1x1 = one_by_one and _SPLIT and _WGRAD_SPLIT and C0 % 64 == 0 and C0 <= 128 and (B * H * W) % 64 == 0
+        dyw, Nw = (dy, Np) if (Np % 64 == 0 or own_1x1) else (_pad_channels(dy, _up(Np)), _up(Np))
         ws = _ws(L.nbp_conv_wgrad_workspace_bytes(B, H, W, C0, C1, Nw, k), dev)
         # the 3x3 weight gradients take the split scheme too (the entry point falls through to the fp32 pipe for the rest)
         dymax = None

@@ -808,3 +808,24 @@ def test_composed_backward_at_the_oracle_point(hip, nbp_weights):
             worst.append((name, rel, norms[name]))
     # (the ~45 skipped tensors are the conv biases in front of a train-mode BatchNorm, whose true gradient is zero)
     assert checked >= 140 and not worst, (checked, sorted(worst, key=lambda t: -t[1])[:10])
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 32), (1, 16, 64, 128, 64), (2, 16, 16, 64, 64)])
+def test_1x1_layer_gradients_on_the_split_scheme(hip, shape):
+    """Round 5: a 1x1 layer (Attention_block.W_g / W_x) in training -- forward and data gradient through the gates' kernel with one
+    source, weight gradient through wgrad_1x1_split_kernel (32 output channels unpadded: the kernel masks the missing columns) --
+    against float64 autograd."""
+    B, H, W, C, N = shape
+    x, w, bias = _rand(B, H, W, C, seed=1), _rand(N, C, 1, 1, seed=2) * 0.1, _rand(N, seed=3) * 0.1
+    gy = _rand(B, H, W, N, seed=4)
+    xr, wr = x.double().permute(0, 3, 1, 2).clone().requires_grad_(True), w.double().clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, bias.double())
+    yr.backward(gy.double().permute(0, 3, 1, 2))
+    tr._reset_arena(torch.device(D))
+    xd, wd, bd = x.to(D).requires_grad_(True), w.to(D).requires_grad_(True), bias.to(D).requires_grad_(True)
+    y = tr.ConvFn.apply(xd, None, wd, bd, False)
+    y.backward(gy.to(D))
+    for nm, got, want in (("y", y.detach().cpu().double(), yr.detach().permute(0, 2, 3, 1)), ("dx", xd.grad.cpu().double(), xr.grad.permute(0, 2, 3, 1)),
+                          ("dw", wd.grad.cpu().double(), wr.grad), ("db", bd.grad.cpu().double(), gy.double().sum((0, 1, 2)))):
+        sc = float(want.abs().max())
+        assert float((got - want).abs().max()) < 3e-6 * sc, (nm, float((got - want).abs().max()) / sc)
