@@ -235,11 +235,9 @@ def ptr(t) -> int:
 _knobs = {}
 # switches that change the ARITHMETIC (results differ beyond reordering): a benchmark line measured with one of them set is
 # not the headline configuration (bench.py refuses to call it `value`)
-NUMERICS_KNOBS = {"NBP_CONV_PRECISION", "NBP_TRAIN_SPLIT", "NBP_TRAIN_WGRAD_SPLIT", "NBP_SPLIT_MAX_K", "NBP_SPLIT_MAX_K_SMALL",
-                  "NBP_SPLIT_SMALL_MB", "NBP_SPLIT_R8_SK", "NBP_GATE_WIDE_PSI", "NBP_SPLIT_HALO", "NBP_SPLIT_UP", "NBP_SPLIT_GATE", "NBP_GATE_PSI",
-                  "NBP_SPLIT_MIN_BLOCKS", "NBP_SPLIT_DEEP", "NBP_CONV_HEAD", "NBP_F32_HALO", "NBP_F32_HALO4", "NBP_F32_HALO_MIN",
-                  "NBP_BF16_UP", "NBP_BF16_HALO", "NBP_BF16_PSI", "NBP_BF16_FUSE", "NBP_FIRST_MFMA", "NBP_WGRAD_HALO",
-                  "NBP_WGRAD_BLOCKS", "NBP_TRAIN_FUSE"}
+NUMERICS_KNOBS = {"NBP_CONV_PRECISION", "NBP_TRAIN_SPLIT", "NBP_TRAIN_WGRAD_SPLIT", "NBP_SPLIT_MAX_K", "NBP_SPLIT_MAX_K_SMALL", "NBP_GATE_PSI",
+                  "NBP_CONV_HEAD", "NBP_BF16_PSI", "NBP_BF16_FUSE", "NBP_TRAIN_FUSE", "NBP_TRAIN_SPLIT_1X1", "NBP_TRAIN_CHAIN_BOUND",
+                  "NBP_TRAIN_UP_DGRAD", "NBP_TRAIN_UP_WGRAD"}
 
 
 def tuning_active() -> bool:

@@ -579,13 +579,12 @@ static bool halo_ok(int H, int W, int N, int ksize, int bn) {
 ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int split_k, int groups, int H, int W,
                             int ksize, int ups) {
     ConvPlan p;
-    static const int allow_up = nbp_tune_int("NBP_BF16_UP", 1);
-    if ((tile == NBP_TILE_AUTO && allow_up && ups && ksize == 3 && split_k <= 0) || tile == NBP_TILE_HALO_UP_128 ||
+    if ((tile == NBP_TILE_AUTO && ups && ksize == 3 && split_k <= 0) || tile == NBP_TILE_HALO_UP_128 ||
         tile == NBP_TILE_HALO_UP_64) {
         // up_conv as four parity convolutions of the low-resolution image (8 x 32 low-resolution tiles)
         const int bn = tile == NBP_TILE_HALO_UP_128 ? 128 : tile == NBP_TILE_HALO_UP_64 ? 64 : (N % 128 == 0 ? 128 : 64);
         if (!((H | W) & 1) && halo_ok(H / 2, W / 2, N, 3, bn)) {
-            static const int min_blocks_up = nbp_tune_int("NBP_BF16_HALO_MIN", 128);
+            constexpr int min_blocks_up = 128;
             const long long blocks = (M / 4 / 256) * (N / bn) * groups * 4;
             const int cc = chunks_total / 9;
             int sk = split_k <= 0 ? 1 : split_k;
@@ -602,14 +601,13 @@ ConvPlan nbp_plan_conv_bf16(long long M, int N, int chunks_total, int tile, int 
     if (tile == NBP_TILE_AUTO && ksize == 3 && split_k <= 0) {
         // halo-tile kernel once tiles (x split-K over whole chunks) give >= ~128 workgroups
         // (threshold from tools/bench_forward.py sweeps at B = 1..8, S = 256 / 512)
-        static const int allow = nbp_tune_int("NBP_BF16_HALO", 1);
         const int bn = N % 128 == 0 ? 128 : 64;
-        static const int min_blocks = nbp_tune_int("NBP_BF16_HALO_MIN", 128);
+        constexpr int min_blocks = 128;
         const long long blocks = (M / 256) * (N / bn) * groups;
         const int cc = chunks_total / 9;
         int sk = 1;
         while (blocks * sk < min_blocks && cc / (sk * 2) >= 4 && sk < 16) sk *= 2;
-        if (allow && halo_ok(H, W, N, ksize, bn) && blocks * sk >= min_blocks) {
+        if (halo_ok(H, W, N, ksize, bn) && blocks * sk >= min_blocks) {
             tile = bn == 128 ? NBP_TILE_HALO_128 : NBP_TILE_HALO_64;
             split_k = sk;
         }
@@ -731,8 +729,7 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
         NBP_RETURN_IF(!halo_ok(H, W, N, ksize, ti.bn), NBP_E_SHAPE);
     a.split_k = p.split_k; a.chunks_per_split = p.chunks_per_split;
     {
-        static const int forced = nbp_tune_int("NBP_XCD_REMAP", -1);
-        a.xcd_remap = forced >= 0 ? forced : ((a.M / 256) * (N / ti.bn) >= 512 ? 1 : 0);
+        a.xcd_remap = (a.M / 256) * (N / ti.bn) >= 512 ? 1 : 0;
     }
     a.partial = nullptr;
     if (p.split_k > 1) {
@@ -776,8 +773,7 @@ int nbp_conv_igemm_bf16_launch_g(const ConvOperandsH& o, const ConvOperandsH* o2
         case NBP_TILE_HALO_UP_128: rc = launch_halo<4, 1, true>(a, f, st, p.tile); break;
         case NBP_TILE_HALO_UP_64: rc = launch_halo<2, 2, true>(a, f, st, p.tile); break;
         case NBP_TILE_HALO_64: {
-            static const int tps = nbp_tune_int("NBP_BF16_TPS", 2);
-            rc = tps == 2 ? launch_halo<2, 2>(a, f, st, p.tile) : launch_halo<2, 1>(a, f, st, p.tile);
+            rc = launch_halo<2, 2>(a, f, st, p.tile);       // (two taps per weight stage; one per stage measured slower, round 2)
             break;
         }
         default: return NBP_E_ARG;
@@ -964,8 +960,7 @@ int nbp_conv_first_bf16_launch(const float* x_nchw, int B, int H, int W, const f
     NBP_RETURN_IF(!x_nchw || !w_oihw || !scale || !shift || !out_nhwc, NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 1 || W < 1, NBP_E_ARG);
     long long M = (long long)B * H * W;
-    static const int use_mfma = nbp_tune_int("NBP_FIRST_MFMA", 1);
-    if (use_mfma && (H & 7) == 0 && (W & 31) == 0) {
+    if ((H & 7) == 0 && (W & 31) == 0) {
         conv_first_mfma_bf16_kernel<<<(unsigned)(M / 256 < 2048 ? M / 256 : 2048), 256, 0, st>>>(x_nchw, B, H, W, w_oihw, scale, shift, out_nhwc);
         return nbp_launch_status();
     }

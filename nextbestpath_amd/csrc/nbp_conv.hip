@@ -437,18 +437,17 @@ static bool is_halo_tile(int t) {
 
 ConvPlan nbp_plan_conv(long long M, int N, int chunks_total, int tile, int split_k, int groups, int H, int W, int ksize) {
     if (tile == NBP_TILE_AUTO && ksize == 3 && split_k <= 0) {
-        // halo-tile kernel (no split-K) once tiles alone fill the chip; NBP_F32_HALO=0 disables, NBP_F32_HALO_MIN tunes
-        static const int allow = nbp_tune_int("NBP_F32_HALO", 1);
-        static const int min_blocks = nbp_tune_int("NBP_F32_HALO_MIN", 256);
+        // halo-tile kernel (no split-K) once tiles alone fill the chip
+        constexpr int min_blocks = 256;
         const int bn = N % 128 == 0 ? 128 : 64;
         // split-K over whole 32-channel chunks may fill the chip when the tiles alone do not (each slice keeps
         // >= 2 chunks = 18 (chunk, tap) steps)
         const int cc = chunks_total / 9;
         // 8-row tiles; 4-row tiles (twice the workgroups, half the MFMAs per barrier: tile ids 8 / 9) were measured
         // neutral at B = 1..8 when preferred over a split-K > 2, so the automatic choice uses them only on request
-        static const int allow4 = nbp_tune_int("NBP_F32_HALO4", 0);
+        constexpr int allow4 = 0;
         int sk_of[2] = {0, 0};      // split-K that fills the chip with 8-row / 4-row tiles (0 = not possible)
-        for (int v = 0; v < 2 && allow; ++v) {
+        for (int v = 0; v < 2; ++v) {
             const int rows = v == 0 ? 8 : 4;
             if ((v == 1 && !allow4) || !halo_ok_f32(H, W, N, ksize, bn, rows)) continue;
             const long long blocks = (M / (rows * 32)) * (N / bn) * groups;
@@ -577,11 +576,10 @@ int nbp_conv_igemm_launch_g(const ConvOperands& o, const ConvOperands* o2, int C
     a.split_k = p.split_k; a.chunks_per_split = p.chunks_per_split;
     {   // XCD-contiguous tile runs cut the L2-miss traffic of the 3x3 halo rows; measured on MI355X they are
         // neutral-to-better (+2 %) once the grid is several waves deep and cost up to 10 % on single-wave grids,
-        // so only multi-wave grids get them.  NBP_XCD_REMAP=0/1 forces the choice (A/B measurements).
-        static const int forced = nbp_tune_int("NBP_XCD_REMAP", -1);
+        // so only multi-wave grids get them.
         const long long tiles = nbp_cdiv(a.M, ti.bm) * (N / ti.bn);
         const bool halo = is_halo_tile(p.tile);
-        a.xcd_remap = forced >= 0 ? forced : ((halo ? tiles >= 512 : tiles >= 2048) ? 1 : 0);
+        a.xcd_remap = (halo ? tiles >= 512 : tiles >= 2048) ? 1 : 0;
     }
     a.partial = nullptr;
     if (p.split_k > 1) {
@@ -731,7 +729,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
 // instruction fetch: ~11 us of the ~19 us a one-tile workgroup takes) is paid once per workgroup, so no more workgroups than
 // two per CU (NBP_FIRST_GRID overrides)
 static unsigned first_grid(long long M) {
-    static const int cap = [] { const int v = nbp_tune_int("NBP_FIRST_GRID", 512); return v > 0 ? v : 512; }();
+    constexpr int cap = 512;
     const long long tiles = M / 256;
     return (unsigned)(tiles < cap ? tiles : cap);
 }
@@ -741,9 +739,8 @@ static unsigned first_grid(long long M) {
 int nbp_conv_first_amax_launch(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale, const float* shift,
                                float* out_nhwc, unsigned* amax_out, int* did_amax, hipStream_t st) {
     long long M = (long long)B * H * W;
-    static const int use_mfma = nbp_tune_int("NBP_FIRST_MFMA", 1);
     *did_amax = 0;
-    if (use_mfma && (H & 7) == 0 && (W & 31) == 0) {
+    if ((H & 7) == 0 && (W & 31) == 0) {
         conv_first_mfma_kernel<<<first_grid(M), 256, 0, st>>>(x_nchw, B, H, W, w_oihw, scale, shift, out_nhwc, amax_out);
         *did_amax = amax_out ? 1 : 0;
         return nbp_launch_status();
@@ -757,8 +754,7 @@ extern "C" int nbp_conv_first_f32(const float* x_nchw, int B, int H, int W, cons
     NBP_RETURN_IF(!x_nchw || !w_oihw || !scale || !shift || !out_nhwc, NBP_E_ARG);
     NBP_RETURN_IF(B < 1 || H < 1 || W < 1, NBP_E_ARG);
     long long M = (long long)B * H * W;
-    static const int use_mfma = nbp_tune_int("NBP_FIRST_MFMA", 1);
-    if (use_mfma && (H & 7) == 0 && (W & 31) == 0) {     // 8 x 32 pixel tiles; other sizes take the VALU kernel below
+    if ((H & 7) == 0 && (W & 31) == 0) {     // 8 x 32 pixel tiles; other sizes take the VALU kernel below
         conv_first_mfma_kernel<<<first_grid(M), 256, 0, (hipStream_t)stream>>>(x_nchw, B, H, W, w_oihw, scale, shift, out_nhwc, nullptr);
         return nbp_launch_status();
     }

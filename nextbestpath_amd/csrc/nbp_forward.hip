@@ -423,8 +423,7 @@ struct PathSplit : PathF32 {
     }
     static int conv(Ctx& ctx, const nbp_weights* h, const int* li, const Ops& o, const Ops* o2, int C0, int C1, int ups, int B,
                     int H, int ks, int N, void* ws, size_t wsb, hipStream_t st) {
-        static const int allow_gate = nbp_tune_int("NBP_SPLIT_GATE", 1);
-        if (allow_gate && ks == 1 && C1 == C0 && C0 % 64 == 0 && !ups && h->w1[li[0]] && (!o2 || h->w1[li[1]])) {
+        if (ks == 1 && C1 == C0 && C0 % 64 == 0 && !ups && h->w1[li[0]] && (!o2 || h->w1[li[1]])) {
             // attention gate: relu([g | x] W + b) as one 1x1 GEMM on the split scheme
             const long long M = (long long)B * H * H;
             ConvOperandsSplit s[2];

@@ -624,7 +624,7 @@ extern "C" int nbp_step_maps_batch_f32(int n, const float* const* points, const 
     const size_t SS = (size_t)S * S;
     // points per workgroup = 8192 x rounds (NBP_MAP_ROUNDS = 1 | 2 | 4): with a group's workgroups side by side the chip is full
     // anyway, and a table that sees more consecutive points flushes fewer keys per point
-    static const int rounds = [] { const int v = nbp_tune_int("NBP_MAP_ROUNDS", 4); return v == 1 || v == 2 ? v : 4; }();
+    constexpr int rounds = 4;
     MapBatch b;
     unsigned max_wg = 1;
     for (int r = 0; r < MAP_BATCH; ++r) {

@@ -892,7 +892,7 @@ static CamSet camset_from_host(const float* cams12_host, int n) {
     return cs;
 }
 
-static int ticket_fence() { static const int v = nbp_tune_int("NBP_TICKET_FENCE", 0); return v; }
+static int ticket_fence() { constexpr int v = 0; return v; }
 struct ShadeSrc { const unsigned long long* zface; const float* verts; const int* faces; const float* vcolors; float ambient; };
 static int unproject_launch(const float* depth, const unsigned char* mask_or_null, const float* cams12_host, int n_frames, int H,
                             int W, float tan_half_fov, float fov_range, double gathering_factor, unsigned seed, int* counts2,
@@ -1039,7 +1039,7 @@ static int raster_launch(const float* verts, int n_verts, const int* faces, int 
         e = hipMemsetAsync(gray, 0, (size_t)n_frames * sizeof(double), st);
         if (e != hipSuccess) return (int)e;
     }
-    static const int SEG = [] { const int v = nbp_tune_int("NBP_RASTER_SEG", SEG_DEFAULT); return v >= 1024 ? v / 1024 * 1024 : SEG_DEFAULT; }();
+    constexpr int SEG = SEG_DEFAULT;
     const int nseg = (int)nbp_cdiv(n_faces, SEG);
     dim3 g2((unsigned)(tiles_x * tiles_y * nseg), (unsigned)n_frames);
     raster_tile_kernel<<<g2, 64, 0, st>>>(recs, n_faces, H, W, tan_half_fov, z_clip, tiles_x, tiles_y, ctiles_x, ctiles_y,
@@ -1165,7 +1165,7 @@ extern "C" int nbp_raster_zface_batch_f32(int n, const float* const* verts, cons
     hipStream_t st = (hipStream_t)stream;
     const int ctiles_x = (int)nbp_cdiv(tiles_x, COARSE), ctiles_y = (int)nbp_cdiv(tiles_y, COARSE);
     const size_t nct = (size_t)ctiles_x * ctiles_y * n_frames;
-    static const int SEG = [] { const int v = nbp_tune_int("NBP_RASTER_SEG", SEG_DEFAULT); return v >= 1024 ? v / 1024 * 1024 : SEG_DEFAULT; }();
+    constexpr int SEG = SEG_DEFAULT;
     RasterBatch b;
     unsigned g_setup = 1, g_tile = 1;
     for (int r = 0; r < STEP_BATCH; ++r) {

@@ -149,7 +149,7 @@ __device__ unsigned nbp_dbg_n;
 // low-resolution tile, plain output (no parity scatter, no 2 x 2 sum pass).  a.H / a.W = the low-resolution output, a.Hs / a.Ws = dout.
 template <int TW, int TM, int TN, bool PH, bool BS = false, bool P2 = false, bool DG = false>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_h2_kernel(SplitArgs a) {
-    static_assert(!P2 || (PH && !BS), "two-parity form: up_conv layers, eval");
+    static_assert(!P2 || PH, "two-parity form: up_conv layers");
     static_assert(!DG || (PH && !BS && !P2), "data gradient of an up_conv layer: the one-parity tap structure");
     constexpr bool PHO = PH && !DG;                            // the launch writes one output parity of the full-resolution image
     int zs = blockIdx.z;
@@ -415,6 +415,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const bool bn_stats = BS && final_out && o.bn_part;
     double* const bsh = reinterpret_cast<double*>(ldsb);       // [wave][BN columns][sum | sum of squares]: the stage buffers are dead
     if constexpr (BS) { if (bn_stats) __syncthreads(); }       // (every wave has left the last stage's LDS reads)
+    double bs1[BS ? TN : 1], bs2[BS ? TN : 1];                 // BS: this lane's column sums over its pixels (both parities of P2)
+#pragma unroll
+    for (int j = 0; j < (BS ? TN : 1); ++j) { bs1[j] = 0.0; bs2[j] = 0.0; }
     float hp[HEADABLE ? TM : 1][16];
     if constexpr (HEADABLE) {
 #pragma unroll
@@ -449,15 +452,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
         }
         if constexpr (BS) {
-            if (bn_stats) {
-                // this lane's column over its TM x 16 pixels, the other half wave's pixels by one exchange, in double
-                double s1 = 0.0, s2 = 0.0;
+            if (bn_stats) {             // this lane's column over its TM x 16 pixels, in double
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { const double d = (double)vals[i][r]; s1 += d; s2 = fma(d, d, s2); }
-                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-                if (lane < 32) { bsh[(wave * BN + j * 32 + lane) * 2] = s1; bsh[(wave * BN + j * 32 + lane) * 2 + 1] = s2; }
+                    for (int r = 0; r < 16; ++r) { const double d = (double)vals[i][r]; bs1[j] += d; bs2[j] = fma(d, d, bs2[j]); }
             }
         }
         // 2x2 max-pool of the same values: the four pixels of a window are registers of ONE lane (a wave's row blocks are
@@ -522,12 +521,17 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     if constexpr (BS) {
         if (bn_stats) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {                     // the other half wave's pixels by one exchange
+                const double s1 = bs1[j] + __shfl_xor(bs1[j], 32), s2 = bs2[j] + __shfl_xor(bs2[j], 32);
+                if (lane < 32) { bsh[(wave * BN + j * 32 + lane) * 2] = s1; bsh[(wave * BN + j * 32 + lane) * 2 + 1] = s2; }
+            }
             __syncthreads();
             if (tid < BN) {                                    // the four waves' pixel rows in a fixed order
                 double s1 = 0.0, s2 = 0.0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { s1 += bsh[(w * BN + tid) * 2]; s2 += bsh[(w * BN + tid) * 2 + 1]; }
-                const long long row = PH ? (long long)tile_lin * 4 + (py * 2 + px) : (long long)tile_lin;
+                const long long row = P2 ? (long long)tile_lin * 2 + py : PH ? (long long)tile_lin * 4 + (py * 2 + px) : (long long)tile_lin;
                 o.bn_part[(row * 2) * a.N + n0 + tid] = s1;
                 o.bn_part[(row * 2 + 1) * a.N + n0 + tid] = s2;
             }
@@ -775,7 +779,6 @@ struct WgradSplitArgs {
     int co_tiles, n_tiles, splits;
     const unsigned* amax0; const unsigned* amax1; const unsigned* amaxy;
     float* part;           // [split][tap][Ctot][N]
-    int prefetch;          // 1: the next tile's loads are issued before the current tile's MFMAs (NBP_WGRAD_PREFETCH)
 };
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
@@ -854,9 +857,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
             yr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (unsigned)((m * a.N + co0 + c4 * 4) * 4), 0, 0);
         }
     };
-    if (a.prefetch && (int)blockIdx.y < a.n_tiles) fetch(blockIdx.y);
+    if ((int)blockIdx.y < a.n_tiles) fetch(blockIdx.y);
     for (int tile = blockIdx.y; tile < a.n_tiles; tile += a.splits) {
-        if (!a.prefetch) fetch(tile);
         __syncthreads();                       // every wave is done with the previous tile's planes
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
             *reinterpret_cast<u32x2*>(d + 2 * YPL) = u32x2{l0, l1};
         }
         __syncthreads();
-        if (a.prefetch && tile + a.splits < a.n_tiles) fetch(tile + a.splits);
+        if (tile + a.splits < a.n_tiles) fetch(tile + a.splits);
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
             // the row offset is made opaque to the compiler: left visible, it keeps the fragments of the halo rows that tile rows r
@@ -930,9 +932,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitArgs a) {
 // the low-resolution image like wgrad_split_kernel: the (TR + 1) x (TW + 1) halo of X it needs (rows v0 - 1 + py .., columns
 // u0 - 1 + px ..) and the tile's 64 pixels of dY's parity plane go global -> registers -> scale, split -> LDS fp16 planes
 // [32-channel half][pixel][32 channels]; transpose reads hand both MFMA operands 8 consecutive pixels of one channel per lane.
-// Four accumulator tiles per wave instead of nine: 64 + 44 registers of accumulators and prefetch, no scratch, three workgroups per CU.
+// Four accumulator tiles per wave instead of nine: 64 + 44 registers of accumulators and prefetch, no scratch (two or three workgroups
+// per CU measure the same; the bound of two leaves the allocator room).
 template <int TW>
-__global__ __launch_bounds__(256, 3) void wgrad_up_split_kernel(WgradSplitArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_up_split_kernel(WgradSplitArgs a) {
     constexpr int TR = 64 / TW, HW_ = TW + 2, HP = (TR + 1) * HW_;     // tile rows; halo pixels ((TR + 1) rows x (TW + 2): TW + 1 are used)
     constexpr int NX = (HP * 16 + 255) / 256;
     constexpr int XPL = HP * 64, YPL = 64 * 64;
@@ -1432,8 +1435,7 @@ int launch_h2(const SplitArgs& a, hipStream_t st, int tile) {
 static int chain_bounded_split(int sk, int cc, int taps, long long M, int N, int groups) {
     static const int max_k = nbp_tune_int("NBP_SPLIT_MAX_K", NBP_SPLIT_MAX_K_DEFAULT);
     static const int max_k_small = nbp_tune_int("NBP_SPLIT_MAX_K_SMALL", NBP_SPLIT_MAX_K_SMALL_DEFAULT);
-    static const int small_mb = nbp_tune_int("NBP_SPLIT_SMALL_MB", 64);
-    const bool small = (double)M * N * groups * 4.0 <= (double)small_mb * 1048576.0;
+    const bool small = (double)M * N * groups * 4.0 <= 64.0 * 1048576.0;       // one slice of all groups <= 64 MB
     const int mk = small && max_k_small > 0 ? max_k_small : max_k;
     if (mk <= 0) return sk;
     const int max_chunks = mk / (16 * taps) > 1 ? mk / (16 * taps) : 1;
@@ -1453,42 +1455,34 @@ static long long half_rows_below() {
     return v;
 }
 
-// Whether the doubled workgroup count of 8-row tiles may buy fewer split-K slices (NBP_SPLIT_R8_SK = 1) or the slices stay those of
-// the 16-row plan (0): fewer slices are longer accumulation chains -- inside the chain bound, but the rollout-input error statistics of
-// tests/test_gpu_rollout_parity.py sit at the bound's edge then
-static bool r8_counts_double() {
-    static const int v = nbp_tune_int("NBP_SPLIT_R8_SK", 0);
-    return v != 0;
-}
+// (The split-K slices of an 8-row launch stay those of the 16-row plan: letting the doubled workgroup count buy fewer slices was
+// measured no faster, and its longer chains put the rollout-input error statistics of tests/test_gpu_rollout_parity.py at the edge
+// of their bound -- round 3.)
 
 // ... and for launches whose last round of workgroups is a thin tail: with S = 512 resident workgroups (two per CU) a launch of 640
 // 16-row workgroups is one full round plus a quarter-full one, 1280 half-size ones are 2.5 half rounds.  Measured (B = 5, whose
 // full-resolution layers are 640 workgroups): -2.8 % of the forward.  A HALF-full last round (768, 1280 workgroups: B = 12, 20) does not
 // gain -- its workgroups run alone on their CUs, 1.7 x faster -- and pays the 8-row tiles' doubled weight traffic (+0.3 .. +0.9 %), so
-// the rule takes tails of up to 160 workgroups only (NBP_SPLIT_R8_TAIL = that bound, 0 = off).
+// the rule takes tails of up to 160 workgroups only.
 static bool half_rows_for_tail(long long workgroups) {
-    static const int bound = nbp_tune_int("NBP_SPLIT_R8_TAIL", 160);
-    if (bound <= 0 || workgroups <= 512) return false;
+    if (workgroups <= 512) return false;
     const long long rem = workgroups % 512;
-    return rem > 0 && rem <= bound;
+    return rem > 0 && rem <= 160;
 }
 
 ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize, int ups) {
     ConvPlan p{0, 1, chunks_total};
-    static const int allow = nbp_tune_int("NBP_SPLIT_HALO", 1);
-    static const int allow_up = nbp_tune_int("NBP_SPLIT_UP", 1);
-    if (allow && allow_up && ups && !((H | W) & 1)) {
+    constexpr int min_blocks = 256;           // split-K workgroup target: one workgroup per CU
+    if (ups && !((H | W) & 1)) {
         const int twu = split_tile_width(H / 2, W / 2, N, ksize);
         if (twu) {
-            static const int min_blocks_up = nbp_tune_int("NBP_SPLIT_MIN_BLOCKS", 256);
             const int cc = chunks_total / 9 * 2;
-            long long blocks = (M / 4 / (16 * twu)) * (N / (twu == 32 ? 64 : 128)) * groups * 4;
+            const long long blocks = (M / 4 / (16 * twu)) * (N / (twu == 32 ? 64 : 128)) * groups * 4;
             const bool r8 = blocks < half_rows_below();      // 8-row tiles: twice the workgroups, half the chain each
-            if (r8 && r8_counts_double()) blocks *= 2;
             int sk = split_k;
             if (sk <= 0) {
                 sk = 1;
-                while (blocks * sk < min_blocks_up && cc / (sk * 2) >= 4 && sk < 16) sk *= 2;
+                while (blocks * sk < min_blocks && cc / (sk * 2) >= 4 && sk < 16) sk *= 2;
             }
             if (split_k == 0) sk = chain_bounded_split(sk, cc, 4, M, N, groups);      // (split_k < 0: by occupancy only)
             if (sk > cc) sk = cc;
@@ -1501,22 +1495,19 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
     }
     // one workgroup per CU without split-K beats two with it: the partial sums cost more than the idle barrier slots
     // (B = 4 forward 2.65 ms at 256, 2.85 at 512, 2.89 at 128)
-    static const int min_blocks = nbp_tune_int("NBP_SPLIT_MIN_BLOCKS", 256);
-    const int tw = allow ? split_tile_width(H, W, N, ksize) : 0;
+    const int tw = split_tile_width(H, W, N, ksize);
     if (!tw) return p;
     const int cc = chunks_total / 9 * 2;      // the kernel's K chunks are 16 channels (chunks_total counts (32 channels, tap))
-    long long blocks = (M / (16 * tw)) * (N / (tw == 32 ? 64 : 128)) * groups;
+    const long long blocks = (M / (16 * tw)) * (N / (tw == 32 ? 64 : 128)) * groups;
     const bool r8 = blocks < half_rows_below();
-    if (r8 && r8_counts_double()) blocks *= 2;
     int sk = split_k;
     if (sk <= 0) {      // split-K over whole chunks until one workgroup per CU exists (each slice keeps >= 64 channels)
         sk = 1;
         while (blocks * sk < min_blocks && cc / (sk * 2) >= 4 && sk < 16) sk *= 2;
-        // one more halving of K towards two workgroups per CU, but only while a slice keeps >= deep_chunks 16-channel chunks: the
-        // fixed cost of a workgroup (first halo, epilogue, its share of the reduce) is ~1.5 chunks (NBP_SPLIT_DEEP, 0 = off; measured
-        // B = 12: 5.07 -> 5.02 ms, B = 8 / 1 unchanged, B = 4 +0.6 %; with 8 chunks B = 4 loses 2.5 %)
-        static const int deep = nbp_tune_int("NBP_SPLIT_DEEP", 16);
-        if (deep > 0 && blocks * sk < 2 * min_blocks && cc / (sk * 2) >= deep && sk < 16) sk *= 2;
+        // one more halving of K towards two workgroups per CU, but only while a slice keeps >= 16 16-channel chunks: the fixed cost
+        // of a workgroup (first halo, epilogue, its share of the reduce) is ~1.5 chunks (measured B = 12: 5.07 -> 5.02 ms, B = 8 / 1
+        // unchanged, B = 4 +0.6 %; with 8 chunks B = 4 loses 2.5 %)
+        if (blocks * sk < 2 * min_blocks && cc / (sk * 2) >= 16 && sk < 16) sk *= 2;
         // split_k < 0 (the training step): slices by occupancy only.  The accuracy-driven slices exist for the eval forward's parity bar
         // on rollout inputs (error vs fp64 within ~2.5x of torch CPU's blocked fp32 GEMM); without them a chain is what the fp32 MFMA
         // pipe's own chain is (rms error 1.9e-8 of sum |terms| at K = 9216 against the pipe's 3.0e-8, tools/diag/split_precision.hip),
@@ -1584,7 +1575,6 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
         a.bytesw = (unsigned)bwu;
     }
     {
-        static const int forced = nbp_tune_int("NBP_XCD_REMAP", -1);
         const long long ptiles = a.M / (ph ? 4 : 1) / (th * tw), nbk = N / (tw == 32 ? 64 : 128);
         const long long tiles = ptiles * nbk;
         // bytes that cross the fabric: mode 1 = 8 x weights + activations, mode 2 = weights + min(nbk, 8) x activations
@@ -1595,7 +1585,6 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
         const bool heavy = 7.0 * wb > ((nbk < 8 ? nbk : 8) - 1) * ab * 3.0;
         int mode = tiles >= 8 ? 1 : 0;      // (no run-time difference between the modes on this kernel: chosen by fabric bytes)
         if (fits2 && heavy && tiles >= 8) mode = 2;
-        if (forced >= 0) mode = (forced == 2 && !fits2) ? 0 : forced;
         a.xcd_remap = mode;
     }
     a.partial = nullptr;
@@ -1622,18 +1611,17 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     if (bn_part && bn_rows && p.split_k == 1 && !r8 && groups == 1) {
         a.g[0].bn_part = bn_part;
         *bn_rows = (int)(a.M / (16 * tw));               // pixel tiles (x 4 parities for the up_conv form: the same count)
-        return ph ? (tw == 32 ? launch_h2<32, 4, 2, true, true>(a, st, p.tile) : launch_h2<16, 2, 4, true, true>(a, st, p.tile))
+        // (up_conv layers: the two-parity form here too -- the one-parity 16-row form carried 136 B of scratch per lane)
+        return ph ? (tw == 32 ? launch_h2<32, 2, 2, true, true, true>(a, st, p.tile) : launch_h2<16, 2, 4, true, true>(a, st, p.tile))
                   : (tw == 32 ? launch_h2<32, 4, 2, false, true>(a, st, p.tile) : launch_h2<16, 2, 4, false, true>(a, st, p.tile));
     }
-    // up_conv layers on full-height tiles: both column parities in one workgroup of half the height (same workgroup count, one
-    // staged halo for two parities; NBP_SPLIT_UP2 = 0: one parity per workgroup, as round 3)
-    static const int allow_p2 = nbp_tune_int("NBP_SPLIT_UP2", 1);
-    // (NBP_SPLIT_UP2 = 2 also takes the 16-pixel-wide levels, where the form measured 7 % slower per launch: 619 against 577 us at B = 24)
-    int rc = (ph && !r8 && allow_p2 && (tw == 32 || allow_p2 >= 2))
-                 ? (tw == 32 ? launch_h2<32, 2, 2, true, false, true>(a, st, p.tile) : launch_h2<16, 1, 4, true, false, true>(a, st, p.tile))
+    // up_conv layers on full-height 32-pixel-wide tiles: both column parities in one workgroup of half the height (same workgroup
+    // count, one staged halo for two parities).  The 16-pixel-wide levels keep one parity per workgroup (the two-parity form measured
+    // 7 % slower per launch there: 619 against 577 us at B = 24); round 3's one-parity 16 x 32 form (120 B of scratch per lane) is gone.
+    int rc = (ph && !r8 && tw == 32) ? launch_h2<32, 2, 2, true, false, true>(a, st, p.tile)
            : r8 ? (ph ? (tw == 32 ? launch_h2<32, 2, 2, true>(a, st, p.tile) : launch_h2<16, 1, 4, true>(a, st, p.tile))
                       : (tw == 32 ? launch_h2<32, 2, 2, false>(a, st, p.tile) : launch_h2<16, 1, 4, false>(a, st, p.tile)))
-           : ph ? (tw == 32 ? launch_h2<32, 4, 2, true>(a, st, p.tile) : launch_h2<16, 2, 4, true>(a, st, p.tile))
+           : ph ? launch_h2<16, 2, 4, true>(a, st, p.tile)
                 : (tw == 32 ? launch_h2<32, 4, 2, false>(a, st, p.tile) : launch_h2<16, 2, 4, false>(a, st, p.tile));
     if (rc) return rc;
     if (p.split_k > 1) {
@@ -1716,8 +1704,7 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
     // ... unless 128 columns are the whole gate and its psi tail is on offer: the tail then rides in the epilogue (bn == N below) and
     // its own launch goes (level 4 below B = 8: -0.8 % of the B = 1 forward, -1.1 % at B = 4)
     static const int allow_psi = nbp_tune_int("NBP_GATE_PSI", 1);
-    static const int wide_psi = nbp_tune_int("NBP_GATE_WIDE_PSI", 1);
-    const bool psi_wants_128 = wide_psi && allow_psi && psi && N == 128 && psi->wpsi[0] && psi->st[0] && psi->gated[0];
+    const bool psi_wants_128 = allow_psi && psi && N == 128 && psi->wpsi[0] && psi->st[0] && psi->gated[0];
     if (bn == 128 && nbp_cdiv(M, 128) * (N / 128) * groups < 512 && !psi_wants_128) bn = 64;
     // the gate's tail (psi, x * psi) runs in the epilogue when a workgroup holds every column of its pixels
     const bool with_psi = allow_psi && psi && bn == N && psi->wpsi[0] && psi->st[0] && psi->gated[0] &&
@@ -1754,7 +1741,7 @@ int nbp_upconv_dgrad_split_launch(const float* dy, int N, int B, int H, int W, c
     NBP_RETURN_IF(b0 >= (1ll << 31) || bw >= (1ll << 31), NBP_E_SHAPE);
     a.bytes0 = (unsigned)b0; a.bytes1 = (unsigned)b0; a.bytesw = (unsigned)bw;
     a.chunks_total = 4 * (N / 16);
-    const long long blocks = (a.M / (16 * tw)) * (C / (tw == 32 ? 64 : 128));
+    const long long blocks = (a.M / ((tw == 32 ? 8 : 16) * tw)) * (C / (tw == 32 ? 64 : 128));
     int sk = split_k;
     if (sk <= 0) { sk = 1; while (blocks * sk < 256 && a.chunks_total / (sk * 2) >= 4 && sk < 16) sk *= 2; }
     if (sk > a.chunks_total) sk = a.chunks_total;
@@ -1766,7 +1753,9 @@ int nbp_upconv_dgrad_split_launch(const float* dy, int N, int B, int H, int W, c
         NBP_RETURN_IF(!ws || ws_bytes < (size_t)a.split_k * a.M * C * sizeof(float), NBP_E_WS);
         a.partial = (float*)ws;
     }
-    int rc = tw == 32 ? launch_h2<32, 4, 2, true, false, false, true>(a, st, NBP_TILE_SPLIT_UP_DGRAD)
+    // (8 x 32-pixel tiles on the 32-pixel-wide levels: the 16-row one-parity form carries 124 B of scratch per lane in its staging
+    // section and measured the same, 520.9 against 518-521 maps/s for the training step)
+    int rc = tw == 32 ? launch_h2<32, 2, 2, true, false, false, true>(a, st, NBP_TILE_SPLIT_UP_DGRAD)
                       : launch_h2<16, 2, 4, true, false, false, true>(a, st, NBP_TILE_SPLIT_UP_DGRAD);
     if (rc) return rc;
     if (a.split_k > 1) {
@@ -1824,7 +1813,6 @@ int nbp_wgrad_split_launch(const float* src0, int C0, const float* src1, int C1,
     a.src0 = src0; a.src1 = src1 ? src1 : src0; a.C0 = C0; a.C1 = C1; a.ups = ups ? 1 : 0; a.H = H; a.W = W; a.Hs = Hs; a.Ws = Ws;
     a.dy = dy; a.N = N; a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0; a.bytesy = (unsigned)by;
     a.co_tiles = N / 64; a.n_tiles = n_tiles; a.splits = splits;
-    { static const int pf = nbp_tune_int("NBP_WGRAD_PREFETCH", 1); a.prefetch = pf; }
     a.amax0 = amax0_in ? amax0_in : amax3; a.amax1 = amax1_in ? amax1_in : amax3 + AMAX_WORDS;
     a.amaxy = amaxy_in ? amaxy_in : amax3 + 2 * AMAX_WORDS; a.part = part;
     const bool wide = W % 32 == 0 && H % 2 == 0;              // 2 x 32 tiles, else 4 x 16 (nbp_wgrad_split_ok)
@@ -1975,7 +1963,7 @@ extern "C" int nbp_upconv_wgrad_split_f32(const float* x, int C, int B, int Hs, 
     WgradSplitArgs a;
     a.src0 = x; a.src1 = x; a.C0 = C; a.C1 = 0; a.ups = 1; a.H = 2 * Hs; a.W = 2 * Ws; a.Hs = Hs; a.Ws = Ws;
     a.dy = dy; a.N = N; a.bytes0 = (unsigned)b0; a.bytes1 = (unsigned)b0; a.bytesy = (unsigned)by;
-    a.co_tiles = N / 64; a.n_tiles = n_tiles; a.splits = splits; a.prefetch = 1;
+    a.co_tiles = N / 64; a.n_tiles = n_tiles; a.splits = splits;
     a.amax0 = (const unsigned*)amax_x; a.amax1 = a.amax0; a.amaxy = (const unsigned*)amax_y;
     a.part = (float*)((char*)(((uintptr_t)ws + 255) / 256 * 256));
     const bool wide = Ws % 32 == 0 && Hs % 2 == 0;
@@ -2006,7 +1994,7 @@ int nbp_wgrad_1x1_split_launch(const float* x, int C, long long M, const float* 
     NBP_RETURN_IF(M % 64 != 0, NBP_E_SHAPE);                       // (every level of the network; the kernel counts pixels as H x 64)
     a.src0 = x; a.src1 = x; a.C0 = C; a.C1 = 0; a.ups = 0; a.H = (int)(M / 64); a.W = 64; a.Hs = a.H; a.Ws = a.W;
     a.dy = dy; a.N = N; a.bytes0 = (unsigned)(M * C * 4); a.bytes1 = a.bytes0; a.bytesy = (unsigned)(M * N * 4);
-    a.co_tiles = (N + 63) / 64; a.n_tiles = n_tiles; a.splits = splits; a.prefetch = 1;
+    a.co_tiles = (N + 63) / 64; a.n_tiles = n_tiles; a.splits = splits;
     a.amax0 = amax_x; a.amax1 = amax_x; a.amaxy = amax_y; a.part = part;
     dim3 grid((unsigned)((C / 64) * a.co_tiles), (unsigned)splits);
     wgrad_1x1_split_kernel<<<grid, 256, 8 * 64 * 64, st>>>(a);
@@ -2032,7 +2020,7 @@ extern "C" size_t nbp_upconv_split_dgrad_workspace_bytes(int B, int H, int W, in
     if (B < 1 || H < 1 || W < 1 || N < 16 || C < 64) return 0;
     const int tw = split_tile_width(H, W, C, 3);
     if (!tw) return 0;
-    const long long M = (long long)B * H * W, blocks = (M / (16 * tw)) * (C / (tw == 32 ? 64 : 128));
+    const long long M = (long long)B * H * W, blocks = (M / ((tw == 32 ? 8 : 16) * tw)) * (C / (tw == 32 ? 64 : 128));
     const int chunks = 4 * (N / 16);
     int sk = 1;
     while (blocks * sk < 256 && chunks / (sk * 2) >= 4 && sk < 16) sk *= 2;

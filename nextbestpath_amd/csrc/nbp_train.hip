@@ -967,7 +967,7 @@ static void wgrad_halo_plan(int B, int H, int W, int Ctot, int N, int* n_tiles, 
     *n_tiles = B * (H / 2) * (W / 32);
     const long long pairs = (long long)(Ctot / 64) * (N / 64);
     // one round of two workgroups per CU; more pixel splits only add partial slices for wgrad_reduce to read back
-    static const int target = nbp_tune_int("NBP_WGRAD_BLOCKS", 512);
+    constexpr int target = 512;
     long long s = nbp_cdiv(target, pairs);
     if (s > *n_tiles) s = *n_tiles;
     if (s > 1024) s = 1024;
@@ -1458,8 +1458,7 @@ extern "C" int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, 
     NBP_RETURN_IF(b0 >= (1ll << 31) || b1 >= (1ll << 31), NBP_E_SHAPE);
     a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0;
     hipStream_t st = (hipStream_t)stream;
-    static const int use_halo = nbp_tune_int("NBP_WGRAD_HALO", 1);
-    if (use_halo && wgrad_halo_ok(H, W, ksize) && (long long)B * H * W * N * 4 < (1ll << 31)) {
+    if (wgrad_halo_ok(H, W, ksize) && (long long)B * H * W * N * 4 < (1ll << 31)) {
         WgradHaloArgs h;
         h.src0 = src0; h.src1 = src1; h.C0 = C0; h.C1 = C1; h.ups = a.ups; h.H = H; h.W = W; h.Hs = a.Hs; h.Ws = a.Ws;
         h.dy = dy; h.N = N; h.bytes0 = a.bytes0; h.bytes1 = a.bytes1; h.bytesy = (unsigned)((long long)B * H * W * N * 4);
