@@ -789,10 +789,10 @@ def main():
             # ---- BASELINE configs[2]: one training step (fwd + bwd + AdamW) on 32 maps of 256x256, fp32
             try:
                 from nextbestpath_amd.networks import training as tr
-                from nextbestpath_amd.trainers.train_nbp_model import _collate, make_synthetic_experiences
+                from nextbestpath_amd.trainers.train_nbp_model import _collate, make_optimizer, make_synthetic_experiences
                 torch.manual_seed(9)
                 tnet = NBP().to(dev).train()
-                opt = torch.optim.AdamW(tnet.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+                opt = make_optimizer(tnet)
                 xs, gtl, coords, gains, bidx = _collate(make_synthetic_experiences(32, 256, seed=3), dev)
 
                 def train_step():

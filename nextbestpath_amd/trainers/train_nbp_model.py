@@ -18,14 +18,28 @@ import random
 import numpy as np
 import torch
 
+from .. import _lib
 from ..networks import training as tr
 from ..networks.nbp_model import NBP
 
 
+def make_optimizer(nbp, lr=0.001):
+    """The reference's optimizer (nbp_utils.py:228): AdamW(lr 1e-3, betas (0.9, 0.999), eps 1e-8, weight decay 0.01).  On the device the
+    update of the 200 MB of parameters runs as torch's FUSED multi-tensor kernel (one pass over p, g, m, v instead of the ~10
+    element-wise passes of the default `foreach` form: 3 % of a B = 32 training step); same update rule."""
+    kw = dict(lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    params = list(nbp.parameters())
+    if params and all(p.is_cuda for p in params) and _lib.tune("NBP_TRAIN_FUSED_ADAMW", "1") == "1":
+        try:
+            return torch.optim.AdamW(params, fused=True, **kw)
+        except (RuntimeError, TypeError, ValueError):     # a torch build without the fused kernel
+            pass
+    return torch.optim.AdamW(params, **kw)
+
+
 def initialize_nbp(params, nbp, torch_seed=9, initialize=False, pretrained=False, ddp_rank=None):
     """ref nbp_utils.py:213-231: AdamW(lr 1e-3, betas (0.9, 0.999), eps 1e-8, weight decay 0.01)."""
-    optimizer = torch.optim.AdamW(nbp.parameters(), lr=0.001, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
-    return nbp, optimizer, 10000.0, 0
+    return nbp, make_optimizer(nbp), 10000.0, 0
 
 
 def make_synthetic_experiences(n, S=256, seed=0):

@@ -14,7 +14,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nextbestpath_amd.networks import training as tr  # noqa: E402
 from nextbestpath_amd.networks.nbp_model import NBP  # noqa: E402
-from nextbestpath_amd.trainers.train_nbp_model import _collate, make_synthetic_experiences  # noqa: E402
+from nextbestpath_amd.trainers.train_nbp_model import _collate, make_optimizer, make_synthetic_experiences  # noqa: E402
 
 
 def main():
@@ -28,7 +28,7 @@ def main():
     dev = torch.device("cuda")
     torch.manual_seed(9)
     net = NBP().to(dev).train()
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    opt = make_optimizer(net)
     db = make_synthetic_experiences(a.batch, a.size, seed=3)
     xs, gt, coords, gains, bidx = _collate(db, dev)
 
