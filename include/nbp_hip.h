@@ -180,6 +180,11 @@ int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, 
                           const void* w_planes, const void* wamax, int N, const float* scale, const float* shift, int relu,
                           float* out, const void* amax_in_or_null, void* amax_out_or_null, int split_k, void* ws,
                           size_t ws_bytes, void* stream);
+/* Weight gradient of Conv1.conv.0 (nbp_model.py:66: 5 -> 64 channels, 3x3) straight from the NCHW network input x [B,5,H,W] and
+ * dy [B,H,W,64] (NHWC): dw [64][5][3][3].  H % 8 == 0, W % 32 == 0 (else NBP_E_SHAPE: the caller pads the input to 64 channels and
+ * takes nbp_conv_wgrad_split_f32).  The forward of the layer is nbp_conv_first_f32. */
+size_t nbp_conv_first_wgrad_workspace_bytes(void);
+int nbp_conv_first_wgrad_f32(const float* x_nchw, int B, int H, int W, const float* dy, float* dw, void* ws, size_t ws_bytes, void* stream);
 /* Data gradient of an up_conv layer (nbp_model.py:25-33: x2 nearest upsample + 3x3 convolution, C -> N channels) in the parity form of
  * nbp_upconv3x3_split_f32: dx [B,H,W,C] at the LOW resolution straight from dy [B,2H,2W,N] -- 16 tap-products per low-resolution pixel
  * instead of the 36 of the full-resolution 3x3 data gradient followed by a 2x2 sum.  nbp_pack_upconv_weight_split_dgrad: 32 N C fp16
@@ -266,6 +271,9 @@ int nbp_pack_conv_weight(const float* w_oihw, int N, int C, int ksize, const flo
  * w is the raw OIHW [64,5,3,3] tensor. */
 int nbp_conv_first_f32(const float* x_nchw, int B, int H, int W, const float* w_oihw,
                        const float* scale, const float* shift, float* out_nhwc, void* stream);
+/* The same layer without the ReLU (training: the train-mode BatchNorm that follows takes conv + bias); H % 8 == 0, W % 32 == 0. */
+int nbp_conv_first_linear_f32(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale,
+                              const float* shift, float* out_nhwc, void* stream);
 /* nn.MaxPool2d(2,2) on NHWC (ref :68). */
 int nbp_maxpool2_nhwc_f32(const float* in, int B, int H, int W, int C, float* out, void* stream);
 /* Attention gate tail (ref :59-62): psi = sigmoid((q . w_psi) * s + t) per pixel,

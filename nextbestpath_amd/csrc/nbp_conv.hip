@@ -725,6 +725,13 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
                                 [](float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }, amax_out);
 }
 
+__global__ __launch_bounds__(256) void conv_first_mfma_linear_kernel(const float* __restrict__ x, int B, int H, int W,
+                                                                     const float* __restrict__ w, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, float* __restrict__ out) {
+    auto st4 = [](float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; };
+    conv_first_mfma_body<float, decltype(st4), false>(x, B, H, W, w, scale, shift, out, st4, nullptr);
+}
+
 // Workgroups of the 8 x 32-tile kernel: it loops over tiles, and a workgroup's fixed cost (launch, weights into LDS, cold
 // instruction fetch: ~11 us of the ~19 us a one-tile workgroup takes) is paid once per workgroup, so no more workgroups than
 // two per CU (NBP_FIRST_GRID overrides)
@@ -760,6 +767,16 @@ extern "C" int nbp_conv_first_f32(const float* x_nchw, int B, int H, int W, cons
     }
     conv_first_kernel<<<(unsigned)nbp_cdiv(M, 64), 256, 0, (hipStream_t)stream>>>(x_nchw, B, H, W, w_oihw, scale,
                                                                                    shift, out_nhwc);
+    return nbp_launch_status();
+}
+
+// The layer WITHOUT the ReLU (training: out = conv(x) * scale + shift feeds a train-mode BatchNorm); H % 8 == 0, W % 32 == 0.
+extern "C" int nbp_conv_first_linear_f32(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale,
+                                         const float* shift, float* out_nhwc, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!x_nchw || !w_oihw || !scale || !shift || !out_nhwc || B < 1, NBP_E_ARG);
+    NBP_RETURN_IF(H < 8 || W < 32 || (H & 7) || (W & 31), NBP_E_SHAPE);
+    conv_first_mfma_linear_kernel<<<first_grid((long long)B * H * W), 256, 0, (hipStream_t)stream>>>(x_nchw, B, H, W, w_oihw, scale, shift, out_nhwc);
     return nbp_launch_status();
 }
 

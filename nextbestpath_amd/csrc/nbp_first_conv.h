@@ -7,7 +7,8 @@
 #pragma once
 #include "common.h"
 
-template <typename OutT, typename Store4>
+// RELU = false (training): the layer's own output, conv + bias, for the train-mode BatchNorm that follows
+template <typename OutT, typename Store4, bool RELU = true>
 __device__ __forceinline__ void conv_first_mfma_body(const float* __restrict__ x, int B, int H, int W,
                                                      const float* __restrict__ w, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, OutT* __restrict__ out, Store4 store4,
@@ -104,7 +105,7 @@ __device__ __forceinline__ void conv_first_mfma_body(const float* __restrict__ x
                     const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + n);
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = fmaxf(acc[i][j][4 * rq + e] * sc[e] + sh[e], 0.f); mx = fmaxf(mx, v[e]); }
+                    for (int e = 0; e < 4; ++e) { const float u = acc[i][j][4 * rq + e] * sc[e] + sh[e]; v[e] = RELU ? fmaxf(u, 0.f) : u; mx = fmaxf(mx, fabsf(v[e])); }
                     store4(reinterpret_cast<OutT*>(trw + (i * 32 + ln) * TRB) + (PASSES == 2 ? n - 32 * pass : n), v);
                 }
             }

@@ -1038,6 +1038,69 @@ static int wgrad_reduce_launch(const float* part, int splits, int taps, int Ctot
     return nbp_launch_status();
 }
 
+// ------------------------------------------------------------------ weight gradient of Conv1.conv.0 (5 -> 64 channels, NCHW input)
+// dW[co][c][tap] = sum over pixels of dY[p][co] x[c][p + tap]: a [64 x M] x [M x 45] product.  The step used to pad the network input
+// from 5 to 64 channels and run the 64 -> 64 kernels on it (a 537-MB padded copy, a convolution and a weight gradient at 13 x the
+// work); here a workgroup walks 8 x 32-pixel tiles like conv_first_mfma_kernel: the five 10 x 34 input planes and the tile's 256
+// pixels of dY (64 KB, by DMA) sit in LDS, wave (wi, wj) owns the 32 (co) x 32 (k = c 9 + tap, 45 padded to 64) block and feeds
+// v_mfma_f32_32x32x2_f32 with pixel pairs: A = dY^T (contiguous channels), B = the patch column of each lane (its own halo offset).
+// Partial sums [workgroup][k][co]; the slice reduction writes OIHW.
+constexpr int FW_PLANE = 10 * 34;
+__global__ __launch_bounds__(256, 2) void wgrad_first_kernel(const float* __restrict__ x, int B, int H, int W, const float* __restrict__ dy,
+                                                             unsigned dy_bytes, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char fl[];
+    float* const hal = reinterpret_cast<float*>(fl);                       // [5][10][34] (+ pad)
+    char* const ys = fl + 7168;                                            // [256 pixels][64 channels] fp32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1, kh = lane >> 5, ln = lane & 31;
+    const int tiles_x = W >> 5, tiles_y = H >> 3, n_tiles = B * tiles_y * tiles_x;
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, dy_bytes, 0x00020000);
+    const int k = wj * 32 + ln;                                            // this lane's column of the patch matrix
+    const int koff = k < 45 ? (k / 9) * FW_PLANE + ((k % 9) / 3) * 34 + (k % 9) % 3 : -1;
+    const int drow = lane >> 4, dslot = lane & 15;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+        int tile = tile_id;
+        const int tx = tile % tiles_x; tile /= tiles_x;
+        const int ty = tile % tiles_y;
+        const int b = tile / tiles_y;
+        const int y0 = ty * 8, x0 = tx * 32;
+        __syncthreads();                                                   // the previous tile's reads are done
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                                     // dY: 256 pixels x 256 B = 64 slots of 1 KB (4 pixels each)
+            const int q = 4 * i + wave;
+            const int p = 4 * q + drow;                                    // pixel of the tile: row p / 32, column p % 32
+            const long long m = ((long long)b * H + y0 + (p >> 5)) * W + x0 + (p & 31);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (wg_lds_ptr_t)(ys + q * 1024), 16, (unsigned)((m * 64 + dslot * 4) * 4), 0, 0, 0);
+        }
+        for (int i = tid; i < 5 * FW_PLANE; i += 256) {
+            const int ci = i / FW_PLANE, r = i - ci * FW_PLANE;
+            const int hy = r / 34, hx = r - hy * 34;
+            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            hal[i] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? x[((long long)(b * 5 + ci) * H + yy) * W + xx] : 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* yw = reinterpret_cast<const float*>(ys) + wi * 32 + ln;
+#pragma unroll 8
+        for (int pp = 0; pp < 128; ++pp) {
+            const int p = 2 * pp + kh;                                     // this half wave's pixel of the pair
+            const float av = yw[p * 64];
+            const float bv = koff >= 0 ? hal[koff + (p >> 5) * 34 + (p & 31)] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    }
+    // D[co][k]: row = co (the A side), column = k
+    float* out = part + (long long)blockIdx.x * 64 * 64;                   // [k][co]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        out[(wj * 32 + ln) * 64 + co] = acc[r];
+    }
+}
+
 // flipped + transposed packing for the data gradient: dst[(co)/32][tap][ci][co%32] = w[co][ci][taps-1-tap]
 __global__ void pack_dgrad_kernel(const float* __restrict__ w, int N, int C, int taps, int Cpad, int Npad,
                                   float* __restrict__ dst) {
@@ -1497,6 +1560,35 @@ extern "C" int nbp_conv_wgrad_f32(const float* src0, int C0, const float* src1, 
         const bool room = ws_bytes >= (size_t)(sp + WGRAD_REDUCE_GROUPS) * a.taps * (C0 + C1) * N * sizeof(float) + 256;
         return wgrad_reduce_launch(a.part, sp, a.taps, C0 + C1, N, c_real, n_real, dw, room ? tmp : nullptr, st);
     }
+}
+
+// dW [64][5][3][3] of Conv1.conv.0 from the network input x [B,5,H,W] (NCHW, as the forward reads it) and dy [B,H,W,64]; H % 8 == 0,
+// W % 32 == 0.  Workspace: nbp_conv_first_wgrad_workspace_bytes.
+constexpr int FW_GRID = 512;
+extern "C" size_t nbp_conv_first_wgrad_workspace_bytes(void) { return 256 + (size_t)(FW_GRID + WGRAD_REDUCE_GROUPS) * 64 * 64 * sizeof(float); }
+extern "C" int nbp_conv_first_wgrad_f32(const float* x_nchw, int B, int H, int W, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                                        void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!x_nchw || !dy || !dw || !ws || B < 1, NBP_E_ARG);
+    NBP_RETURN_IF(H < 8 || W < 32 || (H & 7) || (W & 31), NBP_E_SHAPE);
+    NBP_RETURN_IF(ws_bytes < nbp_conv_first_wgrad_workspace_bytes(), NBP_E_WS);
+    const long long by = (long long)B * H * W * 64 * 4;
+    NBP_RETURN_IF(by >= (1ll << 31), NBP_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)(((uintptr_t)ws + 255) / 256 * 256);
+    const int n_tiles = B * (H / 8) * (W / 32), grid = n_tiles < FW_GRID ? n_tiles : FW_GRID;
+    constexpr int smem = 7168 + 256 * 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_first_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    wgrad_first_kernel<<<grid, 256, smem, st>>>(x_nchw, B, H, W, dy, (unsigned)by, part);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    // slices [grid][k = 64][co = 64] -> dw[co][k < 45]
+    return wgrad_reduce_launch(part, grid, 1, 64, 64, 45, 64, dw, part + (size_t)grid * 64 * 64, st);
 }
 
 // (nbp_split.hip)

@@ -424,6 +424,41 @@ class ConvFn(torch.autograd.Function):
         return dx0, dx1, dw, db, None, None
 
 
+# Conv1.conv.0 straight from the NCHW network input (csrc/nbp_first_conv.h forward, wgrad_first_kernel backward) instead of a
+# 64-channel padded copy through the 64 -> 64 kernels.  NBP_TRAIN_FIRST_CONV=0: round 4's form.
+_FIRST_CONV = _lib.tune("NBP_TRAIN_FIRST_CONV", "1") == "1"
+
+
+class FirstConvFn(torch.autograd.Function):
+    """y [B,S,S,64] (NHWC) = conv3x3(x [B,5,S,S] NCHW) + bias (nbp_model.py:66); the network input takes no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        L = _lib.lib()
+        B, _, H, W = x.shape
+        dev = x.device
+        w = weight.detach().contiguous()
+        y = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
+        _chk(L.nbp_conv_first_linear_f32(_lib.ptr(x), B, H, W, _lib.ptr(w), _lib.ptr(_const(1.0, 64, dev)), _lib.ptr(bias.detach().contiguous()),
+                                  _lib.ptr(y), _st()), "conv_first")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        (x,) = ctx.saved_tensors
+        B, _, H, W = x.shape
+        dev = dy.device
+        info = _noted(dy, "colsum") if dy.is_contiguous() else None
+        dy = dy.contiguous()
+        db = info[1] if (info is not None and info[1].numel() == 64) else _colsum(dy.view(B * H * W, 64))
+        dw = torch.empty(64, 5, 3, 3, dtype=torch.float32, device=dev)
+        ws = _ws(L.nbp_conv_first_wgrad_workspace_bytes(), dev)
+        _chk(L.nbp_conv_first_wgrad_f32(_lib.ptr(x), B, H, W, _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(ws), ws.numel(), _st()), "conv_first_wgrad")
+        return None, dw, db
+
+
 class BNFn(torch.autograd.Function):
     """nn.BatchNorm2d in training mode (+ optional fused ReLU); updates the running statistics in place."""
 
@@ -767,10 +802,18 @@ def forward_train(net, x):
 
 
 def _forward_train(net, x, L, B, S, dev):
-    xh = torch.empty(B, S, S, 5, dtype=torch.float32, device=dev)
-    _chk(L.nbp_nchw_to_nhwc_f32(_lib.ptr(x.contiguous().float()), B, 5, S, S, _lib.ptr(xh), _st()), "to_nhwc")
-    x0 = _pad_channels(xh, 64)
-    x1 = _block(net.Conv1.conv, x0, None, "Conv1")
+    seq = net.Conv1.conv
+    if (_FIRST_CONV and S % 32 == 0 and tuple(seq[0].weight.shape) == (64, 5, 3, 3) and B * S * S * 64 * 4 < 2 ** 31):
+        # the first layer reads the NCHW input itself; the rest of the block as _block
+        y = _t("Conv1.conv.0", FirstConvFn.apply(x.contiguous().float(), seq[0].weight, seq[0].bias))
+        y = _bn(seq[1], y, True, "Conv1.conv.1")
+        y = _t("Conv1.conv.3", ConvFn.apply(y, None, seq[3].weight, seq[3].bias, False, True))
+        x1 = _bn(seq[4], y, True, "Conv1.conv.4")
+    else:
+        xh = torch.empty(B, S, S, 5, dtype=torch.float32, device=dev)
+        _chk(L.nbp_nchw_to_nhwc_f32(_lib.ptr(x.contiguous().float()), B, 5, S, S, _lib.ptr(xh), _st()), "to_nhwc")
+        x0 = _pad_channels(xh, 64)
+        x1 = _block(net.Conv1.conv, x0, None, "Conv1")
     x2 = _block(net.Conv2.conv, _t("pool1", MaxPoolFn.apply(x1)), None, "Conv2")
     x3 = _block(net.Conv3.conv, _t("pool2", MaxPoolFn.apply(x2)), None, "Conv3")
     x4 = _block(net.Conv4.conv, _t("pool3", MaxPoolFn.apply(x3)), None, "Conv4")
