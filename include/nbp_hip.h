@@ -678,7 +678,9 @@ int nbp_colsum_f32(const float* x, const float* rows_or_null, long long M, int C
                    size_t ws_bytes, void* stream);
 /* op 0: relu(a+b)  1: a*(b>0)  2: sigmoid(a)  3: a*b*(1-b)  4: a+b  5: a+b[0] */
 int nbp_elementwise_f32(int op, const float* a, const float* b, long long n, float* out, void* stream);
-int nbp_rowscale_f32(const float* x, const float* s, long long M, int C, float* out, void* stream);   /* x[m][c]*s[m] */
+int nbp_rowscale_f32(const float* x, const float* s, long long M, int C, float* out, void* stream);
+/* ... that also leaves max |out| in the 64 zeroed words of amax_out (C % 4 == 0, 16-byte aligned tensors, else NBP_E_SHAPE). */
+int nbp_rowscale_amax_f32(const float* x, const float* s, long long M, int C, float* out, void* amax_out, void* stream);   /* x[m][c]*s[m] */
 /* backward of out = x * s[m] in one pass: dx[m][c] = dy[m][c] * s[m], ds[m] = sum_c dy[m][c] * x[m][c]; dy's rows are ldy >= C floats
  * apart (a channel slice of a wider gradient is read in place); C, ldy multiples of 4, 16-byte aligned pointers (else NBP_E_SHAPE) */
 int nbp_rowscale_backward_f32(const float* dy, long long ldy, const float* x, const float* s, long long M, int C, float* dx,

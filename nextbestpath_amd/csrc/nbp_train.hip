@@ -544,12 +544,20 @@ __global__ __launch_bounds__(256) void ew4_kernel(int op, const float* __restric
     }
 }
 
+// amax_out (or null): 64 zeroed words that receive max |out| -- the gated tensor feeds a split convolution, whose operand scale would
+// otherwise cost a pass of its own over the tensor
 __global__ __launch_bounds__(256) void rowscale4_kernel(const float* __restrict__ x, const float* __restrict__ s,
-                                                        long long total4, int C4, float* __restrict__ out) {
+                                                        long long total4, int C4, float* __restrict__ out,
+                                                        unsigned* __restrict__ amax_out = nullptr) {
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
     f32x4* o4 = reinterpret_cast<f32x4*>(out);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x)
-        o4[i] = x4[i] * s[i / C4];
+    float mx = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 v = x4[i] * s[i / C4];
+        o4[i] = v;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (amax_out) train_wave_amax(mx, amax_out);
 }
 
 __global__ __launch_bounds__(256) void slice_channels4_kernel(const float* __restrict__ in, long long M, int Cin4, int c04, int Cs4,
@@ -1371,6 +1379,14 @@ extern "C" int nbp_rowscale_f32(const float* x, const float* s, long long M, int
         rowscale4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, (hipStream_t)stream>>>(x, s, M * C / 4, C / 4, out);
     else
         rowscale_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, (hipStream_t)stream>>>(x, s, M * C, C, out);
+    return nbp_launch_status();
+}
+// ... that also leaves max |out| in the 64 zeroed words of amax_out (C % 4 == 0, 16-byte aligned tensors)
+extern "C" int nbp_rowscale_amax_f32(const float* x, const float* s, long long M, int C, float* out, void* amax_out, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!x || !s || !out || !amax_out || M < 1 || C < 4, NBP_E_ARG);
+    NBP_RETURN_IF((C & 3) || (((uintptr_t)x | (uintptr_t)out) & 15), NBP_E_SHAPE);
+    rowscale4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, (hipStream_t)stream>>>(x, s, M * C / 4, C / 4, out, (unsigned*)amax_out);
     return nbp_launch_status();
 }
 

@@ -631,7 +631,12 @@ class RowScaleFn(torch.autograd.Function):
         B, H, W, C = x.shape
         x, s = x.contiguous(), s.contiguous()
         out = torch.empty_like(x)
-        _chk(_lib.lib().nbp_rowscale_f32(_lib.ptr(x), _lib.ptr(s), B * H * W, C, _lib.ptr(out), _st()), "rowscale")
+        if _FUSE and C % 4 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0:
+            slot = _fresh_slots(x.device)              # max |x psi| for the convolution that consumes the gated tensor
+            _chk(_lib.lib().nbp_rowscale_amax_f32(_lib.ptr(x), _lib.ptr(s), B * H * W, C, _lib.ptr(out), _lib.ptr(slot), _st()), "rowscale_amax")
+            _note(out, amax=slot)
+        else:
+            _chk(_lib.lib().nbp_rowscale_f32(_lib.ptr(x), _lib.ptr(s), B * H * W, C, _lib.ptr(out), _st()), "rowscale")
         ctx.save_for_backward(x, s)
         return out
 
