@@ -1611,6 +1611,10 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     if (bn_part && bn_rows && p.split_k == 1 && !r8 && groups == 1) {
         a.g[0].bn_part = bn_part;
         *bn_rows = (int)(a.M / (16 * tw));               // pixel tiles (x 4 parities for the up_conv form: the same count)
+        if (!ph && tw == 32 && N % 128 == 0) {           // 8 x 32 pixels x 128 channels (see below): twice the pixel tiles
+            *bn_rows = (int)(a.M / 256);
+            return launch_h2<32, 2, 4, false, true>(a, st, p.tile);
+        }
         // (up_conv layers: the two-parity form here too -- the one-parity 16-row form carried 136 B of scratch per lane)
         return ph ? (tw == 32 ? launch_h2<32, 2, 2, true, true, true>(a, st, p.tile) : launch_h2<16, 2, 4, true, true>(a, st, p.tile))
                   : (tw == 32 ? launch_h2<32, 4, 2, false, true>(a, st, p.tile) : launch_h2<16, 2, 4, false, true>(a, st, p.tile));
@@ -1622,7 +1626,12 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
            : r8 ? (ph ? (tw == 32 ? launch_h2<32, 2, 2, true>(a, st, p.tile) : launch_h2<16, 1, 4, true>(a, st, p.tile))
                       : (tw == 32 ? launch_h2<32, 2, 2, false>(a, st, p.tile) : launch_h2<16, 1, 4, false>(a, st, p.tile)))
            : ph ? launch_h2<16, 2, 4, true>(a, st, p.tile)
-                : (tw == 32 ? launch_h2<32, 4, 2, false>(a, st, p.tile) : launch_h2<16, 2, 4, false>(a, st, p.tile));
+                // 32-pixel-wide levels: 8 x 32 pixels x 128 channels where the layer has them (round 5) -- the same workgroup count, MFMAs
+                // per stage and sums in the same order as 16 x 32 x 64, but a 10 x 34 halo staged per 128 output channels instead of an
+                // 18 x 34 one per 64: 44 % less halo traffic, splitting and LDS writes per output (every N % 128 == 0 layer 1.4 - 2.7 %
+                // faster at B = 24, the forward 9.46 -> 9.38 ms; profiles/r05/tile_8x32x128.txt)
+                : (tw == 32 ? (N % 128 == 0 ? launch_h2<32, 2, 4, false>(a, st, p.tile) : launch_h2<32, 4, 2, false>(a, st, p.tile))
+                            : launch_h2<16, 2, 4, false>(a, st, p.tile));
     if (rc) return rc;
     if (p.split_k > 1) {
         const long long MN = a.M * N;
