@@ -171,8 +171,10 @@ def net_bf16(nbp_weights):
     return net.cuda().eval()
 
 
-@pytest.mark.parametrize("B,S", [(1, 32), (2, 64), (1, 128), (3, 48), (2, 96), (1, 16)])
+@pytest.mark.parametrize("B,S", [(1, 32), (2, 64), (1, 128), (3, 48), (2, 96), (1, 16), (1, 256), (1, 512)])
 def test_forward_bf16_vs_restatement(hip, net_bf16, nbp_weights, B, S):
+    """... up to the sizes the path is benchmarked at (256 x 256 and configs[4]'s 512 x 512 were held only through
+    goal-cell agreement with the fp32 path)."""
     from nextbestpath_amd.utility.synthetic import make_count_maps
     x = make_count_maps(B, S, seed=11)
     with torch.no_grad():
