@@ -54,6 +54,8 @@ TILE_NOTES = {1: "implicit GEMM 128x128", 2: "implicit GEMM 256x64", 3: "implici
               11: "up_conv as 2x2 parity convolutions of the low-resolution input, both column parities per workgroup on 8-row tiles; same kernel body",
               12: "bf16 up_conv parity form, 128 ch", 13: "bf16 up_conv parity form, 64 ch",
               15: "8x32 px x 64 ch: launches with fewer 16-row tiles than CUs; same kernel body",
+              19: "attention gates: relu([g | x] W + b) as one 1x1 GEMM on the split scheme, psi tail in the epilogue",
+              18: "8x32 px x 128 ch on the 32-pixel-wide layers with N % 128 == 0; fp32 operands as 2 scaled fp16 pieces, 3 fp16 MFMAs per product",
               16: "up_conv parity form on 8-row low-resolution tiles, one parity per workgroup"}
 
 
@@ -72,7 +74,7 @@ def tile_label(tile):
 
 
 SPLIT_TILE = 10
-SPLIT_TILES = (10, 11, 15, 16)
+SPLIT_TILES = (10, 11, 15, 16, 18)
 PARITY_TILES = (11, 16)          # execute 4/9 of the reference formulation's products
 TIMED = {"fp32": "nbp_forward_timed_f32", "fp32_split": "nbp_forward_timed_split_f32", "bf16": "nbp_forward_timed_bf16"}
 
@@ -172,7 +174,7 @@ def live_traffic(n_points, precision="fp32", batch=12):
                os.path.join(ROOT, "tools", "pmc_workload.py"), "--points", str(n_points), "--precision", precision,
                "--batch", str(batch)]
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
         except subprocess.TimeoutExpired:
             return None, f"rocprofv3 --pmc {counter} timed out"
         if r.returncode != 0:

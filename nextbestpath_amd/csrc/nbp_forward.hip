@@ -418,6 +418,7 @@ struct PathSplit : PathF32 {
     typedef AmaxBook Ctx;
     static constexpr int MODE = 2;
     static ConvPlan plan(long long M, int N, int chunks, int groups, int H = 0, int ksize = 0, int ups = 0) {
+        if (ksize == 1) return ConvPlan{NBP_TILE_SPLIT_GATE, 1, chunks};      // the gates: gate1x1_h2_kernel, no split-K (conv below)
         const ConvPlan p = nbp_plan_conv_split(M, N, chunks, 0, groups, H, H, ksize, ups);
         return p.tile ? p : PathF32::plan(M, N, chunks, groups, H, ksize);
     }

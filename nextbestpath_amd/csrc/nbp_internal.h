@@ -14,7 +14,10 @@ enum { NBP_TILE_AUTO = 0, NBP_TILE_128x128 = 1, NBP_TILE_256x64 = 2, NBP_TILE_25
        // 10 / 11: nbp_split.hip, 16x32 / 16x16-pixel halo tiles on the fp16 matrix pipe (11: up_conv as parity convolutions);
        // 15 / 16: their 8-row forms (launches that would leave CUs idle); 12 / 13: the bf16 up_conv parity kernels
        NBP_TILE_SPLIT_HALO_R8 = 15, NBP_TILE_SPLIT_UP_R8 = 16,
-       NBP_TILE_SPLIT_UP_DGRAD = 17 };   // nbp_split.hip: data gradient of an up_conv layer in parity form (training)
+       NBP_TILE_SPLIT_UP_DGRAD = 17,    // nbp_split.hip: data gradient of an up_conv layer in parity form (training)
+       NBP_TILE_SPLIT_HALO_128 = 18,
+       NBP_TILE_SPLIT_GATE = 19 };      // nbp_split.hip: the attention gates' 1x1 GEMM over [g | x] (gate1x1_h2_kernel)
+      //  // nbp_split.hip: 8 x 32 pixels x 128 channels (32-pixel-wide layers with N % 128 == 0)
 struct TileInfo { int bm, bn; };
 struct ConvPlan { int tile; int split_k; int chunks_per_split; };
 

@@ -1519,7 +1519,9 @@ ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, 
     const int per = (int)nbp_cdiv(cc, sk);
     p.split_k = (int)nbp_cdiv(cc, per); p.chunks_per_split = per;
     const bool r8t = r8 || half_rows_for_tail((M / (16 * tw)) * (N / (tw == 32 ? 64 : 128)) * groups * p.split_k);
-    p.tile = r8t ? NBP_TILE_SPLIT_HALO_R8 : NBP_TILE_SPLIT_HALO_64;
+    // (full-height plans of 32-pixel-wide layers with N % 128 == 0 run 8 x 32 pixels x 128 channels: its own tile id, so that a
+    // per-layer timing table and a profile's kernel rows name the same instantiation)
+    p.tile = r8t ? NBP_TILE_SPLIT_HALO_R8 : (tw == 32 && N % 128 == 0) ? NBP_TILE_SPLIT_HALO_128 : NBP_TILE_SPLIT_HALO_64;
     return p;
 }
 
@@ -1556,11 +1558,12 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     a.bytes0 = (unsigned)b0; a.bytes1 = C1 ? (unsigned)b1 : (unsigned)b0; a.bytesw = (unsigned)bw;
     const bool have_up = ups && o.planes_up && o.wamax_up && (!o2 || (o2->planes_up && o2->wamax_up));
     const ConvPlan p = nbp_plan_conv_split(a.M, N, (C0 + C1) / 32 * 9, split_k, groups, H, W, ksize, have_up ? 1 : 0);
-    NBP_RETURN_IF(p.tile != NBP_TILE_SPLIT_HALO_64 && p.tile != NBP_TILE_SPLIT_UP && p.tile != NBP_TILE_SPLIT_HALO_R8 &&
+    NBP_RETURN_IF(p.tile != NBP_TILE_SPLIT_HALO_64 && p.tile != NBP_TILE_SPLIT_HALO_128 && p.tile != NBP_TILE_SPLIT_UP && p.tile != NBP_TILE_SPLIT_HALO_R8 &&
                   p.tile != NBP_TILE_SPLIT_UP_R8, NBP_E_SHAPE);
     const bool ph = p.tile == NBP_TILE_SPLIT_UP || p.tile == NBP_TILE_SPLIT_UP_R8;
     const bool r8 = p.tile == NBP_TILE_SPLIT_HALO_R8 || p.tile == NBP_TILE_SPLIT_UP_R8;
-    const int th = r8 ? 8 : 16;
+    const bool wide = p.tile == NBP_TILE_SPLIT_HALO_128;      // 8 x 32 pixels x 128 channels
+    const int th = (r8 || wide) ? 8 : 16;
     a.split_k = p.split_k; a.chunks_per_split = p.chunks_per_split;
     a.chunks_total = (C0 + C1) / 16;
     const int tw = ph ? split_tile_width(H / 2, W / 2, N, ksize) : split_tile_width(H, W, N, ksize);
@@ -1575,7 +1578,7 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
         a.bytesw = (unsigned)bwu;
     }
     {
-        const long long ptiles = a.M / (ph ? 4 : 1) / (th * tw), nbk = N / (tw == 32 ? 64 : 128);
+        const long long ptiles = a.M / (ph ? 4 : 1) / (th * tw), nbk = N / ((tw == 32 && !wide) ? 64 : 128);      // = the launch's grid
         const long long tiles = ptiles * nbk;
         // bytes that cross the fabric: mode 1 = 8 x weights + activations, mode 2 = weights + min(nbk, 8) x activations
         const double wb = (double)(C0 + C1) * (ph ? 16 : 9) * N * 4, ab = (double)a.M / (ups ? 4 : 1) * (C0 + C1) * 4;
@@ -1611,7 +1614,7 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     if (bn_part && bn_rows && p.split_k == 1 && !r8 && groups == 1) {
         a.g[0].bn_part = bn_part;
         *bn_rows = (int)(a.M / (16 * tw));               // pixel tiles (x 4 parities for the up_conv form: the same count)
-        if (!ph && tw == 32 && N % 128 == 0) {           // 8 x 32 pixels x 128 channels (see below): twice the pixel tiles
+        if (wide) {                                      // 8 x 32 pixels x 128 channels (see below): twice the pixel tiles
             *bn_rows = (int)(a.M / 256);
             return launch_h2<32, 2, 4, false, true>(a, st, p.tile);
         }
@@ -1630,7 +1633,7 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
                 // per stage and sums in the same order as 16 x 32 x 64, but a 10 x 34 halo staged per 128 output channels instead of an
                 // 18 x 34 one per 64: 44 % less halo traffic, splitting and LDS writes per output (every N % 128 == 0 layer 1.4 - 2.7 %
                 // faster at B = 24, the forward 9.46 -> 9.38 ms; profiles/r05/tile_8x32x128.txt)
-                : (tw == 32 ? (N % 128 == 0 ? launch_h2<32, 2, 4, false>(a, st, p.tile) : launch_h2<32, 4, 2, false>(a, st, p.tile))
+                : (tw == 32 ? (wide ? launch_h2<32, 2, 4, false>(a, st, p.tile) : launch_h2<32, 4, 2, false>(a, st, p.tile))
                             : launch_h2<16, 2, 4, false>(a, st, p.tile));
     if (rc) return rc;
     if (p.split_k > 1) {
@@ -1721,6 +1724,11 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
     if (fused) *fused = with_psi;
     dim3 grid((unsigned)nbp_cdiv(M, 128), (unsigned)(N / bn), (unsigned)groups);
     const size_t smem = 2 * (size_t)8 * bn * 16;
+    {
+        char nm[64];
+        snprintf(nm, sizeof(nm), "gate1x1_h2_kernel<%d, %s>", bn / 32, with_psi ? "true" : "false");
+        nbp_note_kernel_symbol(NBP_TILE_SPLIT_GATE, nm);
+    }
     if (with_psi) {
         if (bn == 128) gate1x1_h2_kernel<4, true><<<grid, 256, smem, st>>>(a);
         else if (bn == 64) gate1x1_h2_kernel<2, true><<<grid, 256, smem, st>>>(a);
