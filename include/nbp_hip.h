@@ -185,6 +185,13 @@ int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, 
  * takes nbp_conv_wgrad_split_f32).  The forward of the layer is nbp_conv_first_f32. */
 size_t nbp_conv_first_wgrad_workspace_bytes(void);
 int nbp_conv_first_wgrad_f32(const float* x_nchw, int B, int H, int W, const float* dy, float* dw, void* ws, size_t ws_bytes, void* stream);
+/* Training-step forms of nbp_pack_conv_weight_split / _dgrad: `_prezeroed` takes a max-|w| word the caller zeroed (no memset launch),
+ * `_dgrad_known` reuses the word the forward's pack of the same weights left (the data-gradient planes hold the same values): one
+ * launch instead of three. */
+int nbp_pack_conv_weight_split_prezeroed(const float* w_oihw, int N, int C, int ksize, int c_total, void* dst_planes,
+                                         void* wamax_zeroed, void* stream);
+int nbp_pack_conv_weight_split_dgrad_known(const float* w_oihw, int N, int C, int c_total, void* dst_planes, const void* wamax_known,
+                                           void* stream);
 /* Data gradient of an up_conv layer (nbp_model.py:25-33: x2 nearest upsample + 3x3 convolution, C -> N channels) in the parity form of
  * nbp_upconv3x3_split_f32: dx [B,H,W,C] at the LOW resolution straight from dy [B,2H,2W,N] -- 16 tap-products per low-resolution pixel
  * instead of the 36 of the full-resolution 3x3 data gradient followed by a 2x2 sum.  nbp_pack_upconv_weight_split_dgrad: 32 N C fp16

@@ -139,6 +139,8 @@ SIGNATURES["nbp_upconv_split_dgrad_workspace_bytes"] = (_sz, [_i, _i, _i, _i, _i
 SIGNATURES["nbp_upconv3x3_split_dgrad_f32"] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp])
 SIGNATURES["nbp_upconv_wgrad_split_workspace_bytes"] = (_sz, [_i, _i, _i, _i, _i])
 SIGNATURES["nbp_upconv_wgrad_split_f32"] = (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp])
+SIGNATURES["nbp_pack_conv_weight_split_prezeroed"] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp])
+SIGNATURES["nbp_pack_conv_weight_split_dgrad_known"] = (_i, [_vp, _i, _i, _i, _vp, _vp, _vp])
 SIGNATURES["nbp_rowscale_amax_f32"] = (_i, [_vp, _vp, _ll, _i, _vp, _vp, _vp])
 SIGNATURES["nbp_conv_first_linear_f32"] = (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
 SIGNATURES["nbp_conv_first_wgrad_workspace_bytes"] = (_sz, [])

@@ -1875,6 +1875,32 @@ extern "C" int nbp_pack_conv_weight_split_dgrad(const float* w_oihw, int N, int 
     return nbp_launch_status();
 }
 
+// The training step's forms of the two packs above (round 5: a 3x3 layer cost six launches per step for its weights -- memset, max,
+// pack, twice): `_prezeroed` takes a max-|w| word the caller has already zeroed (one fill per forward for all layers) and
+// `_dgrad_known` the word the forward's pack of the same weights left, since the data-gradient planes hold the same values.
+extern "C" int nbp_pack_conv_weight_split_prezeroed(const float* w_oihw, int N, int C, int ksize, int c_total, void* dst_planes,
+                                                    void* wamax_zeroed, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!w_oihw || !dst_planes || !wamax_zeroed, NBP_E_ARG);
+    NBP_RETURN_IF((ksize != 1 && ksize != 3) || N < 1 || C < 1 || C > c_total || c_total % 32, NBP_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)N * C * ksize * ksize;
+    amax_kernel<<<min(nbp_ew_grid(total, 256), 256), 256, 0, st>>>(w_oihw, total, nullptr, (long long)C * ksize * ksize, (unsigned*)wamax_zeroed, 1u);
+    pack_conv_weight_h2_kernel<<<nbp_ew_grid(total, 256), 256, 0, st>>>(w_oihw, N, C, ksize * ksize, nullptr, 0, (const unsigned*)wamax_zeroed,
+                                                                       (unsigned short*)dst_planes);
+    return nbp_launch_status();
+}
+extern "C" int nbp_pack_conv_weight_split_dgrad_known(const float* w_oihw, int N, int C, int c_total, void* dst_planes,
+                                                      const void* wamax_known, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!w_oihw || !dst_planes || !wamax_known, NBP_E_ARG);
+    NBP_RETURN_IF(N < 1 || C < 1 || N > c_total || c_total % 32, NBP_E_SHAPE);
+    const long long total = (long long)N * C * 9;
+    pack_conv_weight_h2_kernel<<<nbp_ew_grid(total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, C, N, 9, nullptr, 0, (const unsigned*)wamax_known,
+                                                                                        (unsigned short*)dst_planes, 1);
+    return nbp_launch_status();
+}
+
 extern "C" int nbp_amax_f32(const float* x, long long n, void* amax_inout, void* stream) {
     NBP_ENTER();
     NBP_RETURN_IF(!x || !amax_inout || n < 0, NBP_E_ARG);

@@ -94,14 +94,14 @@ def _pack_split(w_oihw, n_pad, c_total):
     # the pack kernel writes every plane entry of the channels it is given: only padded channels need the zero fill
     alloc = torch.zeros if C != c_total else torch.empty
     planes = alloc(c_total // 16 * 9 * 4 * n_pad * 8, dtype=torch.int16, device=w_oihw.device)
-    wamax = torch.empty(1, dtype=torch.int32, device=w_oihw.device)          # zeroed by the pack launch itself
+    wamax = _fresh_slots(w_oihw.device)[:1]          # a zeroed word of the forward's arena (no memset launch per layer)
     # the pack kernel indexes rows by the padded count: give it a zero-padded weight when N < n_pad
     if N != n_pad:
         wp = torch.zeros(n_pad, C, k, k, dtype=torch.float32, device=w_oihw.device)
         wp[:N] = w_oihw
         w_oihw = wp
-    _chk(_lib.lib().nbp_pack_conv_weight_split(_lib.ptr(w_oihw), n_pad, C, 3, None, 0, c_total, _lib.ptr(planes), _lib.ptr(wamax),
-                                               _st()), "pack_split")
+    _chk(_lib.lib().nbp_pack_conv_weight_split_prezeroed(_lib.ptr(w_oihw), n_pad, C, 3, c_total, _lib.ptr(planes), _lib.ptr(wamax),
+                                                         _st()), "pack_split")
     return planes, wamax
 
 
@@ -299,6 +299,7 @@ class ConvFn(torch.autograd.Function):
             shift[:N] = bias.detach()
         H, W = (x0.shape[1] * 2, x0.shape[2] * 2) if ups else (x0.shape[1], x0.shape[2])
         xmax = None                      # joint max-|.| slot of the inputs: taken once, reused by the weight gradient
+        wmax_fwd = None
         # bn_next: a BatchNorm consumes this output -- its statistics' partial sums come out of the epilogue (not for padded
         # channel counts, whose output is sliced; not under an observer, which may rewrite the output)
         bn = bool(bn_next) and _BN_EPILOGUE and N == Np and _observer is None
@@ -307,7 +308,9 @@ class ConvFn(torch.autograd.Function):
             y = _upconv_split(x0, w, Np, scale, shift, xmax, bn)
         elif _split_ok(H, W, Np, k):
             xmax = _amax_slot(x0, x1)
-            y = _conv_split(x0, x1, ups, _pack_split(w, Np, Ctot), Np, scale, shift, False, xmax, bn)
+            packed = _pack_split(w, Np, Ctot)
+            wmax_fwd = packed[1]                       # max |w|: the data gradient's planes hold the same values
+            y = _conv_split(x0, x1, ups, packed, Np, scale, shift, False, xmax, bn)
         elif one_by_one:
             xmax = _amax_slot(x0)
             planes = torch.empty(C0 // 16 * 4 * N * 8, dtype=torch.int16, device=dev)
@@ -320,6 +323,7 @@ class ConvFn(torch.autograd.Function):
             y = _igemm(x0, x1, ups, wpk, Np, k, scale, shift, False)
         ctx.save_for_backward(x0, x1 if x1 is not None else torch.empty(0, device=dev), w)
         ctx.xmax = xmax
+        ctx.wmax_fwd = wmax_fwd
         ctx.meta = (N, c_real, k, C0, C1, Np, bool(ups), x1 is not None, one_by_one)
         return _slice_channels(y, 0, N)
 
@@ -398,8 +402,13 @@ class ConvFn(torch.autograd.Function):
                 if c_real == Ctot and N == Np:
                     # flip + permute + pack in one launch (they were an ATen flip, a strided copy and the pack)
                     planes = torch.empty(Np // 16 * 9 * 4 * Ctot * 8, dtype=torch.int16, device=dev)
-                    wamax = torch.empty(1, dtype=torch.int32, device=dev)
-                    _chk(L.nbp_pack_conv_weight_split_dgrad(_lib.ptr(w), N, c_real, Np, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_dgrad_split")
+                    if getattr(ctx, "wmax_fwd", None) is not None:      # the forward's pack of the same weights measured max |w|
+                        wamax = ctx.wmax_fwd
+                        _chk(L.nbp_pack_conv_weight_split_dgrad_known(_lib.ptr(w), N, c_real, Np, _lib.ptr(planes), _lib.ptr(wamax), _st()),
+                             "pack_dgrad_split")
+                    else:
+                        wamax = torch.empty(1, dtype=torch.int32, device=dev)
+                        _chk(L.nbp_pack_conv_weight_split_dgrad(_lib.ptr(w), N, c_real, Np, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_dgrad_split")
                     packed = (planes, wamax)
                 else:
                     wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()            # [c_real, N, 3, 3]
