@@ -13,7 +13,9 @@ pairs = [("kernel_stats.csv", "kernel_stats.csv"), ("pmc_summary.csv", "pmc_summ
          ("fwd_f32/pmc_summary.csv", "forward_f32_pmc_summary.csv"), ("fwd_bf16/kernel_stats.csv", "forward_bf16_kernel_stats.csv"),
          ("fwd_bf16/pmc_summary.csv", "forward_bf16_pmc_summary.csv"), ("train/kernel_stats.csv", "train_kernel_stats.csv"),
          ("power_trace_b24.txt", "power_trace_b24.txt"), ("power_trace_bf16_512_b8.txt", "power_trace_bf16_512_b8.txt"),
-         ("fwd_graph_ab.txt", "fwd_graph_ab.txt"), ("bf16_layer_table.txt", "bf16_layer_table.txt"), ("map_bins_ab.txt", "map_bins_ab.txt")]
+         ("fwd_graph_ab.txt", "fwd_graph_ab.txt"), ("bf16_layer_table.txt", "bf16_layer_table.txt"), ("map_bins_ab.txt", "map_bins_ab.txt"), ("train_trace.txt", "train_trace.txt"), ("train_pmc_summary.txt", "train_pmc_summary.txt"),
+         ("train_host_time.txt", "train_host_time.txt"), ("bench_bn.txt", "bench_bn.txt"), ("bench_train.json", "bench_train.json"),
+         ("forward_layers_b24.txt", "forward_layers_b24.txt"), ("forward_layers_b1.txt", "forward_layers_b1.txt")]
 for a, b in pairs:
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 0:

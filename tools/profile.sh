@@ -29,7 +29,7 @@ for kind in split f32 bf16; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/fwd_${kind}/stats" -o trace -- $FW > "$REPO/$OUT/fwd_${kind}_stats.log" 2>&1
 done
 # configs[2]: the training step
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/train/stats" -o trace -- python $REPO/tools/bench_train.py --steps 3 --warmup 1 > "$REPO/$OUT/train.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/train/stats" -o trace -- python $REPO/tools/bench_train.py --steps 3 --warmup 1 --cpu-batch 0 > "$REPO/$OUT/train.log" 2>&1
 cd "$REPO"
 python tools/summarize_prof.py "$OUT" > "$OUT/summary.log" 2>&1
 for kind in split f32 bf16; do python tools/summarize_prof.py "$OUT/fwd_${kind}" >> "$OUT/summary.log" 2>&1; done
@@ -42,6 +42,14 @@ timeout 200 python tools/diag/power_trace.py --batch 8 --seconds 3 --precision b
 timeout 300 python tools/diag/fwd_graph_ab.py --batches 1 2 4 24 > "$OUT/fwd_graph_ab.txt" 2>&1
 timeout 300 python tools/diag/bf16_layer_table.py > "$OUT/bf16_layer_table.txt" 2>&1
 timeout 200 python tools/diag/map_bins_ab.py > "$OUT/map_bins_ab.txt" 2>&1
+# round 5: the training step per dispatch (which layer sizes a kernel's time sits in), its counters, its enqueue time, the BatchNorm passes
+bash tools/diag/train_trace.sh "$OUT/train_trace.txt" > /dev/null 2>&1
+bash tools/diag/train_pmc.sh "$OUT/train_pmc" > /dev/null 2>&1; cp "$OUT/train_pmc/summary.txt" "$OUT/train_pmc_summary.txt" 2>/dev/null
+timeout 200 python tools/diag/train_host_time.py > "$OUT/train_host_time.txt" 2>&1
+timeout 200 python tools/bench_bn.py > "$OUT/bench_bn.txt" 2>&1
+timeout 300 python tools/bench_train.py --cpu-batch 1 > "$OUT/bench_train.json" 2> /dev/null
+timeout 300 python tools/bench_forward.py --split --batch 24 --size 256 --reps 30 > "$OUT/forward_layers_b24.txt" 2>&1
+timeout 300 python tools/bench_forward.py --split --batch 1 --size 256 --reps 200 > "$OUT/forward_layers_b1.txt" 2>&1
 # gpurun merges at most 64 MiB back: the per-dispatch traces and counter rows are summarised above (kernel_stats.csv, pmc_summary.csv)
 find "$OUT" \( -name "*kernel_trace.csv" -o -name "*counter_collection.csv" -o -name "*agent_info.csv" \) -delete
 du -sh "$OUT" | tail -1
