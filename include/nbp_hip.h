@@ -185,6 +185,14 @@ int nbp_conv3x3_split_f32(const float* src0, int C0, const float* src1, int C1, 
  * takes nbp_conv_wgrad_split_f32).  The forward of the layer is nbp_conv_first_f32. */
 size_t nbp_conv_first_wgrad_workspace_bytes(void);
 int nbp_conv_first_wgrad_f32(const float* x_nchw, int B, int H, int W, const float* dy, float* dw, void* ws, size_t ws_bytes, void* stream);
+/* Every weight pack of a training step in two launches.  descs_dev: n records on the device, each
+ *   { const float* w; uint16_t* planes; uint16_t* planes_t; uint32_t* wamax; int32 N, C, kind, pad; }   (nbp_prepack_desc_bytes() = 48)
+ * kind 0: 3x3 layer w [N][C][3][3] -> planes of nbp_pack_conv_weight_split and planes_t of nbp_pack_conv_weight_split_dgrad;
+ * kind 1: 1x1 layer w [N][C] -> planes (ksize 1) and planes_t of nbp_pack_conv1x1_weight_split_dgrad;
+ * kind 2: up_conv layer -> planes of nbp_pack_upconv_weight_split and planes_t of nbp_pack_upconv_weight_split_dgrad.
+ * planes_t may be null.  wamax: the record's own word inside wamax_words [n] (zeroed by the call).  N % 16 == 0, C % 16 == 0. */
+int nbp_prepack_weights_split(const void* descs_dev, int n, void* wamax_words, void* stream);
+int nbp_prepack_desc_bytes(void);
 /* Training-step forms of nbp_pack_conv_weight_split / _dgrad: `_prezeroed` takes a max-|w| word the caller zeroed (no memset launch),
  * `_dgrad_known` reuses the word the forward's pack of the same weights left (the data-gradient planes hold the same values): one
  * launch instead of three. */

@@ -141,6 +141,8 @@ SIGNATURES["nbp_upconv_wgrad_split_workspace_bytes"] = (_sz, [_i, _i, _i, _i, _i
 SIGNATURES["nbp_upconv_wgrad_split_f32"] = (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp])
 SIGNATURES["nbp_pack_conv_weight_split_prezeroed"] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp])
 SIGNATURES["nbp_pack_conv_weight_split_dgrad_known"] = (_i, [_vp, _i, _i, _i, _vp, _vp, _vp])
+SIGNATURES["nbp_prepack_weights_split"] = (_i, [_vp, _i, _vp, _vp])
+SIGNATURES["nbp_prepack_desc_bytes"] = (_i, [])
 SIGNATURES["nbp_rowscale_amax_f32"] = (_i, [_vp, _vp, _ll, _i, _vp, _vp, _vp])
 SIGNATURES["nbp_conv_first_linear_f32"] = (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
 SIGNATURES["nbp_conv_first_wgrad_workspace_bytes"] = (_sz, [])

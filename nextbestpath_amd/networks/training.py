@@ -247,17 +247,20 @@ def _upconv_ok(Hs, Ws, N):
     return _SPLIT and Hs % 16 == 0 and ((Ws % 32 == 0 and N % 64 == 0) or (Ws % 16 == 0 and N % 128 == 0))
 
 
-def _upconv_split(src, w_oihw, n_pad, scale, shift, amax=None, bn=False):
+def _upconv_split(src, w_oihw, n_pad, scale, shift, amax=None, bn=False, pre=None):
     L = _lib.lib()
     N, C, _, _ = w_oihw.shape
     B, Hs, Ws, C0 = src.shape
-    if N != n_pad or C != C0:       # zero rows / channels up to the padded counts
-        wp = torch.zeros(n_pad, C0, 3, 3, dtype=torch.float32, device=w_oihw.device)
-        wp[:N, :C] = w_oihw
-        w_oihw = wp
-    planes = torch.empty(4 * (C0 // 16) * 4 * 4 * n_pad * 8, dtype=torch.int16, device=src.device)
-    wamax = torch.empty(1, dtype=torch.int32, device=src.device)             # zeroed by the pack launch itself
-    _chk(L.nbp_pack_upconv_weight_split(_lib.ptr(w_oihw), n_pad, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_upconv")
+    if pre is not None and N == n_pad and C == C0:
+        planes, wamax = pre[3], pre[5]              # packed at the start of the forward (_prepack_run)
+    else:
+        if N != n_pad or C != C0:       # zero rows / channels up to the padded counts
+            wp = torch.zeros(n_pad, C0, 3, 3, dtype=torch.float32, device=w_oihw.device)
+            wp[:N, :C] = w_oihw
+            w_oihw = wp
+        planes = torch.empty(4 * (C0 // 16) * 4 * 4 * n_pad * 8, dtype=torch.int16, device=src.device)
+        wamax = torch.empty(1, dtype=torch.int32, device=src.device)             # zeroed by the pack launch itself
+        _chk(L.nbp_pack_upconv_weight_split(_lib.ptr(w_oihw), n_pad, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_upconv")
     H, W = 2 * Hs, 2 * Ws
     out = torch.empty(B, H, W, n_pad, dtype=torch.float32, device=src.device)
     ws = _ws(L.nbp_conv_split_planned_workspace_bytes_k(B, H, W, C0, n_pad, 1, _TRAIN_SK, None), src.device)
@@ -272,6 +275,71 @@ def _upconv_split(src, w_oihw, n_pad, scale, shift, amax=None, bn=False):
     _chk(L.nbp_upconv3x3_split_f32(_lib.ptr(src), C0, B, H, W, _lib.ptr(planes), _lib.ptr(wamax), n_pad, _lib.ptr(scale),
                                    _lib.ptr(shift), 0, _lib.ptr(out), _lib.ptr(amax), None, _TRAIN_SK, _lib.ptr(ws), ws.numel(), _st()), "upconv3x3_split")
     return out
+
+
+# ---- all weight packs of a step in two launches (csrc/nbp_split.hip: nbp_prepack_weights_split).  forward_train builds (once per set of
+# parameter storages) a device table of the layers the split kernels take -- 3x3, up_conv and the gates' 1x1 layers -- with persistent
+# plane buffers, runs the two launches at the start of every forward, and the layers look their planes up by the weight's address;
+# a layer called outside forward_train (tests) packs for itself as before.  NBP_TRAIN_PREPACK=0: every layer packs for itself.
+_PREPACK = _lib.tune("NBP_TRAIN_PREPACK", "1") == "1"
+_PRE_CACHE = {}          # key (device, parameter addresses) -> table
+_PRE = None              # the current step's {weight address: (kind, N, C, planes, planes_t, wamax)}
+
+
+def _prepack_layers(net):
+    out = []
+    for name, mod in net.named_modules():
+        w = getattr(mod, "weight", None)
+        if not isinstance(mod, torch.nn.Conv2d) or w is None:
+            continue
+        N, C, k, _ = w.shape
+        if N % 16 or C % 16:
+            continue                                   # Conv1.conv.0 (5 channels), psi, the heads
+        if k == 3:
+            out.append((w, 2 if ".up." in name + "." else 0, N, C))
+        elif k == 1 and N % 32 == 0 and C % 32 == 0:
+            out.append((w, 1, N, C))
+    return out
+
+
+def _prepack_run(net, dev):
+    """Packs every layer's weights for this step; returns the lookup table (None: switched off / nothing to pack)."""
+    import numpy as np
+    if not (_PREPACK and _SPLIT):
+        return None
+    L = _lib.lib()
+    layers = _prepack_layers(net)
+    if not layers:
+        return None
+    key = (str(dev),) + tuple(w.data_ptr() for w, *_ in layers)
+    tab = _PRE_CACHE.get(key)
+    if tab is None:
+        _PRE_CACHE.clear()                             # (one network at a time: the buffers are 2 x the weights)
+        assert L.nbp_prepack_desc_bytes() == 48
+        n = len(layers)
+        wamax = torch.zeros(n, dtype=torch.int32, device=dev)
+        rec = np.zeros(n, dtype=np.dtype([("w", "<u8"), ("planes", "<u8"), ("planes_t", "<u8"), ("wamax", "<u8"), ("N", "<i4"), ("C", "<i4"),
+                                            ("kind", "<i4"), ("pad", "<i4")]))
+        look, keep = {}, []
+        for i, (w, kind, N, C) in enumerate(layers):
+            taps = {0: 9, 1: 1, 2: 16}[kind]
+            planes = torch.empty(taps * 4 * N * C // 2, dtype=torch.int16, device=dev)      # 4 B per (tap, weight): hi + lo fp16
+            planes_t = torch.empty(taps * 4 * N * C // 2, dtype=torch.int16, device=dev)
+            rec[i] = (w.data_ptr(), planes.data_ptr(), planes_t.data_ptr(), wamax.data_ptr() + 4 * i, N, C, kind, 0)
+            look[w.data_ptr()] = (kind, N, C, planes, planes_t, wamax[i:i + 1])
+            keep.append(w)
+        descs = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        tab = _PRE_CACHE[key] = {"descs": descs, "wamax": wamax, "look": look, "n": n, "keep": keep}
+    _chk(L.nbp_prepack_weights_split(_lib.ptr(tab["descs"]), tab["n"], _lib.ptr(tab["wamax"]), _st()), "prepack")
+    return tab["look"]
+
+
+def _prepacked(w, kind, N, C):
+    """This step's planes of weight tensor w, or None."""
+    if _PRE is None:
+        return None
+    e = _PRE.get(w.data_ptr())
+    return e if (e is not None and e[0] == kind and e[1] == N and e[2] == C) else None
 
 
 class ConvFn(torch.autograd.Function):
@@ -303,19 +371,26 @@ class ConvFn(torch.autograd.Function):
         # bn_next: a BatchNorm consumes this output -- its statistics' partial sums come out of the epilogue (not for padded
         # channel counts, whose output is sliced; not under an observer, which may rewrite the output)
         bn = bool(bn_next) and _BN_EPILOGUE and N == Np and _observer is None
+        pre = None                       # this step's prepacked planes of the layer (kind, N, C, planes, planes_t, wamax)
         if ups and k == 3 and x1 is None and _upconv_ok(x0.shape[1], x0.shape[2], Np):
             xmax = _amax_slot(x0)
-            y = _upconv_split(x0, w, Np, scale, shift, xmax, bn)
+            pre = _prepacked(w, 2, N, c_real) if (N == Np and c_real == C0) else None
+            y = _upconv_split(x0, w, Np, scale, shift, xmax, bn, pre)
         elif _split_ok(H, W, Np, k):
             xmax = _amax_slot(x0, x1)
-            packed = _pack_split(w, Np, Ctot)
+            pre = _prepacked(w, 0, N, c_real) if (N == Np and c_real == Ctot) else None
+            packed = (pre[3], pre[5]) if pre is not None else _pack_split(w, Np, Ctot)
             wmax_fwd = packed[1]                       # max |w|: the data gradient's planes hold the same values
             y = _conv_split(x0, x1, ups, packed, Np, scale, shift, False, xmax, bn)
         elif one_by_one:
             xmax = _amax_slot(x0)
-            planes = torch.empty(C0 // 16 * 4 * N * 8, dtype=torch.int16, device=dev)
-            wamax = torch.empty(1, dtype=torch.int32, device=dev)
-            _chk(L.nbp_pack_conv_weight_split(_lib.ptr(w), N, C0, 1, None, 0, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_split_1x1")
+            pre = _prepacked(w, 1, N, C0)
+            if pre is not None:
+                planes, wamax = pre[3], pre[5]
+            else:
+                planes = torch.empty(C0 // 16 * 4 * N * 8, dtype=torch.int16, device=dev)
+                wamax = torch.empty(1, dtype=torch.int32, device=dev)
+                _chk(L.nbp_pack_conv_weight_split(_lib.ptr(w), N, C0, 1, None, 0, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_split_1x1")
             y = _conv1x1_split(x0, planes, wamax, N, scale, shift, xmax)
         else:
             wpk = torch.empty(Ctot // 32 * k * k * Np * 32, dtype=torch.float32, device=dev)
@@ -324,6 +399,7 @@ class ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x0, x1 if x1 is not None else torch.empty(0, device=dev), w)
         ctx.xmax = xmax
         ctx.wmax_fwd = wmax_fwd
+        ctx.pre = pre
         ctx.meta = (N, c_real, k, C0, C1, Np, bool(ups), x1 is not None, one_by_one)
         return _slice_channels(y, 0, N)
 
@@ -378,9 +454,13 @@ class ConvFn(torch.autograd.Function):
             one, zero = _const(1.0, Ctot, dev), _const(0.0, Ctot, dev)
             if (ups and k == 3 and not has1 and _UP_DGRAD and N == Np and c_real == C0 and _upconv_ok(H // 2, W // 2, C0)
                     and B * H * W * Np * 4 < 2 ** 31):
-                planes = torch.empty(32 * Np * C0, dtype=torch.int16, device=dev)
-                wamax = torch.empty(1, dtype=torch.int32, device=dev)
-                _chk(L.nbp_pack_upconv_weight_split_dgrad(_lib.ptr(w), Np, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_upconv_dgrad")
+                pre = getattr(ctx, "pre", None)
+                if pre is not None and pre[0] == 2:
+                    planes, wamax = pre[4], pre[5]
+                else:
+                    planes = torch.empty(32 * Np * C0, dtype=torch.int16, device=dev)
+                    wamax = torch.empty(1, dtype=torch.int32, device=dev)
+                    _chk(L.nbp_pack_upconv_weight_split_dgrad(_lib.ptr(w), Np, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_upconv_dgrad")
                 if dymax is None:
                     dymax = info[0] if info is not None else _amax_slot(dy)
                 dxl = torch.empty(B, H // 2, W // 2, C0, dtype=torch.float32, device=dev)
@@ -391,9 +471,13 @@ class ConvFn(torch.autograd.Function):
                 return dxl, None, dw, db, None, None
             if one_by_one:
                 # dx = dy W^T: a 1x1 convolution from N to C0 channels on the same kernel
-                planes = torch.empty(N // 16 * 4 * C0 * 8, dtype=torch.int16, device=dev)
-                wamax = torch.empty(1, dtype=torch.int32, device=dev)
-                _chk(L.nbp_pack_conv1x1_weight_split_dgrad(_lib.ptr(w), N, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_dgrad_1x1")
+                pre = getattr(ctx, "pre", None)
+                if pre is not None and pre[0] == 1:
+                    planes, wamax = pre[4], pre[5]
+                else:
+                    planes = torch.empty(N // 16 * 4 * C0 * 8, dtype=torch.int16, device=dev)
+                    wamax = torch.empty(1, dtype=torch.int32, device=dev)
+                    _chk(L.nbp_pack_conv1x1_weight_split_dgrad(_lib.ptr(w), N, C0, _lib.ptr(planes), _lib.ptr(wamax), _st()), "pack_dgrad_1x1")
                 if dymax is None:
                     dymax = info[0] if info is not None else _amax_slot(dy)
                 dx = _conv1x1_split(dy, planes, wamax, C0, one, zero, dymax)
@@ -401,8 +485,11 @@ class ConvFn(torch.autograd.Function):
                 # dx = conv3x3(dy, w^T with the taps reversed): output channels = the (padded) input channels
                 if c_real == Ctot and N == Np:
                     # flip + permute + pack in one launch (they were an ATen flip, a strided copy and the pack)
-                    planes = torch.empty(Np // 16 * 9 * 4 * Ctot * 8, dtype=torch.int16, device=dev)
-                    if getattr(ctx, "wmax_fwd", None) is not None:      # the forward's pack of the same weights measured max |w|
+                    pre = getattr(ctx, "pre", None)
+                    planes = pre[4] if (pre is not None and pre[0] == 0) else torch.empty(Np // 16 * 9 * 4 * Ctot * 8, dtype=torch.int16, device=dev)
+                    if pre is not None and pre[0] == 0:
+                        wamax = pre[5]
+                    elif getattr(ctx, "wmax_fwd", None) is not None:      # the forward's pack of the same weights measured max |w|
                         wamax = ctx.wmax_fwd
                         _chk(L.nbp_pack_conv_weight_split_dgrad_known(_lib.ptr(w), N, c_real, Np, _lib.ptr(planes), _lib.ptr(wamax), _st()),
                              "pack_dgrad_split")
@@ -804,8 +891,9 @@ def forward_train(net, x):
     B, _, S, _ = x.shape
     dev = x.device
     _reset_arena(dev)
-    global _NBT
+    global _NBT, _PRE
     _NBT = []
+    _PRE = _prepack_run(net, dev) if _observer is None else None
     try:
         return _forward_train(net, x, L, B, S, dev)
     finally:
@@ -813,6 +901,7 @@ def forward_train(net, x):
             with torch.no_grad():
                 torch._foreach_add_(_NBT, 1)       # nn.BatchNorm2d's num_batches_tracked += 1 (46 one-element kernels otherwise)
         _NBT = None
+        _PRE = None                                # (each layer's context holds its planes for the backward)
 
 
 def _forward_train(net, x, L, B, S, dev):

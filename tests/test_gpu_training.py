@@ -406,6 +406,37 @@ def test_full_network_training_step_small_gross_check(hip, nbp_weights):
             assert rel < 0.15, (name, rel)   # this input has a pre-activation 7.6e-6 from zero in Up_conv5_1.conv.1: one ReLU mask flip
 
 
+@pytest.mark.parametrize("S", [64, 256])
+def test_step_with_all_weight_packs_up_front_is_the_step_with_per_layer_packs(hip, nbp_weights, monkeypatch, S):
+    """nbp_prepack_weights_split (two launches for every layer's planes) against each layer packing for itself: the same planes, so the
+    same outputs and gradients bit for bit; and after an optimizer step the table's planes follow the new weights."""
+    x, coords, gains, gt2, sd = _inputs(S, nbp_weights)
+    hits = []
+    real = tr._prepacked
+    monkeypatch.setattr(tr, "_prepacked", lambda *a: (hits.append(real(*a) is not None), real(*a))[1])
+    monkeypatch.setattr(tr, "_PREPACK", True)
+    net_a, o1a, o2a, la = _hip_step(sd, x, coords, gains, gt2)
+    assert sum(hits) >= (30 if S == 256 else 10), sum(hits)
+    monkeypatch.setattr(tr, "_PREPACK", False)
+    net_b, o1b, o2b, lb = _hip_step(sd, x, coords, gains, gt2)
+    assert torch.equal(o1a, o1b) and torch.equal(o2a, o2b) and torch.equal(la, lb)
+    for (name, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        assert torch.equal(pa.grad, pb.grad), name
+    # second step on changed weights (same storages: the cached table is reused, the planes are not)
+    outs = []
+    for flag, net in ((True, net_a), (False, net_b)):
+        monkeypatch.setattr(tr, "_PREPACK", flag)
+        with torch.no_grad():
+            for p_ in net.parameters():
+                p_.mul_(1.25)
+        net.zero_grad()
+        o1, o2 = net(x.to(D))
+        (o1.square().mean() + o2.square().mean()).backward()
+        outs.append((o1.detach(), o2.detach(), [p_.grad.clone() for p_ in net.parameters() if p_.grad is not None]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][2], outs[1][2]))
+
+
 def test_optimizer_step_runs_and_repacks(hip, nbp_weights):
     """A2/A3 plumbing: AdamW step on the HIP gradients, then eval-mode forward sees the new weights."""
     x, coords, gains, gt2, sd = _inputs(32, nbp_weights)
