@@ -198,6 +198,14 @@ __global__ __launch_bounds__(256) void points_scatter4_kernel(const float* __res
     }
 }
 
+// The columns around a cloud point are culled by their distance to it: a column whose (x, y) box is farther than the threshold is
+// skipped, the others are walked only over the z cells within the remaining budget (a random point meets 20.6 of its 27 cells).
+// The test is in cell units against PLAN_R cells = 1.001 x the threshold: the 0.1 % slack covers the fp32 rounding of
+// (x - lo) * inv on both sides (~1e-5 cells each), so no GT point within the threshold is ever in a skipped cell.
+// PLAN_R = cells to a threshold.  2 (cells of half the threshold, 5 x 5 columns, 2.6 x fewer pair tests) was measured: the same
+// 30 us stand-alone and -2 % in the lock-step -- the launch is bound by its dependent loads (the random gather of the sampled
+// cloud points, two run bounds per column), not by the pair tests (profiles/r05/rejected_experiments.txt).
+constexpr int PLAN_R = 1;
 template <int LANES, int UNROLL>
 __device__ __forceinline__ void coverage_mark_body(unsigned bx, unsigned by, unsigned gx, unsigned gy, const float* __restrict__ pc, const long long* __restrict__ n_dev,
                                                             long long n_host, long long k, unsigned seed, Grid g, float d2max,
@@ -207,6 +215,7 @@ __device__ __forceinline__ void coverage_mark_body(unsigned bx, unsigned by, uns
     // d2max = the largest float whose square root is below the threshold (sq_below, host): d2 <= d2max is the reference's
     // cdist(...) < threshold decision exactly (sqrtf is monotone and correctly rounded on both sides) without the ~12
     // instructions of a correctly rounded square root per point pair -- the kernel is bound by those pair tests
+    constexpr int R = PLAN_R, D = 2 * R + 1;
     const long long N = n_dev ? *n_dev : n_host;
     const long long M = N > k ? k : N;
     if (bx == 0 && threadIdx.x == 0) *m_out = (int)M;
@@ -217,14 +226,30 @@ __device__ __forceinline__ void coverage_mark_body(unsigned bx, unsigned by, uns
         const long long src = N > k ? (long long)perm_index((unsigned)j, (unsigned)N, bits, seed) : j;
         const float x = pc[3 * src], y = pc[3 * src + 1], z = pc[3 * src + 2];
         // unclamped cell: a cloud point outside the grid (= the GT box grown by thr) is farther than thr from every GT point
-        const float fi = floorf((x - g.lo[0]) * g.inv), fj = floorf((y - g.lo[1]) * g.inv), fk = floorf((z - g.lo[2]) * g.inv);
-        if (!(fi >= -1.f && fi <= (float)g.n[0] && fj >= -1.f && fj <= (float)g.n[1] && fk >= -1.f && fk <= (float)g.n[2])) continue;
+        const float ux = (x - g.lo[0]) * g.inv, uy = (y - g.lo[1]) * g.inv, uz = (z - g.lo[2]) * g.inv;
+        const float fi = floorf(ux), fj = floorf(uy), fk = floorf(uz);
+        if (!(fi >= (float)-R && fi <= (float)(g.n[0] - 1 + R) && fj >= (float)-R && fj <= (float)(g.n[1] - 1 + R) && fk >= (float)-R &&
+              fk <= (float)(g.n[2] - 1 + R)))
+            continue;
         const int ci = (int)fi, cj = (int)fj, ck = (int)fk;
-        const int d0 = max(ck - 1, 0), d1 = min(ck + 1, g.n[2] - 1);
-        if (d0 > d1) continue;
-        for (int col = sub; col < 9; col += LANES) {
-            const int a = ci + col / 3 - 1, b = cj + col % 3 - 1;
+        const float ox = ux - fi, oy = uy - fj, oz = uz - fk;          // position inside the cell, [0, 1]
+        for (int col = sub; col < D * D; col += LANES) {
+            const int da = col / D - R, db = col % D - R;
+            const int a = ci + da, b = cj + db;
             if (a < 0 || a >= g.n[0] || b < 0 || b >= g.n[1]) continue;
+            const float dx = da > 0 ? (float)da - ox : (da < 0 ? ox - (float)(da + 1) : 0.f);
+            const float dy = db > 0 ? (float)db - oy : (db < 0 ? oy - (float)(db + 1) : 0.f);
+            const float rem = (float)(R * R) - (dx * dx + dy * dy);
+            if (rem < 0.f) continue;
+            int k0 = 0, k1 = 0;
+#pragma unroll
+            for (int dk = 1; dk <= R; ++dk) {
+                const float below = oz + (float)(dk - 1), above = (float)dk - oz;
+                if (below * below <= rem) k0 = -dk;
+                if (above * above <= rem) k1 = dk;
+            }
+            const int d0 = max(ck + k0, 0), d1 = min(ck + k1, g.n[2] - 1);
+            if (d0 > d1) continue;
             const int base = (a * g.n[1] + b) * g.n[2];
             const int hi = gt_start[base + d1 + 1];
             int q = gt_start[base + d0];
@@ -384,6 +409,23 @@ static int coverage_grid(const float* bbox_lo, const float* bbox_hi, float thr, 
 
 static size_t al256(size_t b) { return (b + 255) / 256 * 256; }
 
+// the grid of a coverage PLAN: cells of thr / PLAN_R (coverage_mark_body), over the GT box grown by thr
+static int coverage_plan_grid(const float* bbox_lo, const float* bbox_hi, float thr, Grid* g, size_t* ncell) {
+    size_t n = 1;
+    const double w = (double)thr / PLAN_R;
+    for (int a = 0; a < 3; ++a) {
+        g->lo[a] = bbox_lo[a] - thr;
+        const double ext = (double)bbox_hi[a] + thr - g->lo[a];
+        if (!(ext > 0)) return NBP_E_ARG;
+        g->n[a] = (int)(ext / w) + 1;
+        n *= (size_t)g->n[a];
+    }
+    g->inv = (float)(1.0 / (w * 1.001));             // PLAN_R cells = 1.001 thr
+    if (n > (size_t)1 << 28) return NBP_E_SHAPE;
+    *ncell = n;
+    return 0;
+}
+
 extern "C" size_t nbp_coverage_workspace_bytes(const float* bbox_lo_host, const float* bbox_hi_host, float threshold,
                                                long long sample_k) {
     Grid g; size_t ncell;
@@ -448,7 +490,7 @@ static void plan_carve(void* plan, size_t ncell, int G, int** start, float4** so
 extern "C" size_t nbp_coverage_plan_bytes(const float* bbox_lo_host, const float* bbox_hi_host, float threshold, int G) {
     Grid g; size_t ncell;
     if (!bbox_lo_host || !bbox_hi_host || !(threshold > 0) || G < 1) return 0;
-    if (coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell)) return 0;
+    if (coverage_plan_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell)) return 0;
     return 256 + al256((ncell + 1) * 4) + al256((size_t)G * 16) + al256((size_t)G * 4);
 }
 
@@ -456,7 +498,7 @@ extern "C" size_t nbp_coverage_plan_workspace_bytes(const float* bbox_lo_host, c
                                                     int G) {
     Grid g; size_t ncell;
     if (!bbox_lo_host || !bbox_hi_host || !(threshold > 0) || G < 1) return 0;
-    if (coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell)) return 0;
+    if (coverage_plan_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell)) return 0;
     return 256 + al256(ncell * 4) + al256((ncell / SCAN_TILE + 1) * 4) + 2 * al256((size_t)G * 4);
 }
 
@@ -466,7 +508,7 @@ extern "C" int nbp_coverage_plan_build_f32(const float* gt3, int G, float thresh
     NBP_ENTER();
     NBP_RETURN_IF(!gt3 || !plan || !ws || !bbox_lo_host || !bbox_hi_host || G < 1 || !(threshold > 0), NBP_E_ARG);
     Grid g; size_t ncell;
-    int rc = coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell);
+    int rc = coverage_plan_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell);
     if (rc) return rc;
     NBP_RETURN_IF(plan_bytes < nbp_coverage_plan_bytes(bbox_lo_host, bbox_hi_host, threshold, G), NBP_E_WS);
     NBP_RETURN_IF(ws_bytes < nbp_coverage_plan_workspace_bytes(bbox_lo_host, bbox_hi_host, threshold, G), NBP_E_WS);
@@ -496,7 +538,7 @@ extern "C" int nbp_coverage_count_planned_f32(void* plan, int G, float threshold
     NBP_RETURN_IF(!plan || !pc3 || !count_accum || !m_out || !bbox_lo_host || !bbox_hi_host, NBP_E_ARG);
     NBP_RETURN_IF(G < 1 || N < 0 || sample_k < 1 || !(threshold > 0) || N > 0xffffffffll || epoch == 0, NBP_E_ARG);
     Grid g; size_t ncell;
-    int rc = coverage_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell);
+    int rc = coverage_plan_grid(bbox_lo_host, bbox_hi_host, threshold, &g, &ncell);
     if (rc) return rc;
     int* start; float4* sorted; unsigned* stamp;
     plan_carve(plan, ncell, G, &start, &sorted, &stamp);
@@ -529,7 +571,7 @@ extern "C" int nbp_coverage_count_planned_batch_f32(int n, void* const* plans, c
                       N[q] > 0xffffffffll || epoch[q] == 0, NBP_E_ARG);
         CovItem& a = b.it[r];
         size_t ncell;
-        const int rc = coverage_grid(bbox_lo_host + 3 * q, bbox_hi_host + 3 * q, threshold, &a.g, &ncell);
+        const int rc = coverage_plan_grid(bbox_lo_host + 3 * q, bbox_hi_host + 3 * q, threshold, &a.g, &ncell);
         if (rc) return rc;
         int* start; float4* sorted; unsigned* stamp;
         plan_carve(plans[q], ncell, G[q], &start, &sorted, &stamp);

@@ -52,7 +52,7 @@ def test_bench_live_traffic_pass_finds_the_dominant_kernel(hip):
     assert rf["traffic_is_live"] is True and rf["traffic_source"].startswith("rocprofv3"), rf["traffic_source"]
     assert rf["traffic"] > 0 and 0.5 < rf["traffic_over_algorithmic"] < 4.0
     assert sc["traffic_is_live"] is True and sc["traffic"] > 0
-    assert all(k.startswith(("conv3x3_halo_h2_kernel<", "tile ")) for k in rf["by_kernel"])
+    assert all(k.startswith(("conv3x3_halo_h2_kernel<", "gate1x1_h2_kernel<", "tile ")) for k in rf["by_kernel"]), list(rf["by_kernel"])
     for key in ("train_maps_per_s", "bf16_512_b8_frac", "fwd_b1_ms", "single_rollout_steps_per_s", "lockstep_forward_share",
                 "value_fp32_pipe", "all_conv_frac_executed", "roofline_traffic_is_live"):
         assert key in d                                      # top-level scalars (None for the stages --no-extra-stages skips)
