@@ -36,6 +36,10 @@ _STEP_MAPS = _lib.tune("NBP_STEP_MAPS", "1") == "1"      # A/B: 0 = the step's m
 # the eval forward as a replayed hipGraph (packing.ForwardGraph): 0 = never, 1 = a single rollout's B = 1 forward, 2 = also the
 # lock-step groups' batched forwards
 _FWD_GRAPH = int(_lib.tune("NBP_FWD_GRAPH", "1"))
+# Rollout.step: the step's forward on a stream of its own, behind the map stage by an event.  The reference runs the network at
+# every step and reads its output only when it replans (nbp_planning.py:166 / :252): a step that does not replan goes on to the move
+# and the next observation while its forward (every kernel of it, on the same input) is still running.  0 = everything in stream order.
+_STEP_OVERLAP = _lib.tune("NBP_STEP_OVERLAP", "1") == "1"
 # the step's maps from the tile-binned shadow copy of the cloud (utils.CloudBins; bit-identical maps): 0 = the append-order kernel
 _MAP_BINS = _lib.tune("NBP_MAP_BINS", "1") == "1"
 
@@ -53,6 +57,20 @@ class RolloutState:
         self.net_in = torch.zeros(1, 5, grid, grid, dtype=torch.float32, device=device)
         self.bins = None             # utils.CloudBins of `cloud` (made by the rollout: the tile grid needs the scene's extent)
         self.frames_appended = 0     # frames un-projected into the cloud so far (host bound of its size: <= that many x per-frame keep)
+        self._overlap = None         # forward_overlap(): two network inputs / streams / event pairs, used alternately
+
+    def forward_overlap(self):
+        """Two network-input buffers with a forward stream and an event pair each (Rollout.step alternates between them, so that
+        the forward of step t may still be reading its input while step t + 1 builds the next one)."""
+        if self._overlap is None:
+            main = torch.cuda.current_stream(self.device)
+            ins = [self.net_in, torch.zeros_like(self.net_in)]
+            streams = [torch.cuda.Stream(self.device) for _ in ins]
+            for f in streams:
+                f.wait_stream(main)
+            self._overlap = {"net_in": ins, "streams": streams, "maps": [torch.cuda.Event() for _ in ins],
+                             "done": [torch.cuda.Event() for _ in ins], "used": [False for _ in ins]}
+        return self._overlap
 
 
 def setup_test_camera(params, mesh, start_cam_idx, settings, device, seed=0):
@@ -245,9 +263,11 @@ class Rollout:
         return (self, depth, cams, st.cloud, st.cloud_count, seed, st.cloud_rgb if shade else None, shade)
 
     def step(self):
+        static = getattr(self.nbp, "forward_static", None) if _FWD_GRAPH >= 1 else None
+        if static is not None and _STEP_OVERLAP and _STEP_MAPS and not self.nbp.training:
+            return self._step_forward_on_its_own_stream(static)
         self.pre()
         with torch.no_grad():          # S9: one NBP forward per step (the reference also runs it without replanning, :252)
-            static = getattr(self.nbp, "forward_static", None) if _FWD_GRAPH >= 1 else None
             # net_in is a persistent tensor: the ~60 launches of a B = 1 forward replay as one hipGraph (bit-identical outputs)
             out1, out2 = static(self.st.net_in) if static is not None else self.nbp(self.st.net_in)
         self.plan_enqueue(out1, out2)
@@ -255,6 +275,40 @@ class Rollout:
             torch.cuda.current_stream().synchronize()
         self.plan_finish()
         self.post()
+
+    def _step_forward_on_its_own_stream(self, static):
+        """step() with the forward (the replayed hipGraph of this input buffer) on a side stream: same kernels, same inputs, same
+        results; only a replanning step waits for it."""
+        st = self.st
+        ov = st.forward_overlap()
+        slot = self.pose_i & 1
+        main = torch.cuda.current_stream(self.device)
+        net_in, fwd = ov["net_in"][slot], ov["streams"][slot]
+        if ov["used"][slot]:
+            main.wait_event(ov["done"][slot])          # the forward of two steps ago has read this buffer
+        st.net_in = net_in                             # (the input of the latest step, whichever buffer it is)
+        self.pre(net_in)
+        ov["maps"][slot].record(main)
+        with torch.cuda.stream(fwd), torch.no_grad():
+            fwd.wait_event(ov["maps"][slot])
+            out1, out2 = static(net_in)
+            ov["done"][slot].record(fwd)
+        ov["used"][slot] = True
+        if self.need_replan:
+            main.wait_event(ov["done"][slot])
+            self.plan_enqueue(out1, out2)
+            main.synchronize()
+            self.plan_finish()
+        self.post()
+
+    def finish(self):
+        """The caller's stream waits for the forwards still in flight (before the network's weights or the state are reused)."""
+        ov = self.st._overlap
+        if ov is not None:
+            main = torch.cuda.current_stream(self.device)
+            for used, ev in zip(ov["used"], ov["done"]):
+                if used:
+                    main.wait_event(ev)
 
     def coverage_evolution(self, n):
         counts = self.st.coverage_counts[:n].cpu().numpy()
@@ -620,6 +674,7 @@ def compute_nbp_trajectory(params, nbp, camera, gt_scene_pc, mesh, mesh_for_chec
     ro = Rollout(params, nbp, camera, gt_scene_pc, mesh, mesh_for_check, y_bins, device, state, seed)
     for _ in range(n_poses):
         ro.step()
+    ro.finish()
     coverage_evolution = ro.coverage_evolution(n_poses)
     n_cloud = int(ro.st.cloud_count.item())
     print("Time: ", time.time() - t1)
@@ -686,6 +741,7 @@ def run_one(params, nbp, dataset, run, device, test_resolution=0.05, state=None,
     nbp.eval()
     for _ in range(n_poses):
         ro.step()
+    ro.finish()
     return _result(ro, n_poses)
 
 

@@ -53,6 +53,44 @@ def test_short_rollout_invariants_and_determinism(hip, dataset, nbp_weights):
     assert a["coverage"] == b["coverage"] and a["X_cam_history"] == b["X_cam_history"]     # seeded => bit identical
 
 
+def test_step_with_the_forward_on_its_own_stream_is_the_step_in_stream_order(hip, dataset, nbp_weights, monkeypatch, tmp_path):
+    """Rollout.step runs the step's forward on a side stream (two input buffers used alternately; only a replanning step waits for
+    it): the same trajectory, coverage, cloud and -- at the last step -- network input and outputs as with everything in stream
+    order, and a RolloutState taken over by the next rollout starts clean."""
+    from nextbestpath_amd.simulator import scene as sc
+    from nextbestpath_amd.simulator.mesh import make_maze_scene
+    from nextbestpath_amd.testers import nbp_planning as tp
+    params = tp.load_params(os.path.join(ROOT, "configs/macarons/macarons_default_training_config.json"))
+    make_maze_scene(str(tmp_path / "m"), seed=115, cells=10, size=6.0, height=1.2, tess=0.25)      # bench.py's kind of scene
+    ds0, ds1 = sc.SceneDataset(dataset), sc.SceneDataset(str(tmp_path), ["m"])
+    net = _net(nbp_weights)
+    dev = torch.device("cuda")
+    got = {}
+    for overlap in (False, True):
+        monkeypatch.setattr(tp, "_STEP_OVERLAP", overlap)
+        state = tp.RolloutState(dev)
+        for ds, n_steps, seed in ((ds0, 9, 5), (ds1, 70, 23)):            # the second rollout reuses the first one's state
+            ro = tp.build_rollout(params, net, ds, tp.list_runs(ds, params)[0], dev, state=state, seed=seed)
+            replans = []
+            for _ in range(n_steps):
+                ro.step()
+                replans.append(ro.need_replan)
+            ro.finish()
+            torch.cuda.synchronize()
+        n = int(ro.st.cloud_count.item())
+        with torch.no_grad():
+            o1, o2 = net(ro.st.net_in)
+        got[overlap] = (replans, ro.coverage_evolution(70), ro.camera.X_cam_history.tolist(), ro.st.cloud[:n].clone(),
+                        ro.st.net_in.clone(), o1.clone(), o2.clone())
+        assert (state._overlap is not None) == overlap
+    a, b = got[False], got[True]
+    assert a[0] == b[0], (a[0], b[0])
+    assert any(a[0]) and sum(not r for r in a[0]) >= 10, a[0]        # steps of both kinds in the window
+    assert a[1] == b[1] and a[2] == b[2]
+    for x, y in zip(a[3:], b[3:]):
+        assert torch.equal(x, y)
+
+
 def test_entry_point_json_schema(hip, dataset, tmp_path):
     cfg = {"numGPU": 0, "dataset_path": dataset, "test_scenes": [], "params_name":
            "macarons_default_training_config.json", "model_name": "x.pth", "results_json_name": "out_test_entry.json",
