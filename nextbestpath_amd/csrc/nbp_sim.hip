@@ -373,10 +373,10 @@ struct FaceRec { float a[3], un[3], q[3], tnum, pad[2]; };   // 48 bytes
 // raster_setup_kernel (one thread per face and frame) transforms the face, clips its screen box against the near plane and
 // appends (face id, fine-tile box) to the list of every coarse tile the box touches -- one wave-aggregated atomic per
 // wave and coarse tile; a coarse list has room for every face, so nothing is ever dropped (the reference renders with
-// max_faces_per_bin = 500000, macarons/testers/scene.py:440-446).  raster_tile_kernel: one wave per (fine tile, list
-// segment) scans its segment 64 entries at a time, ray-casts the faces whose box covers the tile and merges its 64 depths
+// max_faces_per_bin = 500000, macarons/testers/scene.py:440-446).  raster_tile_kernel: four waves per (2 x 2 block of fine tiles,
+// list segment) scan the segment once, each wave ray-casts the faces whose box covers its tile and merges its 64 depths
 // into the z-buffer with atomicMin on the float bit pattern (positive floats order like unsigned ints), so a tile with
-// thousands of faces is shared by many waves instead of being one wave's tail.
+// thousands of faces is shared by many waves instead of being one wave's tail (raster_block_body).
 constexpr int COARSE = 8;              // fine tiles per coarse tile side
 constexpr int SEG_DEFAULT = 16384;     // list entries per wave (NBP_RASTER_SEG): with the hit list taken through LDS in pieces a wave can walk a
                                        // whole coarse list, and the empty extra segments of shorter ones cost 1-3 us (4096: 50.3 / 65.1 us for 4 frames of
@@ -480,28 +480,40 @@ __device__ __forceinline__ void raster_setup_body(unsigned bx, unsigned by, unsi
     }
 }
 
-__device__ __forceinline__ void raster_tile_body(unsigned bx, unsigned by, unsigned gx, unsigned gy, const FaceRec* __restrict__ recs, int n_faces, int H, int W,
-                                                         float tanh_fov, float zclip, int tiles_x, int tiles_y, int ctiles_x,
-                                                         int ctiles_y, const int* __restrict__ ccount,
-                                                         const BinEntry* __restrict__ clist, unsigned* __restrict__ zbuf_bits,
-                                                         unsigned long long* __restrict__ zface, int SEG) {
-    __shared__ int hits[HITS];
-    __shared__ __attribute__((aligned(16))) FaceRec sh[64];
+// The ray casts, with the coarse list scanned once per 2 x 2 block of fine tiles (round 5; until then every fine tile of a coarse
+// tile walked the coarse tile's whole list for the entries whose box covers it -- 64 scans of the same list, 40 % of the launch by
+// its own trace).  A workgroup of four waves owns a block of four fine tiles: together they scan the list segment ONCE for the entries
+// whose box touches the block (compacted into LDS, HITS at a time), then each wave takes the block's entries 64 at a time, keeps
+// those covering its own tile, gathers their face records through LDS and ray-casts.  The set of faces a pixel is tested against is
+// the same, and the winner (nearest, lowest face id among equal depths) does not depend on the order: the same image bit for bit.
+constexpr int RB = 2;                  // fine tiles per block side
+__device__ __forceinline__ void raster_block_body(unsigned bx, unsigned by, const FaceRec* __restrict__ recs, int n_faces, int H, int W,
+                                                  float tanh_fov, float zclip, int tiles_x, int tiles_y, int ctiles_x,
+                                                  const int* __restrict__ ccount, const BinEntry* __restrict__ clist,
+                                                  unsigned* __restrict__ zbuf_bits, unsigned long long* __restrict__ zface, int SEG) {
+    __shared__ BinEntry bhits[HITS];
+    __shared__ int nb_sh;
+    __shared__ __attribute__((aligned(16))) FaceRec sh[4][64];
+    __shared__ int shf[4][64];
     const int fr = by;
-    const int ntiles = tiles_x * tiles_y;
-    const int tile = bx % ntiles, seg = bx / ntiles;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int nct = ctiles_x * ctiles_y, ct = (ty / COARSE) * ctiles_x + tx / COARSE;
+    const int blocks_x = (tiles_x + RB - 1) / RB, blocks_y = (tiles_y + RB - 1) / RB;
+    const int nblocks = blocks_x * blocks_y;
+    const int blk = bx % nblocks, seg = bx / nblocks;
+    const int bxx = blk % blocks_x, byy = blk / blocks_x;
+    const int nct = ctiles_x * ((tiles_y + COARSE - 1) / COARSE);
+    const int ct = ((byy * RB) / COARSE) * ctiles_x + (bxx * RB) / COARSE;       // (COARSE is a multiple of RB: a block lies in one coarse tile)
     const int n = ccount[fr * nct + ct];
     const int s0 = seg * SEG;
     if (s0 >= n) return;
     const int s1 = min(n, s0 + SEG);
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const BinEntry* lst = clist + ((size_t)fr * nct + ct) * n_faces;
+    const int btx0 = bxx * RB, btx1 = btx0 + RB - 1, bty0 = byy * RB, bty1 = bty0 + RB - 1;
+    const int tx = btx0 + (wave & 1), ty = bty0 + (wave >> 1);
+    const bool live = tx < tiles_x && ty < tiles_y;                               // (an odd tile count leaves a block half empty)
     const int col = tx * TILE + (lane & 7), row = ty * TILE + (lane >> 3);
     const int s = H < W ? H : W;
-    // pixel-centre ray in view space (PyTorch3D NDC: +X left, +Y up)
     const float ndc_x = ((float)W - (2.f * col + 1.f)) / (float)s;
     const float ndc_y = ((float)H - (2.f * row + 1.f)) / (float)s;
     const float dx = ndc_x * tanh_fov, dy = ndc_y * tanh_fov;   // dz = 1
@@ -509,52 +521,65 @@ __device__ __forceinline__ void raster_tile_body(unsigned bx, unsigned by, unsig
     float zbest = 3.0e38f;
     int fbest = -1;
     const float eps = 1e-6f;
-    // The segment goes through in pieces of HITS entries: the hit list of a piece is 4 KB of LDS instead of 16 KB for
-    // the whole segment, so 20 waves instead of 8 are resident per CU (the kernel is a chain of dependent round trips
-    // -- count, entries, records -- and lives on having many waves in flight).
     for (int c0 = s0; c0 < s1; c0 += HITS) {
         const int c1 = min(s1, c0 + HITS);
-        // pass 1: the faces of this piece whose fine-tile box covers the tile (entry loads are independent: the compiler
-        // keeps several in flight), compacted into LDS
-        int nh = 0;
-        for (int base = c0; base < c1; base += 64) {
+        if (tid == 0) nb_sh = 0;
+        __syncthreads();
+        // pass 1, the four waves together: entries of this piece whose fine-tile box touches the block
+        for (int base = c0; base < c1; base += 256) {
             bool in = false;
-            int face = 0;
-            if (base + lane < c1) {
-                const BinEntry e = lst[base + lane];
-                face = e.face;
-                in = tx >= (int)(e.box & 255u) && tx <= (int)((e.box >> 8) & 255u) && ty >= (int)((e.box >> 16) & 255u) &&
-                     ty <= (int)(e.box >> 24);
+            BinEntry e = {0, 0u};
+            if (base + tid < c1) {
+                e = lst[base + tid];
+                in = btx1 >= (int)(e.box & 255u) && btx0 <= (int)((e.box >> 8) & 255u) && bty1 >= (int)((e.box >> 16) & 255u) &&
+                     bty0 <= (int)(e.box >> 24);
             }
             const unsigned long long bal = __ballot(in);
-            if (in) hits[nh + __popcll(bal & lt)] = face;
-            nh += __popcll(bal);
+            int wbase = 0;
+            if (lane == 0 && bal) wbase = atomicAdd(&nb_sh, __popcll(bal));
+            wbase = __shfl(wbase, 0);
+            if (in) bhits[wbase + __popcll(bal & lt)] = e;
         }
-        // pass 2: 64 face records at a time through LDS (one gather round trip per 64 faces), every lane ray-casts its pixel
-        for (int hb = 0; hb < nh; hb += 64) {
-            const int m = min(64, nh - hb);
-            __syncthreads();
-            if (lane < m) sh[lane] = rb[hits[hb + lane]];
-            __syncthreads();
-            for (int k = 0; k < m; ++k) {
-                const FaceRec& f = sh[k];
-                // det = a . d ; u = (un . d)/det ; v = (q . d)/det ; z = tnum/det with d = (dx, dy, 1): three linear forms and a reciprocal
-                const float det = (f.a[0] * dx + f.a[1] * dy) + f.a[2];
-                if (fabsf(det) < 1e-12f) continue;
-                const float inv = 1.f / det;
-                const float u = ((f.un[0] * dx + f.un[1] * dy) + f.un[2]) * inv;
-                const float vv = ((dx * f.q[0] + dy * f.q[1]) + f.q[2]) * inv;
-                const float z = f.tnum * inv;
-                // equal depths (shared edges): the lowest face id wins, whatever the order of the lists (for the colours)
-                if (u >= -eps && vv >= -eps && u + vv <= 1.f + eps && z > zclip) {
-                    const int fid = hits[hb + k];
-                    if (z < zbest || (z == zbest && fid < fbest)) { zbest = z; fbest = fid; }
+        __syncthreads();
+        const int nb = nb_sh;
+        // pass 2, each wave for its tile: 64 block entries at a time -> those covering the tile -> their records through LDS
+        if (live)
+            for (int hb = 0; hb < nb; hb += 64) {
+                bool in = false;
+                int face = 0;
+                if (hb + lane < nb) {
+                    const BinEntry e = bhits[hb + lane];
+                    face = e.face;
+                    in = tx >= (int)(e.box & 255u) && tx <= (int)((e.box >> 8) & 255u) && ty >= (int)((e.box >> 16) & 255u) &&
+                         ty <= (int)(e.box >> 24);
                 }
+                const unsigned long long bal = __ballot(in);
+                const int m = __popcll(bal);
+                if (in) {
+                    const int k = __popcll(bal & lt);
+                    sh[wave][k] = rb[face];
+                    shf[wave][k] = face;
+                }
+                __builtin_amdgcn_s_waitcnt(0);          // (one wave: its own LDS writes are visible to itself once they have retired)
+                __builtin_amdgcn_wave_barrier();
+                for (int k = 0; k < m; ++k) {
+                    const FaceRec& f = sh[wave][k];
+                    const float det = (f.a[0] * dx + f.a[1] * dy) + f.a[2];
+                    if (fabsf(det) < 1e-12f) continue;
+                    const float inv = 1.f / det;
+                    const float u = ((f.un[0] * dx + f.un[1] * dy) + f.un[2]) * inv;
+                    const float vv = ((dx * f.q[0] + dy * f.q[1]) + f.q[2]) * inv;
+                    const float z = f.tnum * inv;
+                    if (u >= -eps && vv >= -eps && u + vv <= 1.f + eps && z > zclip) {
+                        const int fid = shf[wave][k];
+                        if (z < zbest || (z == zbest && fid < fbest)) { zbest = z; fbest = fid; }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();        // the next 64 overwrite sh[wave]
             }
-        }
-        __syncthreads();                                        // the next piece overwrites hits[]
+        __syncthreads();                                            // the next piece overwrites bhits[]
     }
-    if (row < H && col < W && zbest < 1.0e38f) {
+    if (live && row < H && col < W && zbest < 1.0e38f) {
         const size_t pix = ((size_t)fr * H + row) * W + col;
         if (zface) atomicMin(&zface[pix], ((unsigned long long)__float_as_uint(zbest) << 32) | (unsigned)fbest);
         else atomicMin(&zbuf_bits[pix], __float_as_uint(zbest));
@@ -623,19 +648,19 @@ __global__ __launch_bounds__(256) void raster_setup_batch_kernel(RasterBatch b, 
     raster_setup_body(blockIdx.x, blockIdx.y, a.gx_setup, gridDim.y, a.verts, a.faces, a.n_faces, a.cam, H, W, tanh_fov, zclip, a.recs,
                       ctiles_x, ctiles_y, a.ccount, a.clist, nullptr, a.zface);
 }
-__global__ __launch_bounds__(64) void raster_tile_kernel(const FaceRec* __restrict__ recs, int n_faces, int H, int W, float tanh_fov,
-                                                         float zclip, int tiles_x, int tiles_y, int ctiles_x, int ctiles_y,
-                                                         const int* __restrict__ ccount, const BinEntry* __restrict__ clist,
-                                                         unsigned* __restrict__ zbuf_bits, unsigned long long* __restrict__ zface, int SEG) {
-    raster_tile_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, recs, n_faces, H, W, tanh_fov, zclip, tiles_x, tiles_y, ctiles_x, ctiles_y,
-                     ccount, clist, zbuf_bits, zface, SEG);
+__global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restrict__ recs, int n_faces, int H, int W, float tanh_fov,
+                                                          float zclip, int tiles_x, int tiles_y, int ctiles_x, int ctiles_y,
+                                                          const int* __restrict__ ccount, const BinEntry* __restrict__ clist,
+                                                          unsigned* __restrict__ zbuf_bits, unsigned long long* __restrict__ zface, int SEG) {
+    raster_block_body(blockIdx.x, blockIdx.y, recs, n_faces, H, W, tanh_fov, zclip, tiles_x, tiles_y, ctiles_x, ccount, clist, zbuf_bits, zface,
+                      SEG);
 }
-__global__ __launch_bounds__(64) void raster_tile_batch_kernel(RasterBatch b, int H, int W, float tanh_fov, float zclip, int tiles_x,
-                                                               int tiles_y, int ctiles_x, int ctiles_y, int SEG) {
+__global__ __launch_bounds__(256) void raster_tile_batch_kernel(RasterBatch b, int H, int W, float tanh_fov, float zclip, int tiles_x,
+                                                                int tiles_y, int ctiles_x, int ctiles_y, int SEG) {
     const RasterItem& a = b.it[blockIdx.z];
     if (blockIdx.x >= a.gx_tile) return;
-    raster_tile_body(blockIdx.x, blockIdx.y, a.gx_tile, gridDim.y, a.recs, a.n_faces, H, W, tanh_fov, zclip, tiles_x, tiles_y, ctiles_x,
-                     ctiles_y, a.ccount, a.clist, nullptr, a.zface, SEG);
+    raster_block_body(blockIdx.x, blockIdx.y, a.recs, a.n_faces, H, W, tanh_fov, zclip, tiles_x, tiles_y, ctiles_x, a.ccount, a.clist, nullptr,
+                      a.zface, SEG);
 }
 __global__ __launch_bounds__(256) void raster_shade_kernel(const unsigned long long* __restrict__ zface, const float* __restrict__ verts,
                                                            const int* __restrict__ faces, const float* __restrict__ vcolors, CamSet cams,
@@ -1041,8 +1066,8 @@ static int raster_launch(const float* verts, int n_verts, const int* faces, int 
     }
     constexpr int SEG = SEG_DEFAULT;
     const int nseg = (int)nbp_cdiv(n_faces, SEG);
-    dim3 g2((unsigned)(tiles_x * tiles_y * nseg), (unsigned)n_frames);
-    raster_tile_kernel<<<g2, 64, 0, st>>>(recs, n_faces, H, W, tan_half_fov, z_clip, tiles_x, tiles_y, ctiles_x, ctiles_y,
+    dim3 g2((unsigned)((int)nbp_cdiv(tiles_x, RB) * (int)nbp_cdiv(tiles_y, RB) * nseg), (unsigned)n_frames);
+    raster_tile_kernel<<<g2, 256, 0, st>>>(recs, n_faces, H, W, tan_half_fov, z_clip, tiles_x, tiles_y, ctiles_x, ctiles_y,
                                           ccount, clist, (unsigned*)zbuf, zface, SEG);
     if ((rc = nbp_launch_status())) return rc;
     if (!zface) {
@@ -1180,7 +1205,7 @@ extern "C" int nbp_raster_zface_batch_f32(int n, const float* const* verts, cons
         a.verts = verts[q]; a.faces = faces[q]; a.vcolors = nullptr; a.zbuf = zbuf[q]; a.zface = (unsigned long long*)zface[q];
         a.n_faces = n_faces[q];
         a.gx_setup = r < n ? (unsigned)nbp_cdiv(n_faces[q], 256) : 0;
-        a.gx_tile = r < n ? (unsigned)(tiles_x * tiles_y * (int)nbp_cdiv(n_faces[q], SEG)) : 0;
+        a.gx_tile = r < n ? (unsigned)((int)nbp_cdiv(tiles_x, RB) * (int)nbp_cdiv(tiles_y, RB) * (int)nbp_cdiv(n_faces[q], SEG)) : 0;
         if (a.gx_setup > g_setup) g_setup = a.gx_setup;
         if (a.gx_tile > g_tile) g_tile = a.gx_tile;
         for (int f = 0; f < 4; ++f)
@@ -1194,7 +1219,7 @@ extern "C" int nbp_raster_zface_batch_f32(int n, const float* const* verts, cons
     if (rc) return rc;
     raster_setup_batch_kernel<<<dim3(g_setup, (unsigned)n_frames, (unsigned)n), 256, 0, st>>>(b, H, W, tan_half_fov, z_clip, ctiles_x, ctiles_y);
     if ((rc = nbp_launch_status())) return rc;
-    raster_tile_batch_kernel<<<dim3(g_tile, (unsigned)n_frames, (unsigned)n), 64, 0, st>>>(b, H, W, tan_half_fov, z_clip, tiles_x, tiles_y,
+    raster_tile_batch_kernel<<<dim3(g_tile, (unsigned)n_frames, (unsigned)n), 256, 0, st>>>(b, H, W, tan_half_fov, z_clip, tiles_x, tiles_y,
                                                                                           ctiles_x, ctiles_y, SEG);
     if ((rc = nbp_launch_status())) return rc;
     raster_depth_batch_kernel<<<dim3((unsigned)nbp_cdiv((long long)H * W, 256), (unsigned)n_frames, (unsigned)n), 256, 0, st>>>(b, H, W,
