@@ -824,6 +824,9 @@ def main():
         stage["group_streams"] = multi.stream_check          # the lock-step's streams were verified to run side by side
         if single is not None:
             stage["single_rollout_steps_per_s"] = round(single, 2)
+            stage["single_rollout_note"] = ("Rollout.step: every step's forward runs (hipGraph replay) on a stream of its own; a step "
+                                            "that does not replan does not wait for it (NBP_STEP_OVERLAP=" +
+                                            ("1" if tp._STEP_OVERLAP else "0") + ")")
         stage["windows"] = windows
         stage["raster_spilled_tiles"] = int(sum(int(r.camera._overflow.item()) for r in rollouts))
 
