@@ -41,12 +41,6 @@ int nbp_device_info(char* arch_host, int arch_len, int* cu_count_host);
  * switches read so far whose value differs from the default into buf_host (truncated to len - 1) and returns their number. */
 int nbp_tuning_active(void);
 int nbp_tuning_report(char* buf_host, int len);
-
-/* A stream whose kernels run only on the compute units of mask_words_host (n_words x 32 bits, bit k = CU k of the driver's numbering;
- * hipExtStreamCreateWithCUMask).  No counterpart in the reference (its rollouts run on torch's default stream); used by
- * testers/nbp_planning.py::MultiRollout to confine the step's latency-bound kernels to a few CUs (NBP_SMALL_CUS). */
-int nbp_stream_create_cu_mask(const unsigned* mask_words_host, int n_words, void** stream_out);
-int nbp_stream_destroy(void* stream);
 /* Kernel symbol (as a profiler demangles it, without "void" / the anonymous namespace / the argument list) that convolution tile
  * id `tile` (nbp_layer_timing.tile) was most recently launched as in this process; returns its length, 0 if that tile id has not
  * been launched yet.  The launchers build the text from their own template arguments. */

@@ -21,8 +21,6 @@ SIGNATURES = {
     "nbp_device_info": (_i, [C.c_char_p, _i, C.POINTER(_i)]),
     "nbp_tuning_active": (_i, []),
     "nbp_tuning_report": (_i, [C.c_char_p, _i]),
-    "nbp_stream_create_cu_mask": (_i, [C.POINTER(C.c_uint), _i, C.POINTER(C.c_void_p)]),
-    "nbp_stream_destroy": (_i, [_vp]),
     "nbp_tile_kernel_symbol": (_i, [_i, C.c_char_p, _i]),
     "nbp_packed_weights_bytes": (_sz, []),
     "nbp_pack_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, _sz, _vp, C.POINTER(_vp)]),

@@ -8,7 +8,6 @@
 #include <string.h>
 #include <stdio.h>
 #include <mutex>
-#include <hip/hip_runtime.h>
 #include "nbp_hip.h"
 
 namespace {
@@ -89,16 +88,3 @@ extern "C" int nbp_tuning_report(char* buf_host, int len) {
     }
     return n;
 }
-
-// A HIP stream whose kernels are dispatched only to the compute units named in mask_words (hipExtStreamCreateWithCUMask: bit k of
-// word k / 32 = CU k in the driver's numbering; tools/probes/cu_mask_probe.hip prints how that numbering maps to XCDs).  For the
-// lock-step's experiment of confining the step's small kernels to a few CUs (testers/nbp_planning.py: NBP_SMALL_CUS).
-extern "C" int nbp_stream_create_cu_mask(const unsigned* mask_words_host, int n_words, void** stream_out) {
-    if (!mask_words_host || n_words < 1 || !stream_out) return NBP_E_ARG;
-    hipStream_t st = nullptr;
-    const hipError_t e = hipExtStreamCreateWithCUMask(&st, (unsigned)n_words, mask_words_host);
-    if (e != hipSuccess) return (int)e;
-    *stream_out = (void*)st;
-    return 0;
-}
-extern "C" int nbp_stream_destroy(void* stream) { return stream ? (int)hipStreamDestroy((hipStream_t)stream) : 0; }
