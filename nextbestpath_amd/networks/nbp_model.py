@@ -146,7 +146,10 @@ class NBP(nn.Module):
         g = self._graphs.pop(key, None)
         if g is None:
             while len(self._graphs) >= _MAX_GRAPHS:
-                self._graphs.pop(next(iter(self._graphs)))         # least recently used first (dicts keep insertion order)
+                # least recently used first (dicts keep insertion order).  A replay of it may still be running on a stream the
+                # caller is not on (Rollout.step replays on side streams): wait before its buffers and executable go (rare).
+                torch.cuda.synchronize(x.device)
+                self._graphs.pop(next(iter(self._graphs)))
             g = packing.ForwardGraph(packed, x)
         self._graphs[key] = g                                      # (re-inserted: most recently used last)
         return g()

@@ -314,7 +314,8 @@ def _prepack_run(net, dev):
     key = (str(dev),) + tuple(w.data_ptr() for w, *_ in layers)
     tab = _PRE_CACHE.get(key)
     if tab is None:
-        _PRE_CACHE.clear()                             # (one network at a time: the buffers are 2 x the weights)
+        while len(_PRE_CACHE) >= 2:                    # (two networks at most -- e.g. a trained and a frozen copy: the buffers are
+            _PRE_CACHE.pop(next(iter(_PRE_CACHE)))     #  2 x the weights each; the least recently built one goes)
         assert L.nbp_prepack_desc_bytes() == 48
         n = len(layers)
         wamax = torch.zeros(n, dtype=torch.int32, device=dev)
