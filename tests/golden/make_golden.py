@@ -124,6 +124,66 @@ def gen_training(model, B=2, S=32, K=7, tag="S32B2"):
     print(f"train {tag}: loss", float(loss), "|grad Conv1|", float(named[keys[0]].grad.abs().max()))
 
 
+def _sample(t, cap=4096):
+    """At most `cap` strided entries of a tensor + (stride, sum, sum |.|, max |.|) of ALL its entries, in float64."""
+    f = t.detach().double().flatten()
+    stride = max(1, (f.numel() + cap - 1) // cap)
+    return f[::stride].numpy(), np.array([stride, float(f.sum()), float(f.abs().sum()), float(f.abs().max())])
+
+
+def gen_blocks(model):
+    """Forward + backward of the reference's block classes (conv_block :8-21, up_conv :23-34, Attention_block :36-62) in train mode on
+    the seeded cases of nextbestpath_amd/utility/synthetic.py::BLOCK_CASES -- evaluated in float64 (the module cast with .double():
+    the reference's own code path, rounding removed) and in float32 (its distance to the float64 run is recorded per tensor, for
+    context).  Stored per case and tensor: <= 4096 strided samples + sums; inputs and parameters are regenerated from the seed by the
+    consumer and pinned here by their sums."""
+    from nextbestpath_amd.utility.synthetic import BLOCK_CASES, make_block_case
+    torch.set_num_threads(8)
+    out = {"tags": np.array([r[0] for r in BLOCK_CASES])}
+    for row in BLOCK_CASES:
+        tag = row[0]
+        kind, cin, cout, sd, inputs, dy = make_block_case(tag)
+        res = {}
+        for dt in (torch.float64, torch.float32):
+            blk = {"conv_block": lambda: model.conv_block(sum(cin), cout), "up_conv": lambda: model.up_conv(cin[0], cout),
+                   "attention": lambda: model.Attention_block(cin[0], cin[1], cout)}[kind]()
+            blk.load_state_dict(sd, strict=True)
+            blk = blk.to(dt).train()
+            xs = [x.to(dt).clone().requires_grad_(True) for x in inputs]
+            if kind == "conv_block":
+                xin = torch.cat(xs, 1) if len(xs) > 1 else xs[0]
+                y = blk(xin)
+            elif kind == "up_conv":
+                y = blk(xs[0])
+            else:
+                y = blk(xs[0], xs[1])          # (g, x)
+            y.backward(dy.to(dt))
+            r = {"y": y.detach()}
+            for i, x in enumerate(xs):
+                r[f"dx{i}"] = x.grad
+            for k, p_ in blk.named_parameters():
+                r["d__" + k.replace(".", "__")] = p_.grad
+            for k, b_ in blk.named_buffers():
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    r["buf__" + k.replace(".", "__")] = b_.detach()
+            res[dt] = r
+        r64, r32 = res[torch.float64], res[torch.float32]
+        worst = 0.0
+        for k, v in r64.items():
+            smp, st = _sample(v)
+            out[f"{tag}__{k}"] = smp
+            out[f"{tag}__{k}__stats"] = st
+            e32 = float((r32[k].double() - v).abs().max()) / max(float(v.abs().max()), 1e-30)
+            out[f"{tag}__{k}__fp32_err"] = np.array(e32)
+            worst = max(worst, e32)
+        # the ReLUs really are open (the premise of the 1e-5 comparison): smallest pre-activation margin is recorded by the consumer's
+        # own check; here the inputs / parameters are pinned
+        out[f"{tag}__pin"] = np.array([float(sum(x.double().sum() for x in inputs)), float(dy.double().sum()),
+                                       float(sum(v.double().sum() for v in sd.values() if v.is_floating_point()))])
+        print(f"block {tag}: {kind} {cin}->{cout}: {len(r64)} tensors, worst torch-fp32 distance to fp64 {worst:.2e} of the tensor's max")
+    np.savez_compressed(os.path.join(HERE, "nbp_blocks_bwd.npz"), **out)
+
+
 def gen_maps(utils):
     rng = np.random.default_rng(21)
     dev = torch.device("cpu")
@@ -512,6 +572,9 @@ if __name__ == "__main__":
     if "--only-scene" in sys.argv:
         gen_scene(mu)
         sys.exit(0)
+    if "--only-blocks" in sys.argv:
+        gen_blocks(model)
+        sys.exit(0)
     if "--only-train-large" in sys.argv:
         gen_training(model, B=4, S=128, K=40, tag="S128B4")
         sys.exit(0)
@@ -524,3 +587,4 @@ if __name__ == "__main__":
     gen_network(model)
     gen_training(model)
     gen_training(model, B=4, S=128, K=40, tag="S128B4")
+    gen_blocks(model)
