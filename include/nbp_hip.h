@@ -492,6 +492,19 @@ int nbp_axis_ray_counts_f32(const float* verts, const int* faces, int n_faces, c
  * (third-party rasterisation); oracle/slice_raster.py restates THIS definition bit for bit. */
 int nbp_slice_obstacle_f32(const float* verts, const int* faces, int n_faces, float y0, float cx, float cz,
                            int S, float lo, float hi, float half_width_px, float* out, void* stream);
+/* The same label on the REFERENCE's pixel grid (round 6; pinned by tests/golden/obstacle_label.npz, which the reference's own
+ * draw -> PNG -> resize -> threshold stage produced from this library's mesh / plane segments).  utils.py:232-258 draws into the
+ * axes of a 2.56 in x 2.56 in figure at 100 dpi (default subplot box 198.4 x 197.12 px), x limits +-view/2 around the camera and
+ * the y limits shrunk to keep the aspect (adjustable='datalim': 79.48 units for 80), saves the axes box ('tight' includes it:
+ * 198 x 197 px), resizes to S x S and flips left-right.  So a world point lands on u = ((cx - x) + half_u) scale_u,
+ * v = ((cz - z) + half_v) scale_v with scale_u = 2.48 * 256 / 198, scale_v = 2.48 * 256 / 197 px per unit at S = 256, and a
+ * 1.5 pt stroke with projecting caps is half_width_px = cap_px = 1.347 px there (nextbestpath_amd/utility/hipops.py::
+ * reference_figure_geometry).  cap_px = 0: round stroke ends, as nbp_slice_obstacle_f32.  What stays unpinned is Agg's
+ * anti-aliasing and PIL's Lanczos filter themselves: the labels agree with the reference's to within one pixel of line position
+ * (tests/test_training_data_cpu.py), not pixel for pixel. */
+int nbp_slice_obstacle_fig_f32(const float* verts, const int* faces, int n_faces, float y0, float cx, float cz,
+                               int S, float half_u, float scale_u, float half_v, float scale_v, float half_width_px,
+                               float cap_px, float* out, void* stream);
 /* Depth-map space carving of proxy points (A20): Camera.get_points_in_fov (mu:2849-2884) +
  * get_signed_distance_to_depth_maps (mu:2900-2949) + Scene.update_proxy_supervision_occ /
  * update_proxy_out_of_field (mu:3329-3363) fused per point.  For each proxy point inside the frustum

@@ -183,6 +183,7 @@ SIGNATURES["nbp_shade_image_f32"] = (_i, [_vp, _vp, _vp, _vp, _fpp, _i, _i, _i, 
 SIGNATURES["nbp_unproject_append_shaded_f32"] = (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _fpp, _i, _i, _i, _f, _f, _d, C.c_uint, _f,
                                                       _vp, _vp, _vp, _vp, _ll, _vp, _sz, _vp])
 SIGNATURES["nbp_slice_obstacle_f32"] = (_i, [_vp, _vp, _i, _f, _f, _f, _i, _f, _f, _f, _vp, _vp])
+SIGNATURES["nbp_slice_obstacle_fig_f32"] = (_i, [_vp, _vp, _i, _f, _f, _f, _i, _f, _f, _f, _f, _f, _f, _vp, _vp])
 
 _lock = threading.Lock()
 _lib = None

@@ -1395,9 +1395,13 @@ extern "C" unsigned nbp_perm_index_host(unsigned j, unsigned n, unsigned seed) {
 // half_width pixels of it.  Image axes as in the reference after its left-right flip: column grows with
 // -(x - cx), row with -(z - cz), the window is [lo, hi] around the camera (pixel AREAS, i.e. centres at +0.5).
 namespace {
+// Pixel coordinates of a world point: u = ((cx - x) + hu) su, v = ((cz - z) + hv) sv.  cap: how far a segment's stroke extends
+// beyond its end points along its direction (0: the round "within half_width of the segment" stroke; > 0: a rectangle with
+// matplotlib's default projecting caps).
 __global__ __launch_bounds__(256) void slice_obstacle_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
-                                                             int F, float y0, float cx, float cz, int S, float hi,
-                                                             float scale, float half_width, float* __restrict__ out) {
+                                                             int F, float y0, float cx, float cz, int S, float hu, float su_,
+                                                             float hv, float sv_, float half_width, float cap,
+                                                             float* __restrict__ out) {
     const int f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (f >= F) return;
@@ -1416,14 +1420,14 @@ __global__ __launch_bounds__(256) void slice_obstacle_kernel(const float* __rest
             const float t = py[k] / (py[k] - py[q]);
             const float x = px[k] + t * (px[q] - px[k]);
             const float z = pz[k] + t * (pz[q] - pz[k]);
-            if (n < 2) { su[n] = ((cx - x) + hi) * scale; sv[n] = ((cz - z) + hi) * scale; }
+            if (n < 2) { su[n] = ((cx - x) + hu) * su_; sv[n] = ((cz - z) + hv) * sv_; }
             ++n;
         }
     }
     if (n != 2) return;
     const float wu = su[1] - su[0], wv = sv[1] - sv[0];
     const float L2 = wu * wu + wv * wv;
-    const float pad = half_width + 1.0f;
+    const float pad = fmaxf(half_width, cap) + 1.0f;
     const int c0 = max(0, (int)floorf(fminf(su[0], su[1]) - pad)), c1 = min(S - 1, (int)ceilf(fmaxf(su[0], su[1]) + pad));
     const int r0 = max(0, (int)floorf(fminf(sv[0], sv[1]) - pad)), r1 = min(S - 1, (int)ceilf(fmaxf(sv[0], sv[1]) + pad));
     if (c1 < c0 || r1 < r0) return;
@@ -1432,6 +1436,13 @@ __global__ __launch_bounds__(256) void slice_obstacle_kernel(const float* __rest
     for (int i = lane; i < total; i += 64) {
         const int r = r0 + i / wbox, c = c0 + i % wbox;
         const float qu = ((float)c + 0.5f) - su[0], qv = ((float)r + 0.5f) - sv[0];
+        if (cap > 0.f) {                 // rectangle: |normal distance| <= half_width, along-distance in [-cap, L + cap]
+            if (!(L2 > 0.f)) continue;
+            const float L = sqrtf(L2);
+            const float ta = (qu * wu + qv * wv) / L, tn = fabsf(qv * wu - qu * wv) / L;
+            if (ta >= -cap && ta <= L + cap && tn <= half_width) out[r * S + c] = 1.0f;
+            continue;
+        }
         float t = 0.f;
         if (L2 > 0.f) t = fminf(fmaxf((qu * wu + qv * wv) / L2, 0.f), 1.f);
         const float du = qu - t * wu, dv = qv - t * wv;
@@ -1449,6 +1460,21 @@ extern "C" int nbp_slice_obstacle_f32(const float* verts, const int* faces, int 
     if (e != hipSuccess) return (int)e;
     const float scale = (float)((double)S / ((double)hi - (double)lo));
     slice_obstacle_kernel<<<(unsigned)nbp_cdiv((long long)n_faces * 64, 256), 256, 0, st>>>(verts, faces, n_faces, y0, cx, cz,
-                                                                                          S, hi, scale, half_width_px, out);
+                                                                                          S, hi, scale, hi, scale, half_width_px, 0.f, out);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_slice_obstacle_fig_f32(const float* verts, const int* faces, int n_faces, float y0, float cx, float cz,
+                                          int S, float half_u, float scale_u, float half_v, float scale_v, float half_width_px,
+                                          float cap_px, float* out, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!verts || !faces || !out || n_faces < 1 || S < 1 || !(scale_u > 0.f) || !(scale_v > 0.f) || !(half_width_px > 0.f) ||
+                  !(cap_px >= 0.f), NBP_E_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)S * S * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    slice_obstacle_kernel<<<(unsigned)nbp_cdiv((long long)n_faces * 64, 256), 256, 0, st>>>(verts, faces, n_faces, y0, cx, cz,
+                                                                                          S, half_u, scale_u, half_v, scale_v,
+                                                                                          half_width_px, cap_px, out);
     return nbp_launch_status();
 }

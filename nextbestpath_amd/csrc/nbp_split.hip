@@ -147,14 +147,9 @@ __device__ unsigned nbp_dbg_n;
 // which sets its halo gather (the parity plane, read straight from dout: + py W + px pixels) and the origin of its 2 x 2 taps
 // (1 - py, 1 - px); the filter-row flip r' = 1 - r is baked into the packed planes (pack_upconv_dgrad_h2_kernel).  One workgroup per
 // low-resolution tile, plain output (no parity scatter, no 2 x 2 sum pass).  a.H / a.W = the low-resolution output, a.Hs / a.Ws = dout.
-// WR: weight stages resident in LDS (a ring).  2 = double buffer (the stage after the current one streams in behind its MFMAs:
-// launches that fill the chip, where a CU's other workgroup covers the wait).  4 = three stages ahead, for launches of at most one
-// workgroup per CU (a single rollout's forward): there a stage is ~0.5 us of MFMAs and its weights come from HBM / the fabric in
-// 1-2 us, so with one stage of prefetch every stage waits for its weights (round 6).
-template <int TW, int TM, int TN, bool PH, bool BS = false, bool P2 = false, bool DG = false, int WR = 2>
+template <int TW, int TM, int TN, bool PH, bool BS = false, bool P2 = false, bool DG = false>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_h2_kernel(SplitArgs a) {
     static_assert(!P2 || PH, "two-parity form: up_conv layers");
-    static_assert(WR == 2 || (WR == 4 && !BS && !P2 && !DG), "weight ring: double buffer, or three stages ahead (eval, small launches)");
     static_assert(!DG || (PH && !BS && !P2), "data gradient of an up_conv layer: the one-parity tap structure");
     constexpr bool PHO = PH && !DG;                            // the launch writes one output parity of the full-resolution image
     int zs = blockIdx.z;
@@ -283,7 +278,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // q = (tap in row * 4 + plane * 2 + k half) * NB + 64-row block; packed planes are [chunk][tap][plane][k half][N][8 fp16]
     auto issue_w = [&](int u) {
         const int c = u / ROWS, row = u - ROWS * c;
-        char* dst = wbuf + (u & (WR - 1)) * WB;
+        char* dst = wbuf + (u & 1) * WB;
         // PH: the four parities' planes follow each other, each [chunk][4 taps][plane][k half][N][8]
 #pragma unroll
         for (int pq = 0; pq < NPAR; ++pq) {
@@ -317,13 +312,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
     const int c_begin = zs * a.chunks_per_split;
     const int c_end = min(c_begin + a.chunks_per_split, a.chunks_total);
-    const int u_end = c_end * ROWS;
-    constexpr int WIW = NPAR * WI / 4;                         // weight DMA instructions per wave and stage
     if (c_begin < c_end) {
         load_halo(c_begin);
-#pragma unroll
-        for (int k = 0; k < WR - 1; ++k)
-            if (c_begin * ROWS + k < u_end) issue_w(c_begin * ROWS + k);
+        issue_w(c_begin * ROWS);
         store_halo();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -336,9 +327,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int row = 0; row < ROWS; ++row) {
             const int u = c * ROWS + row;
             NBP_TS(1);
-            const bool ahead = u + WR - 1 < u_end;
-            if (ahead) issue_w(u + WR - 1);
-            const char* Bt = wbuf + (u & (WR - 1)) * WB + brow;
+            if (row < ROWS - 1 || more) issue_w(u + 1);
+            const char* Bt = wbuf + (u & 1) * WB + brow;
             if constexpr (P2) {
                 // halo column 0: (px 0, tap 0); column 1: (px 0, tap 1) and (px 1, tap 0); column 2: (px 1, tap 1)
                 constexpr int PX[3] = {1, 0, 0};
@@ -401,17 +391,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
             }
             NBP_TS(2);
-            // stage u + 1's weights must have landed.  WR = 4: they were issued two stages ago; younger than them are the DMAs of
-            // stages u + 2 and u + 3 and -- unless this is a chunk's last row of three, whose halo loads went out before them -- the
-            // next chunk's NF halo loads, which may all stay in flight (the counter retires in order)
-            if constexpr (WR == 2) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                static_assert(WR - 1 >= ROWS, "a stage with weights ahead is never in the last chunk");
-                if (!ahead) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (ROWS == 3 && row == ROWS - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WR - 2) * WIW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WR - 2) * WIW + NF) : "memory");
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             NBP_TS(3);
             __syncthreads();
             NBP_TS(4);
@@ -1539,21 +1519,20 @@ int split_tile_width(int H, int W, int N, int ksize) {
     return 0;
 }
 
-template <int TW, int TM, int TN, bool PH, bool BS = false, bool P2 = false, bool DG = false, int WR = 2>
+template <int TW, int TM, int TN, bool PH, bool BS = false, bool P2 = false, bool DG = false>
 int launch_h2(const SplitArgs& a, hipStream_t st, int tile) {
     {
         char nm[96];
-        snprintf(nm, sizeof(nm), WR == 2 ? "conv3x3_halo_h2_kernel<%d, %d, %d, %s, %s, %s, %s>" : "conv3x3_halo_h2_kernel<%d, %d, %d, %s, %s, %s, %s, %d>",
-                 TW, TM, TN, PH ? "true" : "false", BS ? "true" : "false", P2 ? "true" : "false", DG ? "true" : "false", WR);
+        snprintf(nm, sizeof(nm), "conv3x3_halo_h2_kernel<%d, %d, %d, %s, %s, %s, %s>", TW, TM, TN, PH ? "true" : "false", BS ? "true" : "false",
+                 P2 ? "true" : "false", DG ? "true" : "false");
         nbp_note_kernel_symbol(tile, nm);
     }
     constexpr int TH = 4 * TM * (32 / TW);
     constexpr int HPIX = (TH + 2) * (TW + 2), RS = (HPIX + 7) / 8 * 8 * 16 + 64, NB = TN / 2;
-    constexpr size_t smem = 4 * (size_t)RS + WR * (size_t)(PH ? 8 : 12) * NB * 1024 * (P2 ? 2 : 1);
-    static_assert(smem <= 160 * 1024, "LDS");
+    constexpr size_t smem = 4 * (size_t)RS + 2 * (size_t)(PH ? 8 : 12) * NB * 1024 * (P2 ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS, P2, DG, WR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS, P2, DG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -1561,7 +1540,7 @@ int launch_h2(const SplitArgs& a, hipStream_t st, int tile) {
     // PH: tiles of the low-resolution image, four parities in blockIdx.z (fastest); DG: a.M counts the low-resolution output itself
     constexpr bool PHO = PH && !DG;
     dim3 grid((unsigned)(a.M / (PHO ? 4 : 1) / (TH * TW)), (unsigned)(a.N / (TN * 32)), (unsigned)(a.split_k * a.groups * (PHO ? (P2 ? 2 : 4) : 1)));
-    conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS, P2, DG, WR><<<grid, 256, smem, st>>>(a);
+    conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS, P2, DG><<<grid, 256, smem, st>>>(a);
     return nbp_launch_status();
 }
 
@@ -1772,14 +1751,7 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     // up_conv layers on full-height 32-pixel-wide tiles: both column parities in one workgroup of half the height (same workgroup
     // count, one staged halo for two parities).  The 16-pixel-wide levels keep one parity per workgroup (the two-parity form measured
     // 7 % slower per launch there: 619 against 577 us at B = 24); round 3's one-parity 16 x 32 form (120 B of scratch per lane) is gone.
-    // launches of at most one workgroup per CU (8-row tiles: a single rollout's forward) keep three weight stages in flight
-    // (the ring costs LDS: 70 KB per workgroup on the 32-pixel-wide tiles -- still two per CU -- and 110 KB on the 16-pixel-wide ones)
-    static const int deep_max = nbp_tune_int("NBP_SPLIT_DEEP_RING_BLOCKS", 256);
-    const long long wgs = (a.M / (ph ? 4 : 1) / (th * tw)) * (N / ((tw == 32 && !wide) ? 64 : 128)) * p.split_k * groups * (ph ? 4 : 1);
-    const bool deep = r8 && wgs <= (long long)deep_max * (tw == 32 ? 2 : 1);
     int rc = (ph && !r8 && tw == 32) ? launch_h2<32, 2, 2, true, false, true>(a, st, p.tile)
-           : deep ? (ph ? (tw == 32 ? launch_h2<32, 2, 2, true, false, false, false, 4>(a, st, p.tile) : launch_h2<16, 1, 4, true, false, false, false, 4>(a, st, p.tile))
-                        : (tw == 32 ? launch_h2<32, 2, 2, false, false, false, false, 4>(a, st, p.tile) : launch_h2<16, 1, 4, false, false, false, false, 4>(a, st, p.tile)))
            : r8 ? (ph ? (tw == 32 ? launch_h2<32, 2, 2, true>(a, st, p.tile) : launch_h2<16, 1, 4, true>(a, st, p.tile))
                       : (tw == 32 ? launch_h2<32, 2, 2, false>(a, st, p.tile) : launch_h2<16, 1, 4, false>(a, st, p.tile)))
            : ph ? launch_h2<16, 2, 4, true>(a, st, p.tile)

@@ -186,6 +186,33 @@ def slice_obstacle(verts, faces, y0, cx, cz, S=256, grid_range=(-40, 40), half_w
     return out
 
 
+def reference_figure_geometry(S=256, view_size=80.0):
+    """(half_u, scale_u, half_v, scale_v, half_width_px, cap_px) of the reference's label image (utils.py:232-258): a 2.56 in figure
+    at 100 dpi whose default axes box is 0.775 x 0.77 of it (198.4 x 197.12 px), x limits view_size wide, y limits shrunk to the box's
+    aspect, the box saved as 198 x 197 px ('tight' bbox, pad 0), resized to S x S, flipped left-right; lines 1.5 pt wide with
+    projecting caps.  Pinned by tests/golden/obstacle_label.npz."""
+    fig = 2.56 * 100.0
+    ax_w, ax_h = 0.775 * fig, 0.77 * fig                   # matplotlib's default subplot box: left .125 right .9 bottom .11 top .88
+    png_w, png_h = int(ax_w), int(ax_h)                    # the saved crop
+    px_per_unit = ax_w / view_size                         # equal aspect: the same on both axes before the resize
+    scale_u, scale_v = px_per_unit * S / png_w, px_per_unit * S / png_h
+    centre_u = S - (ax_w / 2.0) * S / png_w                # after the left-right flip
+    centre_v = (png_h - ax_h / 2.0) * S / png_h            # rows count from the top of the 197-px crop
+    half_width = 0.5 * (1.5 * 100.0 / 72.0) * 0.5 * (S / png_w + S / png_h)
+    return centre_u / scale_u, scale_u, centre_v / scale_v, scale_v, half_width, half_width
+
+
+def slice_obstacle_fig(verts, faces, y0, cx, cz, S=256, view_size=80.0, out=None):
+    """The GT obstacle label on the reference's own pixel grid (nbp_slice_obstacle_fig_f32)."""
+    if out is None:
+        out = torch.empty(S, S, dtype=torch.float32, device=verts.device)
+    hu, su, hv, sv, hw, cap = reference_figure_geometry(S, view_size)
+    rc = _lib.lib().nbp_slice_obstacle_fig_f32(_lib.ptr(verts), _lib.ptr(faces), faces.shape[0], float(y0), float(cx), float(cz),
+                                               S, hu, su, hv, sv, hw, cap, _lib.ptr(out), _st())
+    _lib.check(rc, "nbp_slice_obstacle_fig_f32")
+    return out
+
+
 def fuse_obstacle(out2, maps6, traj, threshold=0.13):
     S = maps6.shape[-1]
     obst = torch.empty(S, S, dtype=torch.float32, device=maps6.device)

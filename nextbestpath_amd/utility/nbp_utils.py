@@ -233,9 +233,14 @@ def read_combined_data(env, sample_m=2304 * 2, sample_size=2176 * 2):
 
 
 # ------------------------------------------------------------------ GT obstacle label
-def get_binary_obstacle_array(mesh, camera_pose, view_size=80, grid_size=256):
-    """ref utils.py:226-262 -> [S,S] fp32 {0,1} on the device (nbp_slice_obstacle_f32)."""
+def get_binary_obstacle_array(mesh, camera_pose, view_size=80, grid_size=256, reference_label_semantics=True):
+    """ref utils.py:226-262 -> [S,S] fp32 {0,1} on the device.  reference_label_semantics (default): the label sits on the pixel
+    grid of the reference's matplotlib figure -- 80 units across the columns, 79.48 across the rows, 2.7-px strokes with projecting
+    caps (hipops.reference_figure_geometry; pinned by tests/golden/obstacle_label.npz to within one pixel of line position).  False:
+    the isotropic +-view_size/2 window at 1.04-px round strokes of rounds 1-5 (nbp_slice_obstacle_f32)."""
     x, y, z = (float(v) for v in list(camera_pose)[:3])
+    if reference_label_semantics:
+        return hipops.slice_obstacle_fig(mesh.verts, mesh.faces, y, x, z, grid_size, float(view_size))
     return hipops.slice_obstacle(mesh.verts, mesh.faces, y, x, z, grid_size, (-view_size / 2, view_size / 2))
 
 

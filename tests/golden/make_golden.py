@@ -184,6 +184,127 @@ def gen_blocks(model):
     np.savez_compressed(os.path.join(HERE, "nbp_blocks_bwd.npz"), **out)
 
 
+def label_scene():
+    """A small walled room with an inner wall, a box and a rotated box (oblique segments), y up, 3 units high: [V,3] f32, [F,3] i64."""
+    v, f = [], []
+
+    def wall(a, b, h=3.0):
+        i = len(v)
+        v.extend([[a[0], 0, a[1]], [b[0], 0, b[1]], [b[0], h, b[1]], [a[0], h, a[1]]])
+        f.extend([[i, i + 1, i + 2], [i, i + 2, i + 3]])
+
+    def loop(pts):
+        for k in range(len(pts)):
+            wall(pts[k], pts[(k + 1) % len(pts)])
+    loop([(-20, -10), (25, -10), (25, 30), (-20, 30)])
+    loop([(0, 0), (5, 0), (5, 12), (0, 12)])
+    wall((-20, 8), (-6, 8))
+    c, s_ = np.cos(0.5), np.sin(0.5)
+    loop([(12 + c * a - s_ * b, 18 + s_ * a + c * b) for a, b in [(-6, -3), (6, -3), (6, 3), (-6, 3)]])
+    loop([(-12 + 4 * np.cos(t), 20 + 4 * np.sin(t)) for t in np.linspace(0, 2 * np.pi, 12, endpoint=False)])
+    return np.asarray(v, np.float32), np.asarray(f, np.int64)
+
+
+def gen_obstacle_label(utils):
+    """get_binary_obstacle_array (next_best_path/utility/utils.py:226-262) RUN AS IT IS -- matplotlib figure, PNG, PIL resize,
+    flip, threshold -- with trimesh (absent) as the one stub: mesh_plane returns the segments of oracle/slice_raster.py::
+    plane_segments, load_path a path of one two-point entity per segment.  Pillow >= 10 dropped Image.ANTIALIAS (an alias of
+    LANCZOS): restored for the call.  Stored: the scene, the poses, the labels (bit-packed)."""
+    from PIL import Image
+    from oracle.slice_raster import plane_segments
+    if not hasattr(Image, "ANTIALIAS"):
+        Image.ANTIALIAS = Image.LANCZOS
+    verts, faces = label_scene()
+    poses = np.array([[3.0, 1.5, 4.0, 0, 0], [-30.0, 1.5, 10.0, 0, 0], [10.0, 0.7, -20.0, 0, 0], [40.0, 2.2, 45.0, 0, 0],
+                      [-9.3, 1.1, 21.7, 0, 0]], np.float32)
+    labels = []
+    for pose in poses:
+        segs = plane_segments(verts, faces, pose[1]).astype(np.float64)
+        path = types.SimpleNamespace(vertices=segs.reshape(-1, 3),
+                                     entities=[types.SimpleNamespace(points=np.array([2 * i, 2 * i + 1])) for i in range(len(segs))])
+        utils.trimesh = types.SimpleNamespace(intersections=types.SimpleNamespace(mesh_plane=lambda mesh, n, o, _s=segs: _s),
+                                              load_path=lambda inter, _p=path: _p)
+        lab = utils.get_binary_obstacle_array(None, torch.from_numpy(pose))
+        assert lab.shape == (256, 256) and set(np.unique(lab)) <= {0, 1}
+        labels.append(np.packbits(lab.astype(np.uint8), axis=None))
+        print("obstacle label", pose[:3], "segments", len(segs), "pixels", int(lab.sum()))
+    import matplotlib, PIL
+    np.savez_compressed(os.path.join(HERE, "obstacle_label.npz"), verts=verts, faces=faces, poses=poses, labels=np.stack(labels),
+                        versions=np.array([matplotlib.__version__, PIL.__version__]))
+
+
+def gen_carve(mu):
+    """Depth-map space carving through the REFERENCE's own code: Camera.get_points_in_fov (macarons_utils.py:
+    2849-2884), Camera.get_signed_distance_to_depth_maps (:2900-2949: mask fill, NDC -> grid scaling, F.grid_sample bilinear /
+    border / align_corners=False, the subtraction) and Scene.update_proxy_out_of_field / update_proxy_supervision_occ (:3329-3363).
+    The one stub is the PyTorch3D camera object: its two transforms return the view-space points and NDC projections that
+    oracle/camera.py's restatement of the library's conventions computes (fp32, R / T from its look_at) -- so what this fixture pins
+    is everything DOWNSTREAM of the projection; the projection itself stays parity-unpinned (package absent)."""
+    from oracle import camera as ocam
+    H, W = 64, 114
+    renderer = types.SimpleNamespace(rasterizer=types.SimpleNamespace(raster_settings=types.SimpleNamespace(image_size=(H, W))))
+    x_min, x_max = torch.tensor([-24.0, 0.0, -21.0]), torch.tensor([24.0, 12.0, 21.0])
+    cam = mu.Camera(x_min, x_max, 15, 1, 13, 5, 8, 4, 1000.0, renderer, "cpu", contrast_factor=1.0, gathering_factor=0.05)
+    rng = np.random.default_rng(20)
+    out = {"HW": np.array([H, W]), "zfar": np.array(1000.0, np.float32), "tol": np.array(10.0, np.float32),
+           "score_threshold": np.array(0.95, np.float32)}
+    P = 6000
+    pts = rng.uniform([-60, -5, -60], [60, 25, 60], (P, 3)).astype(np.float32)
+    n_inside = rng.integers(0, 4, (P, 1)).astype(np.float32)
+    n_behind = np.minimum(rng.integers(0, 4, (P, 1)), n_inside).astype(np.float32)
+    occ = np.ones((P, 1), np.float32)
+    oof = np.ones((P, 1), np.float32)
+    out.update(pts=pts, n_inside_init=n_inside.copy(), n_behind_init=n_behind.copy())
+    scene = types.SimpleNamespace(proxy_n_inside_fov=torch.from_numpy(n_inside), proxy_n_behind_depth=torch.from_numpy(n_behind),
+                                  proxy_supervision_occ=torch.from_numpy(occ), out_of_field=torch.from_numpy(oof), score_threshold=0.95)
+    for k, (X, V, fov_range) in enumerate([((3.0, 3.3, -6.0), (0.0, 45.0), 70.0), ((-15.0, 3.3, 12.0), (-30.0, 200.0), 70.0),
+                                           ((20.0, 3.3, 18.0), (30.0, 315.0), 40.0)]):
+        R, T = ocam.camera_RT(np.array(X), np.array(V))
+        # depth map of this view: a smooth surface 5 .. 60 units away with "no hit" holes (zbuf -1, mask False)
+        yy, xx = np.mgrid[0:H, 0:W]
+        depth = (20.0 + 15.0 * np.sin(xx / 9.0 + k) + 10.0 * np.cos(yy / 7.0) + rng.uniform(0, 3, (H, W))).astype(np.float32)
+        hole = rng.random((H, W)) < 0.15
+        depth[hole] = -1.0
+        mask = ~hole
+        # the stub camera: view-space points and NDC projections by oracle/camera.py's formulae (fp32)
+        p = pts
+        v = np.empty_like(p)
+        for j in range(3):
+            v[:, j] = ((p[:, 0] * R[0, j] + p[:, 1] * R[1, j]) + p[:, 2] * R[2, j]) + T[j]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            nx = v[:, 0] / (v[:, 2] * ocam.TAN_HALF_FOV)
+            ny = v[:, 1] / (v[:, 2] * ocam.TAN_HALF_FOV)
+        proj = np.stack([nx, ny, np.ones_like(nx)], 1).astype(np.float32)
+        C = ocam.camera_center(R, T)
+        index = {pp.tobytes(): i for i, pp in enumerate(p)}
+
+        def rows(q):
+            return np.array([index[r.tobytes()] for r in q.numpy()], np.int64)
+
+        class _Tf:
+            def __init__(self, table):
+                self.table = table
+
+            def transform_points(self, q):
+                return torch.from_numpy(self.table[rows(q)].copy())
+        fov_camera = types.SimpleNamespace(get_full_projection_transform=lambda: _Tf(proj), get_world_to_view_transform=lambda: _Tf(v),
+                                           get_camera_center=lambda: torch.from_numpy(C).view(1, 3), R=torch.from_numpy(R).view(1, 3, 3))
+        tp = torch.from_numpy(pts)
+        fov_pts, fov_mask = cam.get_points_in_fov(tp, return_mask=True, fov_camera=fov_camera, fov_range=fov_range)
+        sd = cam.get_signed_distance_to_depth_maps(pts=fov_pts, depth_maps=torch.from_numpy(depth).view(1, H, W, 1),
+                                                   mask=torch.from_numpy(mask).view(1, H, W, 1), fov_camera=fov_camera)
+        mu.Scene.update_proxy_out_of_field(scene, fov_mask)
+        mu.Scene.update_proxy_supervision_occ(scene, fov_mask, sd, tol=10.0)
+        out.update({f"R{k}": R, f"T{k}": T, f"depth{k}": depth, f"mask{k}": mask, f"fov_range{k}": np.array(fov_range, np.float32),
+                    f"fov_mask{k}": fov_mask.numpy(), f"sd{k}": sd.view(-1).numpy(),
+                    f"n_inside{k}": scene.proxy_n_inside_fov.numpy().copy(), f"n_behind{k}": scene.proxy_n_behind_depth.numpy().copy(),
+                    f"occ{k}": scene.proxy_supervision_occ.numpy().copy(), f"oof{k}": scene.out_of_field.numpy().copy()})
+        print(f"carve view {k}: {int(fov_mask.sum())} of {P} points in the field of view, sd range {float(sd.min()):.1f} .. {float(sd.max()):.1f}, "
+              f"occ = 0 on {int((scene.proxy_supervision_occ == 0).sum())}")
+    out["ndc_minmax"] = np.array([float(cam.min_ndc_x), float(cam.max_ndc_x), float(cam.min_ndc_y), float(cam.max_ndc_y)], np.float32)
+    np.savez_compressed(os.path.join(HERE, "carve.npz"), **out)
+
+
 def gen_maps(utils):
     rng = np.random.default_rng(21)
     dev = torch.device("cpu")
@@ -572,6 +693,12 @@ if __name__ == "__main__":
     if "--only-scene" in sys.argv:
         gen_scene(mu)
         sys.exit(0)
+    if "--only-carve" in sys.argv:
+        gen_carve(mu)
+        sys.exit(0)
+    if "--only-label" in sys.argv:
+        gen_obstacle_label(utils)
+        sys.exit(0)
     if "--only-blocks" in sys.argv:
         gen_blocks(model)
         sys.exit(0)
@@ -588,3 +715,5 @@ if __name__ == "__main__":
     gen_training(model)
     gen_training(model, B=4, S=128, K=40, tag="S128B4")
     gen_blocks(model)
+    gen_obstacle_label(utils)
+    gen_carve(mu)

@@ -227,6 +227,29 @@ def test_carving_vs_oracle(hip):
         assert np.array_equal(a, b.cpu().numpy())
 
 
+def test_carving_vs_reference_golden(hip, golden_dir):
+    """nbp_carve_update_f32 against the state the REFERENCE's own get_points_in_fov / get_signed_distance_to_depth_maps /
+    update_proxy_* left after three views (tests/golden/carve.npz; the PyTorch3D projection is the fixture's one stub)."""
+    from test_oracle_planner_sim import _carve_golden_sequence
+    dev = {}
+
+    def step(k, g, H, W, state):
+        if not dev:
+            dev["pts"] = torch.from_numpy(g["pts"]).to(D)
+            dev["st"] = [torch.from_numpy(a.copy()).to(D) for a in state]
+        ho.carve_update(dev["pts"], torch.from_numpy(g[f"depth{k}"]).to(D), torch.from_numpy(g[f"mask{k}"].astype(np.uint8)).to(D),
+                        np.concatenate([g[f"R{k}"].reshape(-1), g[f"T{k}"]]), float(g["zfar"]), float(g[f"fov_range{k}"]),
+                        float(g["tol"]), float(g["score_threshold"]), *dev["st"])
+        st = [a.cpu().numpy() for a in dev["st"]]
+        # the kernel keeps no signed distances: the oracle's (bit-exact twin of the kernel, test_carving_vs_oracle) stand in for
+        # the distance check, the counters / occupancy below are the kernel's own
+        inf, sd = ocam.carve_update(g["pts"], g[f"depth{k}"], g[f"mask{k}"], g[f"R{k}"], g[f"T{k}"], float(g["zfar"]),
+                                    float(g[f"fov_range{k}"]), float(g["tol"]), float(g["score_threshold"]),
+                                    *[a.copy() for a in state])
+        return inf, sd, st
+    _carve_golden_sequence(golden_dir, step)
+
+
 def test_edge_arguments_never_crash(hip):
     """Degenerate / hostile arguments to the simulator, map and planner entry points: an error code or a sane result,
     never a crash (each call is followed by a device synchronisation so that a faulting kernel would surface here)."""

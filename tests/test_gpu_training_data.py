@@ -46,6 +46,35 @@ def test_slice_obstacle_matches_restatement(hip, dataset, pose):
     assert np.array_equal(got512, slice_obstacle(mesh.verts_host, mesh.faces_host, pose[1], pose[0], pose[2], 512, -80, 80))
 
 
+@pytest.mark.parametrize("pose", [(0.0, 3.3, 0.0), (7.3, 5.0, -11.9), (-30.0, 1.0, 25.0), (100.0, 3.0, 0.0)])
+def test_slice_obstacle_on_the_reference_pixel_grid_matches_restatement(hip, dataset, pose):
+    """nbp_slice_obstacle_fig_f32 (the default of nbp_utils.get_binary_obstacle_array since round 6) == oracle, bit for bit."""
+    from nextbestpath_amd.utility import hipops, nbp_utils
+    from oracle.slice_raster import slice_obstacle_fig
+    mesh = _mesh(dataset)
+    got = nbp_utils.get_binary_obstacle_array(mesh, (pose[0], pose[1], pose[2], 0.0, 0.0)).cpu().numpy()
+    assert np.array_equal(got, slice_obstacle_fig(mesh.verts_host, mesh.faces_host, pose[1], pose[0], pose[2]))
+    assert (got.sum() > 50) if pose[0] < 50 else (got.sum() == 0)
+    old = nbp_utils.get_binary_obstacle_array(mesh, (pose[0], pose[1], pose[2], 0.0, 0.0), reference_label_semantics=False).cpu().numpy()
+    assert np.array_equal(old, slice_obstacle(mesh.verts_host, mesh.faces_host, pose[1], pose[0], pose[2]))
+    got512 = hipops.slice_obstacle_fig(mesh.verts, mesh.faces, pose[1], pose[0], pose[2], 512, 160.0).cpu().numpy()
+    assert np.array_equal(got512, slice_obstacle_fig(mesh.verts_host, mesh.faces_host, pose[1], pose[0], pose[2], 512, 160.0))
+
+
+def test_slice_obstacle_kernel_vs_reference_golden(hip, golden_dir):
+    """The HIP label against the labels the reference's own matplotlib / PIL stage produced (tests/golden/obstacle_label.npz)."""
+    from nextbestpath_amd.utility import hipops
+    from test_training_data_cpu import _label_agreement
+    g = np.load(os.path.join(golden_dir, "obstacle_label.npz"))
+    verts = torch.from_numpy(g["verts"]).cuda()
+    faces = torch.from_numpy(g["faces"].astype(np.int32)).cuda()
+    for pose, packed in zip(g["poses"], g["labels"]):
+        ref = np.unpackbits(packed)[:256 * 256].reshape(256, 256)
+        got = hipops.slice_obstacle_fig(verts, faces, pose[1], pose[0], pose[2]).cpu().numpy()
+        iou, r1, o1, r2, o2 = _label_agreement(got, ref)
+        assert r2 == 0 and o2 == 0 and r1 <= 0.002 and o1 <= 0.002 and iou >= 0.7, (pose, iou, r1, o1, r2, o2)
+
+
 def test_trajectory_collection_fills_store(hip, dataset, tmp_path):
     from nextbestpath_amd.networks.nbp_model import NBP
     from nextbestpath_amd.simulator import scene as sc

@@ -237,6 +237,45 @@ def test_carving_oracle_bilinear_matches_torch_grid_sample_and_plane_kat():
     assert st2[2].tolist() == [0.0, 0.0, 1.0, 1.0, 1.0]
 
 
+def _carve_golden_sequence(golden_dir, step):
+    """Runs `step(k, R, T, depth, mask, fov_range, state)` over the three views of tests/golden/carve.npz and checks the state
+    after each against what the REFERENCE's own code left (make_golden.py::gen_carve)."""
+    g = np.load(os.path.join(golden_dir, "carve.npz"))
+    H, W = (int(v) for v in g["HW"])
+    P = len(g["pts"])
+    state = [g["n_inside_init"].reshape(P).copy(), g["n_behind_init"].reshape(P).copy(), np.ones(P, np.float32), np.ones(P, np.float32)]
+    for k in range(3):
+        inf, sd, state = step(k, g, H, W, state)
+        want_mask = g[f"fov_mask{k}"]
+        assert np.array_equal(inf, want_mask), (k, int((inf != want_mask).sum()))
+        # signed distances: torch's grid_sample against the restated bilinear blend.  Where a "no hit" pixel (1.1 zfar = 1100) meets
+        # a surface pixel the blend has a slope of ~1080 per pixel, and one fp32 ulp of the sample coordinate (4e-6 px at x ~ 60)
+        # moves it by 4e-3: the bound is that, not a looser arithmetic (median deviation 0, 99th percentile 6e-5)
+        dev = np.abs(sd[want_mask] - g[f"sd{k}"])
+        assert dev.max() <= 8e-3 and np.percentile(dev, 99) <= 5e-4 and np.median(dev) <= 4e-6, (float(dev.max()), float(np.percentile(dev, 99)))
+        for got, key in zip(state, ("n_inside", "n_behind", "occ", "oof")):
+            assert np.array_equal(got, g[f"{key}{k}"].reshape(P)), (k, key)
+    return g
+
+
+def test_carving_oracle_vs_reference_golden(golden_dir):
+    """oracle/camera.py::carve_update against Camera.get_points_in_fov + get_signed_distance_to_depth_maps + Scene.update_proxy_*
+    of the reference run on the same points / depth maps (macarons_utils.py:2849-2949, 3329-3363): identical field-of-view masks,
+    signed distances to 2e-3 (of depths up to 1100), identical counters and occupancy after each of three views.  The PyTorch3D
+    projection feeding those functions was the restatement's own (the fixture's one stub): that part stays parity-unpinned."""
+    def step(k, g, H, W, state):
+        inf, sd = ocam.carve_update(g["pts"], g[f"depth{k}"], g[f"mask{k}"], g[f"R{k}"], g[f"T{k}"], float(g["zfar"]),
+                                    float(g[f"fov_range{k}"]), float(g["tol"]), float(g["score_threshold"]), *state)
+        return inf, sd, state
+    g = _carve_golden_sequence(golden_dir, step)
+    # the NDC window the reference's Camera.__init__ derived for this image size is the restatement's
+    H, W = (int(v) for v in g["HW"])
+    s = min(H, W)
+    max_x, max_y = np.float32(W / s), np.float32(H / s)
+    want = [max_x - (np.float32(W - 1) / np.float32(s - 1)) * np.float32(2), max_x, max_y - (np.float32(H - 1) / np.float32(s - 1)) * np.float32(2), max_y]
+    assert np.allclose(g["ndc_minmax"], want, rtol=0, atol=1e-6)
+
+
 def test_level_order_search_equals_heap_search_on_random_lattices():
     """Host logic of the product (integer level-order search on a precomputed edge mask) against the heapq restatement
     of generate_Dijkstra_path (long_term_utils.py:366-383) on 40 random lattices with random DIRECTED blocked edges:
