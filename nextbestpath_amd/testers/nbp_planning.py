@@ -746,19 +746,29 @@ def run_one(params, nbp, dataset, run, device, test_resolution=0.05, state=None,
 
 
 def run_many(params, nbp, dataset, runs, device, seeds, test_resolution=0.05, n_poses=N_POSES, rollouts_per_gpu=48,
-             grid=256):
-    """Runs `runs` in lock-step groups of `rollouts_per_gpu` (MultiRollout); same results as run_one each."""
+             grid=256, timing=None):
+    """Runs `runs` in lock-step groups of `rollouts_per_gpu` (MultiRollout); same results as run_one each.  `timing` (a dict)
+    receives the wall-clock seconds of scene / GT-surface / camera setup and of the stepping (device-synchronised)."""
+    import time
     out = []
     nbp.eval()
     for g0 in range(0, len(runs), rollouts_per_gpu):
+        t0 = time.perf_counter()
         chunk = list(zip(runs[g0:g0 + rollouts_per_gpu], seeds[g0:g0 + rollouts_per_gpu]))
         ros = [build_rollout(params, nbp, dataset, run, device, test_resolution, None, seed, grid)
                for run, seed in chunk]
         multi = MultiRollout(ros, nbp, device)
+        if timing is not None:
+            torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
         for _ in range(n_poses):
             multi.step()
         multi.flush()
         out += [_result(ro, n_poses) for ro in ros]
+        if timing is not None:
+            torch.cuda.synchronize(device)
+            timing["build_s"] = timing.get("build_s", 0.0) + (t1 - t0)
+            timing["step_s"] = timing.get("step_s", 0.0) + (time.perf_counter() - t1)
         del ros, multi
         torch.cuda.empty_cache()
     return out
@@ -772,7 +782,9 @@ def test_nbp_planning(params_file, model_file, results_json_file, numGPU, test_s
     BASELINE.json configs[4] (512 grid at the same 0.3125 units per pixel, bf16 convolutions).  Under torchrun the flattened
     (scene, start pose) runs are sharded round-robin over the ranks and the coverage curves are
     gathered with ONE all_gather over RCCL (backend "nccl" on ROCm; "gloo" on CPU-only hosts)."""
+    import time
     from ..parallel_rollout import gather_results, init_distributed, shard
+    t_start = time.perf_counter()
     here = os.path.dirname(os.path.abspath(__file__))
     configs_dir = configs_dir or os.path.join(here, "../../configs/macarons")
     results_dir = results_dir or os.path.join(here, "../../data")
@@ -797,11 +809,13 @@ def test_nbp_planning(params_file, model_file, results_json_file, numGPU, test_s
     dataset = sim_scene.SceneDataset(dataset_path, test_scenes)
     runs = list_runs(dataset, params)
     mine = shard(runs, rank, world)
+    timing = {"load_s": time.perf_counter() - t_start}          # parameters, weights (packed on first use), dataset listing
     with torch.no_grad():
         results = run_many(params, nbp, dataset, mine, device, [seed + 1000 * r[0] + r[1] for r in mine],
-                           test_resolution, n_poses, rollouts_per_gpu, grid_size)
+                           test_resolution, n_poses, rollouts_per_gpu, grid_size, timing=timing)
     for run, res in zip(mine, results):
         res["run_id"] = runs.index(run)
+    t_gather = time.perf_counter()
     gathered = gather_results(results, runs, rank, world, device, n_poses)
     if rank == 0:
         out = {}
@@ -817,4 +831,8 @@ def test_nbp_planning(params_file, model_file, results_json_file, numGPU, test_s
             json.dump(out, fh)
         print("Saved data about test losses in", results_json_file)
         print("All trajectories computed.")
+        # one machine-readable line for bench.py's full_rollout stage: where the wall clock of a whole test run goes
+        timing.update(gather_write_s=time.perf_counter() - t_gather, total_s=time.perf_counter() - t_start, runs=len(runs),
+                      runs_this_rank=len(mine), n_poses=n_poses, world=world, scenes=len(dataset))
+        print("[nbp] timing " + json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in timing.items()}), flush=True)
     return gathered
