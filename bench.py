@@ -436,7 +436,7 @@ def main():
 
     replans0 = sum(r.n_replans for r in rollouts)
     with PowerSampler(local_rank) as ps_timed:
-        dt, _ = timed_steps(args.steps)
+        dt, dt_mine = timed_steps(args.steps)
     power_timed = ps_timed.summary()
     n1 = cloud_points()
     replans_timed = sum(r.n_replans for r in rollouts) - replans0
@@ -851,7 +851,6 @@ def main():
 
     full = None
     if rank == 0 and world == 1 and not args.no_full_rollout and not args.no_extra_stages:
-        del multi, rollouts
         torch.cuda.empty_cache()
         full = full_rollout()
 

@@ -229,7 +229,7 @@ int nbp_pack_conv_weight_split_dgrad(const float* w_oihw, int N, int C, int c_to
 /* Training: the same convolution (and its up_conv form), whose epilogue also leaves the column sums of the output and of its
  * squares for the BatchNorm behind it (nextbestpath_amd/networks/training.py: ConvFn -> BNFn; the reference's nn.Sequential of
  * Conv2d + BatchNorm2d, nbp_model.py:14-33): bn_part receives *bn_rows rows of [2][N] doubles -- at most
- * nbp_conv_bn_part_rows(B, H, W) rows -- finalised by nbp_bn_train_forward_part_f32 without another pass over the tensor.
+ * nbp_conv_bn_part_rows(B, H, W) rows -- finalised by nbp_bn_train_forward_part4_f32 without another pass over the tensor.
  * *bn_rows = 0: this launch did not take them (split-K or half-height tiles); the caller's BatchNorm reads the tensor itself. */
 int nbp_conv_bn_part_rows(int B, int H, int W);
 int nbp_conv3x3_split_bn_f32(const float* src0, int C0, const float* src1, int C1, int ups, int B, int H, int W,
@@ -241,10 +241,10 @@ int nbp_upconv3x3_split_bn_f32(const float* src, int C, int B, int H, int W, con
                                void* amax_out_or_null, int split_k, void* ws, size_t ws_bytes, double* bn_part, int* bn_rows,
                                void* stream);
 /* BatchNorm2d training forward from those partial sums (zero_row = C zeros): finalize + normalise, x is read once */
-int nbp_bn_train_forward_part_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
-                                  float momentum, float* running_mean, float* running_var, int relu, float* mean, float* invstd,
-                                  float* y, void* amax_out, double* stat_out, const double* part, int rows, const float* zero_row,
-                                  void* stream);
+int nbp_bn_train_forward_part4_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, int relu, float* mean, float* invstd,
+                                   float* y, void* amax_out, double* stat_out, int stat_doubles, const double* part, int rows,
+                                   const float* zero_row, void* stream);
 /* Single bf16 layer: as nbp_conv_igemm_f32 with bf16 (uint16 storage) NHWC sources / output, C0, C1 multiples
  * of 64, w_packed from nbp_pack_conv_weight_bf16 ([(c_off+c)/64][tap][N][64] bf16), fp32 scale / shift. */
 int nbp_conv_igemm_bf16(const unsigned short* src0, int C0, const unsigned short* src1, int C1, int ups,
@@ -687,16 +687,19 @@ int nbp_bn_train_backward_fused_f32(const float* dy, const float* x, const float
                                     const float* mean, const float* invstd, const float* gamma, int relu,
                                     float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* amax_out,
                                     void* ws, size_t ws_bytes, void* stream);
-/* Round 4: the backward without reading y.  nbp_bn_train_forward_stat_f32 = nbp_bn_train_forward_amax_f32 that also hands out the
+/* Round 4: the backward without reading y.  nbp_bn_train_forward_stat4_f32 = nbp_bn_train_forward_amax_f32 that also hands out the
  * UNROUNDED statistics the normalisation used (stat_out: [4 C] doubles, 32-byte aligned: mean | invstd | lo | hi, the last two with
  * relu only: y > 0 <=> lo <= x <= hi exactly, two floats per channel found by bisection with the forward's own arithmetic);
  * nbp_bn_train_backward_stat_f32 = nbp_bn_train_backward_fused_f32 whose ReLU mask (y > 0) is rebuilt from x -- which the pass
  * reads anyway -- through the forward's own arithmetic on those statistics (C % 4 == 0): two tensor reads less per BatchNorm and
  * step, the same mask bit for bit. */
-int nbp_bn_train_forward_stat_f32(const float* x, long long M, int C, const float* gamma, const float* beta,
-                                  float eps, float momentum, float* running_mean, float* running_var,
-                                  int relu, float* mean, float* invstd, float* y, void* amax_out, double* stat_out,
-                                  void* ws, size_t ws_bytes, void* stream);
+/* (round 6: `stat_doubles` = the doubles behind stat_out, NBP_E_WS below 4 C; without relu the two bounds are written as
+ * (-inf, +inf).  The names changed with the signature -- ..._stat_f32 / ..._part_f32 of rounds 4-5 are gone -- so a caller built for the
+ * [2 C] contract of round 4 fails to link instead of being overrun.) */
+int nbp_bn_train_forward_stat4_f32(const float* x, long long M, int C, const float* gamma, const float* beta,
+                                   float eps, float momentum, float* running_mean, float* running_var,
+                                   int relu, float* mean, float* invstd, float* y, void* amax_out, double* stat_out, int stat_doubles,
+                                   void* ws, size_t ws_bytes, void* stream);
 int nbp_bn_train_backward_stat_f32(const float* dy, const float* x, const double* stat_d, const float* beta, long long M, int C,
                                    const float* mean, const float* invstd, const float* gamma, int relu,
                                    float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* amax_out,

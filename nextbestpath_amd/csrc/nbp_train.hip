@@ -84,7 +84,7 @@ __device__ __forceinline__ f32x4 bn_value4(f32x4 x, f64x4 mu, f64x4 is, f64x4 g,
     const f64x4 r = s + bt;
     return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
 }
-// stat_d = [mean | invstd | lo | hi] doubles (nbp_bn_train_forward_stat_f32), or null: mask from y.
+// stat_d = [mean | invstd | lo | hi] doubles (nbp_bn_train_forward_stat4_f32), or null: mask from y.
 // lo / hi: bn_value is a composition of rounded monotone operations, hence monotone in x (direction = sign of gamma), so the
 // forward's ReLU mask (y > 0) is EXACTLY lo <= x <= hi for two floats found once per channel by bisection over the ordered floats
 // with the forward's own arithmetic (bn_finalize_kernel).  The backward kernels test two fp32 compares per element instead of
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
                                                           double* __restrict__ stat_d, const float* __restrict__ gamma = nullptr,
-                                                          const float* __restrict__ beta = nullptr) {
+                                                          const float* __restrict__ beta = nullptr, int four_planes = 0) {
     __shared__ double sh[FIN_SL][2][FIN_CH];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, ks = threadIdx.x / FIN_CH;
     double s0, s1;
@@ -250,6 +250,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         float lo, hi;
         bn_mask_bounds(mu, 1.0 / sqrt(var + (double)eps), (double)gamma[c], (double)beta[c], &lo, &hi);
         stat_d[2 * C + c] = (double)lo; stat_d[3 * C + c] = (double)hi;
+    } else if (four_planes) {   // no ReLU in this forward: "every element passes"
+        stat_d[2 * C + c] = (double)__int_as_float(0xff800000); stat_d[3 * C + c] = (double)__int_as_float(0x7f800000);
     }
     if (run_mean) {
         const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
@@ -1211,12 +1213,17 @@ extern "C" int nbp_bn_train_forward_amax_f32(const float* x, long long M, int C,
     return bn_forward_impl(x, M, C, gamma, beta, eps, momentum, running_mean, running_var, relu, mean, invstd, y, amax_out_v, nullptr, ws,
                            ws_bytes, stream);
 }
-extern "C" int nbp_bn_train_forward_stat_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
-                                             float momentum, float* running_mean, float* running_var, int relu, float* mean,
-                                             float* invstd, float* y, void* amax_out_v, double* stat_out, void* ws, size_t ws_bytes,
-                                             void* stream) {
+// (the statistics buffer grew from [2 C] to [4 C] doubles in round 5 under an unchanged name and signature -- a caller built
+// against the older contract would have been overrun silently.  The entry points carry the buffer's size now and a new name, so such
+// a caller fails to link instead; and the two bounds are ALWAYS written -- without relu as (-inf, +inf), "every element passes" -- so
+// that a backward asking for the mask on statistics of a forward that had none reads defined values.)
+extern "C" int nbp_bn_train_forward_stat4_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
+                                              float momentum, float* running_mean, float* running_var, int relu, float* mean,
+                                              float* invstd, float* y, void* amax_out_v, double* stat_out, int stat_doubles, void* ws,
+                                              size_t ws_bytes, void* stream) {
     NBP_ENTER();
     NBP_RETURN_IF(!stat_out || ((uintptr_t)stat_out & 31), NBP_E_ARG);
+    NBP_RETURN_IF(stat_doubles < 4 * C, NBP_E_WS);
     return bn_forward_impl(x, M, C, gamma, beta, eps, momentum, running_mean, running_var, relu, mean, invstd, y, amax_out_v, stat_out, ws,
                            ws_bytes, stream);
 }
@@ -1245,7 +1252,7 @@ static int bn_forward_impl(const float* x, long long M, int C, const float* gamm
     // (stat_out: the caller's [4 C] doubles -- the ReLU mask's two bounds per channel are found here too)
     bn_finalize_kernel<<<(unsigned)nbp_cdiv(C, FIN_CH), 256, 0, st>>>(ext_part ? zero_row : x, part, nblk, C, M, eps, momentum, mean, invstd,
                                                                       running_mean, running_var, stat_d, (stat_out && relu) ? gamma : nullptr,
-                                                                      beta);
+                                                                      beta, stat_out ? 1 : 0);
     if ((rc = nbp_launch_status())) return rc;
     if (C % 4 == 0) bn_apply4_kernel<<<nbp_ew_grid(M * C / 4, 256), 256, 0, st>>>(x, M * C / 4, C / 4, stat_d, gamma, beta, relu, y, amax_out);
     else bn_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(x, M * C, C, stat_d, gamma, beta, relu, y);
@@ -1254,12 +1261,13 @@ static int bn_forward_impl(const float* x, long long M, int C, const float* gamm
 
 // ... with the statistics' partial sums already written by the convolution that produced x (nbp_conv3x3_split_bn_f32 /
 // nbp_upconv3x3_split_bn_f32: rows x [2][C] doubles of sum x, sum x^2): finalize + apply only, x is read once.  zero_row = C zeros.
-extern "C" int nbp_bn_train_forward_part_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
-                                             float momentum, float* running_mean, float* running_var, int relu, float* mean,
-                                             float* invstd, float* y, void* amax_out_v, double* stat_out, const double* part, int rows,
-                                             const float* zero_row, void* stream) {
+extern "C" int nbp_bn_train_forward_part4_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
+                                              float momentum, float* running_mean, float* running_var, int relu, float* mean,
+                                              float* invstd, float* y, void* amax_out_v, double* stat_out, int stat_doubles,
+                                              const double* part, int rows, const float* zero_row, void* stream) {
     NBP_ENTER();
     NBP_RETURN_IF(!stat_out || ((uintptr_t)stat_out & 31) || !part || rows < 1 || !zero_row, NBP_E_ARG);
+    NBP_RETURN_IF(stat_doubles < 4 * C, NBP_E_WS);
     return bn_forward_impl(x, M, C, gamma, beta, eps, momentum, running_mean, running_var, relu, mean, invstd, y, amax_out_v, stat_out,
                            nullptr, 0, stream, part, rows, zero_row);
 }
@@ -1293,7 +1301,7 @@ extern "C" int nbp_bn_train_backward_fused_f32(const float* dy, const float* x, 
                             dx_colsum, amax_out_v, ws, ws_bytes, stream);
 }
 // The same with the ReLU mask rebuilt from x (read anyway) through the forward's unrounded statistics (stat_d of
-// nbp_bn_train_forward_stat_f32) and beta, instead of reading y: C % 4 == 0 only.
+// nbp_bn_train_forward_stat4_f32) and beta, instead of reading y: C % 4 == 0 only.
 extern "C" int nbp_bn_train_backward_stat_f32(const float* dy, const float* x, const double* stat_d, const float* beta, long long M, int C,
                                               const float* mean, const float* invstd, const float* gamma, int relu, float* dx,
                                               float* dgamma, float* dbeta, float* dx_colsum, void* amax_out_v, void* ws,

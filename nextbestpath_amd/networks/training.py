@@ -311,7 +311,11 @@ def _prepack_run(net, dev):
     layers = _prepack_layers(net)
     if not layers:
         return None
-    key = (str(dev),) + tuple(w.data_ptr() for w, *_ in layers)
+    # the key holds what the device table froze at build time: every weight's address AND its shape / dtype / element count (a
+    # parameter whose storage was replaced and later landed on the same address with another shape must not reuse stale N / C;
+    # ADVICE r05).  Assumptions documented beside ctx.pre: one stream, and weights unchanged between a forward and ITS backward
+    # (an optimizer step comes after the backward; the next forward re-packs into the same persistent planes).
+    key = (str(dev),) + tuple((w.data_ptr(), tuple(w.shape), str(w.dtype), w.untyped_storage().data_ptr(), w.numel()) for w, *_ in layers)
     tab = _PRE_CACHE.get(key)
     if tab is None:
         while len(_PRE_CACHE) >= 2:                    # (two networks at most -- e.g. a trained and a frozen copy: the buffers are
@@ -328,7 +332,7 @@ def _prepack_run(net, dev):
             planes_t = torch.empty(taps * 4 * N * C // 2, dtype=torch.int16, device=dev)
             rec[i] = (w.data_ptr(), planes.data_ptr(), planes_t.data_ptr(), wamax.data_ptr() + 4 * i, N, C, kind, 0)
             look[w.data_ptr()] = (kind, N, C, planes, planes_t, wamax[i:i + 1])
-            keep.append(w)
+            keep.append((w, w.untyped_storage()))      # the storages themselves, not only the Parameter objects
         descs = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
         tab = _PRE_CACHE[key] = {"descs": descs, "wamax": wamax, "look": look, "n": n, "keep": keep}
     _chk(L.nbp_prepack_weights_split(_lib.ptr(tab["descs"]), tab["n"], _lib.ptr(tab["wamax"]), _st()), "prepack")
@@ -372,7 +376,10 @@ class ConvFn(torch.autograd.Function):
         # bn_next: a BatchNorm consumes this output -- its statistics' partial sums come out of the epilogue (not for padded
         # channel counts, whose output is sliced; not under an observer, which may rewrite the output)
         bn = bool(bn_next) and _BN_EPILOGUE and N == Np and _observer is None
-        pre = None                       # this step's prepacked planes of the layer (kind, N, C, planes, planes_t, wamax)
+        # this step's prepacked planes of the layer (kind, N, C, planes, planes_t, wamax).  They live in ONE persistent buffer per
+        # layer that every forward_train() of this network overwrites: backward(t) after a LATER forward_train() is only right while
+        # the weights are unchanged in between and everything runs on one stream (true of the trainer: forward, backward, step)
+        pre = None
         if ups and k == 3 and x1 is None and _upconv_ok(x0.shape[1], x0.shape[2], Np):
             xmax = _amax_slot(x0)
             pre = _prepacked(w, 2, N, c_real) if (N == Np and c_real == C0) else None
@@ -578,15 +585,15 @@ class BNFn(torch.autograd.Function):
         stat = torch.empty(4 * C, dtype=torch.float64, device=dev) if (_MASK_FROM_X and relu and C % 4 == 0 and _observer is None) else None       # mean | invstd | mask bounds lo | hi
         part = _noted(x, "bnpart") if stat is not None else None
         if part is not None:
-            _chk(L.nbp_bn_train_forward_part_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
-                                                 _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
-                                                 _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(slot), _lib.ptr(stat), _lib.ptr(part[0]), part[1],
-                                                 _lib.ptr(_const(0.0, C, dev)), _st()), "bn_fwd_part")
+            _chk(L.nbp_bn_train_forward_part4_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
+                                                  _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
+                                                  _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(slot), _lib.ptr(stat), stat.numel(),
+                                                  _lib.ptr(part[0]), part[1], _lib.ptr(_const(0.0, C, dev)), _st()), "bn_fwd_part")
         elif stat is not None:
-            _chk(L.nbp_bn_train_forward_stat_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
-                                                 _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
-                                                 _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(slot), _lib.ptr(stat), _lib.ptr(ws), ws.numel(),
-                                                 _st()), "bn_fwd")
+            _chk(L.nbp_bn_train_forward_stat4_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
+                                                  _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),
+                                                  _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(slot), _lib.ptr(stat), stat.numel(),
+                                                  _lib.ptr(ws), ws.numel(), _st()), "bn_fwd")
         else:
             _chk(L.nbp_bn_train_forward_amax_f32(_lib.ptr(x), M, C, _lib.ptr(g), _lib.ptr(b), float(eps), float(momentum),
                                                  _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(mean),

@@ -105,6 +105,9 @@ class Rollout:
         # the reference hard-codes 256 / 64 / +-40 (nbp_planning.py:43-45); other grids keep 0.3125 units per pixel
         self.S, self.V, self.grid_range = grid, grid // 4, (-40 * grid // 256, 40 * grid // 256)
         self.st = state or RolloutState(device, grid=grid)
+        # a state taken over from an earlier rollout may still have that rollout's side-stream forwards in flight on its input
+        # buffers: this stream waits for them before the state is overwritten
+        self._wait_forwards()
         self.st.cloud_count.zero_()
         self.st.coverage_counts.zero_()
         self.st.frames_appended = 0
@@ -301,16 +304,23 @@ class Rollout:
             self.plan_finish()
         self.post()
 
-    def finish(self):
-        """The caller's stream waits for the forwards still in flight (before the network's weights or the state are reused)."""
-        ov = self.st._overlap
+    def _wait_forwards(self):
+        ov = getattr(self.st, "_overlap", None)
         if ov is not None:
             main = torch.cuda.current_stream(self.device)
-            for used, ev in zip(ov["used"], ov["done"]):
+            for k, (used, ev) in enumerate(zip(ov["used"], ov["done"])):
                 if used:
                     main.wait_event(ev)
+                    ov["used"][k] = False          # (a later step on this slot records the event again before anyone waits on it)
+
+    def finish(self):
+        """The caller's stream waits for the forwards still in flight (before the network's weights or the state are reused).
+        Idempotent; coverage_evolution() -- what every driver ends a rollout with -- calls it, and a Rollout that takes over a used
+        state waits in its constructor, so a loop over step() that never calls finish() is safe as well."""
+        self._wait_forwards()
 
     def coverage_evolution(self, n):
+        self.finish()
         counts = self.st.coverage_counts[:n].cpu().numpy()
         G = np.float32(len(self.gt))
         return [float(np.float32(c) / G) for c in counts[:, 0]]

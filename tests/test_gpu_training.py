@@ -371,8 +371,10 @@ def test_full_network_training_step_vs_oracle(hip, nbp_weights):
     # Up4_1.up.2 -- its beta gradient moved by exactly that element's dy, 5.6e-4 of the tensor's scale, and the weight gradient of the
     # convolution in front of it with it).  Such a flip shows as the parameters of ONE BatchNorm and the convolution feeding it, each
     # within 2e-3 of its scale; anything else fails.
+    # (the allowance is pinned to THAT layer -- a regression confined to any other BatchNorm / convolution pair fails, and
+    # so does a second flip.)
     layers = {n.rsplit(".", 2)[0] for n, *_ in bad}
-    assert len(layers) <= 1 and len(bad) <= 3 and all(e <= 2e-3 * sc for _, e, _, sc in bad), bad[:8]
+    assert layers <= {"Up4_1.up"} and len(bad) <= 3 and all(e <= 2e-3 * sc for _, e, _, sc in bad), bad[:8]
     # running statistics were updated exactly once with momentum 0.1 (unbiased variance)
     got = net.state_dict()
     sd3 = {k: v.clone() for k, v in sd.items()}
