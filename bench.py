@@ -679,7 +679,7 @@ def main():
             sc_traffic, src2 = committed_traffic("map_binned_kernel", "pmc_summary.csv")
             sc_src = f"{src2}; live pass: {live_src}" if src2 else live_src
         scatter = {"bound": "hbm", "kernel": "map_binned_kernel (tile-binned shadow copy of the cloud: one workgroup per 2048-point page of a "
-                                             "2.5-unit tile on a dense LDS histogram; new points counted directly and filed by the same launch)",
+                                             "2.5-unit tile on a dense LDS histogram; new points are filed by the un-projection launch that appends them)",
                    "achieved": round(alg / (ms_sc * 1e-3) / 1e9, 1),
                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(alg / (ms_sc * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                    "traffic": None if sc_traffic is None else round(sc_traffic), "traffic_source": sc_src, "traffic_is_live": sc_live,
@@ -707,11 +707,62 @@ def main():
         alg_big = 12 * big.shape[0] + 6 * S * S * 4
         scatter["at_3M_points"] = {"ms_steady": round(ms_big, 4), "achieved": round(alg_big / (ms_big * 1e-3) / 1e9, 1),
                                    "frac_steady": round(alg_big / (ms_big * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-        del big, maps_big, bins_big, bins_b
+        del big, maps_big, bins_big
         cams4 = np.stack([f[1] for f in cam.frames[-4:]])
         H_, W_ = params.image_height, params.image_width
         zb = torch.empty(4, H_, W_, device=dev)
         ms_r = ev_time(lambda: hipops.raster_zbuf(mesh.verts, mesh.faces, cams4, H_, W_, bin_cap=mesh.bin_cap, out=zb))
+        # the ONE-launch form a single rollout's step runs since round 6 (Rollout.pre): the un-projection launch that appends a
+        # frame's points files them into the bins and clears the maps (the points are in its registers), the build is the page launch
+        # alone.  ms_build = that launch on the rollout's cloud with everything filed; filing_and_clear_ms = what the filing + the
+        # 1.8 MB clear add to the un-projection of one frame (same frame, alternating, clouds that grow by the same points).
+        ms_one = ev_time(lambda: hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=nd_b, out=maps_b, bins=bins_b,
+                                                         prefiled=True), reps=50)
+        # (the timed loop accumulated onto uncleared maps; the comparison below runs on a cleared buffer)
+        hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=nd_b, out=maps_b, bins=bins_b)
+        maps_two = maps_b.clone()
+        maps_b.zero_()
+        hu.accumulate_step_maps(ro.st.cloud, pose, y_bins, S, (-40, 40), n_dev=nd_b, out=maps_b, bins=bins_b, prefiled=True)
+        one_equal = bool(torch.equal(maps_b, maps_two))
+        del maps_two
+        cap_f = 400_000
+        cl_a, cl_b = torch.zeros(cap_f, 3, device=dev), torch.zeros(cap_f, 3, device=dev)
+        cn_a, cn_b = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+        bins_f = hu.CloudBins(ext_lo, ext_hi, cap_f, dev)
+        traj_f = torch.zeros(S, S, device=dev)
+        t_plain, t_filed = [], []
+        for rep in range(4):
+            for which, acc in ((0, t_plain), (1, t_filed)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for k in range(10):
+                    if which == 0:
+                        hipops.unproject_append(zb[:1], None, cams4[:1], cl_a, cn_a, 0.05, 70.0, seed=rep * 16 + k)
+                    else:
+                        hipops.unproject_append(zb[:1], None, cams4[:1], cl_b, cn_b, 0.05, 70.0, seed=rep * 16 + k, bins=bins_f,
+                                                clear=(maps_b, traj_f))
+                e1.record()
+                torch.cuda.synchronize()
+                acc.append(e0.elapsed_time(e1) / 10)
+        filed_ok = bins_f.header()
+        ms_file = max(0.0, sorted(t_filed)[1] - sorted(t_plain)[1])
+        ms_step = ms_one + ms_file
+        scatter["two_launch_form"] = {"ms": scatter["ms"], "ms_steady": scatter["ms_steady"], "frac": scatter["frac"],
+                                      "frac_steady": scatter["frac_steady"],
+                                      "note": "bin_append_kernel + map_binned_kernel per build (rounds 4-5; still what a caller without the "
+                                              "filing un-projection gets, and what the group form runs per rollout)"}
+        scatter.update({"ms": round(ms_step, 4), "achieved": round(alg / (ms_step * 1e-3) / 1e9, 1),
+                        "frac": round(alg / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                        "one_launch_form": {"ms_build": round(ms_one, 4), "filing_and_clear_ms": round(ms_file, 4),
+                                            "unproject_1_frame_plain_ms": round(sorted(t_plain)[1], 4),
+                                            "unproject_1_frame_filing_ms": round(sorted(t_filed)[1], 4),
+                                            "maps_equal_two_launch_build": one_equal,
+                                            "store_in_step_after_40_filed_frames": bool(filed_ok["n_binned"] == int(cn_b.item()) and filed_ok["error"] == 0),
+                                            "frac_build_alone": round(alg / (ms_one * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+                        "note": "ms = the one-launch build (map_binned_kernel alone) + what filing the frame's points and clearing the maps "
+                                "adds to the un-projection launch in front of it; at this size a launch's fixed cost is several times "
+                                "the HBM time of the bytes (3.6 us at 8 TB/s)"})
+        del bins_b, bins_f, cl_a, cl_b
         F_ = int(mesh.faces.shape[0])
         rb = 4 * (36 * F_ + 4 * H_ * W_)
         stage["raster_4_frames"] = {"ms": round(ms_r, 4), "faces": F_, "frames_per_s": round(4e3 / ms_r, 1),
@@ -913,6 +964,8 @@ def main():
         out["roofline_frac"] = None if roofline is None else roofline["frac"]
         out["roofline_traffic_is_live"] = None if roofline is None else roofline["traffic_is_live"]
         out["scatter_frac"] = None if scatter is None else scatter["frac"]
+        # what the TIMED region launches is the group form (nbp_step_maps_binned_batch_f32 over a pipeline group's rollouts)
+        out["scatter_frac_group_form"] = None if scatter is None else scatter["group_form"]["frac"]
         # A/B switches (NBP_TUNING=1 ...): state every non-default one; a line measured with a switch that changes the
         # arithmetic is not the headline configuration and does not get to call itself `value`
         knobs = _lib.effective_knobs()

@@ -381,6 +381,14 @@ int nbp_step_maps_binned_f32(void* store, int page_bound, const float* points, l
                              float cx, float cy, float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi,
                              int S, float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
                              int n_traj_fresh, float* out6, float* net_in5, void* stream);
+/* nbp_step_maps_binned_f32 as ONE launch (round 6): the page build alone, for a store whose points were filed by the launch that
+ * appended them to the cloud and whose outputs that launch cleared (nbp_unproject_append_filed_f32 with the same store, zero6 = out6,
+ * zero1 = net_in5 + 4 S^2).  Same arguments, same maps.  Points the store has not seen (appended by any other route since) are still
+ * counted -- directly, slowly -- so a caller's bookkeeping slip costs time, never points. */
+int nbp_step_maps_prefiled_f32(void* store, int page_bound, const float* points, long long N, const long long* N_dev_or_null,
+                               float cx, float cy, float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi,
+                               int S, float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
+                               int n_traj_fresh, float* out6, float* net_in5, void* stream);
 int nbp_step_maps_binned_batch_f32(int n, void* const* stores, const int* page_bound, const float* const* points,
                                    const long long* N_cap, const long long* const* N_dev, const float* poses_xyz_host,
                                    const float* bounds_host, const int* n_bounds, const float* band_lo_hi_host, int S, float lo,
@@ -475,6 +483,20 @@ int nbp_unproject_append_shaded_f32(const float* depth, const unsigned char* mas
                                     float fov_range, double gathering_factor, unsigned seed, float ambient,
                                     int* counts2, float* cloud, float* cloud_rgb, long long* cloud_count,
                                     long long capacity, void* ws, size_t ws_bytes, void* stream);
+/* The three calls above in one (by which colour source is given: none, rgb [n_frames,H,W,3], or zface + verts + faces + vcolors3)
+ * that also FILES every appended point into the cloud's tile-binned store (nbp_cloud_bins_init; the point is in registers anyway)
+ * and, when zero6 / zero1 are given, clears the 6 S^2 / S^2 floats the map build behind it accumulates into: that build is then
+ * nbp_step_maps_prefiled_f32 -- one launch instead of two (round 6).  It files only while the store is in step with the cloud
+ * (header n_binned == *cloud_count at entry); otherwise the points stay unfiled and the next build counts them directly.
+ * Needs the three-launch form (H W % 4 == 0, 16-byte aligned frames): NBP_E_SHAPE otherwise.  Replaces the same reference lines as
+ * nbp_unproject_append_f32 (mu:2788-2847) + the scatter's bookkeeping (next_best_path/testers/nbp_planning.py:114-127). */
+int nbp_unproject_append_filed_f32(const float* depth, const unsigned char* mask_or_null, const float* rgb_or_null,
+                                   const void* zface_or_null, const float* verts, const int* faces, const float* vcolors3,
+                                   const float* cams12_host, int n_frames, int H, int W, float tan_half_fov,
+                                   float fov_range, double gathering_factor, unsigned seed, float ambient, int* counts2,
+                                   float* cloud, float* cloud_rgb_or_null, long long* cloud_count, long long capacity,
+                                   void* bins_store, float* zero6_or_null, float* zero1_or_null, int S, void* ws,
+                                   size_t ws_bytes, void* stream);
 
 /* line_segment_mesh_intersection (mu:120-151): hit[e] = 1 iff the ray from segs6[e][0:3] towards
  * segs6[e][3:6] meets a triangle at distance < |segment|. */
@@ -709,6 +731,11 @@ int nbp_colsum_f32(const float* x, const float* rows_or_null, long long M, int C
                    size_t ws_bytes, void* stream);
 /* op 0: relu(a+b)  1: a*(b>0)  2: sigmoid(a)  3: a*b*(1-b)  4: a+b  5: a+b[0] */
 int nbp_elementwise_f32(int op, const float* a, const float* b, long long n, float* out, void* stream);
+/* out[m][c] = sum_k src_k[m ld_k + c] (k = 0 .. n - 1, left to right in fp32; n <= 8; C % 4 == 0; 16-byte aligned pointers; ld_k >= C
+ * floats, a multiple of 4: a source may be a channel slice of a wider NHWC tensor).  The gradient of an activation with n consumers
+ * (a skip connection: max-pool + two attention gates x two uses) in one pass instead of autograd's n - 1 binary adds -- what
+ * loss.backward() does implicitly in next_best_path/utility/nbp_utils.py:383.  srcs_host / ld_host: HOST arrays of n entries. */
+int nbp_sum_n_f32(int n, const float* const* srcs_host, const long long* ld_host, long long M, int C, float* out, void* stream);
 int nbp_rowscale_f32(const float* x, const float* s, long long M, int C, float* out, void* stream);
 /* ... that also leaves max |out| in the 64 zeroed words of amax_out (C % 4 == 0, 16-byte aligned tensors, else NBP_E_SHAPE). */
 int nbp_rowscale_amax_f32(const float* x, const float* s, long long M, int C, float* out, void* amax_out, void* stream);   /* x[m][c]*s[m] */
@@ -758,6 +785,27 @@ int nbp_scatter_values_f32(const float* dpred, const long long* coords_bcxy, int
  * double); dp (optional) = grad_coef * d(mean loss)/dp. */
 int nbp_loss_f32(int mode, const float* p, const float* t, long long n, float grad_coef, double* sum_out,
                  float* dp_or_null, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- The replay store's container in LMDB's on-disk format (csrc/nbp_mdb.cpp; host only).  The reference keeps its experience
+ * records in an LMDB environment (next_best_path/trainers/train_nbp_model.py:61-63 lmdb.open(path, map_size);
+ * next_best_path/utility/nbp_utils.py:32-141: txn.put per record, ordered cursors, txn.delete of the validation records).  liblmdb is
+ * not in this image: these entry points read and write <dir>/data.mdb in LMDB 0.9's file format (4096-byte pages, unnamed main
+ * database, memcmp key order, overflow pages for records > 2038 bytes), so that a store written here opens with lmdb and one written
+ * by the reference opens here.  One writer; every put / del is its own committed transaction.  Parity unpinned against liblmdb.
+ *   nbp_mdb_open     creates <dir> and an empty environment, or loads an existing one (NBP_E_SHAPE: not an LMDB file of this shape --
+ *                    other page size, named or duplicate-key databases); sync_each_commit: fdatasync before and after each meta write
+ *   nbp_mdb_put      insert or replace; nbp_mdb_del: 0 deleted, 1 not found; nbp_mdb_get: 0 found (*vlen_out = size; the bytes are
+ *                    copied when cap >= size), 1 not found
+ *   nbp_mdb_keys     every key in order, packed [u16 length][bytes]...; *needed_out = packed size (cap = 0 sizes the buffer)
+ *   nbp_mdb_stat     {depth, branch pages, leaf pages, overflow pages, entries, last page, txnid, page size}                          */
+int nbp_mdb_open(const char* dir_path, unsigned long long map_size, int sync_each_commit, void** env_out);
+int nbp_mdb_close(void* env);
+long long nbp_mdb_entries(void* env);
+int nbp_mdb_put(void* env, const void* key, size_t klen, const void* val, size_t vlen);
+int nbp_mdb_del(void* env, const void* key, size_t klen);
+int nbp_mdb_get(void* env, const void* key, size_t klen, void* buf, size_t cap, size_t* vlen_out);
+int nbp_mdb_keys(void* env, void* buf, size_t cap, size_t* needed_out);
+int nbp_mdb_stat(void* env, unsigned long long* out8);
 
 #ifdef __cplusplus
 }

@@ -182,6 +182,18 @@ SIGNATURES["nbp_raster_zface_f32"] = (_i, [_vp, _i, _vp, _i, _fpp, _i, _i, _i, _
 SIGNATURES["nbp_shade_image_f32"] = (_i, [_vp, _vp, _vp, _vp, _fpp, _i, _i, _i, _f, _f, _f, _vp, _vp])
 SIGNATURES["nbp_unproject_append_shaded_f32"] = (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _fpp, _i, _i, _i, _f, _f, _d, C.c_uint, _f,
                                                       _vp, _vp, _vp, _vp, _ll, _vp, _sz, _vp])
+SIGNATURES["nbp_mdb_open"] = (_i, [C.c_char_p, C.c_ulonglong, _i, C.POINTER(_vp)])
+SIGNATURES["nbp_mdb_close"] = (_i, [_vp])
+SIGNATURES["nbp_mdb_entries"] = (_ll, [_vp])
+SIGNATURES["nbp_mdb_put"] = (_i, [_vp, C.c_char_p, _sz, C.c_char_p, _sz])
+SIGNATURES["nbp_mdb_del"] = (_i, [_vp, C.c_char_p, _sz])
+SIGNATURES["nbp_mdb_get"] = (_i, [_vp, C.c_char_p, _sz, _vp, _sz, C.POINTER(_sz)])
+SIGNATURES["nbp_mdb_keys"] = (_i, [_vp, _vp, _sz, C.POINTER(_sz)])
+SIGNATURES["nbp_mdb_stat"] = (_i, [_vp, C.POINTER(C.c_ulonglong)])
+SIGNATURES["nbp_sum_n_f32"] = (_i, [_i, _vp, _vp, _ll, _i, _vp, _vp])
+SIGNATURES["nbp_unproject_append_filed_f32"] = (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _fpp, _i, _i, _i, _f, _f, _d, C.c_uint, _f,
+                                                     _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _i, _vp, _sz, _vp])
+SIGNATURES["nbp_step_maps_prefiled_f32"] = SIGNATURES["nbp_step_maps_binned_f32"]
 SIGNATURES["nbp_slice_obstacle_f32"] = (_i, [_vp, _vp, _i, _f, _f, _f, _i, _f, _f, _f, _vp, _vp])
 SIGNATURES["nbp_slice_obstacle_fig_f32"] = (_i, [_vp, _vp, _i, _f, _f, _f, _i, _f, _f, _f, _f, _f, _f, _vp, _vp])
 

@@ -9,6 +9,8 @@
 #include "common.h"
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #pragma clang fp contract(off)
 
 namespace {
@@ -206,42 +208,11 @@ __global__ __launch_bounds__(THREADS) void map_accumulate_batch_kernel(MapBatch 
 // concurrent convolutions stream through (the page side alone is free there).
 // Counts are integers, so the maps are bit-identical to map_accumulate_kernel's whatever the order (tests/test_gpu_maps.py, every
 // rollout parity test).
-// Slot reservation: one atomicAdd per (wave, tile), all of a wave's in flight together; the lane whose slot is the first of a page
-// allocates it and publishes (tile, page ordinal) -> page id in an open-addressing hash (one 64-bit CAS: key and id appear together;
-// entries are never removed), lanes of other waves probe for the key and wait at the first empty slot of its probe sequence
-// (bounded) -- within a wave every allocation is issued before any lane waits, so a waiter never blocks its own allocator.  A tile
-// may own any number of pages (a wall the agent lingers at collects > 10^5 points).  What cannot be filed (outside the tile grid,
-// the page pool exhausted, a wait that timed out) goes to an index list that every build walks with direct atomics; if that list
-// fills up too the store marks itself broken (header word 2) and every later build counts the whole cloud directly:
-// slow, never wrong.
-constexpr int BIN_PAGE_BITS = 11, BIN_PAGE = 1 << BIN_PAGE_BITS;      // 2048 points = 24 KB per page
-constexpr unsigned BIN_OVF = 1u << 16;
+// Store layout, slot reservation and the wave-cooperative filing: nbp_bins.h (shared with the un-projection launch of nbp_sim.hip,
+// which files the points it appends so that a single rollout's build is ONE launch: nbp_step_maps_prefiled_f32).
+#include "nbp_bins.h"
 constexpr int BIN_R = 16;                                             // LDS histogram: 16 x 16 cells (a 2.5-unit tile is 9 x 9 + slack)
 constexpr int BIN_APPEND_WGS = 128, BIN_OVF_WGS = 4;     // 128 x 256 threads: one step's ~29 k new points in one pass
-struct BinDesc {                // head of the store (device memory, 256 B reserved)
-    // error is STICKY: set (never cleared) by a filing launch whose side list overflowed, reset only by nbp_cloud_bins_init.  Every
-    // workgroup of a filing launch reads it once at entry and another workgroup may set it during the same launch, so late
-    // workgroups may file nothing while n_binned still advances to N: correct only because every later build then counts the whole
-    // cloud directly (map_binned_kernel's `broken` branch) -- clearing the flag by any other route would lose those points
-    // (tests/test_gpu_maps.py::test_binned_maps_points_that_cannot_be_filed_are_still_counted walks through the break).
-    unsigned n_pages, n_overflow, error, ticket;
-    long long n_binned;                                   // points of the cloud already filed
-    int nx, nz, nt, max_pages;
-    float x0, z0, inv_t, tile;
-    unsigned hash_mask, pad0;                             // page hash: hash_mask + 1 entries (a power of two >= 2 max_pages)
-    unsigned long long off_count, off_table, off_info, off_ovf, off_pages, total_bytes;
-};
-static_assert(sizeof(BinDesc) <= 256, "BinDesc header");
-
-struct BinView { BinDesc* d; unsigned* count; unsigned long long* table; unsigned* info; unsigned* ovf; float* pages; };
-constexpr unsigned long long BIN_EMPTY = ~0ull;           // hash entry: (key << 32) | page id; key = tile | page ordinal << 16
-constexpr unsigned BIN_POOL_EXHAUSTED = 0xFFFFFFFEu;      // page id published when the pool has no page left
-__device__ __forceinline__ BinView bin_view(char* store) {
-    BinDesc* d = reinterpret_cast<BinDesc*>(store);
-    return BinView{d, reinterpret_cast<unsigned*>(store + d->off_count), reinterpret_cast<unsigned long long*>(store + d->off_table),
-                   reinterpret_cast<unsigned*>(store + d->off_info), reinterpret_cast<unsigned*>(store + d->off_ovf),
-                   reinterpret_cast<float*>(store + d->off_pages)};
-}
 
 __device__ __forceinline__ int channel_of(float y, const Bounds& bd) {
     int cnt = 0;
@@ -263,75 +234,17 @@ __device__ __forceinline__ void count_direct(float x, float y, float z, const Ma
 // each): two memset launches less per build -- every launch boundary is an L2 write-back / invalidate under the other group's forward.
 __device__ __forceinline__ void bin_append_body(char* store, const float* __restrict__ cloud, long long N, unsigned wg, unsigned n_wg,
                                                 float* __restrict__ zero6, float* __restrict__ zero1, int SS) {
-    {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const int n6 = zero6 ? 6 * SS / 4 : 0, n1 = zero1 ? SS / 4 : 0;          // (SS % 4 == 0: launcher)
-        for (int i = (int)(wg * 256 + threadIdx.x); i < n6 + n1; i += (int)(n_wg * 256))
-            reinterpret_cast<f32x4*>(i < n6 ? zero6 : zero1)[i < n6 ? i : i - n6] = z;
-    }
+    bin_clear_maps(zero6, zero1, SS, wg, n_wg);          // (SS % 4 == 0: launcher)
     const BinView v = bin_view(store);
     const long long first = v.d->n_binned;
     if (v.d->error == 0u) {                               // (a broken store files nothing more: its builds scan the cloud)
-        const int nx = v.d->nx, nz = v.d->nz, max_pages = v.d->max_pages;
-        const float x0 = v.d->x0, z0 = v.d->z0, inv_t = v.d->inv_t;
-        const unsigned mask = v.d->hash_mask;
-        const int lane = threadIdx.x & 63;
-        const unsigned long long lt = (1ull << lane) - 1ull;
+        const BinGeom g = bin_geom(v);
         for (long long i0 = first + (long long)wg * 256; i0 < N; i0 += (long long)n_wg * 256) {      // uniform per workgroup
             const long long i = i0 + threadIdx.x;
             const bool active = i < N;
             f32x3 p = {__builtin_nanf(""), 0.f, 0.f};
             if (active) p = *reinterpret_cast<const f32x3*>(cloud + 3 * i);
-            const float fx = (p[0] - x0) * inv_t, fz = (p[2] - z0) * inv_t;
-            const int tx = (int)floorf(fx), tz = (int)floorf(fz);
-            const bool inside = active && fx >= 0.f && fz >= 0.f && tx < nx && tz < nz;       // NaN fails
-            const int t = inside ? tz * nx + tx : -1;
-            // groups of lanes with the same tile (ballots only), then ONE reserving atomic per group, all in flight together
-            int leader = lane;
-            unsigned rank = 0, gsize = 0;
-            unsigned long long todo = __ballot(inside);
-            while (todo) {
-                const int l0 = __ffsll((long long)todo) - 1;
-                const int t0 = __shfl(t, l0);
-                const unsigned long long m = __ballot(inside && t == t0);
-                if (inside && t == t0) { leader = l0; rank = (unsigned)__popcll(m & lt); gsize = (unsigned)__popcll(m); }
-                todo &= ~m;
-            }
-            unsigned b = 0;
-            if (inside && lane == leader) b = atomicAdd(&v.count[t], gsize);
-            b = __shfl(b, leader);
-            const unsigned slot = b + rank;
-            const unsigned k = slot >> BIN_PAGE_BITS;
-            const unsigned key = (unsigned)t | (k << 16);
-            unsigned pos = (key * 0x9E3779B1u) >> 7 & mask;
-            if (inside && (slot & (BIN_PAGE - 1)) == 0) {         // first slot of a page: allocate it and publish (key -> id)
-                const unsigned got = atomicAdd(&v.d->n_pages, 1u);
-                unsigned pub = BIN_POOL_EXHAUSTED;                // the pool is exhausted: waiters go to the side list
-                if (got < (unsigned)max_pages) { v.info[got] = key; pub = got; }
-                const unsigned long long e = ((unsigned long long)key << 32) | pub;
-                unsigned q = pos;
-                for (unsigned probe = 0; probe <= mask; ++probe, q = (q + 1) & mask)
-                    if (atomicCAS(&v.table[q], BIN_EMPTY, e) == BIN_EMPTY) break;         // (2 max_pages entries: a free one exists)
-            }
-            int pid = -1;
-            if (inside) {
-                int budget = 1 << 20;
-                while (budget > 0) {
-                    // (relaxed: only the entry itself is awaited -- an acquire here is an L2 invalidate per probe on gfx950)
-                    const unsigned long long e = __hip_atomic_load(&v.table[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (e == BIN_EMPTY) { --budget; __builtin_amdgcn_s_sleep(2); continue; }    // not published yet: it lands here or later
-                    if ((unsigned)(e >> 32) == key) { const unsigned id = (unsigned)e; pid = id == BIN_POOL_EXHAUSTED ? -2 : (int)id; break; }
-                    pos = (pos + 1) & mask;                       // another key's entry (permanent): move on
-                }
-            }
-            if (pid >= 0) {
-                float* dst = v.pages + ((size_t)pid * BIN_PAGE + (slot & (BIN_PAGE - 1))) * 3;
-                dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
-            } else if (active) {
-                const unsigned q = atomicAdd(&v.d->n_overflow, 1u);
-                if (q < BIN_OVF) v.ovf[q] = (unsigned)i;
-                else v.d->error = 1u;                             // broken from the next build on: the whole cloud is counted directly
-            }
+            bin_file_wave(v, g, active, p, i);
         }
     }
     __shared__ int last;
@@ -345,9 +258,17 @@ __device__ __forceinline__ void bin_append_body(char* store, const float* __rest
     }
 }
 
+// The launch-constant part of a store's header.  The single-rollout launch gets it in its kernel arguments (the host remembers what
+// nbp_cloud_bins_init wrote: one dependent round trip less in a launch that is a chain of them); valid = 0: read from the store.
+struct BinStatic { unsigned long long off_count, off_info, off_ovf, off_pages; int nx, max_pages; float x0, z0, tile; int valid; };
+
 // One workgroup of 256 threads.  Roles by index: [0, n_page_wg) pages, then BIN_OVF_WGS side list, 1 trajectory.
+// SPEC (the single-rollout launch, latency-bound): a page's 2048 slots are loaded without waiting for its tile's count -- slots no
+// point was filed into hold NaN since nbp_cloud_bins_init and fail cell_of -- so the chain is {header word, page info} -> page
+// data -> LDS -> flush; without it (the group launch, throughput-bound) only the filled slots are read.
+template <bool SPEC>
 __device__ __forceinline__ void map_binned_body(const MapItem& a, char* store, unsigned wg, unsigned n_page_wg, int S, float lo,
-                                                float sc, int* hist) {
+                                                float sc, int* hist, BinStatic g = BinStatic{0, 0, 0, 0, 0, 0, 0.f, 0.f, 0.f, 0}) {
     float* __restrict__ out = a.out;
     const float cx = a.cx, cz = a.cz;
     const int SS = S * S;
@@ -371,8 +292,15 @@ __device__ __forceinline__ void map_binned_body(const MapItem& a, char* store, u
         }
         return;
     }
-    const BinView v = bin_view(store);
-    const bool broken = v.d->error != 0u;                  // (set by an append launch, never by this one)
+    BinDesc* const d = reinterpret_cast<BinDesc*>(store);
+    if (!g.valid) g = BinStatic{d->off_count, d->off_info, d->off_ovf, d->off_pages, d->nx, d->max_pages, d->x0, d->z0, d->tile, 1};
+    const BinView v{d, reinterpret_cast<unsigned*>(store + g.off_count), nullptr, reinterpret_cast<unsigned*>(store + g.off_info),
+                    reinterpret_cast<unsigned*>(store + g.off_ovf), reinterpret_cast<float*>(store + g.off_pages)};
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 dyn = *reinterpret_cast<const u32x4*>(store);      // n_pages, n_overflow, error, ticket: one load
+    // (this workgroup's first page: its info word is fetched beside the header word, not behind it; page_bound <= max_pages)
+    unsigned info_first = wg < n_page_wg && wg < (unsigned)g.max_pages ? v.info[wg] : 0u;
+    const bool broken = dyn[2] != 0u;                      // (set by an append launch, never by this one)
     if (wg >= n_page_wg) {                                 // the side list -- or, for a broken store, the whole cloud -- with direct atomics
         const unsigned w = wg - n_page_wg;
         if (broken) {
@@ -384,26 +312,37 @@ __device__ __forceinline__ void map_binned_body(const MapItem& a, char* store, u
             }
             return;
         }
-        const unsigned n = min(v.d->n_overflow, BIN_OVF);
+        const unsigned n = min(dyn[1], BIN_OVF);
         for (unsigned i = w * 256 + threadIdx.x; i < n; i += BIN_OVF_WGS * 256) {
             const f32x3 p = *reinterpret_cast<const f32x3*>(a.p + 3 * (size_t)v.ovf[i]);
+            count_direct(p[0], p[1], p[2], a, S, lo, sc);
+        }
+        // points no launch has filed yet ([n_binned, N): none after bin_append_kernel, none in the prefiled form when every append
+        // went through the filing un-projection) are counted directly as well: a caller's bookkeeping slip costs time, never points
+        long long N = a.N;
+        if (a.n_dev) N = *a.n_dev;
+        for (long long i = v.d->n_binned + (long long)w * 256 + threadIdx.x; i < N; i += (long long)BIN_OVF_WGS * 256) {
+            const f32x3 p = *reinterpret_cast<const f32x3*>(a.p + 3 * i);
             count_direct(p[0], p[1], p[2], a, S, lo, sc);
         }
         return;
     }
     if (broken) return;
-    const unsigned n_pages = min(v.d->n_pages, (unsigned)v.d->max_pages);
+    const unsigned n_pages = min(dyn[0], (unsigned)g.max_pages);
     // (one page per workgroup when the host's bound n_page_wg covers the pages that exist; a bound that is too low only costs time)
     for (unsigned page = wg; page < n_pages; page += n_page_wg) {
-        const unsigned info = v.info[page];
+        const unsigned info = page == wg ? info_first : v.info[page];
         const int t = (int)(info & 0xffffu), k = (int)(info >> 16);
-        const unsigned tc = v.count[t];
-        if (tc <= (unsigned)k * BIN_PAGE) continue;        // (cannot happen: a page exists once its first slot is reserved)
-        const int cnt = (int)min((unsigned)BIN_PAGE, tc - (unsigned)k * BIN_PAGE);
+        int cnt = BIN_PAGE;
+        if (!SPEC) {
+            const unsigned tc = v.count[t];
+            if (tc <= (unsigned)k * BIN_PAGE) continue;    // (cannot happen: a page exists once its first slot is reserved)
+            cnt = (int)min((unsigned)BIN_PAGE, tc - (unsigned)k * BIN_PAGE);
+        }
         // the block of cells the tile can reach (one cell of slack each way: a point outside it, or outside the LDS block, goes direct)
-        const int tx = t % v.d->nx, tz = t / v.d->nx;
-        const float T = v.d->tile;
-        const float xa = v.d->x0 + tx * T, xb = v.d->x0 + (tx + 1) * T, za = v.d->z0 + tz * T, zb = v.d->z0 + (tz + 1) * T;
+        const int tx = t % g.nx, tz = t / g.nx;
+        const float T = g.tile;
+        const float xa = g.x0 + tx * T, xb = g.x0 + (tx + 1) * T, za = g.z0 + tz * T, zb = g.z0 + (tz + 1) * T;
         const float r_hi = rintf((-(za - cz) - lo) * sc) + 1.f, r_lo = rintf((-(zb - cz) - lo) * sc) - 1.f;
         const float c_hi = rintf((-(xa - cx) - lo) * sc) + 1.f, c_lo = rintf((-(xb - cx) - lo) * sc) - 1.f;
         if (r_hi < 0.f || r_lo >= (float)S || c_hi < 0.f || c_lo >= (float)S) continue;      // the tile is outside the window
@@ -451,9 +390,10 @@ __global__ __launch_bounds__(256) void bin_append_kernel(char* store, const floa
                                                          float* zero6, float* zero1, int SS) {
     bin_append_body(store, cloud, n_dev ? *n_dev : N, blockIdx.x, gridDim.x, zero6, zero1, SS);
 }
-__global__ __launch_bounds__(256) void map_binned_kernel(MapItem a, char* store, unsigned n_page_wg, int S, float lo, float sc) {
+template <bool SPEC>
+__global__ __launch_bounds__(256) void map_binned_kernel(MapItem a, char* store, unsigned n_page_wg, int S, float lo, float sc, BinStatic g) {
     __shared__ int hist[6 * BIN_R * BIN_R];
-    map_binned_body(a, store, blockIdx.x, n_page_wg, S, lo, sc, hist);
+    map_binned_body<SPEC>(a, store, blockIdx.x, n_page_wg, S, lo, sc, hist, g);
 }
 struct BinBatch { char* store[MAP_BATCH]; unsigned n_page_wg[MAP_BATCH]; };
 __global__ __launch_bounds__(256) void bin_append_batch_kernel(MapBatch b, BinBatch s, int SS) {
@@ -464,7 +404,7 @@ __global__ __launch_bounds__(256) void map_binned_batch_kernel(MapBatch b, BinBa
     __shared__ int hist[6 * BIN_R * BIN_R];
     const unsigned r = blockIdx.y;
     if (blockIdx.x >= s.n_page_wg[r] + BIN_OVF_WGS + 1) return;
-    map_binned_body(b.it[r], s.store[r], blockIdx.x, s.n_page_wg[r], S, lo, sc, hist);
+    map_binned_body<false>(b.it[r], s.store[r], blockIdx.x, s.n_page_wg[r], S, lo, sc, hist);
 }
 
 __global__ __launch_bounds__(256) void bin_init_kernel(char* store, BinDesc d) {
@@ -507,6 +447,17 @@ static BinDesc bin_desc(const float* lo_xz, const float* hi_xz, long long capaci
     d.off_pages = take((unsigned long long)d.max_pages * BIN_PAGE * 12);
     d.total_bytes = off;
     return d;
+}
+// what nbp_cloud_bins_init wrote into a store's header, by store address (a store re-initialised elsewhere, or one the table does not
+// know, is simply read from the device by the launch)
+static std::mutex g_bin_mu;
+static std::unordered_map<const void*, BinDesc> g_bin_known;
+static BinStatic bin_static_of(const void* store) {
+    std::lock_guard<std::mutex> lk(g_bin_mu);
+    const auto it = g_bin_known.find(store);
+    if (it == g_bin_known.end()) return BinStatic{0, 0, 0, 0, 0, 0, 0.f, 0.f, 0.f, 0};
+    const BinDesc& d = it->second;
+    return BinStatic{d.off_count, d.off_info, d.off_ovf, d.off_pages, d.nx, d.max_pages, d.x0, d.z0, d.tile, 1};
 }
 static bool bin_geometry_ok(const float* lo_xz, const float* hi_xz, long long capacity) {
     return lo_xz && hi_xz && capacity > 0 && capacity < 65535ll * BIN_PAGE && hi_xz[0] >= lo_xz[0] && hi_xz[1] >= lo_xz[1] &&
@@ -681,6 +632,11 @@ extern "C" int nbp_cloud_bins_init(void* store, size_t store_bytes, const float*
     const BinDesc d = bin_desc(lo_xz_host, hi_xz_host, capacity);
     NBP_RETURN_IF(store_bytes < d.total_bytes, NBP_E_WS);
     bin_init_kernel<<<1024, 256, 0, (hipStream_t)stream>>>((char*)store, d);
+    {
+        std::lock_guard<std::mutex> lk(g_bin_mu);
+        if (g_bin_known.size() > 4096) g_bin_known.clear();        // (stores come and go with their rollouts: bounded, and only a cache)
+        g_bin_known[store] = d;
+    }
     return nbp_launch_status();
 }
 
@@ -689,10 +645,10 @@ extern "C" int nbp_cloud_bins_init(void* store, size_t store_bytes, const float*
 // the pages in use (the store's max_pages is always safe; a tighter bound launches fewer idle workgroups; one that is too low only
 // costs time: page workgroups stride over every page that exists).
 // traj_pts / net_in5 may both be null: only out6 is produced (the reference-API form accumulate_step_maps).
-extern "C" int nbp_step_maps_binned_f32(void* store, int page_bound, const float* points, long long N, const long long* N_dev_or_null,
-                                        float cx, float cy, float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi,
-                                        int S, float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
-                                        int n_traj_fresh, float* out6, float* net_in5, void* stream) {
+static int step_maps_binned(bool prefiled, void* store, int page_bound, const float* points, long long N, const long long* N_dev_or_null,
+                            float cx, float cy, float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi,
+                            int S, float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
+                            int n_traj_fresh, float* out6, float* net_in5, void* stream) {
     NBP_ENTER();
     (void)cy;
     NBP_RETURN_IF(!store || page_bound < 1 || !out6 || N < 0 || S < 1 || !(hi > lo), NBP_E_ARG);
@@ -714,18 +670,41 @@ extern "C" int nbp_step_maps_binned_f32(void* store, int page_bound, const float
         tr.pts = traj_pts; tr.out = net_in5 + 4 * SS; tr.n_old = n_traj_old; tr.n_fresh = n_traj_fresh;
         for (int i = 0; i < 24; ++i) tr.fresh[i] = i < 3 * n_traj_fresh ? traj_fresh_host[i] : 0.f;
     }
-    {       // files the new points AND clears the maps / the trajectory channel (no memset launches)
+    if (!prefiled) {       // files the new points AND clears the maps / the trajectory channel (no memset launches)
         bin_append_kernel<<<BIN_APPEND_WGS, 256, 0, st>>>((char*)store, points, N, N_dev_or_null, out6, tr.out, (int)SS);
         const int rc0 = nbp_launch_status();
         if (rc0) return rc0;
     }
-    map_binned_kernel<<<(unsigned)page_bound + BIN_OVF_WGS + 1, 256, 0, st>>>(
-        MapItem{points, N, N_dev_or_null, cx, cz, bd, band_lo, band_hi, out6, tr}, (char*)store, (unsigned)page_bound, S, lo,
-        grid_scale(S, lo, hi));
+    // NBP_MAP_SPEC=1 (A/B): whole pages are loaded without waiting for their tile's count (one dependent load less, partial pages
+    // read in full); measured within the box-to-box noise of the count-bounded form (profiles/r06/scatter_one_launch.txt)
+    static const bool spec = nbp_tune_int("NBP_MAP_SPEC", 0) != 0;
+    const MapItem item{points, N, N_dev_or_null, cx, cz, bd, band_lo, band_hi, out6, tr};
+    const unsigned n_wg = (unsigned)page_bound + BIN_OVF_WGS + 1;
+    if (spec) map_binned_kernel<true><<<n_wg, 256, 0, st>>>(item, (char*)store, (unsigned)page_bound, S, lo, grid_scale(S, lo, hi), bin_static_of(store));
+    else map_binned_kernel<false><<<n_wg, 256, 0, st>>>(item, (char*)store, (unsigned)page_bound, S, lo, grid_scale(S, lo, hi), bin_static_of(store));
     int rc = nbp_launch_status();
     if (rc || !net_in5) return rc;
     e = hipMemcpyAsync(net_in5, out6, 4 * SS * sizeof(float), hipMemcpyDeviceToDevice, st);
     return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int nbp_step_maps_binned_f32(void* store, int page_bound, const float* points, long long N, const long long* N_dev_or_null,
+                                        float cx, float cy, float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi,
+                                        int S, float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
+                                        int n_traj_fresh, float* out6, float* net_in5, void* stream) {
+    return step_maps_binned(false, store, page_bound, points, N, N_dev_or_null, cx, cy, cz, bounds_host, n_bounds, band_lo, band_hi, S, lo, hi,
+                            traj_pts, n_traj_old, traj_fresh_host, n_traj_fresh, out6, net_in5, stream);
+}
+
+// The same build as ONE launch (map_binned_kernel alone), for a store whose points were filed by the launch that appended them to
+// the cloud and whose outputs that launch cleared (nbp_unproject_append_filed_f32 with store / zero6 = out6 / zero1 = net_in5 + 4 S^2).
+// Points the store has not seen (appended by any other route since the last filing launch) are still counted -- directly, slowly.
+extern "C" int nbp_step_maps_prefiled_f32(void* store, int page_bound, const float* points, long long N, const long long* N_dev_or_null,
+                                          float cx, float cy, float cz, const float* bounds_host, int n_bounds, float band_lo, float band_hi,
+                                          int S, float lo, float hi, float* traj_pts, int n_traj_old, const float* traj_fresh_host,
+                                          int n_traj_fresh, float* out6, float* net_in5, void* stream) {
+    return step_maps_binned(true, store, page_bound, points, N, N_dev_or_null, cx, cy, cz, bounds_host, n_bounds, band_lo, band_hi, S, lo, hi,
+                            traj_pts, n_traj_old, traj_fresh_host, n_traj_fresh, out6, net_in5, stream);
 }
 
 // nbp_step_maps_batch_f32 on the rollouts' binned copies (stores[n], page_bound[n]: HOST arrays)

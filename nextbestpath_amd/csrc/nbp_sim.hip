@@ -233,6 +233,14 @@ __device__ __forceinline__ void unproject_compact4_body(unsigned bx, unsigned by
     }
 }
 
+// ---- filing into the cloud's tile-binned shadow copy (nbp_bins.h; csrc/nbp_maps.hip builds the maps from it).  A launch that gets a
+// store files every point it appends (the point is in registers anyway) and clears the buffers the map build behind it accumulates
+// into, so that the build of a single rollout is ONE launch (nbp_step_maps_prefiled_f32) instead of bin_append_kernel + map_binned_kernel.
+// It files only while the store is in step with the cloud (n_binned == *cloud_count at entry, launch-uniform: both are advanced by
+// the last workgroup only); otherwise the points stay unfiled and the next build counts them directly / bin_append_kernel files them.
+#include "nbp_bins.h"
+struct BinFile { char* store; float* zero6; float* zero1; int SS; };
+
 // K2: gather the sub-sample and append it to the cloud at *cloud_count + sum of earlier frames.
 __device__ __forceinline__ void unproject_append_body(unsigned bx, unsigned by, unsigned gx, unsigned gy, const float* __restrict__ depth, const Cam* cams,
                                                                int H, int W, float tanh_fov, unsigned seed,
@@ -243,23 +251,47 @@ __device__ __forceinline__ void unproject_append_body(unsigned bx, unsigned by, 
                                                                const float* __restrict__ rgb, float* __restrict__ cloud_rgb,
                                                                const unsigned long long* __restrict__ zface,
                                                                const float* __restrict__ verts, const int* __restrict__ faces,
-                                                               const float* __restrict__ vcolors, float ambient, int fence = 0) {
+                                                               const float* __restrict__ vcolors, float ambient, int fence = 0,
+                                                               BinFile bf = BinFile{nullptr, nullptr, nullptr, 0}) {
     const int f = by;
     const int HW = H * W;
     const int nvalid = counts[2 * f], nkeep = counts[2 * f + 1];
-    long long base = *cloud_count;
+    const long long count0 = *cloud_count;
+    long long base = count0;
     for (int g = 0; g < f; ++g) base += counts[2 * g + 1];
     const unsigned bits = perm_bits((unsigned)nvalid);
     const unsigned sd = seed + 0x632BE5ABu * (unsigned)(f + 1);
     const Cam cam = cams[f];
-    for (int j = bx * blockDim.x + threadIdx.x; j < nkeep; j += gx * blockDim.x) {
-        if (base + j >= capacity) break;
-        const unsigned pix = list[(size_t)f * HW + perm_index((unsigned)j, (unsigned)nvalid, bits, sd)];
-        const int row = (int)(pix / (unsigned)W), col = (int)(pix - (unsigned)row * W);
-        float o[3];
-        unproject_pixel(row, col, depth[(size_t)f * HW + pix], H, W, tanh_fov, cam.R, cam.T, o);
-        float* dst = cloud + (base + j) * 3;
-        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+    // the store, when given and in step with the cloud: filing needs whole waves in the loop (ballots), hence the rounded trip count
+    BinView bv{};
+    BinGeom bg{};
+    bool in_step = false, filing = false;
+    if (bf.store) {
+        bin_clear_maps(bf.zero6, bf.zero1, bf.SS, by * gx + bx, gx * gy);
+        bv = bin_view(bf.store);
+        in_step = bv.d->n_binned == count0;
+        filing = in_step && bv.d->error == 0u;            // (a broken store files nothing more: its builds scan the cloud)
+        if (filing) bg = bin_geom(bv);
+    }
+    const int step = (int)(gx * blockDim.x);
+    const int n_trip = filing ? (nkeep + 63) / 64 * 64 : nkeep;
+    for (int j = bx * blockDim.x + threadIdx.x; j < n_trip; j += step) {
+        const bool active = j < nkeep && base + j < capacity;
+        if (!filing && !active) break;
+        bins_f32x3 pt = {__builtin_nanf(""), 0.f, 0.f};
+        unsigned pix = 0;
+        int row = 0, col = 0;
+        if (active) {
+            pix = list[(size_t)f * HW + perm_index((unsigned)j, (unsigned)nvalid, bits, sd)];
+            row = (int)(pix / (unsigned)W); col = (int)(pix - (unsigned)row * W);
+            float o[3];
+            unproject_pixel(row, col, depth[(size_t)f * HW + pix], H, W, tanh_fov, cam.R, cam.T, o);
+            float* dst = cloud + (base + j) * 3;
+            dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+            pt = bins_f32x3{o[0], o[1], o[2]};
+        }
+        if (filing) bin_file_wave(bv, bg, active, pt, base + j);
+        if (!active) continue;
         if (cloud_rgb) {                                   // the colours of the kept pixels (mu:2840-2845)
             float* cd = cloud_rgb + (base + j) * 3;
             if (zface) {                                   // deferred shading: only the ~5 % of pixels that are kept
@@ -290,6 +322,7 @@ __device__ __forceinline__ void unproject_append_body(unsigned bx, unsigned by, 
         long long n = *cloud_count;
         for (int g = 0; g < n_frames; ++g) n += counts[2 * g + 1];
         *cloud_count = n < capacity ? n : capacity;
+        if (in_step) bv.d->n_binned = n < capacity ? n : capacity;      // filed, or a broken store (whose builds scan the cloud)
         *done_ticket = 0;
     }
 }
@@ -341,9 +374,9 @@ __global__ __launch_bounds__(256) void unproject_append_kernel(const float* __re
                                                                int* __restrict__ done_ticket, const float* __restrict__ rgb,
                                                                float* __restrict__ cloud_rgb, const unsigned long long* __restrict__ zface,
                                                                const float* __restrict__ verts, const int* __restrict__ faces,
-                                                               const float* __restrict__ vcolors, float ambient, int fence) {
+                                                               const float* __restrict__ vcolors, float ambient, int fence, BinFile bf) {
     unproject_append_body(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, depth, cams.c, H, W, tanh_fov, seed, list, counts, cloud, cloud_count,
-                          capacity, n_frames, done_ticket, rgb, cloud_rgb, zface, verts, faces, vcolors, ambient, fence);
+                          capacity, n_frames, done_ticket, rgb, cloud_rgb, zface, verts, faces, vcolors, ambient, fence, bf);
 }
 __global__ __launch_bounds__(256) void unproject_append_batch_kernel(UnprojBatch b, int H, int W, float tanh_fov, int n_frames, float ambient,
                                                                      int fence) {
@@ -922,7 +955,8 @@ struct ShadeSrc { const unsigned long long* zface; const float* verts; const int
 static int unproject_launch(const float* depth, const unsigned char* mask_or_null, const float* cams12_host, int n_frames, int H,
                             int W, float tan_half_fov, float fov_range, double gathering_factor, unsigned seed, int* counts2,
                             float* cloud, long long* cloud_count, long long capacity, void* ws, size_t ws_bytes, void* stream,
-                            const float* rgb_or_null, float* cloud_rgb_or_null, ShadeSrc sh = ShadeSrc{nullptr, nullptr, nullptr, nullptr, 0.f});
+                            const float* rgb_or_null, float* cloud_rgb_or_null, ShadeSrc sh = ShadeSrc{nullptr, nullptr, nullptr, nullptr, 0.f},
+                            BinFile bf = BinFile{nullptr, nullptr, nullptr, 0});
 
 extern "C" int nbp_unproject_append_f32(const float* depth, const unsigned char* mask_or_null, const float* cams12_host,
                                         int n_frames, int H, int W, float tan_half_fov, float fov_range,
@@ -958,10 +992,35 @@ extern "C" int nbp_unproject_append_shaded_f32(const float* depth, const unsigne
                             ShadeSrc{(const unsigned long long*)zface, verts, faces, vcolors3, ambient});
 }
 
+// nbp_unproject_append_f32 / _rgb_f32 / _shaded_f32 (by which colour source is given: none, rgb, or zface + verts + faces + vcolors3)
+// that also FILES the appended points into the cloud's tile-binned store (nbp_cloud_bins_init) and, when zero6 / zero1 are given,
+// clears the 6 S^2 / S^2 floats the map build behind it accumulates into: that build is then nbp_step_maps_prefiled_f32, one launch.
+extern "C" int nbp_unproject_append_filed_f32(const float* depth, const unsigned char* mask_or_null, const float* rgb_or_null,
+                                              const void* zface_or_null, const float* verts, const int* faces, const float* vcolors3,
+                                              const float* cams12_host, int n_frames, int H, int W, float tan_half_fov,
+                                              float fov_range, double gathering_factor, unsigned seed, float ambient, int* counts2,
+                                              float* cloud, float* cloud_rgb_or_null, long long* cloud_count, long long capacity,
+                                              void* bins_store, float* zero6_or_null, float* zero1_or_null, int S, void* ws,
+                                              size_t ws_bytes, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!bins_store || ((uintptr_t)bins_store & 255), NBP_E_ARG);
+    NBP_RETURN_IF(rgb_or_null && zface_or_null, NBP_E_ARG);
+    NBP_RETURN_IF((rgb_or_null || zface_or_null) && !cloud_rgb_or_null, NBP_E_ARG);
+    NBP_RETURN_IF(zface_or_null && (!verts || !faces || !vcolors3), NBP_E_ARG);
+    const long long SS = (long long)S * S;
+    if (zero6_or_null || zero1_or_null)
+        NBP_RETURN_IF(S < 1 || SS % 4 != 0 || 6 * SS >= (1ll << 31) || ((uintptr_t)zero6_or_null & 15) || ((uintptr_t)zero1_or_null & 15), NBP_E_SHAPE);
+    const bool colours = rgb_or_null || zface_or_null;
+    return unproject_launch(depth, mask_or_null, cams12_host, n_frames, H, W, tan_half_fov, fov_range, gathering_factor, seed,
+                            counts2, cloud, cloud_count, capacity, ws, ws_bytes, stream, rgb_or_null, colours ? cloud_rgb_or_null : nullptr,
+                            ShadeSrc{(const unsigned long long*)zface_or_null, verts, faces, vcolors3, ambient},
+                            BinFile{(char*)bins_store, zero6_or_null, zero1_or_null, (int)SS});
+}
+
 static int unproject_launch(const float* depth, const unsigned char* mask_or_null, const float* cams12_host, int n_frames, int H,
                             int W, float tan_half_fov, float fov_range, double gathering_factor, unsigned seed, int* counts2,
                             float* cloud, long long* cloud_count, long long capacity, void* ws, size_t ws_bytes, void* stream,
-                            const float* rgb_or_null, float* cloud_rgb_or_null, ShadeSrc sh) {
+                            const float* rgb_or_null, float* cloud_rgb_or_null, ShadeSrc sh, BinFile bf) {
     NBP_ENTER();
     NBP_RETURN_IF(!depth || !cams12_host || !counts2 || !cloud || !cloud_count || !ws, NBP_E_ARG);
     NBP_RETURN_IF(n_frames < 1 || n_frames > MAX_CAMS || H < 2 || W < 2 || capacity < 1, NBP_E_ARG);
@@ -977,6 +1036,8 @@ static int unproject_launch(const float* depth, const unsigned char* mask_or_nul
     dim3 grid((unsigned)nbp_cdiv(max_keep, 256), (unsigned)n_frames);
     int rc;
     const bool fast = (HW & 3) == 0 && ((uintptr_t)depth & 15) == 0 && (!mask_or_null || ((uintptr_t)mask_or_null & 3) == 0);
+    // filing rides on the three-launch form (its last workgroup advances the store with the cloud)
+    NBP_RETURN_IF(bf.store && !fast, NBP_E_SHAPE);
     if (fast) {
         // three launches: chunk counts (also resets the ticket), ordered compaction, gather + append + size update
         const int nb4 = (int)nbp_cdiv(HW, FAST_CHUNK);             // <= nblk: the workspace is sized for 2048-pixel chunks
@@ -987,9 +1048,10 @@ static int unproject_launch(const float* depth, const unsigned char* mask_or_nul
         unproject_compact4_kernel<<<g4, 256, 0, st>>>(depth, mask_or_null, HW, nb4, fov_range, gathering_factor, blk_count, list,
                                                       counts2);
         if ((rc = nbp_launch_status())) return rc;
+        if (bf.store && (bf.zero6 || bf.zero1) && grid.x * grid.y < 64u) grid.x = (64u + grid.y - 1) / grid.y;      // enough workgroups for the clear
         unproject_append_kernel<<<grid, 256, 0, st>>>(depth, cams, H, W, tan_half_fov, seed, list, counts2, cloud, cloud_count,
                                                       capacity, n_frames, ticket, rgb_or_null, cloud_rgb_or_null, sh.zface, sh.verts, sh.faces,
-                                                      sh.vcolors, sh.ambient, ticket_fence());
+                                                      sh.vcolors, sh.ambient, ticket_fence(), bf);
         return nbp_launch_status();
     }
     dim3 gc((unsigned)nblk, (unsigned)n_frames);
@@ -1000,7 +1062,7 @@ static int unproject_launch(const float* depth, const unsigned char* mask_or_nul
     if ((rc = nbp_launch_status())) return rc;
     unproject_append_kernel<<<grid, 256, 0, st>>>(depth, cams, H, W, tan_half_fov, seed, list, counts2, cloud, cloud_count,
                                                   capacity, n_frames, nullptr, rgb_or_null, cloud_rgb_or_null, sh.zface, sh.verts, sh.faces,
-                                                  sh.vcolors, sh.ambient, 0);
+                                                  sh.vcolors, sh.ambient, 0, BinFile{nullptr, nullptr, nullptr, 0});
     if ((rc = nbp_launch_status())) return rc;
     cloud_count_update_kernel<<<1, 64, 0, st>>>(counts2, n_frames, cloud_count, capacity);
     return nbp_launch_status();

@@ -546,6 +546,46 @@ __global__ __launch_bounds__(256) void ew4_kernel(int op, const float* __restric
     }
 }
 
+// out[m][c] = sum_k src_k[m ld_k + c], k = 0 .. n - 1 in that order (fp32, left to right: deterministic): the gradient of a tensor with
+// n consumers in ONE pass (n reads, one write) instead of autograd's n - 1 binary adds (3 (n - 1) passes).  A source may be a channel
+// slice of a wider tensor (row stride ld_k >= C floats: ConvFn.backward hands out views of a two-source convolution's joint gradient).
+constexpr int SUM_N_MAX = 8;
+struct SumNArgs { const float* src[SUM_N_MAX]; long long ld4[SUM_N_MAX]; int n; };
+__global__ __launch_bounds__(256) void sum_n4_kernel(SumNArgs a, long long M, int C4, float* __restrict__ out) {
+    // a thread stays on one float4 column (256 % C4 == 0 for every channel count of the network; wider rows take several columns) and
+    // walks rows: no division per element, ROWS rows of every source in flight
+    constexpr int ROWS = 2;
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    const int CT = C4 < 256 ? C4 : 256, rpb = 256 / CT;
+    const int c_local = threadIdx.x % CT, rsub = threadIdx.x / CT;
+    if (rsub >= rpb) return;
+    const long long rstep = (long long)gridDim.x * rpb;
+    for (int c = c_local; c < C4; c += CT)
+        for (long long r = (long long)blockIdx.x * rpb + rsub; r < M; r += ROWS * rstep) {
+            f32x4 v[ROWS][SUM_N_MAX];
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                const long long ru = r + u * rstep;
+                if (ru < M) {
+#pragma unroll
+                    for (int k = 0; k < SUM_N_MAX; ++k)
+                        if (k < a.n) v[u][k] = reinterpret_cast<const f32x4*>(a.src[k])[ru * a.ld4[k] + c];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                const long long ru = r + u * rstep;
+                if (ru < M) {
+                    f32x4 s = v[u][0];
+#pragma unroll
+                    for (int k = 1; k < SUM_N_MAX; ++k)
+                        if (k < a.n) s += v[u][k];
+                    o4[ru * C4 + c] = s;
+                }
+            }
+        }
+}
+
 // amax_out (or null): 64 zeroed words that receive max |out| -- the gated tensor feeds a split convolution, whose operand scale would
 // otherwise cost a pass of its own over the tensor
 __global__ __launch_bounds__(256) void rowscale4_kernel(const float* __restrict__ x, const float* __restrict__ s,
@@ -1377,6 +1417,24 @@ extern "C" int nbp_elementwise_f32(int op, const float* a, const float* b, long 
     const bool al16 = (((uintptr_t)a | (uintptr_t)out | (uintptr_t)(op == 2 || op == 5 ? a : b)) & 15) == 0;
     if (n % 4 == 0 && al16) ew4_kernel<<<nbp_ew_grid(n / 4, 256), 256, 0, (hipStream_t)stream>>>(op, a, b, n / 4, out);
     else ew_kernel<<<nbp_ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(op, a, b, n, out);
+    return nbp_launch_status();
+}
+
+extern "C" int nbp_sum_n_f32(int n, const float* const* srcs_host, const long long* ld_host, long long M, int C, float* out, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(n < 1 || n > SUM_N_MAX || !srcs_host || !ld_host || !out || M < 1 || C < 4 || C % 4 != 0 || ((uintptr_t)out & 15), NBP_E_ARG);
+    SumNArgs a = {};
+    a.n = n;
+    for (int k = 0; k < n; ++k) {
+        NBP_RETURN_IF(!srcs_host[k] || ((uintptr_t)srcs_host[k] & 15) || ld_host[k] < C || ld_host[k] % 4 != 0, NBP_E_ARG);
+        a.src[k] = srcs_host[k]; a.ld4[k] = ld_host[k] / 4;
+    }
+    {
+        const int C4 = C / 4, rpb = 256 / (C4 < 256 ? C4 : 256);
+        long long blocks = (M + 2ll * rpb - 1) / (2ll * rpb);
+        if (blocks > 8192) blocks = 8192;
+        sum_n4_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(a, M, C4, out);
+    }
     return nbp_launch_status();
 }
 

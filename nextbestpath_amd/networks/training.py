@@ -640,6 +640,65 @@ class BNFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None
 
 
+# An activation with several consumers (the encoder skips: max-pool + two uses per attention gate; x5 and every up_conv output: two)
+# goes through FanOutFn: n aliases forward, and the consumers' gradients meet in ONE n-ary sum launch (csrc/nbp_train.hip:
+# sum_n4_kernel, n reads + 1 write) instead of autograd's n - 1 binary adds (3 (n - 1) tensor passes; 19 ATen launches per step).
+# NBP_TRAIN_FANOUT=0: autograd sums (round 5).
+_FANOUT = _lib.tune("NBP_TRAIN_FANOUT", "1") == "1"
+
+
+class FanOutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        live = [g for g in grads if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        shp = live[0].shape
+        C = shp[-1]
+        M = live[0].numel() // C
+        ok = C % 4 == 0 and len(live) <= 8
+        srcs, lds = [], []
+        for g in live:
+            # a contiguous tensor, or a channel slice of a wider NHWC tensor (rows ld floats apart): read in place
+            ld = g.stride(-2) if g.dim() >= 2 else C
+            dense = g.dim() == 4 and g.stride(3) == 1 and ld >= C and ld % 4 == 0 and g.stride(1) == shp[2] * ld and \
+                g.stride(0) == shp[1] * shp[2] * ld and g.data_ptr() % 16 == 0
+            if not dense:
+                g, ld = g.contiguous(), C
+                ok = ok and g.data_ptr() % 16 == 0
+            srcs.append(g)
+            lds.append(ld)
+        if not ok:
+            out = srcs[0] + srcs[1]
+            for g in srcs[2:]:
+                out = out + g
+            return out, None
+        out = torch.empty(shp, dtype=torch.float32, device=live[0].device)
+        n = len(srcs)
+        ptrs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in srcs])
+        ldv = (ctypes.c_longlong * n)(*lds)
+        _chk(_lib.lib().nbp_sum_n_f32(n, ptrs, ldv, M, C, _lib.ptr(out), _st()), "sum_n")
+        return out, None
+
+
+def _fan(x, n):
+    """n aliases of x for its n consumers (each keeps what the producer noted about x)."""
+    if not (_FANOUT and n > 1 and torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    outs = FanOutFn.apply(x, n)
+    note = getattr(x, "_nbp_note", None)
+    if note is not None:
+        for o in outs:
+            o._nbp_note = dict(note)
+    return outs
+
+
 class MaxPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -883,14 +942,14 @@ def _up_conv(seq, x, name=""):
     return _bn(seq[2], y, True, name + ".up.2")
 
 
-def _gate(att, g, x, name=""):
-    """Attention_block (ref :36-62)."""
+def _gate(att, g, x, name="", x_scale=None):
+    """Attention_block (ref :36-62).  x_scale: the alias of x the final x * psi reads (FanOutFn), x itself when None."""
     g1 = _bn(att.W_g[1], _t(name + ".W_g.0", ConvFn.apply(g, None, att.W_g[0].weight, att.W_g[0].bias, False)), False, name + ".W_g.1")
     x1 = _bn(att.W_x[1], _t(name + ".W_x.0", ConvFn.apply(x, None, att.W_x[0].weight, att.W_x[0].bias, False)), False, name + ".W_x.1")
     q = _t(name + ".q", AddReluFn.apply(g1, x1))
     p = _t(name + ".psi.0", PsiConvFn.apply(q, att.psi[0].weight, att.psi[0].bias))
     psi = _t(name + ".psi", SigmoidFn.apply(_bn(att.psi[1], p, False, name + ".psi.1")))
-    return _t(name + ".out", RowScaleFn.apply(x, psi))
+    return _t(name + ".out", RowScaleFn.apply(x if x_scale is None else x_scale, psi))
 
 
 def forward_train(net, x):
@@ -925,18 +984,28 @@ def _forward_train(net, x, L, B, S, dev):
         _chk(L.nbp_nchw_to_nhwc_f32(_lib.ptr(x.contiguous().float()), B, 5, S, S, _lib.ptr(xh), _st()), "to_nhwc")
         x0 = _pad_channels(xh, 64)
         x1 = _block(net.Conv1.conv, x0, None, "Conv1")
-    x2 = _block(net.Conv2.conv, _t("pool1", MaxPoolFn.apply(x1)), None, "Conv2")
-    x3 = _block(net.Conv3.conv, _t("pool2", MaxPoolFn.apply(x2)), None, "Conv3")
-    x4 = _block(net.Conv4.conv, _t("pool3", MaxPoolFn.apply(x3)), None, "Conv4")
-    x5 = _block(net.Conv5.conv, _t("pool4", MaxPoolFn.apply(x4)), None, "Conv5")
-    skips = {5: x4, 4: x3, 3: x2, 2: x1}
+    # every tensor with several consumers goes through _fan: its gradient is one n-ary sum (the skips x1 .. x4 feed the max-pool and,
+    # per decoder that reaches their level, a gate's W_x convolution and its x * psi; x5 both decoders; an up_conv output the gate's
+    # W_g convolution and the block behind the gate)
+    f1 = _fan(x1, 3)
+    x2 = _block(net.Conv2.conv, _t("pool1", MaxPoolFn.apply(f1[0])), None, "Conv2")
+    f2 = _fan(x2, 3)
+    x3 = _block(net.Conv3.conv, _t("pool2", MaxPoolFn.apply(f2[0])), None, "Conv3")
+    f3 = _fan(x3, 5)
+    x4 = _block(net.Conv4.conv, _t("pool3", MaxPoolFn.apply(f3[0])), None, "Conv4")
+    f4 = _fan(x4, 5)
+    x5 = _block(net.Conv5.conv, _t("pool4", MaxPoolFn.apply(f4[0])), None, "Conv5")
+    f5 = _fan(x5, 2)
+    # (level, decoder) -> the two aliases of the skip that decoder's gate reads
+    skips = {(5, 1): f4[1:3], (5, 2): f4[3:5], (4, 1): f3[1:3], (4, 2): f3[3:5], (3, 2): f2[1:3], (2, 2): f1[1:3]}
     outs = {}
     for d, levels in ((1, (5, 4)), (2, (5, 4, 3, 2))):
-        cur = x5
+        cur = f5[d - 1]
         for Lv in levels:
-            dd = _up_conv(getattr(net, f"Up{Lv}_{d}").up, cur, f"Up{Lv}_{d}")
-            a = _gate(getattr(net, f"Att{Lv}_{d}"), dd, skips[Lv], f"Att{Lv}_{d}")
-            cur = _block(getattr(net, f"Up_conv{Lv}_{d}").conv, a, dd, f"Up_conv{Lv}_{d}")
+            dd = _fan(_up_conv(getattr(net, f"Up{Lv}_{d}").up, cur, f"Up{Lv}_{d}"), 2)
+            sk = skips[(Lv, d)]
+            a = _gate(getattr(net, f"Att{Lv}_{d}"), dd[0], sk[0], f"Att{Lv}_{d}", x_scale=sk[1])
+            cur = _block(getattr(net, f"Up_conv{Lv}_{d}").conv, a, dd[1], f"Up_conv{Lv}_{d}")
         outs[d] = cur
     o1 = ConvFn.apply(outs[1], None, net.Final1.weight, net.Final1.bias, False)          # [B,S/4,S/4,8]
     out1 = ToNCHWFn.apply(o1)

@@ -42,6 +42,9 @@ _FWD_GRAPH = int(_lib.tune("NBP_FWD_GRAPH", "1"))
 _STEP_OVERLAP = _lib.tune("NBP_STEP_OVERLAP", "1") == "1"
 # the step's maps from the tile-binned shadow copy of the cloud (utils.CloudBins; bit-identical maps): 0 = the append-order kernel
 _MAP_BINS = _lib.tune("NBP_MAP_BINS", "1") == "1"
+# single rollout: the un-projection launches file the points they append into the bins and clear the maps, so that the step's map
+# build is ONE launch (nbp_step_maps_prefiled_f32; bit-identical maps): 0 = bin_append_kernel + map_binned_kernel per build
+_MAP_PREFILED = _lib.tune("NBP_MAP_PREFILED", "1") == "1"
 
 
 class RolloutState:
@@ -57,6 +60,7 @@ class RolloutState:
         self.net_in = torch.zeros(1, 5, grid, grid, dtype=torch.float32, device=device)
         self.bins = None             # utils.CloudBins of `cloud` (made by the rollout: the tile grid needs the scene's extent)
         self.frames_appended = 0     # frames un-projected into the cloud so far (host bound of its size: <= that many x per-frame keep)
+        self.frames_filed = 0        # ... of which the bins have seen (filed by the appending launch, or caught up by a two-launch build)
         self._overlap = None         # forward_overlap(): two network inputs / streams / event pairs, used alternately
 
     def forward_overlap(self):
@@ -111,6 +115,7 @@ class Rollout:
         self.st.cloud_count.zero_()
         self.st.coverage_counts.zero_()
         self.st.frames_appended = 0
+        self.st.frames_filed = 0
         if _MAP_BINS:
             vh = np.asarray(mesh.verts_host, np.float32)
             lo, hi = (float(vh[:, 0].min()), float(vh[:, 2].min())), (float(vh[:, 0].max()), float(vh[:, 2].max()))
@@ -136,15 +141,22 @@ class Rollout:
     # rollouts and share one stream synchronisation per step; step() is the single-rollout composition.
     def pre(self, net_in=None):
         """S2-S8: coverage, un-projection of the current frame, maps, replan decision.  No host sync."""
-        self.pre_observe()
         st, S = self.st, self.S
         net_in = st.net_in if net_in is None else net_in
+        # the bins are in step with the cloud (every frame so far was filed): this step's un-projection files its points too and
+        # clears the maps, and the build below is the page launch alone
+        prefiled = _MAP_PREFILED and _STEP_MAPS and st.bins is not None and st.frames_filed == st.frames_appended
+        self.pre_coverage()
+        self.pre_unproject(clear=(st.maps6, net_in[0, 4]) if prefiled else None)
+        prefiled = prefiled and st.frames_filed == st.frames_appended
         # S5-S7 in one call: six maps, trajectory channel, network input (was seven launches: accumulate_step_maps,
         # transform_points_to_n_pieces, map_points_to_n_imgs and two copies)
         if _STEP_MAPS:
             full_pc, n_upper, n_dev, pose, y_bins, traj_dev, n_old, fresh, bins = self.maps_item()
             hu.step_maps(full_pc, pose, y_bins, S, self.grid_range, traj_dev, n_old, fresh, st.maps6, net_in[0], n_dev=n_dev,
-                         bins=bins, n_upper=n_upper)
+                         bins=bins, n_upper=n_upper, prefiled=prefiled)
+            if bins is not None:
+                st.frames_filed = st.frames_appended   # (a two-launch build files whatever the store had not seen)
             self.traj_img = net_in[0, 4]               # stays valid until this rollout's next pre()
         else:
             hu.accumulate_step_maps(st.cloud, self.pose, self.y_bins, S, self.grid_range, n_dev=st.cloud_count, out=st.maps6)
@@ -169,14 +181,23 @@ class Rollout:
         self.cov_plan.count(st.cloud, st.coverage_counts[pose_i % N_POSES], n_dev=st.cloud_count, n=st.cloud.shape[0],
                             seed=self.step_seed + 7 * pose_i, out_is_zero=pose_i < N_POSES)
 
-    def pre_unproject(self):
+    def _filing(self, depth):
+        """The bins, when this un-projection call may file into them (in step with the cloud, three-launch form), else None."""
+        st = self.st
+        ok = _MAP_PREFILED and st.bins is not None and st.frames_filed == st.frames_appended and hipops.unproject_files(depth, None)
+        return st.bins if ok else None
+
+    def pre_unproject(self, clear=None):
         st, camera, params, pose_i = self.st, self.camera, self.params, self.pose_i
         depth, cams = camera.frames_batch([-1])
         colour = camera.colour_source([-1])
+        bins = self._filing(depth)
         hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
                                 params.sensor_range, seed=self.step_seed + 11 * pose_i,
-                                cloud_rgb=st.cloud_rgb if colour else None, **colour)
+                                cloud_rgb=st.cloud_rgb if colour else None, bins=bins, clear=clear if bins is not None else None, **colour)
         st.frames_appended += 1
+        if bins is not None:
+            st.frames_filed += 1
         self.pose, _ = camera.get_pose_from_idx(camera.cam_idx)
 
     def maps_item(self):
@@ -222,10 +243,13 @@ class Rollout:
         camera.move_and_capture(self.mesh, next_idx)
         depth, cams = camera.frames_batch([-5, -4, -3, -2])
         colour = camera.colour_source([-5, -4, -3, -2])
+        bins = self._filing(depth)
         hipops.unproject_append(depth, None, cams, st.cloud, st.cloud_count, params.gathering_factor,
                                 params.sensor_range, seed=self.step_seed + 11 * self.pose_i + 5,
-                                cloud_rgb=st.cloud_rgb if colour else None, **colour)
+                                cloud_rgb=st.cloud_rgb if colour else None, bins=bins, **colour)
         st.frames_appended += 4
+        if bins is not None:
+            st.frames_filed += 4
         self.post_finish()
 
     def post_choose(self):

@@ -56,11 +56,20 @@ def _cam_arg(cams):
     return a, a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0]
 
 
+def unproject_files(depth, mask):
+    """Can unproject_append(..., bins=) file this call's points?  (The filing rides on the three-launch form: H W % 4 == 0, 16-byte
+    aligned frames.)"""
+    F_, H, W = depth.shape
+    return (H * W) % 4 == 0 and depth.data_ptr() % 16 == 0 and (mask is None or mask.data_ptr() % 4 == 0)
+
+
 def unproject_append(depth, mask, cams, cloud, cloud_count, gathering_factor=0.05, fov_range=70.0, seed=0,
-                     tan_half_fov=TAN_HALF_FOV, rgb=None, cloud_rgb=None, shade=None):
+                     tan_half_fov=TAN_HALF_FOV, rgb=None, cloud_rgb=None, shade=None, bins=None, clear=None):
     """depth [F,H,W] fp32 (F <= 8), mask [F,H,W] uint8|None, cams host [F,12]; appends to cloud [cap,3] at the
     device counter cloud_count (int64[1]).  Returns counts [F,2] int32 (device): a VIEW into this stream's scratch, valid
-    until the next unproject_append on the same stream -- clone it to keep it."""
+    until the next unproject_append on the same stream -- clone it to keep it.
+    bins (utils.CloudBins of `cloud`): the launch also files the appended points into the tile-binned store; clear = (maps6 [6,S,S],
+    traj [S,S]): ... and zeroes what the map build behind it accumulates into (utils.step_maps(..., prefiled=True): one launch)."""
     F_, H, W = depth.shape
     if F_ > 8:
         raise ValueError("unproject_append: at most 8 frames per call")
@@ -68,6 +77,20 @@ def unproject_append(depth, mask, cams, cloud, cloud_count, gathering_factor=0.0
     keep, cam_ptr, _ = _cam_arg(cams)
     ws = _workspace_for("unproject", (F_, H, W), lambda: L.nbp_unproject_workspace_bytes(F_, H, W) + 256, depth.device)
     counts = ws[-64:].view(torch.int32).reshape(8, 2)[:F_]          # per-stream scratch: no allocation per call
+    if bins is not None:
+        zface = verts = faces = vcolors = None
+        ambient = 0.85
+        if shade is not None:
+            zface, verts, faces, vcolors, ambient = shade
+            rgb = None
+        z6, z1, S = (None, None, 0) if clear is None else (clear[0], clear[1], int(clear[0].shape[-1]))
+        rc = L.nbp_unproject_append_filed_f32(_lib.ptr(depth), _lib.ptr(mask), _lib.ptr(rgb), _lib.ptr(zface), _lib.ptr(verts),
+                                              _lib.ptr(faces), _lib.ptr(vcolors), cam_ptr, F_, H, W, tan_half_fov, float(fov_range),
+                                              float(gathering_factor), int(seed) & 0xFFFFFFFF, float(ambient), _lib.ptr(counts),
+                                              _lib.ptr(cloud), _lib.ptr(cloud_rgb), _lib.ptr(cloud_count), cloud.shape[0],
+                                              bins.store.data_ptr(), _lib.ptr(z6), _lib.ptr(z1), S, _lib.ptr(ws), ws.numel(), _st())
+        _lib.check(rc, "nbp_unproject_append_filed_f32")
+        return counts
     if shade is not None:      # deferred shading: (zface [F,H,W] int64, verts, faces, vcolors, ambient) -> colours of kept pixels
         zface, verts, faces, vcolors, ambient = shade
         rc = L.nbp_unproject_append_shaded_f32(_lib.ptr(depth), _lib.ptr(mask), _lib.ptr(zface), _lib.ptr(verts), _lib.ptr(faces),

@@ -5,9 +5,9 @@
 Record schema and value encoding are the reference's: a msgpack map with 'current_model_input' [1,5,S,S] f32,
 'current_gt_2d_layout' [1,1,S,S] f32, 'target_value_map_pixel' [K,3] i64 (heading, row, col),
 'actual_coverage_gain' [K] f32, 'pose_i'; arrays in msgpack-numpy's {nd, type, kind, shape, data} form; keys are
-zero-padded millisecond timestamps (`%012d`, 13 digits today).  The container is LMDB when the `lmdb` module is importable (the reference's
-format, byte for byte) and an append-only log file with the same key/value pairs otherwise (lmdb is not installable
-in this image; msgpack-numpy is absent too, hence the explicit encoder below).
+zero-padded millisecond timestamps (`%012d`, 13 digits today).  The container is LMDB: through the `lmdb` module when it is importable,
+otherwise through this package's own reader / writer of LMDB's file format (MdbEnv -> csrc/nbp_mdb.cpp; lmdb is not installable in this
+image; msgpack-numpy is absent too, hence the explicit encoder below).  LogEnv (an append-only log, rounds 2-5) still opens its own files.
 
 All map work of the collection (cloud accumulation, slab maps, trajectory image, GT obstacle label, coverage,
 rendering, un-projection, NBP forward) runs on the HIP kernels; the host keeps the reference's control flow:
@@ -159,12 +159,87 @@ class LmdbEnv:
         self.env.close()
 
 
+class MdbEnv:
+    """<path>/data.mdb in LMDB's on-disk format through the native container of this package (csrc/nbp_mdb.cpp: nbp_mdb_*), for
+    hosts without the `lmdb` module: a store written here opens with lmdb.open(path) and one the reference wrote opens here.  Same
+    interface as LmdbEnv / LogEnv; every put / delete is its own committed transaction, as in the reference."""
+
+    def __init__(self, path, map_size=200 * 1024 ** 3, sync=False):
+        import ctypes as C
+        from .. import _lib
+        self._L, self._C = _lib.lib(), C
+        h = C.c_void_p()
+        _lib.check(self._L.nbp_mdb_open(os.fsencode(path), int(map_size), int(bool(sync)), C.byref(h)), "nbp_mdb_open")
+        self._h = h
+
+    def put(self, key: bytes, value: bytes):
+        rc = self._L.nbp_mdb_put(self._h, key, len(key), value, len(value))
+        if rc:
+            raise RuntimeError(f"nbp_mdb_put failed ({rc})")
+
+    def delete(self, key: bytes):
+        rc = self._L.nbp_mdb_del(self._h, key, len(key))
+        if rc not in (0, 1):
+            raise RuntimeError(f"nbp_mdb_del failed ({rc})")
+        return rc == 0
+
+    def get(self, key: bytes):
+        C = self._C
+        n = C.c_size_t()
+        rc = self._L.nbp_mdb_get(self._h, key, len(key), None, 0, C.byref(n))
+        if rc == 1:
+            return None
+        buf = C.create_string_buffer(max(n.value, 1))
+        rc = self._L.nbp_mdb_get(self._h, key, len(key), buf, n.value, C.byref(n))
+        if rc:
+            raise RuntimeError(f"nbp_mdb_get failed ({rc})")
+        return buf.raw[:n.value]
+
+    def entries(self):
+        return int(self._L.nbp_mdb_entries(self._h))
+
+    def stat(self):
+        out = (self._C.c_ulonglong * 8)()
+        self._L.nbp_mdb_stat(self._h, out)
+        names = ("depth", "branch_pages", "leaf_pages", "overflow_pages", "entries", "last_pgno", "last_txnid", "psize")
+        return dict(zip(names, (int(v) for v in out)))
+
+    def keys(self):
+        C = self._C
+        n = C.c_size_t()
+        self._L.nbp_mdb_keys(self._h, None, 0, C.byref(n))
+        buf = C.create_string_buffer(max(n.value, 1))
+        self._L.nbp_mdb_keys(self._h, buf, n.value, C.byref(n))
+        raw, out, i = buf.raw[:n.value], [], 0
+        while i < len(raw):
+            k = struct.unpack_from("<H", raw, i)[0]
+            out.append(raw[i + 2:i + 2 + k])
+            i += 2 + k
+        return out
+
+    def items(self):
+        for k in self.keys():              # (a snapshot of the keys: deleting while iterating is safe, as with a write cursor)
+            v = self.get(k)
+            if v is not None:
+                yield k, v
+
+    def close(self):
+        if self._h:
+            self._L.nbp_mdb_close(self._h)
+            self._h = None
+
+
 def open_experience_db(path, map_size=200 * 1024 ** 3):
+    """train_nbp_model.py:61-63.  The `lmdb` module when it is importable; otherwise LMDB's file format through the native container
+    (MdbEnv) -- unless `path` already holds the append-only log of rounds 2-5 (data.log), which keeps opening as it was written."""
     try:
         import lmdb  # noqa: F401
         return LmdbEnv(path, map_size)
     except ImportError:
+        pass
+    if os.path.exists(os.path.join(path, "data.log")) and not os.path.exists(os.path.join(path, "data.mdb")):
         return LogEnv(path)
+    return MdbEnv(path, map_size)
 
 
 _last_key = [0]

@@ -112,7 +112,7 @@ class CloudBins:
 
 
 def accumulate_step_maps(full_pc, camera_pose, y_bins, grid_size=256, grid_range=(-40, 40), band=0.1, n_dev=None,
-                         out=None, bins=None):
+                         out=None, bins=None, prefiled=False):
     """One fused pass replacing nbp_planning.py:114-127 + :172-183.
 
     Returns [6,S,S]: four height slabs (torch.bucketize(p_y, y_bins[:-1]) - 1 semantics),
@@ -137,10 +137,13 @@ def accumulate_step_maps(full_pc, camera_pose, y_bins, grid_size=256, grid_range
         if bins is not None:          # on the tile-binned shadow copy of THIS cloud tensor (CloudBins): same maps, bit for bit
             if p.data_ptr() != full_pc.data_ptr():
                 raise ValueError("accumulate_step_maps(bins=...): the cloud must be the contiguous fp32 tensor the bins follow")
-            rc = _lib.lib().nbp_step_maps_binned_f32(bins.store.data_ptr(), bins.page_bound(p.shape[0]), p.data_ptr(), p.shape[0], n_dev,
-                                                     cx, cy, cz, arr, len(bounds), band_lo, band_hi, S, float(grid_range[0]),
-                                                     float(grid_range[1]), None, 0, None, 0, out.data_ptr(), None, _lib.current_stream())
-            _lib.check(rc, "nbp_step_maps_binned_f32")
+            # prefiled: the launch that appended the points filed them and cleared `out` (hipops.unproject_append(bins=, clear=)):
+            # the page build alone, one launch
+            fn = _lib.lib().nbp_step_maps_prefiled_f32 if prefiled else _lib.lib().nbp_step_maps_binned_f32
+            rc = fn(bins.store.data_ptr(), bins.page_bound(p.shape[0]), p.data_ptr(), p.shape[0], n_dev,
+                    cx, cy, cz, arr, len(bounds), band_lo, band_hi, S, float(grid_range[0]),
+                    float(grid_range[1]), None, 0, None, 0, out.data_ptr(), None, _lib.current_stream())
+            _lib.check(rc, "nbp_step_maps_prefiled_f32" if prefiled else "nbp_step_maps_binned_f32")
             return out
         rc = _lib.lib().nbp_map_accumulate_f32(p.data_ptr(), p.shape[0], n_dev, cx, cy, cz, arr, len(bounds), band_lo,
                                                band_hi, S, float(grid_range[0]), float(grid_range[1]),
@@ -150,7 +153,7 @@ def accumulate_step_maps(full_pc, camera_pose, y_bins, grid_size=256, grid_range
 
 
 def step_maps(full_pc, camera_pose, y_bins, grid_size, grid_range, traj_dev, n_traj_old, traj_fresh, out6, net_in5,
-              band=0.1, n_dev=None, bins=None, n_upper=None):
+              band=0.1, n_dev=None, bins=None, n_upper=None, prefiled=False):
     """accumulate_step_maps + the trajectory channel + the copy of the four slabs into the network input, in one call
     (nbp_step_maps_f32: two memsets, one kernel, one copy instead of seven launches).  traj_dev: device [cap,3] history
     of camera positions, n_traj_old of them valid; traj_fresh: host [k<=8,3] new positions, appended by the kernel.
@@ -171,12 +174,15 @@ def step_maps(full_pc, camera_pose, y_bins, grid_size, grid_range, traj_dev, n_t
     band_hi, band_lo = float(np.float32(cy + band)), float(np.float32(cy - band))
     if bins is not None:              # the tile-binned shadow copy of this cloud (CloudBins): same maps, bit for bit
         nu = full_pc.shape[0] if n_upper is None else min(int(n_upper), full_pc.shape[0])
-        rc = _lib.lib().nbp_step_maps_binned_f32(bins.store.data_ptr(), bins.page_bound(nu), full_pc.data_ptr(), full_pc.shape[0],
-                                                 None if n_dev is None else n_dev.data_ptr(), cx, cy, cz, arr, len(bounds), band_lo,
-                                                 band_hi, S, float(grid_range[0]), float(grid_range[1]), traj_dev.data_ptr(),
-                                                 int(n_traj_old), fresh.ctypes.data, len(fresh), out6.data_ptr(), net_in5.data_ptr(),
-                                                 _lib.current_stream())
-        _lib.check(rc, "nbp_step_maps_binned_f32")
+        # prefiled: every point was filed by the launch that appended it, and that launch cleared out6 and the trajectory channel
+        # (hipops.unproject_append(bins=, clear=(out6, net_in5[4]))): the page build alone
+        fn = _lib.lib().nbp_step_maps_prefiled_f32 if prefiled else _lib.lib().nbp_step_maps_binned_f32
+        rc = fn(bins.store.data_ptr(), bins.page_bound(nu), full_pc.data_ptr(), full_pc.shape[0],
+                None if n_dev is None else n_dev.data_ptr(), cx, cy, cz, arr, len(bounds), band_lo,
+                band_hi, S, float(grid_range[0]), float(grid_range[1]), traj_dev.data_ptr(),
+                int(n_traj_old), fresh.ctypes.data, len(fresh), out6.data_ptr(), net_in5.data_ptr(),
+                _lib.current_stream())
+        _lib.check(rc, "nbp_step_maps_prefiled_f32" if prefiled else "nbp_step_maps_binned_f32")
         return
     rc = _lib.lib().nbp_step_maps_f32(full_pc.data_ptr(), full_pc.shape[0], None if n_dev is None else n_dev.data_ptr(),
                                       cx, cy, cz, arr, len(bounds), band_lo, band_hi, S, float(grid_range[0]),

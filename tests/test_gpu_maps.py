@@ -231,3 +231,101 @@ def test_binned_step_maps_and_batch_equal_the_unbinned_calls(hip):
         tc[:2] = torch.from_numpy(trajs[0][:2]).cuda()
         hu.step_maps(clouds[0], poses[0], ybins, S, gr, tc, 2, trajs[0][2:], o6c, nic, n_dev=n_devs[0], bins=binss[0])
         assert torch.equal(o6c, o6a[0]) and torch.equal(nic, nia[0])
+
+
+# ---- round 6: the un-projection launch files the points it appends (and clears the maps), the build is the page launch alone
+def _frames(rng, F_, H, W):
+    from oracle import camera as ocam
+    from nextbestpath_amd.utility import hipops as ho
+    depth = rng.uniform(0.6, 60, (F_, H, W)).astype(np.float32)
+    depth[rng.random((F_, H, W)) < 0.2] = -1
+    poses = [([float(rng.uniform(-8, 8)), 3.3, float(rng.uniform(-8, 8))], [float(rng.uniform(-30, 30)), float(rng.uniform(0, 360))])
+             for _ in range(F_)]
+    RT = [ocam.camera_RT(x, v) for x, v in poses]
+    return torch.from_numpy(depth).cuda(), ho.cams12(np.stack([r for r, _ in RT]), np.stack([t for _, t in RT]), "cuda")
+
+
+@pytest.mark.parametrize("colours", [False, True])
+def test_filing_unprojection_and_one_launch_build_equal_the_two_launch_build(hip, colours):
+    """Frames appended through unproject_append(bins=, clear=): the cloud (and its colours) are those of the plain call bit for bit,
+    the store stays in step with the cloud (n_binned == cloud size, nothing on the side list), and the ONE-launch build
+    (prefiled) gives the append-order kernel's maps; stale maps / trajectory channel are cleared by the filing launch."""
+    from nextbestpath_amd.utility import hipops as ho
+    S, gr, H, W = 256, (-40, 40), 128, 228
+    rng = np.random.default_rng(3)
+    cap = 300_000
+    cloud, ref = torch.zeros(cap, 3, device="cuda"), torch.zeros(cap, 3, device="cuda")
+    rgbc, rgbr = torch.zeros(cap, 3, device="cuda"), torch.zeros(cap, 3, device="cuda")
+    cnt, cnt_ref = torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    bins = hu.CloudBins((-160.0, -160.0), (160.0, 160.0), cap, "cuda")
+    ybins = torch.arange(0.5, 11.5 + 2.75, 2.75)
+    maps6 = torch.full((6, S, S), 7.0, device="cuda")           # stale contents: the filing launch clears them
+    traj = torch.full((S, S), 5.0, device="cuda")
+    for step, F_ in enumerate([1, 4, 1, 4, 4, 1]):
+        depth, cams = _frames(rng, F_, H, W)
+        rgb = torch.rand(F_, H, W, 3, device="cuda") if colours else None
+        kw = dict(rgb=rgb, cloud_rgb=rgbc) if colours else {}
+        kw_ref = dict(rgb=rgb, cloud_rgb=rgbr) if colours else {}
+        assert ho.unproject_files(depth, None)
+        clear = (maps6, traj) if F_ == 1 else None             # (as Rollout.pre: the frame in front of the build clears)
+        ho.unproject_append(depth, None, cams, cloud, cnt, 0.2, 70.0, seed=100 + step, bins=bins, clear=clear, **kw)
+        ho.unproject_append(depth, None, cams, ref, cnt_ref, 0.2, 70.0, seed=100 + step, **kw_ref)
+        n = int(cnt.item())
+        assert n == int(cnt_ref.item()) and torch.equal(cloud[:n], ref[:n])
+        if colours:
+            assert torch.equal(rgbc[:n], rgbr[:n])
+        h = bins.header()
+        assert h["n_binned"] == n and h["error"] == 0 and h["n_overflow"] == 0, (step, h)
+        if clear is None:
+            continue
+        assert float(traj.abs().sum()) == 0.0
+        traj.fill_(5.0)
+        pose = torch.tensor([float(rng.uniform(-10, 10)), 3.3, float(rng.uniform(-10, 10)), 0.0, 0.0])
+        got = hu.accumulate_step_maps(cloud, pose, ybins, S, gr, n_dev=cnt, out=maps6, bins=bins, prefiled=True)
+        want = hu.accumulate_step_maps(ref, pose, ybins, S, gr, n_dev=cnt_ref)
+        assert torch.equal(got, want), step
+        assert float(want.sum()) > 0
+        maps6.fill_(7.0)
+    assert n > 50_000
+
+
+def test_one_launch_build_counts_points_no_launch_filed(hip):
+    """A frame appended by the plain call puts the store out of step: the filing call behind it refuses to file (n_binned stays),
+    and the one-launch build still counts every point (the unfiled tail directly); a two-launch build catches the store up and
+    filing resumes."""
+    from nextbestpath_amd.utility import hipops as ho
+    S, gr, H, W = 256, (-40, 40), 64, 116
+    rng = np.random.default_rng(9)
+    cap = 100_000
+    cloud = torch.zeros(cap, 3, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    bins = hu.CloudBins((-160.0, -160.0), (160.0, 160.0), cap, "cuda")
+    ybins = torch.arange(0.5, 11.5 + 2.75, 2.75)
+    maps6 = torch.zeros(6, S, S, device="cuda")
+    pose = torch.tensor([1.0, 3.3, -2.0, 0.0, 0.0])
+    d, c = _frames(rng, 4, H, W)
+    ho.unproject_append(d, None, c, cloud, cnt, 0.3, 70.0, seed=1, bins=bins)
+    n1 = int(cnt.item())
+    assert bins.header()["n_binned"] == n1
+    d, c = _frames(rng, 4, H, W)
+    ho.unproject_append(d, None, c, cloud, cnt, 0.3, 70.0, seed=2)                    # not filed
+    d, c = _frames(rng, 1, H, W)
+    ho.unproject_append(d, None, c, cloud, cnt, 0.3, 70.0, seed=3, bins=bins, clear=(maps6, None))   # out of step: files nothing
+    n3 = int(cnt.item())
+    assert n3 > n1 and bins.header()["n_binned"] == n1
+    got = hu.accumulate_step_maps(cloud, pose, ybins, S, gr, n_dev=cnt, out=maps6, bins=bins, prefiled=True)
+    want = hu.accumulate_step_maps(cloud, pose, ybins, S, gr, n_dev=cnt)
+    assert torch.equal(got, want)
+    got = hu.accumulate_step_maps(cloud, pose, ybins, S, gr, n_dev=cnt, out=maps6, bins=bins)                     # catches up
+    assert torch.equal(got, want) and bins.header()["n_binned"] == n3
+    d, c = _frames(rng, 1, H, W)
+    ho.unproject_append(d, None, c, cloud, cnt, 0.3, 70.0, seed=4, bins=bins, clear=(maps6, None))
+    n4 = int(cnt.item())
+    assert bins.header()["n_binned"] == n4 > n3
+    got = hu.accumulate_step_maps(cloud, pose, ybins, S, gr, n_dev=cnt, out=maps6, bins=bins, prefiled=True)
+    assert torch.equal(got, hu.accumulate_step_maps(cloud, pose, ybins, S, gr, n_dev=cnt))
+    # a frame the three-launch form does not take (H W % 4 != 0) cannot file: the wrapper says so and the library refuses
+    odd = torch.full((1, 63, 115), 2.0, device="cuda")
+    assert not ho.unproject_files(odd, None)
+    with pytest.raises(Exception):
+        ho.unproject_append(odd, None, c, cloud, cnt, 0.3, 70.0, seed=5, bins=bins)
