@@ -736,6 +736,24 @@ int nbp_elementwise_f32(int op, const float* a, const float* b, long long n, flo
  * (a skip connection: max-pool + two attention gates x two uses) in one pass instead of autograd's n - 1 binary adds -- what
  * loss.backward() does implicitly in next_best_path/utility/nbp_utils.py:383.  srcs_host / ld_host: HOST arrays of n entries. */
 int nbp_sum_n_f32(int n, const float* const* srcs_host, const long long* ld_host, long long M, int C, float* out, void* stream);
+/* The element-wise middle of Attention_block in TRAINING mode (nbp_model.py:52-60), between the two 1x1 convolutions and x * psi:
+ *     g1 = BN_g(g_pre);  x1 = BN_x(x_pre);  q = relu(g1 + x1);  p = q . w_psi + b_psi        (batch statistics, running stats updated)
+ * fused: two statistics passes + ONE pass that reads g_pre / x_pre and writes q [M,F] and p [M] (the separate launches were BatchNorm
+ * apply twice, add-relu and a row-dot: 8 tensor passes for 3), and its backward from dp = dL/dp: both BatchNorm backwards, the ReLU
+ * mask, dq = dp (x) w_psi and the psi weight's gradient in one reduce + one apply pass (15 tensor passes for 8).  Every output is the
+ * separate launches' bit for bit (p sums its row in nbp_rowdot_f32's order).  F = F_int: F / 4 a power of two in [4, 64].  stat_g / stat_x: [4 F] doubles, 32-byte aligned; csum_* = column sums of d g_pre / d x_pre (the 1x1 convolutions' bias
+ * gradients), amax_* (or NULL) = 64 zeroed words receiving max |.| of them; ws >= nbp_gate_mid_workspace_bytes(M, F). */
+size_t nbp_gate_mid_workspace_bytes(long long M, int F);
+int nbp_gate_mid_forward_f32(const float* g_pre, const float* x_pre, long long M, int F,
+                             const float* gamma_g, const float* beta_g, float* run_mean_g, float* run_var_g, float eps_g, float mom_g,
+                             const float* gamma_x, const float* beta_x, float* run_mean_x, float* run_var_x, float eps_x, float mom_x,
+                             float* mean_g, float* invstd_g, float* mean_x, float* invstd_x, double* stat_g, double* stat_x,
+                             const float* w_psi, const float* b_psi, float* q, float* p, void* ws, size_t ws_bytes, void* stream);
+int nbp_gate_mid_backward_f32(const float* dp, const float* w_psi, const float* q, const float* g_pre, const float* x_pre,
+                              long long M, int F, const float* mean_g, const float* invstd_g, const float* gamma_g,
+                              const float* mean_x, const float* invstd_x, const float* gamma_x, float* dg_pre, float* dx_pre,
+                              float* dgamma_g, float* dbeta_g, float* dgamma_x, float* dbeta_x, float* dw_psi, float* csum_g,
+                              float* csum_x, void* amax_g, void* amax_x, void* ws, size_t ws_bytes, void* stream);
 int nbp_rowscale_f32(const float* x, const float* s, long long M, int C, float* out, void* stream);
 /* ... that also leaves max |out| in the 64 zeroed words of amax_out (C % 4 == 0, 16-byte aligned tensors, else NBP_E_SHAPE). */
 int nbp_rowscale_amax_f32(const float* x, const float* s, long long M, int C, float* out, void* amax_out, void* stream);   /* x[m][c]*s[m] */

@@ -190,6 +190,11 @@ SIGNATURES["nbp_mdb_del"] = (_i, [_vp, C.c_char_p, _sz])
 SIGNATURES["nbp_mdb_get"] = (_i, [_vp, C.c_char_p, _sz, _vp, _sz, C.POINTER(_sz)])
 SIGNATURES["nbp_mdb_keys"] = (_i, [_vp, _vp, _sz, C.POINTER(_sz)])
 SIGNATURES["nbp_mdb_stat"] = (_i, [_vp, C.POINTER(C.c_ulonglong)])
+SIGNATURES["nbp_gate_mid_workspace_bytes"] = (_sz, [_ll, _i])
+SIGNATURES["nbp_gate_mid_forward_f32"] = (_i, [_vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp,
+                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp])
+SIGNATURES["nbp_gate_mid_backward_f32"] = (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp])
 SIGNATURES["nbp_sum_n_f32"] = (_i, [_i, _vp, _vp, _ll, _i, _vp, _vp])
 SIGNATURES["nbp_unproject_append_filed_f32"] = (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _fpp, _i, _i, _i, _f, _f, _d, C.c_uint, _f,
                                                      _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _i, _vp, _sz, _vp])
@@ -261,7 +266,10 @@ NUMERICS_KNOBS = {"NBP_CONV_PRECISION", "NBP_TRAIN_SPLIT", "NBP_TRAIN_WGRAD_SPLI
                   "NBP_TRAIN_UP_DGRAD", "NBP_TRAIN_UP_WGRAD",
                   #  Conv1.conv.0 on the fp32 MFMA pipe instead of the split scheme -- it flipped a ReLU mask in
                   # test_full_network_training_step_vs_oracle; the fused AdamW rounds in another order than the foreach form
-                  "NBP_TRAIN_FIRST_CONV", "NBP_TRAIN_FUSED_ADAMW"}
+                  "NBP_TRAIN_FIRST_CONV", "NBP_TRAIN_FUSED_ADAMW",
+                  # (round 6) the n-ary gradient sums add in another order than autograd's pairwise adds (the fused gate middle,
+                  # NBP_TRAIN_GATE_FUSE, is bit-identical to the separate Functions: not listed)
+                  "NBP_TRAIN_FANOUT"}
 # bit-identical switches (NBP_TRAIN_PREPACK, NBP_STEP_OVERLAP, ...) are not listed here; effective_knobs() reports every switch
 # that is off its default, numerics-affecting or not
 

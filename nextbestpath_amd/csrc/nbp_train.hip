@@ -494,6 +494,212 @@ __global__ __launch_bounds__(256) void bn_backward_apply4_sum_kernel(const float
     if (amax_out) train_wave_amax(mx, amax_out);
 }
 
+// ------------------------------------------------------------------ the attention gate's element-wise middle, fused (round 6)
+// Attention_block.forward (nbp_model.py:52-60) between the two 1x1 convolutions and x * psi:
+//     g1 = BN_g(g_pre);  x1 = BN_x(x_pre);  q = relu(g1 + x1);  p = psi_conv(q) = q . w + b
+// as its own launches these were BN apply (R + W) twice, add-relu (2 R + W), row-dot (R) over [M, F_int] tensors -- 8 passes; here
+// ONE pass reads g_pre and x_pre, writes q and p (3 passes).  g1 and x1 are evaluated exactly as bn_apply4_kernel does (bn_value4,
+// rounded to fp32 each) and p sums its row in rowdot_kernel's order: q and p are the separate launches' bit for bit.  Thread layout: a thread owns one float4 column (256 % F4 == 0) and walks rows; the F4 lanes of
+// a row are consecutive lanes of one wave.
+struct GateBn { const double* stat_g; const double* stat_x; const float* gamma_g; const float* beta_g; const float* gamma_x; const float* beta_x; };
+__global__ __launch_bounds__(256) void gate_mid_fwd4_kernel(const float* __restrict__ gp, const float* __restrict__ xp, long long M, int F4,
+                                                            GateBn bn, const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* __restrict__ q, float* __restrict__ p) {
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gp);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(xp);
+    f32x4* q4 = reinterpret_cast<f32x4*>(q);
+    const int c = threadIdx.x % F4, rsub = threadIdx.x / F4, rpb = 256 / F4;
+    const f64x4 mug = reinterpret_cast<const f64x4*>(bn.stat_g)[c], isg = reinterpret_cast<const f64x4*>(bn.stat_g + 4 * (size_t)F4)[c];
+    const f64x4 mux = reinterpret_cast<const f64x4*>(bn.stat_x)[c], isx = reinterpret_cast<const f64x4*>(bn.stat_x + 4 * (size_t)F4)[c];
+    const f64x4 gg = to_d4(reinterpret_cast<const f32x4*>(bn.gamma_g)[c]), bg = to_d4(reinterpret_cast<const f32x4*>(bn.beta_g)[c]);
+    const f64x4 gx = to_d4(reinterpret_cast<const f32x4*>(bn.gamma_x)[c]), bx = to_d4(reinterpret_cast<const f32x4*>(bn.beta_x)[c]);
+    const f32x4 wv = reinterpret_cast<const f32x4*>(w)[c];
+    const float b0 = b[0];
+    const long long rstep = (long long)gridDim.x * rpb;
+    // (every lane of a row's group runs the same trip count: the shuffles below need the whole group)
+    for (long long r0 = (long long)blockIdx.x * rpb; r0 < M; r0 += 2 * rstep) {
+        f32x4 gv[2], xv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long r = r0 + u * rstep + rsub;
+            if (r < M) { gv[u] = g4[r * F4 + c]; xv[u] = x4[r * F4 + c]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long r = r0 + u * rstep + rsub;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (r < M) {
+                const f32x4 a = bn_value4(gv[u], mug, isg, gg, bg), t = bn_value4(xv[u], mux, isx, gx, bx);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(a[e] + t[e], 0.f);
+                q4[r * F4 + c] = o;
+            }
+            // p = q . w in rowdot_kernel's order, so that p -- and with it everything downstream -- is the separate launches' bit for bit:
+            // there, lane L of 16 chains fmaf over the elements L, L + 16, L + 32, ... and the 16 chains meet in a xor tree 8, 4, 2, 1.
+            // Element e of this lane's float4 (column c) is element 4 c + e of the row: chain L = 4 (c & 3) + e, position c >> 2.  The
+            // chains run down the lanes c, c + 4, c + 8, ... (F4 / 4 sequential steps), the tree is two lane exchanges and two in-lane adds.
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < (F4 >> 2); ++k) {
+                f32x4 prev;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) prev[e] = __shfl_up(acc[e], 4);
+                if ((c >> 2) == k) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(o[e], wv[e], k ? prev[e] : 0.f);
+                }
+            }
+            // (the finished chains sit in the row's last four lanes: L = 4 j + e with j = c & 3)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], 2);         // L ^ 8
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], 1);         // L ^ 4
+            const float t0 = acc[0] + acc[2], t1 = acc[1] + acc[3];              // L ^ 2
+            if (c == F4 - 1 && r < M) p[r] = (t0 + t1) + b0;                     // L ^ 1, then PsiConvFn's bias add
+        }
+    }
+}
+
+// Backward of the same: from dp (the gradient of p) -- dq = dp (x) w, dz = dq (q > 0) -- both BatchNorm backwards at once.
+// Reduce pass: per channel s0 = sum dz, s1g = sum dz g_pre, s1x = sum dz x_pre (raw, as colreduce4_kernel<1>) and sw = sum q dp (the psi
+// weight's gradient); rows in colreduce4_kernel's chunk order, so the sums are the separate launches' bit for bit.
+__global__ __launch_bounds__(256) void gate_mid_bwd_reduce4_kernel(const float* __restrict__ dp, const float* __restrict__ w,
+                                                                   const float* __restrict__ q, const float* __restrict__ gp,
+                                                                   const float* __restrict__ xp, long long M, int F4,
+                                                                   double* __restrict__ part) {
+    const int CT = F4 < 256 ? F4 : 256, rpb = 256 / CT;
+    const int c = threadIdx.x % CT, rsub = threadIdx.x / CT;
+    __shared__ f64x4 sh[4][256];
+    const f32x4* q4 = reinterpret_cast<const f32x4*>(q);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gp);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(xp);
+    const long long R = 4ll * rpb, n_chunks = (M + R - 1) / R;
+    f64x4 s0 = {0.0, 0.0, 0.0, 0.0}, s1g = s0, s1x = s0, sw = s0;
+    if (rsub < rpb && c < F4) {
+        const f32x4 wv = reinterpret_cast<const f32x4*>(w)[c];
+        auto step = [&](long long r) {
+            const float d = dp[r];
+            const f32x4 qv = q4[r * F4 + c], gv = g4[r * F4 + c], xv = x4[r * F4 + c];
+            f32x4 dz;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dz[e] = qv[e] > 0.f ? d * wv[e] : 0.f;
+            const f64x4 dzd = to_d4(dz);
+            s0 += dzd; s1g += dzd * to_d4(gv); s1x += dzd * to_d4(xv);
+            sw += to_d4(qv) * (double)d;
+        };
+        for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+            const long long r = ch * R + rsub;
+            if (r + 3 * rpb < M) { step(r); step(r + rpb); step(r + 2 * rpb); step(r + 3 * rpb); }
+            else
+                for (long long k = r; k < M; k += rpb) step(k);
+        }
+    }
+    sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1g; sh[2][threadIdx.x] = s1x; sh[3][threadIdx.x] = sw;
+    __syncthreads();
+    if (rsub == 0 && c < F4) {
+        for (int k = 1; k < rpb; ++k) { s0 += sh[0][k * CT + c]; s1g += sh[1][k * CT + c]; s1x += sh[2][k * CT + c]; sw += sh[3][k * CT + c]; }
+        f64x4* o = reinterpret_cast<f64x4*>(part + (long long)blockIdx.x * 4 * F4 * 4);
+        o[c] = s0; o[F4 + c] = s1g; o[2 * F4 + c] = s1x; o[3 * F4 + c] = sw;
+    }
+}
+
+// column sums of the partials [blk][4][C] in the fixed order of colsum_pair (slice ks adds rows ks, ks + 32, ...; the 32 slices meet
+// in LDS): dbeta (shared by both BatchNorms) | dgamma_g | dgamma_x | dw_psi, and the unrounded [2 C] sums each apply needs
+__global__ __launch_bounds__(256) void gate_mid_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C,
+                                                                    const float* __restrict__ mean_g, const float* __restrict__ invstd_g,
+                                                                    const float* __restrict__ mean_x, const float* __restrict__ invstd_x,
+                                                                    float* __restrict__ dbeta_g, float* __restrict__ dgamma_g,
+                                                                    float* __restrict__ dbeta_x, float* __restrict__ dgamma_x,
+                                                                    float* __restrict__ dw, double* __restrict__ sums_g,
+                                                                    double* __restrict__ sums_x) {
+    __shared__ double sh[FIN_SL][4][FIN_CH];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, ks = threadIdx.x / FIN_CH;
+    double s[4] = {0, 0, 0, 0};
+    if (c < C)
+        for (int k = ks; k < nblk; k += FIN_SL) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += part[((long long)k * 4 + j) * C + c];
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[ks][j][threadIdx.x % FIN_CH] = s[j];
+    __syncthreads();
+    if (c >= C || ks != 0) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s[j] = 0; for (int k = 0; k < FIN_SL; ++k) s[j] += sh[k][j][threadIdx.x % FIN_CH]; }
+    const double dgg = (double)invstd_g[c] * (s[1] - (double)mean_g[c] * s[0]);
+    const double dgx = (double)invstd_x[c] * (s[2] - (double)mean_x[c] * s[0]);
+    dbeta_g[c] = (float)s[0]; dbeta_x[c] = (float)s[0];
+    dgamma_g[c] = (float)dgg; dgamma_x[c] = (float)dgx;
+    dw[c] = (float)s[3];
+    sums_g[c] = s[0]; sums_g[C + c] = dgg;
+    sums_x[c] = s[0]; sums_x[C + c] = dgx;
+}
+
+// Apply pass: d g_pre and d x_pre (bn_dx4's affine form, no ReLU inside the BatchNorms), their column sums (the 1x1 convolutions'
+// bias gradients) and max |.| (their split data / weight gradients' scale), as bn_backward_apply4_sum_kernel leaves them.
+__global__ __launch_bounds__(256) void gate_mid_bwd_apply4_kernel(const float* __restrict__ dp, const float* __restrict__ w,
+                                                                  const float* __restrict__ q, const float* __restrict__ gp,
+                                                                  const float* __restrict__ xp, long long M, int F4,
+                                                                  const float* __restrict__ mean_g, const float* __restrict__ invstd_g,
+                                                                  const float* __restrict__ gamma_g, const double* __restrict__ sums_g,
+                                                                  const float* __restrict__ mean_x, const float* __restrict__ invstd_x,
+                                                                  const float* __restrict__ gamma_x, const double* __restrict__ sums_x,
+                                                                  float* __restrict__ dgp, float* __restrict__ dxp,
+                                                                  double* __restrict__ part, unsigned* __restrict__ amax_g,
+                                                                  unsigned* __restrict__ amax_x) {
+    const int CT = F4 < 256 ? F4 : 256, rpb = 256 / CT;
+    const int c = threadIdx.x % CT, rsub = threadIdx.x / CT;
+    __shared__ f64x4 sh[2][256];
+    const double invM = 1.0 / (double)M;
+    const f32x4* q4 = reinterpret_cast<const f32x4*>(q);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gp);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(xp);
+    f32x4* dg4 = reinterpret_cast<f32x4*>(dgp);
+    f32x4* dx4 = reinterpret_cast<f32x4*>(dxp);
+    const long long R = 4ll * rpb, n_chunks = (M + R - 1) / R;
+    f64x4 sg = {0.0, 0.0, 0.0, 0.0}, sx = sg;
+    float mg = 0.f, mx = 0.f;
+    if (rsub < rpb && c < F4) {
+        const MaskStat none{nullptr, nullptr, nullptr};
+        const BnAffine kg = bn_affine4(c, F4, mean_g, invstd_g, gamma_g, sums_g, invM, none, false);
+        const BnAffine kx = bn_affine4(c, F4, mean_x, invstd_x, gamma_x, sums_x, invM, none, false);
+        const f32x4 wv = reinterpret_cast<const f32x4*>(w)[c];
+        auto emit = [&](long long r, float d, f32x4 qv, f32x4 gv, f32x4 xv) {
+            f32x4 dz;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dz[e] = qv[e] > 0.f ? d * wv[e] : 0.f;
+            const f32x4 og = bn_dx4(dz, gv, gv, kg, 0, false), ox = bn_dx4(dz, xv, xv, kx, 0, false);
+            dg4[r * F4 + c] = og; dx4[r * F4 + c] = ox;
+            sg += to_d4(og); sx += to_d4(ox);
+            mg = fmaxf(fmaxf(mg, fmaxf(fabsf(og[0]), fabsf(og[1]))), fmaxf(fabsf(og[2]), fabsf(og[3])));
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(ox[0]), fabsf(ox[1]))), fmaxf(fabsf(ox[2]), fabsf(ox[3])));
+        };
+        for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+            const long long r = ch * R + rsub;
+            if (r + 3 * rpb < M) {
+                float d[4]; f32x4 qv[4], gv[4], xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long i = (r + u * rpb) * F4 + c;
+                    d[u] = dp[r + u * rpb]; qv[u] = q4[i]; gv[u] = g4[i]; xv[u] = x4[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) emit(r + u * rpb, d[u], qv[u], gv[u], xv[u]);
+            } else {
+                for (long long k = r; k < M; k += rpb) emit(k, dp[k], q4[k * F4 + c], g4[k * F4 + c], x4[k * F4 + c]);
+            }
+        }
+    }
+    sh[0][threadIdx.x] = sg; sh[1][threadIdx.x] = sx;
+    __syncthreads();
+    if (rsub == 0 && c < F4) {
+        for (int k = 1; k < rpb; ++k) { sg += sh[0][k * CT + c]; sx += sh[1][k * CT + c]; }
+        reinterpret_cast<f64x4*>(part + ((long long)blockIdx.x * 2 + 0) * F4 * 4)[c] = sg;
+        reinterpret_cast<f64x4*>(part + ((long long)blockIdx.x * 2 + 1) * F4 * 4)[c] = sx;
+    }
+    if (amax_g) train_wave_amax(mg, amax_g);
+    if (amax_x) train_wave_amax(mx, amax_x);
+}
+
 // ------------------------------------------------------------------ small elementwise pieces
 // op 0: out = relu(a + b)          op 1: out = dy * (y > 0)         op 2: out = sigmoid(a)
 // op 3: out = dy * y * (1 - y)     op 4: out = a + b                op 5: out = a + b[0]
@@ -1389,6 +1595,89 @@ static int bn_backward_impl(const float* dy, const float* x, const float* y_or_n
     else
         bn_backward_apply_kernel<<<nbp_ew_grid(M * C, 256), 256, 0, st>>>(dy, x, y_or_null, M * C, C, M, mean, invstd, gamma,
                                                                          sums, relu, dx);
+    return nbp_launch_status();
+}
+
+// ---- the attention gate's element-wise middle in training (kernels above).  F = F_int: a multiple of 4 with F / 4 a power of two
+// <= 64 (32, 64, 128, 256 in the network).  stat_g / stat_x: [4 F] doubles each (unrounded mean | invstd | -inf | +inf, as
+// nbp_bn_train_forward_stat4_f32 writes them without relu); mean_* / invstd_*: [F] floats for the backward.
+extern "C" size_t nbp_gate_mid_workspace_bytes(long long M, int F) {
+    long long rpb;
+    const int nblk = blocks_for_rows(M, &rpb);
+    return (size_t)nblk * 4 * F * sizeof(double) + (size_t)4 * F * sizeof(double) + 1024;
+}
+static bool gate_mid_shape_ok(long long M, int F) {
+    if (M < 1 || F < 4 || F % 4 != 0) return false;
+    const int F4 = F / 4;
+    return F4 >= 4 && F4 <= 64 && (F4 & (F4 - 1)) == 0 && M * F < (1ll << 40);
+}
+extern "C" int nbp_gate_mid_forward_f32(const float* g_pre, const float* x_pre, long long M, int F,
+                                        const float* gamma_g, const float* beta_g, float* run_mean_g, float* run_var_g, float eps_g, float mom_g,
+                                        const float* gamma_x, const float* beta_x, float* run_mean_x, float* run_var_x, float eps_x, float mom_x,
+                                        float* mean_g, float* invstd_g, float* mean_x, float* invstd_x, double* stat_g, double* stat_x,
+                                        const float* w_psi, const float* b_psi, float* q, float* p, void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!g_pre || !x_pre || !gamma_g || !beta_g || !gamma_x || !beta_x || !mean_g || !invstd_g || !mean_x || !invstd_x || !stat_g ||
+                  !stat_x || !w_psi || !b_psi || !q || !p || !ws, NBP_E_ARG);
+    NBP_RETURN_IF(!gate_mid_shape_ok(M, F), NBP_E_SHAPE);
+    NBP_RETURN_IF((((uintptr_t)g_pre | (uintptr_t)x_pre | (uintptr_t)q | (uintptr_t)w_psi | (uintptr_t)gamma_g | (uintptr_t)beta_g |
+                    (uintptr_t)gamma_x | (uintptr_t)beta_x) & 15) || (((uintptr_t)stat_g | (uintptr_t)stat_x) & 31), NBP_E_ARG);
+    NBP_RETURN_IF(ws_bytes < nbp_gate_mid_workspace_bytes(M, F), NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    long long rpb;
+    const int nblk = blocks_for_rows(M, &rpb);
+    double* part = (double*)(((uintptr_t)ws + 255) / 256 * 256);
+    int rc;
+    for (int which = 0; which < 2; ++which) {          // the two BatchNorms' statistics (one read of each tensor)
+        const float* src = which ? x_pre : g_pre;
+        colreduce4_kernel<0><<<nblk, 256, 0, st>>>(src, nullptr, nullptr, nullptr, nullptr, nullptr, M, F / 4, 0, rpb, part);
+        if ((rc = nbp_launch_status())) return rc;
+        bn_finalize_kernel<<<(unsigned)nbp_cdiv(F, FIN_CH), 256, 0, st>>>(src, part, nblk, F, M, which ? eps_x : eps_g, which ? mom_x : mom_g,
+                                                                          which ? mean_x : mean_g, which ? invstd_x : invstd_g,
+                                                                          which ? run_mean_x : run_mean_g, which ? run_var_x : run_var_g,
+                                                                          which ? stat_x : stat_g, nullptr, which ? beta_x : beta_g, 1);
+        if ((rc = nbp_launch_status())) return rc;
+    }
+    const int F4 = F / 4, rows_pb = 256 / F4;
+    long long blocks = (M + 2ll * rows_pb - 1) / (2ll * rows_pb);
+    if (blocks > 4096) blocks = 4096;
+    gate_mid_fwd4_kernel<<<(unsigned)blocks, 256, 0, st>>>(g_pre, x_pre, M, F4, GateBn{stat_g, stat_x, gamma_g, beta_g, gamma_x, beta_x}, w_psi,
+                                                           b_psi, q, p);
+    return nbp_launch_status();
+}
+
+// dp [M] = the gradient of p.  Outputs: d g_pre, d x_pre [M, F]; dgamma / dbeta of both BatchNorms; dw_psi [F]; csum_g / csum_x [F] =
+// the column sums of d g_pre / d x_pre (the 1x1 convolutions' bias gradients); amax_g / amax_x (or null): 64 zeroed words each that
+// receive max |d g_pre| / max |d x_pre|.
+extern "C" int nbp_gate_mid_backward_f32(const float* dp, const float* w_psi, const float* q, const float* g_pre, const float* x_pre,
+                                         long long M, int F, const float* mean_g, const float* invstd_g, const float* gamma_g,
+                                         const float* mean_x, const float* invstd_x, const float* gamma_x, float* dg_pre, float* dx_pre,
+                                         float* dgamma_g, float* dbeta_g, float* dgamma_x, float* dbeta_x, float* dw_psi, float* csum_g,
+                                         float* csum_x, void* amax_g, void* amax_x, void* ws, size_t ws_bytes, void* stream) {
+    NBP_ENTER();
+    NBP_RETURN_IF(!dp || !w_psi || !q || !g_pre || !x_pre || !mean_g || !invstd_g || !gamma_g || !mean_x || !invstd_x || !gamma_x || !dg_pre ||
+                  !dx_pre || !dgamma_g || !dbeta_g || !dgamma_x || !dbeta_x || !dw_psi || !csum_g || !csum_x || !ws, NBP_E_ARG);
+    NBP_RETURN_IF(!gate_mid_shape_ok(M, F), NBP_E_SHAPE);
+    NBP_RETURN_IF((((uintptr_t)q | (uintptr_t)g_pre | (uintptr_t)x_pre | (uintptr_t)dg_pre | (uintptr_t)dx_pre | (uintptr_t)w_psi |
+                    (uintptr_t)mean_g | (uintptr_t)invstd_g | (uintptr_t)gamma_g | (uintptr_t)mean_x | (uintptr_t)invstd_x |
+                    (uintptr_t)gamma_x) & 15), NBP_E_ARG);
+    NBP_RETURN_IF(ws_bytes < nbp_gate_mid_workspace_bytes(M, F), NBP_E_WS);
+    hipStream_t st = (hipStream_t)stream;
+    long long rpb;
+    const int nblk = blocks_for_rows(M, &rpb);
+    double* part = (double*)(((uintptr_t)ws + 255) / 256 * 256);
+    double* sums_g = part + (((size_t)nblk * 4 * F + 31) / 32 * 32);
+    double* sums_x = sums_g + 2 * (size_t)F;
+    gate_mid_bwd_reduce4_kernel<<<nblk, 256, 0, st>>>(dp, w_psi, q, g_pre, x_pre, M, F / 4, part);
+    int rc = nbp_launch_status();
+    if (rc) return rc;
+    gate_mid_bwd_finalize_kernel<<<(unsigned)nbp_cdiv(F, FIN_CH), 256, 0, st>>>(part, nblk, F, mean_g, invstd_g, mean_x, invstd_x, dbeta_g,
+                                                                                dgamma_g, dbeta_x, dgamma_x, dw_psi, sums_g, sums_x);
+    if ((rc = nbp_launch_status())) return rc;
+    gate_mid_bwd_apply4_kernel<<<nblk, 256, 0, st>>>(dp, w_psi, q, g_pre, x_pre, M, F / 4, mean_g, invstd_g, gamma_g, sums_g, mean_x, invstd_x,
+                                                     gamma_x, sums_x, dg_pre, dx_pre, part, (unsigned*)amax_g, (unsigned*)amax_x);
+    if ((rc = nbp_launch_status())) return rc;
+    colsum_finalize_kernel<<<(unsigned)nbp_cdiv(F, FIN_CH), 256, 0, st>>>(part, nblk, F, csum_g, csum_x);
     return nbp_launch_status();
 }
 

@@ -826,6 +826,73 @@ class RowScaleFn(torch.autograd.Function):
         return dx, ds.view(s.shape)
 
 
+# The attention gate's element-wise middle as ONE Function (csrc/nbp_train.hip: gate_mid_*): BN_g, BN_x, add-relu and the psi row-dot in one
+# pass over the two 1x1 convolutions' outputs, and the whole of its backward in a reduce + an apply pass -- every output bit-identical to
+# the separate Functions' (BNFn x 2, AddReluFn, PsiConvFn: rounds 3-5), which NBP_TRAIN_GATE_FUSE=0 brings back.
+_GATE_FUSE = _lib.tune("NBP_TRAIN_GATE_FUSE", "1") == "1"
+
+
+def _gate_mid_ok(gp, xp):
+    F = gp.shape[-1]
+    F4 = F // 4
+    return (_GATE_FUSE and _observer is None and gp.shape == xp.shape and F % 4 == 0 and 4 <= F4 <= 64 and F4 & (F4 - 1) == 0
+            and gp.is_contiguous() and xp.is_contiguous() and gp.data_ptr() % 16 == 0 and xp.data_ptr() % 16 == 0)
+
+
+class GateMidFn(torch.autograd.Function):
+    """p = psi_conv(relu(BN_g(g_pre) + BN_x(x_pre))) (nbp_model.py:52-58, train mode); running statistics updated in place."""
+
+    @staticmethod
+    def forward(ctx, gp, xp, gam_g, bet_g, rm_g, rv_g, eps_g, mom_g, gam_x, bet_x, rm_x, rv_x, eps_x, mom_x, w_psi, b_psi):
+        L = _lib.lib()
+        B, H, W, F = gp.shape
+        M = B * H * W
+        dev = gp.device
+        f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+        mean_g, inv_g, mean_x, inv_x = f32(F), f32(F), f32(F), f32(F)
+        stat_g = torch.empty(4 * F, dtype=torch.float64, device=dev)
+        stat_x = torch.empty(4 * F, dtype=torch.float64, device=dev)
+        q = torch.empty_like(gp)
+        p = f32(M)
+        gg, bg = gam_g.detach().contiguous(), bet_g.detach().contiguous()
+        gx, bx = gam_x.detach().contiguous(), bet_x.detach().contiguous()
+        w = w_psi.detach().reshape(-1).contiguous()
+        ws = _ws(L.nbp_gate_mid_workspace_bytes(M, F), dev)
+        _chk(L.nbp_gate_mid_forward_f32(_lib.ptr(gp), _lib.ptr(xp), M, F, _lib.ptr(gg), _lib.ptr(bg), _lib.ptr(rm_g), _lib.ptr(rv_g),
+                                        float(eps_g), float(mom_g), _lib.ptr(gx), _lib.ptr(bx), _lib.ptr(rm_x), _lib.ptr(rv_x), float(eps_x),
+                                        float(mom_x), _lib.ptr(mean_g), _lib.ptr(inv_g), _lib.ptr(mean_x), _lib.ptr(inv_x),
+                                        _lib.ptr(stat_g), _lib.ptr(stat_x), _lib.ptr(w), _lib.ptr(b_psi.detach().contiguous()), _lib.ptr(q),
+                                        _lib.ptr(p), _lib.ptr(ws), ws.numel(), _st()), "gate_mid_forward")
+        ctx.save_for_backward(gp, xp, q, mean_g, inv_g, gg, mean_x, inv_x, gx, w)
+        ctx.wshape = w_psi.shape
+        return p.view(B, H, W, 1)
+
+    @staticmethod
+    def backward(ctx, dp):
+        L = _lib.lib()
+        gp, xp, q, mean_g, inv_g, gg, mean_x, inv_x, gx, w = ctx.saved_tensors
+        B, H, W, F = gp.shape
+        M = B * H * W
+        dev = gp.device
+        dp = dp.contiguous().view(M)
+        f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+        dgp, dxp = torch.empty_like(gp), torch.empty_like(xp)
+        dgam_g, dbet_g, dgam_x, dbet_x, dw, cs_g, cs_x = f32(F), f32(F), f32(F), f32(F), f32(F), f32(F), f32(F)
+        slots = _fresh_slots(dev, 2) if _FUSE else None
+        sl_g, sl_x = (slots[:64], slots[64:]) if slots is not None else (None, None)
+        ws = _ws(L.nbp_gate_mid_workspace_bytes(M, F), dev)
+        _chk(L.nbp_gate_mid_backward_f32(_lib.ptr(dp), _lib.ptr(w), _lib.ptr(q), _lib.ptr(gp), _lib.ptr(xp), M, F, _lib.ptr(mean_g),
+                                         _lib.ptr(inv_g), _lib.ptr(gg), _lib.ptr(mean_x), _lib.ptr(inv_x), _lib.ptr(gx), _lib.ptr(dgp),
+                                         _lib.ptr(dxp), _lib.ptr(dgam_g), _lib.ptr(dbet_g), _lib.ptr(dgam_x), _lib.ptr(dbet_x), _lib.ptr(dw),
+                                         _lib.ptr(cs_g), _lib.ptr(cs_x), _lib.ptr(sl_g), _lib.ptr(sl_x), _lib.ptr(ws), ws.numel(), _st()),
+             "gate_mid_backward")
+        if _FUSE:        # what BNFn.backward hands the 1x1 convolutions in front: max |.| slot and column sums of their dy
+            _note(dgp, colsum=(sl_g, cs_g))
+            _note(dxp, colsum=(sl_x, cs_x))
+        db = _colsum(dp.view(M, 1))
+        return dgp, dxp, dgam_g, dbet_g, None, None, None, None, dgam_x, dbet_x, None, None, None, None, dw.view(ctx.wshape), db
+
+
 class ToNCHWFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -944,10 +1011,23 @@ def _up_conv(seq, x, name=""):
 
 def _gate(att, g, x, name="", x_scale=None):
     """Attention_block (ref :36-62).  x_scale: the alias of x the final x * psi reads (FanOutFn), x itself when None."""
-    g1 = _bn(att.W_g[1], _t(name + ".W_g.0", ConvFn.apply(g, None, att.W_g[0].weight, att.W_g[0].bias, False)), False, name + ".W_g.1")
-    x1 = _bn(att.W_x[1], _t(name + ".W_x.0", ConvFn.apply(x, None, att.W_x[0].weight, att.W_x[0].bias, False)), False, name + ".W_x.1")
-    q = _t(name + ".q", AddReluFn.apply(g1, x1))
-    p = _t(name + ".psi.0", PsiConvFn.apply(q, att.psi[0].weight, att.psi[0].bias))
+    gp = _t(name + ".W_g.0", ConvFn.apply(g, None, att.W_g[0].weight, att.W_g[0].bias, False))
+    xp = _t(name + ".W_x.0", ConvFn.apply(x, None, att.W_x[0].weight, att.W_x[0].bias, False))
+    if _gate_mid_ok(gp, xp):
+        bg, bx = att.W_g[1], att.W_x[1]
+        p = GateMidFn.apply(gp, xp, bg.weight, bg.bias, bg.running_mean, bg.running_var, bg.eps, bg.momentum, bx.weight, bx.bias,
+                            bx.running_mean, bx.running_var, bx.eps, bx.momentum, att.psi[0].weight, att.psi[0].bias)
+        for mod in (bg, bx):
+            if _NBT is not None:
+                _NBT.append(mod.num_batches_tracked)
+            else:
+                with torch.no_grad():
+                    mod.num_batches_tracked += 1
+    else:
+        g1 = _bn(att.W_g[1], gp, False, name + ".W_g.1")
+        x1 = _bn(att.W_x[1], xp, False, name + ".W_x.1")
+        q = _t(name + ".q", AddReluFn.apply(g1, x1))
+        p = _t(name + ".psi.0", PsiConvFn.apply(q, att.psi[0].weight, att.psi[0].bias))
     psi = _t(name + ".psi", SigmoidFn.apply(_bn(att.psi[1], p, False, name + ".psi.1")))
     return _t(name + ".out", RowScaleFn.apply(x if x_scale is None else x_scale, psi))
 

@@ -86,12 +86,17 @@ def _module(kind, cin, cout, sd, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gate_fuse", [True, False])
 @pytest.mark.parametrize("tag", TAGS)
-def test_hip_blocks_vs_reference_golden(hip, golden_dir, tag):
+def test_hip_blocks_vs_reference_golden(hip, golden_dir, tag, gate_fuse, monkeypatch):
     """networks/training.py::_block / _up_conv / _gate (the per-layer autograd.Functions over csrc/nbp_train.hip, nbp_split.hip)
     against the reference block's float64 forward / backward: outputs, input gradients, every parameter gradient and the
-    BatchNorm running statistics after the forward, all within 1e-5 of the tensor's maximum."""
+    BatchNorm running statistics after the forward, all within 1e-5 of the tensor's maximum.  gate_fuse: the attention gate's
+    element-wise middle as one fused Function (round 6, the default) or as the separate Functions of rounds 3-5."""
     from nextbestpath_amd.networks import training as tr
+    if not gate_fuse and not tag.startswith("att"):
+        pytest.skip("gate_fuse only changes Attention_block")
+    monkeypatch.setattr(tr, "_GATE_FUSE", gate_fuse)
     g = _golden(golden_dir)
     kind, cin, cout, sd, inputs, dy = make_block_case(tag)
     _pin(g, tag, sd, inputs, dy)

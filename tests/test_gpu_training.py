@@ -888,3 +888,44 @@ def test_first_convolution_and_its_weight_gradient_from_the_nchw_input(hip, shap
                           ("db", bd.grad.cpu().double(), br.grad)):
         sc = float(want.abs().max())
         assert float((got - want).abs().max()) < 3e-6 * sc, (nm, float((got - want).abs().max()) / sc)
+
+
+@pytest.mark.parametrize("Fg,Fint,B,H,W", [(64, 32, 2, 32, 32), (128, 64, 1, 16, 48), (256, 128, 1, 16, 32), (512, 256, 3, 16, 16)])
+def test_fused_gate_middle_is_the_separate_functions_bit_for_bit(hip, monkeypatch, Fg, Fint, B, H, W):
+    """Round 6: GateMidFn (BN_g, BN_x, add-relu, psi row-dot and all of their backward in three kernels) against the separate
+    Functions of rounds 3-5 on the same Attention_block: output, both input gradients, every parameter gradient and the BatchNorm
+    buffers are IDENTICAL (the fused kernels evaluate the same roundings in the same order; the row-dot reproduces rowdot_kernel's
+    16 chains and its xor tree)."""
+    from nextbestpath_amd.networks import nbp_model as nm
+    from nextbestpath_amd.networks import training as tr
+    torch.manual_seed(Fint)
+    ref = nm._Gate(Fg, Fg, Fint)
+    with torch.no_grad():
+        for k, p in ref.named_parameters():
+            if k.endswith("1.weight"):
+                p.uniform_(0.3, 0.9)
+            elif k.endswith("1.bias"):
+                p.uniform_(-0.2, 0.2)
+    g0 = torch.randn(B, H, W, Fg)
+    x0 = torch.randn(B, H, W, Fg)
+    dy = torch.randn(B, H, W, Fg)
+    res = []
+    for fuse in (True, False):
+        monkeypatch.setattr(tr, "_GATE_FUSE", fuse)
+        m = nm._Gate(Fg, Fg, Fint)
+        m.load_state_dict(ref.state_dict())
+        m = m.cuda().train()
+        g, x = g0.cuda().requires_grad_(True), x0.cuda().requires_grad_(True)
+        tr._reset_arena(g.device)
+        y = tr._gate(m, g, x)
+        y.backward(dy.cuda())
+        torch.cuda.synchronize()
+        res.append((y.detach(), g.grad, x.grad, {k: p.grad for k, p in m.named_parameters()},
+                    {k: b.clone() for k, b in m.named_buffers() if b.dtype.is_floating_point}))
+    (ya, ga, xa, pa, ba), (yb, gb, xb, pb, bb) = res
+    assert torch.equal(ya, yb) and torch.equal(ga, gb) and torch.equal(xa, xb)
+    for k in pb:
+        assert torch.equal(pa[k], pb[k]), k
+    for k in bb:
+        assert torch.equal(ba[k], bb[k]), k
+    assert float(ya.abs().sum()) > 0 and float(ga.abs().sum()) > 0
