@@ -168,6 +168,7 @@ class MdbEnv:
         import ctypes as C
         from .. import _lib
         self._L, self._C = _lib.lib(), C
+        os.makedirs(path, exist_ok=True)          # (lmdb.open creates the last component only; the trainers hand over nested paths)
         h = C.c_void_p()
         _lib.check(self._L.nbp_mdb_open(os.fsencode(path), int(map_size), int(bool(sync)), C.byref(h)), "nbp_mdb_open")
         self._h = h
