@@ -171,3 +171,31 @@ def _has_lmdb():
         return True
     except ImportError:
         return False
+
+
+def test_long_keys_of_unequal_length(tmp_path):
+    """Keys from 1 to 511 bytes (LMDB's limit), so that branch pages hold few separators of very different sizes: splits pick a cut with
+    both halves inside a page, and a delete that swaps a short separator for a long one may split its parent (erase returns a sibling)."""
+    p = str(tmp_path / "db")
+    rng = random.Random(11)
+    env = nu.MdbEnv(p)
+    model = {}
+    alphabet = b"abcdefghijklmnopqrstuvwxyz"
+    for round_ in range(4):
+        for _ in range(1500):
+            n = rng.choice([1, 2, 7, 64, 200, 400, 510, 511])
+            key = bytes(rng.choice(alphabet) for _ in range(min(n, 6))) + bytes([rng.randrange(97, 123)]) * max(0, n - 6)
+            val = b"x" * rng.choice([0, 3, 900, 1500, 3000])
+            env.put(key, val)
+            model[key] = val
+        ks = sorted(model)
+        for key in rng.sample(ks, len(ks) // 2):
+            assert env.delete(key)
+            del model[key]
+        assert env.keys() == sorted(model)
+        env.close()
+        _check(p, model)
+        env = nu.MdbEnv(p)
+    with pytest.raises(RuntimeError):
+        env.put(b"k" * 512, b"too long a key")
+    env.close()
