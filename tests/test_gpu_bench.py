@@ -32,6 +32,11 @@ def test_bench_single_gpu_line(hip):
     assert d["strong_scaling"]["scenes_per_rank"] == [3] and d["strong_scaling"]["value"] > 0
     assert d["value_fp32_pipe"] is None         # --no-extra-stages: no fp32-pipe window
     assert sc["maps_equal_append_order_kernel"] is True and sc["side_list"] == 0 and sc["group_form"]["frac"] > 0
+    # round 6: the single rollout's step as ONE launch (the filing un-projection in front of it), the two-launch form beside it
+    one = sc["one_launch_form"]
+    assert one["maps_equal_two_launch_build"] is True and one["store_in_step_after_40_filed_frames"] is True
+    assert one["ms_build"] > 0 and sc["two_launch_form"]["ms"] > 0 and abs(sc["ms"] - (one["ms_build"] + one["filing_and_clear_ms"])) < 2e-4
+    assert d["scatter_frac"] == sc["frac"] and d["scatter_frac_group_form"] == sc["group_form"]["frac"]
     assert d["tuning"] == {"active": False, "non_default_knobs": {}, "numerics_affecting": []}
     assert cpu["kind"] == "port" and cpu["value"] > 0 and set(cpu["legs_ms"]) == {"nbp_forward", "raster", "unproject",
                                                                                  "map_accumulate", "coverage"}
