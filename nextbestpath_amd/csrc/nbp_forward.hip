@@ -392,6 +392,10 @@ struct AmaxBook {
     bool gated_taken = false;
     void offer_gated(void* g0, void* g1) { gated[0] = (float*)g0; gated[1] = (float*)g1; gated_taken = false; }
     bool took_gated() { const bool t = gated_taken; gated[0] = gated[1] = nullptr; gated_taken = false; return t; }
+    // a fused gate launch may have written psi [M] to the head of a gated buffer instead of x * psi (GatePsi::psi_only): the convolution
+    // that then gets that buffer as its source 0 reads x itself and multiplies while it stages (ConvOperandsSplit::psi0)
+    const float* psi_key[2] = {nullptr, nullptr};
+    const float* psi_x[2] = {nullptr, nullptr};
     // same for the max-pool after an encoder block: offered before the block's second conv, taken by a launch without split-K
     float* pool = nullptr;
     bool pool_taken = false;
@@ -445,6 +449,17 @@ struct PathSplit : PathF32 {
             // costs the small elements of the consumer's other source their low bits); the slots are bound only if it ran
             unsigned* gslot[2] = {nullptr, nullptr};
             if (ctx.gated[0]) for (int g = 0; g < (o2 ? 2 : 1); ++g) psi.gated_amax[g] = gslot[g] = ctx.unbound();
+            // x * psi formed by the consumer (Up_conv{L}.conv.0: cat(x psi, d) through the plain split kernel) instead of written here
+            // and read back there: the gate moves g + x instead of g + x + x psi.  Needs the measured max |x psi| (the consumer's
+            // operand scale) and a consumer the split kernel takes.  Measured at B = 24 (profiles/r06/psi_on_load_ab.txt): the gates of
+            // levels 4 / 3 go 157 -> 133 and 148 -> 122 us and their consumers pay 7-12 us for the multiply in their staging pass; the
+            // level-2 gate (64 channels, 12288 workgroups of 4 waves) is not bound by its stores and gains nothing while its consumer pays
+            // 16 us -- hence >= 128 channels.  Bit-identical either way.  NBP_SPLIT_PSI_ON_LOAD: 0 = the gated tensor is always
+            // written (rounds 3-5), 1 = levels with >= 128 channels (default), 2 = every fused gate.
+            static const int psi_on_load = nbp_tune_int("NBP_SPLIT_PSI_ON_LOAD", 1);
+            const ConvPlan pc = nbp_plan_conv_split(M, C0, (C0 + C0) / 32 * 9, 0, o2 ? 2 : 1, H, H, 3, 0);
+            psi.psi_only = psi_on_load && (C0 >= 128 || psi_on_load >= 2) && ctx.gated[0] && gslot[0] && (!o2 || gslot[1]) && pc.tile != 0 &&
+                           M * C0 * 4 < (1ll << 31);
             int fused = 0;
             const int rc = nbp_gate1x1_split_launch_g(s[0], o2 ? &s[1] : nullptr, C0, M, N, 1, st, ctx.gated[0] ? &psi : nullptr, &fused);
             if (fused) {
@@ -452,6 +467,7 @@ struct PathSplit : PathF32 {
                 for (int g = 0; g < (o2 ? 2 : 1); ++g) {
                     if (gslot[g]) ctx.bind(ctx.gated[g], gslot[g]);
                     else ctx.alias(ctx.gated[g], (g ? *o2 : o).src1);      // |x psi| <= |x|
+                    if (psi.psi_only) { ctx.psi_key[g] = ctx.gated[g]; ctx.psi_x[g] = (g ? *o2 : o).src1; }
                 }
             }
             return rc;
@@ -468,6 +484,11 @@ struct PathSplit : PathF32 {
             if (!rc && C1) rc = ctx.ensure(q.src1, hw * C1, &s[g].amax1);
             if (rc) return rc;
             s[g].amax_out = ctx.fresh(q.out);
+            for (int k = 0; k < 2; ++k)        // source 0 is a buffer that holds psi, not x * psi: read x and multiply while staging
+                if (ctx.psi_key[k] && q.src0 == ctx.psi_key[k]) {
+                    s[g].src0 = ctx.psi_x[k]; s[g].psi0 = ctx.psi_key[k];
+                    ctx.psi_key[k] = nullptr; ctx.psi_x[k] = nullptr;
+                }
         }
         float* pools[2] = {ctx.pool, nullptr};
         int pooled = 0, headed = 0;

@@ -69,6 +69,9 @@ struct ConvOperandsSplit {
     const float* src0; const float* src1; const void* planes; const float* scale; const float* shift; float* out;
     const unsigned* amax0; const unsigned* amax1; const unsigned* wamax; unsigned* amax_out;
     const void* planes_up; const unsigned* wamax_up;     // up_conv layers: the parity filters (nbp_pack_upconv_weight_split_launch) or null
+    // not null (plain 3x3 layers): source 0 is read as src0[m][c] * psi0[m] -- the attention gate's x * psi (nbp_model.py:60) formed in
+    // the consumer's halo staging instead of written by the gate and read back (amax0 is then max |x psi|, measured by the gate launch)
+    const float* psi0 = nullptr;
 };
 ConvPlan nbp_plan_conv_split(long long M, int N, int chunks_total, int split_k, int groups, int H, int W, int ksize, int ups = 0);
 int nbp_pack_upconv_weight_split_launch(const float* w_oihw, int N, int C, void* dst, unsigned* wamax_out, hipStream_t st);
@@ -94,7 +97,10 @@ int nbp_pack_gate_weight_split_launch(const float* wg, const float* scale_g, con
 // psi != null offers the gate's tail (per group: psi weights [N], {scale, shift}, gated output [M,C] = src1 * psi); *fused tells
 // whether the launch took it (a workgroup must hold all N columns of its pixels) -- if not, q is written and the caller runs
 // nbp_psi_gate_f32 as before
-struct GatePsi { const float* wpsi[2]; const float* st[2]; float* gated[2]; unsigned* gated_amax[2] = {nullptr, nullptr}; };   // gated_amax: zeroed 64-word slots for max |gated| (or null)
+struct GatePsi { const float* wpsi[2]; const float* st[2]; float* gated[2]; unsigned* gated_amax[2] = {nullptr, nullptr};     // gated_amax: zeroed 64-word slots for max |gated| (or null)
+                 // psi_only: a fused launch writes psi [M] to the head of gated[g] instead of the gated tensor [M, C] (max |x psi| still goes to
+                 // gated_amax): the consumer multiplies while it stages its input (ConvOperandsSplit::psi0) -- a third of the gate's bytes less
+                 int psi_only = 0; };
 int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit* o2, int C, long long M, int N, int relu,
                                hipStream_t st, const GatePsi* psi = nullptr, int* fused = nullptr);
 int nbp_conv_first_amax_launch(const float* x_nchw, int B, int H, int W, const float* w_oihw, const float* scale, const float* shift,

@@ -99,6 +99,9 @@ struct SplitOps {
     // their squares, in double, as row (pixel tile [x 4 + parity]) of bn_part[rows][2][N] -- the BatchNorm behind the
     // convolution finalises these instead of reading the tensor once more (nbp_train.hip: colsum_pair)
     double* bn_part;
+    // not null (plain 3x3 kernel): source 0 is src0[pixel][c] * psi0[pixel] -- the attention gate's x * psi formed while the halo is
+    // staged (the products are the gate kernel's own fp32 products, so the planes are what they were bit for bit)
+    const float* psi0;
 };
 struct SplitArgs {
     SplitOps g[2];              // blockIdx.z >= split_k: the second problem of a grouped launch
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* const halo = ldsb;
     char* const wbuf = ldsb + HALO_BYTES;
+    float* const psil = reinterpret_cast<float*>(ldsb + HALO_BYTES + 2 * WB);      // (plain kernel: psi of the tile's halo pixels)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef NBP_DBG_TS
@@ -241,6 +245,20 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr unsigned OOB = 0x80000000u;
     const int c16_0 = a.C0 >> 4;
 
+    // psi of this tile's halo pixels (0 outside the image, where the loads return zeros anyway), once per workgroup
+    bool psi_on = false;
+    if constexpr (!PH) {
+        psi_on = o.psi0 != nullptr;
+        if (psi_on) {
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                const int hr = (tid >> 2) + 64 * k;
+                if ((tid & 3) == 0 && hr < HPIX) psil[hr] = hpix[k] >= 0 ? o.psi0[hpix[k]] : 0.f;
+            }
+            __syncthreads();
+        }
+    }
+
     u32x4 hreg[NF];
     auto load_halo = [&](int c) {       // 16-channel chunk c of the concatenated input
         if constexpr (DG) {             // chunk = (parity q, 16 channels of dout): the parity plane of the halo tile
@@ -262,11 +280,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             hreg[k] = first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0);
         }
     };
-    auto store_halo = [&]() {
+    auto store_halo = [&](int c) {      // (c: the chunk hreg holds)
+        const bool gated = psi_on && c < c16_0;           // a chunk of source 0 behind an attention gate: x * psi
 #pragma unroll
         for (int k = 0; k < NF; ++k) {
             if ((tid >> 2) + 64 * k >= HPIX) continue;
-            const f32x4 v = __builtin_bit_cast(f32x4, hreg[k]);
+            f32x4 v = __builtin_bit_cast(f32x4, hreg[k]);
+            if constexpr (!PH) { if (gated) v = v * psil[(tid >> 2) + 64 * k]; }
             unsigned h0, l0, h1, l1;
             split_pair(v[0] * sa, v[1] * sa, h0, l0);
             split_pair(v[2] * sa, v[3] * sa, h1, l1);
@@ -315,7 +335,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (c_begin < c_end) {
         load_halo(c_begin);
         issue_w(c_begin * ROWS);
-        store_halo();
+        store_halo(c_begin);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -398,7 +418,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         if (more) {                     // every wave is past its last read of this chunk's planes
             __builtin_amdgcn_s_setprio(0);      // the staging pass yields issue slots to the co-resident workgroup's MFMAs (1 %)
-            store_halo();
+            store_halo(c + 1);
             NBP_TS(5);
             __syncthreads();
             NBP_TS(6);
@@ -574,6 +594,7 @@ struct GateArgs {
     const float* st[2];
     float* gated[2];
     unsigned* gated_amax[2];    // 64-word slots (or null) that receive max |gated|: psi can be << 1, the bound max |x| is loose
+    int psi_only;               // PSI form: psi [M] goes to the head of gated[] and the products x * psi are only measured (gated_amax), not written
 };
 
 template <int TN, bool PSI>
@@ -715,7 +736,11 @@ __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
         const float psi = 1.f / (1.f + expf(-z));
         float* psil = reinterpret_cast<float*>(wbuf) + wave * 32;      // the weight buffers are free: the loop ended on a barrier
         const int r = (lane & 31) >> 1;
-        if (!(lane & 1)) psil[(r & 3) + 8 * (r >> 2) + 4 * khalf] = psi;
+        if (!(lane & 1)) {
+            const int pix = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            psil[pix] = psi;
+            if (a.psi_only && mw + pix < a.M) a.gated[blockIdx.z][mw + pix] = psi;       // the consumer multiplies while it stages x
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // same wave wrote what it reads
         // gated = x * psi: the wave's 32 pixels x C channels as float4s, 1 KB contiguous per instruction; x = source 1, read a
         // moment ago as the second half of K (L2 / MALL hits)
@@ -735,7 +760,7 @@ __global__ __launch_bounds__(256, 2) void gate1x1_h2_kernel(GateArgs a) {
                 if (i < total && i < lim) {
                     const float ps = psil[i / C4];
                     const f32x4 g = v[u] * ps;
-                    g4[i] = g;
+                    if (!a.psi_only) g4[i] = g;
                     gmx = fmaxf(fmaxf(gmx, fmaxf(fabsf(g[0]), fabsf(g[1]))), fmaxf(fabsf(g[2]), fabsf(g[3])));
                 }
             }
@@ -1529,7 +1554,7 @@ int launch_h2(const SplitArgs& a, hipStream_t st, int tile) {
     }
     constexpr int TH = 4 * TM * (32 / TW);
     constexpr int HPIX = (TH + 2) * (TW + 2), RS = (HPIX + 7) / 8 * 8 * 16 + 64, NB = TN / 2;
-    constexpr size_t smem = 4 * (size_t)RS + 2 * (size_t)(PH ? 8 : 12) * NB * 1024 * (P2 ? 2 : 1);
+    constexpr size_t smem = 4 * (size_t)RS + 2 * (size_t)(PH ? 8 : 12) * NB * 1024 * (P2 ? 2 : 1) + (PH ? 0 : (HPIX * 4 + 15) / 16 * 16);      // (+ psi of the halo pixels)
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_h2_kernel<TW, TM, TN, PH, BS, P2, DG>),
@@ -1672,8 +1697,9 @@ int nbp_conv_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSplit*
     SplitArgs a;
     for (int g = 0; g < 2; ++g) {
         const ConvOperandsSplit& s = (g && o2) ? *o2 : o;
-        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, C1 ? s.amax1 : nullptr, s.wamax, s.amax_out, nullptr, nullptr, {nullptr, nullptr}, nullptr, nullptr};
+        a.g[g] = SplitOps{s.src0, s.src1, s.planes, s.scale, s.shift, s.out, s.amax0, C1 ? s.amax1 : nullptr, s.wamax, s.amax_out, nullptr, nullptr, {nullptr, nullptr}, nullptr, nullptr, s.psi0};
     }
+    NBP_RETURN_IF((o.psi0 || (o2 && o2->psi0)) && ups, NBP_E_SHAPE);       // (psi rides in the plain kernel's staging only)
     a.C0 = C0; a.C1 = C1; a.ups = ups ? 1 : 0;
     a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W;
     a.N = N; a.relu = relu; a.groups = groups;
@@ -1836,6 +1862,7 @@ int nbp_gate1x1_split_launch_g(const ConvOperandsSplit& o, const ConvOperandsSpl
         a.wpsi[g] = psi ? psi->wpsi[gi] : nullptr; a.st[g] = psi ? psi->st[gi] : nullptr; a.gated[g] = psi ? psi->gated[gi] : nullptr;
         a.gated_amax[g] = psi ? psi->gated_amax[gi] : nullptr;
     }
+    a.psi_only = psi ? psi->psi_only : 0;
     a.C = C; a.C1 = C; a.N = N; a.relu = relu; a.M = M; a.bytes0 = (unsigned)b0; a.bytesw = (unsigned)bw; a.groups = groups;
     // 128-channel blocks only when they alone fill the chip twice; otherwise more, narrower workgroups
     int bn = N % 128 == 0 ? 128 : (N % 64 == 0 ? 64 : 32);

@@ -282,7 +282,7 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
     clean = {k: v for k, v in os.environ.items() if not k.startswith("NBP_")}
     for tag, env in (("both", {}), ("nopool", {**T, "NBP_CONV_POOL": "0"}), ("nopsi", {**T, "NBP_GATE_PSI": "0"}),
                      ("nohead", {**T, "NBP_CONV_HEAD": "0"}), ("nor8", {**T, "NBP_SPLIT_R8_BLOCKS": "0"}),
-                     ("noup2", {**T, "NBP_SPLIT_UP2": "0"}),
+                     ("noup2", {**T, "NBP_SPLIT_UP2": "0"}), ("gatedw", {**T, "NBP_SPLIT_PSI_ON_LOAD": "0"}), ("psiall", {**T, "NBP_SPLIT_PSI_ON_LOAD": "2"}),
                      # a polluted environment WITHOUT the opt-in must change nothing
                      ("polluted", {"NBP_CONV_POOL": "0", "NBP_GATE_PSI": "0", "NBP_CONV_HEAD": "0", "NBP_SPLIT_MAX_K": "576",
                                    "NBP_SPLIT_MAX_K_SMALL": "288", "NBP_SPLIT_R8_SK": "1", "NBP_SPLIT_HALO": "0", "NBP_SPLIT_UP": "0",
@@ -306,6 +306,11 @@ def test_epilogue_fusions_against_the_separate_kernels(hip, tmp_path):
         # products in the same order into every accumulator: bit-identical
         w1, w2 = outs["noup2"][k]
         assert torch.equal(o1, w1) and torch.equal(o2, w2), k
+        # round 6: x * psi formed in the consumer's halo staging (the gate writes psi [M] only) against the gated tensor written by the
+        # gate and read back: the same fp32 products, scaled and split the same way: bit-identical
+        for tag in ("gatedw", "psiall"):                      # (never / on every fused level; the default takes levels with >= 128 channels)
+            g1, g2 = outs[tag][k]
+            assert torch.equal(o1, g1) and torch.equal(o2, g2), (tag, k)
         u1, u2 = outs["polluted"][k]                          # no NBP_TUNING=1: the environment is not read
         assert torch.equal(o1, u1) and torch.equal(o2, u2), k
 
