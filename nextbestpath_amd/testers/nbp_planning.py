@@ -69,7 +69,9 @@ class RolloutState:
         if self._overlap is None:
             main = torch.cuda.current_stream(self.device)
             ins = [self.net_in, torch.zeros_like(self.net_in)]
-            streams = [torch.cuda.Stream(self.device) for _ in ins]
+            # streams that really run beside `main` and beside each other (HIP maps streams onto four hardware queues; a forward
+            # stream that shares main's queue serialises the step: 1100 -> 890 steps/s, seen in about one bench run in eight)
+            streams, self.overlap_info = _concurrent_streams(self.device, len(ins), against=(main,))
             for f in streams:
                 f.wait_stream(main)
             self._overlap = {"net_in": ins, "streams": streams, "maps": [torch.cuda.Event() for _ in ins],
@@ -350,14 +352,15 @@ class Rollout:
         return [float(np.float32(c) / G) for c in counts[:, 0]]
 
 
-def _concurrent_streams(device, n, tries=24, cycles=300_000):
+def _concurrent_streams(device, n, tries=24, cycles=300_000, against=()):
     """n torch streams whose kernels the runtime really runs side by side, and how that was established.
 
     HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) when they are first used, and two streams on one
     queue run their kernels strictly one after the other -- the lock-step's two groups then stop overlapping.  Measured: after
     ANY hipGraph capture in the process (the single-rollout path's ForwardGraph) the next two pool streams land on one queue and
     the 48-rollout lock-step loses 6 % (profiles/r04/stream_queue_collision.txt).  So the streams are not taken on trust: a
-    candidate is kept only if a short spin kernel on it overlaps with one on every stream already chosen."""
+    candidate is kept only if a short spin kernel on it overlaps with one on every stream already chosen (and on every stream of
+    `against`: the single rollout's forward streams must run beside the stream the step itself is enqueued on)."""
     def overlap(a, b):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         torch.cuda.synchronize(device)
@@ -379,7 +382,7 @@ def _concurrent_streams(device, n, tries=24, cycles=300_000):
         tested += 1
         with torch.cuda.stream(st):
             torch.cuda._sleep(1)                   # first use: the stream gets its hardware queue here
-        if all(overlap(c, st) for c in chosen):
+        if all(overlap(c, st) for c in list(against) + chosen):
             chosen.append(st)
     ok = len(chosen) == n
     while len(chosen) < n:                         # (never seen: fewer than n distinct queues among `tries` streams)
