@@ -45,6 +45,19 @@ _MAP_BINS = _lib.tune("NBP_MAP_BINS", "1") == "1"
 # single rollout: the un-projection launches file the points they append into the bins and clear the maps, so that the step's map
 # build is ONE launch (nbp_step_maps_prefiled_f32; bit-identical maps): 0 = bin_append_kernel + map_binned_kernel per build
 _MAP_PREFILED = _lib.tune("NBP_MAP_PREFILED", "1") == "1"
+_GC_FREEZE = _lib.tune("NBP_GC_FREEZE", "1") == "1"
+
+
+def _settle_gc():
+    """A rollout's setup leaves ~10^5 long-lived Python objects behind (the lattice planner's node / edge tables); CPython's
+    generational collector walks all of them in every full collection -- 70-80 ms, once or twice per 100-step rollout, i.e. as long
+    as 80 exploration steps (tools/diag/single_step_spikes.py: 1140 steps/s with the collector off, 450-500 with it on over steps
+    40-100).  After setup they are collected once and then FROZEN (gc.freeze: moved to the permanent generation, no longer walked;
+    reference counting still frees them).  NBP_GC_FREEZE=0: off."""
+    if _GC_FREEZE:
+        import gc
+        gc.collect()
+        gc.freeze()
 
 
 class RolloutState:
@@ -72,6 +85,8 @@ class RolloutState:
             # streams that really run beside `main` and beside each other (HIP maps streams onto four hardware queues; a forward
             # stream that shares main's queue serialises the step: 1100 -> 890 steps/s, seen in about one bench run in eight)
             streams, self.overlap_info = _concurrent_streams(self.device, len(ins), against=(main,))
+            # (a high-priority third stream for the forward of a replanning step -- the one the step waits for, ahead of the dead
+            # forwards still running beside it -- was measured: 1142 / 1157 against 1135 / 1138 steps/s, within noise; not kept)
             for f in streams:
                 f.wait_stream(main)
             self._overlap = {"net_in": ins, "streams": streams, "maps": [torch.cuda.Event() for _ in ins],
@@ -138,6 +153,7 @@ class Rollout:
         self.step_seed = seed * 1_000_003
         self.pose_i = 0
         self.n_replans = 0
+        _settle_gc()
 
     # The step is split in enqueue-only halves so that MultiRollout can batch the NBP forward of several
     # rollouts and share one stream synchronisation per step; step() is the single-rollout composition.
@@ -352,7 +368,7 @@ class Rollout:
         return [float(np.float32(c) / G) for c in counts[:, 0]]
 
 
-def _concurrent_streams(device, n, tries=24, cycles=300_000, against=()):
+def _concurrent_streams(device, n, tries=24, cycles=300_000, against=(), priority=0):
     """n torch streams whose kernels the runtime really runs side by side, and how that was established.
 
     HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) when they are first used, and two streams on one
@@ -375,10 +391,10 @@ def _concurrent_streams(device, n, tries=24, cycles=300_000, against=()):
         return ev[0].elapsed_time(ev[2]) < 1.5 * ev[0].elapsed_time(ev[1])
 
     if not hasattr(torch.cuda, "_sleep"):          # (a torch without the spin kernel: the streams are taken as they come)
-        return [torch.cuda.Stream(device) for _ in range(n)], {"streams_tested": 0, "concurrent": None}
+        return [torch.cuda.Stream(device, priority=priority) for _ in range(n)], {"streams_tested": 0, "concurrent": None}
     chosen, tested = [], 0
     while len(chosen) < n and tested < tries:
-        st = torch.cuda.Stream(device)
+        st = torch.cuda.Stream(device, priority=priority)
         tested += 1
         with torch.cuda.stream(st):
             torch.cuda._sleep(1)                   # first use: the stream gets its hardware queue here
@@ -386,7 +402,7 @@ def _concurrent_streams(device, n, tries=24, cycles=300_000, against=()):
             chosen.append(st)
     ok = len(chosen) == n
     while len(chosen) < n:                         # (never seen: fewer than n distinct queues among `tries` streams)
-        chosen.append(torch.cuda.Stream(device))
+        chosen.append(torch.cuda.Stream(device, priority=priority))
     return chosen, {"streams_tested": tested, "concurrent": ok}
 
 
