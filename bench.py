@@ -384,10 +384,10 @@ def main():
             r1.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(20):
-            r1.step()
+        for _ in range(60):            # steps 40-100: long enough to contain whatever happens once or twice per rollout (a full
+            r1.step()                  # garbage collection cost 70-80 ms in there until round 6: profiles/r06/single_rollout_gc.txt)
         torch.cuda.synchronize()
-        single = 20 / (time.perf_counter() - t0)
+        single = 60 / (time.perf_counter() - t0)
         del r1
     rollouts = [make_rollout(k) for k in range(R)]
     multi = tp.MultiRollout(rollouts, net, dev)
@@ -884,7 +884,7 @@ def main():
             stage["single_rollout_steps_per_s"] = round(single, 2)
             stage["single_rollout_note"] = ("Rollout.step: every step's forward runs (hipGraph replay) on a stream of its own; a step "
                                             "that does not replan does not wait for it (NBP_STEP_OVERLAP=" +
-                                            ("1" if tp._STEP_OVERLAP else "0") + ")")
+                                            ("1" if tp._STEP_OVERLAP else "0") + "); 60 steps (40-100 of the trajectory) of one rollout")
         stage["windows"] = windows
         stage["raster_spilled_tiles"] = int(sum(int(r.camera._overflow.item()) for r in rollouts))
 
