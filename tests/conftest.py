@@ -31,3 +31,14 @@ def hip():
 def nbp_weights():
     from nextbestpath_amd.utility.synthetic import make_nbp_state_dict
     return make_nbp_state_dict(9)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _thaw_frozen_objects():
+    """Rollout setup freezes its long-lived objects out of the cyclic collector (testers/nbp_planning.py::_settle_gc).  A test
+    session builds hundreds of rollouts: after every module the frozen set is thawed and collected, so that objects in reference
+    cycles (and the device tensors they hold) do not outlive their tests."""
+    yield
+    import gc
+    gc.unfreeze()
+    gc.collect()
