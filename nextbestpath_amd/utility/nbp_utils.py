@@ -229,6 +229,12 @@ class MdbEnv:
             self._L.nbp_mdb_close(self._h)
             self._h = None
 
+    def __del__(self):                     # (an environment dropped without close(): the file descriptor goes with it)
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 def open_experience_db(path, map_size=200 * 1024 ** 3):
     """train_nbp_model.py:61-63.  The `lmdb` module when it is importable; otherwise LMDB's file format through the native container
