@@ -357,6 +357,8 @@ class CollectionRollout:
         self.experiences = []
         self.coverage_evolution = []
         self.n_stored = 0
+        from ..testers.nbp_planning import _settle_gc
+        _settle_gc()                   # the planner's long-lived tables leave the cyclic collector's walks (see there)
 
     # -- S1-S8 of a step: coverage, current frame, maps, GT label, trajectory image
     def _observe(self, pose_i):
