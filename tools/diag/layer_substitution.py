@@ -3,7 +3,7 @@
 The network is evaluated in fp64 (torch CPU) with ONE 3x3 conv + BN + ReLU layer at a time replaced by (a) the split kernel,
 (b) the fp32 MFMA pipe, (c) stock torch CPU fp32 -- each fed the fp64 input rounded to fp32 -- and the resulting out1 is
 compared with the all-fp64 out1: local error of that layer x its amplification through the rest of the (exact) network.
-Usage: layer_substitution.py [steps] [hard]"""
+Usage: layer_substitution.py [steps] [hard]   |   layer_substitution.py <steps> scene <k>   (the input of step <steps> of parity_long's scene k)"""
 import os, sys, tempfile
 import numpy as np, torch, torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,10 @@ from nextbestpath_amd.networks.packing import fold_affine
 
 N_STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 tmp = tempfile.mkdtemp()
-if len(sys.argv) > 2 and sys.argv[2] == "hard":
+if len(sys.argv) > 3:                       # a scene of tools/diag/parity_long.py: layer_substitution.py <steps> scene <k>
+    k = int(sys.argv[3])
+    hip_ro, ora, mesh = _both_rollouts(tmp, cells=8, size=4.8, tess=0.3, scene_seed=k, seed=5 + k)
+elif len(sys.argv) > 2 and sys.argv[2] == "hard":
     hip_ro, ora, mesh = _both_rollouts(tmp, cells=12, size=7.2, tess=0.15, scene_seed=101, seed=9)
 else:
     hip_ro, ora, mesh = _both_rollouts(tmp, cells=8, size=4.8, tess=0.3, scene_seed=0, seed=5)
