@@ -874,6 +874,27 @@ def main():
                                                    "frac_of_split_ceiling_reference_formulation":
                                                        round(32 * 546.9e9 / tdt / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4),
                                                    "flop_per_map_reference_formulation": 546.9e9}
+                # ... and the trainer's own epoch loop (train_experience_data: host-resident replay records, collation, host-to-device
+                # copies, an AdamW step every 8 batches) over 6 batches of 32 after 2 warm ones: what train_nbp.py sustains end to end
+                try:
+                    import types as _types
+                    from nextbestpath_amd.trainers import train_nbp_model as _T
+                    recs = make_synthetic_experiences(192, 256, seed=4)
+                    tp_ = _types.SimpleNamespace(nbp_batch_size=32)
+                    _T.train_experience_data(list(recs[:64]), tp_, opt, tnet, dev, current_epoch=2)
+                    torch.cuda.synchronize()
+                    tl0 = time.perf_counter()
+                    _T.train_experience_data(list(recs), tp_, opt, tnet, dev, current_epoch=2)
+                    torch.cuda.synchronize()
+                    tl = time.perf_counter() - tl0
+                    stage["config3_train_step_b32"]["trainer_loop_maps_per_s"] = round(192 / tl, 2)
+                    stage["config3_train_step_b32"]["trainer_loop_note"] = (
+                        "train_experience_data on 192 host-resident records (6 batches of 32): batches staged on a copy stream from pinned "
+                        "buffers, losses kept on the device until the optimizer step (round 6; the reference-shaped loop -- torch.cat, "
+                        "pageable .to(device), loss.item() per batch -- ran 200 maps/s: profiles/r06/train_loop_ab.txt)")
+                    del recs
+                except Exception as e2:
+                    stage["config3_train_step_b32"]["trainer_loop_error"] = repr(e2)[:200]
                 del tnet, opt, xs, gtl
                 torch.cuda.empty_cache()
             except Exception as e:                      # the headline must not depend on the training stage
@@ -957,6 +978,7 @@ def main():
             return v.get(key) if isinstance(v, dict) else None
         n_groups = len(multi.groups)
         out["train_maps_per_s"] = _g("config3_train_step_b32", "maps_per_s")
+        out["train_loop_maps_per_s"] = _g("config3_train_step_b32", "trainer_loop_maps_per_s")
         out["bf16_512_b8_frac"] = _g("config5_forward_bf16_512_b8", "frac_executed_of_conv_ceiling")
         out["fwd_b1_ms"] = _g("nbp_forward_b1", "ms")
         out["fwd_group_ms"] = _g("nbp_forward", "ms")

@@ -60,9 +60,14 @@ def make_synthetic_experiences(n, S=256, seed=0):
     return out
 
 
+_STAGE_BATCHES = _lib.tune("NBP_TRAIN_STAGE_BATCHES", "1") == "1"      # 0: every batch through _collate's synchronous copies
+
+
 def _collate(batch_data, device):
-    xs = torch.cat([torch.from_numpy(np.copy(d["current_model_input"])) for d in batch_data]).to(device)
-    gt = torch.cat([torch.from_numpy(np.copy(d["current_gt_2d_layout"])) for d in batch_data]).to(device)
+    # (np.concatenate, not torch.cat of 32 x 1.3 MB: on a 256-core host torch's intra-op thread pool made that concatenation cost
+    # 50-600 ms per batch, tools/diag/train_loop_ab.py)
+    xs = torch.from_numpy(np.concatenate([d["current_model_input"] for d in batch_data])).to(device)
+    gt = torch.from_numpy(np.concatenate([d["current_gt_2d_layout"] for d in batch_data])).to(device)
     coords = [torch.from_numpy(np.copy(d["target_value_map_pixel"])) for d in batch_data]
     # the reference indexes predicted_value_map[b, c, x, y] (nbp_utils.py:379), which raises on a bad coordinate; the
     # device gather has no exception path, so replay records (possibly written elsewhere) are range-checked here
@@ -74,6 +79,94 @@ def _collate(batch_data, device):
     sizes = torch.tensor([len(c) for c in coords])
     bidx = torch.repeat_interleave(torch.arange(len(coords)), sizes).to(device)
     return xs, gt, torch.cat(coords).to(device), gains, bidx
+
+
+class _BatchStager:
+    """The next batch's host-to-device copies on a stream of their own, from pinned staging buffers (two sets, used alternately), so
+    that they run under the current batch's forward / backward instead of in front of the next one's: `.to(device)` from pageable
+    memory is host-synchronous AND stream-ordered behind the kernels already queued (the reference pays exactly that,
+    nbp_utils.py:352-355).  Same tensors on the device, bit for bit."""
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device)
+        self.pins = [{}, {}]
+        self.done = [None, None]
+        self.k = 0
+
+    def _pin(self, slot, name, shape, dtype):
+        numel = int(np.prod(shape)) if len(shape) else 1
+        buf = self.pins[slot].get(name)
+        if buf is None or buf.numel() < numel or buf.dtype != dtype:
+            buf = self.pins[slot][name] = torch.empty(max(numel, 1), dtype=dtype).pin_memory()
+        return buf[:numel].view(shape)
+
+    def begin(self):
+        """Next staging slot: waits (host) for the copies that last read its pinned buffers (two batches ago)."""
+        self.slot = self.k & 1
+        self.k += 1
+        if self.done[self.slot] is not None:
+            self.done[self.slot].synchronize()
+        self.filled = {}
+
+    def buffer(self, name, shape, dtype):
+        """A pinned tensor of this slot to be filled by the caller (records are copied straight into it: no torch.cat, whose
+        intra-op thread pool made a 42 MB concatenation cost 50 ms on the 256-core host)."""
+        t = self._pin(self.slot, name, tuple(shape), dtype)
+        self.filled[name] = t
+        return t
+
+    def commit(self):
+        """-> ({name: device tensor}, event the consumer's stream must wait for)"""
+        out = {}
+        with torch.cuda.stream(self.stream):
+            for name, p in self.filled.items():
+                out[name] = torch.empty(p.shape, dtype=p.dtype, device=self.device)
+                out[name].copy_(p, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.done[self.slot] = ev
+        return out, ev
+
+
+def _collate_staged(batch_data, device, stager):
+    """_collate with the copies on the stager's stream: returns the same five tensors; the CURRENT stream waits for them."""
+    n = len(batch_data)
+    x0 = batch_data[0]["current_model_input"]
+    S = x0.shape[-1]
+    coords = [np.asarray(d["target_value_map_pixel"]) for d in batch_data]
+    V = S // 4
+    for d, c in zip(batch_data, coords):
+        if c.size and (c.min() < 0 or c[:, 0].max() >= 8 or c[:, 1:].max() >= V):
+            raise IndexError(f"target_value_map_pixel out of range for an [8,{V},{V}] value map (pose_i={d.get('pose_i')})")
+    K = int(sum(len(c) for c in coords))
+    stager.begin()
+    xs = stager.buffer("xs", (n,) + tuple(x0.shape[1:]), torch.float32).numpy()
+    gt = stager.buffer("gt", (n,) + tuple(batch_data[0]["current_gt_2d_layout"].shape[1:]), torch.float32).numpy()
+    cd = stager.buffer("coords", (K, 3), torch.int64).numpy()
+    gn = stager.buffer("gains", (K,), torch.float32).numpy()
+    bi = stager.buffer("bidx", (K,), torch.int64).numpy()
+    k = 0
+    for i, (d, c) in enumerate(zip(batch_data, coords)):
+        xs[i] = d["current_model_input"][0]
+        gt[i] = d["current_gt_2d_layout"][0]
+        m = len(c)
+        cd[k:k + m] = c
+        gn[k:k + m] = d["actual_coverage_gain"]
+        bi[k:k + m] = i
+        k += m
+    dev, ev = stager.commit()
+    return (dev["xs"], dev["gt"], dev["coords"], dev["gains"], dev["bidx"]), ev
+
+
+def _collate_any(batch_data, device, stager):
+    """Staged collation for records of the replay store's shape (one map per record); anything else through _collate."""
+    if all(d["current_model_input"].shape[0] == 1 and d["current_gt_2d_layout"].shape[0] == 1 for d in batch_data):
+        return _collate_staged(batch_data, device, stager)
+    ev = torch.cuda.Event()
+    out = _collate(batch_data, device)
+    ev.record(torch.cuda.current_stream(device))
+    return out, ev
 
 
 BUCKET_BYTES = 64 << 20      # xGMI rings are per-link bound (~153 GB/s): 4 buckets cover the 200 MB of gradients
@@ -138,33 +231,57 @@ def train_experience_data(training_set_db, params, optimizer, nbp, device, curre
     that reaches the end of the set (:385).  Under torchrun the ranks agree on "empty" and on the batch count, because
     the step contains the gradient all-reduce."""
     random.shuffle(training_set_db)
-    training_loss, accumulated, updates = [], 0.0, 0
+    # the batch losses of an accumulation window stay on the device until its optimizer step (the reference's `batch_loss.item()`
+    # per batch, nbp_utils.py:384, is a device synchronisation per batch: the GPU then idles through the next batch's collation and
+    # host-to-device copy).  Same numbers: the same fp32 losses, converted and added as Python floats in the same order.
+    training_loss, pending, updates = [], [], 0
     accumulation_steps = 8
     bs = params.nbp_batch_size
     n_batches = _common_count((len(training_set_db) + bs - 1) // bs, device)
     multi_rank = _dist() is not None
-    for bi in range(n_batches):
+    stager = _BatchStager(device) if (torch.device(device).type == "cuda" and _STAGE_BATCHES) else None
+
+    def batch_of(bi):
         batch = training_set_db[bi * bs:(bi + 1) * bs]
         if current_epoch == 1:
             batch = [d for d in batch if d["pose_i"] > 10]
+        return batch
+
+    staged = None            # (batch index, tensors, event) of the batch whose copies were started under the previous one's compute
+    for bi in range(n_batches):
+        batch = batch_of(bi)
         have = 1 if batch else 0
         if multi_rank:
             have = _common_count(have, device)
         if not have:
             continue
-        xs, gt, coords, gains, bidx = _collate(batch, device)
+        if stager is None:
+            xs, gt, coords, gains, bidx = _collate(batch, device)
+        else:
+            if staged is None or staged[0] != bi:
+                staged = (bi,) + _collate_any(batch, device, stager)
+            (xs, gt, coords, gains, bidx), ev = staged[1], staged[2]
+            torch.cuda.current_stream(device).wait_event(ev)
+            for t in (xs, gt, coords, gains, bidx):
+                t.record_stream(torch.cuda.current_stream(device))
         out1, out2 = nbp(xs)
         pred = tr.gather_values(out1, bidx, coords)
         loss = nbp.loss(pred, gains, out2, gt)
         loss.backward()
-        accumulated += loss.item()
+        pending.append(loss.detach())
         updates += 1
+        if stager is not None and bi + 1 < n_batches:       # the next batch's collation and copies, under this batch's kernels
+            nb = batch_of(bi + 1)
+            staged = ((bi + 1,) + _collate_any(nb, device, stager)) if nb else None
         if updates % accumulation_steps == 0 or bi + 1 == n_batches:
             allreduce_gradients(nbp)
             optimizer.step()
             optimizer.zero_grad()
+            accumulated = 0.0
+            for v in torch.stack(pending).tolist():       # (one device -> host copy per optimizer step)
+                accumulated += v
             training_loss.append(accumulated / accumulation_steps)
-            accumulated, updates = 0.0, 0
+            pending, updates = [], 0
     return training_loss
 
 
@@ -185,14 +302,24 @@ def sync_buffers(nbp):
 
 def validation_model(training_set_db, params, nbp, device):
     """ref nbp_utils.py:293-338: plain MSE + BCE in eval mode."""
-    total, count = 0.0, 0
+    parts, count = [], 0
     bs = params.nbp_batch_size
+    stager = _BatchStager(device) if (torch.device(device).type == "cuda" and _STAGE_BATCHES) else None
     for i in range(0, len(training_set_db), bs):
-        xs, gt, coords, gains, bidx = _collate(training_set_db[i:i + bs], device)
+        if stager is None:
+            xs, gt, coords, gains, bidx = _collate(training_set_db[i:i + bs], device)
+        else:
+            (xs, gt, coords, gains, bidx), ev = _collate_any(training_set_db[i:i + bs], device, stager)
+            torch.cuda.current_stream(device).wait_event(ev)
+            for t in (xs, gt, coords, gains, bidx):
+                t.record_stream(torch.cuda.current_stream(device))
         out1, out2 = nbp(xs)
         pred = tr.gather_values(out1, bidx, coords)
-        total += (tr.MeanLossFn.apply(pred, gains, 0) + tr.MeanLossFn.apply(out2, gt, 1)).item()
+        parts.append((tr.MeanLossFn.apply(pred, gains, 0) + tr.MeanLossFn.apply(out2, gt, 1)).detach())    # (no sync per batch)
         count += 1
+    total = 0.0
+    for v in (torch.stack(parts).tolist() if parts else []):
+        total += v
     return total / max(count, 1)
 
 

@@ -929,3 +929,33 @@ def test_fused_gate_middle_is_the_separate_functions_bit_for_bit(hip, monkeypatc
     for k in bb:
         assert torch.equal(ba[k], bb[k]), k
     assert float(ya.abs().sum()) > 0 and float(ga.abs().sum()) > 0
+
+
+def test_trainer_with_staged_batches_is_the_trainer_with_synchronous_copies(hip, monkeypatch):
+    """Round 6: train_experience_data keeps an accumulation window's losses on the device and copies the next batch in on a stream of
+    its own from pinned buffers (no device synchronisation per batch).  Same batches, same order, same tensors: the per-update losses
+    and the weights after two epochs are identical to the loop with _collate's synchronous copies."""
+    import types
+    import random
+    from nextbestpath_amd.networks.nbp_model import NBP
+    from nextbestpath_amd.trainers import train_nbp_model as T
+    params = types.SimpleNamespace(nbp_batch_size=3)
+    db = T.make_synthetic_experiences(20, S=64, seed=7)       # 7 batches: an accumulation window that ends on the last, partial batch
+    for i, d in enumerate(db):
+        d["pose_i"] = 5 + i                                   # epoch 1 drops the records with pose_i <= 10 (a batch may empty out)
+    res = []
+    for staged in (True, False):
+        monkeypatch.setattr(T, "_STAGE_BATCHES", staged)
+        torch.manual_seed(3); random.seed(3); np.random.seed(3)
+        net = NBP().to(D)
+        _, opt, _, _ = T.initialize_nbp(params, net)
+        net.train()
+        losses = [T.train_experience_data(list(db), params, opt, net, D, current_epoch=ep) for ep in (1, 2)]
+        net.eval()
+        with torch.no_grad():
+            v = T.validation_model(db[:6], params, net, D)
+        res.append((losses, v, {k: t.detach().clone() for k, t in net.state_dict().items()}))
+    (la, va, sa), (lb, vb, sb) = res
+    assert la == lb and va == vb and len(la[1]) >= 1
+    for k in sb:
+        assert torch.equal(sa[k], sb[k]), k
